@@ -1,0 +1,206 @@
+/* pagraph_hip.h — C-ABI of libpagraph_hip.so (MI355X / gfx950).
+ *
+ * The reference (zhiqi-0/PaGraph) has NO native code and NO FFI: its "plugin
+ * boundary" for the minibatch hot path is a handful of Python call sites that
+ * hand torch / DGL tensors to torch-CUDA index ops and to DGL 0.4.1's C++
+ * sampler and SpMM kernels.  Each entry point below replaces one of those call
+ * sites; the citation names the reference file:line it stands in for.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; no torch / DGL types.
+ *   - every device pointer is HBM on the current HIP device unless it says
+ *     "host" or "pinned"; pinned pointers must be hipHostMalloc'ed (or
+ *     torch pin_memory) so the device can address them.
+ *   - all kernels are enqueued on `stream` (a hipStream_t passed as void*) and
+ *     are asynchronous w.r.t. the host.  Nothing here synchronises unless the
+ *     comment says so.
+ *   - return value: 0 = PG_OK, negative = error (pg_strerror()).  Nothing
+ *     throws.  The caller owns every buffer; the library owns only the opaque
+ *     handles it creates.
+ *   - ids are int64 like the reference's LongTensors.  Adjacency `indices`
+ *     are int32 (a per-GPU partition has < 2^31 vertices); `indptr` is int64
+ *     (a partition may have > 2^31 edges).
+ */
+#ifndef PAGRAPH_HIP_H
+#define PAGRAPH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_OK 0
+#define PG_ERR_INVALID (-1)  /* bad argument (null pointer, negative size, too many fields) */
+#define PG_ERR_HIP (-2)      /* a HIP runtime call failed; pg_last_hip_error() has the code */
+#define PG_ERR_NOMEM (-3)
+#define PG_ERR_UNSUPPORTED (-4)
+#define PG_ERR_OVERFLOW (-5) /* a caller-provided capacity was too small */
+
+#define PG_MAX_FIELDS 4
+#define PG_MAX_LAYERS 8
+
+typedef void* pg_stream_t; /* hipStream_t */
+
+int pg_version(void);
+const char* pg_strerror(int code);
+int pg_last_hip_error(void);
+/* number of CUs of the current device, or <0 when no HIP device is visible */
+int pg_device_cu_count(void);
+
+/* ------------------------------------------------------------------------
+ * 1. Feature cache  —  PaGraph/storage/storage.py  (GraphCacheServer)
+ * ------------------------------------------------------------------------
+ * HBM layout: per field one dense row-major fp32 array `cache[slot, :]`
+ * (storage.py:151 `gpu_fix_cache[name]`), row stride `cache_stride` floats.
+ * The reference's two per-vertex arrays gpu_flag (bool, storage.py:38) and
+ * localid2cacheid (int64, storage.py:50) are fused into ONE int32
+ * `slot_map[local_id]`: >=0 cache slot, -1 not cached.
+ */
+typedef struct pg_field {
+  const float* cache;   /* device [cached_rows, cache_stride]; may be NULL when nothing is cached */
+  float* out;           /* device [n, out_stride] — the frame handed to the model (storage.py:186) */
+  int32_t dim;          /* floats per row (storage.py:65 dims[name]) */
+  int32_t cache_stride; /* floats */
+  int32_t out_stride;   /* floats */
+  int32_t _pad;
+} pg_field_t;
+
+/* storage.py:38,50 — slot_map[0:node_num] = -1 */
+int pg_slot_map_reset(int32_t* slot_map, int64_t node_num, pg_stream_t stream);
+/* storage.py:145,153 — slot_map[nids[j]] = j  (localid2cacheid[nids]=arange; gpu_flag[nids]=True) */
+int pg_slot_map_assign(int32_t* slot_map, const int64_t* nids, int64_t rows, pg_stream_t stream);
+/* views for API parity: gpu_flag (uint8 0/1) and localid2cacheid (int64, 0 where uncached) */
+int pg_slot_map_export(const int32_t* slot_map, int64_t node_num, uint8_t* gpu_flag,
+                       int64_t* localid2cacheid, pg_stream_t stream);
+
+/* storage.py:176-204 (fetch_data inner loop, all layers in ONE launch).
+ * For every r in [0,n): id = ids[r]; s = slot_map[id];
+ *   s >= 0 : out_f[r,:] = cache_f[s,:]  for every field f            (storage.py:191-193)
+ *   s <  0 : row r is appended to the miss list:
+ *            miss_pos[j] = r, miss_fullid[j] = nid_map[id]           (storage.py:117,182)
+ * `miss_count` (device or pinned int32, zeroed by this call) receives the
+ * number of misses; miss list order is unspecified (a permutation of the
+ * reference's mask order) — results do not depend on it.
+ * miss_pos / miss_fullid need capacity n.  They may be pinned-host pointers
+ * so the host can read them after the stream reaches this point.          */
+int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
+                   const pg_field_t* fields, int n_fields, int32_t* miss_pos, int64_t* miss_fullid,
+                   int32_t* miss_count, pg_stream_t stream);
+
+/* storage.py:207-216 (fetch_from_cache): full cache, slot == local id. out_f[r,:] = cache_f[ids[r],:] */
+int pg_gather_rows_full(const int64_t* ids, int64_t n, const pg_field_t* fields, int n_fields,
+                        pg_stream_t stream);
+
+/* storage.py:199-200 — out[pos[j], :] = staged[j, :] for j < n (n from host, or *n_dev when n_dev != NULL
+ * in which case `n` is the launch upper bound). `staged` is device memory, row stride = dim.        */
+int pg_scatter_rows(const float* staged, const int32_t* pos, int64_t n, const int32_t* n_dev,
+                    int32_t dim, float* out, int32_t out_stride, pg_stream_t stream);
+
+/* storage.py:128 — the server-side `table[nids]` on host memory, multi-threaded:
+ * staged[j, 0:dim] = table[fullids[j], 0:dim]. Pure host function (blocks until done).             */
+int pg_host_gather_rows(const float* table, int64_t table_stride, int32_t dim, const int64_t* fullids,
+                        int64_t n, float* staged, int n_threads);
+
+/* Zero-copy variant of the miss path: the device reads `table` (pinned host memory,
+ * device-addressable) directly over PCIe: out[pos[j],:] = table[fullid[j],:] for j < *n_dev.        */
+int pg_scatter_rows_from_host(const float* table_pinned, int64_t table_stride, const int32_t* pos,
+                              const int64_t* fullid, int64_t n_max, const int32_t* n_dev, int32_t dim,
+                              float* out, int32_t out_stride, pg_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 2. Neighbour sampler  —  dgl.contrib.sampling.NeighborSampler as called at
+ *    examples/profile/pa_gcn.py:71-76 and PaGraph/partition/utils.py:11-18.
+ *    DGL 0.4.1 is not part of the reference checkout; semantics follow the
+ *    build-defined spec in DESIGN.md §"Sampler spec" (parity unpinned).
+ * ------------------------------------------------------------------------ */
+typedef struct pg_sampler pg_sampler_t;
+
+typedef struct pg_nodeflow_desc {
+  /* outputs, all device memory owned by the caller */
+  int64_t* node_mapping;   /* [cap_nodes] local ids, layer 0 first (NodeFlow._node_mapping)       */
+  int32_t* layer_offsets;  /* [num_layers+1] device copy (NodeFlow._layer_offsets)                */
+  int32_t* blk_indptr;     /* concatenated per block: block b at blk_indptr + blk_indptr_off[b],
+                              length |layer b+1| + 1, edge offsets relative to the block          */
+  int32_t* blk_src;        /* concatenated per block at blk_src + blk_src_off[b]: position of the
+                              edge's source inside layer b                                        */
+  int32_t* sizes_pinned;   /* pinned host [2*PG_MAX_LAYERS]: [0..L] layer sizes (layer 0 first),
+                              [PG_MAX_LAYERS .. ] edges per block; valid once `stream` drains     */
+  int64_t cap_nodes;
+  int64_t blk_indptr_off[PG_MAX_LAYERS];
+  int64_t blk_src_off[PG_MAX_LAYERS];
+} pg_nodeflow_desc_t;
+
+/* indptr/indices: CSC of the partition (in-neighbours of v = indices[indptr[v]:indptr[v+1]],
+ * ascending).  max_seeds = batch size, fanout = expand_factor, num_hops -> num_hops+1 layers.   */
+int pg_sampler_create(int64_t num_vertices, const int64_t* indptr, const int32_t* indices,
+                      int32_t max_seeds, int32_t fanout, int32_t num_hops, pg_sampler_t** out);
+int pg_sampler_destroy(pg_sampler_t* s);
+/* worst-case capacities for one batch: total nodes over all layers, per-block dst rows and edges */
+int pg_sampler_capacity(const pg_sampler_t* s, int64_t* cap_nodes, int64_t* cap_blk_rows /*[num_hops]*/,
+                        int64_t* cap_blk_edges /*[num_hops]*/);
+/* one minibatch: seeds (device int64[n_seeds], unique) -> NodeFlow. RNG key (seed, epoch, batch). */
+int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, uint64_t seed,
+                      uint32_t epoch, uint32_t batch, const pg_nodeflow_desc_t* out, pg_stream_t stream);
+
+/* Full-neighbour frontier expansion used by the L-hop closure (PaGraph/partition/utils.py:11-28):
+ * marks every in-neighbour of frontier[0:n] in `bitmap` (uint64 words, bit v = vertex v) and
+ * optionally marks the frontier itself; returns nothing else — pair with pg_bitmap_to_ids.       */
+int pg_frontier_mark_neighbors(const int64_t* indptr, const int32_t* indices, const int64_t* frontier,
+                               int64_t n, uint64_t* bitmap, int mark_self, pg_stream_t stream);
+/* sorted ids of the set bits; count written to *count_dev (device int64). word_rank (uint32 per word,
+ * may be NULL) receives the exclusive popcount prefix for later rank queries. scratch: >= 4*(n_words/1024 + 2) bytes. */
+int pg_bitmap_to_ids(const uint64_t* bitmap, int64_t n_words, int64_t* out_ids, int64_t cap,
+                     int64_t* count_dev, uint32_t* word_rank, void* scratch, pg_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 3. Block aggregation  —  nf.block_compute(i, copy_src, mean|sum, ...) at
+ *    PaGraph/model/gcn_nssc.py:71-74,139-142 and graphsage_nssc.py:98-111.
+ * ------------------------------------------------------------------------ */
+#define PG_REDUCE_MEAN 0
+#define PG_REDUCE_SUM 1
+/* out[v,:] = reduce_{e in [indptr[v],indptr[v+1])} h[src[e],:]   (0 when v has no edge)          */
+int pg_spmm_fwd(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride,
+                int64_t n_dst, int32_t dim, int reduce, float* out, int32_t out_stride,
+                pg_stream_t stream);
+/* grad_h[src[e],:] += grad_out[v,:] * (mean ? 1/deg(v) : 1). grad_h must be zeroed by the caller. */
+int pg_spmm_bwd(const int32_t* indptr, const int32_t* src, const float* grad_out, int32_t go_stride,
+                int64_t n_dst, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,
+                pg_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 4. Offline partitioning (host)  —  PaGraph/partition/dg.py:59-103
+ * ------------------------------------------------------------------------
+ * CSC of the full graph on the host. belongs_out[V] (int8, -1 = unassigned). Returns r_vnum/p_vnum.
+ * r_mask_out: P*V bytes (r_belongs, dg.py:64) or NULL.                                            */
+int pg_dg_partition(int64_t V, const int64_t* indptr, const int32_t* indices, const int64_t* train_nids,
+                    int64_t n_train, int32_t P, int32_t hops, int8_t* belongs_out, uint8_t* r_mask_out,
+                    int64_t* p_vnum_out, int64_t* r_vnum_out);
+
+/* ------------------------------------------------------------------------
+ * 5. Synthetic inputs  —  PaGraph/data/preprocess.py:50-114 + PaRMAT (README.md:36-41)
+ * ------------------------------------------------------------------------ */
+/* RMAT candidate edges [first, first+n): integer-threshold recursive quadrant descent keyed by
+ * (seed, edge index). a,b,c in Q32 fixed point (0.45 -> 0.45*2^32). out on device.               */
+int pg_rmat_edges(uint64_t seed, int32_t scale, uint32_t a_q32, uint32_t b_q32, uint32_t c_q32,
+                  int64_t first, int64_t n, int64_t* src, int64_t* dst, pg_stream_t stream);
+/* feat[r, c] = U[0,1) fp32 from Philox keyed (seed; row0+r, c) — rows [row0,row0+rows)          */
+int pg_random_features(uint64_t seed, int64_t row0, int64_t rows, int32_t dim, float* out,
+                       int64_t out_stride, pg_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 6. Timing helper for bench.py — HIP events on the stream the kernels run on.
+ * ------------------------------------------------------------------------ */
+typedef struct pg_timer pg_timer_t;
+int pg_timer_create(pg_timer_t** t);
+int pg_timer_destroy(pg_timer_t* t);
+int pg_timer_start(pg_timer_t* t, pg_stream_t stream);
+int pg_timer_stop(pg_timer_t* t, pg_stream_t stream);
+/* blocks on the stop event */
+int pg_timer_elapsed_ms(pg_timer_t* t, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAGRAPH_HIP_H */

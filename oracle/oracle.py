@@ -1,0 +1,383 @@
+"""Python face of the CPU oracle (TEST INFRASTRUCTURE — see pgc_oracle.c header).
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  numpy restatements follow the reference's numpy/torch code line by line
+(citations inline); loops that would be slow in Python live in pgc_oracle.c.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_f32p = ctypes.POINTER(ctypes.c_float)
+
+
+def build():
+    """compile pgc_oracle.c -> libpgc_oracle.so (gcc; seconds)"""
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libpgc_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = ctypes.CDLL(path)
+        L.pgc_fetch_rows.restype = ctypes.c_int64
+        L.pgc_fetch_rows.argtypes = [_i64p, ctypes.c_int64, _u8p, _i64p, _i64p, _f32p, _f32p, ctypes.c_int32, _f32p]
+        L.pgc_sample_nodeflow.restype = ctypes.c_int
+        L.pgc_sample_nodeflow.argtypes = [_i64p, _i32p, _i64p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                          ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _i64p, _i32p, _i32p,
+                                          _i64p, _i32p, _i64p, _i32p]
+        L.pgc_sample_epoch.restype = ctypes.c_int64
+        L.pgc_sample_epoch.argtypes = [_i64p, _i32p, _i64p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                       ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int64,
+                                       ctypes.c_int64, _i64p, ctypes.c_int64]
+        L.pgc_spmm_fwd.restype = None
+        L.pgc_spmm_fwd.argtypes = [_i32p, _i32p, _f32p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int, _f32p]
+        L.pgc_spmm_bwd.restype = None
+        L.pgc_spmm_bwd.argtypes = [_i32p, _i32p, _f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+                                   ctypes.c_int, _f32p]
+        L.pgc_rmat_edges.restype = None
+        L.pgc_rmat_edges.argtypes = [ctypes.c_uint64, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint32,
+                                     ctypes.c_uint32, ctypes.c_int64, ctypes.c_int64, _i64p, _i64p]
+        L.pgc_random_features.restype = None
+        L.pgc_random_features.argtypes = [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, _f32p,
+                                          ctypes.c_int64]
+        L.pgc_philox4x32_10.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+# --------------------------------------------------------------------------
+# RNG
+# --------------------------------------------------------------------------
+def philox4x32_10(ctr, key):
+    c = (ctypes.c_uint32 * 4)(*[int(x) & 0xFFFFFFFF for x in ctr])
+    k = (ctypes.c_uint32 * 2)(*[int(x) & 0xFFFFFFFF for x in key])
+    o = (ctypes.c_uint32 * 4)()
+    lib().pgc_philox4x32_10(c, k, o)
+    return [int(x) for x in o]
+
+
+# --------------------------------------------------------------------------
+# feature cache (PaGraph/storage/storage.py)
+# --------------------------------------------------------------------------
+class CacheState:
+    """The reference's per-partition state (storage.py:31-56) as numpy arrays."""
+
+    def __init__(self, node_num, nid_map):
+        self.node_num = int(node_num)
+        self.nid_map = _c(nid_map, np.int64)                      # :34
+        self.gpu_flag = np.zeros(node_num, dtype=np.uint8)        # :38
+        self.localid2cacheid = np.zeros(node_num, dtype=np.int64)  # :50
+        self.cached_num = 0
+        self.full_cached = False
+        self.cache = {}                                           # gpu_fix_cache, :48
+        self.try_num = 0
+        self.miss_num = 0
+
+    def cache_fix_data(self, nids, tables, is_full=False):
+        """storage.py:135-154; `tables` = full host tables, rows fetched as :117-131"""
+        nids = _c(nids, np.int64)
+        rows = len(nids)
+        self.localid2cacheid[nids] = np.arange(rows)              # :145
+        self.cached_num = rows                                    # :146
+        for name, tab in tables.items():
+            self.cache[name] = np.ascontiguousarray(tab[self.nid_map[nids]], dtype=np.float32)  # :117,131,151
+        self.gpu_flag[nids] = 1                                   # :153
+        self.full_cached = is_full                                # :154
+
+    def auto_cache_select(self, out_degrees, capability):
+        """storage.py:90-104: full when capability >= node_num, else top-`capability`
+        by out-degree, descending.  torch.argsort there is unstable; the build
+        defines ties as 'lower id first' (stable sort on -degree)."""
+        if capability >= self.node_num:
+            return np.arange(self.node_num, dtype=np.int64), True
+        order = np.argsort(-np.asarray(out_degrees, dtype=np.int64), kind="stable")
+        return order[:capability].astype(np.int64), False
+
+    def fetch_layer(self, tnid, tables):
+        """storage.py:176-204 for one layer; returns {name: rows}"""
+        tnid = _c(tnid, np.int64)
+        out = {}
+        miss = 0
+        for name, tab in tables.items():
+            tab = _c(tab, np.float32)
+            dim = tab.shape[1]
+            o = np.empty((len(tnid), dim), dtype=np.float32)
+            cache = self.cache.get(name)
+            if cache is None or cache.size == 0:
+                cache = np.zeros((1, dim), dtype=np.float32)
+            miss = lib().pgc_fetch_rows(_p(tnid, _i64p), len(tnid), _p(self.gpu_flag, _u8p),
+                                        _p(self.localid2cacheid, _i64p), _p(self.nid_map, _i64p),
+                                        _p(cache, _f32p), _p(tab, _f32p), dim, _p(o, _f32p))
+            out[name] = o
+        self.try_num += len(tnid)                                 # :203-204,219-221
+        self.miss_num += int(miss)
+        return out
+
+    def get_miss_rate(self):
+        """storage.py:223-227"""
+        r = float(self.miss_num) / self.try_num
+        self.miss_num = 0
+        self.try_num = 0
+        return r
+
+
+def fetch_layer_numpy(state, tnid, tables):
+    """Pure-numpy twin of CacheState.fetch_layer (same lines), used to cross-check the C loop."""
+    tnid = np.asarray(tnid, dtype=np.int64)
+    mask = state.gpu_flag[tnid].astype(bool)                      # :179
+    out = {}
+    for name, tab in tables.items():
+        o = np.empty((len(tnid), tab.shape[1]), dtype=np.float32)
+        if mask.any():
+            o[mask] = state.cache[name][state.localid2cacheid[tnid[mask]]]  # :191-193
+        if (~mask).any():
+            o[~mask] = tab[state.nid_map[tnid[~mask]]]            # :117,128,199-200
+        out[name] = o
+    return out, int((~mask).sum())
+
+
+# --------------------------------------------------------------------------
+# sampler (build-defined spec)
+# --------------------------------------------------------------------------
+def nodeflow_caps(batch, k, hops):
+    caps = [0] * (hops + 1)
+    caps[hops] = batch
+    for l in range(hops - 1, -1, -1):
+        caps[l] = caps[l + 1] * k
+    return caps
+
+
+def sample_nodeflow(indptr, indices, seeds, k, hops, seed, epoch, batch):
+    """returns dict(node_mapping, layer_offsets, blocks=[(indptr, src)] layer-0 block first)"""
+    indptr = _c(indptr, np.int64)
+    indices = _c(indices, np.int32)
+    seeds = _c(seeds, np.int64)
+    caps = nodeflow_caps(len(seeds), k, hops)
+    nm = np.zeros(sum(caps) + 1, dtype=np.int64)
+    lo = np.zeros(hops + 2, dtype=np.int32)
+    ioff = np.zeros(8, dtype=np.int64)
+    soff = np.zeros(8, dtype=np.int64)
+    ic = sc = 0
+    for b in range(hops - 1, -1, -1):
+        ioff[b], soff[b] = ic, sc
+        ic += caps[b + 1] + 1
+        sc += caps[b + 1] * k
+    bip = np.zeros(ic + 1, dtype=np.int32)
+    bsr = np.zeros(sc + 1, dtype=np.int32)
+    eo = np.zeros(8, dtype=np.int32)
+    rc = lib().pgc_sample_nodeflow(_p(indptr, _i64p), _p(indices, _i32p), _p(seeds, _i64p), len(seeds), k, hops,
+                                   ctypes.c_uint64(seed), epoch, batch, _p(nm, _i64p), _p(lo, _i32p),
+                                   _p(bip, _i32p), _p(ioff, _i64p), _p(bsr, _i32p), _p(soff, _i64p), _p(eo, _i32p))
+    if rc != 0:
+        raise RuntimeError("pgc_sample_nodeflow failed")
+    offs = lo[:hops + 2].copy()
+    blocks = []
+    for b in range(hops):
+        nd = offs[b + 2] - offs[b + 1]
+        blocks.append((bip[ioff[b]:ioff[b] + nd + 1].copy(), bsr[soff[b]:soff[b] + eo[b]].copy()))
+    return {"node_mapping": nm[:offs[hops + 1]].copy(), "layer_offsets": offs, "blocks": blocks}
+
+
+def sample_epoch_rows(indptr, indices, seeds, batch_size, k, hops, seed, epoch, first_batch, n_batches,
+                      keep_rows=False):
+    indptr = _c(indptr, np.int64)
+    indices = _c(indices, np.int32)
+    seeds = _c(seeds, np.int64)
+    cap = sum(nodeflow_caps(batch_size, k, hops))
+    rows = np.full((n_batches, cap), -1, dtype=np.int64) if keep_rows else None
+    tot = lib().pgc_sample_epoch(_p(indptr, _i64p), _p(indices, _i32p), _p(seeds, _i64p), len(seeds), batch_size, k,
+                                 hops, ctypes.c_uint64(seed), epoch, first_batch, n_batches,
+                                 _p(rows, _i64p) if keep_rows else None, cap)
+    return int(tot), rows
+
+
+# --------------------------------------------------------------------------
+# aggregation + model (PaGraph/model/*.py)
+# --------------------------------------------------------------------------
+def spmm_fwd(indptr, src, h, n_dst, reduce="mean"):
+    h = _c(h, np.float32)
+    indptr = _c(indptr, np.int32)
+    src = _c(src, np.int32)
+    out = np.empty((n_dst, h.shape[1]), dtype=np.float32)
+    lib().pgc_spmm_fwd(_p(indptr, _i32p), _p(src, _i32p), _p(h, _f32p), n_dst, h.shape[1],
+                       1 if reduce == "mean" else 0, _p(out, _f32p))
+    return out
+
+
+def spmm_bwd(indptr, src, grad_out, n_src, reduce="mean"):
+    go = _c(grad_out, np.float32)
+    indptr = _c(indptr, np.int32)
+    src = _c(src, np.int32)
+    gh = np.empty((n_src, go.shape[1]), dtype=np.float32)
+    lib().pgc_spmm_bwd(_p(indptr, _i32p), _p(src, _i32p), _p(go, _f32p), go.shape[0], n_src, go.shape[1],
+                       1 if reduce == "mean" else 0, _p(gh, _f32p))
+    return gh
+
+
+def _relu(x):
+    return np.maximum(x, 0)
+
+
+def gcn_forward(nf, feats0, params, n_layers=1):
+    """GCNSampling.forward, dropout off (gcn_nssc.py:60-77) with NodeUpdate (:14-24).
+    params: list of (W[out,in], b[out]) per layer; nf from sample_nodeflow; feats0 = layer-0 features."""
+    offs = nf["layer_offsets"]
+    h = feats0
+    acts = []
+    n = len(params)
+    for i, (W, b) in enumerate(params):
+        ip, sr = nf["blocks"][i]
+        nd = offs[i + 2] - offs[i + 1]
+        agg = spmm_fwd(ip, sr, h, nd, "mean")                     # :71-74
+        z = agg @ W.T + b                                         # :18
+        if i == n - 1:
+            h = z                                                 # output layer: no activation (:58)
+        elif i == n_layers - 1:
+            h = np.concatenate([z, _relu(z)], axis=1)             # :20-21 skip concat
+        else:
+            h = _relu(z)                                          # :22-23
+        acts.append(h)
+    return h, acts
+
+
+def sage_forward(nf, feats_by_layer, params, n_layers=1):
+    """GraphSageSampling.forward, aggregator 'mean', dropout off
+    (graphsage_nssc.py:74-134, NodeUpdate :21-30). params: list of
+    (W_self, b_self, W_neigh, b_neigh). feats_by_layer[l] = features of NodeFlow layer l."""
+    offs = nf["layer_offsets"]
+    L = len(offs) - 1                                             # nf.num_layers
+    h = [np.asarray(f, dtype=np.float32) for f in feats_by_layer]  # :89-90
+    n = len(params)
+    for lid, (Ws, bs, Wn, bn) in enumerate(params):               # :92
+        act = {}
+        for i in range(lid, L - 1):                               # :93
+            ip, sr = nf["blocks"][i]
+            nd = offs[i + 2] - offs[i + 1]
+            neigh = spmm_fwd(ip, sr, h[i], nd, "mean")            # :98-101
+            z = h[i + 1] @ Ws.T + bs + neigh @ Wn.T + bn          # :24
+            if lid == n - 1:
+                a = z
+            elif lid == n_layers - 1:
+                a = np.concatenate([z, _relu(z)], axis=1)
+            else:
+                a = _relu(z)
+            act[i + 1] = a
+        for i in range(lid + 1, L):                               # :129-131
+            h[i] = act[i]
+    return h[L - 1]
+
+
+# --------------------------------------------------------------------------
+# partitioning (PaGraph/partition/dg.py, utils.py) — small-case Python restatements
+# --------------------------------------------------------------------------
+def dg_partition(P, indptr, indices, V, train_nids, hops):
+    """dg.py:59-103 restated with explicit loops (slow; small graphs only)."""
+    def in_nb(n):
+        return indices[indptr[n]:indptr[n + 1]]
+
+    def in_nb_hop(nid):                                           # dg.py:18-27
+        if hops == 1:
+            return in_nb(nid)
+        nids = []
+        for _depth in range(hops):
+            neighs = nids[-1] if nids else [nid]
+            for n in neighs:
+                nids.append(in_nb(n))
+        return np.unique(np.hstack(nids))
+
+    belongs = -np.ones(V, dtype=np.int8)
+    r_belongs = [np.zeros(V, dtype=bool) for _ in range(P)]
+    p_vnum = np.zeros(P, dtype=np.int64)
+    r_vnum = np.zeros(P, dtype=np.int64)
+    for nid in train_nids:
+        nb = in_nb_hop(nid)
+        com = np.ones(P, dtype=np.int64)                          # :47
+        nbb = belongs[nb]
+        bel = nbb[nbb != -1]
+        pid, freq = np.unique(bel, return_counts=True)
+        com[pid] += freq
+        avg = V * 0.65 / P                                        # :54
+        score = com * (-p_vnum + avg) / (r_vnum + 1)              # :55
+        ids = np.argsort(score, kind="stable")[-2:]               # :31 (insertion sort for P<=16 == stable)
+        if score[ids[0]] != score[ids[1]]:
+            ind = ids[1]
+        else:
+            ind = ids[0] if p_vnum[ids[0]] < p_vnum[ids[1]] else ids[1]
+        if belongs[nid] == -1:                                    # :76-83
+            belongs[nid] = ind
+            p_vnum[ind] += 1
+            for u in np.append(nb, nid):
+                if not r_belongs[ind][u]:
+                    r_belongs[ind][u] = True
+                    r_vnum[ind] += 1
+    sub_v = [np.where(r_belongs[p])[0] for p in range(P)]
+    sub_trainv = [np.where(belongs == p)[0] for p in range(P)]
+    return sub_v, sub_trainv
+
+
+def closure_subgraph(indptr, indices, V, train_nid, num_hops):
+    """utils.py:9-52 get_sub_graph with DGL's sampler replaced by its spec
+    (full-neighbour per-layer expansion, per-layer dedup). Returns
+    (sub_indptr, sub_indices [CSR row=src col=dst], sub2full, subtrainid)."""
+    import scipy.sparse as spsp
+    train_nid = np.asarray(train_nid, dtype=np.int64)
+    layer = train_nid
+    srcs, dsts = [], []
+    for _ in range(num_hops):
+        s_all = [indices[indptr[v]:indptr[v + 1]].astype(np.int64) for v in layer]
+        d_all = [np.full(indptr[v + 1] - indptr[v], v, dtype=np.int64) for v in layer]
+        s = np.concatenate(s_all) if s_all else np.zeros(0, np.int64)
+        d = np.concatenate(d_all) if d_all else np.zeros(0, np.int64)
+        srcs.append(s); dsts.append(d)
+        layer = np.unique(s)
+    full_srcs = np.concatenate(srcs[::-1]); full_dsts = np.concatenate(dsts[::-1])   # :25-31
+    sub2full = np.unique(np.concatenate((full_srcs, full_dsts)))  # :33
+    full2sub = np.zeros(np.max(sub2full) + 1, dtype=np.int64)     # :34-35
+    full2sub[sub2full] = np.arange(len(sub2full), dtype=np.int64)
+    sub_srcs = full2sub[full_srcs]; sub_dsts = full2sub[full_dsts]  # :37-38
+    vnum = len(sub2full)
+    coo = spsp.coo_matrix((np.ones(len(sub_srcs), dtype=np.uint8), (sub_srcs, sub_dsts)), shape=(vnum, vnum))
+    csr = coo.tocsr()                                             # :43
+    csr.sort_indices()
+    tnid = train_nid.copy()                                       # :48
+    valid_t_max = np.max(sub2full); valid_t_min = np.min(tnid)    # :49-50
+    tnid = np.where(tnid <= valid_t_max, tnid, valid_t_min)       # :51
+    subtrainid = full2sub[np.unique(tnid)]                        # :52
+    return csr.indptr.astype(np.int64), csr.indices.astype(np.int64), sub2full, subtrainid
+
+
+# --------------------------------------------------------------------------
+# synthetic inputs
+# --------------------------------------------------------------------------
+def rmat_edges(seed, scale, first, n, a=0.45, b=0.22, c=0.22):
+    q = lambda x: int(round(x * 2 ** 32)) & 0xFFFFFFFF
+    src = np.empty(n, dtype=np.int64)
+    dst = np.empty(n, dtype=np.int64)
+    lib().pgc_rmat_edges(ctypes.c_uint64(seed), scale, q(a), q(b), q(c), first, n, _p(src, _i64p), _p(dst, _i64p))
+    return src, dst
+
+
+def random_features(seed, row0, rows, dim):
+    out = np.empty((rows, dim), dtype=np.float32)
+    lib().pgc_random_features(ctypes.c_uint64(seed), row0, rows, dim, _p(out, _f32p), dim)
+    return out

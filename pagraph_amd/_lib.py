@@ -1,0 +1,125 @@
+"""ctypes binding of libpagraph_hip.so (the C-ABI declared in include/pagraph_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails,
+this raises.  torch is imported first on purpose — the library is linked against
+libamdhip64.so.7, and loading it after torch makes the dynamic loader reuse the
+HIP runtime torch already mapped (one runtime, shared streams and allocations).
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpagraph_hip.so")
+
+PG_MAX_FIELDS = 4
+PG_MAX_LAYERS = 8
+PG_REDUCE_MEAN = 0
+PG_REDUCE_SUM = 1
+
+c_i32, c_i64, c_u32, c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
+vp = ctypes.c_void_p
+
+
+class PgField(ctypes.Structure):
+    _fields_ = [("cache", vp), ("out", vp), ("dim", c_i32), ("cache_stride", c_i32),
+                ("out_stride", c_i32), ("_pad", c_i32)]
+
+
+class PgNodeflowDesc(ctypes.Structure):
+    _fields_ = [("node_mapping", vp), ("layer_offsets", vp), ("blk_indptr", vp), ("blk_src", vp),
+                ("sizes_pinned", vp), ("cap_nodes", c_i64),
+                ("blk_indptr_off", c_i64 * PG_MAX_LAYERS), ("blk_src_off", c_i64 * PG_MAX_LAYERS)]
+
+
+class PgError(RuntimeError):
+    pass
+
+
+_SIGS = {
+    "pg_version": (ctypes.c_int, []),
+    "pg_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "pg_last_hip_error": (ctypes.c_int, []),
+    "pg_device_cu_count": (ctypes.c_int, []),
+    "pg_slot_map_reset": (ctypes.c_int, [vp, c_i64, vp]),
+    "pg_slot_map_assign": (ctypes.c_int, [vp, vp, c_i64, vp]),
+    "pg_slot_map_export": (ctypes.c_int, [vp, c_i64, vp, vp, vp]),
+    "pg_gather_rows": (ctypes.c_int, [vp, c_i64, vp, vp, ctypes.POINTER(PgField), ctypes.c_int, vp, vp, vp, vp]),
+    "pg_gather_rows_full": (ctypes.c_int, [vp, c_i64, ctypes.POINTER(PgField), ctypes.c_int, vp]),
+    "pg_scatter_rows": (ctypes.c_int, [vp, vp, c_i64, vp, c_i32, vp, c_i32, vp]),
+    "pg_host_gather_rows": (ctypes.c_int, [vp, c_i64, c_i32, vp, c_i64, vp, ctypes.c_int]),
+    "pg_scatter_rows_from_host": (ctypes.c_int, [vp, c_i64, vp, vp, c_i64, vp, c_i32, vp, c_i32, vp]),
+    "pg_sampler_create": (ctypes.c_int, [c_i64, vp, vp, c_i32, c_i32, c_i32, ctypes.POINTER(vp)]),
+    "pg_sampler_destroy": (ctypes.c_int, [vp]),
+    "pg_sampler_capacity": (ctypes.c_int, [vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    "pg_sampler_sample": (ctypes.c_int, [vp, vp, c_i32, c_u64, c_u32, c_u32, ctypes.POINTER(PgNodeflowDesc), vp]),
+    "pg_frontier_mark_neighbors": (ctypes.c_int, [vp, vp, vp, c_i64, vp, ctypes.c_int, vp]),
+    "pg_bitmap_to_ids": (ctypes.c_int, [vp, c_i64, vp, c_i64, vp, vp, vp, vp]),
+    "pg_spmm_fwd": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp]),
+    "pg_spmm_bwd": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp]),
+    "pg_dg_partition": (ctypes.c_int, [c_i64, vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp]),
+    "pg_rmat_edges": (ctypes.c_int, [c_u64, c_i32, c_u32, c_u32, c_u32, c_i64, c_i64, vp, vp, vp]),
+    "pg_random_features": (ctypes.c_int, [c_u64, c_i64, c_i64, c_i32, vp, c_i64, vp]),
+    "pg_timer_create": (ctypes.c_int, [ctypes.POINTER(vp)]),
+    "pg_timer_destroy": (ctypes.c_int, [vp]),
+    "pg_timer_start": (ctypes.c_int, [vp, vp]),
+    "pg_timer_stop": (ctypes.c_int, [vp, vp]),
+    "pg_timer_elapsed_ms": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_float)]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+def load():
+    """dlopen the HIP library; raises PgError (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PgError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C pagraph_amd/csrc`. pagraph_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)  # AttributeError here = header / library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        L = load()
+        msg = L.pg_strerror(rc).decode()
+        hip = L.pg_last_hip_error() if rc == -2 else 0
+        raise PgError(f"{what or 'libpagraph_hip'}: {msg} (code {rc}, hip error {hip})")
+
+
+def stream_ptr(stream=None):
+    """hipStream_t of a torch stream (default: current stream of the current device)"""
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def ptr(t):
+    """raw pointer of a tensor (None -> NULL)"""
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def make_fields(items):
+    """items: iterable of (cache_tensor_or_None, out_tensor, dim, cache_stride, out_stride)"""
+    items = list(items)
+    if len(items) > PG_MAX_FIELDS:
+        raise PgError(f"at most {PG_MAX_FIELDS} fields per gather")
+    arr = (PgField * max(1, len(items)))()
+    for i, (cache, out, dim, cs, os_) in enumerate(items):
+        arr[i].cache = cache.data_ptr() if cache is not None else 0
+        arr[i].out = out.data_ptr()
+        arr[i].dim = dim
+        arr[i].cache_stride = cs
+        arr[i].out_stride = os_
+    return arr, len(items)

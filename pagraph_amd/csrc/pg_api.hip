@@ -1,0 +1,108 @@
+// Host-side entry points that are not kernels: version/errors, the server-side
+// row gather of the miss path (storage.py:128), HIP-event timer for bench.py.
+#include <algorithm>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "pg_common.h"
+
+namespace pg {
+thread_local int g_last_hip_error = 0;
+}
+
+struct pg_timer {
+  hipEvent_t start, stop;
+};
+
+extern "C" {
+
+int pg_version(void) { return 100; /* 0.1.0 */ }
+
+const char* pg_strerror(int code) {
+  switch (code) {
+    case PG_OK: return "ok";
+    case PG_ERR_INVALID: return "invalid argument";
+    case PG_ERR_HIP: return "HIP runtime error";
+    case PG_ERR_NOMEM: return "out of memory";
+    case PG_ERR_UNSUPPORTED: return "unsupported";
+    case PG_ERR_OVERFLOW: return "capacity overflow";
+    default: return "unknown error";
+  }
+}
+
+int pg_last_hip_error(void) { return pg::g_last_hip_error; }
+
+int pg_device_cu_count(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return -1;
+  return p.multiProcessorCount;
+}
+
+// storage.py:128 `self.graph._node_frame._frame[name].data[nids]` — the CPU
+// fancy-index over the host feature table. Rows are scattered in DRAM, so the
+// copy is split over threads; `staged` is normally pinned so the following
+// hipMemcpyAsync is a true async DMA (the reference's pageable copy is not).
+int pg_host_gather_rows(const float* table, int64_t table_stride, int32_t dim, const int64_t* fullids,
+                        int64_t n, float* staged, int n_threads) {
+  if (n < 0 || dim <= 0 || table_stride < dim) return PG_ERR_INVALID;
+  if (n == 0) return PG_OK;
+  if (!table || !fullids || !staged) return PG_ERR_INVALID;
+  const size_t row_bytes = (size_t)dim * sizeof(float);
+  auto work = [&](int64_t lo, int64_t hi) {
+    for (int64_t j = lo; j < hi; ++j)
+      std::memcpy(staged + j * dim, table + fullids[j] * table_stride, row_bytes);
+  };
+  int t = std::max(1, n_threads);
+  t = (int)std::min<int64_t>(t, (n + 255) / 256);
+  if (t <= 1) {
+    work(0, n);
+    return PG_OK;
+  }
+  std::vector<std::thread> th;
+  th.reserve(t - 1);
+  const int64_t per = (n + t - 1) / t;
+  for (int i = 1; i < t; ++i) th.emplace_back(work, std::min<int64_t>(n, i * per), std::min<int64_t>(n, (i + 1) * per));
+  work(0, std::min<int64_t>(n, per));
+  for (auto& x : th) x.join();
+  return PG_OK;
+}
+
+int pg_timer_create(pg_timer_t** t) {
+  if (!t) return PG_ERR_INVALID;
+  pg_timer* p = new (std::nothrow) pg_timer;
+  if (!p) return PG_ERR_NOMEM;
+  if (hipEventCreate(&p->start) != hipSuccess || hipEventCreate(&p->stop) != hipSuccess) {
+    delete p;
+    return PG_ERR_HIP;
+  }
+  *t = p;
+  return PG_OK;
+}
+int pg_timer_destroy(pg_timer_t* t) {
+  if (!t) return PG_OK;
+  (void)hipEventDestroy(t->start);
+  (void)hipEventDestroy(t->stop);
+  delete t;
+  return PG_OK;
+}
+int pg_timer_start(pg_timer_t* t, pg_stream_t s) {
+  if (!t) return PG_ERR_INVALID;
+  PG_HIP(hipEventRecord(t->start, pg::as_stream(s)));
+  return PG_OK;
+}
+int pg_timer_stop(pg_timer_t* t, pg_stream_t s) {
+  if (!t) return PG_ERR_INVALID;
+  PG_HIP(hipEventRecord(t->stop, pg::as_stream(s)));
+  return PG_OK;
+}
+int pg_timer_elapsed_ms(pg_timer_t* t, float* ms) {
+  if (!t || !ms) return PG_ERR_INVALID;
+  PG_HIP(hipEventSynchronize(t->stop));
+  PG_HIP(hipEventElapsedTime(ms, t->start, t->stop));
+  return PG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+// Shared bits of libpagraph_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pagraph_hip.h"
+
+namespace pg {
+
+constexpr int kWave = 64;
+
+extern thread_local int g_last_hip_error;
+
+inline int hip_fail(hipError_t e) {
+  g_last_hip_error = (int)e;
+  return PG_ERR_HIP;
+}
+
+#define PG_HIP(expr)                               \
+  do {                                             \
+    hipError_t _e = (expr);                        \
+    if (_e != hipSuccess) return pg::hip_fail(_e); \
+  } while (0)
+
+#define PG_LAUNCH_CHECK() PG_HIP(hipGetLastError())
+
+inline hipStream_t as_stream(pg_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+template <typename T>
+__host__ __device__ inline T ceil_div(T a, T b) {
+  return (a + b - 1) / b;
+}
+
+// Philox4x32-10 (Salmon et al., SC'11): the counter-based RNG of the sampler
+// spec. Same arithmetic as oracle/pgc_oracle.c (independent restatement).
+struct Philox {
+  static constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  static constexpr uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+  __host__ __device__ static inline void round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)M0 * c[0];
+    const uint64_t p1 = (uint64_t)M1 * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+  }
+  __host__ __device__ static inline void gen(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                             uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+    uint32_t c[4] = {c0, c1, c2, c3};
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      round(c, k0, k1);
+      k0 += W0;
+      k1 += W1;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+  }
+};
+
+// uniform integer in [0, n) from a 64-bit draw: floor(r * n / 2^64)
+__host__ __device__ inline uint64_t bounded(uint64_t r, uint64_t n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(r, n);
+#else
+  return (uint64_t)(((unsigned __int128)r * n) >> 64);
+#endif
+}
+
+}  // namespace pg

@@ -1,0 +1,484 @@
+// Per-layer frontier-expand neighbour sampler on a CSC adjacency in HBM.
+//
+// Stands in for DGL 0.4.1's C++/OpenMP NeighborSampler as the reference calls
+// it at examples/profile/pa_gcn.py:71-76 (fan-out k, neighbor_type='in',
+// num_hops) and, with fan-out = infinity, at PaGraph/partition/utils.py:11-18.
+// DGL's source is not in the reference checkout: the semantics implemented here
+// are the build-defined spec of DESIGN.md ("Sampler spec"), restated
+// independently in oracle/pgc_oracle.c.
+//
+// Per block b (layer b+1 = destinations, layer b = sources), stream-ordered:
+//   k_sample      wave per destination vertex: deg <= k takes the whole
+//                 adjacency list (coalesced), else Floyd's k-subset with
+//                 Philox4x32-10 draws keyed (seed; v, epoch, batch, layer, j);
+//                 picks go to an ELL buffer and are marked in a V-bit bitmap
+//                 (atomicOr) — the per-layer dedup.
+//   k_scan_cnt    exclusive scan of per-destination pick counts -> block indptr
+//   k_bm_count / k_bm_scan / k_bm_emit
+//                 popcount prefix over the bitmap words: emits the layer's
+//                 vertex ids ASCENDING (the spec's canonical order) and the
+//                 per-word rank table; LDS holds the per-wave partials.
+//   k_relabel     edge source id -> position in the layer = word_rank[w] +
+//                 popcount(bits below) — no hash table, no sort.
+//   k_clear       zero the bitmap words the layer touched.
+// k_pack finally concatenates the layers (layer 0 first) into node_mapping and
+// writes the sizes straight into pinned host memory.
+// All sizes stay on the device; launches are sized by worst-case capacities.
+#include <new>
+
+#include "pg_common.h"
+
+namespace pg {
+
+constexpr int kScanThreads = 1024;
+constexpr int kWordsPerBlock = 1024;  // bitmap words handled by one 256-thread block (4 per thread)
+
+// ---- block-wide exclusive scan of one int per thread (blockDim <= 1024) ----
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const int t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+// returns exclusive prefix; *total = block sum. lds: >= 16 ints
+__device__ __forceinline__ int block_excl_scan(int v, int* lds, int* total) {
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave, nw = blockDim.x / kWave;
+  const int incl = wave_incl_scan(v, lane);
+  if (lane == kWave - 1) lds[w] = incl;
+  __syncthreads();
+  if (w == 0) {
+    int s = lane < nw ? lds[lane] : 0;
+    s = wave_incl_scan(s, lane);
+    if (lane < nw) lds[lane] = s;
+  }
+  __syncthreads();
+  const int base = w == 0 ? 0 : lds[w - 1];
+  *total = lds[nw - 1];
+  __syncthreads();
+  return base + incl - v;
+}
+
+// ---------------------------------------------------------------------------
+struct SampleArgs {
+  const int64_t* indptr;
+  const int32_t* indices;
+  const int64_t* dst_ids;  // layer b+1 vertex ids
+  const int32_t* n_dst;    // device count
+  int32_t* nbr;            // ELL [cap_dst, k] picked neighbour ids
+  int32_t* cnt;            // [cap_dst]
+  unsigned long long* bitmap;
+  int32_t k;
+  uint32_t seed_lo, seed_hi, epoch, batch, layer;
+};
+
+__global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
+  const int n = *a.n_dst;
+  const int k = a.k;
+  for (int64_t p = wave0; p < n; p += nwaves) {
+    const int64_t v = a.dst_ids[p];
+    const int64_t beg = a.indptr[v];
+    const int64_t deg = a.indptr[v + 1] - beg;
+    int32_t* out = a.nbr + p * k;
+    if (deg <= k) {
+      // take the whole in-neighbour list, adjacency order
+      if (lane < deg) {
+        const int32_t u = a.indices[beg + lane];
+        out[lane] = u;
+        atomicOr(&a.bitmap[u >> 6], 1ull << (u & 63));
+      }
+      if (lane == 0) a.cnt[p] = (int32_t)deg;
+    } else {
+      // Floyd's algorithm for a uniform k-subset of {0..deg-1}: for j = 0..k-1,
+      // m = deg-k+j, t ~ U{0..m}; pick t unless already picked, then pick m.
+      uint64_t t = 0;
+      if (lane < k) {
+        uint32_t r[4];
+        Philox::gen((uint32_t)v, a.epoch, a.batch, (a.layer << 24) | (uint32_t)(lane >> 1), a.seed_lo,
+                    a.seed_hi, r);
+        const uint64_t r64 = (lane & 1) ? ((uint64_t)r[3] << 32 | r[2]) : ((uint64_t)r[1] << 32 | r[0]);
+        t = bounded(r64, (uint64_t)(deg - k + lane) + 1);
+      }
+      uint64_t sel = t;
+      for (int j = 1; j < k; ++j) {
+        const uint64_t tj = __shfl(t, j);
+        const bool dup = __ballot(lane < j && sel == tj) != 0ull;
+        if (lane == j && dup) sel = (uint64_t)(deg - k + j);
+      }
+      if (lane < k) {
+        const int32_t u = a.indices[beg + (int64_t)sel];
+        out[lane] = u;
+        atomicOr(&a.bitmap[u >> 6], 1ull << (u & 63));
+      }
+      if (lane == 0) a.cnt[p] = k;
+    }
+  }
+}
+
+// exclusive scan of cnt[0:n] -> indptr[0:n+1]; single block, loops over tiles
+__global__ __launch_bounds__(kScanThreads) void k_scan_cnt(const int32_t* __restrict__ cnt,
+                                                           const int32_t* __restrict__ n_dev,
+                                                           int32_t* __restrict__ indptr,
+                                                           int32_t* __restrict__ total_out) {
+  __shared__ int lds[16];
+  const int n = *n_dev;
+  int carry = 0;
+  for (int base = 0; base < n; base += kScanThreads) {
+    const int i = base + threadIdx.x;
+    const int v = i < n ? cnt[i] : 0;
+    int tot;
+    const int ex = block_excl_scan(v, lds, &tot);
+    if (i < n) indptr[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) {
+    indptr[n] = carry;
+    *total_out = carry;
+  }
+}
+
+// ---- bitmap -> ascending ids ------------------------------------------------
+__global__ __launch_bounds__(256) void k_bm_count(const unsigned long long* __restrict__ bm, int64_t n_words,
+                                                  int32_t* __restrict__ partial) {
+  __shared__ int lds[16];
+  const int64_t w0 = (int64_t)blockIdx.x * kWordsPerBlock + threadIdx.x * 4;
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (w0 + i < n_words) c += __popcll(bm[w0 + i]);
+  int tot;
+  (void)block_excl_scan(c, lds, &tot);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// exclusive scan of the per-block partials in place; total -> *count_out (int32) and *count64 (optional)
+__global__ __launch_bounds__(kScanThreads) void k_bm_scan(int32_t* __restrict__ partial, int n_blocks,
+                                                          int32_t* __restrict__ count_out,
+                                                          int64_t* __restrict__ count64) {
+  __shared__ int lds[16];
+  int carry = 0;
+  for (int base = 0; base < n_blocks; base += kScanThreads) {
+    const int i = base + threadIdx.x;
+    const int v = i < n_blocks ? partial[i] : 0;
+    int tot;
+    const int ex = block_excl_scan(v, lds, &tot);
+    if (i < n_blocks) partial[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) {
+    if (count_out) *count_out = carry;
+    if (count64) *count64 = carry;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bm_emit(const unsigned long long* __restrict__ bm, int64_t n_words,
+                                                 const int32_t* __restrict__ partial,
+                                                 int64_t* __restrict__ out_ids, int64_t cap,
+                                                 uint32_t* __restrict__ word_rank) {
+  __shared__ int lds[16];
+  const int64_t w0 = (int64_t)blockIdx.x * kWordsPerBlock + threadIdx.x * 4;
+  unsigned long long w[4];
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    w[i] = (w0 + i < n_words) ? bm[w0 + i] : 0ull;
+    c += __popcll(w[i]);
+  }
+  int tot;
+  int pos = partial[blockIdx.x] + block_excl_scan(c, lds, &tot);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (w0 + i < n_words) {
+      if (word_rank) word_rank[w0 + i] = (uint32_t)pos;
+      unsigned long long x = w[i];
+      const int64_t vbase = (w0 + i) << 6;
+      while (x) {
+        const int b = __ffsll((long long)x) - 1;
+        x &= x - 1;
+        if (pos < cap) out_ids[pos] = vbase + b;
+        ++pos;
+      }
+    }
+  }
+}
+
+// ELL picks -> CSR block with sources relabelled to layer positions
+__global__ __launch_bounds__(256) void k_relabel(const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt,
+                                                 const int32_t* __restrict__ n_dst, int32_t k,
+                                                 const int32_t* __restrict__ indptr,
+                                                 const unsigned long long* __restrict__ bm,
+                                                 const uint32_t* __restrict__ word_rank,
+                                                 int32_t* __restrict__ blk_src) {
+  const int64_t total = (int64_t)(*n_dst) * k;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / k;
+    const int j = (int)(i - p * k);
+    if (j < cnt[p]) {
+      const int32_t u = nbr[i];
+      const int64_t w = u >> 6;
+      const unsigned long long below = bm[w] & ((1ull << (u & 63)) - 1ull);
+      blk_src[indptr[p] + j] = (int32_t)(word_rank[w] + __popcll(below));
+    }
+  }
+}
+
+__global__ void k_clear_words(unsigned long long* bm, const int64_t* ids, const int32_t* n_dev) {
+  const int n = *n_dev;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    bm[ids[i] >> 6] = 0ull;
+}
+
+struct PackArgs {
+  const int64_t* layer_ids[PG_MAX_LAYERS];
+  const int32_t* layer_cnt[PG_MAX_LAYERS];
+  const int32_t* blk_edges[PG_MAX_LAYERS];
+  int64_t* node_mapping;
+  int32_t* layer_offsets;
+  int32_t* sizes_pinned;
+  int64_t cap_nodes;
+  int32_t num_layers;
+};
+
+__global__ __launch_bounds__(256) void k_pack(const PackArgs a) {
+  int off[PG_MAX_LAYERS + 1];
+  off[0] = 0;
+#pragma unroll
+  for (int l = 0; l < PG_MAX_LAYERS; ++l) off[l + 1] = off[l] + (l < a.num_layers ? *a.layer_cnt[l] : 0);
+  const int64_t total = off[PG_MAX_LAYERS];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total && i < a.cap_nodes;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t v = 0;
+#pragma unroll
+    for (int l = 0; l < PG_MAX_LAYERS; ++l)
+      if (l < a.num_layers && i >= off[l] && i < off[l + 1]) v = a.layer_ids[l][i - off[l]];
+    a.node_mapping[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+    for (int l = 0; l < PG_MAX_LAYERS; ++l) {
+      if (l <= a.num_layers) a.layer_offsets[l] = off[l];
+      if (l < a.num_layers) a.sizes_pinned[l] = off[l + 1] - off[l];
+      if (l + 1 < a.num_layers) a.sizes_pinned[PG_MAX_LAYERS + l] = *a.blk_edges[l];
+    }
+    __threadfence_system();
+  }
+}
+
+// copy seeds into the top layer buffer + set its count
+__global__ void k_seed_layer(const int64_t* seeds, int32_t n, int64_t* layer_ids, int32_t* layer_cnt) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) layer_ids[i] = seeds[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *layer_cnt = n;
+}
+
+// fan-out = infinity: mark every in-neighbour of the frontier (closure builder)
+__global__ __launch_bounds__(256) void k_mark_neighbors(const int64_t* __restrict__ indptr,
+                                                        const int32_t* __restrict__ indices,
+                                                        const int64_t* __restrict__ frontier, int64_t n,
+                                                        unsigned long long* __restrict__ bm, int mark_self) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
+  for (int64_t p = wave0; p < n; p += nwaves) {
+    const int64_t v = frontier[p];
+    const int64_t beg = indptr[v], end = indptr[v + 1];
+    for (int64_t e = beg + lane; e < end; e += kWave) {
+      const int32_t u = indices[e];
+      atomicOr(&bm[u >> 6], 1ull << (u & 63));
+    }
+    if (mark_self && lane == 0) atomicOr(&bm[v >> 6], 1ull << (v & 63));
+  }
+}
+
+static inline int grid_for(int64_t n, int per_block, int cap = 8192) {
+  int64_t g = ceil_div<int64_t>(n, per_block);
+  if (g < 1) g = 1;
+  return (int)(g > cap ? cap : g);
+}
+
+}  // namespace pg
+
+using namespace pg;
+
+struct pg_sampler {
+  int64_t V = 0;
+  const int64_t* indptr = nullptr;
+  const int32_t* indices = nullptr;
+  int32_t B = 0, k = 0, hops = 0;
+  int64_t cap[PG_MAX_LAYERS] = {0};  // per-layer vertex capacity, layer 0 first
+  int64_t n_words = 0;
+  int n_bm_blocks = 0;
+  // device buffers
+  unsigned long long* bitmap = nullptr;
+  uint32_t* word_rank = nullptr;
+  int32_t* partial = nullptr;
+  int64_t* layer_ids[PG_MAX_LAYERS] = {nullptr};
+  int32_t* counters = nullptr;  // [0..L] layer counts, [PG_MAX_LAYERS..] block edge counts
+  int32_t* nbr = nullptr;       // ELL picks of the current block (reused)
+  int32_t* cnt = nullptr;
+};
+
+static void sampler_free(pg_sampler* s) {
+  if (!s) return;
+  (void)hipFree(s->bitmap);
+  (void)hipFree(s->word_rank);
+  (void)hipFree(s->partial);
+  for (auto p : s->layer_ids) (void)hipFree(p);
+  (void)hipFree(s->counters);
+  (void)hipFree(s->nbr);
+  (void)hipFree(s->cnt);
+  delete s;
+}
+
+extern "C" {
+
+int pg_sampler_create(int64_t V, const int64_t* indptr, const int32_t* indices, int32_t max_seeds,
+                      int32_t fanout, int32_t num_hops, pg_sampler_t** out) {
+  if (!out || V <= 0 || V > INT32_MAX || !indptr || !indices || max_seeds <= 0 || fanout <= 0 ||
+      num_hops <= 0 || num_hops + 1 > PG_MAX_LAYERS)
+    return PG_ERR_INVALID;
+  if (fanout > kWave) return PG_ERR_UNSUPPORTED;  // one wave resolves one vertex's k picks
+  pg_sampler* s = new (std::nothrow) pg_sampler;
+  if (!s) return PG_ERR_NOMEM;
+  s->V = V; s->indptr = indptr; s->indices = indices;
+  s->B = max_seeds; s->k = fanout; s->hops = num_hops;
+  const int L = num_hops;  // top layer index
+  s->cap[L] = max_seeds;
+  for (int l = L - 1; l >= 0; --l) {
+    const int64_t c = s->cap[l + 1] * fanout;
+    s->cap[l] = c < V ? c : V;
+  }
+  s->n_words = ceil_div<int64_t>(V, 64);
+  s->n_bm_blocks = (int)ceil_div<int64_t>(s->n_words, kWordsPerBlock);
+  int64_t max_dst = 0;
+  for (int l = 1; l <= L; ++l) max_dst = s->cap[l] > max_dst ? s->cap[l] : max_dst;
+  bool ok = true;
+  ok &= hipMalloc(&s->bitmap, s->n_words * 8) == hipSuccess;
+  ok &= hipMalloc(&s->word_rank, s->n_words * 4) == hipSuccess;
+  ok &= hipMalloc(&s->partial, (size_t)s->n_bm_blocks * 4 + 4) == hipSuccess;
+  for (int l = 0; l <= L; ++l) ok &= hipMalloc(&s->layer_ids[l], s->cap[l] * 8) == hipSuccess;
+  ok &= hipMalloc(&s->counters, 2 * PG_MAX_LAYERS * 4) == hipSuccess;
+  ok &= hipMalloc(&s->nbr, max_dst * fanout * 4) == hipSuccess;
+  ok &= hipMalloc(&s->cnt, max_dst * 4) == hipSuccess;
+  if (ok) ok &= hipMemset(s->bitmap, 0, s->n_words * 8) == hipSuccess;
+  if (ok) ok &= hipMemset(s->counters, 0, 2 * PG_MAX_LAYERS * 4) == hipSuccess;
+  if (!ok) {
+    sampler_free(s);
+    return PG_ERR_NOMEM;
+  }
+  *out = s;
+  return PG_OK;
+}
+
+int pg_sampler_destroy(pg_sampler_t* s) {
+  sampler_free(s);
+  return PG_OK;
+}
+
+int pg_sampler_capacity(const pg_sampler_t* s, int64_t* cap_nodes, int64_t* cap_blk_rows, int64_t* cap_blk_edges) {
+  if (!s) return PG_ERR_INVALID;
+  int64_t tot = 0;
+  for (int l = 0; l <= s->hops; ++l) tot += s->cap[l];
+  if (cap_nodes) *cap_nodes = tot;
+  for (int b = 0; b < s->hops; ++b) {
+    if (cap_blk_rows) cap_blk_rows[b] = s->cap[b + 1];
+    if (cap_blk_edges) cap_blk_edges[b] = s->cap[b + 1] * s->k;
+  }
+  return PG_OK;
+}
+
+int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, uint64_t seed, uint32_t epoch,
+                      uint32_t batch, const pg_nodeflow_desc_t* o, pg_stream_t stream) {
+  if (!s || !o || !seeds || n_seeds <= 0 || n_seeds > s->B) return PG_ERR_INVALID;
+  if (!o->node_mapping || !o->layer_offsets || !o->blk_indptr || !o->blk_src || !o->sizes_pinned)
+    return PG_ERR_INVALID;
+  int64_t need = 0;
+  for (int l = 0; l <= s->hops; ++l) need += s->cap[l];
+  if (o->cap_nodes < need) return PG_ERR_OVERFLOW;
+  hipStream_t st = as_stream(stream);
+  const int L = s->hops;
+  int32_t* lcnt = s->counters;
+  int32_t* ecnt = s->counters + PG_MAX_LAYERS;
+
+  hipLaunchKernelGGL(k_seed_layer, dim3(grid_for(n_seeds, 256, 64)), dim3(256), 0, st, seeds, n_seeds,
+                     s->layer_ids[L], lcnt + L);
+  PG_LAUNCH_CHECK();
+  for (int b = L - 1; b >= 0; --b) {
+    const int64_t cap_dst = s->cap[b + 1];
+    SampleArgs a{};
+    a.indptr = s->indptr; a.indices = s->indices;
+    a.dst_ids = s->layer_ids[b + 1]; a.n_dst = lcnt + b + 1;
+    a.nbr = s->nbr; a.cnt = s->cnt; a.bitmap = s->bitmap; a.k = s->k;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.epoch = epoch; a.batch = batch; a.layer = (uint32_t)b;
+    hipLaunchKernelGGL(k_sample, dim3(grid_for(cap_dst, 4)), dim3(256), 0, st, a);
+    PG_LAUNCH_CHECK();
+    int32_t* indptr_b = o->blk_indptr + o->blk_indptr_off[b];
+    int32_t* src_b = o->blk_src + o->blk_src_off[b];
+    hipLaunchKernelGGL(k_scan_cnt, dim3(1), dim3(kScanThreads), 0, st, s->cnt, lcnt + b + 1, indptr_b, ecnt + b);
+    PG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bm_count, dim3(s->n_bm_blocks), dim3(256), 0, st, s->bitmap, s->n_words, s->partial);
+    PG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bm_scan, dim3(1), dim3(kScanThreads), 0, st, s->partial, s->n_bm_blocks, lcnt + b,
+                       (int64_t*)nullptr);
+    PG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bm_emit, dim3(s->n_bm_blocks), dim3(256), 0, st, s->bitmap, s->n_words, s->partial,
+                       s->layer_ids[b], s->cap[b], s->word_rank);
+    PG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_relabel, dim3(grid_for(cap_dst * s->k, 256)), dim3(256), 0, st, s->nbr, s->cnt,
+                       lcnt + b + 1, s->k, indptr_b, s->bitmap, s->word_rank, src_b);
+    PG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_clear_words, dim3(grid_for(s->cap[b], 256, 1024)), dim3(256), 0, st, s->bitmap,
+                       s->layer_ids[b], lcnt + b);
+    PG_LAUNCH_CHECK();
+  }
+  PackArgs p{};
+  for (int l = 0; l <= L; ++l) {
+    p.layer_ids[l] = s->layer_ids[l];
+    p.layer_cnt[l] = lcnt + l;
+  }
+  for (int b = 0; b < L; ++b) p.blk_edges[b] = ecnt + b;
+  p.node_mapping = o->node_mapping; p.layer_offsets = o->layer_offsets; p.sizes_pinned = o->sizes_pinned;
+  p.cap_nodes = o->cap_nodes; p.num_layers = L + 1;
+  hipLaunchKernelGGL(k_pack, dim3(grid_for(need, 256, 1024)), dim3(256), 0, st, p);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+int pg_frontier_mark_neighbors(const int64_t* indptr, const int32_t* indices, const int64_t* frontier, int64_t n,
+                               uint64_t* bitmap, int mark_self, pg_stream_t stream) {
+  if (n < 0) return PG_ERR_INVALID;
+  if (n == 0) return PG_OK;
+  if (!indptr || !indices || !frontier || !bitmap) return PG_ERR_INVALID;
+  hipLaunchKernelGGL(k_mark_neighbors, dim3(grid_for(n, 4, 16384)), dim3(256), 0, as_stream(stream), indptr,
+                     indices, frontier, n, reinterpret_cast<unsigned long long*>(bitmap), mark_self);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+int pg_bitmap_to_ids(const uint64_t* bitmap, int64_t n_words, int64_t* out_ids, int64_t cap, int64_t* count_dev,
+                     uint32_t* word_rank, void* scratch, pg_stream_t stream) {
+  if (n_words < 0 || cap < 0) return PG_ERR_INVALID;
+  if (!bitmap || !out_ids || !count_dev || !scratch) return PG_ERR_INVALID;
+  hipStream_t st = as_stream(stream);
+  const int nb = (int)ceil_div<int64_t>(n_words, kWordsPerBlock);
+  if (nb == 0) {
+    PG_HIP(hipMemsetAsync(count_dev, 0, 8, st));
+    return PG_OK;
+  }
+  // scratch holds the per-block partials: caller provides >= 4*(nb+1) bytes
+  int32_t* partial = reinterpret_cast<int32_t*>(scratch);
+  const unsigned long long* bm = reinterpret_cast<const unsigned long long*>(bitmap);
+  hipLaunchKernelGGL(k_bm_count, dim3(nb), dim3(256), 0, st, bm, n_words, partial);
+  PG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bm_scan, dim3(1), dim3(kScanThreads), 0, st, partial, nb, (int32_t*)nullptr, count_dev);
+  PG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bm_emit, dim3(nb), dim3(256), 0, st, bm, n_words, partial, out_ids, cap, word_rank);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+}  // extern "C"

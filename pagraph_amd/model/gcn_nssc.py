@@ -1,0 +1,98 @@
+"""2-layer sampled GCN with skip-concat — same constructor, parameter names
+(`layers.N.linear.{weight,bias}`, `linear.*` under preprocess) and maths as
+PaGraph/model/gcn_nssc.py:6-164, running on pagraph_amd's NodeFlow: the
+aggregation is the HIP SpMM (pg_spmm.hip), the dense step stays nn.Linear
+(hipBLASLt / MFMA through PyTorch-ROCm)."""
+import torch
+import torch.nn as nn
+
+from .. import function as fn
+
+
+class NodeUpdate(nn.Module):
+    """gcn_nssc.py:6-24"""
+
+    def __init__(self, in_feats, out_feats, activation=None, test=False, concat=False):
+        super().__init__()
+        self.linear = nn.Linear(in_feats, out_feats)
+        self.activation = activation
+        self.concat = concat
+        self.test = test
+
+    def forward(self, node):
+        h = node.data['h']
+        if self.test:
+            h = h * node.data['norm']
+        h = self.linear(h)
+        if self.concat:
+            h = torch.cat((h, self.activation(h)), dim=1)
+        elif self.activation:
+            h = self.activation(h)
+        return {'activation': h}
+
+
+def _stack(in_feats, n_hidden, n_classes, n_layers, activation, preprocess, test):
+    """layer list of gcn_nssc.py:45-58 (training) / :114-128 (inference)"""
+    layers = nn.ModuleList()
+    if not preprocess:
+        layers.append(NodeUpdate(in_feats, n_hidden, activation, test=test, concat=(n_layers == 1)))
+    for i in range(1, n_layers):
+        layers.append(NodeUpdate(n_hidden, n_hidden, activation, test=test, concat=(i == n_layers - 1)))
+    layers.append(NodeUpdate(2 * n_hidden, n_classes, test=test))
+    return layers
+
+
+class _GCNBase(nn.Module):
+    reducer = fn.mean
+
+    def _input_transform(self, nf):
+        """gcn_nssc.py:80-90: dense transform of the raw features before any aggregation"""
+        h = nf.layers[0].data['features']
+        if getattr(self, 'dropout', None):
+            h = self.dropout(h)
+        h = self.linear(h)
+        if self.n_layers == 1:
+            return torch.cat((h, self.activation(h)), dim=1)
+        return self.activation(h)
+
+    def _propagate(self, nf, h):
+        for i, layer in enumerate(self.layers):
+            if getattr(self, 'dropout', None) and not self.preprocess:
+                h = self.dropout(h)
+            nf.layers[i].data['h'] = h
+            nf.block_compute(i, fn.copy_src(src='h', out='m'), self.reducer(msg='m', out='h'), layer)
+            h = nf.layers[i + 1].data.pop('activation')
+        return h
+
+    def forward(self, nf):
+        if self.preprocess:
+            return self._propagate(nf, self._input_transform(nf))
+        return self._propagate(nf, nf.layers[0].data['features'])
+
+
+class GCNSampling(_GCNBase):
+    """gcn_nssc.py:27-100 — mean aggregation, dropout before every aggregation"""
+
+    def __init__(self, in_feats, n_hidden, n_classes, n_layers, activation, dropout, preprocess=False):
+        super().__init__()
+        self.preprocess = preprocess
+        self.n_layers = n_layers
+        self.dropout = nn.Dropout(p=dropout) if dropout != 0 else None
+        if preprocess:
+            self.linear = nn.Linear(in_feats, n_hidden)
+            self.activation = activation
+        self.layers = _stack(in_feats, n_hidden, n_classes, n_layers, activation, preprocess, test=False)
+
+
+class GCNInfer(_GCNBase):
+    """gcn_nssc.py:103-164 — sum aggregation scaled by `norm` inside NodeUpdate(test=True)"""
+    reducer = fn.sum
+
+    def __init__(self, in_feats, n_hidden, n_classes, n_layers, activation, preprocess=False):
+        super().__init__()
+        self.preprocess = preprocess
+        self.n_layers = n_layers
+        if preprocess:
+            self.linear = nn.Linear(in_feats, n_hidden)
+            self.activation = activation
+        self.layers = _stack(in_feats, n_hidden, n_classes, n_layers, activation, preprocess, test=True)

@@ -1,0 +1,84 @@
+"""Sampled GraphSAGE (mean / gcn aggregators) — constructor, parameter names
+(`layers.N.fc_self`, `layers.N.fc_neigh`) and dataflow of
+PaGraph/model/graphsage_nssc.py:6-134 on pagraph_amd's NodeFlow.  The 'pool'
+(max) and 'lstm' aggregators are not on the benchmarked path (pa_gs.py:62 passes
+'mean') and raise."""
+import torch
+import torch.nn as nn
+
+from .. import function as fn
+
+
+class NodeUpdate(nn.Module):
+    """graphsage_nssc.py:6-30"""
+
+    def __init__(self, in_feats, out_feats, activation=None, concat=False):
+        super().__init__()
+        self.fc_neigh = nn.Linear(in_feats, out_feats)
+        self.fc_self = nn.Linear(in_feats, out_feats)
+        self.activation = activation
+        self.concat = concat
+        gain = nn.init.calculate_gain('relu')
+        nn.init.xavier_uniform_(self.fc_neigh.weight, gain=gain)
+        nn.init.xavier_uniform_(self.fc_self.weight, gain=gain)
+
+    def forward(self, node):
+        h = self.fc_self(node.data['h']) + self.fc_neigh(node.data['neigh'])
+        if self.concat:
+            h = torch.cat((h, self.activation(h)), dim=1)
+        elif self.activation:
+            h = self.activation(h)
+        return {'activation': h}
+
+
+_REDUCERS = {'mean': fn.mean, 'gcn': fn.sum}
+
+
+class GraphSageSampling(nn.Module):
+    def __init__(self, in_feats, n_hidden, n_classes, n_layers, activation=None, dropout=0.,
+                 aggregator_type='pool', preprocess=False):
+        super().__init__()
+        if aggregator_type not in _REDUCERS:
+            raise NotImplementedError(
+                f"aggregator '{aggregator_type}': only 'mean' and 'gcn' are on the MI355X hot path")
+        self.preprocess = preprocess
+        self.n_layers = n_layers
+        self.dropout = nn.Dropout(dropout)
+        self.activation = activation
+        self.aggregator_type = aggregator_type
+        self.layers = nn.ModuleList()
+        self.reducer = nn.ModuleList()  # kept for state_dict compatibility (lstm only in the reference)
+        if preprocess:
+            self.fc_self = nn.Linear(in_feats, n_hidden)
+            self.fc_neigh = nn.Linear(in_feats, n_hidden)
+        else:
+            self.layers.append(NodeUpdate(in_feats, n_hidden, activation, concat=(n_layers == 1)))
+        for i in range(1, n_layers):
+            self.layers.append(NodeUpdate(n_hidden, n_hidden, activation, concat=(i == n_layers - 1)))
+        self.layers.append(NodeUpdate(2 * n_hidden, n_classes))
+
+    def forward(self, nf):
+        L = nf.num_layers
+        if self.preprocess:
+            # graphsage_nssc.py:75-87: every layer carries 'features' and a pre-aggregated 'neigh'
+            for i in range(L):
+                d = nf.layers[i].data
+                h = self.dropout(d.pop('features'))
+                h = self.fc_self(h) + self.fc_neigh(d.pop('neigh'))
+                d['h'] = torch.cat((h, self.activation(h)), dim=1) if self.n_layers == 1 else self.activation(h)
+        else:
+            for i in range(L):
+                d = nf.layers[i].data
+                d['h'] = d.pop('features')
+        red = _REDUCERS[self.aggregator_type]
+        # graphsage_nssc.py:92-131: model layer `lid` is applied to every block i >= lid, so the
+        # self term of a destination always has the same depth as its neighbour term.
+        for lid, layer in enumerate(self.layers):
+            for i in range(lid, L - 1):
+                d = nf.layers[i].data
+                d['h'] = self.dropout(d.pop('h'))
+                nf.block_compute(i, fn.copy_src(src='h', out='m'), red('m', 'neigh'), layer)
+            for i in range(lid + 1, L):
+                d = nf.layers[i].data
+                d['h'] = d.pop('activation')
+        return nf.layers[L - 1].data.pop('h')

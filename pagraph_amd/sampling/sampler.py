@@ -1,0 +1,148 @@
+"""NeighborSampler — iterable with the call signature of
+dgl.contrib.sampling.NeighborSampler as used at examples/profile/pa_gcn.py:71-76,
+backed by the HIP frontier-expand sampler (pagraph_amd/csrc/pg_sample.hip).
+
+Semantics: the build-defined spec in DESIGN.md ("Sampler spec"); the reference
+never seeds DGL's sampler, so exact parity is defined against oracle/ only.
+One `for nf in sampler` pass = one epoch; batch b+1 is sampled on a side stream
+while the caller works on batch b (the role of DGL's prefetch=True thread).
+"""
+import ctypes
+
+import torch
+
+from .. import _lib as L
+from .nodeflow import NodeFlow
+
+
+class _Slot:
+    def __init__(self, lib, handle, hops, device):
+        cap_nodes = L.c_i64()
+        rows = (L.c_i64 * L.PG_MAX_LAYERS)()
+        edges = (L.c_i64 * L.PG_MAX_LAYERS)()
+        L.check(lib.pg_sampler_capacity(handle, ctypes.byref(cap_nodes), rows, edges), "pg_sampler_capacity")
+        self.cap_nodes = cap_nodes.value
+        self.node_mapping = torch.empty(self.cap_nodes, dtype=torch.int64, device=device)
+        self.layer_offsets = torch.empty(L.PG_MAX_LAYERS + 1, dtype=torch.int32, device=device)
+        self.ip_off, self.src_off = [], []
+        ip = sc = 0
+        for b in range(hops):
+            self.ip_off.append(ip)
+            self.src_off.append(sc)
+            ip += rows[b] + 1
+            sc += edges[b]
+        self.blk_indptr = torch.empty(ip, dtype=torch.int32, device=device)
+        self.blk_src = torch.empty(max(1, sc), dtype=torch.int32, device=device)
+        self.sizes = torch.zeros(2 * L.PG_MAX_LAYERS, dtype=torch.int32).pin_memory()
+        self.ready = torch.cuda.Event()
+        self.free = torch.cuda.Event()
+        self.free_recorded = False
+        d = L.PgNodeflowDesc()
+        d.node_mapping = self.node_mapping.data_ptr()
+        d.layer_offsets = self.layer_offsets.data_ptr()
+        d.blk_indptr = self.blk_indptr.data_ptr()
+        d.blk_src = self.blk_src.data_ptr()
+        d.sizes_pinned = self.sizes.data_ptr()
+        d.cap_nodes = self.cap_nodes
+        for b in range(hops):
+            d.blk_indptr_off[b] = self.ip_off[b]
+            d.blk_src_off[b] = self.src_off[b]
+        self.desc = d
+
+
+class NeighborSampler:
+    def __init__(self, g, batch_size, expand_factor, num_hops=1, neighbor_type='in', seed_nodes=None,
+                 shuffle=False, num_workers=1, prefetch=False, seed=0, copy_out=True):
+        if neighbor_type != 'in':
+            raise L.PgError("only neighbor_type='in' is on the hot path (pa_gcn.py:72)")
+        self.lib = L.load()
+        self.g = g
+        self.device = g.device
+        self.batch_size = int(batch_size)
+        self.fanout = int(expand_factor)
+        self.num_hops = int(num_hops)
+        self.seed = int(seed)
+        self.prefetch = bool(prefetch)
+        self.copy_out = copy_out
+        seeds = torch.as_tensor(seed_nodes if seed_nodes is not None else torch.arange(g.number_of_nodes()))
+        seeds = seeds.to(torch.int64)
+        if shuffle:
+            # spec rule (1): shuffled once per sampler construction, CPU torch RNG seeded by `seed`
+            gen = torch.Generator().manual_seed(self.seed)
+            seeds = seeds.cpu()[torch.randperm(seeds.numel(), generator=gen)]
+        self.seeds = seeds.to(self.device).contiguous()
+        self.num_batches = (self.seeds.numel() + self.batch_size - 1) // self.batch_size
+        self.epoch = 0
+        h = L.vp()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.pg_sampler_create(g.number_of_nodes(), L.ptr(g.indptr), L.ptr(g.indices), self.batch_size,
+                                               min(self.fanout, 2 ** 31 - 1), self.num_hops, ctypes.byref(h)),
+                    "pg_sampler_create")
+        self.handle = h
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.slots = [_Slot(self.lib, self.handle, self.num_hops, self.device) for _ in range(3)]
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.pg_sampler_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.num_batches
+
+    def _enqueue(self, b, epoch):
+        slot = self.slots[b % len(self.slots)]
+        lo = b * self.batch_size
+        n = min(self.batch_size, self.seeds.numel() - lo)
+        if slot.free_recorded:
+            self.stream.wait_event(slot.free)  # the consumer of the batch that used this slot is done
+        with torch.cuda.device(self.device):
+            L.check(self.lib.pg_sampler_sample(self.handle, ctypes.c_void_p(self.seeds.data_ptr() + lo * 8), n,
+                                               self.seed, epoch, b, ctypes.byref(slot.desc),
+                                               L.stream_ptr(self.stream)), "pg_sampler_sample")
+        slot.ready.record(self.stream)
+        return slot
+
+    def _finalize(self, slot):
+        slot.ready.synchronize()  # host needs the layer sizes (4 ints, written to pinned memory by k_pack)
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(slot.ready)
+        L_ = self.num_hops + 1
+        sizes = slot.sizes.tolist()
+        offs = [0]
+        for l in range(L_):
+            offs.append(offs[-1] + sizes[l])
+        nm = slot.node_mapping[:offs[-1]]
+        ips, srcs = [], []
+        for b in range(self.num_hops):
+            nd = sizes[b + 1]
+            ne = sizes[L.PG_MAX_LAYERS + b]
+            ips.append(slot.blk_indptr[slot.ip_off[b]:slot.ip_off[b] + nd + 1])
+            srcs.append(slot.blk_src[slot.src_off[b]:slot.src_off[b] + ne])
+        if self.copy_out:
+            # detach from the ring so a NodeFlow stays valid after the iterator moves on
+            nm = nm.clone()
+            ips = [t.clone() for t in ips]
+            srcs = [t.clone() for t in srcs]
+        return NodeFlow(nm, offs, ips, srcs)
+
+    def __iter__(self):
+        epoch = self.epoch
+        self.epoch += 1
+        nb = self.num_batches
+        if nb == 0:
+            return
+        pending = self._enqueue(0, epoch)
+        for b in range(nb):
+            slot = pending
+            if b + 1 < nb and self.prefetch:
+                pending = self._enqueue(b + 1, epoch)
+            nf = self._finalize(slot)
+            yield nf
+            slot.free.record(torch.cuda.current_stream(self.device))
+            slot.free_recorded = True
+            if b + 1 < nb and not self.prefetch:
+                pending = self._enqueue(b + 1, epoch)

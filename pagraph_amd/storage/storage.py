@@ -1,0 +1,314 @@
+"""GraphCacheServer — MI355X-native counterpart of PaGraph/storage/storage.py:18-227.
+
+Same constructor, attributes and methods as the reference class so that
+examples/profile/pa_gcn.py drops in; underneath, the per-layer torch index ops
+and boolean-mask compactions are one HIP gather launch (pagraph_amd/csrc/
+pg_gather.hip) and the miss path is a pinned-host staging buffer + async H2D +
+row-scatter kernel (or a zero-copy device read of the pinned host table).
+
+HBM layout
+  nid_map      int64 [V_sub]   local -> full id                  (storage.py:34)
+  slot_map     int32 [V_sub]   cache slot or -1; fuses gpu_flag (storage.py:38)
+                               and localid2cacheid (storage.py:50)
+  gpu_fix_cache[name] fp32 [cached_num, dim] row-major, row = slot (storage.py:151)
+"""
+import ctypes
+
+import torch
+
+from .. import _lib as L
+
+
+class _Col:
+    def __init__(self, data):
+        self.data = data
+
+
+class _NodeFrame:
+    def __init__(self, cols):
+        self._frame = cols
+
+
+class HostFeatureStore:
+    """In-process stand-in for the DGL shared-memory graph store the reference
+    attaches to (server/pa_server.py:33-54, examples/profile/pa_gcn.py:33): a
+    name -> host tensor table.  Tables are pinned when possible so the miss path
+    can DMA / zero-copy from them.  `_node_frame._frame[name].data` is the
+    attribute path the reference reads (storage.py:128)."""
+
+    def __init__(self, fields, pin=True):
+        cols = {}
+        self.pinned = {}
+        for name, t in fields.items():
+            t = torch.as_tensor(t)
+            if t.dim() == 1:
+                t = t.unsqueeze(1)
+            t = t.to(torch.float32).contiguous()
+            if pin and torch.cuda.is_available() and not t.is_pinned():
+                try:
+                    t = t.pin_memory()
+                except RuntimeError:
+                    pass  # too large to pin: staged miss path still works from pageable memory
+            self.pinned[name] = t.is_pinned()
+            cols[name] = _Col(t)
+        self._node_frame = _NodeFrame(cols)
+
+    @property
+    def ndata(self):
+        return {k: c.data for k, c in self._node_frame._frame.items()}
+
+
+def _table(graph, name):
+    return graph._node_frame._frame[name].data
+
+
+class GraphCacheServer:
+    """Manage graph features: static top-out-degree HBM cache + hit/miss gather."""
+
+    def __init__(self, graph, node_num, nid_map, gpuid, miss_mode="staged", host_threads=8):
+        self.lib = L.load()  # fails loudly when the HIP library is missing
+        self.graph = graph
+        self.gpuid = gpuid
+        self.node_num = int(node_num)
+        self.device = torch.device("cuda", gpuid)
+        self.nid_map = torch.as_tensor(nid_map).clone().detach().to(self.device, torch.int64)
+        self.slot_map = torch.empty(self.node_num, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.pg_slot_map_reset(L.ptr(self.slot_map), self.node_num, L.stream_ptr()), "pg_slot_map_reset")
+
+        self.cached_num = 0
+        self.capability = self.node_num
+        self.full_cached = False
+        self.dims = {}
+        self.total_dim = 0
+        self.gpu_fix_cache = dict()
+
+        self.log = False
+        self.try_num = 0
+        self.miss_num = 0
+
+        # miss path state
+        assert miss_mode in ("staged", "zerocopy")
+        self.miss_mode = miss_mode
+        self.host_threads = host_threads
+        self._cap = 0
+        self._miss_pos = None            # device int32 [cap]
+        self._miss_fullid = None         # pinned int64 [cap]
+        self._miss_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._miss_count_h = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._staging = {}               # name -> pinned fp32 [cap, dim]
+        self._staged_dev = {}            # name -> device fp32 [cap, dim]
+        self._event = torch.cuda.Event()
+        self._pending_counts = []        # zero-copy mode: (pinned count tensor, event, rows)
+
+    # -- reference-shaped views of the fused slot map --------------------------
+    def _export(self):
+        flag = torch.empty(self.node_num, dtype=torch.uint8, device=self.device)
+        l2c = torch.empty(self.node_num, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.pg_slot_map_export(L.ptr(self.slot_map), self.node_num, L.ptr(flag), L.ptr(l2c),
+                                                L.stream_ptr()), "pg_slot_map_export")
+        return flag.bool(), l2c
+
+    @property
+    def gpu_flag(self):
+        return self._export()[0]
+
+    @property
+    def localid2cacheid(self):
+        return self._export()[1]
+
+    # -- storage.py:59-67 -----------------------------------------------------
+    def init_field(self, embed_names):
+        nid = torch.zeros(1, dtype=torch.int64, device=self.device)
+        feats = self.get_feat_from_server(nid, embed_names)
+        self.total_dim = 0
+        for name in embed_names:
+            self.dims[name] = feats[name].size(1)
+            self.total_dim += feats[name].size(1)
+        if len(self.dims) > L.PG_MAX_FIELDS:
+            raise L.PgError(f"at most {L.PG_MAX_FIELDS} feature fields")
+        print('total dims: {}'.format(self.total_dim))
+
+    # -- storage.py:70-104 ----------------------------------------------------
+    def auto_cache(self, dgl_g, embed_names, cache_ratio=None):
+        """Reference rule: capability = (total - peak_alloc - peak_reserved - 1 GiB) / (4*total_dim).
+        `cache_ratio` (fraction of node_num) overrides it — the reference keeps such overrides
+        commented out at storage.py:85-86; on a 288 GB MI355X the rule alone caches everything."""
+        peak_allocated_mem = torch.cuda.max_memory_allocated(device=self.device)
+        peak_cached_mem = torch.cuda.max_memory_reserved(device=self.device)
+        total_mem = torch.cuda.get_device_properties(self.device).total_memory
+        available = total_mem - peak_allocated_mem - peak_cached_mem - 1024 * 1024 * 1024
+        self.capability = int(available / (self.total_dim * 4))
+        if cache_ratio is not None:
+            self.capability = min(self.capability, int(self.node_num * cache_ratio))
+        print('Cache Memory: {:.2f}G. Capability: {}'.format(available / 1024 / 1024 / 1024, self.capability))
+        if self.capability >= self.node_num:
+            print('cache the full graph...')
+            full_nids = torch.arange(self.node_num, device=self.device)
+            self._fill_cache(full_nids, embed_names, is_full=True)
+        else:
+            print('cache the part of graph... caching percentage: {:.4f}'.format(self.capability / self.node_num))
+            out_degrees = torch.as_tensor(dgl_g.out_degrees()).to(self.device)
+            # descending by out-degree; ties -> lower id first (the reference's torch.argsort is unstable)
+            sort_nid = torch.argsort(out_degrees, descending=True, stable=True)
+            cache_nid = sort_nid[:self.capability]
+            self._fill_cache(cache_nid, embed_names, is_full=False)
+
+    def _fill_cache(self, nids, embed_names, is_full, chunk_rows=1 << 20):
+        """get_feat_from_server + cache_fix_data (storage.py:94-95,103-104) in bounded chunks."""
+        rows = nids.numel()
+        data = {name: torch.empty((rows, self.dims[name]), dtype=torch.float32, device=self.device)
+                for name in embed_names}
+        for lo in range(0, rows, chunk_rows):
+            hi = min(rows, lo + chunk_rows)
+            part = self.get_feat_from_server(nids[lo:hi], embed_names, to_gpu=True)
+            for name in embed_names:
+                data[name][lo:hi] = part[name]
+        self.cache_fix_data(nids, data, is_full=is_full)
+
+    # -- storage.py:107-132 ---------------------------------------------------
+    def get_feat_from_server(self, nids, embed_names, to_gpu=False):
+        """rows of `nids` (local ids, on the GPU) from the host store: full = nid_map[nids];
+        table[full] gathered by the library's host threads into pinned memory."""
+        nids_in_full = self.nid_map[nids].cpu()
+        n = nids_in_full.numel()
+        frame = {}
+        for name in embed_names:
+            tab = _table(self.graph, name)
+            dim = tab.size(1)
+            staged = torch.empty((n, dim), dtype=torch.float32, pin_memory=bool(to_gpu))
+            L.check(self.lib.pg_host_gather_rows(L.ptr(tab), tab.stride(0), dim, L.ptr(nids_in_full), n,
+                                                 L.ptr(staged), self.host_threads), "pg_host_gather_rows")
+            frame[name] = staged.to(self.device, non_blocking=True) if to_gpu else staged
+        if to_gpu:
+            torch.cuda.current_stream(self.device).synchronize()  # staged buffers die with this scope
+        return frame
+
+    # -- storage.py:135-154 ---------------------------------------------------
+    def cache_fix_data(self, nids, data, is_full=False):
+        rows = nids.size(0)
+        nids = nids.to(self.device, torch.int64).contiguous()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.pg_slot_map_assign(L.ptr(self.slot_map), L.ptr(nids), rows, L.stream_ptr()),
+                    "pg_slot_map_assign")
+        self.cached_num = rows
+        for name in data:
+            data_rows = data[name].size(0)
+            assert (rows == data_rows)
+            self.dims[name] = data[name].size(1)
+            self.gpu_fix_cache[name] = data[name].to(self.device, torch.float32).contiguous()
+        self.full_cached = is_full
+
+    # -- buffers for the miss path --------------------------------------------
+    def _ensure_capacity(self, n):
+        if n <= self._cap:
+            return
+        cap = max(n, int(self._cap * 1.5), 1024)
+        self._miss_pos = torch.empty(cap, dtype=torch.int32, device=self.device)
+        self._miss_fullid = torch.empty(cap, dtype=torch.int64).pin_memory()
+        if self.miss_mode == "staged":
+            for name, dim in self.dims.items():
+                self._staging[name] = torch.empty((cap, dim), dtype=torch.float32).pin_memory()
+                self._staged_dev[name] = torch.empty((cap, dim), dtype=torch.float32, device=self.device)
+        self._cap = cap
+
+    # -- storage.py:157-204 ---------------------------------------------------
+    def fetch_data(self, nodeflow):
+        """Fill nodeflow._node_frames[i][name] for every layer and field: hits from the HBM
+        cache, misses from the host store. One gather launch for all layers; rows of layer i are
+        the slice [offsets[i], offsets[i+1]) of one [R, dim] buffer per field."""
+        if self.full_cached:
+            self.fetch_from_cache(nodeflow)
+            return
+        with torch.autograd.profiler.record_function('cache-idxload'):
+            nf_nids = nodeflow._node_mapping.tousertensor().to(self.device, torch.int64)
+            offsets = nodeflow._layer_offsets
+        R = nf_nids.numel()
+        names = list(self.dims)
+        stream = torch.cuda.current_stream(self.device)
+        sp = L.stream_ptr(stream)
+        with torch.autograd.profiler.record_function('cache-allocate'):
+            out = {name: torch.empty((R, self.dims[name]), dtype=torch.float32, device=self.device) for name in names}
+            self._ensure_capacity(R)
+        with torch.autograd.profiler.record_function('cache-gpu'):
+            fields, nf = L.make_fields(
+                (self.gpu_fix_cache.get(name), out[name], self.dims[name],
+                 self.gpu_fix_cache[name].stride(0) if name in self.gpu_fix_cache else self.dims[name],
+                 out[name].stride(0)) for name in names)
+            L.check(self.lib.pg_gather_rows(L.ptr(nf_nids), R, L.ptr(self.slot_map), L.ptr(self.nid_map), fields, nf,
+                                            L.ptr(self._miss_pos), L.ptr(self._miss_fullid), L.ptr(self._miss_count),
+                                            sp), "pg_gather_rows")
+        with torch.autograd.profiler.record_function('cache-cpu'):
+            if self.miss_mode == "zerocopy":
+                for name in names:
+                    tab = _table(self.graph, name)
+                    L.check(self.lib.pg_scatter_rows_from_host(
+                        L.ptr(tab), tab.stride(0), L.ptr(self._miss_pos), L.ptr(self._miss_fullid), R,
+                        L.ptr(self._miss_count), self.dims[name], L.ptr(out[name]), out[name].stride(0), sp),
+                        "pg_scatter_rows_from_host")
+                if self.log:
+                    cnt = torch.empty(1, dtype=torch.int32).pin_memory()
+                    cnt.copy_(self._miss_count, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                    self._pending_counts.append((cnt, ev, R))
+            else:
+                self._miss_count_h.copy_(self._miss_count, non_blocking=True)
+                self._event.record(stream)
+                self._event.synchronize()          # host needs the miss list: only this stream is waited on
+                m = int(self._miss_count_h[0])
+                if m > 0:
+                    full = self._miss_fullid
+                    for name in names:
+                        tab = _table(self.graph, name)
+                        dim = self.dims[name]
+                        stg = self._staging[name]
+                        L.check(self.lib.pg_host_gather_rows(L.ptr(tab), tab.stride(0), dim, L.ptr(full), m,
+                                                             L.ptr(stg), self.host_threads), "pg_host_gather_rows")
+                        dev = self._staged_dev[name]
+                        dev[:m].copy_(stg[:m], non_blocking=True)       # pinned -> HBM, hipMemcpyAsync
+                        L.check(self.lib.pg_scatter_rows(L.ptr(dev), L.ptr(self._miss_pos), m, None, dim,
+                                                         L.ptr(out[name]), out[name].stride(0), sp), "pg_scatter_rows")
+                    # the pinned staging buffers are reused next step: the copy must have left them
+                    self._event.record(stream)
+                    self._event.synchronize()
+                if self.log:
+                    self.log_miss_rate(m, R)
+        with torch.autograd.profiler.record_function('cache-asign'):
+            for i in range(nodeflow.num_layers):
+                nodeflow._node_frames[i] = {name: out[name][offsets[i]:offsets[i + 1]] for name in names}
+
+    # -- storage.py:207-216 ---------------------------------------------------
+    def fetch_from_cache(self, nodeflow):
+        with torch.autograd.profiler.record_function('cache-idxload'):
+            nf_nids = nodeflow._node_mapping.tousertensor().to(self.device, torch.int64)
+            offsets = nodeflow._layer_offsets
+        R = nf_nids.numel()
+        names = list(self.gpu_fix_cache)
+        with torch.autograd.profiler.record_function('cache-gpu'):
+            out = {name: torch.empty((R, self.dims[name]), dtype=torch.float32, device=self.device) for name in names}
+            fields, nf = L.make_fields((self.gpu_fix_cache[name], out[name], self.dims[name],
+                                        self.gpu_fix_cache[name].stride(0), out[name].stride(0)) for name in names)
+            L.check(self.lib.pg_gather_rows_full(L.ptr(nf_nids), R, fields, nf,
+                                                 L.stream_ptr(torch.cuda.current_stream(self.device))),
+                    "pg_gather_rows_full")
+        for i in range(nodeflow.num_layers):
+            nodeflow._node_frames[i] = {name: out[name][offsets[i]:offsets[i + 1]] for name in names}
+        if self.log:
+            self.log_miss_rate(0, R)
+
+    # -- storage.py:219-227 ---------------------------------------------------
+    def log_miss_rate(self, miss_num, total_num):
+        self.try_num += total_num
+        self.miss_num += miss_num
+
+    def get_miss_rate(self):
+        for cnt, ev, rows in self._pending_counts:
+            ev.synchronize()
+            self.log_miss_rate(int(cnt[0]), rows)
+        self._pending_counts = []
+        miss_rate = float(self.miss_num) / self.try_num
+        self.miss_num = 0
+        self.try_num = 0
+        return miss_rate
