@@ -1,0 +1,400 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline measurement on MI355X: epoch time of the
+PaGraph minibatch training loop (examples/profile/pa_gcn.py:82-106), cache-hit % and
+feature-gather GB/s, on the synthetic RMAT 10M-vertex / 100M-edge graph, feat = 600,
+30 % hot-degree cache (BASELINE.json configs[2]; model selectable, default GCN as in
+BASELINE.json's `metric`).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU.  N = 1: the whole train set on one GPU ("1naive": closure of
+every train vertex, hash.py with --partition 1).  N > 1: rank 0 runs dg (C++), every
+rank builds the closure of its own partition, gradients all-reduced by DDP/RCCL; the
+graph is fixed, so scaling is strong.  A "step" = one minibatch: sample -> fetch_data
+(gather + miss path) -> forward/backward/Adam.  Inputs (graph, cache, host table) are
+resident before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=None, help="timed steps (default: 200)")
+    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--model", default="gcn", choices=["gcn", "graphsage"])
+    p.add_argument("--vertices", type=int, default=10_000_000)
+    p.add_argument("--edges", type=int, default=100_000_000)
+    p.add_argument("--feat-size", type=int, default=600)
+    p.add_argument("--n-classes", type=int, default=60)
+    p.add_argument("--batch-size", type=int, default=6000)
+    p.add_argument("--num-neighbors", type=int, default=2)
+    p.add_argument("--cache-ratio", type=float, default=0.30)
+    p.add_argument("--miss-mode", default="staged", choices=["staged", "zerocopy"])
+    p.add_argument("--host-threads", type=int, default=32)
+    p.add_argument("--no-overlap", action="store_true")
+    p.add_argument("--skip-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    p.add_argument("--skip-microbench", action="store_true")
+    p.add_argument("--dg-hops", type=int, default=2)
+    return p.parse_args()
+
+
+# ----------------------------------------------------------------------------- host feature table
+def make_host_table(V, Fdim, rank, local_rank, world, dev, tag):
+    """the 'graph store': ONE host copy of the [V, F] table per node, like the reference's
+    shared-memory store (pa_server.py:33-54). world>1: /dev/shm file mapped by every rank."""
+    from pagraph_amd.data import synthetic as syn
+    if world == 1:
+        t0 = time.time()
+        tab = torch.empty((V, Fdim), dtype=torch.float32, pin_memory=True)
+        syn.fill_random_features(tab, device=dev)
+        log(f"[bench] host table {V}x{Fdim} pinned + filled in {time.time()-t0:.1f}s")
+        return tab, None
+    path = f"/dev/shm/pagraph_bench_{os.environ.get('MASTER_PORT', '0')}_{tag}.bin"
+    if local_rank == 0:
+        tab = torch.from_file(path, shared=True, size=V * Fdim, dtype=torch.float32).view(V, Fdim)
+        syn.fill_random_features(tab, device=dev)
+    dist.barrier()
+    if local_rank != 0:
+        tab = torch.from_file(path, shared=True, size=V * Fdim, dtype=torch.float32).view(V, Fdim)
+    try:
+        rc = torch.cuda.cudart().cudaHostRegister(tab.data_ptr(), tab.numel() * 4, 0)
+        log(f"[bench] rank {rank}: hipHostRegister rc={rc}")
+    except Exception as e:  # staged mode works from unpinned memory too
+        log(f"[bench] rank {rank}: host register unavailable ({e})")
+    return tab, path
+
+
+# ----------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(args, g, sub2full_h, seeds_h, feat_tab, norm_tab, labels_dense_h, steps_per_epoch, budget_s):
+    """The reference's CPU path restated, timed on this box's host cores on a
+    bounded sample of the same workload: C/OpenMP sampler (oracle) + torch CPU `table[nid_map[ids]]`
+    for every NodeFlow row and field (dgl_gcn.py:83 / storage.py:117-131) + H2D + torch-CPU model
+    forward/backward/Adam.  16 threads = the reference's sampler num_workers (pa_gcn.py:148)."""
+    from oracle import oracle
+    threads = 16
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(threads)
+    except OSError:
+        pass
+    torch.set_num_threads(threads)
+    indptr_h = g.indptr.cpu().numpy()
+    indices_h = g.indices.cpu().numpy()
+    k, hops, B = args.num_neighbors, 2, args.batch_size
+    Fdim, C = args.feat_size, args.n_classes
+    hid = 32 if args.model == "gcn" else 16
+    torch.manual_seed(0)
+    if args.model == "gcn":
+        lins = [torch.nn.Linear(Fdim, hid), torch.nn.Linear(2 * hid, C)]
+    else:
+        lins = [torch.nn.Linear(Fdim, hid), torch.nn.Linear(Fdim, hid), torch.nn.Linear(2 * hid, C),
+                torch.nn.Linear(2 * hid, C)]
+    params = [p for l in lins for p in l.parameters()]
+    opt = torch.optim.Adam(params, lr=3e-2)
+    nid_map = torch.from_numpy(sub2full_h)
+
+    def mean_agg(ip, src, h, nd):
+        deg = (ip[1:] - ip[:-1]).clamp(min=1).unsqueeze(1).float()
+        dst = torch.repeat_interleave(torch.arange(nd), (ip[1:] - ip[:-1]).long())
+        out = torch.zeros((nd, h.size(1))).index_add_(0, dst, h[src.long()])
+        return out / deg
+
+    t_s = t_l = t_m = 0.0
+    done = 0
+    t_begin = time.time()
+    while done < 64 and (time.time() - t_begin) < budget_s:
+        t0 = time.time()
+        nf = oracle.sample_nodeflow(indptr_h, indices_h, seeds_h[done * B:(done + 1) * B], k, hops, 0, 0, done)
+        t1 = time.time()
+        ids = torch.from_numpy(nf["node_mapping"])
+        full = nid_map[ids]
+        feats = feat_tab[full]                       # the reference's CPU fancy-index (storage.py:128)
+        norm = norm_tab[full]
+        if torch.cuda.is_available():
+            feats_d = feats.cuda(non_blocking=True); norm_d = norm.cuda(non_blocking=True)
+            torch.cuda.synchronize()
+            del feats_d, norm_d
+        t2 = time.time()
+        o = nf["layer_offsets"]
+        blocks = [(torch.from_numpy(ip.astype(np.int64)), torch.from_numpy(sr)) for ip, sr in nf["blocks"]]
+        h = feats[o[0]:o[1]]
+        if args.model == "gcn":
+            z = lins[0](mean_agg(*blocks[0], h, o[2] - o[1]))
+            h1 = torch.cat([z, F.relu(z)], 1)
+            pred = lins[1](mean_agg(*blocks[1], h1, o[3] - o[2]))
+        else:
+            f1, f2 = feats[o[1]:o[2]], feats[o[2]:o[3]]
+            z1 = lins[0](f1) + lins[1](mean_agg(*blocks[0], h, o[2] - o[1])); a1 = torch.cat([z1, F.relu(z1)], 1)
+            z2 = lins[0](f2) + lins[1](mean_agg(*blocks[1], f1, o[3] - o[2])); a2 = torch.cat([z2, F.relu(z2)], 1)
+            pred = lins[2](a2) + lins[3](mean_agg(*blocks[1], a1, o[3] - o[2]))
+        y = labels_dense_h[ids[o[2]:o[3]]]
+        loss = F.cross_entropy(pred, y)
+        opt.zero_grad(); loss.backward(); opt.step()
+        t3 = time.time()
+        t_s += t1 - t0; t_l += t2 - t1; t_m += t3 - t2
+        done += 1
+    per_step = (t_s + t_l + t_m) / max(1, done)
+    return {"value": per_step * steps_per_epoch, "unit": "s/epoch (extrapolated)", "cores": threads, "kind": "port",
+            "sample": f"{done} minibatches of the same workload (B={B}, fanout={k}); per step: "
+                      f"sample {t_s/done*1e3:.1f} ms + feature load+H2D {t_l/done*1e3:.1f} ms + model {t_m/done*1e3:.1f} ms",
+            "ms_per_step": per_step * 1e3}
+
+
+# ----------------------------------------------------------------------------- gather micro-benchmark
+def gather_microbench(cacher, g, dev, rows_list=(42000, 1 << 20)):
+    """cached-feature gather (all hits) at the real step shape and at >= 1M rows; ids drawn
+    degree-proportionally from the cached set (seed 0). HIP events on the launch stream."""
+    from pagraph_amd import _lib as L
+    lib = L.load()
+    names = list(cacher.dims)
+    D = sum(cacher.dims.values())
+    cached_ids = torch.nonzero(cacher.slot_map >= 0).squeeze(1)
+    w = g.out_degrees()[cached_ids].float() + 1.0
+    gen = torch.Generator(device=dev).manual_seed(0)
+    res = {}
+    stream = torch.cuda.current_stream(dev)
+    sp = L.stream_ptr(stream)
+    for R in rows_list:
+        ids = cached_ids[torch.multinomial(w, R, replacement=True, generator=gen)].contiguous()
+        out = {n: torch.empty((R, cacher.dims[n]), dtype=torch.float32, device=dev) for n in names}
+        mpos = torch.empty(R, dtype=torch.int32, device=dev)
+        mfull = torch.empty(R, dtype=torch.int64, device=dev)
+        mcnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        fields, nf = L.make_fields((cacher.gpu_fix_cache[n], out[n], cacher.dims[n], cacher.gpu_fix_cache[n].stride(0),
+                                    out[n].stride(0)) for n in names)
+        call = lambda: L.check(lib.pg_gather_rows(L.ptr(ids), R, L.ptr(cacher.slot_map), L.ptr(cacher.nid_map), fields,
+                                                  nf, L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt), sp))
+        for _ in range(3):
+            call()
+        reps = 20
+        timers = []
+        for _ in range(reps):
+            t = L.vp(); L.check(lib.pg_timer_create(ctypes.byref(t)))
+            L.check(lib.pg_timer_start(t, sp)); call(); L.check(lib.pg_timer_stop(t, sp))
+            timers.append(t)
+        ms = []
+        for t in timers:
+            v = ctypes.c_float(); L.check(lib.pg_timer_elapsed_ms(t, ctypes.byref(v))); ms.append(v.value)
+            lib.pg_timer_destroy(t)
+        assert int(mcnt.item()) == 0
+        avg = float(np.mean(ms))
+        bytes_ = R * (8 * D + 17)
+        res[R] = {"rows": R, "avg_ms": avg, "GBps": bytes_ / avg / 1e6, "frac": bytes_ / avg / 1e6 / HBM_PEAK_GBPS}
+        del out
+    return res
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: pagraph_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from pagraph_amd import _lib as L
+    from pagraph_amd import parallel
+    from pagraph_amd.data import synthetic as syn
+    from pagraph_amd.model import GCNSampling, GraphSageSampling
+    from pagraph_amd.partition.dg import dg_raw
+    from pagraph_amd.partition.utils import closure_device
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    from pagraph_amd.trainer import MinibatchTrainer, cycle_batches
+    L.load()
+
+    V, E, Fdim, C, B, k = args.vertices, args.edges, args.feat_size, args.n_classes, args.batch_size, args.num_neighbors
+    n_layers = 1
+    num_hops = n_layers + 1                                   # pa_gcn.py:52
+    hidden = 32 if args.model == "gcn" else 16                # pa_gcn.py:130 / pa_gs.py:134
+    lr = 3e-2 if args.model == "gcn" else 1e-2                # pa_gcn.py:137 / pa_gs.py:141
+
+    # ---- dataset (preprocess.py recipe, seeded) ------------------------------------------
+    t0 = time.time()
+    indptr, indices = syn.rmat_graph(V, E, device=dev)
+    torch.cuda.synchronize()
+    log(f"[bench] rank {rank}: RMAT V={V} nnz={indices.numel()} in {time.time()-t0:.1f}s")
+    train_mask, _, _ = syn.split_dataset(V)
+    labels_full = syn.random_labels(V, C)
+    train_full = torch.nonzero(train_mask).squeeze(1)
+    g_full = DeviceGraph.from_csc(indptr, indices, V)
+    in_deg = (indptr[1:] - indptr[:-1]).float()
+
+    # ---- partition ------------------------------------------------------------------------
+    t0 = time.time()
+    if world == 1:
+        my_train = train_full
+    else:
+        belongs = torch.empty(V, dtype=torch.int8)
+        if rank == 0:
+            b, _, p_vnum, r_vnum = dg_raw(world, indptr.cpu().numpy(), indices.cpu().numpy(), V, train_full.numpy(),
+                                          args.dg_hops)
+            belongs = torch.from_numpy(b)
+            log(f"[bench] dg P={world} hops={args.dg_hops}: {time.time()-t0:.1f}s p_vnum={p_vnum.tolist()} r_vnum={r_vnum.tolist()}")
+        belongs = belongs.to(dev)
+        parallel.broadcast_tensor(belongs, src=0)
+        my_train = torch.nonzero(belongs == rank).squeeze(1).cpu()
+    sub_indptr, sub_indices, sub2full, subtrain = closure_device(g_full, my_train, num_hops)
+    Vs = sub2full.numel()
+    del g_full, indptr, indices
+    torch.cuda.empty_cache()
+    g = DeviceGraph.from_csc(sub_indptr, sub_indices, Vs)
+    log(f"[bench] rank {rank}: closure V_sub={Vs} nnz_sub={sub_indices.numel()} train={subtrain.numel()} in {time.time()-t0:.1f}s")
+    # labels in local-id space (pa_gcn.py:38-41)
+    labels = torch.zeros(int(subtrain.max().item()) + 1, dtype=torch.int64, device=dev)
+    labels[subtrain] = labels_full.to(dev)[sub2full[subtrain]]
+
+    # ---- feature provider (pa_server.py:38-54) --------------------------------------------
+    feat_tab, shm_path = make_host_table(V, Fdim, rank, local_rank, world, dev, "feat")
+    fields = {"features": feat_tab}
+    embed_names = ["features"]
+    norm_tab = None
+    if args.model == "gcn":
+        norm_tab = (1.0 / in_deg).unsqueeze(1).cpu()          # pa_server.py:43 (inf for isolated vertices, as there)
+        fields["norm"] = norm_tab
+        embed_names = ["features", "norm"]                    # pa_gcn.py:46
+    store = HostFeatureStore(fields, pin=(world == 1))
+    cacher = GraphCacheServer(store, Vs, sub2full, local_rank, miss_mode=args.miss_mode, host_threads=args.host_threads)
+    cacher.init_field(embed_names)
+    cacher.log = True
+    D = cacher.total_dim
+
+    # ---- model ------------------------------------------------------------------------------
+    torch.manual_seed(rank)
+    if args.model == "gcn":
+        model = GCNSampling(Fdim, hidden, C, n_layers, F.relu, 0.2, False)
+    else:
+        model = GraphSageSampling(Fdim, hidden, C, n_layers, F.relu, 0.2, 'mean', False)
+    model = model.to(dev)
+    loss_fcn = torch.nn.CrossEntropyLoss()
+    optimizer = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=0)
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
+    sampler = NeighborSampler(g, B, k, neighbor_type='in', shuffle=True, num_workers=16, num_hops=num_hops,
+                              seed_nodes=subtrain, prefetch=True, seed=rank, copy_out=True)
+    steps_per_epoch = parallel.equalize_steps(len(sampler), device=dev)
+    K = args.steps if args.steps is not None else 200
+    W = args.warmup
+    trainer = MinibatchTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, overlap=not args.no_overlap)
+    trainer.after_first_step = lambda: cacher.auto_cache(g, embed_names, cache_ratio=args.cache_ratio)  # pa_gcn.py:99-100
+    model.train()
+    it = cycle_batches(sampler, W + K + 1)
+
+    # ---- warmup (untimed; the cache is filled after its first step, as in the reference) ----
+    t0 = time.time()
+    if W > 0:
+        trainer.run_steps(it, W)
+    if cacher.cached_num == 0:
+        cacher.auto_cache(g, embed_names, cache_ratio=args.cache_ratio)
+    torch.cuda.synchronize()
+    log(f"[bench] rank {rank}: warmup {W} steps + cache fill ({cacher.cached_num} rows) in {time.time()-t0:.1f}s")
+    if cacher.try_num:
+        cacher.get_miss_rate()                                 # reset counters
+
+    # ---- timed region ------------------------------------------------------------------------
+    cacher.profile = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    done = trainer.run_steps(it, K)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.time() - t0
+    assert done == K, (done, K)
+    elapsed = parallel.max_over_ranks(elapsed, device=dev)
+    prof, cacher.profile = cacher.profile, None
+    miss_rate = cacher.get_miss_rate()
+    ms_per_step = elapsed * 1e3 / K
+    epoch_s = ms_per_step * steps_per_epoch / 1e3
+
+    # ---- in-loop gather kernel time (HIP events on the load stream) ---------------------------
+    g_ms, g_bytes, g_rows = [], [], []
+    lib = L.load()
+    for timer, R, m in prof:
+        v = ctypes.c_float()
+        L.check(lib.pg_timer_elapsed_ms(timer, ctypes.byref(v)))
+        lib.pg_timer_destroy(timer)
+        m = 0 if m is None else m
+        g_ms.append(v.value)
+        g_rows.append(R)
+        g_bytes.append((R - m) * 8 * D + R * 17 + m * 12)      # algorithmic bytes of one launch
+    avg_ms = float(np.mean(g_ms)) if g_ms else float("nan")
+    achieved = float(np.mean(g_bytes)) / avg_ms / 1e6 if g_ms else float("nan")
+    roofline = {"kernel": "k_gather", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "avg_launch_ms": avg_ms,
+                "rows_per_launch": float(np.mean(g_rows)) if g_rows else 0.0,
+                "algorithmic_bytes_per_launch": float(np.mean(g_bytes)) if g_bytes else 0.0}
+
+    micro = None
+    if not args.skip_microbench and rank == 0 and cacher.cached_num > 0 and not cacher.full_cached:
+        micro = gather_microbench(cacher, g, dev)
+        roofline["large"] = micro[max(micro)]
+        roofline["step_shape_all_hits"] = micro[min(micro)]
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.skip_cpu_baseline:
+        labels_h = labels.cpu()
+        cpu = cpu_baseline(args, g, sub2full.cpu().numpy(), sampler.seeds.cpu().numpy(), feat_tab,
+                           norm_tab if norm_tab is not None else torch.zeros((V, 1)), labels_h, steps_per_epoch,
+                           args.cpu_baseline_seconds)
+
+    seeds_total = parallel.sum_over_ranks(min(K * B, K * B), device=dev)
+    if rank == 0:
+        out = {
+            "metric": "epoch_time_s", "value": epoch_s, "unit": "s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"RMAT {V} vertices / {E} undirected edges (nnz {2*E}), feat={Fdim}, "
+                                   f"2-layer {'GCN' if args.model == 'gcn' else 'GraphSAGE-mean'} hidden {hidden}, "
+                                   f"batch {B}, fan-out {k}, {int(args.cache_ratio*100)}% hot-degree cache, "
+                                   f"{'dg' if world > 1 else '1naive'} partition x{world}",
+                       "steps_per_epoch": steps_per_epoch, "epoch_time_extrapolated_from_steps": K,
+                       "miss_mode": args.miss_mode, "overlap": not args.no_overlap, "partition_vertices": Vs},
+            "cache_hit_pct": 100.0 * (1.0 - miss_rate),
+            "feat_gather_GBps": (micro[max(micro)]["GBps"] if micro else achieved),
+            "seeds_per_s": seeds_total / elapsed,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        if shm_path and local_rank == 0:
+            try:
+                os.unlink(shm_path)
+            except OSError:
+                pass
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

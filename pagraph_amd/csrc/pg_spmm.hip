@@ -127,8 +127,7 @@ int pg_spmm_fwd(const int32_t* indptr, const int32_t* src, const float* h, int32
   if (n_dst < 0 || dim <= 0 || h_stride < dim || out_stride < dim) return PG_ERR_INVALID;
   if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return PG_ERR_INVALID;
   if (n_dst == 0) return PG_OK;
-  if (!indptr || !out) return PG_ERR_INVALID;
-  if (!src || !h) return PG_ERR_INVALID;
+  if (!indptr || !out) return PG_ERR_INVALID;  // src / h may be NULL only for an edgeless block
   hipStream_t st = as_stream(stream);
   int vec = 1;
   if (dim % 4 == 0 && h_stride % 4 == 0 && out_stride % 4 == 0 && al(h, 16) && al(out, 16)) vec = 4;
@@ -152,7 +151,7 @@ int pg_spmm_bwd(const int32_t* indptr, const int32_t* src, const float* grad_out
   if (n_dst < 0 || dim <= 0 || go_stride < dim || gh_stride < dim) return PG_ERR_INVALID;
   if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return PG_ERR_INVALID;
   if (n_dst == 0) return PG_OK;
-  if (!indptr || !src || !grad_out || !grad_h) return PG_ERR_INVALID;
+  if (!indptr || !grad_out) return PG_ERR_INVALID;  // src / grad_h may be NULL only for an edgeless block
   int l2 = log2_ceil_pow2(dim < 64 ? dim : 64);
   const int rows_per_block = 4 * (64 >> l2);
   const unsigned grid = (unsigned)ceil_div<int64_t>(n_dst, rows_per_block);

@@ -21,7 +21,7 @@ class DeviceGraph:
       indptr  int64 [V+1]    indices int32 [nnz] (ascending inside a column)."""
 
     def __init__(self, adj, readonly=True, device=None):
-        self.device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         csc = spsp.csc_matrix(adj)
         csc.sum_duplicates()
         csc.sort_indices()

@@ -100,6 +100,9 @@ class GraphCacheServer:
         self._staged_dev = {}            # name -> device fp32 [cap, dim]
         self._event = torch.cuda.Event()
         self._pending_counts = []        # zero-copy mode: (pinned count tensor, event, rows)
+        # bench.py: when a list, every gather launch is bracketed by HIP events on its own stream
+        # and (timer_handle, rows, misses_or_None) is appended
+        self.profile = None
 
     # -- reference-shaped views of the fused slot map --------------------------
     def _export(self):
@@ -236,9 +239,17 @@ class GraphCacheServer:
                 (self.gpu_fix_cache.get(name), out[name], self.dims[name],
                  self.gpu_fix_cache[name].stride(0) if name in self.gpu_fix_cache else self.dims[name],
                  out[name].stride(0)) for name in names)
+            timer = None
+            if self.profile is not None:
+                timer = L.vp()
+                L.check(self.lib.pg_timer_create(ctypes.byref(timer)), "pg_timer_create")
+                L.check(self.lib.pg_timer_start(timer, sp), "pg_timer_start")
             L.check(self.lib.pg_gather_rows(L.ptr(nf_nids), R, L.ptr(self.slot_map), L.ptr(self.nid_map), fields, nf,
                                             L.ptr(self._miss_pos), L.ptr(self._miss_fullid), L.ptr(self._miss_count),
                                             sp), "pg_gather_rows")
+            if timer is not None:
+                L.check(self.lib.pg_timer_stop(timer, sp), "pg_timer_stop")
+                self.profile.append([timer, R, None])
         with torch.autograd.profiler.record_function('cache-cpu'):
             if self.miss_mode == "zerocopy":
                 for name in names:
@@ -275,6 +286,8 @@ class GraphCacheServer:
                     self._event.synchronize()
                 if self.log:
                     self.log_miss_rate(m, R)
+                if self.profile:
+                    self.profile[-1][2] = m
         with torch.autograd.profiler.record_function('cache-asign'):
             for i in range(nodeflow.num_layers):
                 nodeflow._node_frames[i] = {name: out[name][offsets[i]:offsets[i + 1]] for name in names}

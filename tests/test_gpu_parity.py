@@ -1,0 +1,403 @@
+"""GPU (-m gpu): the HIP path, called through the C-ABI, against the oracle and the
+golden vectors from the reference's own Python. Integer/byte/index work: bit exact.
+Floating point (aggregation, model): tolerance 1e-4 (BASELINE.json north_star)."""
+import ctypes
+import glob
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as spsp
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-4
+
+
+class FakeNF:
+    """the NodeFlow surface fetch_data touches (storage.py:171-173,202)"""
+
+    def __init__(self, layers, device):
+        from pagraph_amd.sampling.nodeflow import _UserTensor
+        cat = torch.from_numpy(np.concatenate([np.asarray(l, np.int64) for l in layers])).to(device)
+        self._node_mapping = _UserTensor(cat)
+        self._layer_offsets = [0]
+        for l in layers:
+            self._layer_offsets.append(self._layer_offsets[-1] + len(l))
+        self.num_layers = len(layers)
+        self._node_frames = [None] * len(layers)
+
+
+def _cacher(z, dev, mode="staged"):
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    store = HostFeatureStore({"features": torch.from_numpy(z["features_table"]), "norm": torch.from_numpy(z["norm_table"])})
+    c = GraphCacheServer(store, len(z["nid_map"]), torch.from_numpy(z["nid_map"]), 0, miss_mode=mode)
+    c.init_field(["features", "norm"])
+    return c
+
+
+@pytest.mark.parametrize("mode", ["staged", "zerocopy"])
+@pytest.mark.parametrize("F", [8, 600, 602])
+def test_fetch_data_vs_reference_golden(dev, hiplib, golden_dir, F, mode):
+    """G1/G2: GraphCacheServer.fetch_data == the reference's outputs, bit for bit"""
+    z = np.load(os.path.join(golden_dir, f"g1_fetch_data_F{F}.npz"))
+    c = _cacher(z, dev, mode)
+    c.log = True
+    nids = torch.from_numpy(z["cached_nids"]).to(dev)
+    c.cache_fix_data(nids, c.get_feat_from_server(nids, ["features", "norm"], to_gpu=True), is_full=False)
+    assert np.array_equal(c.localid2cacheid.cpu().numpy(), z["state_localid2cacheid"])
+    assert np.array_equal(c.gpu_flag.cpu().numpy(), z["state_gpu_flag"])
+    assert c.cached_num == int(z["state_cached_num"])
+    layers = [z[f"layer{i}_nids"] for i in range(int(z["num_layers"]))]
+    nf = FakeNF(layers, dev)
+    c.fetch_data(nf)
+    torch.cuda.synchronize()
+    for i in range(len(layers)):
+        for name in ("features", "norm"):
+            got = nf._node_frames[i][name].cpu().numpy()
+            assert got.shape == z[f"layer{i}_{name}"].shape
+            assert np.array_equal(got, z[f"layer{i}_{name}"]), (i, name)
+    assert c.get_miss_rate() == float(z["miss_rate"])
+
+
+@pytest.mark.parametrize("F", [8, 600, 602])
+def test_fetch_from_cache_vs_reference_golden(dev, hiplib, golden_dir, F):
+    """G3: the full-cache path"""
+    z = np.load(os.path.join(golden_dir, f"g3_fetch_from_cache_F{F}.npz"))
+    c = _cacher(z, dev)
+    full = torch.arange(len(z["nid_map"]), device=dev)
+    c.cache_fix_data(full, c.get_feat_from_server(full, ["features", "norm"], to_gpu=True), is_full=True)
+    layers = [z[f"layer{i}_nids"] for i in range(int(z["num_layers"]))]
+    nf = FakeNF(layers, dev)
+    c.fetch_data(nf)
+    for i in range(len(layers)):
+        for name in ("features", "norm"):
+            assert np.array_equal(nf._node_frames[i][name].cpu().numpy(), z[f"layer{i}_{name}"])
+
+
+@pytest.mark.parametrize("tag", ["partial", "full"])
+def test_auto_cache_vs_reference_golden(dev, hiplib, golden_dir, tag, monkeypatch):
+    """G5: capability rule + top-out-degree selection (storage.py:78-104)"""
+    import types
+    z = np.load(os.path.join(golden_dir, f"g5_auto_cache_{tag}.npz"))
+    c = _cacher(z, dev)
+    monkeypatch.setattr(torch.cuda, "max_memory_allocated", lambda device=None: int(z["peak_allocated"]))
+    monkeypatch.setattr(torch.cuda, "max_memory_reserved", lambda device=None: int(z["peak_cached"]))
+    monkeypatch.setattr(torch.cuda, "get_device_properties",
+                        lambda d: types.SimpleNamespace(total_memory=int(z["total_memory"])))
+    g = types.SimpleNamespace(out_degrees=lambda: torch.from_numpy(z["out_degrees"]))
+    c.auto_cache(g, ["features", "norm"])
+    assert c.capability == int(z["capability"]) and c.cached_num == int(z["cached_num"])
+    assert c.full_cached == bool(z["full_cached"])
+    assert np.array_equal(c.gpu_flag.cpu().numpy(), z["gpu_flag"])
+    assert np.array_equal(c.localid2cacheid.cpu().numpy(), z["localid2cacheid"])
+    assert np.array_equal(c.gpu_fix_cache["features"].cpu().numpy(), z["cache_features"])
+    assert np.array_equal(c.gpu_fix_cache["norm"].cpu().numpy(), z["cache_norm"])
+
+
+@pytest.mark.parametrize("n,F,ratio", [(1, 600, 0.5), (63, 600, 0.0), (64, 602, 1.0), (65, 600, 0.3), (4097, 128, 0.3),
+                                        (50000, 600, 0.3), (600000, 64, 0.7), (1000, 7, 0.5), (1000, 33, 0.5)])
+def test_gather_vs_oracle_random(dev, hiplib, oracle, n, F, ratio):
+    """pg_gather_rows vs the C oracle on seeded ids: ragged tails, dims that force the
+    dwordx4 / dwordx2 / dword / lane-per-row paths, empty cache, both launch shapes"""
+    from pagraph_amd import _lib as L
+    rng = np.random.default_rng(n + F)
+    V, N = 3000, 5000
+    table = rng.random((N, F), dtype=np.float32)
+    nid_map = np.sort(rng.choice(N, V, replace=False)).astype(np.int64)
+    st = oracle.CacheState(V, nid_map)
+    cached = rng.permutation(V)[:int(V * ratio)].astype(np.int64)
+    st.cache_fix_data(cached, {"f": table}, ratio == 1.0)
+    ids = rng.integers(0, V, n).astype(np.int64)
+    want = st.fetch_layer(ids, {"f": table})["f"]
+    # device side through the raw C-ABI
+    d_ids = torch.from_numpy(ids).to(dev)
+    slot = torch.empty(V, dtype=torch.int32, device=dev)
+    sp = L.stream_ptr()
+    L.check(hiplib.pg_slot_map_reset(L.ptr(slot), V, sp))
+    d_cached = torch.from_numpy(cached).to(dev)
+    L.check(hiplib.pg_slot_map_assign(L.ptr(slot), L.ptr(d_cached), len(cached), sp))
+    cache = torch.from_numpy(st.cache["f"]).to(dev) if len(cached) else None
+    out = torch.full((n, F), -1.0, device=dev)
+    mpos = torch.empty(n, dtype=torch.int32, device=dev)
+    mfull = torch.empty(n, dtype=torch.int64, device=dev)
+    mcnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    fields, nf = L.make_fields([(cache, out, F, F, F)])
+    L.check(hiplib.pg_gather_rows(L.ptr(d_ids), n, L.ptr(slot), L.ptr(torch.from_numpy(nid_map).to(dev)), fields, nf,
+                                  L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt), sp))
+    m = int(mcnt.item())
+    assert m == st.miss_num
+    pos = mpos[:m].cpu().numpy(); full = mfull[:m].cpu().numpy()
+    hit = st.gpu_flag[ids].astype(bool)
+    assert np.array_equal(np.sort(pos), np.nonzero(~hit)[0])             # exactly the missing rows
+    assert np.array_equal(full, nid_map[ids[pos]])                       # with their full-graph ids
+    got = out.cpu().numpy()
+    assert np.array_equal(got[hit], want[hit])
+    assert np.all(got[~hit] == -1.0)                                     # misses untouched by the gather
+    # finish the misses with the scatter kernel
+    staged = torch.from_numpy(table[full]).to(dev)
+    L.check(hiplib.pg_scatter_rows(L.ptr(staged), L.ptr(mpos), m, None, F, L.ptr(out), F, sp))
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+def _rand_csc(rng, V, E, powerlaw=True):
+    if powerlaw:
+        w = 1.0 / np.arange(1, V + 1) ** 0.9; w /= w.sum()
+        s = rng.choice(V, E, p=w); d = rng.choice(V, E, p=w)
+    else:
+        s = rng.integers(0, V, E); d = rng.integers(0, V, E)
+    a = spsp.coo_matrix((np.ones(2 * E, np.int8), (np.concatenate([s, d]), np.concatenate([d, s]))), shape=(V, V)).tocsr()
+    a.data[:] = 1
+    return a
+
+
+@pytest.mark.parametrize("V,E,B,k,hops", [(2000, 12000, 256, 2, 2), (5000, 60000, 1000, 2, 2), (800, 9000, 100, 5, 3),
+                                           (3000, 20000, 333, 1, 1), (4000, 50000, 512, 64, 1), (100000, 900000, 6000, 2, 2)])
+def test_sampler_vs_oracle_bit_exact(dev, hiplib, oracle, V, E, B, k, hops):
+    """NodeFlow node-id sets, layer offsets and block CSRs equal the CPU restatement under a fixed seed"""
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    rng = np.random.default_rng(V + k)
+    adj = _rand_csc(rng, V, E)
+    g = DeviceGraph(adj)
+    train = np.sort(rng.choice(V, int(V * 0.65), replace=False)).astype(np.int64)
+    smp = NeighborSampler(g, B, k, neighbor_type='in', shuffle=True, num_hops=hops, seed_nodes=train, prefetch=True, seed=42)
+    seeds_order = smp.seeds.cpu().numpy()
+    assert np.array_equal(np.sort(seeds_order), train)
+    csc = spsp.csc_matrix(adj); csc.sort_indices()
+    for epoch in range(2):
+        nb = 0
+        for b, nf in enumerate(smp):
+            if b > 3 and b < len(smp) - 1:
+                continue                                  # first batches + the short last batch
+            s = seeds_order[b * B:(b + 1) * B]
+            ref = oracle.sample_nodeflow(csc.indptr, csc.indices, s, k, hops, 42, epoch, b)
+            assert nf._layer_offsets == [int(x) for x in ref["layer_offsets"][:hops + 2]]
+            assert np.array_equal(nf._node_mapping.tousertensor().cpu().numpy(), ref["node_mapping"])
+            for i in range(hops):
+                assert np.array_equal(nf.blk_indptr[i].cpu().numpy(), ref["blocks"][i][0])
+                assert np.array_equal(nf.blk_src[i].cpu().numpy(), ref["blocks"][i][1])
+            nb += 1
+        assert nb >= 1 and b == len(smp) - 1
+
+
+@pytest.mark.parametrize("n_dst,n_src,deg,dim,reduce", [(500, 900, 2, 600, "mean"), (6000, 12000, 2, 64, "mean"),
+                                                         (100, 50, 7, 602, "sum"), (37, 80, 3, 33, "mean"),
+                                                         (1000, 1000, 0, 64, "mean"), (300, 400, 4, 1200, "sum")])
+def test_spmm_fwd_bwd_vs_oracle(dev, hiplib, oracle, n_dst, n_src, deg, dim, reduce):
+    from pagraph_amd.ops import block_aggregate
+    rng = np.random.default_rng(n_dst + dim)
+    cnt = rng.integers(0, deg + 1, n_dst) if deg else np.zeros(n_dst, np.int64)
+    indptr = np.zeros(n_dst + 1, np.int32); indptr[1:] = np.cumsum(cnt)
+    src = rng.integers(0, n_src, int(indptr[-1])).astype(np.int32)
+    h = rng.standard_normal((n_src, dim)).astype(np.float32)
+    want = oracle.spmm_fwd(indptr, src, h, n_dst, reduce)
+    th = torch.from_numpy(h).to(dev).requires_grad_(True)
+    out = block_aggregate(torch.from_numpy(indptr).to(dev), torch.from_numpy(src).to(dev), th, n_dst, reduce)
+    got = out.detach().cpu().numpy()
+    assert np.array_equal(got, want)            # same summation order as the sequential oracle
+    go = rng.standard_normal((n_dst, dim)).astype(np.float32)
+    out.backward(torch.from_numpy(go).to(dev))
+    want_g = oracle.spmm_bwd(indptr, src, go, n_src, reduce)
+    assert np.allclose(th.grad.cpu().numpy(), want_g, rtol=0, atol=TOL)   # atomics: order differs
+
+
+@pytest.mark.parametrize("arch", ["gcn", "gcn_pre", "sage", "infer"])
+def test_model_forward_vs_oracle(dev, hiplib, oracle, arch):
+    """layer outputs within 1e-4 of the CPU restatement (dropout off)"""
+    import torch.nn.functional as Fn
+    from pagraph_amd.model import GCNInfer, GCNSampling, GraphSageSampling
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    rng = np.random.default_rng(9)
+    V, Fdim, C, B, k = 3000, 600, 60, 500, 2
+    hops = 1 if arch == "gcn_pre" else 2
+    adj = _rand_csc(rng, V, 20000)
+    g = DeviceGraph(adj)
+    feats = rng.random((V, Fdim), dtype=np.float32)
+    train = np.arange(0, V, 2, dtype=np.int64)
+    smp = NeighborSampler(g, B, k, neighbor_type='in', shuffle=False, num_hops=hops, seed_nodes=train, seed=3)
+    nf = next(iter(smp))
+    csc = spsp.csc_matrix(adj); csc.sort_indices()
+    ref = oracle.sample_nodeflow(csc.indptr, csc.indices, train[:B], k, hops, 3, 0, 0)
+    nm = ref["node_mapping"]; o = ref["layer_offsets"]
+    norm = (1.0 / np.maximum(1, np.diff(csc.indptr))).astype(np.float32).reshape(-1, 1)
+    for i in range(nf.num_layers):
+        ids = nm[o[i]:o[i + 1]]
+        nf._node_frames[i] = {"features": torch.from_numpy(feats[ids]).to(dev), "norm": torch.from_numpy(norm[ids]).to(dev)}
+    torch.manual_seed(1)
+    if arch in ("gcn", "gcn_pre"):
+        model = GCNSampling(Fdim, 32, C, 1, Fn.relu, 0.0, preprocess=(arch == "gcn_pre")).to(dev)
+    elif arch == "infer":
+        model = GCNInfer(Fdim, 32, C, 1, Fn.relu).to(dev)
+    else:
+        model = GraphSageSampling(Fdim, 16, C, 1, Fn.relu, 0.0, 'mean').to(dev)
+    got = model(nf).detach().cpu().numpy()
+    P = lambda lin: (lin.weight.detach().cpu().numpy(), lin.bias.detach().cpu().numpy())
+    if arch == "gcn":
+        want, _ = oracle.gcn_forward(ref, feats[nm[o[0]:o[1]]], [P(l.linear) for l in model.layers])
+    elif arch == "gcn_pre":
+        W, b = P(model.linear)
+        z = feats[nm[o[0]:o[1]]] @ W.T + b
+        h0 = np.concatenate([z, np.maximum(z, 0)], 1)
+        W1, b1 = P(model.layers[0].linear)
+        want = oracle.spmm_fwd(*ref["blocks"][0], h0, o[2] - o[1], "mean") @ W1.T + b1
+    elif arch == "infer":
+        h = feats[nm[o[0]:o[1]]]
+        for i, l in enumerate(model.layers):
+            W, b = P(l.linear)
+            agg = oracle.spmm_fwd(*ref["blocks"][i], h, o[i + 2] - o[i + 1], "sum") * norm[nm[o[i + 1]:o[i + 2]]]
+            z = agg @ W.T + b
+            h = np.concatenate([z, np.maximum(z, 0)], 1) if i == 0 else z
+        want = h
+    else:
+        params = [P(l.fc_self) + P(l.fc_neigh) for l in model.layers]
+        want = oracle.sage_forward(ref, [feats[nm[o[i]:o[i + 1]]] for i in range(3)], params)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < TOL * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "g6_*.npz"))), ids=os.path.basename)
+def test_closure_vs_golden(dev, hiplib, path):
+    """get_sub_graph on the GPU == the reference's numpy tail on the stand-in sampler (utils.py:25-52)"""
+    from pagraph_amd.partition.utils import get_sub_graph
+    from pagraph_amd.sampling import DeviceGraph
+    z = np.load(path)
+    V = int(z["V"])
+    csc = spsp.csc_matrix((np.ones(len(z["csc_indices"]), np.int8), z["csc_indices"], z["csc_indptr"]), shape=(V, V))
+    g = DeviceGraph(csc)
+    csr, sub2full, subtrain = get_sub_graph(g, z["train_nids"], int(z["hops"]))
+    csr.sort_indices()
+    assert np.array_equal(sub2full, z["sub2full"]) and np.array_equal(subtrain, z["subtrainid"])
+    assert np.array_equal(csr.indptr, z["sub_indptr"]) and np.array_equal(csr.indices, z["sub_indices"])
+    assert csr.data.dtype == np.uint8 and np.all(csr.data == 1)
+
+
+def test_closure_vs_oracle_medium(dev, hiplib, oracle):
+    from pagraph_amd.partition.utils import closure_device
+    from pagraph_amd.sampling import DeviceGraph
+    rng = np.random.default_rng(77)
+    V = 20000
+    adj = _rand_csc(rng, V, 60000)
+    g = DeviceGraph(adj)
+    csc = spsp.csc_matrix(adj); csc.sort_indices()
+    train = np.sort(rng.choice(V, 2000, replace=False)).astype(np.int64)
+    for hops in (1, 2, 3):
+        ip, ix, s2f, st = closure_device(g, train, hops)
+        o_ip, o_ix, o_s2f, o_st = oracle.closure_subgraph(csc.indptr, csc.indices, V, train, hops)
+        assert np.array_equal(s2f.cpu().numpy(), o_s2f) and np.array_equal(st.cpu().numpy(), o_st)
+        Vs = len(o_s2f)
+        mine = spsp.csc_matrix((np.ones(ix.numel(), np.int8), ix.cpu().numpy(), ip.cpu().numpy()), shape=(Vs, Vs)).tocsr()
+        mine.sort_indices()
+        assert np.array_equal(mine.indptr, o_ip) and np.array_equal(mine.indices, o_ix)
+
+
+def test_synthetic_generators_vs_oracle(dev, hiplib, oracle):
+    from pagraph_amd.data import synthetic as syn
+    s, d = syn.rmat_candidates(99, 17, 1000, 200000, dev)
+    os_, od = oracle.rmat_edges(99, 17, 1000, 200000)
+    assert np.array_equal(s.cpu().numpy(), os_) and np.array_equal(d.cpu().numpy(), od)
+    f = syn.random_features_device(5000, 600, seed=5, device=dev, row0=123)
+    assert np.array_equal(f.cpu().numpy(), oracle.random_features(5, 123, 5000, 600))
+    f2 = syn.random_features_device(100, 602, seed=5, device=dev)
+    assert np.array_equal(f2.cpu().numpy(), oracle.random_features(5, 0, 100, 602))
+    assert float(f.min()) >= 0.0 and float(f.max()) < 1.0
+    # graph builder: exactly E distinct undirected edges, symmetric, sorted columns, no loops
+    V, E = 20000, 100000
+    ip, ix = syn.rmat_graph(V, E, seed=3, device=dev)
+    assert ip[-1].item() == 2 * E and ix.numel() == 2 * E
+    a = spsp.csc_matrix((np.ones(2 * E, np.int8), ix.cpu().numpy(), ip.cpu().numpy()), shape=(V, V))
+    assert a.has_sorted_indices or (a.sort_indices() is None)
+    assert (a != a.T).nnz == 0 and a.diagonal().sum() == 0
+    a.sum_duplicates(); assert a.nnz == 2 * E
+    # sequential "first E unique candidates" semantics, checked with numpy on the oracle's candidates
+    factor = 1.35
+    while True:                                  # same candidate-count schedule as rmat_graph
+        n = int(E * factor) + 1024
+        cs, cd = oracle.rmat_edges(3, 15, 0, n)
+        u = np.minimum(cs, cd); v = np.maximum(cs, cd)
+        seen, chosen = set(), []
+        for a_, b_ in zip(u.tolist(), v.tolist()):
+            if a_ != b_ and b_ < V and (a_, b_) not in seen:
+                seen.add((a_, b_)); chosen.append((a_, b_))
+                if len(chosen) == E:
+                    break
+        if len(chosen) == E:
+            break
+        factor *= 1.5
+    ref = spsp.coo_matrix((np.ones(E, np.int8), ([c[0] for c in chosen], [c[1] for c in chosen])), shape=(V, V))
+    ref = (ref + ref.T).tocsc(); ref.sort_indices()
+    assert np.array_equal(ref.indptr, ip.cpu().numpy()) and np.array_equal(ref.indices, ix.cpu().numpy())
+
+
+def test_full_size_gather_properties(dev, hiplib):
+    """BASELINE-size gather (R = 1M rows, F = 600, 30% cache) checked through size-independent
+    properties: every output row equals its source row (row checksums match a checksum of the
+    table gathered by torch), hits + misses partition the rows, idempotence."""
+    from pagraph_amd import _lib as L
+    from pagraph_amd.data import synthetic as syn
+    V, F, R = 400000, 600, 1 << 20
+    table = syn.random_features_device(V, F, seed=1, device=dev)       # the "host" table, kept in HBM for the check
+    deg_order = torch.randperm(V, device=dev)
+    cached = deg_order[:int(V * 0.3)].contiguous()
+    cache = table[cached].contiguous()
+    slot = torch.empty(V, dtype=torch.int32, device=dev)
+    sp = L.stream_ptr()
+    L.check(hiplib.pg_slot_map_reset(L.ptr(slot), V, sp))
+    L.check(hiplib.pg_slot_map_assign(L.ptr(slot), L.ptr(cached), cached.numel(), sp))
+    ids = torch.randint(0, V, (R,), device=dev)
+    nid_map = torch.arange(V, device=dev)
+    out = torch.zeros((R, F), device=dev)
+    mpos = torch.empty(R, dtype=torch.int32, device=dev); mfull = torch.empty(R, dtype=torch.int64, device=dev)
+    mcnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    fields, nf = L.make_fields([(cache, out, F, F, F)])
+    for _ in range(2):                                                   # idempotent
+        L.check(hiplib.pg_gather_rows(L.ptr(ids), R, L.ptr(slot), L.ptr(nid_map), fields, nf, L.ptr(mpos), L.ptr(mfull),
+                                      L.ptr(mcnt), sp))
+    m = int(mcnt.item())
+    hit = slot[ids] >= 0
+    assert m == int((~hit).sum())
+    assert torch.equal(torch.sort(mpos[:m].long()).values, torch.nonzero(~hit).squeeze(1))
+    assert torch.equal(mfull[:m], ids[mpos[:m].long()])
+    L.check(hiplib.pg_scatter_rows(L.ptr(table[mfull[:m]].contiguous()), L.ptr(mpos), m, None, F, L.ptr(out), F, sp))
+    assert torch.equal(out, table[ids])
+
+
+def test_trainer_loop_runs_and_learns(dev, hiplib):
+    """a few steps of the pa_gcn.py loop: loss decreases on a learnable synthetic task"""
+    import torch.nn.functional as Fn
+    from pagraph_amd.model import GCNSampling
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    rng = np.random.default_rng(0)
+    V, Fdim, C = 6000, 64, 4
+    labels = rng.integers(0, C, V)
+    # homophilous graph: a GCN without self loops can only learn a vertex's label from its neighbours
+    order = np.argsort(labels, kind="stable"); start = np.searchsorted(labels[order], np.arange(C + 1))
+    s_ = rng.integers(0, V, 40000)
+    d_ = order[start[labels[s_]] + rng.integers(0, 1 << 30, 40000) % (start[labels[s_] + 1] - start[labels[s_]])]
+    adj = spsp.coo_matrix((np.ones(80000, np.int8), (np.concatenate([s_, d_]), np.concatenate([d_, s_]))), shape=(V, V)).tocsr()
+    g = DeviceGraph(adj)
+    feats = (np.eye(C, Fdim, dtype=np.float32)[labels] + 0.1 * rng.standard_normal((V, Fdim))).astype(np.float32)
+    store = HostFeatureStore({"features": torch.from_numpy(feats)})
+    c = GraphCacheServer(store, V, torch.arange(V), 0)
+    c.init_field(["features"])
+    c.log = True
+    train = np.arange(V, dtype=np.int64)
+    smp = NeighborSampler(g, 512, 2, neighbor_type='in', shuffle=True, num_hops=2, seed_nodes=train, prefetch=True, seed=1)
+    torch.manual_seed(0)
+    model = GCNSampling(Fdim, 32, C, 1, Fn.relu, 0.2).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=3e-2)
+    lab = torch.from_numpy(labels).to(dev)
+    losses = []
+    for epoch in range(3):
+        for step, nf in enumerate(smp):
+            c.fetch_data(nf)
+            y = lab[nf.layer_parent_nid(-1)]
+            loss = Fn.cross_entropy(model(nf), y)
+            opt.zero_grad(); loss.backward(); opt.step()
+            losses.append(loss.item())
+            if epoch == 0 and step == 0:
+                c.auto_cache(g, ["features"], cache_ratio=0.3)
+    assert losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])
+    mr = c.get_miss_rate()
+    assert 0.0 < mr < 1.0

@@ -1,0 +1,101 @@
+"""CPU: the oracle (oracle/) against the golden vectors produced by the REFERENCE's
+own Python (oracle/gen_golden.py) and against published known-answer vectors."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+
+# Random123 v1.14 kat_vectors, philox4x32-10
+PHILOX_KAT = [
+    ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+     (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+]
+
+
+@pytest.mark.parametrize("ctr,key,want", PHILOX_KAT)
+def test_philox_known_answers(oracle, ctr, key, want):
+    assert tuple(oracle.philox4x32_10(ctr, key)) == want
+
+
+def _state_from_g1(oracle, z):
+    st = oracle.CacheState(len(z["nid_map"]), z["nid_map"])
+    tables = {"features": z["features_table"], "norm": z["norm_table"]}
+    st.cache_fix_data(z["cached_nids"], tables, is_full=False)
+    return st, tables
+
+
+@pytest.mark.parametrize("F", [8, 600, 602])
+def test_g1_fetch_data(oracle, golden_dir, F):
+    z = np.load(os.path.join(golden_dir, f"g1_fetch_data_F{F}.npz"))
+    st, tables = _state_from_g1(oracle, z)
+    # G2: state after cache_fix_data
+    assert np.array_equal(st.localid2cacheid, z["state_localid2cacheid"])
+    assert np.array_equal(st.gpu_flag.astype(bool), z["state_gpu_flag"])
+    assert st.cached_num == int(z["state_cached_num"])
+    for i in range(int(z["num_layers"])):
+        got = st.fetch_layer(z[f"layer{i}_nids"], tables)
+        np_got, _ = oracle.fetch_layer_numpy(st, z[f"layer{i}_nids"], tables)
+        for name in ("features", "norm"):
+            assert got[name].shape == z[f"layer{i}_{name}"].shape
+            assert np.array_equal(got[name], z[f"layer{i}_{name}"]), (i, name)   # pure copy: bit exact
+            assert np.array_equal(np_got[name], z[f"layer{i}_{name}"])
+    assert st.try_num == int(z["try_num"]) and st.miss_num == int(z["miss_num"])
+    assert st.get_miss_rate() == float(z["miss_rate"])
+
+
+@pytest.mark.parametrize("F", [8, 600, 602])
+def test_g3_fetch_from_cache(oracle, golden_dir, F):
+    z = np.load(os.path.join(golden_dir, f"g3_fetch_from_cache_F{F}.npz"))
+    V = len(z["nid_map"])
+    st = oracle.CacheState(V, z["nid_map"])
+    tables = {"features": z["features_table"], "norm": z["norm_table"]}
+    st.cache_fix_data(np.arange(V), tables, is_full=True)
+    for i in range(int(z["num_layers"])):
+        got = st.fetch_layer(z[f"layer{i}_nids"], tables)
+        for name in ("features", "norm"):
+            assert np.array_equal(got[name], z[f"layer{i}_{name}"])
+    assert st.miss_num == 0
+
+
+@pytest.mark.parametrize("tag", ["partial", "full"])
+def test_g5_auto_cache(oracle, golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, f"g5_auto_cache_{tag}.npz"))
+    V = len(z["nid_map"])
+    total_dim = z["features_table"].shape[1] + 1
+    avail = int(z["total_memory"]) - int(z["peak_allocated"]) - int(z["peak_cached"]) - 1024 ** 3
+    cap = int(avail / (total_dim * 4))                       # storage.py:81-84
+    assert cap == int(z["capability"])
+    st = oracle.CacheState(V, z["nid_map"])
+    ids, full = st.auto_cache_select(z["out_degrees"], cap)
+    st.cache_fix_data(ids, {"features": z["features_table"], "norm": z["norm_table"]}, full)
+    assert full == bool(z["full_cached"]) and st.cached_num == int(z["cached_num"])
+    assert np.array_equal(st.gpu_flag.astype(bool), z["gpu_flag"])
+    assert np.array_equal(st.localid2cacheid, z["localid2cacheid"])
+    assert np.array_equal(st.cache["features"], z["cache_features"])
+    assert np.array_equal(st.cache["norm"], z["cache_norm"])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "g4_*.npz"))),
+                         ids=os.path.basename)
+def test_g4_dg(oracle, path):
+    z = np.load(path)
+    P, V, hops = int(z["P"]), int(z["V"]), int(z["hops"])
+    sub_v, sub_trainv = oracle.dg_partition(P, z["csc_indptr"], z["csc_indices"], V, z["train_nids"], hops)
+    for p in range(P):
+        assert np.array_equal(sub_trainv[p], z[f"sub_trainv_{p}"])
+        assert np.array_equal(sub_v[p], z[f"sub_v_{p}"])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "g6_*.npz"))),
+                         ids=os.path.basename)
+def test_g6_closure(oracle, path):
+    z = np.load(path)
+    ip, ix, sub2full, subtrain = oracle.closure_subgraph(z["csc_indptr"], z["csc_indices"], int(z["V"]),
+                                                         z["train_nids"], int(z["hops"]))
+    assert np.array_equal(sub2full, z["sub2full"])
+    assert np.array_equal(subtrain, z["subtrainid"])
+    assert np.array_equal(ip, z["sub_indptr"]) and np.array_equal(ix, z["sub_indices"])
