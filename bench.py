@@ -206,6 +206,19 @@ def gather_microbench(cacher, g, dev, rows_list=(42000, 1 << 20)):
 
 
 def main():
+    # the JSON line is the ONLY thing on stdout: the library's reference-style prints
+    # ('total dims', 'Cache Memory', ...) go to stderr
+    real_stdout = sys.stdout
+    sys.stdout = sys.stderr
+    try:
+        out = run()
+    finally:
+        sys.stdout = real_stdout
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+def run():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
@@ -367,7 +380,8 @@ def main():
                            norm_tab if norm_tab is not None else torch.zeros((V, 1)), labels_h, steps_per_epoch,
                            args.cpu_baseline_seconds)
 
-    seeds_total = parallel.sum_over_ranks(min(K * B, K * B), device=dev)
+    seeds_total = parallel.sum_over_ranks(K * B, device=dev)
+    out = None
     if rank == 0:
         out = {
             "metric": "epoch_time_s", "value": epoch_s, "unit": "s", "n_gpus": world, "steps": K, "warmup": W,
@@ -385,7 +399,6 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         if shm_path and local_rank == 0:
@@ -394,6 +407,7 @@ def main():
             except OSError:
                 pass
         dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":
