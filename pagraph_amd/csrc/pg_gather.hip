@@ -5,18 +5,28 @@
 // compactions (each a device->host sync) and a temp copy of the hit rows —
 // with ONE launch over all rows of all layers.
 //
-// Work decomposition (wave64-native, no LDS, no block barrier):
-//   * a wave owns RPW consecutive output rows; lane l < RPW loads ids[row0+l]
-//     (one coalesced 8*RPW-byte read) and its slot_map entry;
-//   * __ballot over "slot < 0" gives the wave's miss mask: one atomicAdd per
-//     wave reserves a range in the miss list, each missing lane appends
-//     (row, nid_map[id]) at its prefix-popcount rank (storage.py:179-182,117);
-//   * rows are then copied U at a time: the row's slot is broadcast with
-//     __shfl (wave-uniform), lanes stride over the row in 16-byte pieces
-//     (dwordx4 when dim % 4 == 0, dwordx2 for F=602, dword otherwise), U
-//     independent row loads in flight per lane before the first store.
-//   * narrow fields (e.g. 'norm', dim 1) are copied lane-per-row: 64 gathered
-//     loads, one coalesced store.
+// Work decomposition (chosen by measurement, tools/gather_variants.hip; see
+// DESIGN.md "k_gather"):
+//   * a 256-thread block owns T consecutive output rows (T = 8 for big
+//     launches, 4 at the minibatch shape so the grid stays >> 256 CUs);
+//   * stage: thread t < T loads ids[row0+t] and its slot_map entry into LDS
+//     (the index tile is read from HBM exactly once per block);
+//   * hit/miss split (storage.py:179-182,117) runs in its own tiny kernel
+//     k_split just before: 256 rows per block, per-wave __ballot of "slot < 0",
+//     prefix-popcount ranks, ONE atomicAdd per block to reserve a range of the
+//     miss list.  Fusing it into the copy kernel (one atomic per 4..8-row
+//     tile) serialised ~12 ns per tile on the single counter word: 34 K rows
+//     with 25 % misses took 74 us instead of 31 us (measured);
+//   * copy: the tile's T x (dim/VEC) 16-byte pieces are one FLAT index space
+//     striped over the block's 256 lanes — every lane of every load/store
+//     instruction is busy (a row of 600 floats = 150 pieces would leave 42 of
+//     64 lanes idle on its third wave-load), reads are contiguous 2.4 KB runs
+//     of the cache rows, the tile's output is one contiguous T*dim*4-byte run.
+//     Each lane issues U independent 16-byte loads before its first store;
+//     (row, piece) advance incrementally, no division in the loop;
+//   * stores are non-temporal: the gathered frame is consumed by the next
+//     kernel once and must not evict cache rows from L2/MALL (+7..10 %);
+//   * narrow fields (e.g. 'norm', dim 1) are copied lane-per-row.
 #include "pg_common.h"
 
 namespace pg {
@@ -34,105 +44,124 @@ struct GatherArgs {
   pg_field_t f[PG_MAX_FIELDS];
 };
 
+typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef float vf2 __attribute__((ext_vector_type(2)));
+
 template <int VEC>
 struct VecT;
 template <>
-struct VecT<4> { using type = float4; };
+struct VecT<4> { using type = vf4; };
 template <>
-struct VecT<2> { using type = float2; };
+struct VecT<2> { using type = vf2; };
 template <>
 struct VecT<1> { using type = float; };
 
-// copy U rows (wave-uniform slots s[], output rows r[]) of one field, VEC floats per lane access
+constexpr int kGatherBlock = 256;
+
+// flat copy of one field of the block's tile: rows [row0, row0+rows), slots in LDS
 template <int VEC, int U>
-__device__ __forceinline__ void copy_rows(const pg_field_t& fd, const int32_t (&s)[U],
-                                          const int64_t (&r)[U], int lane) {
+__device__ __forceinline__ void copy_tile(const pg_field_t fd, const int32_t* s_slot, int64_t row0, int rows) {
   using V = typename VecT<VEC>::type;
   const int pieces = fd.dim / VEC;
-  const V* src[U];
-  V* dst[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    src[u] = reinterpret_cast<const V*>(fd.cache + (int64_t)(s[u] < 0 ? 0 : s[u]) * fd.cache_stride);
-    dst[u] = reinterpret_cast<V*>(fd.out + r[u] * fd.out_stride);
-  }
-  for (int c = lane; c < pieces; c += kWave) {
+  const int total = rows * pieces;
+  const int step_r = kGatherBlock / pieces, step_c = kGatherBlock % pieces;
+  int r = threadIdx.x / pieces, c = threadIdx.x % pieces;
+  for (int i0 = threadIdx.x; i0 < total; i0 += kGatherBlock * U) {
     V v[U];
+    V* dst[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      dst[u] = nullptr;
+      if (i0 + u * kGatherBlock < total) {
+        const int32_t s = s_slot[r];
+        if (s >= 0) {
+          v[u] = reinterpret_cast<const V*>(fd.cache + (int64_t)s * fd.cache_stride)[c];
+          dst[u] = reinterpret_cast<V*>(fd.out + (row0 + r) * fd.out_stride) + c;
+        }
+      }
+      r += step_r;
+      c += step_c;
+      if (c >= pieces) {
+        c -= pieces;
+        ++r;
+      }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (s[u] >= 0) v[u] = src[u][c];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (s[u] >= 0) dst[u][c] = v[u];
+      if (dst[u]) __builtin_nontemporal_store(v[u], dst[u]);
   }
 }
 
-template <int RPW, int U, bool FULL>
-__global__ __launch_bounds__(256) void k_gather(const GatherArgs a) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
-  const int64_t row0 = wave * RPW;
-  if (row0 >= a.n) return;
-
-  // ---- stage: id -> slot, one row per lane ------------------------------
-  const int64_t my_row = row0 + lane;
-  const bool valid = lane < RPW && my_row < a.n;
+// hit/miss split: appends (row, nid_map[id]) of every row with slot_map[id] < 0 to the miss list
+__global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ ids, int64_t n,
+                                               const int32_t* __restrict__ slot_map,
+                                               const int64_t* __restrict__ nid_map, int32_t* __restrict__ miss_pos,
+                                               int64_t* __restrict__ miss_fullid, int32_t* __restrict__ miss_count) {
+  __shared__ int32_t s_wave[4];
+  __shared__ int32_t s_base;
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
   int64_t id = 0;
-  int32_t slot = -2;  // -2: no row on this lane
-  if (valid) {
-    id = a.ids[my_row];
-    slot = FULL ? (int32_t)id : a.slot_map[id];
+  bool miss = false;
+  if (row < n) {
+    id = ids[row];
+    miss = slot_map[id] < 0;
   }
-  if (!FULL) {
-    // ---- hit/miss split (wave ballot + prefix popcount) -----------------
-    const bool miss = valid && slot < 0;
-    const unsigned long long mmask = __ballot(miss);
-    if (mmask) {
-      int32_t base = 0;
-      if (lane == 0) base = atomicAdd(a.miss_count, (int32_t)__popcll(mmask));
-      base = __shfl(base, 0);
-      if (miss) {
-        const int rank = __popcll(mmask & ((1ull << lane) - 1ull));
-        a.miss_pos[base + rank] = (int32_t)my_row;
-        a.miss_fullid[base + rank] = a.nid_map[id];
+  const unsigned long long mmask = __ballot(miss);
+  if (lane == 0) s_wave[w] = (int32_t)__popcll(mmask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int32_t tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    s_base = tot ? atomicAdd(miss_count, tot) : 0;
+  }
+  __syncthreads();
+  if (miss) {
+    int32_t off = s_base + __popcll(mmask & ((1ull << lane) - 1ull));
+    for (int i = 0; i < w; ++i) off += s_wave[i];
+    miss_pos[off] = (int32_t)row;
+    miss_fullid[off] = nid_map[id];
+  }
+}
+
+template <int T, int U, bool FULL>
+__global__ __launch_bounds__(kGatherBlock) void k_gather(const GatherArgs a) {
+  static_assert(T <= kWave, "the tile's index stage and miss ballot live in wave 0");
+  __shared__ int32_t s_slot[T];
+  const int64_t row0 = (int64_t)blockIdx.x * T;
+  const int rows = (int)((a.n - row0) < T ? (a.n - row0) : T);
+  const int t = threadIdx.x;
+
+  if (t < kWave) {  // wave 0: stage id -> slot
+    const bool valid = t < rows;
+    int64_t id = 0;
+    int32_t slot = -2;
+    if (valid) {
+      id = a.ids[row0 + t];
+      slot = FULL ? (int32_t)id : a.slot_map[id];
+      s_slot[t] = slot;
+    }
+    // narrow fields: lane-per-row (field loops are fully unrolled with constant indices so the
+    // by-value kernel-argument struct stays in SGPRs instead of being copied to an alloca)
+#pragma unroll
+    for (int f = 0; f < PG_MAX_FIELDS; ++f) {
+      if (f >= a.n_fields || a.vec[f] != 0) continue;
+      const pg_field_t fd = a.f[f];
+      if (valid && slot >= 0) {
+        const float* src = fd.cache + (int64_t)slot * fd.cache_stride;
+        float* dst = fd.out + (row0 + t) * fd.out_stride;
+        for (int c = 0; c < fd.dim; ++c) dst[c] = src[c];
       }
     }
   }
+  __syncthreads();
 
-  // ---- narrow fields: lane-per-row ---------------------------------------
-  // (field loops are fully unrolled with constant indices so the by-value
-  //  kernel-argument struct stays in SGPRs instead of being spilled to an alloca)
 #pragma unroll
   for (int f = 0; f < PG_MAX_FIELDS; ++f) {
-    if (f >= a.n_fields || a.vec[f] != 0) continue;
-    const pg_field_t fd = a.f[f];
-    if (valid && slot >= 0) {
-      const float* src = fd.cache + (int64_t)slot * fd.cache_stride;
-      float* dst = fd.out + my_row * fd.out_stride;
-      for (int c = 0; c < fd.dim; ++c) dst[c] = src[c];
-    }
-  }
-
-  // ---- wide fields: wave-per-row, U rows in flight ------------------------
-  const int rows_here = (int)((a.n - row0) < RPW ? (a.n - row0) : RPW);
-  for (int j = 0; j < rows_here; j += U) {
-    int32_t s[U];
-    int64_t r[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int jj = j + u;
-      // wave-uniform broadcast into an SGPR: the hit test below becomes a scalar branch
-      s[u] = (jj < rows_here) ? __builtin_amdgcn_readlane(slot, jj) : -1;
-      r[u] = row0 + jj;
-    }
-#pragma unroll
-    for (int f = 0; f < PG_MAX_FIELDS; ++f) {
-      if (f >= a.n_fields) continue;
-      const int vec = a.vec[f];
-      if (vec == 4) copy_rows<4, U>(a.f[f], s, r, lane);
-      else if (vec == 2) copy_rows<2, U>(a.f[f], s, r, lane);
-      else if (vec == 1) copy_rows<1, U>(a.f[f], s, r, lane);
-    }
+    if (f >= a.n_fields) continue;
+    const int vec = a.vec[f];
+    if (vec == 4) copy_tile<4, U>(a.f[f], s_slot, row0, rows);
+    else if (vec == 2) copy_tile<2, U>(a.f[f], s_slot, row0, rows);
+    else if (vec == 1) copy_tile<1, U>(a.f[f], s_slot, row0, rows);
   }
 }
 
@@ -213,15 +242,14 @@ static inline int grid_1d(int64_t n, int block, int cap = 4096) {
 
 template <bool FULL>
 static int launch_gather(GatherArgs& a, hipStream_t st) {
-  // rows per wave: keep the grid >> 256 CUs at the real step shape (~42K rows)
-  // and amortise the id->slot chain at large n.
-  const int wpb = 4;  // waves per 256-thread block
-  if (a.n >= (int64_t)1 << 19) {
-    const int64_t blocks = ceil_div<int64_t>(a.n, 32 * wpb);
-    hipLaunchKernelGGL((k_gather<32, 4, FULL>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  // tile height: 8 rows/block once the launch has >= 32K blocks anyway, 4 rows/block at the
+  // minibatch shape (~34K rows -> ~8.5K blocks) to keep every CU fed through the tail.
+  if (a.n >= (int64_t)1 << 18) {
+    const int64_t blocks = ceil_div<int64_t>(a.n, 8);
+    hipLaunchKernelGGL((k_gather<8, 4, FULL>), dim3((unsigned)blocks), dim3(kGatherBlock), 0, st, a);
   } else {
-    const int64_t blocks = ceil_div<int64_t>(a.n, 8 * wpb);
-    hipLaunchKernelGGL((k_gather<8, 4, FULL>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    const int64_t blocks = ceil_div<int64_t>(a.n, 4);
+    hipLaunchKernelGGL((k_gather<4, 3, FULL>), dim3((unsigned)blocks), dim3(kGatherBlock), 0, st, a);
   }
   PG_LAUNCH_CHECK();
   return PG_OK;
@@ -289,6 +317,9 @@ int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const
   // a partially cached server may have an empty cache (cache == NULL): every row misses
   int rc = fill_args(a, fields, n_fields, false);
   if (rc != PG_OK) return rc;
+  hipLaunchKernelGGL(k_split, dim3((unsigned)ceil_div<int64_t>(n, 256)), dim3(256), 0, st, ids, n, slot_map, nid_map,
+                     miss_pos, miss_fullid, miss_count);
+  PG_LAUNCH_CHECK();
   return launch_gather<false>(a, st);
 }
 
