@@ -50,7 +50,7 @@ def parse():
     p.add_argument("--batch-size", type=int, default=6000)
     p.add_argument("--num-neighbors", type=int, default=2)
     p.add_argument("--cache-ratio", type=float, default=0.30)
-    p.add_argument("--miss-mode", default="staged", choices=["staged", "zerocopy"])
+    p.add_argument("--miss-mode", default="zerocopy", choices=["staged", "zerocopy"])
     p.add_argument("--host-threads", type=int, default=32)
     p.add_argument("--no-overlap", action="store_true")
     p.add_argument("--skip-cpu-baseline", action="store_true")
