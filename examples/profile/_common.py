@@ -1,0 +1,135 @@
+"""Shared body of pa_gcn.py / pa_gs.py — the loop of the reference's
+examples/profile/pa_gcn.py:27-113 with the same flags and prints."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def init_process(rank, world_size, backend):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ.setdefault('MASTER_PORT', '29501')
+    dist.init_process_group(backend, rank=rank, world_size=world_size)
+    torch.cuda.set_device(rank)
+    torch.manual_seed(rank)
+    print('rank [{}] process successfully launches'.format(rank))
+
+
+def trainer(rank, world_size, args, arch, backend='nccl'):
+    import pagraph_amd.data as data
+    import pagraph_amd.storage as storage
+    from pagraph_amd import parallel, server
+    from pagraph_amd.model import GCNSampling, GraphSageSampling
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    from pagraph_amd.trainer import MinibatchTrainer, cycle_batches
+
+    init_process(rank, world_size, backend)
+    dev = torch.device('cuda', rank)
+    # load data (pa_gcn.py:31-45). The feature store is built in-process instead of attaching
+    # to a DGL shared-memory server.
+    remote_g = server.load_store(args.dataset, 'gcn' if arch == 'gcn' else 'graphsage', args.preprocess)
+    adj, t2fid = data.get_sub_train_graph(args.dataset, rank, world_size)
+    g = DeviceGraph(adj, readonly=True, device=dev)
+    n_classes = args.n_classes
+    train_nid = data.get_sub_train_nid(args.dataset, rank, world_size)
+    sub_labels = data.get_sub_train_labels(args.dataset, rank, world_size)
+    labels = np.zeros(np.max(train_nid) + 1, dtype=np.int64)
+    labels[train_nid] = sub_labels
+    t2fid = torch.LongTensor(t2fid)
+    labels = torch.LongTensor(labels).to(dev)
+    if arch == 'gcn':
+        embed_names = ['features', 'norm']
+    else:
+        embed_names = ['features', 'neigh'] if args.preprocess else ['features']
+    cacher = storage.GraphCacheServer(remote_g, adj.shape[0], t2fid, rank, miss_mode=args.miss_mode)
+    cacher.init_field(embed_names)
+    cacher.log = args.log_miss_rate
+
+    num_hops = args.n_layers if args.preprocess else args.n_layers + 1
+    if arch == 'gcn':
+        model = GCNSampling(args.feat_size, args.n_hidden, n_classes, args.n_layers, F.relu, args.dropout,
+                            args.preprocess)
+    else:
+        model = GraphSageSampling(args.feat_size, args.n_hidden, n_classes, args.n_layers, F.relu, args.dropout,
+                                  'mean', args.preprocess)
+    loss_fcn = torch.nn.CrossEntropyLoss()
+    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+    model.cuda(rank)
+    model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[rank])
+
+    sampler = NeighborSampler(g, args.batch_size, args.num_neighbors, neighbor_type='in', shuffle=True,
+                              num_workers=args.num_workers, num_hops=num_hops, seed_nodes=train_nid, prefetch=True,
+                              seed=rank)
+    steps = parallel.equalize_steps(len(sampler), device=dev)     # partitions differ in size
+    loop = MinibatchTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, overlap=not args.no_overlap)
+    loop.after_first_step = lambda: cacher.auto_cache(g, embed_names, cache_ratio=args.cache_ratio)
+    state = {'epoch': 0}
+
+    def on_step(step, loss):
+        if rank == 0 and step % 20 == 0:
+            print('epoch [{}] step [{}]. Loss: {:.4f}'.format(state['epoch'] + 1, step, loss.item()))
+    loop.on_step = on_step
+
+    epoch_dur = []
+    tic = time.time()
+    for epoch in range(args.n_epochs):
+        state['epoch'] = epoch
+        model.train()
+        torch.cuda.synchronize(dev)
+        epoch_start_time = time.time()
+        loop.run_steps(cycle_batches(sampler, steps), steps)
+        torch.cuda.synchronize(dev)   # the reference does not sync here; without it the time is meaningless
+        if rank == 0:
+            epoch_dur.append(time.time() - epoch_start_time)
+            print('Epoch average time: {:.4f}'.format(np.mean(np.array(epoch_dur[2:]))))
+        if cacher.log:
+            miss_rate = cacher.get_miss_rate()
+            print('Epoch average miss rate: {:.4f}'.format(miss_rate))
+    toc = time.time()
+    print('Total Time: {:.4f}s'.format(toc - tic))
+    dist.destroy_process_group()
+
+
+def main(arch, description, n_hidden, lr):
+    parser = argparse.ArgumentParser(description=description)
+    parser.add_argument("--gpu", type=str, default='cpu', help="gpu ids. such as 0 or 0,1,2")
+    parser.add_argument("--dataset", type=str, default=None, help="path to the dataset folder")
+    parser.add_argument("--feat-size", type=int, default=600, help='input feature size')
+    parser.add_argument("--n-classes", type=int, default=60)
+    parser.add_argument("--dropout", type=float, default=0.2, help="dropout probability")
+    parser.add_argument("--n-hidden", type=int, default=n_hidden, help="number of hidden gcn units")
+    parser.add_argument("--n-layers", type=int, default=1, help="number of hidden gcn layers")
+    parser.add_argument("--preprocess", dest='preprocess', action='store_true')
+    parser.set_defaults(preprocess=False)
+    parser.add_argument("--lr", type=float, default=lr, help="learning rate")
+    parser.add_argument("--n-epochs", type=int, default=10, help="number of training epochs")
+    parser.add_argument("--batch-size", type=int, default=6000, help="batch size")
+    parser.add_argument("--weight-decay", type=float, default=0, help="Weight for L2 loss")
+    parser.add_argument("--num-neighbors", type=int, default=2, help="number of neighbors to be sampled")
+    parser.add_argument("--num-workers", type=int, default=16)
+    parser.add_argument("--remote-sample", dest='remote_sample', action='store_true')
+    parser.set_defaults(remote_sample=False)
+    # additions of this build
+    parser.add_argument("--cache-ratio", type=float, default=None,
+                        help="cap the cache at this fraction of the partition (storage.py:85-86 overrides)")
+    parser.add_argument("--miss-mode", default="zerocopy", choices=["staged", "zerocopy"])
+    parser.add_argument("--no-overlap", action="store_true")
+    parser.add_argument("--log-miss-rate", action="store_true")
+    args = parser.parse_args()
+    if args.remote_sample:
+        print('--remote-sample: sampling already runs on the GPU; flag ignored')
+    if args.gpu == 'cpu':
+        raise SystemExit('pagraph_amd has no CPU path: pass --gpu 0[,1,...]')
+    os.environ['HIP_VISIBLE_DEVICES'] = args.gpu
+    gpu_num = len(args.gpu.split(','))
+    mp.spawn(trainer, args=(gpu_num, args, arch), nprocs=gpu_num, join=True)

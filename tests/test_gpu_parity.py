@@ -401,3 +401,27 @@ def test_trainer_loop_runs_and_learns(dev, hiplib):
     assert losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])
     mr = c.get_miss_rate()
     assert 0.0 < mr < 1.0
+
+
+def test_cli_pipeline_end_to_end(dev, hiplib, tmp_path):
+    """preprocess -> hash partition -> pa_gcn.py / pa_gs.py on a small dataset folder
+    (the reference's README.md:36-110 workflow, same file layout, same prints)"""
+    import subprocess, sys
+    ds = tmp_path / "tiny"
+    ds.mkdir()
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_PORT="29653")
+    run = lambda *a: subprocess.run([sys.executable, *a], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    r = run("-m", "pagraph_amd.data.preprocess", "--dataset", str(ds), "--gen-rmat", "20000", "120000", "--gen-feature",
+            "--feat-size", "64", "--gen-label", "--class-num", "7", "--gen-set")
+    assert r.returncode == 0, r.stderr[-2000:]
+    for f in ("adj.npz", "feat.npy", "labels.npy", "train.npy", "val.npy", "test.npy"):
+        assert (ds / f).exists()
+    r = run("-m", "pagraph_amd.partition.hash", "--dataset", str(ds), "--partition", "1", "--num-hops", "2")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (ds / "1naive" / "subadj_0.npz").exists()
+    for script, extra in (("pa_gcn.py", []), ("pa_gs.py", ["--miss-mode", "staged"])):
+        r = run(os.path.join("examples", "profile", script), "--dataset", str(ds), "--gpu", "0", "--feat-size", "64",
+                "--n-classes", "7", "--n-epochs", "3", "--batch-size", "1000", "--cache-ratio", "0.3", "--log-miss-rate", *extra)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        assert "Epoch average time" in r.stdout and "Total Time" in r.stdout and "total dims" in r.stdout
+        assert "Epoch average miss rate" in r.stdout
