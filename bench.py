@@ -56,7 +56,10 @@ def parse():
     p.add_argument("--skip-cpu-baseline", action="store_true")
     p.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     p.add_argument("--skip-microbench", action="store_true")
-    p.add_argument("--dg-hops", type=int, default=2)
+    p.add_argument("--dg-hops", type=int, default=1,
+                   help="hops used by dg's affinity score (dg.py --num-hops; README default 1). hops=2 on the 10M/100M "
+                        "graph walks sum(deg^2)=4.7e10 neighbours sequentially: ~500 s on the host (measured)")
+    p.add_argument("--dist-backend", default="nccl", help="gloo lets two ranks share one GPU (testing only)")
     return p.parse_args()
 
 
@@ -225,12 +228,13 @@ def run():
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: pagraph_amd has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    gpu = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
 
     from pagraph_amd import _lib as L
     from pagraph_amd import parallel
@@ -294,7 +298,7 @@ def run():
         fields["norm"] = norm_tab
         embed_names = ["features", "norm"]                    # pa_gcn.py:46
     store = HostFeatureStore(fields, pin=(world == 1))
-    cacher = GraphCacheServer(store, Vs, sub2full, local_rank, miss_mode=args.miss_mode, host_threads=args.host_threads)
+    cacher = GraphCacheServer(store, Vs, sub2full, gpu, miss_mode=args.miss_mode, host_threads=args.host_threads)
     cacher.init_field(embed_names)
     cacher.log = True
     D = cacher.total_dim
@@ -309,7 +313,7 @@ def run():
     loss_fcn = torch.nn.CrossEntropyLoss()
     optimizer = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=0)
     if world > 1:
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu])
     sampler = NeighborSampler(g, B, k, neighbor_type='in', shuffle=True, num_workers=16, num_hops=num_hops,
                               seed_nodes=subtrain, prefetch=True, seed=rank, copy_out=True)
     steps_per_epoch = parallel.equalize_steps(len(sampler), device=dev)
@@ -390,7 +394,7 @@ def run():
             "config": {"workload": f"RMAT {V} vertices / {E} undirected edges (nnz {2*E}), feat={Fdim}, "
                                    f"2-layer {'GCN' if args.model == 'gcn' else 'GraphSAGE-mean'} hidden {hidden}, "
                                    f"batch {B}, fan-out {k}, {int(args.cache_ratio*100)}% hot-degree cache, "
-                                   f"{'dg' if world > 1 else '1naive'} partition x{world}",
+                                   f"{('dg(hops=%d)' % args.dg_hops) if world > 1 else '1naive'} partition x{world}, closure hops {num_hops}",
                        "steps_per_epoch": steps_per_epoch, "epoch_time_extrapolated_from_steps": K,
                        "miss_mode": args.miss_mode, "overlap": not args.no_overlap, "partition_vertices": Vs},
             "cache_hit_pct": 100.0 * (1.0 - miss_rate),
