@@ -59,6 +59,7 @@ def parse():
     p.add_argument("--dg-hops", type=int, default=1,
                    help="hops used by dg's affinity score (dg.py --num-hops; README default 1). hops=2 on the 10M/100M "
                         "graph walks sum(deg^2)=4.7e10 neighbours sequentially: ~500 s on the host (measured)")
+    p.add_argument("--profile-host", action="store_true", help="cProfile the timed region (stderr)")
     p.add_argument("--dist-backend", default="nccl", help="gloo lets two ranks share one GPU (testing only)")
     return p.parse_args()
 
@@ -184,10 +185,11 @@ def gather_microbench(cacher, g, dev, rows_list=(42000, 1 << 20)):
         mpos = torch.empty(R, dtype=torch.int32, device=dev)
         mfull = torch.empty(R, dtype=torch.int64, device=dev)
         mcnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        slots = torch.empty(R, dtype=torch.int32, device=dev)
         fields, nf = L.make_fields((cacher.gpu_fix_cache[n], out[n], cacher.dims[n], cacher.gpu_fix_cache[n].stride(0),
                                     out[n].stride(0)) for n in names)
         call = lambda: L.check(lib.pg_gather_rows(L.ptr(ids), R, L.ptr(cacher.slot_map), L.ptr(cacher.nid_map), fields,
-                                                  nf, L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt), sp))
+                                                  nf, L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt), L.ptr(slots), sp))
         for _ in range(3):
             call()
         reps = 20
@@ -340,12 +342,21 @@ def run():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    prof_host = None
+    if args.profile_host:
+        import cProfile
+        prof_host = cProfile.Profile()
+        prof_host.enable()
     t0 = time.time()
     done = trainer.run_steps(it, K)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.time() - t0
+    if prof_host is not None:
+        import pstats
+        prof_host.disable()
+        pstats.Stats(prof_host, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
     assert done == K, (done, K)
     elapsed = parallel.max_over_ranks(elapsed, device=dev)
     prof, cacher.profile = cacher.profile, None

@@ -52,8 +52,9 @@ int pg_device_cu_count(void);
 /* ------------------------------------------------------------------------
  * 1. Feature cache  —  PaGraph/storage/storage.py  (GraphCacheServer)
  * ------------------------------------------------------------------------
- * HBM layout: per field one dense row-major fp32 array `cache[slot, :]`
- * (storage.py:151 `gpu_fix_cache[name]`), row stride `cache_stride` floats.
+ * HBM layout: per field a row-major fp32 array `cache[slot, :]` (storage.py:151
+ * `gpu_fix_cache[name]`), row stride `cache_stride` floats — the Python layer packs all fields of
+ * a vertex into one 128-byte-aligned row and passes column views (cache pointer + stride).
  * The reference's two per-vertex arrays gpu_flag (bool, storage.py:38) and
  * localid2cacheid (int64, storage.py:50) are fused into ONE int32
  * `slot_map[local_id]`: >=0 cache slot, -1 not cached.
@@ -84,10 +85,12 @@ int pg_slot_map_export(const int32_t* slot_map, int64_t node_num, uint8_t* gpu_f
  * number of misses; miss list order is unspecified (a permutation of the
  * reference's mask order) — results do not depend on it.
  * miss_pos / miss_fullid need capacity n.  They may be pinned-host pointers
- * so the host can read them after the stream reaches this point.          */
+ * so the host can read them after the stream reaches this point.
+ * slot_scratch: optional device int32[n]; when given, the split pass stores every row's slot
+ * there (coalesced) and the copy pass reads it back instead of repeating the random lookup.  */
 int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
                    const pg_field_t* fields, int n_fields, int32_t* miss_pos, int64_t* miss_fullid,
-                   int32_t* miss_count, pg_stream_t stream);
+                   int32_t* miss_count, int32_t* slot_scratch, pg_stream_t stream);
 
 /* storage.py:207-216 (fetch_from_cache): full cache, slot == local id. out_f[r,:] = cache_f[ids[r],:] */
 int pg_gather_rows_full(const int64_t* ids, int64_t n, const pg_field_t* fields, int n_fields,

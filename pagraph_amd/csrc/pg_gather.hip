@@ -33,6 +33,7 @@ namespace pg {
 
 struct GatherArgs {
   const int64_t* ids;
+  const int32_t* slots;  // optional: slot of row r, already translated by k_split
   const int32_t* slot_map;
   const int64_t* nid_map;
   int32_t* miss_pos;
@@ -96,7 +97,8 @@ __device__ __forceinline__ void copy_tile(const pg_field_t fd, const int32_t* s_
 __global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ ids, int64_t n,
                                                const int32_t* __restrict__ slot_map,
                                                const int64_t* __restrict__ nid_map, int32_t* __restrict__ miss_pos,
-                                               int64_t* __restrict__ miss_fullid, int32_t* __restrict__ miss_count) {
+                                               int64_t* __restrict__ miss_fullid, int32_t* __restrict__ miss_count,
+                                               int32_t* __restrict__ slots_out) {
   __shared__ int32_t s_wave[4];
   __shared__ int32_t s_base;
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
@@ -105,7 +107,9 @@ __global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ ids, 
   bool miss = false;
   if (row < n) {
     id = ids[row];
-    miss = slot_map[id] < 0;
+    const int32_t s = slot_map[id];
+    miss = s < 0;
+    if (slots_out) slots_out[row] = s;  // coalesced; k_gather then skips the random slot_map lookup
   }
   const unsigned long long mmask = __ballot(miss);
   if (lane == 0) s_wave[w] = (int32_t)__popcll(mmask);
@@ -136,8 +140,12 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(const GatherArgs a) {
     int64_t id = 0;
     int32_t slot = -2;
     if (valid) {
-      id = a.ids[row0 + t];
-      slot = FULL ? (int32_t)id : a.slot_map[id];
+      if (!FULL && a.slots) {
+        slot = a.slots[row0 + t];
+      } else {
+        id = a.ids[row0 + t];
+        slot = FULL ? (int32_t)id : a.slot_map[id];
+      }
       s_slot[t] = slot;
     }
     // narrow fields: lane-per-row (field loops are fully unrolled with constant indices so the
@@ -304,7 +312,7 @@ int pg_slot_map_export(const int32_t* slot_map, int64_t node_num, uint8_t* gpu_f
 
 int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
                    const pg_field_t* fields, int n_fields, int32_t* miss_pos, int64_t* miss_fullid,
-                   int32_t* miss_count, pg_stream_t stream) {
+                   int32_t* miss_count, int32_t* slot_scratch, pg_stream_t stream) {
   if (n < 0 || n > INT32_MAX || !miss_count) return PG_ERR_INVALID;
   hipStream_t st = as_stream(stream);
   PG_HIP(hipMemsetAsync(miss_count, 0, sizeof(int32_t), st));
@@ -313,12 +321,13 @@ int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const
   GatherArgs a{};
   a.ids = ids; a.slot_map = slot_map; a.nid_map = nid_map;
   a.miss_pos = miss_pos; a.miss_fullid = miss_fullid; a.miss_count = miss_count;
+  a.slots = slot_scratch;
   a.n = n;
   // a partially cached server may have an empty cache (cache == NULL): every row misses
   int rc = fill_args(a, fields, n_fields, false);
   if (rc != PG_OK) return rc;
   hipLaunchKernelGGL(k_split, dim3((unsigned)ceil_div<int64_t>(n, 256)), dim3(256), 0, st, ids, n, slot_map, nid_map,
-                     miss_pos, miss_fullid, miss_count);
+                     miss_pos, miss_fullid, miss_count, slot_scratch);
   PG_LAUNCH_CHECK();
   return launch_gather<false>(a, st);
 }

@@ -123,9 +123,10 @@ def test_gather_vs_oracle_random(dev, hiplib, oracle, n, F, ratio):
     mpos = torch.empty(n, dtype=torch.int32, device=dev)
     mfull = torch.empty(n, dtype=torch.int64, device=dev)
     mcnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    scratch = torch.empty(n, dtype=torch.int32, device=dev) if n % 2 else None   # both code paths
     fields, nf = L.make_fields([(cache, out, F, F, F)])
     L.check(hiplib.pg_gather_rows(L.ptr(d_ids), n, L.ptr(slot), L.ptr(torch.from_numpy(nid_map).to(dev)), fields, nf,
-                                  L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt), sp))
+                                  L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt), L.ptr(scratch), sp))
     m = int(mcnt.item())
     assert m == st.miss_num
     pos = mpos[:m].cpu().numpy(); full = mfull[:m].cpu().numpy()
@@ -352,7 +353,7 @@ def test_full_size_gather_properties(dev, hiplib):
     fields, nf = L.make_fields([(cache, out, F, F, F)])
     for _ in range(2):                                                   # idempotent
         L.check(hiplib.pg_gather_rows(L.ptr(ids), R, L.ptr(slot), L.ptr(nid_map), fields, nf, L.ptr(mpos), L.ptr(mfull),
-                                      L.ptr(mcnt), sp))
+                                      L.ptr(mcnt), None, sp))
     m = int(mcnt.item())
     hit = slot[ids] >= 0
     assert m == int((~hit).sum())
