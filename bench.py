@@ -59,6 +59,9 @@ def parse():
     p.add_argument("--dg-hops", type=int, default=1,
                    help="hops used by dg's affinity score (dg.py --num-hops; README default 1). hops=2 on the 10M/100M "
                         "graph walks sum(deg^2)=4.7e10 neighbours sequentially: ~500 s on the host (measured)")
+    p.add_argument("--fetch-all", action="store_true",
+                   help="fetch every layer and field like the reference (default: only what the model reads, SURVEY 8f-2)")
+    p.add_argument("--no-graph", action="store_true", help="eager reference-style loop instead of hipGraph replay")
     p.add_argument("--profile-host", action="store_true", help="cProfile the timed region (stderr)")
     p.add_argument("--dist-backend", default="nccl", help="gloo lets two ranks share one GPU (testing only)")
     return p.parse_args()
@@ -189,7 +192,7 @@ def gather_microbench(cacher, g, dev, rows_list=(42000, 1 << 20)):
         fields, nf = L.make_fields((cacher.gpu_fix_cache[n], out[n], cacher.dims[n], cacher.gpu_fix_cache[n].stride(0),
                                     out[n].stride(0)) for n in names)
         call = lambda: L.check(lib.pg_gather_rows(L.ptr(ids), R, L.ptr(cacher.slot_map), L.ptr(cacher.nid_map), fields,
-                                                  nf, L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt), L.ptr(slots), sp))
+                                                  nf, L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt), L.ptr(slots), None, sp))
         for _ in range(3):
             call()
         reps = 20
@@ -246,7 +249,7 @@ def run():
     from pagraph_amd.partition.utils import closure_device
     from pagraph_amd.sampling import DeviceGraph, NeighborSampler
     from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
-    from pagraph_amd.trainer import MinibatchTrainer, cycle_batches
+    from pagraph_amd.trainer import GraphedTrainer, MinibatchTrainer, cycle_batches
     L.load()
 
     V, E, Fdim, C, B, k = args.vertices, args.edges, args.feat_size, args.n_classes, args.batch_size, args.num_neighbors
@@ -313,15 +316,22 @@ def run():
         model = GraphSageSampling(Fdim, hidden, C, n_layers, F.relu, 0.2, 'mean', False)
     model = model.to(dev)
     loss_fcn = torch.nn.CrossEntropyLoss()
-    optimizer = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=0)
+    use_graph = (world == 1) and not args.no_graph
+    optimizer = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=0, capturable=use_graph, fused=True)
+    need = None if args.fetch_all else model.required_inputs(num_hops + 1)
     if world > 1:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu])
     sampler = NeighborSampler(g, B, k, neighbor_type='in', shuffle=True, num_workers=16, num_hops=num_hops,
-                              seed_nodes=subtrain, prefetch=True, seed=rank, copy_out=True)
+                              seed_nodes=subtrain, prefetch=True, seed=rank, copy_out=True, static=use_graph)
     steps_per_epoch = parallel.equalize_steps(len(sampler), device=dev)
     K = args.steps if args.steps is not None else 200
     W = args.warmup
-    trainer = MinibatchTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, overlap=not args.no_overlap)
+    if use_graph:
+        trainer = GraphedTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, need=need)
+        W = max(W, 3 + 2 * len(sampler.slots))           # eager warm-up + one capture per ring slot, all untimed
+    else:
+        trainer = MinibatchTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, overlap=not args.no_overlap,
+                                   need=need)
     trainer.after_first_step = lambda: cacher.auto_cache(g, embed_names, cache_ratio=args.cache_ratio)  # pa_gcn.py:99-100
     model.train()
     it = cycle_batches(sampler, W + K + 1)
@@ -334,8 +344,7 @@ def run():
         cacher.auto_cache(g, embed_names, cache_ratio=args.cache_ratio)
     torch.cuda.synchronize()
     log(f"[bench] rank {rank}: warmup {W} steps + cache fill ({cacher.cached_num} rows) in {time.time()-t0:.1f}s")
-    if cacher.try_num:
-        cacher.get_miss_rate()                                 # reset counters
+    cacher._stats.zero_()                                      # reset the try/miss counters
 
     # ---- timed region ------------------------------------------------------------------------
     cacher.profile = []
@@ -360,6 +369,7 @@ def run():
     assert done == K, (done, K)
     elapsed = parallel.max_over_ranks(elapsed, device=dev)
     prof, cacher.profile = cacher.profile, None
+    tries_total, miss_total = cacher._stats.tolist()          # accumulated on the device by k_split
     miss_rate = cacher.get_miss_rate()
     ms_per_step = elapsed * 1e3 / K
     epoch_s = ms_per_step * steps_per_epoch / 1e3
@@ -367,11 +377,15 @@ def run():
     # ---- in-loop gather kernel time (HIP events on the load stream) ---------------------------
     g_ms, g_bytes, g_rows = [], [], []
     lib = L.load()
+    n_launch = max(1, len(prof))
     for timer, R, m in prof:
         v = ctypes.c_float()
         L.check(lib.pg_timer_elapsed_ms(timer, ctypes.byref(v)))
         lib.pg_timer_destroy(timer)
-        m = 0 if m is None else m
+        # rows really looked up / missed per launch (padding ids of the fixed-shape path do not count;
+        # in zero-copy mode the per-launch miss count never reaches the host): device-side totals / launches
+        R = tries_total / n_launch
+        m = miss_total / n_launch
         g_ms.append(v.value)
         g_rows.append(R)
         g_bytes.append((R - m) * 8 * D + R * 17 + m * 12)      # algorithmic bytes of one launch
@@ -407,7 +421,9 @@ def run():
                                    f"batch {B}, fan-out {k}, {int(args.cache_ratio*100)}% hot-degree cache, "
                                    f"{('dg(hops=%d)' % args.dg_hops) if world > 1 else '1naive'} partition x{world}, closure hops {num_hops}",
                        "steps_per_epoch": steps_per_epoch, "epoch_time_extrapolated_from_steps": K,
-                       "miss_mode": args.miss_mode, "overlap": not args.no_overlap, "partition_vertices": Vs},
+                       "miss_mode": args.miss_mode, "overlap": not args.no_overlap, "partition_vertices": Vs,
+                       "hip_graph_step": use_graph,
+                       "fetch": "all layers+fields (reference)" if need is None else "only what the model reads"},
             "cache_hit_pct": 100.0 * (1.0 - miss_rate),
             "feat_gather_GBps": (micro[max(micro)]["GBps"] if micro else achieved),
             "seeds_per_s": seeds_total / elapsed,

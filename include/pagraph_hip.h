@@ -77,7 +77,7 @@ int pg_slot_map_export(const int32_t* slot_map, int64_t node_num, uint8_t* gpu_f
                        int64_t* localid2cacheid, pg_stream_t stream);
 
 /* storage.py:176-204 (fetch_data inner loop, all layers in ONE launch).
- * For every r in [0,n): id = ids[r]; s = slot_map[id];
+ * For every r in [0,n): id = ids[r] (id < 0 = padding, row skipped); s = slot_map[id];
  *   s >= 0 : out_f[r,:] = cache_f[s,:]  for every field f            (storage.py:191-193)
  *   s <  0 : row r is appended to the miss list:
  *            miss_pos[j] = r, miss_fullid[j] = nid_map[id]           (storage.py:117,182)
@@ -87,10 +87,12 @@ int pg_slot_map_export(const int32_t* slot_map, int64_t node_num, uint8_t* gpu_f
  * miss_pos / miss_fullid need capacity n.  They may be pinned-host pointers
  * so the host can read them after the stream reaches this point.
  * slot_scratch: optional device int32[n]; when given, the split pass stores every row's slot
- * there (coalesced) and the copy pass reads it back instead of repeating the random lookup.  */
+ * there (coalesced) and the copy pass reads it back instead of repeating the random lookup.
+ * stats: optional device uint64[2], ACCUMULATED (not reset): [0] += rows looked up (ids >= 0),
+ * [1] += misses — the reference's try_num / miss_num (storage.py:219-221) without a host sync. */
 int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
                    const pg_field_t* fields, int n_fields, int32_t* miss_pos, int64_t* miss_fullid,
-                   int32_t* miss_count, int32_t* slot_scratch, pg_stream_t stream);
+                   int32_t* miss_count, int32_t* slot_scratch, uint64_t* stats, pg_stream_t stream);
 
 /* storage.py:207-216 (fetch_from_cache): full cache, slot == local id. out_f[r,:] = cache_f[ids[r],:] */
 int pg_gather_rows_full(const int64_t* ids, int64_t n, const pg_field_t* fields, int n_fields,
@@ -133,6 +135,12 @@ typedef struct pg_nodeflow_desc {
   int64_t cap_nodes;
   int64_t blk_indptr_off[PG_MAX_LAYERS];
   int64_t blk_src_off[PG_MAX_LAYERS];
+  int32_t padded;          /* 0: layers concatenated back to back (the DGL layout).
+                              1: fixed-shape layout for hipGraph replay — layer l starts at the sum of the
+                                 capacities of layers < l (pg_sampler_capacity), unused entries are -1, and
+                                 layer_offsets holds those fixed offsets; sizes_pinned still has the real sizes.
+                              Either way every block's indptr is padded with empty rows up to its capacity. */
+  int32_t _pad;
 } pg_nodeflow_desc_t;
 
 /* indptr/indices: CSC of the partition (in-neighbours of v = indices[indptr[v]:indptr[v+1]],
@@ -140,7 +148,8 @@ typedef struct pg_nodeflow_desc {
 int pg_sampler_create(int64_t num_vertices, const int64_t* indptr, const int32_t* indices,
                       int32_t max_seeds, int32_t fanout, int32_t num_hops, pg_sampler_t** out);
 int pg_sampler_destroy(pg_sampler_t* s);
-/* worst-case capacities for one batch: total nodes over all layers, per-block dst rows and edges */
+/* worst-case capacities for one batch: total nodes over all layers, per-block dst rows and edges
+ * (layer l's capacity = cap_blk_rows[l-1] for l >= 1, cap_blk_edges[0] for l = 0) */
 int pg_sampler_capacity(const pg_sampler_t* s, int64_t* cap_nodes, int64_t* cap_blk_rows /*[num_hops]*/,
                         int64_t* cap_blk_edges /*[num_hops]*/);
 /* one minibatch: seeds (device int64[n_seeds], unique) -> NodeFlow. RNG key (seed, epoch, batch). */

@@ -27,6 +27,8 @@
 //   * stores are non-temporal: the gathered frame is consumed by the next
 //     kernel once and must not evict cache rows from L2/MALL (+7..10 %);
 //   * narrow fields (e.g. 'norm', dim 1) are copied lane-per-row.
+#include <cstdlib>
+
 #include "pg_common.h"
 
 namespace pg {
@@ -98,8 +100,9 @@ __global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ ids, 
                                                const int32_t* __restrict__ slot_map,
                                                const int64_t* __restrict__ nid_map, int32_t* __restrict__ miss_pos,
                                                int64_t* __restrict__ miss_fullid, int32_t* __restrict__ miss_count,
-                                               int32_t* __restrict__ slots_out) {
-  __shared__ int32_t s_wave[4];
+                                               int32_t* __restrict__ slots_out,
+                                               unsigned long long* __restrict__ stats) {
+  __shared__ int32_t s_wave[4], s_valid[4];
   __shared__ int32_t s_base;
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
   const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -107,16 +110,24 @@ __global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ ids, 
   bool miss = false;
   if (row < n) {
     id = ids[row];
-    const int32_t s = slot_map[id];
-    miss = s < 0;
+    const int32_t s = id < 0 ? -2 : slot_map[id];   // id < 0: padding of a fixed-shape NodeFlow
+    miss = s == -1;
     if (slots_out) slots_out[row] = s;  // coalesced; k_gather then skips the random slot_map lookup
   }
   const unsigned long long mmask = __ballot(miss);
-  if (lane == 0) s_wave[w] = (int32_t)__popcll(mmask);
+  const unsigned long long vmask = __ballot(row < n && id >= 0);
+  if (lane == 0) {
+    s_wave[w] = (int32_t)__popcll(mmask);
+    s_valid[w] = (int32_t)__popcll(vmask);
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     const int32_t tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
     s_base = tot ? atomicAdd(miss_count, tot) : 0;
+    if (stats) {  // storage.py:219-221 log_miss_rate, kept on the device
+      atomicAdd(&stats[0], (unsigned long long)(s_valid[0] + s_valid[1] + s_valid[2] + s_valid[3]));
+      if (tot) atomicAdd(&stats[1], (unsigned long long)tot);
+    }
   }
   __syncthreads();
   if (miss) {
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(const GatherArgs a) {
         slot = a.slots[row0 + t];
       } else {
         id = a.ids[row0 + t];
-        slot = FULL ? (int32_t)id : a.slot_map[id];
+        slot = id < 0 ? -2 : (FULL ? (int32_t)id : a.slot_map[id]);
       }
       s_slot[t] = slot;
     }
@@ -191,7 +202,12 @@ __global__ __launch_bounds__(256) void k_scatter(const float* __restrict__ stage
   }
 }
 
-// zero-copy miss path: out[pos[j], :] = table_pinned[fullid[j], :] read over PCIe
+// zero-copy miss path: out[pos[j], :] = table_pinned[fullid[j], :] read over PCIe.
+// Launched with a SMALL grid on purpose: the waves spend microseconds stalled on PCIe reads, and
+// a one-wave-per-row grid starves the compute stream that is supposed to overlap with it
+// (measured, tools/exp_overlap.py: 8.4 K rows, 405 us alone; + 155 us of GEMMs on another stream
+// = 474 us with 2100 blocks, 431 us with 128 blocks, 389 us with 48 blocks; PCIe stays saturated
+// at ~52 GB/s down to 32 blocks and collapses at 16). 48 blocks x 4 waves x 2 rows in flight.
 template <int VEC>
 __global__ __launch_bounds__(256) void k_scatter_host(const float* __restrict__ table,
                                                       int64_t table_stride,
@@ -204,10 +220,19 @@ __global__ __launch_bounds__(256) void k_scatter_host(const float* __restrict__ 
   const int64_t nn = n_dev ? (int64_t)*n_dev : n;
   const int64_t waves = (int64_t)gridDim.x * (blockDim.x / kWave);
   const int pieces = dim / VEC;
-  for (int64_t j = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; j < nn; j += waves) {
-    const V* src = reinterpret_cast<const V*>(table + fullid[j] * table_stride);
-    V* dst = reinterpret_cast<V*>(out + (int64_t)pos[j] * out_stride);
-    for (int c = lane; c < pieces; c += kWave) dst[c] = src[c];
+  for (int64_t j = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; j < nn; j += 2 * waves) {
+    const int64_t j2 = j + waves;
+    const bool two = j2 < nn;
+    const V* src0 = reinterpret_cast<const V*>(table + fullid[j] * table_stride);
+    const V* src1 = reinterpret_cast<const V*>(table + fullid[two ? j2 : j] * table_stride);
+    V* dst0 = reinterpret_cast<V*>(out + (int64_t)pos[j] * out_stride);
+    V* dst1 = reinterpret_cast<V*>(out + (int64_t)pos[two ? j2 : j] * out_stride);
+    for (int c = lane; c < pieces; c += kWave) {
+      const V a = src0[c];
+      const V b = src1[c];
+      dst0[c] = a;
+      if (two) dst1[c] = b;
+    }
   }
 }
 
@@ -312,7 +337,7 @@ int pg_slot_map_export(const int32_t* slot_map, int64_t node_num, uint8_t* gpu_f
 
 int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
                    const pg_field_t* fields, int n_fields, int32_t* miss_pos, int64_t* miss_fullid,
-                   int32_t* miss_count, int32_t* slot_scratch, pg_stream_t stream) {
+                   int32_t* miss_count, int32_t* slot_scratch, uint64_t* stats, pg_stream_t stream) {
   if (n < 0 || n > INT32_MAX || !miss_count) return PG_ERR_INVALID;
   hipStream_t st = as_stream(stream);
   PG_HIP(hipMemsetAsync(miss_count, 0, sizeof(int32_t), st));
@@ -327,7 +352,8 @@ int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const
   int rc = fill_args(a, fields, n_fields, false);
   if (rc != PG_OK) return rc;
   hipLaunchKernelGGL(k_split, dim3((unsigned)ceil_div<int64_t>(n, 256)), dim3(256), 0, st, ids, n, slot_map, nid_map,
-                     miss_pos, miss_fullid, miss_count, slot_scratch);
+                     miss_pos, miss_fullid, miss_count, slot_scratch,
+                     reinterpret_cast<unsigned long long*>(stats));
   PG_LAUNCH_CHECK();
   return launch_gather<false>(a, st);
 }
@@ -368,7 +394,12 @@ int pg_scatter_rows_from_host(const float* table, int64_t table_stride, const in
   if (n_max == 0) return PG_OK;
   if (!table || !pos || !fullid || !out) return PG_ERR_INVALID;
   hipStream_t st = as_stream(stream);
-  const int grid = grid_1d(n_max, 4, 8192);
+  static const int kHostBlocks = [] {
+    const char* e = getenv("PG_SCATTER_HOST_BLOCKS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 48;
+  }();
+  const int grid = grid_1d(n_max, 8, kHostBlocks);
   if (dim % 4 == 0 && out_stride % 4 == 0 && table_stride % 4 == 0 && aligned(table, 16) && aligned(out, 16))
     hipLaunchKernelGGL(k_scatter_host<4>, dim3(grid), dim3(256), 0, st, table, table_stride, pos, fullid, n_max,
                        n_dev, dim, out, out_stride);

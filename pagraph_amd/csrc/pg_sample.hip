@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
 __global__ __launch_bounds__(kScanThreads) void k_scan_cnt(const int32_t* __restrict__ cnt,
                                                            const int32_t* __restrict__ n_dev,
                                                            int32_t* __restrict__ indptr,
-                                                           int32_t* __restrict__ total_out) {
+                                                           int32_t* __restrict__ total_out, int32_t cap_rows) {
   __shared__ int lds[16];
   const int n = *n_dev;
   int carry = 0;
@@ -135,10 +135,9 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_cnt(const int32_t* __rest
     if (i < n) indptr[i] = carry + ex;
     carry += tot;
   }
-  if (threadIdx.x == 0) {
-    indptr[n] = carry;
-    *total_out = carry;
-  }
+  // rows n..cap_rows are empty: a fixed-shape consumer (hipGraph replay) may run over all cap_rows
+  for (int i = n + threadIdx.x; i <= cap_rows; i += kScanThreads) indptr[i] = carry;
+  if (threadIdx.x == 0) *total_out = carry;
 }
 
 // ---- bitmap -> ascending ids ------------------------------------------------
@@ -241,27 +240,36 @@ struct PackArgs {
   int32_t* sizes_pinned;
   int64_t cap_nodes;
   int32_t num_layers;
+  int32_t padded;                     // 1: layer l starts at pad_off[l], unused entries = -1
+  int32_t pad_off[PG_MAX_LAYERS + 1];
 };
 
 __global__ __launch_bounds__(256) void k_pack(const PackArgs a) {
-  int off[PG_MAX_LAYERS + 1];
+  int off[PG_MAX_LAYERS + 1], cnt[PG_MAX_LAYERS];
   off[0] = 0;
 #pragma unroll
-  for (int l = 0; l < PG_MAX_LAYERS; ++l) off[l + 1] = off[l] + (l < a.num_layers ? *a.layer_cnt[l] : 0);
-  const int64_t total = off[PG_MAX_LAYERS];
+  for (int l = 0; l < PG_MAX_LAYERS; ++l) {
+    cnt[l] = l < a.num_layers ? *a.layer_cnt[l] : 0;
+    off[l + 1] = a.padded ? a.pad_off[l < a.num_layers ? l + 1 : a.num_layers] : off[l] + cnt[l];
+  }
+  if (a.padded) {
+#pragma unroll
+    for (int l = 0; l < PG_MAX_LAYERS; ++l) off[l] = a.pad_off[l < a.num_layers ? l : a.num_layers];
+  }
+  const int64_t total = a.padded ? a.pad_off[a.num_layers] : off[PG_MAX_LAYERS];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total && i < a.cap_nodes;
        i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t v = 0;
+    int64_t v = -1;
 #pragma unroll
     for (int l = 0; l < PG_MAX_LAYERS; ++l)
-      if (l < a.num_layers && i >= off[l] && i < off[l + 1]) v = a.layer_ids[l][i - off[l]];
+      if (l < a.num_layers && i >= off[l] && i < off[l] + cnt[l]) v = a.layer_ids[l][i - off[l]];
     a.node_mapping[i] = v;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
 #pragma unroll
     for (int l = 0; l < PG_MAX_LAYERS; ++l) {
-      if (l <= a.num_layers) a.layer_offsets[l] = off[l];
-      if (l < a.num_layers) a.sizes_pinned[l] = off[l + 1] - off[l];
+      if (l <= a.num_layers) a.layer_offsets[l] = a.padded ? a.pad_off[l] : off[l];
+      if (l < a.num_layers) a.sizes_pinned[l] = cnt[l];
       if (l + 1 < a.num_layers) a.sizes_pinned[PG_MAX_LAYERS + l] = *a.blk_edges[l];
     }
     __threadfence_system();
@@ -418,7 +426,8 @@ int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, ui
     PG_LAUNCH_CHECK();
     int32_t* indptr_b = o->blk_indptr + o->blk_indptr_off[b];
     int32_t* src_b = o->blk_src + o->blk_src_off[b];
-    hipLaunchKernelGGL(k_scan_cnt, dim3(1), dim3(kScanThreads), 0, st, s->cnt, lcnt + b + 1, indptr_b, ecnt + b);
+    hipLaunchKernelGGL(k_scan_cnt, dim3(1), dim3(kScanThreads), 0, st, s->cnt, lcnt + b + 1, indptr_b, ecnt + b,
+                       (int32_t)cap_dst);
     PG_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bm_count, dim3(s->n_bm_blocks), dim3(256), 0, st, s->bitmap, s->n_words, s->partial);
     PG_LAUNCH_CHECK();
@@ -443,6 +452,9 @@ int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, ui
   for (int b = 0; b < L; ++b) p.blk_edges[b] = ecnt + b;
   p.node_mapping = o->node_mapping; p.layer_offsets = o->layer_offsets; p.sizes_pinned = o->sizes_pinned;
   p.cap_nodes = o->cap_nodes; p.num_layers = L + 1;
+  p.padded = o->padded ? 1 : 0;
+  p.pad_off[0] = 0;
+  for (int l = 0; l <= L; ++l) p.pad_off[l + 1] = p.pad_off[l] + (int32_t)s->cap[l];
   hipLaunchKernelGGL(k_pack, dim3(grid_for(need, 256, 1024)), dim3(256), 0, st, p);
   PG_LAUNCH_CHECK();
   return PG_OK;

@@ -44,6 +44,18 @@ def _stack(in_feats, n_hidden, n_classes, n_layers, activation, preprocess, test
 
 class _GCNBase(nn.Module):
     reducer = fn.mean
+    uses_norm = False
+
+    def required_inputs(self, num_layers):
+        """{layer: [fields]} this model reads from the NodeFlow frames (for fetch_data(need=...)):
+        training GCN touches only layer 0's 'features' (gcn_nssc.py:64,81); inference also multiplies
+        every destination layer by 'norm' (gcn_nssc.py:16-17)."""
+        need = {0: ['features']}
+        if self.uses_norm:
+            for l in range(1, num_layers):
+                need[l] = ['norm']
+            need = {l: need.get(l, []) for l in range(num_layers)}
+        return need
 
     def _input_transform(self, nf):
         """gcn_nssc.py:80-90: dense transform of the raw features before any aggregation"""
@@ -87,6 +99,7 @@ class GCNSampling(_GCNBase):
 class GCNInfer(_GCNBase):
     """gcn_nssc.py:103-164 — sum aggregation scaled by `norm` inside NodeUpdate(test=True)"""
     reducer = fn.sum
+    uses_norm = True
 
     def __init__(self, in_feats, n_hidden, n_classes, n_layers, activation, preprocess=False):
         super().__init__()

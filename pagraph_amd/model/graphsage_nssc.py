@@ -57,6 +57,11 @@ class GraphSageSampling(nn.Module):
             self.layers.append(NodeUpdate(n_hidden, n_hidden, activation, concat=(i == n_layers - 1)))
         self.layers.append(NodeUpdate(2 * n_hidden, n_classes))
 
+    def required_inputs(self, num_layers):
+        """every layer's 'features' (+ 'neigh' under preprocess) is read (graphsage_nssc.py:75-90)"""
+        f = ['features', 'neigh'] if self.preprocess else ['features']
+        return {l: list(f) for l in range(num_layers)}
+
     def forward(self, nf):
         L = nf.num_layers
         if self.preprocess:

@@ -110,6 +110,15 @@ class NodeFlow:
         self.blk_src = blk_src
         self._node_frames = [None] * self.num_layers
         self.layers = _Layers(self)
+        self.padded = False      # True: fixed-shape layout, ids < 0 are padding (sampler static=True)
+
+    def actual_sizes(self):
+        """(layer sizes, block edge counts) of a padded NodeFlow — synchronises with the sampler"""
+        slot = self._slot
+        slot.ready.synchronize()
+        z = slot.sizes.tolist()
+        from .. import _lib as L
+        return z[:self.num_layers], z[L.PG_MAX_LAYERS:L.PG_MAX_LAYERS + self.num_blocks]
 
     def layer_size(self, i):
         i %= self.num_layers

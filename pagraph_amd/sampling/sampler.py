@@ -16,12 +16,15 @@ from .nodeflow import NodeFlow
 
 
 class _Slot:
-    def __init__(self, lib, handle, hops, device):
+    def __init__(self, lib, handle, hops, device, padded=False):
         cap_nodes = L.c_i64()
         rows = (L.c_i64 * L.PG_MAX_LAYERS)()
         edges = (L.c_i64 * L.PG_MAX_LAYERS)()
         L.check(lib.pg_sampler_capacity(handle, ctypes.byref(cap_nodes), rows, edges), "pg_sampler_capacity")
         self.cap_nodes = cap_nodes.value
+        # per-layer vertex capacities, layer 0 first: layer l >= 1 is block l-1's destination side
+        self.layer_caps = [self.cap_nodes - sum(rows[b] for b in range(hops))] + [rows[b] for b in range(hops)]
+        self.edge_caps = [edges[b] for b in range(hops)]
         self.node_mapping = torch.empty(self.cap_nodes, dtype=torch.int64, device=device)
         self.layer_offsets = torch.empty(L.PG_MAX_LAYERS + 1, dtype=torch.int32, device=device)
         self.ip_off, self.src_off = [], []
@@ -44,6 +47,7 @@ class _Slot:
         d.blk_src = self.blk_src.data_ptr()
         d.sizes_pinned = self.sizes.data_ptr()
         d.cap_nodes = self.cap_nodes
+        d.padded = 1 if padded else 0
         for b in range(hops):
             d.blk_indptr_off[b] = self.ip_off[b]
             d.blk_src_off[b] = self.src_off[b]
@@ -52,7 +56,7 @@ class _Slot:
 
 class NeighborSampler:
     def __init__(self, g, batch_size, expand_factor, num_hops=1, neighbor_type='in', seed_nodes=None,
-                 shuffle=False, num_workers=1, prefetch=False, seed=0, copy_out=True):
+                 shuffle=False, num_workers=1, prefetch=False, seed=0, copy_out=True, static=False):
         if neighbor_type != 'in':
             raise L.PgError("only neighbor_type='in' is on the hot path (pa_gcn.py:72)")
         self.lib = L.load()
@@ -64,6 +68,8 @@ class NeighborSampler:
         self.seed = int(seed)
         self.prefetch = bool(prefetch)
         self.copy_out = copy_out
+        # static=True: fixed-shape NodeFlows (padded layers, no host sync per batch) for hipGraph replay
+        self.static = bool(static)
         seeds = torch.as_tensor(seed_nodes if seed_nodes is not None else torch.arange(g.number_of_nodes()))
         seeds = seeds.to(torch.int64)
         if shuffle:
@@ -80,7 +86,11 @@ class NeighborSampler:
                     "pg_sampler_create")
         self.handle = h
         self.stream = torch.cuda.Stream(device=self.device)
-        self.slots = [_Slot(self.lib, self.handle, self.num_hops, self.device) for _ in range(3)]
+        # stream on which the consumer finishes with a NodeFlow (None = current stream at hand-back);
+        # a ring slot is re-sampled only after the event recorded there
+        self.consumer_stream = None
+        self.slots = [_Slot(self.lib, self.handle, self.num_hops, self.device, padded=self.static)
+                      for _ in range(4 if self.static else 3)]
 
     def __del__(self):
         try:
@@ -104,9 +114,26 @@ class NeighborSampler:
                                                self.seed, epoch, b, ctypes.byref(slot.desc),
                                                L.stream_ptr(self.stream)), "pg_sampler_sample")
         slot.ready.record(self.stream)
+        slot.n_seeds = n
         return slot
 
+    def _finalize_static(self, slot, n_seeds):
+        """no host sync: the consumer's stream waits on the sampler's event, shapes are the capacities"""
+        torch.cuda.current_stream(self.device).wait_event(slot.ready)
+        offs = [0]
+        for c in slot.layer_caps:
+            offs.append(offs[-1] + c)
+        ips = [slot.blk_indptr[slot.ip_off[b]:slot.ip_off[b] + slot.layer_caps[b + 1] + 1] for b in range(self.num_hops)]
+        srcs = [slot.blk_src[slot.src_off[b]:slot.src_off[b] + slot.edge_caps[b]] for b in range(self.num_hops)]
+        nf = NodeFlow(slot.node_mapping[:offs[-1]], offs, ips, srcs)
+        nf.padded = True
+        nf.num_seeds = n_seeds
+        nf._slot = slot
+        return nf
+
     def _finalize(self, slot):
+        if self.static:
+            return self._finalize_static(slot, slot.n_seeds)
         slot.ready.synchronize()  # host needs the layer sizes (4 ints, written to pinned memory by k_pack)
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(slot.ready)
@@ -142,7 +169,7 @@ class NeighborSampler:
                 pending = self._enqueue(b + 1, epoch)
             nf = self._finalize(slot)
             yield nf
-            slot.free.record(torch.cuda.current_stream(self.device))
+            slot.free.record(self.consumer_stream or torch.cuda.current_stream(self.device))
             slot.free_recorded = True
             if b + 1 < nb and not self.prefetch:
                 pending = self._enqueue(b + 1, epoch)

@@ -100,7 +100,7 @@ class GraphCacheServer:
         self._staging = {}               # name -> pinned fp32 [cap, dim]
         self._staged_dev = {}            # name -> device fp32 [cap, dim]
         self._event = torch.cuda.Event()
-        self._pending_counts = []        # zero-copy mode: (pinned count tensor, event, rows)
+        self._stats = torch.zeros(2, dtype=torch.int64, device=self.device)   # [try, miss], accumulated by k_split
         # bench.py: when a list, every gather launch is bracketed by HIP events on its own stream
         # and (timer_handle, rows, misses_or_None) is appended
         self.profile = None
@@ -246,22 +246,40 @@ class GraphCacheServer:
         self._cap = cap
 
     # -- storage.py:157-204 ---------------------------------------------------
-    def fetch_data(self, nodeflow):
+    def fetch_data(self, nodeflow, out=None, need=None):
         """Fill nodeflow._node_frames[i][name] for every layer and field: hits from the HBM
         cache, misses from the host store. One gather launch for all layers; rows of layer i are
-        the slice [offsets[i], offsets[i+1]) of one [R, dim] buffer per field."""
+        the slice [offsets[i], offsets[i+1]) of one [R, dim] buffer per field.
+        `out` (optional): {name: preallocated [>=R, dim] tensor} to gather into — the fixed-shape
+        path (hipGraph replay) passes its static frames; padding ids (< 0) leave their rows untouched.
+        `need` (optional, SURVEY §8f-2 "fetch only what the model reads"): {layer index: [field names]};
+        rows of layers / fields the model never reads are neither gathered nor fetched over PCIe
+        (GCN training reads only layer 0's 'features', gcn_nssc.py:64). Default: everything, as the
+        reference does."""
         if self.full_cached:
-            self.fetch_from_cache(nodeflow)
+            self.fetch_from_cache(nodeflow, out=out)
             return
         with torch.autograd.profiler.record_function('cache-idxload'):
             nf_nids = nodeflow._node_mapping.tousertensor().to(self.device, torch.int64)
             offsets = nodeflow._layer_offsets
-        R = nf_nids.numel()
         names = list(self.dims)
+        row_lo = 0
+        if need is not None:
+            # the needed layers form a prefix-contiguous row range [lo, hi) of the NodeFlow
+            layers = sorted(need)
+            assert layers == list(range(layers[0], layers[-1] + 1)), "needed layers must be contiguous"
+            wanted = set(n for l in layers for n in need[l])
+            names = [n for n in names if n in wanted]
+            row_lo, row_hi = offsets[layers[0]], offsets[layers[-1] + 1]
+            nf_nids = nf_nids[row_lo:row_hi]
+            if out is not None:
+                out = {n: out[n][row_lo:row_hi] for n in names}
+        R = nf_nids.numel()
         stream = torch.cuda.current_stream(self.device)
         sp = L.stream_ptr(stream)
         with torch.autograd.profiler.record_function('cache-allocate'):
-            out = {name: torch.empty((R, self.dims[name]), dtype=torch.float32, device=self.device) for name in names}
+            if out is None:
+                out = {name: torch.empty((R, self.dims[name]), dtype=torch.float32, device=self.device) for name in names}
             self._ensure_capacity(R)
         with torch.autograd.profiler.record_function('cache-gpu'):
             fields, nf = L.make_fields(
@@ -275,7 +293,8 @@ class GraphCacheServer:
                 L.check(self.lib.pg_timer_start(timer, sp), "pg_timer_start")
             L.check(self.lib.pg_gather_rows(L.ptr(nf_nids), R, L.ptr(self.slot_map), L.ptr(self.nid_map), fields, nf,
                                             L.ptr(self._miss_pos), L.ptr(self._miss_fullid), L.ptr(self._miss_count),
-                                            L.ptr(self._slots), sp), "pg_gather_rows")
+                                            L.ptr(self._slots), L.ptr(self._stats) if self.log else None, sp),
+                    "pg_gather_rows")
             if timer is not None:
                 L.check(self.lib.pg_timer_stop(timer, sp), "pg_timer_stop")
                 self.profile.append([timer, R, None])
@@ -287,12 +306,6 @@ class GraphCacheServer:
                         L.ptr(tab), tab.stride(0), L.ptr(self._miss_pos), L.ptr(self._miss_fullid), R,
                         L.ptr(self._miss_count), self.dims[name], L.ptr(out[name]), out[name].stride(0), sp),
                         "pg_scatter_rows_from_host")
-                if self.log:
-                    cnt = torch.empty(1, dtype=torch.int32).pin_memory()
-                    cnt.copy_(self._miss_count, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record(stream)
-                    self._pending_counts.append((cnt, ev, R))
             else:
                 self._miss_count_h.copy_(self._miss_count, non_blocking=True)
                 self._event.record(stream)
@@ -313,23 +326,26 @@ class GraphCacheServer:
                     # the pinned staging buffers are reused next step: the copy must have left them
                     self._event.record(stream)
                     self._event.synchronize()
-                if self.log:
-                    self.log_miss_rate(m, R)
                 if self.profile:
                     self.profile[-1][2] = m
         with torch.autograd.profiler.record_function('cache-asign'):
             for i in range(nodeflow.num_layers):
-                nodeflow._node_frames[i] = {name: out[name][offsets[i]:offsets[i + 1]] for name in names}
+                if need is not None and i not in need:
+                    nodeflow._node_frames[i] = {}
+                    continue
+                keep = names if need is None else [n for n in names if n in need[i]]
+                nodeflow._node_frames[i] = {name: out[name][offsets[i] - row_lo:offsets[i + 1] - row_lo] for name in keep}
 
     # -- storage.py:207-216 ---------------------------------------------------
-    def fetch_from_cache(self, nodeflow):
+    def fetch_from_cache(self, nodeflow, out=None):
         with torch.autograd.profiler.record_function('cache-idxload'):
             nf_nids = nodeflow._node_mapping.tousertensor().to(self.device, torch.int64)
             offsets = nodeflow._layer_offsets
         R = nf_nids.numel()
         names = list(self.gpu_fix_cache)
         with torch.autograd.profiler.record_function('cache-gpu'):
-            out = {name: torch.empty((R, self.dims[name]), dtype=torch.float32, device=self.device) for name in names}
+            if out is None:
+                out = {name: torch.empty((R, self.dims[name]), dtype=torch.float32, device=self.device) for name in names}
             fields, nf = L.make_fields((self.gpu_fix_cache[name], out[name], self.dims[name],
                                         self.gpu_fix_cache[name].stride(0), out[name].stride(0)) for name in names)
             L.check(self.lib.pg_gather_rows_full(L.ptr(nf_nids), R, fields, nf,
@@ -338,7 +354,7 @@ class GraphCacheServer:
         for i in range(nodeflow.num_layers):
             nodeflow._node_frames[i] = {name: out[name][offsets[i]:offsets[i + 1]] for name in names}
         if self.log:
-            self.log_miss_rate(0, R)
+            self._stats[0] += int((nf_nids >= 0).sum()) if getattr(nodeflow, 'padded', False) else R
 
     # -- storage.py:219-227 ---------------------------------------------------
     def log_miss_rate(self, miss_num, total_num):
@@ -346,10 +362,10 @@ class GraphCacheServer:
         self.miss_num += miss_num
 
     def get_miss_rate(self):
-        for cnt, ev, rows in self._pending_counts:
-            ev.synchronize()
-            self.log_miss_rate(int(cnt[0]), rows)
-        self._pending_counts = []
+        # the per-launch counters live on the device (pg_gather_rows `stats`): one sync here, none per step
+        t, m = self._stats.tolist()
+        self._stats.zero_()
+        self.log_miss_rate(m, t)
         miss_rate = float(self.miss_num) / self.try_num
         self.miss_num = 0
         self.try_num = 0

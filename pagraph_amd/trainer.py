@@ -29,7 +29,8 @@ class Prepared:
 
 
 class MinibatchTrainer:
-    def __init__(self, model, loss_fcn, optimizer, cacher, sampler, labels, device, overlap=True):
+    def __init__(self, model, loss_fcn, optimizer, cacher, sampler, labels, device, overlap=True, need=None):
+        self.need = need             # fetch_data(need=...): None = every layer and field, like the reference
         self.model, self.loss_fcn, self.optimizer = model, loss_fcn, optimizer
         self.cacher, self.sampler, self.labels = cacher, sampler, labels
         self.device = device
@@ -45,14 +46,14 @@ class MinibatchTrainer:
         p.nf = nf
         if self.load_stream is None:
             with torch.autograd.profiler.record_function('gpu-load'):
-                self.cacher.fetch_data(nf)
+                self.cacher.fetch_data(nf, need=self.need)
                 p.label = self.labels[nf.layer_parent_nid(-1)]
             p.event = None
             return p
         main = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(self.load_stream):
             with torch.autograd.profiler.record_function('gpu-load'):
-                self.cacher.fetch_data(nf)
+                self.cacher.fetch_data(nf, need=self.need)
                 p.label = self.labels[nf.layer_parent_nid(-1)]
             p.event = torch.cuda.Event()
             p.event.record(self.load_stream)
@@ -127,3 +128,132 @@ def cycle_batches(sampler, steps):
                 return
         if not got:
             return
+
+
+class GraphedTrainer:
+    """The same loop with the whole compute step (forward, loss, backward, Adam) replayed as a
+    hipGraph.  Everything between "seed ids" and "logits" has a fixed shape: the sampler emits
+    padded NodeFlows (layer capacities B*k^(L-l), padding ids -1, empty CSR rows), the gather
+    writes into static frames, padded seeds get label -100 (ignored by the loss).  Per step the
+    host enqueues: 1 sampler call, 1 gather (+ miss scatter), 3 tiny label ops, 1 graph replay —
+    and never waits for the GPU.
+
+    One graph per sampler ring slot (the graph holds the addresses of that slot's CSR buffers
+    and of its static frames; batch k computes while k+1 loads and k+2 is sampled).  Parameters
+    and optimizer state are shared by the graphs; the optimizer must be capture-safe
+    (torch.optim.Adam(..., capturable=True)).  Single process only (DDP is left eager)."""
+
+    def __init__(self, model, loss_fcn, optimizer, cacher, sampler, labels, device, warmup_eager=3, need=None):
+        self.need = need
+        assert sampler.static, "GraphedTrainer needs NeighborSampler(static=True)"
+        self.model, self.loss_fcn, self.optimizer = model, loss_fcn, optimizer
+        self.cacher, self.sampler, self.labels = cacher, sampler, labels
+        self.device = device
+        self.load_stream = torch.cuda.Stream(device=device)
+        # eager warm-up, capture and replay all run on ONE non-default stream, so autograd's
+        # AccumulateGrad nodes and the captured graphs agree on the stream
+        self.compute_stream = torch.cuda.Stream(device=device)
+        sampler.consumer_stream = self.compute_stream   # ring slots are recycled after the graph that read them
+        self.slots = {}
+        self.warmup_eager = warmup_eager
+        self.steps_done = 0
+        self.on_step = None
+        self.after_first_step = None
+        self._first_done = False
+        self.last_loss = None
+
+    class _Slot:
+        pass
+
+    def _make_slot(self, nf):
+        s = GraphedTrainer._Slot()
+        R = nf._node_mapping.tousertensor().numel()
+        s.out = {n: torch.zeros((R, d), dtype=torch.float32, device=self.device) for n, d in self.cacher.dims.items()}
+        s.label = torch.full((nf.layer_size(-1),), -100, dtype=torch.int64, device=self.device)
+        s.ready = torch.cuda.Event()
+        s.done = torch.cuda.Event()
+        s.done_recorded = False
+        s.graph = None
+        s.nf = None
+        s.loss = None
+        return s
+
+    def prepare(self, nf):
+        key = id(nf._slot)
+        if key not in self.slots:
+            self.slots[key] = self._make_slot(nf)
+        s = self.slots[key]
+        with torch.cuda.stream(self.load_stream):
+            self.load_stream.wait_event(nf._slot.ready)  # the sampler wrote this NodeFlow on its own stream
+            if s.done_recorded:
+                self.load_stream.wait_event(s.done)      # the graph that read these buffers has finished
+            self.cacher.fetch_data(nf, out=s.out, need=self.need)
+            ids = nf.layer_parent_nid(-1)
+            lab = self.labels[ids.clamp(min=0)]
+            torch.where(ids >= 0, lab, torch.full_like(lab, -100), out=s.label)
+            s.ready.record(self.load_stream)
+        # the static NodeFlow views of a slot are rebuilt per batch but alias the same memory:
+        # keep the first one (the graph captured ITS tensors) and only refresh the frames
+        if s.nf is None:
+            s.nf = nf
+        return s
+
+    def _step_body(self, s):
+        for i in range(s.nf.num_layers):
+            o0, o1 = s.nf._layer_offsets[i], s.nf._layer_offsets[i + 1]
+            s.nf._node_frames[i] = {n: t[o0:o1] for n, t in s.out.items()
+                                    if self.need is None or n in self.need.get(i, ())}
+        pred = self.model(s.nf)
+        loss = self.loss_fcn(pred, s.label)
+        loss.backward()
+        self.optimizer.step()
+        return loss
+
+    def compute(self, s):
+        main = self.compute_stream
+        main.wait_event(s.ready)
+        with torch.cuda.stream(main):
+            if s.graph is not None:
+                s.graph.replay()
+            elif self.steps_done < self.warmup_eager:
+                self.optimizer.zero_grad(set_to_none=True)
+                s.loss = self._step_body(s).detach()
+            else:
+                g = torch.cuda.CUDAGraph()
+                self.optimizer.zero_grad(set_to_none=True)
+                with torch.cuda.graph(g, stream=main):
+                    s.loss = self._step_body(s).detach()
+                s.graph = g
+                g.replay()                                   # capture does not execute
+            loss = s.loss.clone()        # the slot's static loss tensor is overwritten 4 steps later
+        s.done.record(main)
+        s.done_recorded = True
+        # whoever reads the returned loss does so on the caller's stream: order it after this step
+        torch.cuda.current_stream(self.device).wait_event(s.done)
+        self.steps_done += 1
+        self.last_loss = loss
+        return loss
+
+    def run_steps(self, it, steps=None):
+        done = 0
+        nf = next(it, None)
+        if nf is None:
+            return 0
+        cur = self.prepare(nf)
+        while cur is not None:
+            loss = self.compute(cur)
+            done += 1
+            if not self._first_done:
+                self._first_done = True
+                if self.after_first_step is not None:
+                    torch.cuda.synchronize(self.device)
+                    self.after_first_step()
+            nxt = None
+            if steps is None or done < steps:
+                nf = next(it, None)
+                if nf is not None:
+                    nxt = self.prepare(nf)
+            if self.on_step is not None:
+                self.on_step(done, loss)
+            cur = nxt
+        return done

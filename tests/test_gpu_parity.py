@@ -124,11 +124,13 @@ def test_gather_vs_oracle_random(dev, hiplib, oracle, n, F, ratio):
     mfull = torch.empty(n, dtype=torch.int64, device=dev)
     mcnt = torch.zeros(1, dtype=torch.int32, device=dev)
     scratch = torch.empty(n, dtype=torch.int32, device=dev) if n % 2 else None   # both code paths
+    stats = torch.tensor([5, 7], dtype=torch.int64, device=dev)                    # accumulated, not reset
     fields, nf = L.make_fields([(cache, out, F, F, F)])
     L.check(hiplib.pg_gather_rows(L.ptr(d_ids), n, L.ptr(slot), L.ptr(torch.from_numpy(nid_map).to(dev)), fields, nf,
-                                  L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt), L.ptr(scratch), sp))
+                                  L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt), L.ptr(scratch), L.ptr(stats), sp))
     m = int(mcnt.item())
     assert m == st.miss_num
+    assert stats.tolist() == [5 + n, 7 + m]
     pos = mpos[:m].cpu().numpy(); full = mfull[:m].cpu().numpy()
     hit = st.gpu_flag[ids].astype(bool)
     assert np.array_equal(np.sort(pos), np.nonzero(~hit)[0])             # exactly the missing rows
@@ -353,7 +355,7 @@ def test_full_size_gather_properties(dev, hiplib):
     fields, nf = L.make_fields([(cache, out, F, F, F)])
     for _ in range(2):                                                   # idempotent
         L.check(hiplib.pg_gather_rows(L.ptr(ids), R, L.ptr(slot), L.ptr(nid_map), fields, nf, L.ptr(mpos), L.ptr(mfull),
-                                      L.ptr(mcnt), None, sp))
+                                      L.ptr(mcnt), None, None, sp))
     m = int(mcnt.item())
     hit = slot[ids] >= 0
     assert m == int((~hit).sum())
@@ -426,3 +428,67 @@ def test_cli_pipeline_end_to_end(dev, hiplib, tmp_path):
         assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
         assert "Epoch average time" in r.stdout and "Total Time" in r.stdout and "total dims" in r.stdout
         assert "Epoch average miss rate" in r.stdout
+
+
+@pytest.mark.parametrize("mode", ["staged", "zerocopy"])
+def test_fetch_only_what_the_model_reads(dev, hiplib, golden_dir, mode):
+    """fetch_data(need=...) returns, for the requested layers/fields, exactly the rows
+    the reference's full fetch_data returns (golden G1), and touches nothing else"""
+    z = np.load(os.path.join(golden_dir, "g1_fetch_data_F600.npz"))
+    c = _cacher(z, dev, mode)
+    c.log = True
+    nids = torch.from_numpy(z["cached_nids"]).to(dev)
+    c.cache_fix_data(nids, c.get_feat_from_server(nids, ["features", "norm"], to_gpu=True), is_full=False)
+    layers = [z[f"layer{i}_nids"] for i in range(int(z["num_layers"]))]
+    for need in ({0: ["features"]}, {3: ["norm"], 4: ["features", "norm"]}, {1: ["features"], 2: [], 3: ["norm"]}):
+        nf = FakeNF(layers, dev)
+        c.fetch_data(nf, need=need)
+        torch.cuda.synchronize()
+        for i in range(len(layers)):
+            got = nf._node_frames[i]
+            assert sorted(got) == sorted(need.get(i, []))
+            for name in got:
+                assert np.array_equal(got[name].cpu().numpy(), z[f"layer{i}_{name}"]), (need, i, name)
+    # miss accounting covers only the rows that were looked up
+    c.get_miss_rate()
+    nf = FakeNF(layers, dev)
+    c.fetch_data(nf, need={0: ["features"]})
+    t, m = c._stats.tolist()
+    assert t == len(layers[0]) and m == int((~z["state_gpu_flag"][layers[0]]).sum())
+
+
+def test_graphed_trainer_matches_eager(dev, hiplib):
+    """the hipGraph-replayed step (padded fixed-shape NodeFlows) follows the same loss trajectory as
+    the eager reference-style loop on the same seeds (dropout off => deterministic up to fp32 atomics)"""
+    import torch.nn.functional as Fn
+    from pagraph_amd.model import GCNSampling
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    from pagraph_amd.trainer import GraphedTrainer, MinibatchTrainer, cycle_batches
+    rng = np.random.default_rng(5)
+    V, Fdim, C, B = 5000, 64, 5, 500
+    adj = _rand_csc(rng, V, 30000)
+    g = DeviceGraph(adj)
+    feats = rng.standard_normal((V, Fdim)).astype(np.float32)
+    labels = torch.from_numpy(rng.integers(0, C, V)).to(dev)
+    train = np.arange(0, V, 2, dtype=np.int64)          # 2500 seeds: 5 full batches, no short batch
+    losses = {}
+    for mode in ("eager", "graph"):
+        store = HostFeatureStore({"features": torch.from_numpy(feats)})
+        c = GraphCacheServer(store, V, torch.arange(V), 0, miss_mode="zerocopy")
+        c.init_field(["features"])
+        c.auto_cache(g, ["features"], cache_ratio=0.4)
+        torch.manual_seed(0)
+        model = GCNSampling(Fdim, 16, C, 1, Fn.relu, 0.0).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=(mode == "graph"))
+        smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=True, num_hops=2, seed_nodes=train, prefetch=True,
+                              seed=9, static=(mode == "graph"))
+        cls = GraphedTrainer if mode == "graph" else MinibatchTrainer
+        tr = cls(model, torch.nn.CrossEntropyLoss(), opt, c, smp, labels, dev, need=model.required_inputs(3))
+        out = []
+        tr.on_step = lambda step, loss: out.append(loss.detach().clone())
+        tr.run_steps(cycle_batches(smp, 20), 20)
+        torch.cuda.synchronize()
+        losses[mode] = torch.stack(out).cpu().numpy()
+    assert np.allclose(losses["eager"], losses["graph"], rtol=2e-4, atol=2e-5), (losses["eager"], losses["graph"])
+    assert losses["graph"][-1] < losses["graph"][0]
