@@ -191,15 +191,15 @@ def gather_microbench(cacher, g, dev, rows_list=(42000, 1 << 20)):
         slots = torch.empty(R, dtype=torch.int32, device=dev)
         fields, nf = L.make_fields((cacher.gpu_fix_cache[n], out[n], cacher.dims[n], cacher.gpu_fix_cache[n].stride(0),
                                     out[n].stride(0)) for n in names)
-        call = lambda: L.check(lib.pg_gather_rows(L.ptr(ids), R, L.ptr(cacher.slot_map), L.ptr(cacher.nid_map), fields,
-                                                  nf, L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt), L.ptr(slots), None, sp))
+        call = lambda tmr=None: L.check(lib.pg_gather_rows(L.ptr(ids), R, L.ptr(cacher.slot_map), L.ptr(cacher.nid_map), fields,
+                                                  nf, L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt), L.ptr(slots), None, tmr, sp))
         for _ in range(3):
             call()
         reps = 20
         timers = []
         for _ in range(reps):
             t = L.vp(); L.check(lib.pg_timer_create(ctypes.byref(t)))
-            L.check(lib.pg_timer_start(t, sp)); call(); L.check(lib.pg_timer_stop(t, sp))
+            call(t)
             timers.append(t)
         ms = []
         for t in timers:
@@ -316,10 +316,10 @@ def run():
         model = GraphSageSampling(Fdim, hidden, C, n_layers, F.relu, 0.2, 'mean', False)
     model = model.to(dev)
     loss_fcn = torch.nn.CrossEntropyLoss()
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = not args.no_graph
     optimizer = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=0, capturable=use_graph, fused=True)
     need = None if args.fetch_all else model.required_inputs(num_hops + 1)
-    if world > 1:
+    if world > 1 and not use_graph:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu])
     sampler = NeighborSampler(g, B, k, neighbor_type='in', shuffle=True, num_workers=16, num_hops=num_hops,
                               seed_nodes=subtrain, prefetch=True, seed=rank, copy_out=True, static=use_graph)
@@ -327,7 +327,7 @@ def run():
     K = args.steps if args.steps is not None else 200
     W = args.warmup
     if use_graph:
-        trainer = GraphedTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, need=need)
+        trainer = GraphedTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, need=need, world_size=world)
         W = max(W, 3 + 2 * len(sampler.slots))           # eager warm-up + one capture per ring slot, all untimed
     else:
         trainer = MinibatchTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, overlap=not args.no_overlap,

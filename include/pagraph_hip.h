@@ -89,10 +89,14 @@ int pg_slot_map_export(const int32_t* slot_map, int64_t node_num, uint8_t* gpu_f
  * slot_scratch: optional device int32[n]; when given, the split pass stores every row's slot
  * there (coalesced) and the copy pass reads it back instead of repeating the random lookup.
  * stats: optional device uint64[2], ACCUMULATED (not reset): [0] += rows looked up (ids >= 0),
- * [1] += misses — the reference's try_num / miss_num (storage.py:219-221) without a host sync. */
+ * [1] += misses — the reference's try_num / miss_num (storage.py:219-221) without a host sync.
+ * timer: optional (pg_timer_create); HIP events are recorded on `stream` immediately before and
+ * after the copy kernel only (not the split pass), so pg_timer_elapsed_ms == rocprofv3's k_gather. */
+typedef struct pg_timer pg_timer_t;
 int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
                    const pg_field_t* fields, int n_fields, int32_t* miss_pos, int64_t* miss_fullid,
-                   int32_t* miss_count, int32_t* slot_scratch, uint64_t* stats, pg_stream_t stream);
+                   int32_t* miss_count, int32_t* slot_scratch, uint64_t* stats, pg_timer_t* timer,
+                   pg_stream_t stream);
 
 /* storage.py:207-216 (fetch_from_cache): full cache, slot == local id. out_f[r,:] = cache_f[ids[r],:] */
 int pg_gather_rows_full(const int64_t* ids, int64_t n, const pg_field_t* fields, int n_fields,
@@ -204,7 +208,6 @@ int pg_random_features(uint64_t seed, int64_t row0, int64_t rows, int32_t dim, f
 /* ------------------------------------------------------------------------
  * 6. Timing helper for bench.py — HIP events on the stream the kernels run on.
  * ------------------------------------------------------------------------ */
-typedef struct pg_timer pg_timer_t;
 int pg_timer_create(pg_timer_t** t);
 int pg_timer_destroy(pg_timer_t* t);
 int pg_timer_start(pg_timer_t* t, pg_stream_t stream);

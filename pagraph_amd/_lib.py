@@ -46,7 +46,7 @@ _SIGS = {
     "pg_slot_map_reset": (ctypes.c_int, [vp, c_i64, vp]),
     "pg_slot_map_assign": (ctypes.c_int, [vp, vp, c_i64, vp]),
     "pg_slot_map_export": (ctypes.c_int, [vp, c_i64, vp, vp, vp]),
-    "pg_gather_rows": (ctypes.c_int, [vp, c_i64, vp, vp, ctypes.POINTER(PgField), ctypes.c_int, vp, vp, vp, vp, vp, vp]),
+    "pg_gather_rows": (ctypes.c_int, [vp, c_i64, vp, vp, ctypes.POINTER(PgField), ctypes.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "pg_gather_rows_full": (ctypes.c_int, [vp, c_i64, ctypes.POINTER(PgField), ctypes.c_int, vp]),
     "pg_scatter_rows": (ctypes.c_int, [vp, vp, c_i64, vp, c_i32, vp, c_i32, vp]),
     "pg_host_gather_rows": (ctypes.c_int, [vp, c_i64, c_i32, vp, c_i64, vp, ctypes.c_int]),

@@ -85,7 +85,7 @@ class NeighborSampler:
                                                min(self.fanout, 2 ** 31 - 1), self.num_hops, ctypes.byref(h)),
                     "pg_sampler_create")
         self.handle = h
-        self.stream = torch.cuda.Stream(device=self.device)
+        self.stream = torch.cuda.Stream(device=self.device, priority=-1)   # ~15 tiny latency-bound launches
         # stream on which the consumer finishes with a NodeFlow (None = current stream at hand-back);
         # a ring slot is re-sampled only after the event recorded there
         self.consumer_stream = None

@@ -290,13 +290,11 @@ class GraphCacheServer:
             if self.profile is not None:
                 timer = L.vp()
                 L.check(self.lib.pg_timer_create(ctypes.byref(timer)), "pg_timer_create")
-                L.check(self.lib.pg_timer_start(timer, sp), "pg_timer_start")
             L.check(self.lib.pg_gather_rows(L.ptr(nf_nids), R, L.ptr(self.slot_map), L.ptr(self.nid_map), fields, nf,
                                             L.ptr(self._miss_pos), L.ptr(self._miss_fullid), L.ptr(self._miss_count),
-                                            L.ptr(self._slots), L.ptr(self._stats) if self.log else None, sp),
+                                            L.ptr(self._slots), L.ptr(self._stats) if self.log else None, timer, sp),
                     "pg_gather_rows")
             if timer is not None:
-                L.check(self.lib.pg_timer_stop(timer, sp), "pg_timer_stop")
                 self.profile.append([timer, R, None])
         with torch.autograd.profiler.record_function('cache-cpu'):
             if self.miss_mode == "zerocopy":

@@ -35,7 +35,7 @@ class MinibatchTrainer:
         self.cacher, self.sampler, self.labels = cacher, sampler, labels
         self.device = device
         self.overlap = overlap
-        self.load_stream = torch.cuda.Stream(device=device) if overlap else None
+        self.load_stream = torch.cuda.Stream(device=device, priority=-1) if overlap else None
         self.on_step = None          # callback(step_in_epoch, loss_tensor)
         self.after_first_step = None  # callback() — pa_gcn.py:99-100 (auto_cache)
         self._first_done = False
@@ -141,15 +141,37 @@ class GraphedTrainer:
     One graph per sampler ring slot (the graph holds the addresses of that slot's CSR buffers
     and of its static frames; batch k computes while k+1 loads and k+2 is sampled).  Parameters
     and optimizer state are shared by the graphs; the optimizer must be capture-safe
-    (torch.optim.Adam(..., capturable=True)).  Single process only (DDP is left eager)."""
+    (torch.optim.Adam(..., capturable=True)).
 
-    def __init__(self, model, loss_fcn, optimizer, cacher, sampler, labels, device, warmup_eager=3, need=None):
+    Multi-GPU (world_size > 1, no DDP wrapper): every parameter's .grad is a view of ONE flat
+    buffer.  Graph A (per slot) = zero the flat buffer, forward, loss / world, backward (autograd
+    accumulates straight into the views); then ONE eager all-reduce (RCCL) of the flat buffer —
+    ~90 KB, the collective of pa_gcn.py:65,96 without DDP's bucket machinery — then graph B
+    (shared) = optimizer.step().  Initial parameters are broadcast from rank 0 like DDP does."""
+
+    def __init__(self, model, loss_fcn, optimizer, cacher, sampler, labels, device, warmup_eager=3, need=None,
+                 process_group=None, world_size=1):
         self.need = need
+        self.world = int(world_size)
+        self.pg = process_group
+        self.flat = None
+        self.graph_b = None
+        if self.world > 1:
+            import torch.distributed as dist
+            params = [p for p in model.parameters() if p.requires_grad]
+            for p in params:
+                dist.broadcast(p.data, src=0, group=self.pg)
+            self.flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=device)
+            o = 0
+            for p in params:
+                p.grad = self.flat[o:o + p.numel()].view_as(p)
+                o += p.numel()
         assert sampler.static, "GraphedTrainer needs NeighborSampler(static=True)"
         self.model, self.loss_fcn, self.optimizer = model, loss_fcn, optimizer
         self.cacher, self.sampler, self.labels = cacher, sampler, labels
         self.device = device
-        self.load_stream = torch.cuda.Stream(device=device)
+        # high priority: the short HBM-bound gather should not queue behind the compute stream's GEMMs
+        self.load_stream = torch.cuda.Stream(device=device, priority=-1)
         # eager warm-up, capture and replay all run on ONE non-default stream, so autograd's
         # AccumulateGrad nodes and the captured graphs agree on the stream
         self.compute_stream = torch.cuda.Stream(device=device)
@@ -205,26 +227,50 @@ class GraphedTrainer:
                                     if self.need is None or n in self.need.get(i, ())}
         pred = self.model(s.nf)
         loss = self.loss_fcn(pred, s.label)
-        loss.backward()
-        self.optimizer.step()
+        if self.world > 1:
+            self.flat.zero_()
+            (loss / self.world).backward()      # the SUM all-reduce then yields DDP's mean gradient
+        else:
+            loss.backward()
+            self.optimizer.step()
         return loss
+
+    def _sync_and_step(self, capture_ok):
+        """world > 1: all-reduce the flat gradient (eager), then the optimizer step (graph B)"""
+        import torch.distributed as dist
+        dist.all_reduce(self.flat, group=self.pg)
+        if self.graph_b is not None:
+            self.graph_b.replay()
+        elif not capture_ok:
+            self.optimizer.step()
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.compute_stream):
+                self.optimizer.step()
+            self.graph_b = g
+            g.replay()
 
     def compute(self, s):
         main = self.compute_stream
         main.wait_event(s.ready)
         with torch.cuda.stream(main):
+            warm = self.steps_done < self.warmup_eager
             if s.graph is not None:
                 s.graph.replay()
-            elif self.steps_done < self.warmup_eager:
-                self.optimizer.zero_grad(set_to_none=True)
+            elif warm:
+                if self.world == 1:
+                    self.optimizer.zero_grad(set_to_none=True)
                 s.loss = self._step_body(s).detach()
             else:
                 g = torch.cuda.CUDAGraph()
-                self.optimizer.zero_grad(set_to_none=True)
+                if self.world == 1:
+                    self.optimizer.zero_grad(set_to_none=True)
                 with torch.cuda.graph(g, stream=main):
                     s.loss = self._step_body(s).detach()
                 s.graph = g
                 g.replay()                                   # capture does not execute
+            if self.world > 1:
+                self._sync_and_step(capture_ok=not warm)
             loss = s.loss.clone()        # the slot's static loss tensor is overwritten 4 steps later
         s.done.record(main)
         s.done_recorded = True

@@ -127,7 +127,7 @@ def test_gather_vs_oracle_random(dev, hiplib, oracle, n, F, ratio):
     stats = torch.tensor([5, 7], dtype=torch.int64, device=dev)                    # accumulated, not reset
     fields, nf = L.make_fields([(cache, out, F, F, F)])
     L.check(hiplib.pg_gather_rows(L.ptr(d_ids), n, L.ptr(slot), L.ptr(torch.from_numpy(nid_map).to(dev)), fields, nf,
-                                  L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt), L.ptr(scratch), L.ptr(stats), sp))
+                                  L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt), L.ptr(scratch), L.ptr(stats), None, sp))
     m = int(mcnt.item())
     assert m == st.miss_num
     assert stats.tolist() == [5 + n, 7 + m]
@@ -355,7 +355,7 @@ def test_full_size_gather_properties(dev, hiplib):
     fields, nf = L.make_fields([(cache, out, F, F, F)])
     for _ in range(2):                                                   # idempotent
         L.check(hiplib.pg_gather_rows(L.ptr(ids), R, L.ptr(slot), L.ptr(nid_map), fields, nf, L.ptr(mpos), L.ptr(mfull),
-                                      L.ptr(mcnt), None, None, sp))
+                                      L.ptr(mcnt), None, None, None, sp))
     m = int(mcnt.item())
     hit = slot[ids] >= 0
     assert m == int((~hit).sum())
@@ -492,3 +492,64 @@ def test_graphed_trainer_matches_eager(dev, hiplib):
         losses[mode] = torch.stack(out).cpu().numpy()
     assert np.allclose(losses["eager"], losses["graph"], rtol=2e-4, atol=2e-5), (losses["eager"], losses["graph"])
     assert losses["graph"][-1] < losses["graph"][0]
+
+
+def _two_rank_graph_worker(rank, world, port, out_dir):
+    """two ranks share GPU 0 over gloo: GraphedTrainer's flat-gradient all-reduce path vs DDP eager"""
+    import torch.distributed as dist
+    import torch.nn.functional as Fn
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from pagraph_amd.model import GCNSampling
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    from pagraph_amd.trainer import GraphedTrainer, MinibatchTrainer, cycle_batches
+    rng = np.random.default_rng(5)
+    V, Fdim, C, B = 4000, 32, 4, 250
+    adj = _rand_csc(rng, V, 24000)
+    g = DeviceGraph(adj)
+    feats = rng.standard_normal((V, Fdim)).astype(np.float32)
+    labels = torch.from_numpy(rng.integers(0, C, V)).to(dev)
+    train = np.arange(rank, V, 4, dtype=np.int64)              # disjoint seeds per rank, 1000 each
+    res = {}
+    for mode in ("ddp", "graph"):
+        store = HostFeatureStore({"features": torch.from_numpy(feats)})
+        c = GraphCacheServer(store, V, torch.arange(V), 0, miss_mode="zerocopy")
+        c.init_field(["features"])
+        c.auto_cache(g, ["features"], cache_ratio=0.5)
+        torch.manual_seed(rank)                                 # different init per rank: broadcast must fix it
+        model = GCNSampling(Fdim, 8, C, 1, Fn.relu, 0.0).to(dev)
+        need = model.required_inputs(3)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=(mode == "graph"))
+        smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=True, num_hops=2, seed_nodes=train, prefetch=True,
+                              seed=3 + rank, static=(mode == "graph"))
+        if mode == "ddp":
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
+            tr = MinibatchTrainer(net, torch.nn.CrossEntropyLoss(), opt, c, smp, labels, dev, need=need)
+        else:
+            tr = GraphedTrainer(model, torch.nn.CrossEntropyLoss(), opt, c, smp, labels, dev, need=need, world_size=world)
+        out = []
+        tr.on_step = lambda step, loss: out.append(loss.detach().clone())
+        tr.run_steps(cycle_batches(smp, 12), 12)
+        torch.cuda.synchronize()
+        res[mode] = (torch.stack(out).cpu(), [p.detach().cpu().clone() for p in model.parameters()])
+    torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_graphed_allreduce_matches_ddp(dev, hiplib, tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_two_rank_graph_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(tmp_path / f"r{i}.pt") for i in range(2)]
+    for mode in ("ddp", "graph"):                                # replicas stay identical
+        for a, b in zip(r[0][mode][1], r[1][mode][1]):
+            assert torch.allclose(a, b, rtol=0, atol=1e-6), mode
+    for i in range(2):                                           # same trajectory as DDP
+        assert torch.allclose(r[i]["ddp"][0], r[i]["graph"][0], rtol=3e-4, atol=3e-5), (r[i]["ddp"][0], r[i]["graph"][0])
+        for a, b in zip(r[i]["ddp"][1], r[i]["graph"][1]):
+            assert torch.allclose(a, b, rtol=1e-3, atol=1e-4)

@@ -28,7 +28,7 @@ def test_version_and_errors(hiplib):
     assert hiplib.pg_strerror(0) == b"ok"
     assert hiplib.pg_strerror(-1) == b"invalid argument"
     # argument validation happens before any HIP call
-    assert hiplib.pg_gather_rows(None, -1, None, None, None, 0, None, None, None, None, None, None) == -1
+    assert hiplib.pg_gather_rows(None, -1, None, None, None, 0, None, None, None, None, None, None, None) == -1
     assert hiplib.pg_spmm_fwd(None, None, None, 4, 5, 8, 0, None, 8, None) == -1      # h_stride < dim
     assert hiplib.pg_sampler_create(0, None, None, 1, 1, 1, None) == -1
     assert hiplib.pg_rmat_edges(1, 0, 1, 1, 1, 0, 10, None, None, None) == -1

@@ -30,6 +30,6 @@ for _ in range(3):
 torch.cuda.synchronize()
 for ids in (ids_u, ids_s):
     for _ in range(3):
-        L.check(lib.pg_gather_rows(L.ptr(ids), R, L.ptr(slot), L.ptr(nid_map), fields, nf, L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt), L.ptr(slots), None, sp))
+        L.check(lib.pg_gather_rows(L.ptr(ids), R, L.ptr(slot), L.ptr(nid_map), fields, nf, L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt), L.ptr(slots), None, None, sp))
     torch.cuda.synchronize()
 print("rows", R, "copy bytes each way", R * F * 4, "gather algorithmic bytes", R * (8 * 601 + 17))
