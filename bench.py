@@ -33,6 +33,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def pmc_traffic():
+    """HBM bytes per in-loop k_gather launch from the committed rocprofv3 PMC passes
+    (profiles/rNN/pmc_gather_inloop.json: FETCH_SIZE x2 + WRITE_SIZE, KiB, separate passes —
+    MI355X_MICROARCH.md §HBM). bench.py cannot collect PMC counters itself; None when absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_gather_inloop.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    return d.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -391,8 +403,10 @@ def run():
         g_bytes.append((R - m) * 8 * D + R * 17 + m * 12)      # algorithmic bytes of one launch
     avg_ms = float(np.mean(g_ms)) if g_ms else float("nan")
     achieved = float(np.mean(g_bytes)) / avg_ms / 1e6 if g_ms else float("nan")
+    traffic, traffic_src = pmc_traffic()
     roofline = {"kernel": "k_gather", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "avg_launch_ms": avg_ms,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_ms": avg_ms,
                 "rows_per_launch": float(np.mean(g_rows)) if g_rows else 0.0,
                 "algorithmic_bytes_per_launch": float(np.mean(g_bytes)) if g_bytes else 0.0}
 

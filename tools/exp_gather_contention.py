@@ -65,3 +65,12 @@ for ws in (False, True):
     for wb in (False, True):
         for gap in (0, 0.0005):
             print(f"scatter={ws} busy={wb} gap={gap}: {loop(40, ws, wb, gap)}")
+# ---- HBM-heavy neighbour: dropout-sized elementwise traffic on the compute stream
+big = torch.rand((24000, 600), device=dev); big2 = torch.empty_like(big)
+def busy_hbm(iters):
+    with torch.cuda.stream(sC):
+        for _ in range(iters):
+            torch.mul(big, 1.0001, out=big2)      # 115 MB of HBM traffic, ~25 us
+busy_hbm(4000)
+print("with HBM-heavy elementwise stream:", loop(40, False, False, 0.0002))
+torch.cuda.synchronize()
