@@ -1,0 +1,165 @@
+// Skinny dense step of the first GNN layer: Y[n, N] = X[n, K] · Wᵀ + b with N <= 32
+// (hidden 32 for GCN, 16 for GraphSAGE; pa_gcn.py:130, pa_gs.py:134) and K = feature size —
+// NodeUpdate.forward's nn.Linear (PaGraph/model/gcn_nssc.py:18, graphsage_nssc.py:24).
+//
+// This is the one place the path uses the matrix cores (north star: "MFMA only for the dense
+// feat×W step"): exact-fp32 v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain, same numerics class
+// as the library GEMM it replaces). hipBLASLt spends 86 us (forward) + 52 us (weight gradient)
+// per minibatch on this 12 000 x 600 x 32 shape — its macro-tiles are built for square problems —
+// which made it the largest item on the compute stream once the gather was fast. The shape is
+// HBM/L2-streaming bound: X (29 MB) is read once forward and once backward.
+//
+// forward   block = 4 waves on ONE 32-row tile, K split four ways (each wave: <= 19 octets of k,
+//           4 MFMAs per octet: A = one float4 of its X row per lane, B = two coalesced 128-byte
+//           rows of the pre-transposed weight Wt[K][32]); partial 32x32 tiles reduced through LDS,
+//           bias added, float4 stores.  375 blocks for n = 12 000.
+// backward  dW[N, K] += dYᵀ·X, db[N] += Σ dY: wave = one 32-column slice of K for a chunk of 256
+//           rows (A = dY rows, B = X rows: both coalesced), fp32 hardware atomics into dW / db.
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "pg_common.h"
+
+namespace pg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float df4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTile = 32;
+
+__global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ X, int32_t x_stride,
+                                                    const float* __restrict__ Wt /* [K][32] */,
+                                                    const float* __restrict__ bias /* [N] or null */,
+                                                    float* __restrict__ Y, int32_t y_stride, int64_t n, int32_t K,
+                                                    int32_t N) {
+  __shared__ float red[4][kTile][kTile + 1];
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+  const int64_t r0 = (int64_t)blockIdx.x * kTile;
+  const int64_t row = r0 + (lane & 31);
+  const int half = lane >> 5;
+  const int octets = K / 8;
+  const int o_beg = (octets * w) / 4, o_end = (octets * (w + 1)) / 4;
+  const bool row_ok = row < n;
+  const float* xr = X + (row_ok ? row : 0) * x_stride + 4 * half;
+  const float* wb = Wt + (int64_t)(4 * half) * kTile + (lane & 31);
+  f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int o = o_beg; o < o_end; ++o) {
+    const int kk = o * 8;
+    df4 a = *reinterpret_cast<const df4*>(xr + kk);
+    if (!row_ok) a = df4{0.f, 0.f, 0.f, 0.f};
+    const float* wk = wb + (int64_t)kk * kTile;
+    const float b0 = wk[0 * kTile], b1 = wk[1 * kTile], b2 = wk[2 * kTile], b3 = wk[3 * kTile];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b3, acc, 0, 0, 0);
+  }
+  // C layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[w][(r & 3) + 8 * (r >> 2) + 4 * half][lane & 31] = acc[r];
+  __syncthreads();
+  // 256 threads x 4 outputs: thread t -> row t / 8, cols 4 * (t % 8) .. +3
+  const int orow = threadIdx.x >> 3, oc = (threadIdx.x & 7) * 4;
+  if (r0 + orow < n) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = red[0][orow][oc + j] + red[1][orow][oc + j] + red[2][orow][oc + j] + red[3][orow][oc + j];
+      if (bias && oc + j < N) v[j] += bias[oc + j];
+    }
+    float* yr = Y + (r0 + orow) * y_stride + oc;
+    if (N == kTile && (y_stride & 3) == 0) {
+      *reinterpret_cast<df4*>(yr) = df4{v[0], v[1], v[2], v[3]};
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (oc + j < N) yr[j] = v[j];
+    }
+  }
+}
+
+constexpr int kBwdRows = 256;  // rows per block in the weight-gradient kernel
+
+__global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ dY, int32_t dy_stride,
+                                                      const float* __restrict__ X, int32_t x_stride, int64_t n,
+                                                      int32_t K, int32_t N, float* __restrict__ dW /* [N][K] */,
+                                                      float* __restrict__ db /* [N] or null */) {
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+  const int i = lane & 31, half = lane >> 5;
+  const int c0 = ((int)blockIdx.x * 4 + w) * kTile;  // this wave's 32-column slice of K
+  if (c0 >= K) return;
+  const int64_t rb = (int64_t)blockIdx.y * kBwdRows;
+  const int64_t re = (rb + kBwdRows < n) ? rb + kBwdRows : n;
+  const bool a_ok = i < N, b_ok = c0 + i < K;
+  const bool do_bias = db != nullptr && blockIdx.x == 0 && w == 0;
+  f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  float bsum = 0.f;
+  // `base` is wave-uniform (MFMA needs the whole wave); lane half h works on row base + h
+  int64_t base = rb;
+  for (; base + 7 < re; base += 8) {  // 4 MFMA steps (8 rows) per iteration, loads issued together
+    const int64_t r = base + half;
+    float a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = a_ok ? dY[(r + 2 * u) * dy_stride + i] : 0.f;
+      b[u] = b_ok ? X[(r + 2 * u) * x_stride + c0 + i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+      bsum += a[u];
+    }
+  }
+  for (; base < re; base += 2) {  // tail: the odd half may fall off the end
+    const int64_t r = base + half;
+    const bool ok = r < re;
+    const float a = (ok && a_ok) ? dY[r * dy_stride + i] : 0.f;
+    const float b = (ok && b_ok) ? X[r * x_stride + c0 + i] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    bsum += a;
+  }
+  // C[row = out feature][col = X column]
+  const int j = lane & 31;
+  if (c0 + j < K) {
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int of = (rr & 3) + 8 * (rr >> 2) + 4 * half;
+      if (of < N) unsafeAtomicAdd(dW + (int64_t)of * K + c0 + j, acc[rr]);
+    }
+  }
+  if (do_bias && a_ok) unsafeAtomicAdd(db + i, bsum);
+}
+
+}  // namespace pg
+
+using namespace pg;
+
+extern "C" {
+
+int pg_linear_fwd(const float* X, int32_t x_stride, const float* Wt, const float* bias, float* Y, int32_t y_stride,
+                  int64_t n, int32_t K, int32_t N, pg_stream_t stream) {
+  if (n < 0 || K <= 0 || N <= 0 || x_stride < K || y_stride < N) return PG_ERR_INVALID;
+  if (N > kTile || (K & 7) || (x_stride & 3)) return PG_ERR_UNSUPPORTED;
+  if (n == 0) return PG_OK;
+  if (!X || !Wt || !Y) return PG_ERR_INVALID;
+  if ((reinterpret_cast<uintptr_t>(X) & 15)) return PG_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_linear_fwd, dim3((unsigned)ceil_div<int64_t>(n, kTile)), dim3(256), 0, as_stream(stream), X,
+                     x_stride, Wt, bias, Y, y_stride, n, K, N);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+int pg_linear_bwd_w(const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n, int32_t K,
+                    int32_t N, float* dW, float* db, pg_stream_t stream) {
+  if (n < 0 || K <= 0 || N <= 0 || x_stride < K || dy_stride < N) return PG_ERR_INVALID;
+  if (N > kTile) return PG_ERR_UNSUPPORTED;
+  if (n == 0) return PG_OK;
+  if (!dY || !X || !dW) return PG_ERR_INVALID;
+  const unsigned gx = (unsigned)ceil_div<int64_t>(ceil_div<int64_t>(K, kTile), 4);
+  const unsigned gy = (unsigned)ceil_div<int64_t>(n, kBwdRows);
+  hipLaunchKernelGGL(k_linear_bwd_w, dim3(gx, gy), dim3(256), 0, as_stream(stream), dY, dy_stride, X, x_stride, n, K,
+                     N, dW, db);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+}  // extern "C"

@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from .. import function as fn
+from .. import ops
 
 
 class NodeUpdate(nn.Module):
@@ -23,7 +24,7 @@ class NodeUpdate(nn.Module):
         h = node.data['h']
         if self.test:
             h = h * node.data['norm']
-        h = self.linear(h)
+        h = ops.linear(h, self.linear)
         if self.concat:
             h = torch.cat((h, self.activation(h)), dim=1)
         elif self.activation:
@@ -62,7 +63,7 @@ class _GCNBase(nn.Module):
         h = nf.layers[0].data['features']
         if getattr(self, 'dropout', None):
             h = self.dropout(h)
-        h = self.linear(h)
+        h = ops.linear(h, self.linear)
         if self.n_layers == 1:
             return torch.cat((h, self.activation(h)), dim=1)
         return self.activation(h)

@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from .. import function as fn
+from .. import ops
 
 
 class NodeUpdate(nn.Module):
@@ -23,7 +24,7 @@ class NodeUpdate(nn.Module):
         nn.init.xavier_uniform_(self.fc_self.weight, gain=gain)
 
     def forward(self, node):
-        h = self.fc_self(node.data['h']) + self.fc_neigh(node.data['neigh'])
+        h = ops.linear(node.data['h'], self.fc_self) + ops.linear(node.data['neigh'], self.fc_neigh)
         if self.concat:
             h = torch.cat((h, self.activation(h)), dim=1)
         elif self.activation:
@@ -69,7 +70,7 @@ class GraphSageSampling(nn.Module):
             for i in range(L):
                 d = nf.layers[i].data
                 h = self.dropout(d.pop('features'))
-                h = self.fc_self(h) + self.fc_neigh(d.pop('neigh'))
+                h = ops.linear(h, self.fc_self) + ops.linear(d.pop('neigh'), self.fc_neigh)
                 d['h'] = torch.cat((h, self.activation(h)), dim=1) if self.n_layers == 1 else self.activation(h)
         else:
             for i in range(L):

@@ -38,3 +38,48 @@ def block_aggregate(indptr, src, h, n_dst, reduce="mean"):
     if h.dtype != torch.float32 or not h.is_cuda:
         raise L.PgError("block_aggregate needs fp32 CUDA tensors (no CPU fallback)")
     return _BlockAggregate.apply(indptr, src, h, int(n_dst), reduce)
+
+
+class _SkinnyLinear(torch.autograd.Function):
+    """y = x @ W.T + b on the fp32-MFMA kernels of pg_dense.hip (out_features <= 32)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = L.load()
+        n, K = x.shape
+        N = weight.size(0)
+        wt = weight.t().contiguous()                     # [K, N]
+        if N < 32:
+            wt = torch.nn.functional.pad(wt, (0, 32 - N))
+        y = torch.empty((n, N), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            L.check(lib.pg_linear_fwd(L.ptr(x), x.stride(0), L.ptr(wt), L.ptr(bias), L.ptr(y), y.stride(0), n, K, N,
+                                      L.stream_ptr()), "pg_linear_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        lib = L.load()
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw = torch.zeros_like(weight)
+            gb = torch.zeros(weight.size(0), dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            with torch.cuda.device(x.device):
+                L.check(lib.pg_linear_bwd_w(L.ptr(gy), gy.stride(0), L.ptr(x), x.stride(0), x.size(0), x.size(1),
+                                            weight.size(0), L.ptr(gw), L.ptr(gb), L.stream_ptr()), "pg_linear_bwd_w")
+        if ctx.needs_input_grad[0]:
+            gx = gy @ weight                              # only deeper layers ask for it; they are not skinny-K
+        return gx, gw, gb
+
+
+def linear(x, module):
+    """nn.Linear forward; the first-layer shape (wide K, out_features <= 32) runs on pg_dense.hip"""
+    w, b = module.weight, module.bias
+    if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and w.size(0) <= 32 and x.size(1) % 8 == 0
+            and x.size(1) >= 128 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0):
+        return _SkinnyLinear.apply(x, w, b)
+    return module(x)

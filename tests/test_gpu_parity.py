@@ -553,3 +553,41 @@ def test_two_rank_graphed_allreduce_matches_ddp(dev, hiplib, tmp_path):
         assert torch.allclose(r[i]["ddp"][0], r[i]["graph"][0], rtol=3e-4, atol=3e-5), (r[i]["ddp"][0], r[i]["graph"][0])
         for a, b in zip(r[i]["ddp"][1], r[i]["graph"][1]):
             assert torch.allclose(a, b, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("n,K,N,bias", [(12000, 600, 32, True), (11999, 600, 16, True), (1, 600, 32, True), (33, 128, 7, False),
+                                        (6000, 1200, 32, True), (257, 608, 1, True), (5000, 600, 32, False)])
+def test_skinny_linear_vs_torch(dev, hiplib, n, K, N, bias):
+    """pg_linear_fwd / pg_linear_bwd_w (fp32 MFMA) vs torch's nn.Linear: outputs and weight/bias gradients
+    within 1e-4 relative to the output scale (same exact-fp32 arithmetic, different summation order)"""
+    from pagraph_amd import ops
+    torch.manual_seed(n + K + N)
+    lin = torch.nn.Linear(K, N, bias=bias).to(dev)
+    x = torch.rand((n, K), device=dev) - 0.3
+    y = ops.linear(x, lin)
+    assert y.grad_fn is not None and "SkinnyLinear" in type(y.grad_fn).__name__      # the HIP path ran
+    ref = torch.nn.functional.linear(x.double(), lin.weight.double(), lin.bias.double() if bias else None)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((y.double() - ref).abs().max()) < TOL * scale
+    gy = torch.rand_like(y) - 0.5
+    y.backward(gy)
+    gw_ref = gy.double().t() @ x.double()
+    assert float((lin.weight.grad.double() - gw_ref).abs().max()) < TOL * max(1.0, float(gw_ref.abs().max()))
+    if bias:
+        gb_ref = gy.double().sum(0)
+        assert float((lin.bias.grad.double() - gb_ref).abs().max()) < TOL * max(1.0, float(gb_ref.abs().max()))
+    # an input that needs its own gradient gets one too (deeper layers)
+    x2 = x[:64].clone().requires_grad_(True)
+    lin.zero_grad()
+    ops.linear(x2, lin).sum().backward()
+    assert torch.allclose(x2.grad, lin.weight.sum(0).expand_as(x2), rtol=1e-5, atol=1e-6)
+
+
+def test_skinny_linear_falls_back_outside_envelope(dev, hiplib):
+    from pagraph_amd import ops
+    lin = torch.nn.Linear(602, 32).to(dev)                  # K % 8 != 0 (Reddit's 602)
+    y = ops.linear(torch.rand((100, 602), device=dev), lin)
+    assert "SkinnyLinear" not in type(y.grad_fn).__name__
+    lin = torch.nn.Linear(64, 60).to(dev)                   # wide output
+    y = ops.linear(torch.rand((100, 64), device=dev), lin)
+    assert "SkinnyLinear" not in type(y.grad_fn).__name__
