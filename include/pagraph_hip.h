@@ -191,7 +191,7 @@ int pg_spmm_bwd(const int32_t* indptr, const int32_t* src, const float* grad_out
  * Returns PG_ERR_UNSUPPORTED outside that envelope (callers then use the library GEMM).            */
 int pg_linear_fwd(const float* X, int32_t x_stride, const float* Wt, const float* bias, float* Y,
                   int32_t y_stride, int64_t n, int32_t K, int32_t N, pg_stream_t stream);
-/* dW[N,K] += dY^T X and (db != NULL) db[N] += column sums of dY; dW / db must be zeroed by the caller. */
+/* dW[N,K] += dY^T X and (db != NULL) db[N] += column sums of dY, any N and K; dW / db must be zeroed by the caller. */
 int pg_linear_bwd_w(const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n,
                     int32_t K, int32_t N, float* dW, float* db, pg_stream_t stream);
 

@@ -13,8 +13,10 @@
 //           4 MFMAs per octet: A = one float4 of its X row per lane, B = two coalesced 128-byte
 //           rows of the pre-transposed weight Wt[K][32]); partial 32x32 tiles reduced through LDS,
 //           bias added, float4 stores.  375 blocks for n = 12 000.
-// backward  dW[N, K] += dYᵀ·X, db[N] += Σ dY: wave = one 32-column slice of K for a chunk of 256
-//           rows (A = dY rows, B = X rows: both coalesced), fp32 hardware atomics into dW / db.
+// backward  dW[N, K] += dYᵀ·X, db[N] += Σ dY (any N): wave = one (32-feature, 32-column) tile of dW for
+//           a chunk of 256 rows (A = dY rows, B = X rows: both coalesced), fp32 hardware atomics into
+//           dW / db. Also used for the output layer (N = 60, K = 64): the library GEMM has two
+//           output tiles and a 6000-long reduction there and takes 51 us.
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include "pg_common.h"
@@ -84,13 +86,19 @@ __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ 
                                                       int32_t K, int32_t N, float* __restrict__ dW /* [N][K] */,
                                                       float* __restrict__ db /* [N] or null */) {
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-  const int i = lane & 31, half = lane >> 5;
-  const int c0 = ((int)blockIdx.x * 4 + w) * kTile;  // this wave's 32-column slice of K
-  if (c0 >= K) return;
+  const int half = lane >> 5;
+  // work item of this wave: (feature tile ft of N, 32-column slice c0 of K)
+  const int col_slices = (K + kTile - 1) / kTile;
+  const int item = (int)blockIdx.x * 4 + w;
+  const int ft = item / col_slices;
+  const int f0 = ft * kTile;
+  if (f0 >= N) return;
+  const int c0 = (item - ft * col_slices) * kTile;
+  const int i = f0 + (lane & 31);                    // output feature fed by this lane (A operand)
   const int64_t rb = (int64_t)blockIdx.y * kBwdRows;
   const int64_t re = (rb + kBwdRows < n) ? rb + kBwdRows : n;
-  const bool a_ok = i < N, b_ok = c0 + i < K;
-  const bool do_bias = db != nullptr && blockIdx.x == 0 && w == 0;
+  const bool a_ok = i < N, b_ok = c0 + (lane & 31) < K;
+  const bool do_bias = db != nullptr && c0 == 0;
   f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   float bsum = 0.f;
   // `base` is wave-uniform (MFMA needs the whole wave); lane half h works on row base + h
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ 
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       a[u] = a_ok ? dY[(r + 2 * u) * dy_stride + i] : 0.f;
-      b[u] = b_ok ? X[(r + 2 * u) * x_stride + c0 + i] : 0.f;
+      b[u] = b_ok ? X[(r + 2 * u) * x_stride + c0 + (lane & 31)] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -113,7 +121,7 @@ __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ 
     const int64_t r = base + half;
     const bool ok = r < re;
     const float a = (ok && a_ok) ? dY[r * dy_stride + i] : 0.f;
-    const float b = (ok && b_ok) ? X[r * x_stride + c0 + i] : 0.f;
+    const float b = (ok && b_ok) ? X[r * x_stride + c0 + (lane & 31)] : 0.f;
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     bsum += a;
   }
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ 
   if (c0 + j < K) {
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) {
-      const int of = (rr & 3) + 8 * (rr >> 2) + 4 * half;
+      const int of = f0 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
       if (of < N) unsafeAtomicAdd(dW + (int64_t)of * K + c0 + j, acc[rr]);
     }
   }
@@ -151,10 +159,9 @@ int pg_linear_fwd(const float* X, int32_t x_stride, const float* Wt, const float
 int pg_linear_bwd_w(const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n, int32_t K,
                     int32_t N, float* dW, float* db, pg_stream_t stream) {
   if (n < 0 || K <= 0 || N <= 0 || x_stride < K || dy_stride < N) return PG_ERR_INVALID;
-  if (N > kTile) return PG_ERR_UNSUPPORTED;
   if (n == 0) return PG_OK;
   if (!dY || !X || !dW) return PG_ERR_INVALID;
-  const unsigned gx = (unsigned)ceil_div<int64_t>(ceil_div<int64_t>(K, kTile), 4);
+  const unsigned gx = (unsigned)ceil_div<int64_t>(ceil_div<int64_t>(K, kTile) * ceil_div<int64_t>(N, kTile), 4);
   const unsigned gy = (unsigned)ceil_div<int64_t>(n, kBwdRows);
   hipLaunchKernelGGL(k_linear_bwd_w, dim3(gx, gy), dim3(256), 0, as_stream(stream), dY, dy_stride, X, x_stride, n, K,
                      N, dW, db);

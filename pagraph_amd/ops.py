@@ -41,20 +41,25 @@ def block_aggregate(indptr, src, h, n_dst, reduce="mean"):
 
 
 class _SkinnyLinear(torch.autograd.Function):
-    """y = x @ W.T + b on the fp32-MFMA kernels of pg_dense.hip (out_features <= 32)"""
+    """y = x @ W.T + b with the tall-skinny pieces on the fp32-MFMA kernels of pg_dense.hip:
+    forward when out_features <= 32 and K % 8 == 0; weight / bias gradient (a reduction over all
+    rows into a tiny [N, K] matrix) always."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         lib = L.load()
         n, K = x.shape
         N = weight.size(0)
-        wt = weight.t().contiguous()                     # [K, N]
-        if N < 32:
-            wt = torch.nn.functional.pad(wt, (0, 32 - N))
-        y = torch.empty((n, N), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
-            L.check(lib.pg_linear_fwd(L.ptr(x), x.stride(0), L.ptr(wt), L.ptr(bias), L.ptr(y), y.stride(0), n, K, N,
-                                      L.stream_ptr()), "pg_linear_fwd")
+        if N <= 32 and K % 8 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0:
+            wt = weight.t().contiguous()                     # [K, N]
+            if N < 32:
+                wt = torch.nn.functional.pad(wt, (0, 32 - N))
+            y = torch.empty((n, N), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                L.check(lib.pg_linear_fwd(L.ptr(x), x.stride(0), L.ptr(wt), L.ptr(bias), L.ptr(y), y.stride(0), n, K,
+                                          N, L.stream_ptr()), "pg_linear_fwd")
+        else:
+            y = torch.nn.functional.linear(x, weight, bias)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return y
@@ -66,20 +71,23 @@ class _SkinnyLinear(torch.autograd.Function):
         gy = gy.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw = torch.zeros_like(weight)
-            gb = torch.zeros(weight.size(0), dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            N, K = weight.shape
+            buf = torch.zeros(N * K + N, dtype=torch.float32, device=x.device)   # one fill for dW and db
+            gw = buf[:N * K].view(N, K)
+            gb = buf[N * K:] if ctx.has_bias else None
             with torch.cuda.device(x.device):
-                L.check(lib.pg_linear_bwd_w(L.ptr(gy), gy.stride(0), L.ptr(x), x.stride(0), x.size(0), x.size(1),
-                                            weight.size(0), L.ptr(gw), L.ptr(gb), L.stream_ptr()), "pg_linear_bwd_w")
+                L.check(lib.pg_linear_bwd_w(L.ptr(gy), gy.stride(0), L.ptr(x), x.stride(0), x.size(0), K, N,
+                                            L.ptr(gw), L.ptr(gb), L.stream_ptr()), "pg_linear_bwd_w")
         if ctx.needs_input_grad[0]:
-            gx = gy @ weight                              # only deeper layers ask for it; they are not skinny-K
+            gx = gy @ weight
         return gx, gw, gb
 
 
 def linear(x, module):
-    """nn.Linear forward; the first-layer shape (wide K, out_features <= 32) runs on pg_dense.hip"""
+    """nn.Linear forward for the NodeUpdate layers: tall inputs (thousands of rows, <= 64 outputs)
+    go through _SkinnyLinear, anything else through the module itself"""
     w, b = module.weight, module.bias
-    if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and w.size(0) <= 32 and x.size(1) % 8 == 0
-            and x.size(1) >= 128 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0):
+    if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and w.size(0) <= 64 and x.size(0) >= 1024
+            and x.stride(1) == 1):
         return _SkinnyLinear.apply(x, w, b)
     return module(x)

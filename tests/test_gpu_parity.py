@@ -555,8 +555,9 @@ def test_two_rank_graphed_allreduce_matches_ddp(dev, hiplib, tmp_path):
             assert torch.allclose(a, b, rtol=1e-3, atol=1e-4)
 
 
-@pytest.mark.parametrize("n,K,N,bias", [(12000, 600, 32, True), (11999, 600, 16, True), (1, 600, 32, True), (33, 128, 7, False),
-                                        (6000, 1200, 32, True), (257, 608, 1, True), (5000, 600, 32, False)])
+@pytest.mark.parametrize("n,K,N,bias", [(12000, 600, 32, True), (11999, 600, 16, True), (1025, 600, 32, True), (1033, 128, 7, False),
+                                        (6000, 1200, 32, True), (1257, 608, 1, True), (5000, 600, 32, False),
+                                        (6000, 64, 60, True), (5999, 602, 32, True), (3000, 70, 33, True)])
 def test_skinny_linear_vs_torch(dev, hiplib, n, K, N, bias):
     """pg_linear_fwd / pg_linear_bwd_w (fp32 MFMA) vs torch's nn.Linear: outputs and weight/bias gradients
     within 1e-4 relative to the output scale (same exact-fp32 arithmetic, different summation order)"""
@@ -577,7 +578,7 @@ def test_skinny_linear_vs_torch(dev, hiplib, n, K, N, bias):
         gb_ref = gy.double().sum(0)
         assert float((lin.bias.grad.double() - gb_ref).abs().max()) < TOL * max(1.0, float(gb_ref.abs().max()))
     # an input that needs its own gradient gets one too (deeper layers)
-    x2 = x[:64].clone().requires_grad_(True)
+    x2 = x[:1024].clone().requires_grad_(True)
     lin.zero_grad()
     ops.linear(x2, lin).sum().backward()
     assert torch.allclose(x2.grad, lin.weight.sum(0).expand_as(x2), rtol=1e-5, atol=1e-6)
@@ -585,9 +586,9 @@ def test_skinny_linear_vs_torch(dev, hiplib, n, K, N, bias):
 
 def test_skinny_linear_falls_back_outside_envelope(dev, hiplib):
     from pagraph_amd import ops
-    lin = torch.nn.Linear(602, 32).to(dev)                  # K % 8 != 0 (Reddit's 602)
-    y = ops.linear(torch.rand((100, 602), device=dev), lin)
+    lin = torch.nn.Linear(600, 32).to(dev)                  # too few rows to matter
+    y = ops.linear(torch.rand((100, 600), device=dev), lin)
     assert "SkinnyLinear" not in type(y.grad_fn).__name__
-    lin = torch.nn.Linear(64, 60).to(dev)                   # wide output
-    y = ops.linear(torch.rand((100, 64), device=dev), lin)
+    lin = torch.nn.Linear(64, 128).to(dev)                  # wide output
+    y = ops.linear(torch.rand((5000, 64), device=dev), lin)
     assert "SkinnyLinear" not in type(y.grad_fn).__name__
