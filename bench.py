@@ -73,6 +73,7 @@ def parse():
                         "graph walks sum(deg^2)=4.7e10 neighbours sequentially: ~500 s on the host (measured)")
     p.add_argument("--fetch-all", action="store_true",
                    help="fetch every layer and field like the reference (default: only what the model reads, SURVEY 8f-2)")
+    p.add_argument("--skip-opt-hit", action="store_true", help="skip the oracle cache-hit upper bound (opt_cache_hit.py)")
     p.add_argument("--no-graph", action="store_true", help="eager reference-style loop instead of hipGraph replay")
     p.add_argument("--profile-host", action="store_true", help="cProfile the timed region (stderr)")
     p.add_argument("--dist-backend", default="nccl", help="gloo lets two ranks share one GPU (testing only)")
@@ -416,6 +417,18 @@ def run():
         roofline["large"] = micro[max(micro)]
         roofline["step_shape_all_hits"] = micro[min(micro)]
 
+    opt_hit = deg_hit = None
+    if rank == 0 and not args.skip_opt_hit:
+        # oracle upper bound at the same cache ratio on the same access pattern (opt_cache_hit.py:26-31),
+        # over one full epoch of sampling; `layers` = what fetch_data really looks up
+        from pagraph_amd import analysis
+        probe = NeighborSampler(g, B, k, neighbor_type='in', shuffle=True, num_hops=num_hops, seed_nodes=subtrain,
+                                prefetch=True, seed=rank)
+        freq, _ = analysis.access_frequency(probe, layers=None if need is None else set(need))   # one full epoch
+        opt_hit = 100.0 * analysis.optimal_cache_hit(freq, args.cache_ratio)
+        deg_hit = 100.0 * analysis.degree_cache_hit(freq, g.out_degrees(), args.cache_ratio)
+        del probe, freq
+
     cpu = None
     if rank == 0 and world == 1 and not args.skip_cpu_baseline:
         labels_h = labels.cpu()
@@ -439,6 +452,7 @@ def run():
                        "hip_graph_step": use_graph,
                        "fetch": "all layers+fields (reference)" if need is None else "only what the model reads"},
             "cache_hit_pct": 100.0 * (1.0 - miss_rate),
+            "cache_hit_oracle_upper_bound_pct": opt_hit, "cache_hit_degree_policy_on_trace_pct": deg_hit,
             "feat_gather_GBps": (micro[max(micro)]["GBps"] if micro else achieved),
             "seeds_per_s": seeds_total / elapsed,
             "roofline": roofline,

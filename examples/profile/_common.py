@@ -31,7 +31,7 @@ def trainer(rank, world_size, args, arch, backend='nccl'):
     from pagraph_amd import parallel, server
     from pagraph_amd.model import GCNSampling, GraphSageSampling
     from pagraph_amd.sampling import DeviceGraph, NeighborSampler
-    from pagraph_amd.trainer import MinibatchTrainer, cycle_batches
+    from pagraph_amd.trainer import GraphedTrainer, MinibatchTrainer, cycle_batches
 
     init_process(rank, world_size, backend)
     dev = torch.device('cuda', rank)
@@ -63,15 +63,22 @@ def trainer(rank, world_size, args, arch, backend='nccl'):
         model = GraphSageSampling(args.feat_size, args.n_hidden, n_classes, args.n_layers, F.relu, args.dropout,
                                   'mean', args.preprocess)
     loss_fcn = torch.nn.CrossEntropyLoss()
-    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
     model.cuda(rank)
-    model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[rank])
+    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay,
+                                 capturable=args.graph, fused=True)
+    need = model.required_inputs(num_hops + 1) if args.fetch_needed else None
+    if not args.graph:
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[rank])
 
     sampler = NeighborSampler(g, args.batch_size, args.num_neighbors, neighbor_type='in', shuffle=True,
                               num_workers=args.num_workers, num_hops=num_hops, seed_nodes=train_nid, prefetch=True,
-                              seed=rank)
+                              seed=rank, static=args.graph)
     steps = parallel.equalize_steps(len(sampler), device=dev)     # partitions differ in size
-    loop = MinibatchTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, overlap=not args.no_overlap)
+    if args.graph:      # hipGraph-replayed step over fixed-shape NodeFlows (no DDP wrapper: one flat all-reduce)
+        loop = GraphedTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, need=need, world_size=world_size)
+    else:               # the reference's eager loop
+        loop = MinibatchTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, overlap=not args.no_overlap,
+                                need=need)
     loop.after_first_step = lambda: cacher.auto_cache(g, embed_names, cache_ratio=args.cache_ratio)
     state = {'epoch': 0}
 
@@ -124,6 +131,9 @@ def main(arch, description, n_hidden, lr):
                         help="cap the cache at this fraction of the partition (storage.py:85-86 overrides)")
     parser.add_argument("--miss-mode", default="zerocopy", choices=["staged", "zerocopy"])
     parser.add_argument("--no-overlap", action="store_true")
+    parser.add_argument("--graph", action="store_true", help="replay the training step as a hipGraph")
+    parser.add_argument("--fetch-needed", action="store_true",
+                        help="fetch only the layers/fields the model reads instead of everything (SURVEY 8f-2)")
     parser.add_argument("--log-miss-rate", action="store_true")
     args = parser.parse_args()
     if args.remote_sample:

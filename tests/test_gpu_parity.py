@@ -422,12 +422,16 @@ def test_cli_pipeline_end_to_end(dev, hiplib, tmp_path):
     r = run("-m", "pagraph_amd.partition.hash", "--dataset", str(ds), "--partition", "1", "--num-hops", "2")
     assert r.returncode == 0, r.stderr[-2000:]
     assert (ds / "1naive" / "subadj_0.npz").exists()
-    for script, extra in (("pa_gcn.py", []), ("pa_gs.py", ["--miss-mode", "staged"])):
+    for script, extra in (("pa_gcn.py", []), ("pa_gs.py", ["--miss-mode", "staged"]), ("pa_gcn.py", ["--graph", "--fetch-needed"])):
         r = run(os.path.join("examples", "profile", script), "--dataset", str(ds), "--gpu", "0", "--feat-size", "64",
                 "--n-classes", "7", "--n-epochs", "3", "--batch-size", "1000", "--cache-ratio", "0.3", "--log-miss-rate", *extra)
         assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
         assert "Epoch average time" in r.stdout and "Total Time" in r.stdout and "total dims" in r.stdout
         assert "Epoch average miss rate" in r.stdout
+    r = run(os.path.join("examples", "opt_cache_hit.py"), "--dataset", str(ds), "--n-epochs", "1", "--batch-size", "1000")
+    assert r.returncode == 0, r.stderr[-2000:]
+    vals = [float(l.split(":")[1]) for l in r.stdout.splitlines() if "hit rate" in l]
+    assert len(vals) == 2 and 0.2 < vals[1] <= vals[0] <= 1.0      # degree policy <= oracle
 
 
 @pytest.mark.parametrize("mode", ["staged", "zerocopy"])
@@ -592,3 +596,86 @@ def test_skinny_linear_falls_back_outside_envelope(dev, hiplib):
     lin = torch.nn.Linear(64, 128).to(dev)                  # wide output
     y = ops.linear(torch.rand((5000, 64), device=dev), lin)
     assert "SkinnyLinear" not in type(y.grad_fn).__name__
+
+
+def test_config2_reddit_shape_full_cache(dev, hiplib, oracle):
+    """BASELINE.json configs[1]: Reddit-shaped graph (V = 232 965, F = 602, 41 classes, 153 431 train
+    vertices), whole feature table resident in HBM (full_cached path, storage.py:90-95,207-216), GCN.
+    Degree scaled down (mean ~40 instead of 492) to keep the CPU oracle in seconds. Sampled ids and the
+    gathered F=602 rows (dwordx2 path) are bit exact, logits within 1e-4."""
+    import torch.nn.functional as Fn
+    from pagraph_amd.data import synthetic as syn
+    from pagraph_amd.model import GCNSampling
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    V, E, Fdim, C, B = 232965, 4_600_000, 602, 41, 6000
+    ip, ix = syn.rmat_graph(V, E, seed=77, device=dev)
+    g = DeviceGraph.from_csc(ip, ix, V)
+    feats = syn.random_features_device(V, Fdim, seed=3, device=dev).cpu()
+    norm = (1.0 / (ip[1:] - ip[:-1]).float()).unsqueeze(1).cpu()
+    store = HostFeatureStore({"features": feats, "norm": norm})
+    c = GraphCacheServer(store, V, torch.arange(V), 0)
+    c.init_field(["features", "norm"])
+    c.log = True
+    c.auto_cache(g, ["features", "norm"])                    # 288 GB HBM: the reference rule caches everything
+    assert c.full_cached and c.cached_num == V
+    train = torch.randperm(V, generator=torch.Generator().manual_seed(1))[:153431].sort().values
+    smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=True, num_hops=2, seed_nodes=train, prefetch=True, seed=11)
+    assert len(smp) == 26                                    # SURVEY 8d: 26 steps / epoch
+    iph, ixh = ip.cpu().numpy(), ix.cpu().numpy()
+    seeds = smp.seeds.cpu().numpy()
+    torch.manual_seed(0)
+    model = GCNSampling(Fdim, 32, C, 1, Fn.relu, 0.0).to(dev)
+    params = [(l.linear.weight.detach().cpu().numpy(), l.linear.bias.detach().cpu().numpy()) for l in model.layers]
+    fnp, nnp = feats.numpy(), norm.numpy()
+    for b, nf in enumerate(smp):
+        if b not in (0, 25):
+            continue                                         # a full batch and the short last one (3431 seeds)
+        ref = oracle.sample_nodeflow(iph, ixh, seeds[b * B:(b + 1) * B], 2, 2, 11, 0, b)
+        nm = nf._node_mapping.tousertensor().cpu().numpy()
+        assert np.array_equal(nm, ref["node_mapping"])
+        c.fetch_data(nf)
+        o = ref["layer_offsets"]
+        for i in range(3):
+            assert np.array_equal(nf._node_frames[i]["features"].cpu().numpy(), fnp[nm[o[i]:o[i + 1]]])
+            assert np.array_equal(nf._node_frames[i]["norm"].cpu().numpy(), nnp[nm[o[i]:o[i + 1]]], equal_nan=True)
+        want, _ = oracle.gcn_forward(ref, fnp[nm[o[0]:o[1]]], params)
+        got = model(nf).detach().cpu().numpy()
+        assert got.shape == (len(seeds[b * B:(b + 1) * B]), C)
+        assert np.abs(got - want).max() < TOL * max(1.0, np.abs(want).max())
+    assert c.get_miss_rate() == 0.0
+
+
+def test_sage_preprocess_forward_vs_oracle(dev, hiplib, oracle):
+    """GraphSageSampling(preprocess=True): every layer carries 'features' and a 'neigh' field
+    (graphsage_nssc.py:75-87, pa_gs.py:46-49), one hop fewer"""
+    import torch.nn.functional as Fn
+    from pagraph_amd.model import GraphSageSampling
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    rng = np.random.default_rng(4)
+    V, Fdim, C, B, k, hops = 3000, 64, 7, 400, 2, 1
+    adj = _rand_csc(rng, V, 20000)
+    g = DeviceGraph(adj)
+    feats = rng.random((V, Fdim), dtype=np.float32); neigh = rng.random((V, Fdim), dtype=np.float32)
+    train = np.arange(0, V, 2, dtype=np.int64)
+    nf = next(iter(NeighborSampler(g, B, k, neighbor_type='in', shuffle=False, num_hops=hops, seed_nodes=train, seed=3)))
+    csc = spsp.csc_matrix(adj); csc.sort_indices()
+    ref = oracle.sample_nodeflow(csc.indptr, csc.indices, train[:B], k, hops, 3, 0, 0)
+    nm, o = ref["node_mapping"], ref["layer_offsets"]
+    for i in range(2):
+        ids = nm[o[i]:o[i + 1]]
+        nf._node_frames[i] = {"features": torch.from_numpy(feats[ids]).to(dev), "neigh": torch.from_numpy(neigh[ids]).to(dev)}
+    torch.manual_seed(2)
+    model = GraphSageSampling(Fdim, 16, C, 1, Fn.relu, 0.0, 'mean', preprocess=True).to(dev)
+    got = model(nf).detach().cpu().numpy()
+    P = lambda lin: (lin.weight.detach().cpu().numpy(), lin.bias.detach().cpu().numpy())
+    (Ws, bs), (Wn, bn) = P(model.fc_self), P(model.fc_neigh)
+    h = []
+    for i in range(2):
+        ids = nm[o[i]:o[i + 1]]
+        z = feats[ids] @ Ws.T + bs + neigh[ids] @ Wn.T + bn
+        h.append(np.concatenate([z, np.maximum(z, 0)], 1))
+    (W1s, b1s), (W1n, b1n) = P(model.layers[0].fc_self), P(model.layers[0].fc_neigh)
+    agg = oracle.spmm_fwd(*ref["blocks"][0], h[0], o[2] - o[1], "mean")
+    want = h[1] @ W1s.T + b1s + agg @ W1n.T + b1n
+    assert np.abs(got - want).max() < TOL * max(1.0, np.abs(want).max())
