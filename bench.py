@@ -90,20 +90,41 @@ def make_host_table(V, Fdim, rank, local_rank, world, dev, tag):
         tab = torch.empty((V, Fdim), dtype=torch.float32, pin_memory=True)
         syn.fill_random_features(tab, device=dev)
         log(f"[bench] host table {V}x{Fdim} pinned + filled in {time.time()-t0:.1f}s")
-        return tab, None
+        return tab, True
     path = f"/dev/shm/pagraph_bench_{os.environ.get('MASTER_PORT', '0')}_{tag}.bin"
+    ok = torch.ones(1, dtype=torch.int32, device=dev)
+    tab = None
     if local_rank == 0:
+        try:
+            import glob
+            for stale in glob.glob("/dev/shm/pagraph_bench_*.bin"):      # left behind by a crashed run
+                if time.time() - os.path.getmtime(stale) > 600:
+                    os.unlink(stale)
+            tab = torch.from_file(path, shared=True, size=V * Fdim, dtype=torch.float32).view(V, Fdim)
+            syn.fill_random_features(tab, device=dev)
+        except Exception as e:
+            log(f"[bench] rank {rank}: /dev/shm table failed ({e}); every rank keeps a private copy")
+            ok.zero_()
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    shared = bool(ok.item())
+    if shared and local_rank != 0:
         tab = torch.from_file(path, shared=True, size=V * Fdim, dtype=torch.float32).view(V, Fdim)
+    if not shared:
+        tab = torch.empty((V, Fdim), dtype=torch.float32)
         syn.fill_random_features(tab, device=dev)
+        path = None
     dist.barrier()
-    if local_rank != 0:
-        tab = torch.from_file(path, shared=True, size=V * Fdim, dtype=torch.float32).view(V, Fdim)
+    if shared and local_rank == 0:
+        os.unlink(path)          # every rank holds its mapping; nothing is left behind if the run dies
+        path = None
+    registered = False
     try:
         rc = torch.cuda.cudart().cudaHostRegister(tab.data_ptr(), tab.numel() * 4, 0)
+        registered = int(rc) == 0
         log(f"[bench] rank {rank}: hipHostRegister rc={rc}")
     except Exception as e:  # staged mode works from unpinned memory too
         log(f"[bench] rank {rank}: host register unavailable ({e})")
-    return tab, path
+    return tab, registered
 
 
 # ----------------------------------------------------------------------------- CPU baseline
@@ -307,15 +328,18 @@ def run():
     labels[subtrain] = labels_full.to(dev)[sub2full[subtrain]]
 
     # ---- feature provider (pa_server.py:38-54) --------------------------------------------
-    feat_tab, shm_path = make_host_table(V, Fdim, rank, local_rank, world, dev, "feat")
+    feat_tab, table_device_visible = make_host_table(V, Fdim, rank, local_rank, world, dev, "feat")
+    if not table_device_visible and args.miss_mode == "zerocopy":
+        log(f"[bench] rank {rank}: host table is not device-addressable -> staged miss path")
+        args.miss_mode = "staged"                       # a zero-copy read of unregistered memory would fault
     fields = {"features": feat_tab}
     embed_names = ["features"]
     norm_tab = None
     if args.model == "gcn":
-        norm_tab = (1.0 / in_deg).unsqueeze(1).cpu()          # pa_server.py:43 (inf for isolated vertices, as there)
+        norm_tab = (1.0 / in_deg).unsqueeze(1).cpu().pin_memory()   # pa_server.py:43 (inf for isolated vertices, as there)
         fields["norm"] = norm_tab
         embed_names = ["features", "norm"]                    # pa_gcn.py:46
-    store = HostFeatureStore(fields, pin=(world == 1))
+    store = HostFeatureStore(fields, pin=False)               # both tables are already pinned / registered
     cacher = GraphCacheServer(store, Vs, sub2full, gpu, miss_mode=args.miss_mode, host_threads=args.host_threads)
     cacher.init_field(embed_names)
     cacher.log = True
@@ -460,11 +484,6 @@ def run():
         }
     if world > 1:
         dist.barrier()
-        if shm_path and local_rank == 0:
-            try:
-                os.unlink(shm_path)
-            except OSError:
-                pass
         dist.destroy_process_group()
     return out
 

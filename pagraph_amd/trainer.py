@@ -245,7 +245,7 @@ class GraphedTrainer:
             self.optimizer.step()
         else:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=self.compute_stream):
+            with torch.cuda.graph(g, stream=self.compute_stream, capture_error_mode="thread_local"):
                 self.optimizer.step()
             self.graph_b = g
             g.replay()
@@ -265,7 +265,8 @@ class GraphedTrainer:
                 g = torch.cuda.CUDAGraph()
                 if self.world == 1:
                     self.optimizer.zero_grad(set_to_none=True)
-                with torch.cuda.graph(g, stream=main):
+                # thread_local: RCCL's watchdog thread may touch the runtime while this thread captures
+                with torch.cuda.graph(g, stream=main, capture_error_mode="thread_local"):
                     s.loss = self._step_body(s).detach()
                 s.graph = g
                 g.replay()                                   # capture does not execute
