@@ -62,7 +62,7 @@ def parse():
     p.add_argument("--batch-size", type=int, default=6000)
     p.add_argument("--num-neighbors", type=int, default=2)
     p.add_argument("--cache-ratio", type=float, default=0.30)
-    p.add_argument("--miss-mode", default="zerocopy", choices=["staged", "zerocopy"])
+    p.add_argument("--miss-mode", default="zerocopy", choices=["staged", "zerocopy", "async"])
     p.add_argument("--host-threads", type=int, default=32)
     p.add_argument("--no-overlap", action="store_true")
     p.add_argument("--skip-cpu-baseline", action="store_true")
@@ -75,6 +75,7 @@ def parse():
                    help="fetch every layer and field like the reference (default: only what the model reads, SURVEY 8f-2)")
     p.add_argument("--skip-opt-hit", action="store_true", help="skip the oracle cache-hit upper bound (opt_cache_hit.py)")
     p.add_argument("--no-graph", action="store_true", help="eager reference-style loop instead of hipGraph replay")
+    p.add_argument("--timeline", action="store_true", help="print a per-stream event timeline of a few steps (stderr)")
     p.add_argument("--profile-host", action="store_true", help="cProfile the timed region (stderr)")
     p.add_argument("--dist-backend", default="nccl", help="gloo lets two ranks share one GPU (testing only)")
     return p.parse_args()
@@ -388,6 +389,29 @@ def run():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    tl = None
+    if args.timeline and use_graph:
+        tl = []
+        _prep, _comp = trainer.prepare, trainer.compute
+        def prep(nf):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(trainer.load_stream); s_ = _prep(nf); e1.record(trainer.load_stream)
+            tl.append(("load", e0, e1)); return s_
+        def comp(s_):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            trainer.compute_stream.wait_event(s_.ready)
+            e0.record(trainer.compute_stream); r_ = _comp(s_); e1.record(trainer.compute_stream)
+            tl.append(("comp", e0, e1)); return r_
+        trainer.debug_events = []
+        trainer.prepare, trainer.compute = prep, comp
+        hostlog = []
+        def wrap(obj, name, tag):
+            f = getattr(obj, name)
+            def g_(*a, **k):
+                t0_ = time.perf_counter(); r_ = f(*a, **k); hostlog.append((tag, t0_, time.perf_counter())); return r_
+            setattr(obj, name, g_)
+        wrap(cacher, "wait_misses", "wait_misses"); wrap(cacher, "fetch_data", "fetch_data"); wrap(sampler, "_enqueue", "sampler_enqueue")
+        wrap(sampler, "release", "release")
     prof_host = None
     if args.profile_host:
         import cProfile
@@ -399,6 +423,16 @@ def run():
     if world > 1:
         dist.barrier()
     elapsed = time.time() - t0
+    if tl and getattr(trainer, "debug_events", None):
+        for ev in trainer.debug_events[30:42]:
+            log(f"[load-stream] wait(sampler ready) {ev[0].elapsed_time(ev[1])*1e3:8.1f} us | wait(slot done) {ev[1].elapsed_time(ev[2])*1e3:8.1f} us | work {ev[2].elapsed_time(ev[3])*1e3:8.1f} us")
+    if tl:
+        hb = hostlog[len(hostlog) // 2][1]
+        for tag, a_, b_ in hostlog[len(hostlog) // 2: len(hostlog) // 2 + 40]:
+            log(f"[host] {tag:16s} +{(a_-hb)*1e6:9.1f} us  took {(b_-a_)*1e6:8.1f} us")
+        base = tl[20][1]
+        for name, e0, e1 in tl[20:60]:
+            log(f"[timeline] {name} start {base.elapsed_time(e0)*1e3:9.1f} us  dur {e0.elapsed_time(e1)*1e3:8.1f} us")
     if prof_host is not None:
         import pstats
         prof_host.disable()

@@ -129,7 +129,7 @@ def main(arch, description, n_hidden, lr):
     # additions of this build
     parser.add_argument("--cache-ratio", type=float, default=None,
                         help="cap the cache at this fraction of the partition (storage.py:85-86 overrides)")
-    parser.add_argument("--miss-mode", default="zerocopy", choices=["staged", "zerocopy"])
+    parser.add_argument("--miss-mode", default="zerocopy", choices=["staged", "zerocopy", "async"])
     parser.add_argument("--no-overlap", action="store_true")
     parser.add_argument("--graph", action="store_true", help="replay the training step as a hipGraph")
     parser.add_argument("--fetch-needed", action="store_true",

@@ -118,6 +118,31 @@ int pg_scatter_rows_from_host(const float* table_pinned, int64_t table_stride, c
                               const int64_t* fullid, int64_t n_max, const int32_t* n_dev, int32_t dim,
                               float* out, int32_t out_stride, pg_stream_t stream);
 
+/* Asynchronous miss path (storage.py:117-131,196-200 off the trainer's critical path): a worker
+ * thread owned by the handle waits for the GPU to publish a slot's miss list, gathers table[fullid]
+ * into pinned staging with `n_threads` helpers, and enqueues hipMemcpyAsync + the row scatter on its
+ * own copy stream. One slot per in-flight minibatch.                                                */
+typedef struct pg_missq pg_missq_t;
+typedef struct pg_missq_field {
+  const float* table;    /* host table [V, table_stride] (pageable or pinned) */
+  int64_t table_stride;  /* floats */
+  int32_t dim;
+  int32_t _pad;
+} pg_missq_field_t;
+int pg_missq_create(int device, int n_slots, int64_t max_rows, const pg_missq_field_t* fields, int n_fields,
+                    int n_threads, pg_missq_t** out);
+int pg_missq_destroy(pg_missq_t* q);
+/* the slot's miss-list buffers, to be passed to pg_gather_rows as miss_pos / miss_fullid / miss_count */
+int pg_missq_slot_buffers(pg_missq_t* q, int slot, int32_t** miss_pos_dev, int64_t** miss_fullid_pinned,
+                          int32_t** miss_count_dev);
+/* call right after pg_gather_rows(...slot buffers...) on the same stream: publishes the miss list to the
+ * worker. out_ptrs[f] / out_strides[f]: destination of field f's rows (NULL = field not wanted).   */
+int pg_missq_submit(pg_missq_t* q, int slot, float* const* out_ptrs, const int32_t* out_strides,
+                    pg_stream_t stream);
+/* makes `stream` wait until the slot's miss rows have landed; blocks the HOST only until the worker has
+ * enqueued the copy. miss_count_out (optional) receives the number of rows.                         */
+int pg_missq_wait(pg_missq_t* q, int slot, pg_stream_t stream, int32_t* miss_count_out);
+
 /* ------------------------------------------------------------------------
  * 2. Neighbour sampler  —  dgl.contrib.sampling.NeighborSampler as called at
  *    examples/profile/pa_gcn.py:71-76 and PaGraph/partition/utils.py:11-18.

@@ -34,6 +34,10 @@ class PgNodeflowDesc(ctypes.Structure):
                 ("padded", c_i32), ("_pad", c_i32)]
 
 
+class PgMissqField(ctypes.Structure):
+    _fields_ = [("table", vp), ("table_stride", c_i64), ("dim", c_i32), ("_pad", c_i32)]
+
+
 class PgError(RuntimeError):
     pass
 
@@ -51,6 +55,12 @@ _SIGS = {
     "pg_scatter_rows": (ctypes.c_int, [vp, vp, c_i64, vp, c_i32, vp, c_i32, vp]),
     "pg_host_gather_rows": (ctypes.c_int, [vp, c_i64, c_i32, vp, c_i64, vp, ctypes.c_int]),
     "pg_scatter_rows_from_host": (ctypes.c_int, [vp, c_i64, vp, vp, c_i64, vp, c_i32, vp, c_i32, vp]),
+    "pg_missq_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_i64, ctypes.POINTER(PgMissqField), ctypes.c_int,
+                                       ctypes.c_int, ctypes.POINTER(vp)]),
+    "pg_missq_destroy": (ctypes.c_int, [vp]),
+    "pg_missq_slot_buffers": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]),
+    "pg_missq_submit": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(c_i32), vp]),
+    "pg_missq_wait": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.POINTER(c_i32)]),
     "pg_sampler_create": (ctypes.c_int, [c_i64, vp, vp, c_i32, c_i32, c_i32, ctypes.POINTER(vp)]),
     "pg_sampler_destroy": (ctypes.c_int, [vp]),
     "pg_sampler_capacity": (ctypes.c_int, [vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),

@@ -1,0 +1,366 @@
+// Asynchronous miss path: "cache misses fall through to a pinned-host hipMemcpyAsync on a side
+// stream overlapped with compute" (north star) — the reference's get_feat_from_server
+// (PaGraph/storage/storage.py:117-131: CPU fancy-index over the shared-memory table + H2D copy)
+// moved off the trainer's critical path.
+//
+// Why not just read the host table from a kernel (pg_scatter_rows_from_host)?  It works and needs no
+// host thread, but while a kernel has PCIe reads in flight every kernel boundary of the OTHER streams
+// gets ~1.2 us slower (measured, tools/exp_overlap2.py: a 380 us zero-copy scatter next to a chain of
+// 90 small dependent kernels costs 488 us instead of 380; the same low-occupancy kernel reading HBM
+// overlaps perfectly). The copy engines (SDMA) do not have that side effect.
+//
+// Per slot (one per in-flight minibatch):
+//   GPU, load stream : k_split/k_gather write the miss list (positions -> HBM, full ids -> pinned
+//                      host) ; k_publish copies the miss count to pinned host and raises a flag.
+//   worker thread    : waits for the flag, gathers table[fullid] rows into a pinned staging buffer
+//                      with a small thread pool, enqueues hipMemcpyAsync(staging -> HBM) and the
+//                      row-scatter kernel on its own copy stream, records an event.
+//   consumer         : pg_missq_wait(slot, stream) makes the compute stream wait on that event.
+// The trainer thread never blocks on the GPU; it blocks in pg_missq_wait only if the worker has not
+// yet *enqueued* the copy of a batch that was submitted a whole step earlier.
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "pg_common.h"
+
+namespace pg {
+
+__global__ void k_publish(const int32_t* __restrict__ count_dev, int32_t* count_host, uint32_t* flag_host,
+                          uint32_t seq) {
+  *count_host = *count_dev;
+  __threadfence_system();
+  __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// minimal persistent thread pool: parallel_for over [0, n) in contiguous chunks
+class Pool {
+ public:
+  explicit Pool(int n) : n_(n < 1 ? 1 : n) {
+    for (int i = 1; i < n_; ++i) th_.emplace_back([this, i] { loop(i); });
+  }
+  ~Pool() {
+    {
+      std::lock_guard<std::mutex> l(m_);
+      stop_ = true;
+      ++gen_;
+    }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  void parallel_for(int64_t n, const std::function<void(int64_t, int64_t)>& f) {
+    if (n <= 0) return;
+    const int parts = (int)std::min<int64_t>(n_, (n + 127) / 128);
+    if (parts <= 1) {
+      f(0, n);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> l(m_);
+      fn_ = &f;
+      total_ = n;
+      parts_ = parts;
+      pending_ = parts - 1;
+      ++gen_;
+    }
+    cv_.notify_all();
+    run_part(0);
+    std::unique_lock<std::mutex> l(m_);
+    done_cv_.wait(l, [this] { return pending_ == 0; });
+  }
+
+ private:
+  void run_part(int i) {
+    const int64_t per = (total_ + parts_ - 1) / parts_;
+    const int64_t lo = std::min<int64_t>(total_, i * per), hi = std::min<int64_t>(total_, (i + 1) * per);
+    if (hi > lo) (*fn_)(lo, hi);
+  }
+  void loop(int i) {
+    uint64_t seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> l(m_);
+      cv_.wait(l, [&] { return gen_ != seen; });
+      seen = gen_;
+      if (stop_) return;
+      const bool mine = i < parts_;
+      l.unlock();
+      if (mine) {
+        run_part(i);
+        std::lock_guard<std::mutex> g(m_);
+        if (--pending_ == 0) done_cv_.notify_one();
+      }
+    }
+  }
+  int n_;
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(int64_t, int64_t)>* fn_ = nullptr;
+  int64_t total_ = 0;
+  int parts_ = 0, pending_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+
+}  // namespace pg
+
+using namespace pg;
+
+struct pg_missq_slot {
+  int64_t* fullid_h = nullptr;   // pinned [max_rows]
+  int32_t* count_h = nullptr;    // pinned
+  uint32_t* flag_h = nullptr;    // pinned
+  int32_t* pos_d = nullptr;      // device [max_rows]
+  int32_t* count_d = nullptr;    // device
+  float* staging_h[PG_MAX_FIELDS] = {nullptr};  // pinned [max_rows * dim]
+  float* staged_d[PG_MAX_FIELDS] = {nullptr};   // device [max_rows * dim]
+  hipEvent_t filled = nullptr;
+  uint32_t submitted = 0;  // last sequence number handed to the worker (trainer thread)
+  uint32_t done = 0;       // last sequence number whose copy has been enqueued (worker, under mutex)
+  int32_t last_count = 0;
+  float* out[PG_MAX_FIELDS] = {nullptr};
+  int32_t out_stride[PG_MAX_FIELDS] = {0};
+  std::chrono::steady_clock::time_point t_submit;
+};
+
+struct pg_missq {
+  int device = 0, n_slots = 0, n_fields = 0;
+  int64_t max_rows = 0;
+  pg_missq_field_t fields[PG_MAX_FIELDS];
+  std::vector<pg_missq_slot> slots;
+  hipStream_t copy_stream = nullptr;
+  Pool* pool = nullptr;
+  std::thread worker;
+  std::mutex m;
+  std::condition_variable cv_job, cv_done;
+  std::deque<std::pair<int, uint32_t>> jobs;
+  bool stop = false;
+  int error = PG_OK;
+  // PG_MISSQ_DEBUG=1: accumulated worker phase times (us) printed at destroy
+  double t_sync = 0, t_flag = 0, t_gather = 0, t_enqueue = 0, t_copy = 0, t_sub2flag = 0, t_sub2pop = 0;
+  int64_t n_jobs = 0, n_rows = 0;
+};
+
+static void missq_worker(pg_missq* q) {
+  if (hipSetDevice(q->device) != hipSuccess) {
+    std::lock_guard<std::mutex> l(q->m);
+    q->error = PG_ERR_HIP;
+  }
+  for (;;) {
+    std::pair<int, uint32_t> job;
+    {
+      std::unique_lock<std::mutex> l(q->m);
+      q->cv_job.wait(l, [q] { return q->stop || !q->jobs.empty(); });
+      if (q->stop && q->jobs.empty()) return;
+      job = q->jobs.front();
+      q->jobs.pop_front();
+    }
+    pg_missq_slot& s = q->slots[job.first];
+    int rc = PG_OK;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double, std::micro>(b - a).count();
+    };
+    const auto t0 = now();
+    // the previous copy out of this slot's staging buffers must have drained (4 steps ago: a formality)
+    if (hipEventSynchronize(s.filled) != hipSuccess) rc = PG_ERR_HIP;
+    const auto t1 = now();
+    // wait for the GPU to publish the miss list of this submission
+    while (__atomic_load_n(s.flag_h, __ATOMIC_ACQUIRE) != job.second) {
+      {
+        std::lock_guard<std::mutex> l(q->m);
+        if (q->stop) return;
+      }
+      std::this_thread::sleep_for(std::chrono::microseconds(5));
+    }
+    const int64_t m = *s.count_h;
+    const auto t2 = now();
+    q->t_sub2flag += us(s.t_submit, t2);
+    q->t_sub2pop += us(s.t_submit, t0);
+    double tg = 0, te = 0;
+    if (m > 0 && rc == PG_OK) {
+      for (int f = 0; f < q->n_fields && rc == PG_OK; ++f) {
+        if (!s.out[f]) continue;   // this launch did not ask for the field
+        const pg_missq_field_t& fd = q->fields[f];
+        const size_t row_bytes = (size_t)fd.dim * sizeof(float);
+        float* stg = s.staging_h[f];
+        const int64_t* ids = s.fullid_h;
+        const auto ta = now();
+        q->pool->parallel_for(m, [&](int64_t lo, int64_t hi) {   // storage.py:128 table[nids]
+          for (int64_t j = lo; j < hi; ++j)
+            std::memcpy(stg + j * fd.dim, fd.table + ids[j] * fd.table_stride, row_bytes);
+        });
+        const auto tb = now();
+        tg += us(ta, tb);
+        if (hipMemcpyAsync(s.staged_d[f], stg, (size_t)m * row_bytes, hipMemcpyHostToDevice, q->copy_stream) !=
+            hipSuccess)
+          rc = PG_ERR_HIP;
+        if (rc == PG_OK)
+          rc = pg_scatter_rows(s.staged_d[f], s.pos_d, m, nullptr, fd.dim, s.out[f], s.out_stride[f],
+                               (pg_stream_t)q->copy_stream);                 // storage.py:199-200
+        te += us(tb, now());
+      }
+    }
+    if (hipEventRecord(s.filled, q->copy_stream) != hipSuccess) rc = PG_ERR_HIP;
+    static const bool dbg_copy = getenv("PG_MISSQ_DEBUG") && atoi(getenv("PG_MISSQ_DEBUG")) >= 2;
+    if (dbg_copy) {
+      const auto tc = now();
+      (void)hipEventSynchronize(s.filled);
+      q->t_copy += us(tc, now());
+    }
+    {
+      std::lock_guard<std::mutex> l(q->m);
+      s.done = job.second;
+      s.last_count = (int32_t)m;
+      q->t_sync += us(t0, t1); q->t_flag += us(t1, t2); q->t_gather += tg; q->t_enqueue += te;
+      q->n_jobs += 1; q->n_rows += m;
+      if (rc != PG_OK) q->error = rc;
+    }
+    q->cv_done.notify_all();
+  }
+}
+
+static void missq_free(pg_missq* q) {
+  if (!q) return;
+  if (getenv("PG_MISSQ_DEBUG") && q->n_jobs)
+    fprintf(stderr, "[missq] jobs %ld rows/job %.0f | per job us: event-sync %.1f flag-wait %.1f cpu-gather %.1f enqueue %.1f copy-drain(dbg2) %.1f | submit->pop %.1f submit->flag %.1f\n",
+            (long)q->n_jobs, (double)q->n_rows / q->n_jobs, q->t_sync / q->n_jobs, q->t_flag / q->n_jobs,
+            q->t_gather / q->n_jobs, q->t_enqueue / q->n_jobs, q->t_copy / q->n_jobs, q->t_sub2pop / q->n_jobs, q->t_sub2flag / q->n_jobs);
+  if (q->worker.joinable()) {
+    {
+      std::lock_guard<std::mutex> l(q->m);
+      q->stop = true;
+    }
+    q->cv_job.notify_all();
+    q->worker.join();
+  }
+  for (auto& s : q->slots) {
+    (void)hipHostFree(s.fullid_h);
+    (void)hipHostFree(s.count_h);
+    (void)hipHostFree(s.flag_h);
+    (void)hipFree(s.pos_d);
+    (void)hipFree(s.count_d);
+    for (int f = 0; f < PG_MAX_FIELDS; ++f) {
+      (void)hipHostFree(s.staging_h[f]);
+      (void)hipFree(s.staged_d[f]);
+    }
+    if (s.filled) (void)hipEventDestroy(s.filled);
+  }
+  if (q->copy_stream) (void)hipStreamDestroy(q->copy_stream);
+  delete q->pool;
+  delete q;
+}
+
+extern "C" {
+
+int pg_missq_create(int device, int n_slots, int64_t max_rows, const pg_missq_field_t* fields, int n_fields,
+                    int n_threads, pg_missq_t** out) {
+  if (!out || n_slots <= 0 || n_slots > 64 || max_rows <= 0 || !fields || n_fields <= 0 || n_fields > PG_MAX_FIELDS)
+    return PG_ERR_INVALID;
+  for (int f = 0; f < n_fields; ++f)
+    if (!fields[f].table || fields[f].dim <= 0 || fields[f].table_stride < fields[f].dim) return PG_ERR_INVALID;
+  PG_HIP(hipSetDevice(device));
+  pg_missq* q = new (std::nothrow) pg_missq;
+  if (!q) return PG_ERR_NOMEM;
+  q->device = device; q->n_slots = n_slots; q->n_fields = n_fields; q->max_rows = max_rows;
+  for (int f = 0; f < n_fields; ++f) q->fields[f] = fields[f];
+  q->slots.resize(n_slots);
+  bool ok = hipStreamCreateWithFlags(&q->copy_stream, hipStreamNonBlocking) == hipSuccess;
+  for (auto& s : q->slots) {
+    ok = ok && hipHostMalloc((void**)&s.fullid_h, max_rows * 8, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&s.count_h, 64, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&s.flag_h, 64, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc((void**)&s.pos_d, max_rows * 4) == hipSuccess;
+    ok = ok && hipMalloc((void**)&s.count_d, 64) == hipSuccess;
+    for (int f = 0; f < n_fields && ok; ++f) {
+      const size_t bytes = (size_t)max_rows * fields[f].dim * sizeof(float);
+      ok = ok && hipHostMalloc((void**)&s.staging_h[f], bytes, hipHostMallocDefault) == hipSuccess;
+      ok = ok && hipMalloc((void**)&s.staged_d[f], bytes) == hipSuccess;
+    }
+    ok = ok && hipEventCreateWithFlags(&s.filled, hipEventDisableTiming) == hipSuccess;
+    if (!ok) break;
+    *s.flag_h = 0;
+    *s.count_h = 0;
+    ok = ok && hipMemset(s.count_d, 0, 64) == hipSuccess;
+    ok = ok && hipEventRecord(s.filled, q->copy_stream) == hipSuccess;
+  }
+  if (!ok) {
+    missq_free(q);
+    return PG_ERR_NOMEM;
+  }
+  q->pool = new (std::nothrow) Pool(n_threads);
+  if (!q->pool) {
+    missq_free(q);
+    return PG_ERR_NOMEM;
+  }
+  q->worker = std::thread(missq_worker, q);
+  *out = q;
+  return PG_OK;
+}
+
+int pg_missq_destroy(pg_missq_t* q) {
+  missq_free(q);
+  return PG_OK;
+}
+
+int pg_missq_slot_buffers(pg_missq_t* q, int slot, int32_t** miss_pos_dev, int64_t** miss_fullid_pinned,
+                          int32_t** miss_count_dev) {
+  if (!q || slot < 0 || slot >= q->n_slots) return PG_ERR_INVALID;
+  pg_missq_slot& s = q->slots[slot];
+  if (miss_pos_dev) *miss_pos_dev = s.pos_d;
+  if (miss_fullid_pinned) *miss_fullid_pinned = s.fullid_h;
+  if (miss_count_dev) *miss_count_dev = s.count_d;
+  return PG_OK;
+}
+
+int pg_missq_submit(pg_missq_t* q, int slot, float* const* out_ptrs, const int32_t* out_strides, pg_stream_t stream) {
+  if (!q || slot < 0 || slot >= q->n_slots || !out_ptrs || !out_strides) return PG_ERR_INVALID;
+  pg_missq_slot& s = q->slots[slot];
+  uint32_t seq;
+  {
+    std::unique_lock<std::mutex> l(q->m);
+    // the slot's previous submission must have left the worker (its buffers are about to be reused)
+    q->cv_done.wait(l, [&] { return s.done == s.submitted || q->error != PG_OK; });
+    if (q->error != PG_OK) return q->error;
+    seq = ++s.submitted;
+    s.t_submit = std::chrono::steady_clock::now();
+    for (int f = 0; f < q->n_fields; ++f) {
+      s.out[f] = out_ptrs[f];
+      s.out_stride[f] = out_strides[f];
+    }
+  }
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, as_stream(stream), s.count_d, s.count_h, s.flag_h, seq);
+  PG_LAUNCH_CHECK();
+  {
+    std::lock_guard<std::mutex> l(q->m);
+    q->jobs.emplace_back(slot, seq);
+  }
+  q->cv_job.notify_one();
+  return PG_OK;
+}
+
+int pg_missq_wait(pg_missq_t* q, int slot, pg_stream_t stream, int32_t* miss_count_out) {
+  if (!q || slot < 0 || slot >= q->n_slots) return PG_ERR_INVALID;
+  pg_missq_slot& s = q->slots[slot];
+  {
+    std::unique_lock<std::mutex> l(q->m);
+    static const bool dbg3 = getenv("PG_MISSQ_DEBUG") && atoi(getenv("PG_MISSQ_DEBUG")) >= 3;
+    if (dbg3) fprintf(stderr, "[missq-wait] slot %d submitted %u done %u | queue %zu\n", slot, s.submitted, s.done, q->jobs.size());
+    q->cv_done.wait(l, [&] { return s.done == s.submitted || q->error != PG_OK; });
+    if (q->error != PG_OK) return q->error;
+    if (miss_count_out) *miss_count_out = s.last_count;
+  }
+  PG_HIP(hipStreamWaitEvent(as_stream(stream), s.filled, 0));
+  return PG_OK;
+}
+
+}  // extern "C"

@@ -40,6 +40,7 @@ class _Slot:
         self.ready = torch.cuda.Event()
         self.free = torch.cuda.Event()
         self.free_recorded = False
+        self.held = False            # sampled into and not yet released by its consumer
         d = L.PgNodeflowDesc()
         d.node_mapping = self.node_mapping.data_ptr()
         d.layer_offsets = self.layer_offsets.data_ptr()
@@ -79,6 +80,7 @@ class NeighborSampler:
         self.seeds = seeds.to(self.device).contiguous()
         self.num_batches = (self.seeds.numel() + self.batch_size - 1) // self.batch_size
         self.epoch = 0
+        self._ring_pos = 0
         h = L.vp()
         with torch.cuda.device(self.device):
             L.check(self.lib.pg_sampler_create(g.number_of_nodes(), L.ptr(g.indptr), L.ptr(g.indices), self.batch_size,
@@ -89,6 +91,9 @@ class NeighborSampler:
         # stream on which the consumer finishes with a NodeFlow (None = current stream at hand-back);
         # a ring slot is re-sampled only after the event recorded there
         self.consumer_stream = None
+        # True: the consumer calls release(nf) itself once the work that reads the NodeFlow is enqueued
+        # (needed when it holds several prepared batches at once); False: released when the iterator advances
+        self.manual_release = False
         self.slots = [_Slot(self.lib, self.handle, self.num_hops, self.device, padded=self.static)
                       for _ in range(4 if self.static else 3)]
 
@@ -103,8 +108,27 @@ class NeighborSampler:
     def __len__(self):
         return self.num_batches
 
+    def _release_slot(self, slot):
+        slot.free.record(self.consumer_stream or torch.cuda.current_stream(self.device))
+        slot.free_recorded = True
+        slot.held = False
+
+    def release(self, nf):
+        """manual_release mode: the ring slot behind `nf` may be re-sampled once the work enqueued so far
+        on the consumer stream has finished"""
+        slot = getattr(nf, "_slot", None)
+        if slot is not None:
+            self._release_slot(slot)
+
     def _enqueue(self, b, epoch):
-        slot = self.slots[b % len(self.slots)]
+        # ring position is global (not b % n): an epoch's last batch and the next epoch's first one
+        # must not land in the same slot while the former is still in flight
+        slot = self.slots[self._ring_pos % len(self.slots)]
+        self._ring_pos += 1
+        if slot.held:
+            raise L.PgError("NeighborSampler ring overrun: a NodeFlow handed out earlier was never released "
+                            "(manual_release consumers must call sampler.release(nf) before the ring wraps)")
+        slot.held = True
         lo = b * self.batch_size
         n = min(self.batch_size, self.seeds.numel() - lo)
         if slot.free_recorded:
@@ -163,13 +187,23 @@ class NeighborSampler:
         if nb == 0:
             return
         pending = self._enqueue(0, epoch)
-        for b in range(nb):
-            slot = pending
-            if b + 1 < nb and self.prefetch:
-                pending = self._enqueue(b + 1, epoch)
-            nf = self._finalize(slot)
-            yield nf
-            slot.free.record(self.consumer_stream or torch.cuda.current_stream(self.device))
-            slot.free_recorded = True
-            if b + 1 < nb and not self.prefetch:
-                pending = self._enqueue(b + 1, epoch)
+        slot = None
+        try:
+            for b in range(nb):
+                slot, pending = pending, None
+                if b + 1 < nb and self.prefetch:
+                    pending = self._enqueue(b + 1, epoch)
+                nf = self._finalize(slot)
+                yield nf
+                if not self.manual_release:
+                    self._release_slot(slot)
+                slot = None
+                if b + 1 < nb and not self.prefetch:
+                    pending = self._enqueue(b + 1, epoch)
+        finally:
+            # iterator abandoned mid-epoch (break / cycle_batches): hand back what was never consumed.
+            # Anything already handed out in manual_release mode stays with its consumer.
+            if pending is not None:
+                pending.held = False
+            if slot is not None and not self.manual_release:
+                slot.held = False

@@ -88,7 +88,7 @@ class GraphCacheServer:
         self.miss_num = 0
 
         # miss path state
-        assert miss_mode in ("staged", "zerocopy")
+        assert miss_mode in ("staged", "zerocopy", "async")
         self.miss_mode = miss_mode
         self.host_threads = host_threads
         self._cap = 0
@@ -104,6 +104,10 @@ class GraphCacheServer:
         # bench.py: when a list, every gather launch is bracketed by HIP events on its own stream
         # and (timer_handle, rows, misses_or_None) is appended
         self.profile = None
+        # miss_mode == "async": libpagraph's worker-thread miss queue (pg_missq_*), one slot per in-flight batch
+        self._missq = None
+        self._missq_rows = 0
+        self.missq_slots = 4
 
     # -- reference-shaped views of the fused slot map --------------------------
     def _export(self):
@@ -246,7 +250,7 @@ class GraphCacheServer:
         self._cap = cap
 
     # -- storage.py:157-204 ---------------------------------------------------
-    def fetch_data(self, nodeflow, out=None, need=None):
+    def fetch_data(self, nodeflow, out=None, need=None, slot=None):
         """Fill nodeflow._node_frames[i][name] for every layer and field: hits from the HBM
         cache, misses from the host store. One gather launch for all layers; rows of layer i are
         the slice [offsets[i], offsets[i+1]) of one [R, dim] buffer per field.
@@ -255,7 +259,9 @@ class GraphCacheServer:
         `need` (optional, SURVEY §8f-2 "fetch only what the model reads"): {layer index: [field names]};
         rows of layers / fields the model never reads are neither gathered nor fetched over PCIe
         (GCN training reads only layer 0's 'features', gcn_nssc.py:64). Default: everything, as the
-        reference does."""
+        reference does.
+        `slot` (miss_mode == "async"): index of the in-flight batch; the miss rows land asynchronously,
+        call wait_misses(slot) on the consuming stream before reading the frames."""
         if self.full_cached:
             self.fetch_from_cache(nodeflow, out=out)
             return
@@ -281,6 +287,11 @@ class GraphCacheServer:
             if out is None:
                 out = {name: torch.empty((R, self.dims[name]), dtype=torch.float32, device=self.device) for name in names}
             self._ensure_capacity(R)
+            miss_pos, miss_fullid, miss_count = L.ptr(self._miss_pos), L.ptr(self._miss_fullid), L.ptr(self._miss_count)
+            if self.miss_mode == "async":
+                if slot is None:
+                    raise L.PgError("miss_mode='async' needs fetch_data(..., slot=k)")
+                miss_pos, miss_fullid, miss_count = self._missq_buffers(slot, R)
         with torch.autograd.profiler.record_function('cache-gpu'):
             fields, nf = L.make_fields(
                 (self.gpu_fix_cache.get(name), out[name], self.dims[name],
@@ -291,13 +302,21 @@ class GraphCacheServer:
                 timer = L.vp()
                 L.check(self.lib.pg_timer_create(ctypes.byref(timer)), "pg_timer_create")
             L.check(self.lib.pg_gather_rows(L.ptr(nf_nids), R, L.ptr(self.slot_map), L.ptr(self.nid_map), fields, nf,
-                                            L.ptr(self._miss_pos), L.ptr(self._miss_fullid), L.ptr(self._miss_count),
+                                            miss_pos, miss_fullid, miss_count,
                                             L.ptr(self._slots), L.ptr(self._stats) if self.log else None, timer, sp),
                     "pg_gather_rows")
             if timer is not None:
                 self.profile.append([timer, R, None])
         with torch.autograd.profiler.record_function('cache-cpu'):
-            if self.miss_mode == "zerocopy":
+            if self.miss_mode == "async":
+                optrs = (L.vp * L.PG_MAX_FIELDS)()
+                ostr = (L.c_i32 * L.PG_MAX_FIELDS)()
+                for f, name in enumerate(self.dims):          # queue fields are in self.dims order
+                    if name in out and name in names:
+                        optrs[f] = out[name].data_ptr()
+                        ostr[f] = out[name].stride(0)
+                L.check(self.lib.pg_missq_submit(self._missq, slot, optrs, ostr, sp), "pg_missq_submit")
+            elif self.miss_mode == "zerocopy":
                 for name in names:
                     tab = _table(self.graph, name)
                     L.check(self.lib.pg_scatter_rows_from_host(
@@ -333,6 +352,39 @@ class GraphCacheServer:
                     continue
                 keep = names if need is None else [n for n in names if n in need[i]]
                 nodeflow._node_frames[i] = {name: out[name][offsets[i] - row_lo:offsets[i + 1] - row_lo] for name in keep}
+
+    def _missq_buffers(self, slot, rows):
+        if self._missq is None or rows > self._missq_rows:
+            if self._missq is not None:
+                L.check(self.lib.pg_missq_destroy(self._missq), "pg_missq_destroy")
+            cap = max(int(rows * 1.25), 4096)
+            arr = (L.PgMissqField * len(self.dims))()
+            for f, name in enumerate(self.dims):
+                tab = _table(self.graph, name)
+                arr[f].table, arr[f].table_stride, arr[f].dim = tab.data_ptr(), tab.stride(0), self.dims[name]
+            h = L.vp()
+            L.check(self.lib.pg_missq_create(self.device.index, self.missq_slots, cap, arr, len(self.dims),
+                                             self.host_threads, ctypes.byref(h)), "pg_missq_create")
+            self._missq, self._missq_rows = h, cap
+        pos, full, cnt = L.vp(), L.vp(), L.vp()
+        L.check(self.lib.pg_missq_slot_buffers(self._missq, slot, ctypes.byref(pos), ctypes.byref(full),
+                                               ctypes.byref(cnt)), "pg_missq_slot_buffers")
+        return pos, full, cnt
+
+    def wait_misses(self, slot, stream=None):
+        """miss_mode == 'async': order `stream` (default: current) after the slot's miss rows"""
+        if self.miss_mode != "async" or self._missq is None or self.full_cached:
+            return
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        L.check(self.lib.pg_missq_wait(self._missq, slot, L.stream_ptr(st), None), "pg_missq_wait")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_missq", None):
+                self.lib.pg_missq_destroy(self._missq)
+                self._missq = None
+        except Exception:
+            pass
 
     # -- storage.py:207-216 ---------------------------------------------------
     def fetch_from_cache(self, nodeflow, out=None):

@@ -25,7 +25,7 @@ def _record_stream(nf, stream):
 
 
 class Prepared:
-    __slots__ = ("nf", "label", "event")
+    __slots__ = ("nf", "label", "event", "slot")
 
 
 class MinibatchTrainer:
@@ -39,21 +39,24 @@ class MinibatchTrainer:
         self.on_step = None          # callback(step_in_epoch, loss_tensor)
         self.after_first_step = None  # callback() — pa_gcn.py:99-100 (auto_cache)
         self._first_done = False
+        self._nprep = 0
 
     # -- 'gpu-load' (pa_gcn.py:87-91) ----------------------------------------
     def prepare(self, nf):
         p = Prepared()
         p.nf = nf
+        p.slot = self._nprep % self.cacher.missq_slots     # async miss path: one slot per in-flight batch
+        self._nprep += 1
         if self.load_stream is None:
             with torch.autograd.profiler.record_function('gpu-load'):
-                self.cacher.fetch_data(nf, need=self.need)
+                self.cacher.fetch_data(nf, need=self.need, slot=p.slot)
                 p.label = self.labels[nf.layer_parent_nid(-1)]
             p.event = None
             return p
         main = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(self.load_stream):
             with torch.autograd.profiler.record_function('gpu-load'):
-                self.cacher.fetch_data(nf, need=self.need)
+                self.cacher.fetch_data(nf, need=self.need, slot=p.slot)
                 p.label = self.labels[nf.layer_parent_nid(-1)]
             p.event = torch.cuda.Event()
             p.event.record(self.load_stream)
@@ -65,6 +68,7 @@ class MinibatchTrainer:
     def compute(self, p):
         if p.event is not None:
             torch.cuda.current_stream(self.device).wait_event(p.event)
+        self.cacher.wait_misses(p.slot)
         with torch.autograd.profiler.record_function('gpu-compute'):
             pred = self.model(p.nf)
             loss = self.loss_fcn(pred, p.label)
@@ -176,6 +180,14 @@ class GraphedTrainer:
         # AccumulateGrad nodes and the captured graphs agree on the stream
         self.compute_stream = torch.cuda.Stream(device=device)
         sampler.consumer_stream = self.compute_stream   # ring slots are recycled after the graph that read them
+        sampler.manual_release = True
+        cacher.missq_slots = len(sampler.slots)
+        # batches prepared ahead of the one being computed. The async miss path needs 2: its worker thread
+        # must have finished batch k+1 (GPU publishes the miss list -> CPU gather -> copy enqueued) by the time
+        # the host wants to enqueue compute(k+1), i.e. one whole step after it was submitted.
+        self.lookahead = 2 if cacher.miss_mode == "async" else 1
+        assert self.lookahead + 2 <= len(sampler.slots)   # prepared (+1 transient) + the sampler's own prefetch
+        self._prepared = []
         self.slots = {}
         self.warmup_eager = warmup_eager
         self.steps_done = 0
@@ -206,18 +218,31 @@ class GraphedTrainer:
             self.slots[key] = self._make_slot(nf)
         s = self.slots[key]
         with torch.cuda.stream(self.load_stream):
+            dbg = getattr(self, "debug_events", None)
+            if dbg is not None:
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                ev[0].record(self.load_stream)
             self.load_stream.wait_event(nf._slot.ready)  # the sampler wrote this NodeFlow on its own stream
+            if dbg is not None:
+                ev[1].record(self.load_stream)
             if s.done_recorded:
                 self.load_stream.wait_event(s.done)      # the graph that read these buffers has finished
-            self.cacher.fetch_data(nf, out=s.out, need=self.need)
+            if dbg is not None:
+                ev[2].record(self.load_stream)
+            s.slot_index = self.sampler.slots.index(nf._slot)
+            self.cacher.fetch_data(nf, out=s.out, need=self.need, slot=s.slot_index)
             ids = nf.layer_parent_nid(-1)
             lab = self.labels[ids.clamp(min=0)]
             torch.where(ids >= 0, lab, torch.full_like(lab, -100), out=s.label)
             s.ready.record(self.load_stream)
+            if dbg is not None:
+                ev[3].record(self.load_stream)
+                dbg.append(ev)
         # the static NodeFlow views of a slot are rebuilt per batch but alias the same memory:
         # keep the first one (the graph captured ITS tensors) and only refresh the frames
         if s.nf is None:
             s.nf = nf
+        s.nf_cur = nf
         return s
 
     def _step_body(self, s):
@@ -253,6 +278,7 @@ class GraphedTrainer:
     def compute(self, s):
         main = self.compute_stream
         main.wait_event(s.ready)
+        self.cacher.wait_misses(s.slot_index, main)
         with torch.cuda.stream(main):
             warm = self.steps_done < self.warmup_eager
             if s.graph is not None:
@@ -283,24 +309,30 @@ class GraphedTrainer:
 
     def run_steps(self, it, steps=None):
         done = 0
-        nf = next(it, None)
-        if nf is None:
-            return 0
-        cur = self.prepare(nf)
-        while cur is not None:
+
+        def prepare_one():
+            nf = next(it, None)
+            if nf is None:
+                return False
+            self._prepared.append(self.prepare(nf))
+            return True
+
+        while len(self._prepared) < self.lookahead and prepare_one():
+            pass
+        while self._prepared and (steps is None or done < steps):
+            # top the pipeline up BEFORE (possibly) blocking on the oldest batch's miss rows: the sampler
+            # and the load stream of later batches must never wait for the host
+            if steps is None or done + len(self._prepared) < steps:
+                prepare_one()
+            cur = self._prepared.pop(0)
             loss = self.compute(cur)
+            self.sampler.release(cur.nf_cur)
             done += 1
             if not self._first_done:
                 self._first_done = True
                 if self.after_first_step is not None:
                     torch.cuda.synchronize(self.device)
                     self.after_first_step()
-            nxt = None
-            if steps is None or done < steps:
-                nf = next(it, None)
-                if nf is not None:
-                    nxt = self.prepare(nf)
             if self.on_step is not None:
                 self.on_step(done, loss)
-            cur = nxt
         return done

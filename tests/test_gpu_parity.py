@@ -37,7 +37,7 @@ def _cacher(z, dev, mode="staged"):
     return c
 
 
-@pytest.mark.parametrize("mode", ["staged", "zerocopy"])
+@pytest.mark.parametrize("mode", ["staged", "zerocopy", "async"])
 @pytest.mark.parametrize("F", [8, 600, 602])
 def test_fetch_data_vs_reference_golden(dev, hiplib, golden_dir, F, mode):
     """G1/G2: GraphCacheServer.fetch_data == the reference's outputs, bit for bit"""
@@ -50,15 +50,17 @@ def test_fetch_data_vs_reference_golden(dev, hiplib, golden_dir, F, mode):
     assert np.array_equal(c.gpu_flag.cpu().numpy(), z["state_gpu_flag"])
     assert c.cached_num == int(z["state_cached_num"])
     layers = [z[f"layer{i}_nids"] for i in range(int(z["num_layers"]))]
-    nf = FakeNF(layers, dev)
-    c.fetch_data(nf)
-    torch.cuda.synchronize()
-    for i in range(len(layers)):
-        for name in ("features", "norm"):
-            got = nf._node_frames[i][name].cpu().numpy()
-            assert got.shape == z[f"layer{i}_{name}"].shape
-            assert np.array_equal(got, z[f"layer{i}_{name}"]), (i, name)
-    assert c.get_miss_rate() == float(z["miss_rate"])
+    for rep in range(3):                                  # async: the slots are reused
+        nf = FakeNF(layers, dev)
+        c.fetch_data(nf, slot=rep % 2)
+        c.wait_misses(rep % 2)
+        torch.cuda.synchronize()
+        for i in range(len(layers)):
+            for name in ("features", "norm"):
+                got = nf._node_frames[i][name].cpu().numpy()
+                assert got.shape == z[f"layer{i}_{name}"].shape
+                assert np.array_equal(got, z[f"layer{i}_{name}"]), (i, name)
+        assert c.get_miss_rate() == float(z["miss_rate"])
 
 
 @pytest.mark.parametrize("F", [8, 600, 602])
@@ -434,7 +436,7 @@ def test_cli_pipeline_end_to_end(dev, hiplib, tmp_path):
     assert len(vals) == 2 and 0.2 < vals[1] <= vals[0] <= 1.0      # degree policy <= oracle
 
 
-@pytest.mark.parametrize("mode", ["staged", "zerocopy"])
+@pytest.mark.parametrize("mode", ["staged", "zerocopy", "async"])
 def test_fetch_only_what_the_model_reads(dev, hiplib, golden_dir, mode):
     """fetch_data(need=...) returns, for the requested layers/fields, exactly the rows
     the reference's full fetch_data returns (golden G1), and touches nothing else"""
@@ -446,7 +448,8 @@ def test_fetch_only_what_the_model_reads(dev, hiplib, golden_dir, mode):
     layers = [z[f"layer{i}_nids"] for i in range(int(z["num_layers"]))]
     for need in ({0: ["features"]}, {3: ["norm"], 4: ["features", "norm"]}, {1: ["features"], 2: [], 3: ["norm"]}):
         nf = FakeNF(layers, dev)
-        c.fetch_data(nf, need=need)
+        c.fetch_data(nf, need=need, slot=1)
+        c.wait_misses(1)
         torch.cuda.synchronize()
         for i in range(len(layers)):
             got = nf._node_frames[i]
@@ -456,7 +459,8 @@ def test_fetch_only_what_the_model_reads(dev, hiplib, golden_dir, mode):
     # miss accounting covers only the rows that were looked up
     c.get_miss_rate()
     nf = FakeNF(layers, dev)
-    c.fetch_data(nf, need={0: ["features"]})
+    c.fetch_data(nf, need={0: ["features"]}, slot=0)
+    c.wait_misses(0)
     t, m = c._stats.tolist()
     assert t == len(layers[0]) and m == int((~z["state_gpu_flag"][layers[0]]).sum())
 
@@ -477,17 +481,17 @@ def test_graphed_trainer_matches_eager(dev, hiplib):
     labels = torch.from_numpy(rng.integers(0, C, V)).to(dev)
     train = np.arange(0, V, 2, dtype=np.int64)          # 2500 seeds: 5 full batches, no short batch
     losses = {}
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "graph", "graph-async"):
         store = HostFeatureStore({"features": torch.from_numpy(feats)})
-        c = GraphCacheServer(store, V, torch.arange(V), 0, miss_mode="zerocopy")
+        c = GraphCacheServer(store, V, torch.arange(V), 0, miss_mode="async" if mode == "graph-async" else "zerocopy")
         c.init_field(["features"])
         c.auto_cache(g, ["features"], cache_ratio=0.4)
         torch.manual_seed(0)
         model = GCNSampling(Fdim, 16, C, 1, Fn.relu, 0.0).to(dev)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=(mode == "graph"))
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=(mode != "eager"))
         smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=True, num_hops=2, seed_nodes=train, prefetch=True,
-                              seed=9, static=(mode == "graph"))
-        cls = GraphedTrainer if mode == "graph" else MinibatchTrainer
+                              seed=9, static=(mode != "eager"))
+        cls = GraphedTrainer if mode != "eager" else MinibatchTrainer
         tr = cls(model, torch.nn.CrossEntropyLoss(), opt, c, smp, labels, dev, need=model.required_inputs(3))
         out = []
         tr.on_step = lambda step, loss: out.append(loss.detach().clone())
@@ -495,6 +499,7 @@ def test_graphed_trainer_matches_eager(dev, hiplib):
         torch.cuda.synchronize()
         losses[mode] = torch.stack(out).cpu().numpy()
     assert np.allclose(losses["eager"], losses["graph"], rtol=2e-4, atol=2e-5), (losses["eager"], losses["graph"])
+    assert np.allclose(losses["eager"], losses["graph-async"], rtol=2e-4, atol=2e-5)
     assert losses["graph"][-1] < losses["graph"][0]
 
 
