@@ -62,7 +62,7 @@ def parse():
     p.add_argument("--batch-size", type=int, default=6000)
     p.add_argument("--num-neighbors", type=int, default=2)
     p.add_argument("--cache-ratio", type=float, default=0.30)
-    p.add_argument("--miss-mode", default="zerocopy", choices=["staged", "zerocopy", "async"])
+    p.add_argument("--miss-mode", default="async", choices=["staged", "zerocopy", "async"])
     p.add_argument("--host-threads", type=int, default=32)
     p.add_argument("--no-overlap", action="store_true")
     p.add_argument("--skip-cpu-baseline", action="store_true")
@@ -74,6 +74,7 @@ def parse():
     p.add_argument("--fetch-all", action="store_true",
                    help="fetch every layer and field like the reference (default: only what the model reads, SURVEY 8f-2)")
     p.add_argument("--skip-opt-hit", action="store_true", help="skip the oracle cache-hit upper bound (opt_cache_hit.py)")
+    p.add_argument("--ring", type=int, default=None, help="sampler ring slots (in-flight minibatches)")
     p.add_argument("--no-graph", action="store_true", help="eager reference-style loop instead of hipGraph replay")
     p.add_argument("--timeline", action="store_true", help="print a per-stream event timeline of a few steps (stderr)")
     p.add_argument("--profile-host", action="store_true", help="cProfile the timed region (stderr)")
@@ -360,7 +361,8 @@ def run():
     if world > 1 and not use_graph:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu])
     sampler = NeighborSampler(g, B, k, neighbor_type='in', shuffle=True, num_workers=16, num_hops=num_hops,
-                              seed_nodes=subtrain, prefetch=True, seed=rank, copy_out=True, static=use_graph)
+                              seed_nodes=subtrain, prefetch=True, seed=rank, copy_out=True, static=use_graph,
+                              ring=args.ring)
     steps_per_epoch = parallel.equalize_steps(len(sampler), device=dev)
     K = args.steps if args.steps is not None else 200
     W = args.warmup
@@ -410,6 +412,17 @@ def run():
             def g_(*a, **k):
                 t0_ = time.perf_counter(); r_ = f(*a, **k); hostlog.append((tag, t0_, time.perf_counter())); return r_
             setattr(obj, name, g_)
+        samp_ev = []
+        _enq = sampler._enqueue
+        def enq(b_, e_):
+            a0 = torch.cuda.Event(enable_timing=True); a1 = torch.cuda.Event(enable_timing=True); a2 = torch.cuda.Event(enable_timing=True)
+            a0.record(sampler.stream)
+            sl = sampler.slots[sampler._ring_pos % len(sampler.slots)]
+            if sl.free_recorded:
+                sampler.stream.wait_event(sl.free)
+            a1.record(sampler.stream)
+            r_ = _enq(b_, e_); a2.record(sampler.stream); samp_ev.append((a0, a1, a2)); return r_
+        sampler._enqueue = enq
         wrap(cacher, "wait_misses", "wait_misses"); wrap(cacher, "fetch_data", "fetch_data"); wrap(sampler, "_enqueue", "sampler_enqueue")
         wrap(sampler, "release", "release")
     prof_host = None
@@ -426,6 +439,9 @@ def run():
     if tl and getattr(trainer, "debug_events", None):
         for ev in trainer.debug_events[30:42]:
             log(f"[load-stream] wait(sampler ready) {ev[0].elapsed_time(ev[1])*1e3:8.1f} us | wait(slot done) {ev[1].elapsed_time(ev[2])*1e3:8.1f} us | work {ev[2].elapsed_time(ev[3])*1e3:8.1f} us")
+    if tl:
+        for a0, a1, a2 in samp_ev[30:40]:
+            log(f"[sampler-stream] wait(slot free) {a0.elapsed_time(a1)*1e3:8.1f} us | sampling kernels {a1.elapsed_time(a2)*1e3:8.1f} us")
     if tl:
         hb = hostlog[len(hostlog) // 2][1]
         for tag, a_, b_ in hostlog[len(hostlog) // 2: len(hostlog) // 2 + 40]:

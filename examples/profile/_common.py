@@ -84,6 +84,8 @@ def trainer(rank, world_size, args, arch, backend='nccl'):
 
     def on_step(step, loss):
         if rank == 0 and step % 20 == 0:
+            if args.graph:
+                loop.synchronize()          # the loss of a replayed step lives on the trainer's compute stream
             print('epoch [{}] step [{}]. Loss: {:.4f}'.format(state['epoch'] + 1, step, loss.item()))
     loop.on_step = on_step
 

@@ -142,6 +142,10 @@ int pg_missq_submit(pg_missq_t* q, int slot, float* const* out_ptrs, const int32
 /* makes `stream` wait until the slot's miss rows have landed; blocks the HOST only until the worker has
  * enqueued the copy. miss_count_out (optional) receives the number of rows.                         */
 int pg_missq_wait(pg_missq_t* q, int slot, pg_stream_t stream, int32_t* miss_count_out);
+/* same ordering guarantee without ever blocking the host: a one-wave kernel on `stream` sleeps on a device
+ * flag the worker's copy stream raises after the scatter (gives up after 3 s -> pg_missq_timed_out).   */
+int pg_missq_wait_device(pg_missq_t* q, int slot, pg_stream_t stream);
+int pg_missq_timed_out(pg_missq_t* q, int* out);
 
 /* ------------------------------------------------------------------------
  * 2. Neighbour sampler  —  dgl.contrib.sampling.NeighborSampler as called at

@@ -61,6 +61,8 @@ _SIGS = {
     "pg_missq_slot_buffers": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]),
     "pg_missq_submit": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(c_i32), vp]),
     "pg_missq_wait": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.POINTER(c_i32)]),
+    "pg_missq_wait_device": (ctypes.c_int, [vp, ctypes.c_int, vp]),
+    "pg_missq_timed_out": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int)]),
     "pg_sampler_create": (ctypes.c_int, [c_i64, vp, vp, c_i32, c_i32, c_i32, ctypes.POINTER(vp)]),
     "pg_sampler_destroy": (ctypes.c_int, [vp]),
     "pg_sampler_capacity": (ctypes.c_int, [vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),

@@ -57,7 +57,7 @@ class _Slot:
 
 class NeighborSampler:
     def __init__(self, g, batch_size, expand_factor, num_hops=1, neighbor_type='in', seed_nodes=None,
-                 shuffle=False, num_workers=1, prefetch=False, seed=0, copy_out=True, static=False):
+                 shuffle=False, num_workers=1, prefetch=False, seed=0, copy_out=True, static=False, ring=None):
         if neighbor_type != 'in':
             raise L.PgError("only neighbor_type='in' is on the hot path (pa_gcn.py:72)")
         self.lib = L.load()
@@ -95,7 +95,7 @@ class NeighborSampler:
         # (needed when it holds several prepared batches at once); False: released when the iterator advances
         self.manual_release = False
         self.slots = [_Slot(self.lib, self.handle, self.num_hops, self.device, padded=self.static)
-                      for _ in range(4 if self.static else 3)]
+                      for _ in range(ring if ring else (4 if self.static else 3))]
 
     def __del__(self):
         try:
@@ -143,7 +143,11 @@ class NeighborSampler:
 
     def _finalize_static(self, slot, n_seeds):
         """no host sync: the consumer's stream waits on the sampler's event, shapes are the capacities"""
-        torch.cuda.current_stream(self.device).wait_event(slot.ready)
+        if not self.manual_release:
+            # a pipeline-managed consumer (GraphedTrainer) orders its own streams after slot.ready; making
+            # the CURRENT stream wait here would also stall every stream that implicitly synchronises
+            # with the legacy default stream
+            torch.cuda.current_stream(self.device).wait_event(slot.ready)
         offs = [0]
         for c in slot.layer_caps:
             offs.append(offs[-1] + c)

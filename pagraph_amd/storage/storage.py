@@ -371,12 +371,24 @@ class GraphCacheServer:
                                                ctypes.byref(cnt)), "pg_missq_slot_buffers")
         return pos, full, cnt
 
-    def wait_misses(self, slot, stream=None):
-        """miss_mode == 'async': order `stream` (default: current) after the slot's miss rows"""
+    def wait_misses(self, slot, stream=None, host_blocking=False):
+        """miss_mode == 'async': order `stream` (default: current) after the slot's miss rows. By default
+        the wait happens on the GPU (a one-wave kernel sleeping on a flag) and the host returns at once;
+        host_blocking=True waits for the worker on the CPU and then uses an event."""
         if self.miss_mode != "async" or self._missq is None or self.full_cached:
             return
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
-        L.check(self.lib.pg_missq_wait(self._missq, slot, L.stream_ptr(st), None), "pg_missq_wait")
+        if host_blocking:
+            L.check(self.lib.pg_missq_wait(self._missq, slot, L.stream_ptr(st), None), "pg_missq_wait")
+        else:
+            L.check(self.lib.pg_missq_wait_device(self._missq, slot, L.stream_ptr(st)), "pg_missq_wait_device")
+
+    def misses_timed_out(self):
+        if self._missq is None:
+            return False
+        v = ctypes.c_int(0)
+        L.check(self.lib.pg_missq_timed_out(self._missq, ctypes.byref(v)), "pg_missq_timed_out")
+        return bool(v.value)
 
     def __del__(self):
         try:

@@ -301,11 +301,16 @@ class GraphedTrainer:
             loss = s.loss.clone()        # the slot's static loss tensor is overwritten 4 steps later
         s.done.record(main)
         s.done_recorded = True
-        # whoever reads the returned loss does so on the caller's stream: order it after this step
-        torch.cuda.current_stream(self.device).wait_event(s.done)
+        # NOTE: the returned loss lives on the compute stream. No wait is queued on the caller's (default)
+        # stream on purpose — a pending wait there delayed the sampler / load streams of LATER batches until
+        # this step had finished (measured: the sampler started only when the current graph ended). Call
+        # synchronize() (or compute_stream.synchronize()) before reading it.
         self.steps_done += 1
         self.last_loss = loss
         return loss
+
+    def synchronize(self):
+        self.compute_stream.synchronize()
 
     def run_steps(self, it, steps=None):
         done = 0

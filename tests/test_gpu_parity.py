@@ -494,7 +494,7 @@ def test_graphed_trainer_matches_eager(dev, hiplib):
         cls = GraphedTrainer if mode != "eager" else MinibatchTrainer
         tr = cls(model, torch.nn.CrossEntropyLoss(), opt, c, smp, labels, dev, need=model.required_inputs(3))
         out = []
-        tr.on_step = lambda step, loss: out.append(loss.detach().clone())
+        tr.on_step = lambda step, loss: out.append(loss.detach())   # valid after a device sync
         tr.run_steps(cycle_batches(smp, 20), 20)
         torch.cuda.synchronize()
         losses[mode] = torch.stack(out).cpu().numpy()
@@ -540,7 +540,7 @@ def _two_rank_graph_worker(rank, world, port, out_dir):
         else:
             tr = GraphedTrainer(model, torch.nn.CrossEntropyLoss(), opt, c, smp, labels, dev, need=need, world_size=world)
         out = []
-        tr.on_step = lambda step, loss: out.append(loss.detach().clone())
+        tr.on_step = lambda step, loss: out.append(loss.detach())
         tr.run_steps(cycle_batches(smp, 12), 12)
         torch.cuda.synchronize()
         res[mode] = (torch.stack(out).cpu(), [p.detach().cpu().clone() for p in model.parameters()])

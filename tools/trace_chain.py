@@ -6,7 +6,7 @@ copies = []
 if len(sys.argv) > 2:
     copies = [r for r in csv.DictReader(open(sys.argv[2])) if r["Direction"].endswith("HOST_TO_DEVICE")]
 packs = [r for r in rows if "k_pack" in r["Kernel_Name"]]
-t0 = int(packs[-40]["Start_Timestamp"]); t1 = int(packs[-35]["Start_Timestamp"])
+t0 = int(packs[-40]["Start_Timestamp"]); t1 = int(packs[-34]["Start_Timestamp"])
 ev = []
 prev_q5_end = None
 for r in rows:
@@ -15,13 +15,13 @@ for r in rows:
     n = r["Kernel_Name"]; q = r["Queue_Id"]
     tag = None
     for k, name in (("k_seed_layer", "SAMPLE begin"), ("k_pack", "SAMPLE end"), ("k_split", "LOAD split"), ("k_gather", "LOAD gather"),
-                    ("k_publish", "LOAD publish"), ("k_scatter<", "MISS scatter")):
+                    ("k_publish", "LOAD publish"), ("k_scatter<", "MISS scatter"), ("k_signal", "MISS signal"), ("k_wait_landed", "COMPUTE wait-kernel")):
         if k in n: tag = name
     if tag: ev.append((s, e, q, tag))
 # compute stream = the queue with the most kernels
 from collections import Counter
 cq = Counter(r["Queue_Id"] for r in rows).most_common(1)[0][0]
-comp = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if r["Queue_Id"] == cq and t0 <= int(r["Start_Timestamp"]) <= t1]
+comp = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if r["Queue_Id"] == cq and t0 <= int(r["Start_Timestamp"]) <= t1 and "k_wait_landed" not in r["Kernel_Name"]]
 # group compute kernels into bursts separated by > 20 us gaps
 burst_s = None; last_e = None
 for s, e in comp:
