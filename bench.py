@@ -52,7 +52,7 @@ def log(*a):
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=None, help="timed steps (default: 200)")
+    p.add_argument("--steps", type=int, default=None, help="timed steps (default: 400)")
     p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--model", default="gcn", choices=["gcn", "graphsage"])
     p.add_argument("--vertices", type=int, default=10_000_000)
@@ -364,7 +364,7 @@ def run():
                               seed_nodes=subtrain, prefetch=True, seed=rank, copy_out=True, static=use_graph,
                               ring=args.ring)
     steps_per_epoch = parallel.equalize_steps(len(sampler), device=dev)
-    K = args.steps if args.steps is not None else 200
+    K = args.steps if args.steps is not None else 400
     W = args.warmup
     if use_graph:
         trainer = GraphedTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, need=need, world_size=world)
