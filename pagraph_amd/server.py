@@ -10,6 +10,32 @@ from . import data
 from .storage import HostFeatureStore
 
 
+def preprocess_features(csc, features, norm, chunk_rows=1 << 20):
+    """pa_server.py:45-52: X'[v] = norm[v] * sum_{u->v} X[u] (update_all copy_src/sum, then * norm) as a
+    one-off SpMM on the GPU: the full graph's CSC *is* a NodeFlow block (destinations = all vertices,
+    sources = all vertices), so the aggregation kernel of the training path (pg_spmm_fwd, reduce = sum)
+    does it, destination chunk by chunk."""
+    from . import _lib as L
+    lib = L.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    V, Fdim = features.shape
+    if csc.nnz >= 2 ** 31:
+        raise L.PgError("preprocess_features: more than 2^31 edges needs the 64-bit-indptr kernel")
+    x = features.to(dev).contiguous()
+    indptr = torch.from_numpy(np.ascontiguousarray(csc.indptr, dtype=np.int32)).to(dev)
+    indices = torch.from_numpy(np.ascontiguousarray(csc.indices, dtype=np.int32)).to(dev)
+    nrm = torch.as_tensor(norm, dtype=torch.float32).to(dev)
+    out = torch.empty((V, Fdim), dtype=torch.float32)
+    for lo in range(0, V, chunk_rows):
+        hi = min(V, lo + chunk_rows)
+        # chunk-relative indptr: the kernel indexes src[] with the absolute edge offsets of the chunk
+        agg = torch.empty((hi - lo, Fdim), dtype=torch.float32, device=dev)
+        L.check(lib.pg_spmm_fwd(L.ptr(indptr[lo:hi + 1]), L.ptr(indices), L.ptr(x), x.stride(0), hi - lo, Fdim,
+                                L.PG_REDUCE_SUM, L.ptr(agg), agg.stride(0), L.stream_ptr()), "pg_spmm_fwd")
+        out[lo:hi] = (agg * nrm[lo:hi]).cpu()
+    return out
+
+
 def load_store(dataset, model='gcn', preprocess=False, pin=True):
     coo_adj, feat = data.get_graph_data(dataset)
     features = torch.as_tensor(np.asarray(feat), dtype=torch.float32)
@@ -21,9 +47,7 @@ def load_store(dataset, model='gcn', preprocess=False, pin=True):
         norm = (1. / in_deg).unsqueeze(1)
         if preprocess:
             print('Preprocessing features...')
-            # update_all(copy_src, sum) then * norm: row v = norm[v] * sum_{u->v} X[u]
-            ones = spsp.csc_matrix((np.ones(csc.nnz, np.float32), csc.indices, csc.indptr), shape=csc.shape)
-            features = torch.from_numpy(np.asarray(ones.T @ features.numpy(), dtype=np.float32)) * norm
+            features = preprocess_features(csc, features, norm)
         fields['norm'] = norm
         fields['features'] = features
     elif model == 'graphsage':

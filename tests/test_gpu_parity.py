@@ -424,7 +424,8 @@ def test_cli_pipeline_end_to_end(dev, hiplib, tmp_path):
     r = run("-m", "pagraph_amd.partition.hash", "--dataset", str(ds), "--partition", "1", "--num-hops", "2")
     assert r.returncode == 0, r.stderr[-2000:]
     assert (ds / "1naive" / "subadj_0.npz").exists()
-    for script, extra in (("pa_gcn.py", []), ("pa_gs.py", ["--miss-mode", "staged"]), ("pa_gcn.py", ["--graph", "--fetch-needed"])):
+    for script, extra in (("pa_gcn.py", []), ("pa_gs.py", ["--miss-mode", "staged"]), ("pa_gcn.py", ["--graph", "--fetch-needed", "--miss-mode", "async"]),
+                          ("pa_gcn.py", ["--miss-mode", "async", "--preprocess"])):
         r = run(os.path.join("examples", "profile", script), "--dataset", str(ds), "--gpu", "0", "--feat-size", "64",
                 "--n-classes", "7", "--n-epochs", "3", "--batch-size", "1000", "--cache-ratio", "0.3", "--log-miss-rate", *extra)
         assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
@@ -684,3 +685,22 @@ def test_sage_preprocess_forward_vs_oracle(dev, hiplib, oracle):
     agg = oracle.spmm_fwd(*ref["blocks"][0], h[0], o[2] - o[1], "mean")
     want = h[1] @ W1s.T + b1s + agg @ W1n.T + b1n
     assert np.abs(got - want).max() < TOL * max(1.0, np.abs(want).max())
+
+
+def test_server_preprocess_vs_scipy(dev, hiplib):
+    """f-3: server-side feature preprocessing X' = norm * (A^T X) (pa_server.py:43-52) on the GPU"""
+    from pagraph_amd.server import preprocess_features
+    rng = np.random.default_rng(8)
+    V, Fdim = 5000, 96
+    adj = _rand_csc(rng, V, 30000)
+    csc = spsp.csc_matrix(adj); csc.sum_duplicates(); csc.sort_indices()
+    x = rng.random((V, Fdim), dtype=np.float32)
+    deg = np.diff(csc.indptr).astype(np.float32)
+    with np.errstate(divide="ignore"):
+        norm = (1.0 / deg).reshape(-1, 1).astype(np.float32)            # inf for isolated vertices, as the reference
+    got = preprocess_features(csc, torch.from_numpy(x), torch.from_numpy(norm), chunk_rows=1500).numpy()
+    ones = spsp.csc_matrix((np.ones(csc.nnz, np.float64), csc.indices, csc.indptr), shape=csc.shape)
+    want = np.asarray(ones.T @ x.astype(np.float64))
+    has = deg > 0
+    assert np.allclose(got[has], (want[has] * norm[has]).astype(np.float32), rtol=1e-5, atol=1e-5)
+    assert np.all(np.isnan(got[~has]))                                   # 0 * inf, exactly what the reference computes
