@@ -214,15 +214,20 @@ int pg_spmm_bwd(const int32_t* indptr, const int32_t* src, const float* grad_out
                 int64_t n_dst, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,
                 pg_stream_t stream);
 
-/* Skinny dense step of the first layer — NodeUpdate's nn.Linear at PaGraph/model/gcn_nssc.py:18 and
- * graphsage_nssc.py:24 — on fp32 MFMA: Y[n,N] = X[n,K] * Wt[K,32] + bias, N <= 32, K % 8 == 0,
- * X 16-byte aligned with x_stride % 4 == 0. Wt is the weight transposed and zero-padded to 32 columns.
+/* Skinny dense step of the first layer — NodeUpdate.forward at PaGraph/model/gcn_nssc.py:18-23 and
+ * graphsage_nssc.py:24-29 — on fp32 MFMA: Z = X[n,K] * W^T + bias with W = nn.Linear's weight [N,K],
+ * N <= 32, K % 8 == 0, X / W 16-byte aligned, x_stride % 4 == 0. The epilogue applies NodeUpdate's
+ * activation: act 0: Y = Z; 1: Y = relu(Z); 2: Y = [Z | relu(Z)] (2N columns, the skip connection).
  * Returns PG_ERR_UNSUPPORTED outside that envelope (callers then use the library GEMM).            */
-int pg_linear_fwd(const float* X, int32_t x_stride, const float* Wt, const float* bias, float* Y,
-                  int32_t y_stride, int64_t n, int32_t K, int32_t N, pg_stream_t stream);
-/* dW[N,K] += dY^T X and (db != NULL) db[N] += column sums of dY, any N and K; dW / db must be zeroed by the caller. */
-int pg_linear_bwd_w(const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n,
-                    int32_t K, int32_t N, float* dW, float* db, pg_stream_t stream);
+int pg_linear_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, float* Y,
+                  int32_t y_stride, int64_t n, int32_t K, int32_t N, int32_t act, pg_stream_t stream);
+/* dW[N,K] += dZ^T X and (db != NULL) db[N] += column sums of dZ, any N and K, where dZ is derived on the
+ * fly from G = dL/dY and the saved output Yout according to `act` (act 0: dZ = G, Yout may be NULL).
+ * dW / db must be zeroed by the caller. dz_scratch: device fp32 [n, N], required when act != 0; it
+ * holds dZ afterwards (callers reuse it for dX = dZ W).                                             */
+int pg_linear_bwd_w(const float* G, int32_t g_stride, const float* X, int32_t x_stride, int64_t n,
+                    int32_t K, int32_t N, float* dW, float* db, const float* Yout, int32_t yo_stride,
+                    int32_t act, float* dz_scratch, pg_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 4. Offline partitioning (host)  —  PaGraph/partition/dg.py:59-103

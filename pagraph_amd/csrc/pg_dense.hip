@@ -10,9 +10,10 @@
 // HBM/L2-streaming bound: X (29 MB) is read once forward and once backward.
 //
 // forward   block = 4 waves on ONE 32-row tile, K split four ways (each wave: <= 19 octets of k,
-//           4 MFMAs per octet: A = one float4 of its X row per lane, B = two coalesced 128-byte
-//           rows of the pre-transposed weight Wt[K][32]); partial 32x32 tiles reduced through LDS,
-//           bias added, float4 stores.  375 blocks for n = 12 000.
+//           4 MFMAs per octet: A = one float4 of its X row per lane, B = one float4 of its weight
+//           row per lane — W is read as stored, [N][K], no transpose pass); partial 32x32 tiles reduced
+//           through LDS; epilogue fuses bias and NodeUpdate's activation / skip-concat
+//           (gcn_nssc.py:18-23).  375 blocks for n = 12 000.
 // backward  dW[N, K] += dYᵀ·X, db[N] += Σ dY (any N): wave = one (32-feature, 32-column) tile of dW for
 //           a chunk of 256 rows (A = dY rows, B = X rows: both coalesced), fp32 hardware atomics into
 //           dW / db. Also used for the output layer (N = 60, K = 64): the library GEMM has two
@@ -28,11 +29,13 @@ typedef float df4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTile = 32;
 
+// act: 0 = none, 1 = relu, 2 = concat(z, relu(z)) -> Y has 2N columns (NodeUpdate's skip connection,
+// gcn_nssc.py:20-21). W is the nn.Linear weight as stored: [N, K] row-major.
 __global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ X, int32_t x_stride,
-                                                    const float* __restrict__ Wt /* [K][32] */,
+                                                    const float* __restrict__ W /* [N][K] */,
                                                     const float* __restrict__ bias /* [N] or null */,
                                                     float* __restrict__ Y, int32_t y_stride, int64_t n, int32_t K,
-                                                    int32_t N) {
+                                                    int32_t N, int32_t act) {
   __shared__ float red[4][kTile][kTile + 1];
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
   const int64_t r0 = (int64_t)blockIdx.x * kTile;
@@ -41,19 +44,21 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ X,
   const int octets = K / 8;
   const int o_beg = (octets * w) / 4, o_end = (octets * (w + 1)) / 4;
   const bool row_ok = row < n;
+  const bool col_ok = (lane & 31) < N;
   const float* xr = X + (row_ok ? row : 0) * x_stride + 4 * half;
-  const float* wb = Wt + (int64_t)(4 * half) * kTile + (lane & 31);
+  // B operand: lane (col, half) needs W[col][kk + 4*half + j], j = 0..3 -> one 16-byte load per octet
+  const float* wr = W + (int64_t)(col_ok ? (lane & 31) : 0) * K + 4 * half;
   f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int o = o_beg; o < o_end; ++o) {
     const int kk = o * 8;
     df4 a = *reinterpret_cast<const df4*>(xr + kk);
+    df4 b = *reinterpret_cast<const df4*>(wr + kk);
     if (!row_ok) a = df4{0.f, 0.f, 0.f, 0.f};
-    const float* wk = wb + (int64_t)kk * kTile;
-    const float b0 = wk[0 * kTile], b1 = wk[1 * kTile], b2 = wk[2 * kTile], b3 = wk[3 * kTile];
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b2, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b3, acc, 0, 0, 0);
+    if (!col_ok) b = df4{0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
   }
   // C layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
@@ -69,17 +74,51 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ X,
       if (bias && oc + j < N) v[j] += bias[oc + j];
     }
     float* yr = Y + (r0 + orow) * y_stride + oc;
-    if (N == kTile && (y_stride & 3) == 0) {
+    const bool vec_ok = (N & 3) == 0 && (y_stride & 3) == 0 && oc + 3 < N;
+    if (act == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+    }
+    if (vec_ok) {
       *reinterpret_cast<df4*>(yr) = df4{v[0], v[1], v[2], v[3]};
+      if (act == 2)
+        *reinterpret_cast<df4*>(yr + N) = df4{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f,
+                                              v[2] > 0.f ? v[2] : 0.f, v[3] > 0.f ? v[3] : 0.f};
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (oc + j < N) yr[j] = v[j];
+        if (oc + j < N) {
+          yr[j] = v[j];
+          if (act == 2) yr[N + j] = v[j] > 0.f ? v[j] : 0.f;
+        }
     }
   }
 }
 
 constexpr int kBwdRows = 256;  // rows per block in the weight-gradient kernel
+
+// gradient of the pre-activation z w.r.t. the loss, from the gradient G of the (activated) output and the
+// saved output Yout: act 0: G; act 1 (relu): G * (Yout > 0); act 2 (concat): G[:, :N] + G[:, N:] * (Yout[:, :N] > 0)
+__device__ __forceinline__ float dz_at(const float* __restrict__ G, int32_t g_stride, const float* __restrict__ Yout,
+                                       int32_t yo_stride, int64_t r, int i, int N, int act) {
+  float g = G[r * g_stride + i];
+  if (act == 1) g = Yout[r * yo_stride + i] > 0.f ? g : 0.f;
+  else if (act == 2) g += Yout[r * yo_stride + i] > 0.f ? G[r * g_stride + N + i] : 0.f;
+  return g;
+}
+
+// materialise dZ [n, N] once (every column-slice wave of k_linear_bwd_w re-reads its A operand; deriving
+// it on the fly there re-did this 19 times and tripled the kernel's time)
+__global__ __launch_bounds__(256) void k_dz(const float* __restrict__ G, int32_t g_stride,
+                                            const float* __restrict__ Yout, int32_t yo_stride, int64_t n, int32_t N,
+                                            int32_t act, float* __restrict__ dz) {
+  const int64_t total = n * N;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / N;
+    const int i = (int)(t - r * N);
+    dz[t] = dz_at(G, g_stride, Yout, yo_stride, r, i, N, act);
+  }
+}
 
 __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ dY, int32_t dy_stride,
                                                       const float* __restrict__ X, int32_t x_stride, int64_t n,
@@ -143,26 +182,38 @@ using namespace pg;
 
 extern "C" {
 
-int pg_linear_fwd(const float* X, int32_t x_stride, const float* Wt, const float* bias, float* Y, int32_t y_stride,
-                  int64_t n, int32_t K, int32_t N, pg_stream_t stream) {
-  if (n < 0 || K <= 0 || N <= 0 || x_stride < K || y_stride < N) return PG_ERR_INVALID;
+int pg_linear_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, float* Y, int32_t y_stride,
+                  int64_t n, int32_t K, int32_t N, int32_t act, pg_stream_t stream) {
+  if (n < 0 || K <= 0 || N <= 0 || x_stride < K || act < 0 || act > 2 || y_stride < (act == 2 ? 2 * N : N))
+    return PG_ERR_INVALID;
   if (N > kTile || (K & 7) || (x_stride & 3)) return PG_ERR_UNSUPPORTED;
   if (n == 0) return PG_OK;
-  if (!X || !Wt || !Y) return PG_ERR_INVALID;
-  if ((reinterpret_cast<uintptr_t>(X) & 15)) return PG_ERR_UNSUPPORTED;
+  if (!X || !W || !Y) return PG_ERR_INVALID;
+  if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return PG_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(k_linear_fwd, dim3((unsigned)ceil_div<int64_t>(n, kTile)), dim3(256), 0, as_stream(stream), X,
-                     x_stride, Wt, bias, Y, y_stride, n, K, N);
+                     x_stride, W, bias, Y, y_stride, n, K, N, act);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
 
 int pg_linear_bwd_w(const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n, int32_t K,
-                    int32_t N, float* dW, float* db, pg_stream_t stream) {
-  if (n < 0 || K <= 0 || N <= 0 || x_stride < K || dy_stride < N) return PG_ERR_INVALID;
+                    int32_t N, float* dW, float* db, const float* Yout, int32_t yo_stride, int32_t act,
+                    float* dz_scratch, pg_stream_t stream) {
+  if (n < 0 || K <= 0 || N <= 0 || x_stride < K || act < 0 || act > 2 || dy_stride < (act == 2 ? 2 * N : N))
+    return PG_ERR_INVALID;
+  if (act != 0 && (!Yout || yo_stride < N || !dz_scratch)) return PG_ERR_INVALID;
   if (n == 0) return PG_OK;
   if (!dY || !X || !dW) return PG_ERR_INVALID;
   const unsigned gx = (unsigned)ceil_div<int64_t>(ceil_div<int64_t>(K, kTile) * ceil_div<int64_t>(N, kTile), 4);
   const unsigned gy = (unsigned)ceil_div<int64_t>(n, kBwdRows);
+  if (act != 0) {
+    int64_t g = ceil_div<int64_t>(n * N, 256);
+    hipLaunchKernelGGL(k_dz, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, as_stream(stream), dY, dy_stride, Yout,
+                       yo_stride, n, N, act, dz_scratch);
+    PG_LAUNCH_CHECK();
+    dY = dz_scratch;
+    dy_stride = N;
+  }
   hipLaunchKernelGGL(k_linear_bwd_w, dim3(gx, gy), dim3(256), 0, as_stream(stream), dY, dy_stride, X, x_stride, n, K,
                      N, dW, db);
   PG_LAUNCH_CHECK();

@@ -24,11 +24,17 @@ class NodeUpdate(nn.Module):
         h = node.data['h']
         if self.test:
             h = h * node.data['norm']
-        h = ops.linear(h, self.linear)
-        if self.concat:
-            h = torch.cat((h, self.activation(h)), dim=1)
-        elif self.activation:
-            h = self.activation(h)
+        relu = self.activation in (torch.relu, torch.nn.functional.relu)
+        if self.concat and relu:                 # dense step + skip-concat fused in one kernel
+            h = ops.linear(h, self.linear, ops.ACT_CONCAT)
+        elif self.activation is not None and relu and not self.concat:
+            h = ops.linear(h, self.linear, ops.ACT_RELU)
+        else:
+            h = ops.linear(h, self.linear)
+            if self.concat:
+                h = torch.cat((h, self.activation(h)), dim=1)
+            elif self.activation:
+                h = self.activation(h)
         return {'activation': h}
 
 

@@ -587,6 +587,24 @@ def test_skinny_linear_vs_torch(dev, hiplib, n, K, N, bias):
     if bias:
         gb_ref = gy.double().sum(0)
         assert float((lin.bias.grad.double() - gb_ref).abs().max()) < TOL * max(1.0, float(gb_ref.abs().max()))
+    # fused activation epilogues: relu and NodeUpdate's skip-concat (gcn_nssc.py:20-23), forward + all gradients
+    for act in (ops.ACT_RELU, ops.ACT_CONCAT):
+        lin.zero_grad()
+        xa = x[:2048].clone().requires_grad_(True)
+        ya = ops.linear(xa, lin, act)
+        za = torch.nn.functional.linear(xa.detach().double().requires_grad_(True), lin.weight.double(),
+                                        lin.bias.double() if bias else None)
+        zin = za
+        ra = torch.relu(za) if act == ops.ACT_RELU else torch.cat((za, torch.relu(za)), 1)
+        assert ya.shape == ra.shape and float((ya.double() - ra).abs().max()) < TOL * scale
+        ga = torch.rand_like(ya) - 0.5
+        ya.backward(ga)
+        gz = torch.autograd.grad(ra, zin, ga.double())[0]
+        gw_a = gz.t() @ xa.detach().double()
+        assert float((lin.weight.grad.double() - gw_a).abs().max()) < TOL * max(1.0, float(gw_a.abs().max()))
+        assert float((xa.grad.double() - gz @ lin.weight.double()).abs().max()) < TOL * max(1.0, float(gz.abs().max()) * K ** 0.5)
+        if bias:
+            assert float((lin.bias.grad.double() - gz.sum(0)).abs().max()) < TOL * max(1.0, float(gz.sum(0).abs().max()))
     # an input that needs its own gradient gets one too (deeper layers)
     x2 = x[:1024].clone().requires_grad_(True)
     lin.zero_grad()
