@@ -367,7 +367,8 @@ def run():
     K = args.steps if args.steps is not None else 400
     W = args.warmup
     if use_graph:
-        trainer = GraphedTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, need=need, world_size=world)
+        trainer = GraphedTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, need=need, world_size=world,
+                                 keep_losses=False)
         W = max(W, 3 + 2 * len(sampler.slots))           # eager warm-up + one capture per ring slot, all untimed
     else:
         trainer = MinibatchTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, overlap=not args.no_overlap,
@@ -432,6 +433,7 @@ def run():
         prof_host.enable()
     t0 = time.time()
     done = trainer.run_steps(it, K)
+    t_issued = time.time() - t0          # launch thread done; ~= elapsed when the host is the bottleneck
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -529,6 +531,7 @@ def run():
             "cache_hit_oracle_upper_bound_pct": opt_hit, "cache_hit_degree_policy_on_trace_pct": deg_hit,
             "feat_gather_GBps": (micro[max(micro)]["GBps"] if micro else achieved),
             "seeds_per_s": seeds_total / elapsed,
+            "host_issue_ms_per_step": t_issued / K * 1e3,     # launch thread's share; == ms_per_step when it is the bottleneck
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -75,7 +75,8 @@ def trainer(rank, world_size, args, arch, backend='nccl'):
                               seed=rank, static=args.graph)
     steps = parallel.equalize_steps(len(sampler), device=dev)     # partitions differ in size
     if args.graph:      # hipGraph-replayed step over fixed-shape NodeFlows (no DDP wrapper: one flat all-reduce)
-        loop = GraphedTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, need=need, world_size=world_size)
+        loop = GraphedTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, need=need, world_size=world_size,
+                              keep_losses=False)
     else:               # the reference's eager loop
         loop = MinibatchTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, overlap=not args.no_overlap,
                                 need=need)

@@ -102,6 +102,11 @@ int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const
 int pg_gather_rows_full(const int64_t* ids, int64_t n, const pg_field_t* fields, int n_fields,
                         pg_stream_t stream);
 
+/* batch_labels = labels[batch_nids] (examples/profile/pa_gcn.py:99-100): out[i] = labels[ids[i]], or
+ * `fill` where ids[i] is outside [0, n_labels) (padding ids of a fixed-shape NodeFlow are -1).      */
+int pg_gather_labels(const int64_t* ids, int64_t n, const int64_t* labels, int64_t n_labels, int64_t fill,
+                     int64_t* out, pg_stream_t stream);
+
 /* storage.py:199-200 — out[pos[j], :] = staged[j, :] for j < n (n from host, or *n_dev when n_dev != NULL
  * in which case `n` is the launch upper bound). `staged` is device memory, row stride = dim.        */
 int pg_scatter_rows(const float* staged, const int32_t* pos, int64_t n, const int32_t* n_dev,
@@ -154,6 +159,7 @@ int pg_missq_timed_out(pg_missq_t* q, int* out);
  *    build-defined spec in DESIGN.md §"Sampler spec" (parity unpinned).
  * ------------------------------------------------------------------------ */
 typedef struct pg_sampler pg_sampler_t;
+#define PG_HEAVY_ROW 32   /* a source with more edges than this in one block is a hub */
 
 typedef struct pg_nodeflow_desc {
   /* outputs, all device memory owned by the caller */
@@ -173,7 +179,17 @@ typedef struct pg_nodeflow_desc {
                                  capacities of layers < l (pg_sampler_capacity), unused entries are -1, and
                                  layer_offsets holds those fixed offsets; sizes_pinned still has the real sizes.
                               Either way every block's indptr is padded with empty rows up to its capacity. */
-  int32_t _pad;
+  uint32_t transpose_mask; /* bit b: also emit block b source-major (needs blk_tptr / blk_tdst)          */
+  int32_t* blk_tptr;       /* NULL = no transposes. Block b at blk_tptr + blk_tptr_off[b]: [|layer b| + 1]
+                              offsets into the block's edge range, padded with empty rows up to the
+                              layer's capacity                                                      */
+  int32_t* blk_tdst;       /* at blk_tdst + blk_src_off[b]: for source s, the destinations (positions
+                              inside layer b+1) of its edges, ascending                             */
+  int64_t blk_tptr_off[PG_MAX_LAYERS];
+  int32_t* blk_theavy;     /* may be NULL. Block b at blk_theavy + blk_theavy_off[b]: [0] = number of sources
+                              with more than PG_HEAVY_ROW edges, [1..] those sources (any order); room for
+                              1 + cap_edges(b) / PG_HEAVY_ROW entries                               */
+  int64_t blk_theavy_off[PG_MAX_LAYERS];
 } pg_nodeflow_desc_t;
 
 /* indptr/indices: CSC of the partition (in-neighbours of v = indices[indptr[v]:indptr[v+1]],
@@ -185,7 +201,12 @@ int pg_sampler_destroy(pg_sampler_t* s);
  * (layer l's capacity = cap_blk_rows[l-1] for l >= 1, cap_blk_edges[0] for l = 0) */
 int pg_sampler_capacity(const pg_sampler_t* s, int64_t* cap_nodes, int64_t* cap_blk_rows /*[num_hops]*/,
                         int64_t* cap_blk_edges /*[num_hops]*/);
-/* one minibatch: seeds (device int64[n_seeds], unique) -> NodeFlow. RNG key (seed, epoch, batch). */
+/* one minibatch: seeds (device int64[n_seeds]) -> NodeFlow. RNG key (seed, epoch, batch).
+ * `out` names an output slot (a set of caller-owned buffers). The launch sequence for a slot is fixed, so from
+ * the second call into the same slot on the same stream it is replayed as ONE hipGraph launch (the call's
+ * scalars travel through a pinned parameter block; PG_SAMPLER_NO_GRAPH=1 keeps the ~30 individual launches).
+ * A slot may be sampled into again only after the previous sample into it has completed on the device
+ * (ring of slots, as pagraph_amd.sampling.NeighborSampler does).                                       */
 int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, uint64_t seed,
                       uint32_t epoch, uint32_t batch, const pg_nodeflow_desc_t* out, pg_stream_t stream);
 
@@ -214,6 +235,41 @@ int pg_spmm_bwd(const int32_t* indptr, const int32_t* src, const float* grad_out
                 int64_t n_dst, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,
                 pg_stream_t stream);
 
+/* The same aggregation with the model's nn.Dropout (gcn_nssc.py:66-69, graphsage_nssc.py:86-89: dropout
+ * on a layer's input right before it is aggregated) folded in: out = reduce(dropout(h)[src]) without
+ * materialising dropout(h) or a mask. Counter-based mask: element (r, col) of h, piece = col / 4,
+ *   q = (piece / 128) * 64 + piece % 64, half = (piece / 64) % 2, j = col % 4,
+ *   w = Philox4x32-10(counter (r, q, tag, (uint32)*step), key (seed & 0xffffffff, seed >> 32)),
+ *   u16 = j even ? w[2*half + j/2] & 0xffff : w[2*half + j/2] >> 16;  keep iff u16 >= threshold,
+ *   kept values * 65536 / (65536 - threshold).
+ * threshold = round(p * 65536) in [0, 65535]; 0 (or drop == NULL) = no dropout. `step` is a DEVICE
+ * pointer (NULL = 0) so that a replayed hipGraph sees a new mask every step: the caller bumps it with
+ * its own kernel. Forward needs dim % 4 == 0 and 16-byte aligned rows (else PG_ERR_UNSUPPORTED).     */
+typedef struct pg_dropout {
+  uint32_t threshold;
+  uint32_t tag;          /* distinguishes call sites (layer index, rank) */
+  uint64_t seed;
+  const uint64_t* step;  /* device */
+} pg_dropout_t;
+int pg_spmm_fwd_drop(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride,
+                     int64_t n_dst, int32_t dim, int reduce, float* out, int32_t out_stride,
+                     const pg_dropout_t* drop, pg_stream_t stream);
+/* grad_h[src[e],:] += grad_out[v,:] * (mean ? 1/deg(v) : 1) * mask(src[e],:) * scale; grad_h zeroed by caller */
+int pg_spmm_bwd_drop(const int32_t* indptr, const int32_t* src, const float* grad_out, int32_t go_stride,
+                     int64_t n_dst, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,
+                     const pg_dropout_t* drop, pg_stream_t stream);
+
+/* The same gradient in gather form over the block's source-major copy (pg_nodeflow_desc_t.blk_tptr /
+ * blk_tdst): grad_h[s,:] = mask(s,:) * scale * sum over s's edges of grad_out[dst,:] * (mean ? 1/deg(dst) : 1),
+ * destinations ascending. Every one of the n_src rows is written (no zero fill, no atomics, deterministic).
+ * indptr is the destination-major indptr (degrees). heavy (device, may be NULL): the block's hub list
+ * (blk_theavy: [0] = count, then sources with more than PG_HEAVY_ROW edges; heavy_cap = room behind the
+ * count) — those rows get a block each in a second launch instead of one lane group. drop may be NULL. */
+int pg_spmm_bwd_gather(const int32_t* tptr, const int32_t* tdst, const int32_t* indptr, const float* grad_out,
+                       int32_t go_stride, int64_t n_src, int32_t dim, int reduce, float* grad_h,
+                       int32_t gh_stride, const int32_t* heavy, int32_t heavy_cap, const pg_dropout_t* drop,
+                       pg_stream_t stream);
+
 /* Skinny dense step of the first layer — NodeUpdate.forward at PaGraph/model/gcn_nssc.py:18-23 and
  * graphsage_nssc.py:24-29 — on fp32 MFMA: Z = X[n,K] * W^T + bias with W = nn.Linear's weight [N,K],
  * N <= 32, K % 8 == 0, X / W 16-byte aligned, x_stride % 4 == 0. The epilogue applies NodeUpdate's
@@ -221,13 +277,28 @@ int pg_spmm_bwd(const int32_t* indptr, const int32_t* src, const float* grad_out
  * Returns PG_ERR_UNSUPPORTED outside that envelope (callers then use the library GEMM).            */
 int pg_linear_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, float* Y,
                   int32_t y_stride, int64_t n, int32_t K, int32_t N, int32_t act, pg_stream_t stream);
-/* dW[N,K] += dZ^T X and (db != NULL) db[N] += column sums of dZ, any N and K, where dZ is derived on the
- * fly from G = dL/dY and the saved output Yout according to `act` (act 0: dZ = G, Yout may be NULL).
- * dW / db must be zeroed by the caller. dz_scratch: device fp32 [n, N], required when act != 0; it
- * holds dZ afterwards (callers reuse it for dX = dZ W).                                             */
+/* dW[N,K] = dZ^T X and (db != NULL) db[N] = column sums of dZ, any N and K, where dZ is derived from
+ * G = dL/dY and the saved output Yout according to `act` (act 0: dZ = G, Yout may be NULL). dW (contiguous)
+ * and db are overwritten. dz_scratch: device fp32 [n, N], required when act != 0; it holds dZ afterwards
+ * (callers reuse it for dX = dZ W). partials: device fp32 scratch of pg_linear_bwd_w_scratch(n, K, N)
+ * floats (per-row-chunk partial tiles, summed in chunk order: the result is deterministic).          */
+int64_t pg_linear_bwd_w_scratch(int64_t n, int32_t K, int32_t N);
 int pg_linear_bwd_w(const float* G, int32_t g_stride, const float* X, int32_t x_stride, int64_t n,
                     int32_t K, int32_t N, float* dW, float* db, const float* Yout, int32_t yo_stride,
-                    int32_t act, float* dz_scratch, pg_stream_t stream);
+                    int32_t act, float* dz_scratch, float* partials, pg_stream_t stream);
+
+/* Loss head — torch.nn.CrossEntropyLoss() of examples/profile/pa_gcn.py:80,101-104 (pa_gs.py likewise):
+ * log-softmax + NLL over logits[n, C], mean over the rows whose label is neither ignore_index nor
+ * outside [0, C) (torch aborts on such labels; here they are ignored). Writes
+ *   dlogits[n, C]  (may be NULL)  softmax(x) - onehot(label), NOT yet divided by the row count
+ *   row_loss[n]    per-row loss (scratch),   meta[0] = mean loss (nan when no row counts),
+ *   meta[1] = 1 / #counted rows.                                                                   */
+int pg_xent_fwd(const float* logits, int32_t stride, const int64_t* labels, int64_t n, int32_t C,
+                int64_t ignore_index, float* dlogits, int32_t d_stride, float* row_loss, float* meta,
+                pg_stream_t stream);
+/* gx = dlogits * meta[1] * (*grad_out)  (grad_out: device scalar, NULL = 1)                         */
+int pg_xent_bwd(const float* dlogits, int32_t d_stride, int64_t n, int32_t C, const float* meta,
+                const float* grad_out, float* gx, int32_t gx_stride, pg_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 4. Offline partitioning (host)  —  PaGraph/partition/dg.py:59-103

@@ -76,6 +76,45 @@ def philox4x32_10(ctr, key):
     return [int(x) for x in o]
 
 
+def philox4x32_10_np(c0, c1, c2, c3, k0, k1):
+    """vectorised Philox4x32-10 over numpy arrays (uint64 arithmetic); checked against the C one in tests"""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    mask = np.uint64(0xFFFFFFFF)
+    c = [np.asarray(x, dtype=np.uint64) & mask for x in np.broadcast_arrays(c0, c1, c2, c3)]
+    k0, k1 = int(k0) & 0xFFFFFFFF, int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = np.uint64(M0) * c[0]
+        p1 = np.uint64(M1) * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ np.uint64(k0), p1 & mask,
+             (p0 >> np.uint64(32)) ^ c[3] ^ np.uint64(k1), p0 & mask]
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    return c
+
+
+def dropout_threshold(p):
+    return int(round(float(p) * 65536.0))
+
+
+def dropout_mask(rows, dim, threshold, seed, tag, step):
+    """keep-mask [rows, dim] of the dropout folded into the aggregation (the spec in include/pagraph_hip.h,
+    pg_dropout_t; it stands for nn.Dropout at gcn_nssc.py:66-69 / graphsage_nssc.py:86-89) and the
+    float32 scale of the kept values."""
+    col = np.arange(dim, dtype=np.int64)
+    piece = col >> 2
+    q = ((piece >> 7) << 6) | (piece & 63)
+    half = (piece >> 6) & 1
+    j = col & 3
+    uq, inv = np.unique(q, return_inverse=True)
+    r = np.arange(rows, dtype=np.uint64)[:, None]
+    w = philox4x32_10_np(r, uq[None, :].astype(np.uint64), np.uint64(tag), np.uint64(int(step) & 0xFFFFFFFF),
+                         int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF)
+    w = np.stack(w, axis=-1)                                      # [rows, |uq|, 4]
+    word = w[:, inv, 2 * half + (j >> 1)]                         # [rows, dim]
+    u16 = np.where(j & 1, word >> np.uint64(16), word & np.uint64(0xFFFF))
+    scale = np.float32(65536.0) / np.float32(65536 - threshold)
+    return u16 >= np.uint64(threshold), scale
+
+
 # --------------------------------------------------------------------------
 # feature cache (PaGraph/storage/storage.py)
 # --------------------------------------------------------------------------
@@ -236,6 +275,24 @@ def spmm_bwd(indptr, src, grad_out, n_src, reduce="mean"):
 
 def _relu(x):
     return np.maximum(x, 0)
+
+
+def cross_entropy(logits, labels, ignore_index=-100):
+    """torch.nn.CrossEntropyLoss() of examples/profile/pa_gcn.py:80,101-104 in float64: mean over the rows whose
+    label != ignore_index of logsumexp(x) - x[label]; also d loss / d logits."""
+    x = np.asarray(logits, np.float64)
+    lab = np.asarray(labels, np.int64)
+    valid = lab != ignore_index
+    m = x.max(1, keepdims=True)
+    lse = (m + np.log(np.exp(x - m).sum(1, keepdims=True)))[:, 0]
+    idx = np.where(valid, lab, 0)
+    rows = lse - x[np.arange(x.shape[0]), idx]
+    cnt = int(valid.sum())
+    loss = rows[valid].sum() / cnt if cnt else float("nan")
+    grad = np.exp(x - lse[:, None])
+    grad[np.arange(x.shape[0]), idx] -= 1.0
+    grad[~valid] = 0.0
+    return loss, grad / max(cnt, 1)
 
 
 def gcn_forward(nf, feats0, params, n_layers=1):

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libpagraph_hip.so")
 
 PG_MAX_FIELDS = 4
 PG_MAX_LAYERS = 8
+PG_HEAVY_ROW = 32
 PG_REDUCE_MEAN = 0
 PG_REDUCE_SUM = 1
 
@@ -31,11 +32,16 @@ class PgNodeflowDesc(ctypes.Structure):
     _fields_ = [("node_mapping", vp), ("layer_offsets", vp), ("blk_indptr", vp), ("blk_src", vp),
                 ("sizes_pinned", vp), ("cap_nodes", c_i64),
                 ("blk_indptr_off", c_i64 * PG_MAX_LAYERS), ("blk_src_off", c_i64 * PG_MAX_LAYERS),
-                ("padded", c_i32), ("_pad", c_i32)]
+                ("padded", c_i32), ("transpose_mask", c_u32), ("blk_tptr", vp), ("blk_tdst", vp),
+                ("blk_tptr_off", c_i64 * PG_MAX_LAYERS), ("blk_theavy", vp), ("blk_theavy_off", c_i64 * PG_MAX_LAYERS)]
 
 
 class PgMissqField(ctypes.Structure):
     _fields_ = [("table", vp), ("table_stride", c_i64), ("dim", c_i32), ("_pad", c_i32)]
+
+
+class PgDropout(ctypes.Structure):
+    _fields_ = [("threshold", c_u32), ("tag", c_u32), ("seed", c_u64), ("step", vp)]
 
 
 class PgError(RuntimeError):
@@ -52,6 +58,7 @@ _SIGS = {
     "pg_slot_map_export": (ctypes.c_int, [vp, c_i64, vp, vp, vp]),
     "pg_gather_rows": (ctypes.c_int, [vp, c_i64, vp, vp, ctypes.POINTER(PgField), ctypes.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "pg_gather_rows_full": (ctypes.c_int, [vp, c_i64, ctypes.POINTER(PgField), ctypes.c_int, vp]),
+    "pg_gather_labels": (ctypes.c_int, [vp, c_i64, vp, c_i64, c_i64, vp, vp]),
     "pg_scatter_rows": (ctypes.c_int, [vp, vp, c_i64, vp, c_i32, vp, c_i32, vp]),
     "pg_host_gather_rows": (ctypes.c_int, [vp, c_i64, c_i32, vp, c_i64, vp, ctypes.c_int]),
     "pg_scatter_rows_from_host": (ctypes.c_int, [vp, c_i64, vp, vp, c_i64, vp, c_i32, vp, c_i32, vp]),
@@ -71,8 +78,14 @@ _SIGS = {
     "pg_bitmap_to_ids": (ctypes.c_int, [vp, c_i64, vp, c_i64, vp, vp, vp, vp]),
     "pg_spmm_fwd": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp]),
     "pg_spmm_bwd": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp]),
+    "pg_spmm_fwd_drop": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, vp]),
+    "pg_spmm_bwd_drop": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, vp]),
+    "pg_spmm_bwd_gather": (ctypes.c_int, [vp, vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, c_i32, vp, vp]),
     "pg_linear_fwd": (ctypes.c_int, [vp, c_i32, vp, vp, vp, c_i32, c_i64, c_i32, c_i32, c_i32, vp]),
-    "pg_linear_bwd_w": (ctypes.c_int, [vp, c_i32, vp, c_i32, c_i64, c_i32, c_i32, vp, vp, vp, c_i32, c_i32, vp, vp]),
+    "pg_linear_bwd_w_scratch": (c_i64, [c_i64, c_i32, c_i32]),
+    "pg_linear_bwd_w": (ctypes.c_int, [vp, c_i32, vp, c_i32, c_i64, c_i32, c_i32, vp, vp, vp, c_i32, c_i32, vp, vp, vp]),
+    "pg_xent_fwd": (ctypes.c_int, [vp, c_i32, vp, c_i64, c_i32, c_i64, vp, c_i32, vp, vp, vp]),
+    "pg_xent_bwd": (ctypes.c_int, [vp, c_i32, c_i64, c_i32, vp, vp, vp, c_i32, vp]),
     "pg_dg_partition": (ctypes.c_int, [c_i64, vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp]),
     "pg_rmat_edges": (ctypes.c_int, [c_u64, c_i32, c_u32, c_u32, c_u32, c_i64, c_i64, vp, vp, vp]),
     "pg_random_features": (ctypes.c_int, [c_u64, c_i64, c_i64, c_i32, vp, c_i64, vp]),
@@ -100,8 +113,41 @@ def load():
             fn = getattr(L, name)  # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("PG_HOST_TIMING"):
+            L = _TimedLib(L)
         _lib = L
     return _lib
+
+
+class _TimedLib:
+    """PG_HOST_TIMING=1: host time spent inside every C-ABI call (per-call mean printed at exit) — the
+    replayed step is short enough for the launch thread to be the bottleneck"""
+
+    def __init__(self, lib):
+        import atexit
+        import time
+        self._lib, self._acc, self._clock = lib, {}, time.perf_counter
+        atexit.register(self._report)
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        acc = self._acc.setdefault(name, [0, 0.0])
+        clock = self._clock
+
+        def timed(*a):
+            t0 = clock()
+            r = fn(*a)
+            acc[0] += 1
+            acc[1] += clock() - t0
+            return r
+        setattr(self, name, timed)
+        return timed
+
+    def _report(self):
+        import sys
+        for name, (n, t) in sorted(self._acc.items(), key=lambda kv: -kv[1][1]):
+            if n:
+                print(f"[host-timing] {name:28s} calls {n:7d}  mean {t / n * 1e6:9.1f} us  total {t:8.3f} s", file=sys.stderr)
 
 
 def check(rc, what=""):

@@ -14,9 +14,12 @@
 //           row per lane — W is read as stored, [N][K], no transpose pass); partial 32x32 tiles reduced
 //           through LDS; epilogue fuses bias and NodeUpdate's activation / skip-concat
 //           (gcn_nssc.py:18-23).  375 blocks for n = 12 000.
-// backward  dW[N, K] += dYᵀ·X, db[N] += Σ dY (any N): wave = one (32-feature, 32-column) tile of dW for
-//           a chunk of 256 rows (A = dY rows, B = X rows: both coalesced), fp32 hardware atomics into
-//           dW / db. Also used for the output layer (N = 60, K = 64): the library GEMM has two
+// backward  dW[N, K] = dYᵀ·X, db[N] = Σ dY (any N): block = one (32-feature, 32-column) tile of dW for
+//           a chunk of 64-256 rows split over its 4 waves (A = dY rows, B = X rows: both coalesced), LDS
+//           reduction, the chunk's partial tile written to scratch; k_sum_partials adds the chunks in order
+//           (deterministic). fp32 atomics into dW were tried first: ~70 chunks x 32 floats hit each 128-byte
+//           line of the small dW, the memory-side atomic unit serialises them (~12 ns each) and the kernel
+//           sat at 25-50 us whatever the tiling. Also used for the output layer (N = 60, K = 64): the library GEMM has two
 //           output tiles and a 6000-long reduction there and takes 51 us.
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
@@ -95,7 +98,6 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ X,
   }
 }
 
-constexpr int kBwdRows = 256;  // rows per block in the weight-gradient kernel
 
 // gradient of the pre-activation z w.r.t. the loss, from the gradient G of the (activated) output and the
 // saved output Yout: act 0: G; act 1 (relu): G * (Yout > 0); act 2 (concat): G[:, :N] + G[:, N:] * (Yout[:, :N] > 0)
@@ -120,60 +122,120 @@ __global__ __launch_bounds__(256) void k_dz(const float* __restrict__ G, int32_t
   }
 }
 
+// block = 4 waves on ONE (32-feature, 32-column) tile of dW, each wave reducing its own `rpw` rows
+// (16 rows = 8 MFMA steps with all 16 loads in flight per iteration); the four partial tiles are summed
+// through LDS and leave as one set of atomics per block.
 __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ dY, int32_t dy_stride,
                                                       const float* __restrict__ X, int32_t x_stride, int64_t n,
-                                                      int32_t K, int32_t N, float* __restrict__ dW /* [N][K] */,
-                                                      float* __restrict__ db /* [N] or null */) {
+                                                      int32_t K, int32_t N, float* __restrict__ part, int32_t with_bias,
+                                                      int32_t rpw, int32_t items, int32_t chunks) {
+  __shared__ float red[4][kTile][kTile + 1];
+  __shared__ float bred[4][kWave];
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
   const int half = lane >> 5;
-  // work item of this wave: (feature tile ft of N, 32-column slice c0 of K)
+  // XCD-aware order: workgroups go round-robin over the 8 XCDs, so workgroup id -> (xcd, q); all `items`
+  // tiles of one row chunk run back to back on ONE XCD. Their 128-byte column strips of X straddle cache
+  // lines (row stride 2400 B), which that XCD's L2 then fetches once instead of once per neighbour.
+  const int xcd = (int)(blockIdx.x & 7), q = (int)(blockIdx.x >> 3);
+  const int item = q % items;
+  const int chunk = (q / items) * 8 + xcd;
+  if (chunk >= chunks) return;
   const int col_slices = (K + kTile - 1) / kTile;
-  const int item = (int)blockIdx.x * 4 + w;
   const int ft = item / col_slices;
   const int f0 = ft * kTile;
-  if (f0 >= N) return;
   const int c0 = (item - ft * col_slices) * kTile;
   const int i = f0 + (lane & 31);                    // output feature fed by this lane (A operand)
-  const int64_t rb = (int64_t)blockIdx.y * kBwdRows;
-  const int64_t re = (rb + kBwdRows < n) ? rb + kBwdRows : n;
+  const int64_t rb = ((int64_t)chunk * 4 + w) * rpw;
+  const int64_t re = (rb + rpw < n) ? rb + rpw : n;
   const bool a_ok = i < N, b_ok = c0 + (lane & 31) < K;
-  const bool do_bias = db != nullptr && c0 == 0;
+  const bool do_bias = with_bias && c0 == 0;
+  const float* ap = dY + (a_ok ? i : 0);
+  const float* bp = X + c0 + (b_ok ? (lane & 31) : 0);
   f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   float bsum = 0.f;
   // `base` is wave-uniform (MFMA needs the whole wave); lane half h works on row base + h
   int64_t base = rb;
-  for (; base + 7 < re; base += 8) {  // 4 MFMA steps (8 rows) per iteration, loads issued together
+  for (; base + 15 < re; base += 16) {
     const int64_t r = base + half;
-    float a[4], b[4];
+    float a[8], b[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      a[u] = a_ok ? dY[(r + 2 * u) * dy_stride + i] : 0.f;
-      b[u] = b_ok ? X[(r + 2 * u) * x_stride + c0 + (lane & 31)] : 0.f;
+    for (int u = 0; u < 8; ++u) {
+      a[u] = ap[(r + 2 * u) * dy_stride];
+      b[u] = bp[(r + 2 * u) * x_stride];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
-      bsum += a[u];
+    for (int u = 0; u < 8; ++u) {
+      const float av = a_ok ? a[u] : 0.f, bv = b_ok ? b[u] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      bsum += av;
     }
   }
   for (; base < re; base += 2) {  // tail: the odd half may fall off the end
     const int64_t r = base + half;
     const bool ok = r < re;
-    const float a = (ok && a_ok) ? dY[r * dy_stride + i] : 0.f;
-    const float b = (ok && b_ok) ? X[r * x_stride + c0 + (lane & 31)] : 0.f;
+    const float a = (ok && a_ok) ? ap[r * dy_stride] : 0.f;
+    const float b = (ok && b_ok) ? bp[r * x_stride] : 0.f;
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     bsum += a;
   }
   // C[row = out feature][col = X column]
-  const int j = lane & 31;
-  if (c0 + j < K) {
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      const int of = f0 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
-      if (of < N) unsafeAtomicAdd(dW + (int64_t)of * K + c0 + j, acc[rr]);
-    }
+  for (int rr = 0; rr < 16; ++rr) red[w][(rr & 3) + 8 * (rr >> 2) + 4 * half][lane & 31] = acc[rr];
+  bred[w][lane] = bsum;
+  __syncthreads();
+  const int orow = threadIdx.x >> 3, oc = (threadIdx.x & 7) * 4;
+  const int of = f0 + orow;
+  float* mine = part + (int64_t)chunk * ((int64_t)N * K + N);      // this chunk's partial [N*K | N]
+  if (of < N) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c0 + oc + j < K)
+        mine[(int64_t)of * K + c0 + oc + j] =
+            red[0][orow][oc + j] + red[1][orow][oc + j] + red[2][orow][oc + j] + red[3][orow][oc + j];
   }
-  if (do_bias && a_ok) unsafeAtomicAdd(db + i, bsum);
+  if (do_bias && threadIdx.x < kTile && f0 + (int)threadIdx.x < N) {
+    const int t = threadIdx.x;
+    mine[(int64_t)N * K + f0 + t] = bred[0][t] + bred[0][t + 32] + bred[1][t] + bred[1][t + 32] + bred[2][t] +
+                                    bred[2][t + 32] + bred[3][t] + bred[3][t + 32];
+  }
+}
+
+// dW / db = sum over the row chunks' partials in a fixed order (deterministic). Block = 64 outputs x 4
+// chunk groups, 8 independent loads in flight per thread (a one-thread-per-output loop over ~70 chunks is
+// a chain of dependent-latency loads: 12 us for 5 MB).
+__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ part, int32_t chunks, int64_t nk,
+                                                      int32_t N, float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t j = (int64_t)blockIdx.x * 64 + tx;
+  const int64_t len = nk + N;
+  const bool ok = j < (db ? len : nk);
+  const int per = (chunks + 3) / 4;
+  const int cb = g * per, ce = (cb + per < chunks) ? cb + per : chunks;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (ok) {
+    int c = cb;
+    for (; c + 7 < ce; c += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += part[(int64_t)(c + u) * len + j];
+    }
+    for (; c < ce; ++c) a[0] += part[(int64_t)c * len + j];
+  }
+  red[g][tx] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (g == 0 && ok) {
+    const float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    if (j < nk) dW[j] = v;
+    else db[j - nk] = v;
+  }
+}
+
+static inline int bwd_rows_per_wave(int64_t n, int32_t K, int32_t N) {
+  // rows per wave: 64, shrunk (to >= 16) until the launch has ~1000 blocks
+  const int64_t items = ceil_div<int64_t>(K, kTile) * ceil_div<int64_t>(N, kTile);
+  int rpw = 64;
+  while (rpw > 16 && items * ceil_div<int64_t>(n, 4 * rpw) < 1024) rpw >>= 1;
+  return rpw;
 }
 
 }  // namespace pg
@@ -196,16 +258,24 @@ int pg_linear_fwd(const float* X, int32_t x_stride, const float* W, const float*
   return PG_OK;
 }
 
+int64_t pg_linear_bwd_w_scratch(int64_t n, int32_t K, int32_t N) {
+  if (n <= 0 || K <= 0 || N <= 0) return 0;
+  return ceil_div<int64_t>(n, 4 * bwd_rows_per_wave(n, K, N)) * ((int64_t)N * K + N);
+}
+
 int pg_linear_bwd_w(const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n, int32_t K,
                     int32_t N, float* dW, float* db, const float* Yout, int32_t yo_stride, int32_t act,
-                    float* dz_scratch, pg_stream_t stream) {
+                    float* dz_scratch, float* partials, pg_stream_t stream) {
   if (n < 0 || K <= 0 || N <= 0 || x_stride < K || act < 0 || act > 2 || dy_stride < (act == 2 ? 2 * N : N))
     return PG_ERR_INVALID;
   if (act != 0 && (!Yout || yo_stride < N || !dz_scratch)) return PG_ERR_INVALID;
   if (n == 0) return PG_OK;
-  if (!dY || !X || !dW) return PG_ERR_INVALID;
-  const unsigned gx = (unsigned)ceil_div<int64_t>(ceil_div<int64_t>(K, kTile) * ceil_div<int64_t>(N, kTile), 4);
-  const unsigned gy = (unsigned)ceil_div<int64_t>(n, kBwdRows);
+  if (!dY || !X || !dW || !partials) return PG_ERR_INVALID;
+  const int64_t items = ceil_div<int64_t>(K, kTile) * ceil_div<int64_t>(N, kTile);
+  const int rpw = bwd_rows_per_wave(n, K, N);
+  const int64_t chunks = ceil_div<int64_t>(n, 4 * rpw);
+  const int64_t grid = items * 8 * ceil_div<int64_t>(chunks, 8);
+  if (grid > 0x7fffffff) return PG_ERR_INVALID;
   if (act != 0) {
     int64_t g = ceil_div<int64_t>(n * N, 256);
     hipLaunchKernelGGL(k_dz, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, as_stream(stream), dY, dy_stride, Yout,
@@ -214,8 +284,12 @@ int pg_linear_bwd_w(const float* dY, int32_t dy_stride, const float* X, int32_t 
     dY = dz_scratch;
     dy_stride = N;
   }
-  hipLaunchKernelGGL(k_linear_bwd_w, dim3(gx, gy), dim3(256), 0, as_stream(stream), dY, dy_stride, X, x_stride, n, K,
-                     N, dW, db);
+  hipLaunchKernelGGL(k_linear_bwd_w, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), dY, dy_stride, X, x_stride,
+                     n, K, N, partials, db ? 1 : 0, rpw, (int32_t)items, (int32_t)chunks);
+  PG_LAUNCH_CHECK();
+  const int64_t nk = (int64_t)N * K;
+  hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)ceil_div<int64_t>(nk + N, 64)), dim3(256), 0, as_stream(stream),
+                     partials, (int32_t)chunks, nk, N, dW, db);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }

@@ -301,6 +301,17 @@ static int fill_args(GatherArgs& a, const pg_field_t* fields, int n_fields, bool
   return PG_OK;
 }
 
+// batch_labels = labels[batch_nids] (examples/profile/pa_gcn.py:99-100); ids < 0 are the padding of a
+// fixed-shape NodeFlow and get `fill` (the loss's ignore_index)
+__global__ __launch_bounds__(256) void k_gather_labels(const int64_t* __restrict__ ids, int64_t n,
+                                                       const int64_t* __restrict__ labels, int64_t n_labels,
+                                                       int64_t fill, int64_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = ids[i];
+    out[i] = (v >= 0 && v < n_labels) ? labels[v] : fill;
+  }
+}
+
 }  // namespace pg
 
 using namespace pg;
@@ -375,6 +386,18 @@ int pg_gather_rows_full(const int64_t* ids, int64_t n, const pg_field_t* fields,
   int rc = fill_args(a, fields, n_fields, true);
   if (rc != PG_OK) return rc;
   return launch_gather<true>(a, as_stream(stream));
+}
+
+int pg_gather_labels(const int64_t* ids, int64_t n, const int64_t* labels, int64_t n_labels, int64_t fill,
+                     int64_t* out, pg_stream_t stream) {
+  if (n < 0 || n_labels < 0) return PG_ERR_INVALID;
+  if (n == 0) return PG_OK;
+  if (!ids || !out || (!labels && n_labels > 0)) return PG_ERR_INVALID;
+  int64_t g = ceil_div<int64_t>(n, 256);
+  hipLaunchKernelGGL(k_gather_labels, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, as_stream(stream), ids, n,
+                     labels, n_labels, fill, out);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
 }
 
 int pg_scatter_rows(const float* staged, const int32_t* pos, int64_t n, const int32_t* n_dev, int32_t dim,

@@ -25,6 +25,11 @@
 // writes the sizes straight into pinned host memory.
 // All sizes stay on the device; launches are sized by worst-case capacities.
 #include <new>
+#include <vector>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "pg_common.h"
 
@@ -61,7 +66,17 @@ __device__ __forceinline__ int block_excl_scan(int v, int* lds, int* total) {
 }
 
 // ---------------------------------------------------------------------------
+// what changes from one pg_sampler_sample call to the next. The launch sequence itself is fixed per output
+// slot, so it is captured once into a hipGraph; the host writes this block (pinned, one per slot) and
+// k_seed_layer copies it to the device for the rest of the chain.
+struct SampleParams {
+  const int64_t* seeds;
+  int32_t n_seeds;
+  uint32_t seed_lo, seed_hi, epoch, batch;
+};
+
 struct SampleArgs {
+  const SampleParams* prm;  // device copy
   const int64_t* indptr;
   const int32_t* indices;
   const int64_t* dst_ids;  // layer b+1 vertex ids
@@ -70,7 +85,7 @@ struct SampleArgs {
   int32_t* cnt;            // [cap_dst]
   unsigned long long* bitmap;
   int32_t k;
-  uint32_t seed_lo, seed_hi, epoch, batch, layer;
+  uint32_t layer;
 };
 
 __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
@@ -98,8 +113,8 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
       uint64_t t = 0;
       if (lane < k) {
         uint32_t r[4];
-        Philox::gen((uint32_t)v, a.epoch, a.batch, (a.layer << 24) | (uint32_t)(lane >> 1), a.seed_lo,
-                    a.seed_hi, r);
+        Philox::gen((uint32_t)v, a.prm->epoch, a.prm->batch, (a.layer << 24) | (uint32_t)(lane >> 1),
+                    a.prm->seed_lo, a.prm->seed_hi, r);
         const uint64_t r64 = (lane & 1) ? ((uint64_t)r[3] << 32 | r[2]) : ((uint64_t)r[1] << 32 | r[0]);
         t = bounded(r64, (uint64_t)(deg - k + lane) + 1);
       }
@@ -120,7 +135,8 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
 }
 
 // exclusive scan of cnt[0:n] -> indptr[0:n+1]; single block, loops over tiles
-__global__ __launch_bounds__(kScanThreads) void k_scan_cnt(const int32_t* __restrict__ cnt,
+template <bool CLEAR>
+__global__ __launch_bounds__(kScanThreads) void k_scan_cnt(int32_t* __restrict__ cnt,
                                                            const int32_t* __restrict__ n_dev,
                                                            int32_t* __restrict__ indptr,
                                                            int32_t* __restrict__ total_out, int32_t cap_rows) {
@@ -130,6 +146,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_cnt(const int32_t* __rest
   for (int base = 0; base < n; base += kScanThreads) {
     const int i = base + threadIdx.x;
     const int v = i < n ? cnt[i] : 0;
+    if (CLEAR && i < n) cnt[i] = 0;
     int tot;
     const int ex = block_excl_scan(v, lds, &tot);
     if (i < n) indptr[i] = carry + ex;
@@ -276,13 +293,59 @@ __global__ __launch_bounds__(256) void k_pack(const PackArgs a) {
   }
 }
 
-// copy seeds into the top layer buffer + set its count
-__global__ void k_seed_layer(const int64_t* seeds, int32_t n, int64_t* layer_ids, int32_t* layer_cnt) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) layer_ids[i] = seeds[i];
-  if (blockIdx.x == 0 && threadIdx.x == 0) *layer_cnt = n;
+// ---- block transposes (source-major copy of a block, for the gather-form backward aggregation) -------
+// One (key = source, value = destination row) pair per edge, edges in destination order; a STABLE radix sort
+// by key (rocPRIM) then leaves every source's destinations ascending, which fixes the summation order of
+// the backward pass. Entries past the block's real edge count get the key `pad_key` (> every source).
+// tcnt[s] += #edges whose source is s (zero on entry; the scan that follows clears it again).
+__global__ __launch_bounds__(256) void k_t_keys(const int32_t* __restrict__ indptr, const int32_t* __restrict__ src,
+                                                const int32_t* __restrict__ n_dst_dev,
+                                                const int32_t* __restrict__ nnz_dev, int32_t cap_edges,
+                                                int32_t pad_key, int32_t* __restrict__ key,
+                                                int32_t* __restrict__ val, int32_t* __restrict__ tcnt,
+                                                int32_t* __restrict__ heavy) {
+  const int n = *n_dst_dev, nnz = *nnz_dev;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  for (int v = tid; v < n; v += nth) {
+    for (int e = indptr[v]; e < indptr[v + 1]; ++e) {
+      const int sr = src[e];
+      key[e] = sr;
+      val[e] = v;
+      atomicAdd(tcnt + sr, 1);
+    }
+  }
+  for (int e = nnz + tid; e < cap_edges; e += nth) {
+    key[e] = pad_key;
+    val[e] = 0;
+  }
+  if (tid == 0 && heavy) heavy[0] = 0;
 }
 
-// fan-out = infinity: mark every in-neighbour of the frontier (closure builder)
+// sources with more than PG_HEAVY_ROW edges (hubs; in the benchmark graph: the vertex every isolated train
+// vertex aliases to, utils.py:34) are listed so that the backward pass can give each of them a whole block
+__global__ __launch_bounds__(256) void k_t_heavy(const int32_t* __restrict__ tptr, const int32_t* __restrict__ n_src_dev,
+                                                 int32_t* __restrict__ heavy, int32_t heavy_cap) {
+  const int n = *n_src_dev;
+  for (int sr = blockIdx.x * blockDim.x + threadIdx.x; sr < n; sr += gridDim.x * blockDim.x) {
+    if (tptr[sr + 1] - tptr[sr] > PG_HEAVY_ROW) {
+      const int i = atomicAdd(heavy, 1);
+      if (i < heavy_cap) heavy[1 + i] = sr;
+    }
+  }
+}
+
+// copy seeds into the top layer buffer + set its count; publishes the call's parameters on the device
+__global__ void k_seed_layer(const SampleParams* __restrict__ prm_host, SampleParams* __restrict__ prm_dev,
+                             int64_t* layer_ids, int32_t* layer_cnt) {
+  const SampleParams p = *prm_host;   // pinned host memory: one PCIe read per thread, 64 blocks at most
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p.n_seeds; i += gridDim.x * blockDim.x)
+    layer_ids[i] = p.seeds[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *layer_cnt = p.n_seeds;
+    *prm_dev = p;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_mark_neighbors(const int64_t* __restrict__ indptr,
                                                         const int32_t* __restrict__ indices,
                                                         const int64_t* __restrict__ frontier, int64_t n,
@@ -312,6 +375,18 @@ static inline int grid_for(int64_t n, int per_block, int cap = 8192) {
 using namespace pg;
 
 struct pg_sampler {
+  struct SlotState {
+    const void* key = nullptr;
+    hipStream_t stream = nullptr;
+    pg_nodeflow_desc_t desc{};
+    SampleParams* prm_h = nullptr;   // pinned host
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int64_t calls = 0;
+    bool graph_failed = false;
+  };
+  std::vector<SlotState*> slot_states;
+  SampleParams* prm_d = nullptr;     // device copy of the running call's parameters
   int64_t V = 0;
   const int64_t* indptr = nullptr;
   const int32_t* indices = nullptr;
@@ -327,6 +402,15 @@ struct pg_sampler {
   int32_t* counters = nullptr;  // [0..L] layer counts, [PG_MAX_LAYERS..] block edge counts
   int32_t* nbr = nullptr;       // ELL picks of the current block (reused)
   int32_t* cnt = nullptr;
+  int32_t* tcnt = nullptr;      // per-source edge counts while a block is transposed (zero between uses)
+  int32_t* tkey = nullptr;      // [2][cap edges] sort keys in / out, then [cap edges] values in
+  void* tsort_tmp = nullptr;    // rocPRIM radix sort scratch
+  size_t tsort_bytes = 0;
+  int64_t max_edges = 0;
+  // the transposes run on their own stream, forked right after a block is relabelled, so that block b's
+  // transposition overlaps the sampling of blocks b-1 .. 0 (every kernel here is latency bound)
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 static void sampler_free(pg_sampler* s) {
@@ -338,6 +422,19 @@ static void sampler_free(pg_sampler* s) {
   (void)hipFree(s->counters);
   (void)hipFree(s->nbr);
   (void)hipFree(s->cnt);
+  (void)hipFree(s->tcnt);
+  (void)hipFree(s->tkey);
+  (void)hipFree(s->tsort_tmp);
+  (void)hipFree(s->prm_d);
+  for (auto* c : s->slot_states) {
+    if (c->exec) (void)hipGraphExecDestroy(c->exec);
+    if (c->graph) (void)hipGraphDestroy(c->graph);
+    if (c->prm_h) (void)hipHostFree(c->prm_h);
+    delete c;
+  }
+  if (s->aux) (void)hipStreamDestroy(s->aux);
+  if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+  if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   delete s;
 }
 
@@ -371,8 +468,22 @@ int pg_sampler_create(int64_t V, const int64_t* indptr, const int32_t* indices, 
   ok &= hipMalloc(&s->counters, 2 * PG_MAX_LAYERS * 4) == hipSuccess;
   ok &= hipMalloc(&s->nbr, max_dst * fanout * 4) == hipSuccess;
   ok &= hipMalloc(&s->cnt, max_dst * 4) == hipSuccess;
+  ok &= hipMalloc(&s->prm_d, sizeof(SampleParams)) == hipSuccess;
+  ok &= hipMalloc(&s->tcnt, (s->cap[0] + 1) * 4) == hipSuccess;
   if (ok) ok &= hipMemset(s->bitmap, 0, s->n_words * 8) == hipSuccess;
   if (ok) ok &= hipMemset(s->counters, 0, 2 * PG_MAX_LAYERS * 4) == hipSuccess;
+  if (ok) ok &= hipMemset(s->tcnt, 0, (s->cap[0] + 1) * 4) == hipSuccess;
+  s->max_edges = max_dst * fanout;
+  ok &= hipMalloc(&s->tkey, (size_t)s->max_edges * 3 * 4) == hipSuccess;
+  if (ok) {
+    int32_t* kk = s->tkey;
+    ok &= rocprim::radix_sort_pairs(nullptr, s->tsort_bytes, kk, kk, kk, kk, (size_t)s->max_edges, 0, 32,
+                                    (hipStream_t) nullptr) == hipSuccess;
+    if (ok) ok &= hipMalloc(&s->tsort_tmp, s->tsort_bytes ? s->tsort_bytes : 4) == hipSuccess;
+  }
+  ok &= hipStreamCreateWithPriority(&s->aux, hipStreamNonBlocking, -1) == hipSuccess;
+  ok &= hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess;
+  ok &= hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     sampler_free(s);
     return PG_ERR_NOMEM;
@@ -398,20 +509,17 @@ int pg_sampler_capacity(const pg_sampler_t* s, int64_t* cap_nodes, int64_t* cap_
   return PG_OK;
 }
 
-int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, uint64_t seed, uint32_t epoch,
-                      uint32_t batch, const pg_nodeflow_desc_t* o, pg_stream_t stream) {
-  if (!s || !o || !seeds || n_seeds <= 0 || n_seeds > s->B) return PG_ERR_INVALID;
-  if (!o->node_mapping || !o->layer_offsets || !o->blk_indptr || !o->blk_src || !o->sizes_pinned)
-    return PG_ERR_INVALID;
+// the whole launch sequence of one sample() into the slot described by `o`; nothing in it depends on the
+// call's scalar arguments (those travel through ss->prm_h), so it can be captured into a hipGraph
+static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t st, pg_sampler::SlotState* ss) {
   int64_t need = 0;
   for (int l = 0; l <= s->hops; ++l) need += s->cap[l];
-  if (o->cap_nodes < need) return PG_ERR_OVERFLOW;
-  hipStream_t st = as_stream(stream);
   const int L = s->hops;
   int32_t* lcnt = s->counters;
   int32_t* ecnt = s->counters + PG_MAX_LAYERS;
 
-  hipLaunchKernelGGL(k_seed_layer, dim3(grid_for(n_seeds, 256, 64)), dim3(256), 0, st, seeds, n_seeds,
+  bool forked = false;
+  hipLaunchKernelGGL(k_seed_layer, dim3(grid_for(s->B, 256, 64)), dim3(256), 0, st, ss->prm_h, s->prm_d,
                      s->layer_ids[L], lcnt + L);
   PG_LAUNCH_CHECK();
   for (int b = L - 1; b >= 0; --b) {
@@ -420,13 +528,12 @@ int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, ui
     a.indptr = s->indptr; a.indices = s->indices;
     a.dst_ids = s->layer_ids[b + 1]; a.n_dst = lcnt + b + 1;
     a.nbr = s->nbr; a.cnt = s->cnt; a.bitmap = s->bitmap; a.k = s->k;
-    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
-    a.epoch = epoch; a.batch = batch; a.layer = (uint32_t)b;
+    a.prm = s->prm_d; a.layer = (uint32_t)b;
     hipLaunchKernelGGL(k_sample, dim3(grid_for(cap_dst, 4)), dim3(256), 0, st, a);
     PG_LAUNCH_CHECK();
     int32_t* indptr_b = o->blk_indptr + o->blk_indptr_off[b];
     int32_t* src_b = o->blk_src + o->blk_src_off[b];
-    hipLaunchKernelGGL(k_scan_cnt, dim3(1), dim3(kScanThreads), 0, st, s->cnt, lcnt + b + 1, indptr_b, ecnt + b,
+    hipLaunchKernelGGL(k_scan_cnt<false>, dim3(1), dim3(kScanThreads), 0, st, s->cnt, lcnt + b + 1, indptr_b, ecnt + b,
                        (int32_t)cap_dst);
     PG_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bm_count, dim3(s->n_bm_blocks), dim3(256), 0, st, s->bitmap, s->n_words, s->partial);
@@ -443,6 +550,46 @@ int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, ui
     hipLaunchKernelGGL(k_clear_words, dim3(grid_for(s->cap[b], 256, 1024)), dim3(256), 0, st, s->bitmap,
                        s->layer_ids[b], lcnt + b);
     PG_LAUNCH_CHECK();
+    // source-major copy of this block (gather-form backward aggregation), on the side stream
+    if (o->blk_tptr && o->blk_tdst && ((o->transpose_mask >> b) & 1u)) {
+      // PG_SAMPLER_FORK=1: transposes on a side stream, overlapping the sampling of the remaining blocks.
+      // Off by default: with the asynchronous miss queue's spin-wait kernel in flight the extra stream made
+      // the whole pipeline 3x slower on MI355X (streams sharing a hardware queue with a spinning kernel).
+      static const bool fork = getenv("PG_SAMPLER_FORK") != nullptr;
+      hipStream_t ax = st;
+      if (fork) {
+        PG_HIP(hipEventRecord(s->ev_fork, st));
+        PG_HIP(hipStreamWaitEvent(s->aux, s->ev_fork, 0));
+        forked = true;
+        ax = s->aux;
+      }
+      int32_t* tptr_b = o->blk_tptr + o->blk_tptr_off[b];
+      int32_t* tdst_b = o->blk_tdst + o->blk_src_off[b];
+      int32_t* heavy_b = o->blk_theavy ? o->blk_theavy + o->blk_theavy_off[b] : nullptr;
+      const int32_t cap_edges = (int32_t)(s->cap[b + 1] * s->k);
+      const int32_t pad_key = (int32_t)s->cap[b];
+      int32_t *key_in = s->tkey, *key_out = s->tkey + s->max_edges, *val_in = s->tkey + 2 * s->max_edges;
+      hipLaunchKernelGGL(k_t_keys, dim3(grid_for(s->cap[b + 1], 256, 1024)), dim3(256), 0, ax, indptr_b, src_b,
+                         lcnt + b + 1, ecnt + b, cap_edges, pad_key, key_in, val_in, s->tcnt, heavy_b);
+      PG_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_scan_cnt<true>, dim3(1), dim3(kScanThreads), 0, ax, s->tcnt, lcnt + b, tptr_b,
+                         s->counters + 2 * PG_MAX_LAYERS - 1, (int32_t)s->cap[b]);
+      PG_LAUNCH_CHECK();
+      int bits = 1;
+      while ((1ll << bits) <= pad_key) ++bits;
+      size_t bytes = s->tsort_bytes;
+      PG_HIP(rocprim::radix_sort_pairs(s->tsort_tmp, bytes, key_in, key_out, val_in, tdst_b, (size_t)cap_edges, 0,
+                                       (unsigned)bits, ax));
+      if (heavy_b) {
+        hipLaunchKernelGGL(k_t_heavy, dim3(grid_for(s->cap[b], 256, 1024)), dim3(256), 0, ax, tptr_b, lcnt + b, heavy_b,
+                           (int32_t)(cap_edges / PG_HEAVY_ROW));
+        PG_LAUNCH_CHECK();
+      }
+    }
+  }
+  if (forked) {  // the transposes must be complete before the NodeFlow is published
+    PG_HIP(hipEventRecord(s->ev_join, s->aux));
+    PG_HIP(hipStreamWaitEvent(st, s->ev_join, 0));
   }
   PackArgs p{};
   for (int l = 0; l <= L; ++l) {
@@ -458,6 +605,66 @@ int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, ui
   hipLaunchKernelGGL(k_pack, dim3(grid_for(need, 256, 1024)), dim3(256), 0, st, p);
   PG_LAUNCH_CHECK();
   return PG_OK;
+}
+
+int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, uint64_t seed, uint32_t epoch,
+                      uint32_t batch, const pg_nodeflow_desc_t* o, pg_stream_t stream) {
+  if (!s || !o || !seeds || n_seeds <= 0 || n_seeds > s->B) return PG_ERR_INVALID;
+  if (!o->node_mapping || !o->layer_offsets || !o->blk_indptr || !o->blk_src || !o->sizes_pinned)
+    return PG_ERR_INVALID;
+  int64_t need = 0;
+  for (int l = 0; l <= s->hops; ++l) need += s->cap[l];
+  if (o->cap_nodes < need) return PG_ERR_OVERFLOW;
+  hipStream_t st = as_stream(stream);
+  // per-slot state, keyed by the slot's output buffers and the stream
+  pg_sampler::SlotState* ss = nullptr;
+  for (auto* c : s->slot_states)
+    if (c->key == o->node_mapping && c->stream == st && memcmp(&c->desc, o, sizeof(*o)) == 0) ss = c;
+  if (!ss) {
+    ss = new (std::nothrow) pg_sampler::SlotState;
+    if (!ss) return PG_ERR_NOMEM;
+    if (hipHostMalloc(&ss->prm_h, sizeof(SampleParams), hipHostMallocDefault) != hipSuccess) {
+      delete ss;
+      return PG_ERR_NOMEM;
+    }
+    ss->key = o->node_mapping;
+    ss->stream = st;
+    ss->desc = *o;
+    s->slot_states.push_back(ss);
+  }
+  // the caller reuses a slot only after its previous NodeFlow was consumed, i.e. long after the previous
+  // launch for this slot read its parameter block
+  SampleParams* prm = ss->prm_h;
+  prm->seeds = seeds; prm->n_seeds = n_seeds;
+  prm->seed_lo = (uint32_t)seed; prm->seed_hi = (uint32_t)(seed >> 32);
+  prm->epoch = epoch; prm->batch = batch;
+  ++ss->calls;
+  static const bool no_graph = getenv("PG_SAMPLER_NO_GRAPH") != nullptr;
+  if (ss->exec) {
+    PG_HIP(hipGraphLaunch(ss->exec, st));
+    return PG_OK;
+  }
+  if (no_graph || ss->graph_failed || ss->calls < 2) return enqueue_chain(s, o, st, ss);
+  // second call into this slot: capture the chain (~25-35 launches) once, then replay it with one launch
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    ss->graph_failed = true;
+    return enqueue_chain(s, o, st, ss);
+  }
+  const int rc = enqueue_chain(s, o, st, ss);
+  hipGraph_t graph = nullptr;
+  const hipError_t e_end = hipStreamEndCapture(st, &graph);
+  if (rc == PG_OK && e_end == hipSuccess && graph &&
+      hipGraphInstantiate(&ss->exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+    ss->graph = graph;
+    PG_HIP(hipGraphLaunch(ss->exec, st));
+    return PG_OK;
+  }
+  (void)hipGetLastError();
+  if (graph) (void)hipGraphDestroy(graph);
+  ss->exec = nullptr;
+  ss->graph_failed = true;
+  return enqueue_chain(s, o, st, ss);   // nothing ran during the failed capture
 }
 
 int pg_frontier_mark_neighbors(const int64_t* indptr, const int32_t* indices, const int64_t* frontier, int64_t n,

@@ -108,6 +108,260 @@ __global__ __launch_bounds__(256) void k_spmm_bwd(const int32_t* __restrict__ in
   }
 }
 
+// ---- aggregation with the model's dropout folded in -------------------------------------------------
+// GCNSampling / GraphSageSampling apply nn.Dropout to a layer's input right before aggregating it
+// (gcn_nssc.py:66-69, graphsage_nssc.py:86-89).  As its own kernel that is a read + write of the whole
+// [42K, 600] layer-0 frame plus a byte mask (25 us per step) for an input that needs no gradient, so the
+// mask is generated where the rows are consumed instead.  Mask spec (restated in oracle/oracle.py
+// dropout_mask): element (r, col) of the aggregated tensor, piece = col / 4,
+//   q = (piece / 128) * 64 + piece % 64,  half = (piece / 64) % 2,  j = col % 4
+//   w[0..3] = Philox4x32-10(counter = (r, q, tag, step), key = (seed_lo, seed_hi))
+//   u16     = 16 bits of w[2 * half + j / 2], low half-word for even j, high for odd j
+//   keep iff u16 >= threshold;  kept values are multiplied by scale = 65536 / (65536 - threshold).
+// (pieces p and p + 64 share one Philox call: with 64 lanes on a row, lane l owns pieces l, l + 64, ...)
+struct DropArgs {
+  uint32_t thr, tag, k0, k1;
+  const uint64_t* step;
+  float scale;
+};
+
+__device__ __forceinline__ float4 drop_apply(float4 x, const uint32_t (&o)[4], int half, uint32_t thr, float scale) {
+  const uint32_t w0 = half ? o[2] : o[0], w1 = half ? o[3] : o[1];
+  x.x = (w0 & 0xffffu) >= thr ? x.x * scale : 0.f;
+  x.y = (w0 >> 16) >= thr ? x.y * scale : 0.f;
+  x.z = (w1 & 0xffffu) >= thr ? x.z * scale : 0.f;
+  x.w = (w1 >> 16) >= thr ? x.w * scale : 0.f;
+  return x;
+}
+
+__global__ __launch_bounds__(256) void k_spmm_fwd_drop(const int32_t* __restrict__ indptr,
+                                                       const int32_t* __restrict__ src,
+                                                       const float* __restrict__ h, int32_t h_stride, int64_t n_dst,
+                                                       int32_t dim, int reduce, float* __restrict__ out,
+                                                       int32_t out_stride, int lpr_log2, DropArgs d) {
+  using S = SV<4>;
+  const int lpr = 1 << lpr_log2;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int gl = lane & (lpr - 1);
+  const int rows_per_wave = kWave >> lpr_log2;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+  const int64_t v = wave * rows_per_wave + (lane >> lpr_log2);
+  if (v >= n_dst) return;
+  const uint32_t step = d.step ? (uint32_t)*d.step : 0u;
+  const int pieces = dim / 4;
+  const int32_t beg = indptr[v], end = indptr[v + 1];
+  float4* orow = reinterpret_cast<float4*>(out + v * out_stride);
+  for (int c0 = 0; c0 < pieces; c0 += lpr * kMaxAcc) {
+    float4 acc[kMaxAcc];
+#pragma unroll
+    for (int m = 0; m < kMaxAcc; ++m) acc[m] = S::zero();
+    for (int32_t e = beg; e < end; ++e) {
+      const int32_t sr = src[e];
+      const float4* hrow = reinterpret_cast<const float4*>(h + (int64_t)sr * h_stride);
+      uint32_t o[4] = {0, 0, 0, 0};
+      int have_q = -1;
+#pragma unroll
+      for (int m = 0; m < kMaxAcc; ++m) {
+        const int c = c0 + m * lpr + gl;
+        if (c < pieces) {
+          const float4 x = hrow[c];
+          const int q = ((c >> 7) << 6) | (c & 63);
+          if (q != have_q) {
+            Philox::gen((uint32_t)sr, (uint32_t)q, d.tag, step, d.k0, d.k1, o);
+            have_q = q;
+          }
+          S::add(acc[m], drop_apply(x, o, (c >> 6) & 1, d.thr, d.scale));
+        }
+      }
+    }
+    const float dg = (float)(end - beg);
+#pragma unroll
+    for (int m = 0; m < kMaxAcc; ++m) {
+      const int c = c0 + m * lpr + gl;
+      if (c < pieces) {
+        if (reduce == PG_REDUCE_MEAN && end > beg) S::div(acc[m], dg);
+        orow[c] = acc[m];
+      }
+    }
+  }
+}
+
+// grad_h[src[e], c] += grad_out[v, c] * scale(v) * mask(src[e], c)
+__global__ __launch_bounds__(256) void k_spmm_bwd_drop(const int32_t* __restrict__ indptr,
+                                                       const int32_t* __restrict__ src,
+                                                       const float* __restrict__ go, int32_t go_stride, int64_t n_dst,
+                                                       int32_t dim, int reduce, float* __restrict__ gh,
+                                                       int32_t gh_stride, int lpr_log2, DropArgs d) {
+  const int lpr = 1 << lpr_log2;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int gl = lane & (lpr - 1);
+  const int rows_per_wave = kWave >> lpr_log2;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+  const int64_t v = wave * rows_per_wave + (lane >> lpr_log2);
+  if (v >= n_dst) return;
+  const int32_t beg = indptr[v], end = indptr[v + 1];
+  if (end == beg) return;
+  const uint32_t step = d.step ? (uint32_t)*d.step : 0u;
+  const float dg = (float)(end - beg);
+  const float* grow = go + v * go_stride;
+  for (int c = gl; c < dim; c += lpr) {
+    float g = grow[c];
+    if (reduce == PG_REDUCE_MEAN) g /= dg;
+    g *= d.scale;
+    const int piece = c >> 2, j = c & 3;
+    const int q = ((piece >> 7) << 6) | (piece & 63), half = (piece >> 6) & 1;
+    for (int32_t e = beg; e < end; ++e) {
+      const int32_t sr = src[e];
+      uint32_t o[4];
+      Philox::gen((uint32_t)sr, (uint32_t)q, d.tag, step, d.k0, d.k1, o);
+      const uint32_t w = (j >> 1) ? (half ? o[3] : o[1]) : (half ? o[2] : o[0]);
+      const uint32_t u = (j & 1) ? (w >> 16) : (w & 0xffffu);
+      if (u >= d.thr) unsafeAtomicAdd(gh + (int64_t)sr * gh_stride + c, g);
+    }
+  }
+}
+
+// Backward aggregation in gather form over the block's source-major copy (pg_nodeflow_desc_t.blk_tptr /
+// blk_tdst, built by the sampler off the critical path):
+//   grad_h[s, :] = mask(s, :) * scale * sum_{t in [tptr[s], tptr[s+1])} grad_out[tdst[t], :] / deg(tdst[t])
+// Every row of grad_h is written (no zero fill), nothing is atomic (the scatter form manages ~30 G fp32
+// atomics/s: 26 us for the 12K-edge output block) and the sum runs in ascending destination order.
+template <int VEC, bool DROP>
+__global__ __launch_bounds__(256) void k_spmm_bwd_gather(const int32_t* __restrict__ tptr,
+                                                         const int32_t* __restrict__ tdst,
+                                                         const int32_t* __restrict__ indptr,
+                                                         const float* __restrict__ go, int32_t go_stride,
+                                                         int64_t n_src, int32_t dim, int reduce,
+                                                         float* __restrict__ gh, int32_t gh_stride, int lpr_log2,
+                                                         int skip_heavy, DropArgs d) {
+  using S = SV<VEC>;
+  using V = typename S::type;
+  const int lpr = 1 << lpr_log2;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int gl = lane & (lpr - 1);
+  const int rows_per_wave = kWave >> lpr_log2;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+  const int64_t sr = wave * rows_per_wave + (lane >> lpr_log2);
+  if (sr >= n_src) return;
+  const uint32_t step = (DROP && d.step) ? (uint32_t)*d.step : 0u;
+  const int pieces = dim / VEC;
+  const int32_t beg = tptr[sr], end = tptr[sr + 1];
+  if (skip_heavy && end - beg > PG_HEAVY_ROW) return;   // a hub: k_spmm_bwd_heavy gives it a whole block
+  V* grow = reinterpret_cast<V*>(gh + sr * gh_stride);
+  for (int c = gl; c < pieces; c += lpr) {
+    V acc = S::zero();
+    for (int32_t t = beg; t < end; ++t) {
+      const int32_t v = tdst[t];
+      V g = reinterpret_cast<const V*>(go + (int64_t)v * go_stride)[c];
+      if (reduce == PG_REDUCE_MEAN) S::div(g, (float)(indptr[v + 1] - indptr[v]));
+      S::add(acc, g);
+    }
+    if constexpr (DROP) {
+      if (end > beg) {
+        if constexpr (VEC == 4) {
+          uint32_t o[4];
+          Philox::gen((uint32_t)sr, (uint32_t)(((c >> 7) << 6) | (c & 63)), d.tag, step, d.k0, d.k1, o);
+          acc = drop_apply(acc, o, (c >> 6) & 1, d.thr, d.scale);
+        } else {
+          const int piece = c >> 2, j = c & 3, half = (piece >> 6) & 1;
+          uint32_t o[4];
+          Philox::gen((uint32_t)sr, (uint32_t)(((piece >> 7) << 6) | (piece & 63)), d.tag, step, d.k0, d.k1, o);
+          const uint32_t w = (j >> 1) ? (half ? o[3] : o[1]) : (half ? o[2] : o[0]);
+          const uint32_t u = (j & 1) ? (w >> 16) : (w & 0xffffu);
+          acc = u >= d.thr ? acc * d.scale : 0.f;
+        }
+      }
+    }
+    grow[c] = acc;
+  }
+}
+
+// hubs (sources with more than PG_HEAVY_ROW edges, listed by the sampler): a 1024-thread block per hub.
+// Per chunk of 1024 edges: (destination, degree) staged in LDS with coalesced loads, then 1024 / lpr edge
+// lanes accumulate strided edges — independent loads, so the few hundred edges of a hub cost a handful of
+// memory round trips instead of one per edge — and the partial sums are combined through LDS in lane order
+// (deterministic).
+constexpr int kHeavyThreads = 1024;
+
+template <int VEC, bool DROP>
+__global__ __launch_bounds__(kHeavyThreads) void k_spmm_bwd_heavy(const int32_t* __restrict__ heavy, int32_t heavy_cap,
+                                                                  const int32_t* __restrict__ tptr,
+                                                                  const int32_t* __restrict__ tdst,
+                                                                  const int32_t* __restrict__ indptr,
+                                                                  const float* __restrict__ go, int32_t go_stride,
+                                                                  int32_t dim, int reduce, float* __restrict__ gh,
+                                                                  int32_t gh_stride, int lpr_log2, DropArgs d) {
+  using S = SV<VEC>;
+  using V = typename S::type;
+  __shared__ int32_t s_v[kHeavyThreads];
+  __shared__ float s_w[kHeavyThreads];
+  __shared__ V red[kHeavyThreads];
+  int n_heavy = heavy[0];
+  if (n_heavy > heavy_cap) n_heavy = heavy_cap;
+  const int lpr = 1 << lpr_log2;                  // lanes across the row's pieces
+  const int el = threadIdx.x >> lpr_log2, n_el = kHeavyThreads >> lpr_log2, gl = threadIdx.x & (lpr - 1);
+  const int pieces = dim / VEC;
+  const uint32_t step = (DROP && d.step) ? (uint32_t)*d.step : 0u;
+  for (int hi = blockIdx.x; hi < n_heavy; hi += gridDim.x) {
+    const int sr = heavy[1 + hi];
+    const int32_t beg = tptr[sr], end = tptr[sr + 1];
+    for (int c0 = 0; c0 < pieces; c0 += lpr) {
+      const int c = c0 + gl;
+      V acc = S::zero();
+      for (int32_t base = beg; base < end; base += kHeavyThreads) {
+        const int n = end - base < kHeavyThreads ? end - base : kHeavyThreads;
+        __syncthreads();
+        if ((int)threadIdx.x < n) {
+          const int32_t v = tdst[base + threadIdx.x];
+          s_v[threadIdx.x] = v;
+          s_w[threadIdx.x] = reduce == PG_REDUCE_MEAN ? (float)(indptr[v + 1] - indptr[v]) : 1.f;
+        }
+        __syncthreads();
+        if (c < pieces) {
+#pragma unroll 4
+          for (int k = el; k < n; k += n_el) {
+            V g = reinterpret_cast<const V*>(go + (int64_t)s_v[k] * go_stride)[c];
+            if (reduce == PG_REDUCE_MEAN) S::div(g, s_w[k]);
+            S::add(acc, g);
+          }
+        }
+      }
+      red[threadIdx.x] = acc;
+      __syncthreads();
+      if (el == 0 && c < pieces) {
+        V tot = S::zero();
+        for (int k = 0; k < n_el; ++k) S::add(tot, red[(k << lpr_log2) + gl]);
+        if constexpr (DROP) {
+          if constexpr (VEC == 4) {
+            uint32_t o[4];
+            Philox::gen((uint32_t)sr, (uint32_t)(((c >> 7) << 6) | (c & 63)), d.tag, step, d.k0, d.k1, o);
+            tot = drop_apply(tot, o, (c >> 6) & 1, d.thr, d.scale);
+          } else {
+            const int piece = c >> 2, j = c & 3, half = (piece >> 6) & 1;
+            uint32_t o[4];
+            Philox::gen((uint32_t)sr, (uint32_t)(((piece >> 7) << 6) | (piece & 63)), d.tag, step, d.k0, d.k1, o);
+            const uint32_t w = (j >> 1) ? (half ? o[3] : o[1]) : (half ? o[2] : o[0]);
+            const uint32_t u = (j & 1) ? (w >> 16) : (w & 0xffffu);
+            tot = u >= d.thr ? tot * d.scale : 0.f;
+          }
+        }
+        reinterpret_cast<V*>(gh + (int64_t)sr * gh_stride)[c] = tot;
+      }
+    }
+  }
+}
+
+static inline bool drop_args(const pg_dropout_t* dp, DropArgs* d) {
+  if (!dp || dp->threshold == 0 || dp->threshold > 65535u) return false;
+  d->thr = dp->threshold;
+  d->tag = dp->tag;
+  d->k0 = (uint32_t)dp->seed;
+  d->k1 = (uint32_t)(dp->seed >> 32);
+  d->step = dp->step;
+  d->scale = 65536.f / (float)(65536u - dp->threshold);
+  return true;
+}
+
 static inline bool al(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 static inline int log2_ceil_pow2(int x) {
@@ -143,6 +397,86 @@ int pg_spmm_fwd(const int32_t* indptr, const int32_t* src, const float* h, int32
   else
     hipLaunchKernelGGL(k_spmm_fwd<1>, dim3(grid), dim3(256), 0, st, indptr, src, h, h_stride, n_dst, dim, reduce, out, out_stride, l2);
   PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+int pg_spmm_fwd_drop(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int64_t n_dst,
+                     int32_t dim, int reduce, float* out, int32_t out_stride, const pg_dropout_t* drop,
+                     pg_stream_t stream) {
+  DropArgs d;
+  if (drop && drop->threshold > 65535u) return PG_ERR_INVALID;
+  if (!drop_args(drop, &d)) return pg_spmm_fwd(indptr, src, h, h_stride, n_dst, dim, reduce, out, out_stride, stream);
+  if (n_dst < 0 || dim <= 0 || h_stride < dim || out_stride < dim) return PG_ERR_INVALID;
+  if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return PG_ERR_INVALID;
+  if (!(dim % 4 == 0 && h_stride % 4 == 0 && out_stride % 4 == 0 && al(h, 16) && al(out, 16))) return PG_ERR_UNSUPPORTED;
+  if (n_dst == 0) return PG_OK;
+  if (!indptr || !out) return PG_ERR_INVALID;
+  const int pieces = dim / 4;
+  int l2 = log2_ceil_pow2(pieces < 64 ? pieces : 64);
+  const int rows_per_block = 4 * (64 >> l2);
+  hipLaunchKernelGGL(k_spmm_fwd_drop, dim3((unsigned)ceil_div<int64_t>(n_dst, rows_per_block)), dim3(256), 0,
+                     as_stream(stream), indptr, src, h, h_stride, n_dst, dim, reduce, out, out_stride, l2, d);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+int pg_spmm_bwd_drop(const int32_t* indptr, const int32_t* src, const float* grad_out, int32_t go_stride,
+                     int64_t n_dst, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,
+                     const pg_dropout_t* drop, pg_stream_t stream) {
+  DropArgs d;
+  if (drop && drop->threshold > 65535u) return PG_ERR_INVALID;
+  if (!drop_args(drop, &d))
+    return pg_spmm_bwd(indptr, src, grad_out, go_stride, n_dst, dim, reduce, grad_h, gh_stride, stream);
+  if (n_dst < 0 || dim <= 0 || go_stride < dim || gh_stride < dim || dim % 4) return PG_ERR_INVALID;
+  if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return PG_ERR_INVALID;
+  if (n_dst == 0) return PG_OK;
+  if (!indptr || !grad_out) return PG_ERR_INVALID;
+  int l2 = log2_ceil_pow2(dim < 64 ? dim : 64);
+  const int rows_per_block = 4 * (64 >> l2);
+  hipLaunchKernelGGL(k_spmm_bwd_drop, dim3((unsigned)ceil_div<int64_t>(n_dst, rows_per_block)), dim3(256), 0,
+                     as_stream(stream), indptr, src, grad_out, go_stride, n_dst, dim, reduce, grad_h, gh_stride, l2, d);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+int pg_spmm_bwd_gather(const int32_t* tptr, const int32_t* tdst, const int32_t* indptr, const float* grad_out,
+                       int32_t go_stride, int64_t n_src, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,
+                       const int32_t* heavy, int32_t heavy_cap, const pg_dropout_t* drop, pg_stream_t stream) {
+  if (n_src < 0 || dim <= 0 || go_stride < dim || gh_stride < dim) return PG_ERR_INVALID;
+  if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return PG_ERR_INVALID;
+  if (drop && drop->threshold > 65535u) return PG_ERR_INVALID;
+  if (n_src == 0) return PG_OK;
+  if (!tptr || !indptr || !grad_h) return PG_ERR_INVALID;  // tdst / grad_out may be NULL only for an edgeless block
+  DropArgs d{};
+  const bool dr = drop_args(drop, &d);
+  if (dr && dim % 4) return PG_ERR_INVALID;
+  const bool v4 = dim % 4 == 0 && go_stride % 4 == 0 && gh_stride % 4 == 0 && al(grad_out, 16) && al(grad_h, 16);
+  const int pieces = v4 ? dim / 4 : dim;
+  int l2 = log2_ceil_pow2(pieces < 64 ? pieces : 64);
+  const int rows_per_block = 4 * (64 >> l2);
+  const dim3 grid((unsigned)ceil_div<int64_t>(n_src, rows_per_block));
+  hipStream_t st = as_stream(stream);
+#define PG_BWD_GATHER(VEC, DROP)                                                                                 \
+  hipLaunchKernelGGL((k_spmm_bwd_gather<VEC, DROP>), grid, dim3(256), 0, st, tptr, tdst, indptr, grad_out, go_stride, \
+                     n_src, dim, reduce, grad_h, gh_stride, l2, (heavy && heavy_cap > 0) ? 1 : 0, d)
+  if (v4 && dr) PG_BWD_GATHER(4, true);
+  else if (v4) PG_BWD_GATHER(4, false);
+  else if (dr) PG_BWD_GATHER(1, true);
+  else PG_BWD_GATHER(1, false);
+#undef PG_BWD_GATHER
+  PG_LAUNCH_CHECK();
+  if (heavy && heavy_cap > 0) {
+    const unsigned hgrid = heavy_cap < 64 ? (unsigned)heavy_cap : 64u;
+#define PG_BWD_HEAVY(VEC, DROP)                                                                                   \
+  hipLaunchKernelGGL((k_spmm_bwd_heavy<VEC, DROP>), dim3(hgrid), dim3(kHeavyThreads), 0, st, heavy, heavy_cap, tptr, \
+                     tdst, indptr, grad_out, go_stride, dim, reduce, grad_h, gh_stride, l2, d)
+    if (v4 && dr) PG_BWD_HEAVY(4, true);
+    else if (v4) PG_BWD_HEAVY(4, false);
+    else if (dr) PG_BWD_HEAVY(1, true);
+    else PG_BWD_HEAVY(1, false);
+#undef PG_BWD_HEAVY
+    PG_LAUNCH_CHECK();
+  }
   return PG_OK;
 }
 

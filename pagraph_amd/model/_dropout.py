@@ -1,0 +1,37 @@
+"""nn.Dropout of the sampled models folded into the aggregation kernel that consumes it.
+
+The reference applies `self.dropout(h)` to a layer's input right before `nf.block_compute`
+(PaGraph/model/gcn_nssc.py:66-69, graphsage_nssc.py:86-89). Here the model hands the aggregation a
+DropoutSpec instead (ops.DropoutSpec / pg_dropout_t): the kernel draws the keep-mask from a counter-based
+RNG keyed by (torch.initial_seed(), layer, rank, step). `step` lives in a device buffer bumped once per
+training forward, so a replayed hipGraph gets a new mask each step. Inputs the kernel cannot take
+(CPU tensors, dim % 4 != 0) and eval mode go through nn.Dropout unchanged."""
+import torch
+
+from .. import ops
+
+
+class FusedDropoutMixin:
+    def _init_fused_dropout(self):
+        # non-persistent: the state_dict keeps the reference's keys
+        self.register_buffer('_drop_step', torch.zeros(1, dtype=torch.int64), persistent=False)
+        self._drop_seed = None
+        self.fuse_dropout = True
+
+    def _bump_drop_step(self):
+        if self.training and self._drop_step.is_cuda:
+            self._drop_step.add_(1)
+
+    def _drop_spec(self, layer, h):
+        """DropoutSpec for aggregating `h` as the input of block `layer`, or None (use nn.Dropout)"""
+        mod = getattr(self, 'dropout', None)
+        if not (self.fuse_dropout and self.training and isinstance(mod, torch.nn.Dropout) and 0.0 < mod.p < 1.0):
+            return None
+        if not (self._drop_step.is_cuda and ops.DropoutSpec.fusable(h)):
+            return None
+        if self._drop_seed is None:
+            self._drop_seed = torch.initial_seed()
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()
+        return ops.DropoutSpec(mod.p, self._drop_seed, (rank << 8) | (layer & 0xFF), self._drop_step)

@@ -8,6 +8,7 @@ import torch.nn as nn
 
 from .. import function as fn
 from .. import ops
+from ._dropout import FusedDropoutMixin
 
 
 class NodeUpdate(nn.Module):
@@ -49,7 +50,7 @@ def _stack(in_feats, n_hidden, n_classes, n_layers, activation, preprocess, test
     return layers
 
 
-class _GCNBase(nn.Module):
+class _GCNBase(FusedDropoutMixin, nn.Module):
     reducer = fn.mean
     uses_norm = False
 
@@ -76,14 +77,18 @@ class _GCNBase(nn.Module):
 
     def _propagate(self, nf, h):
         for i, layer in enumerate(self.layers):
+            drop = None
             if getattr(self, 'dropout', None) and not self.preprocess:
-                h = self.dropout(h)
+                drop = self._drop_spec(i, h)             # dropout inside the aggregation kernel ...
+                if drop is None:
+                    h = self.dropout(h)                  # ... or nn.Dropout where that cannot be done
             nf.layers[i].data['h'] = h
-            nf.block_compute(i, fn.copy_src(src='h', out='m'), self.reducer(msg='m', out='h'), layer)
+            nf.block_compute(i, fn.copy_src(src='h', out='m'), self.reducer(msg='m', out='h'), layer, dropout=drop)
             h = nf.layers[i + 1].data.pop('activation')
         return h
 
     def forward(self, nf):
+        self._bump_drop_step()
         if self.preprocess:
             return self._propagate(nf, self._input_transform(nf))
         return self._propagate(nf, nf.layers[0].data['features'])
@@ -97,6 +102,7 @@ class GCNSampling(_GCNBase):
         self.preprocess = preprocess
         self.n_layers = n_layers
         self.dropout = nn.Dropout(p=dropout) if dropout != 0 else None
+        self._init_fused_dropout()
         if preprocess:
             self.linear = nn.Linear(in_feats, n_hidden)
             self.activation = activation
@@ -112,6 +118,7 @@ class GCNInfer(_GCNBase):
         super().__init__()
         self.preprocess = preprocess
         self.n_layers = n_layers
+        self._init_fused_dropout()
         if preprocess:
             self.linear = nn.Linear(in_feats, n_hidden)
             self.activation = activation

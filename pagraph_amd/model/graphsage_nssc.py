@@ -8,6 +8,7 @@ import torch.nn as nn
 
 from .. import function as fn
 from .. import ops
+from ._dropout import FusedDropoutMixin
 
 
 class NodeUpdate(nn.Module):
@@ -35,7 +36,7 @@ class NodeUpdate(nn.Module):
 _REDUCERS = {'mean': fn.mean, 'gcn': fn.sum}
 
 
-class GraphSageSampling(nn.Module):
+class GraphSageSampling(FusedDropoutMixin, nn.Module):
     def __init__(self, in_feats, n_hidden, n_classes, n_layers, activation=None, dropout=0.,
                  aggregator_type='pool', preprocess=False):
         super().__init__()
@@ -45,6 +46,7 @@ class GraphSageSampling(nn.Module):
         self.preprocess = preprocess
         self.n_layers = n_layers
         self.dropout = nn.Dropout(dropout)
+        self._init_fused_dropout()
         self.activation = activation
         self.aggregator_type = aggregator_type
         self.layers = nn.ModuleList()
@@ -65,6 +67,7 @@ class GraphSageSampling(nn.Module):
 
     def forward(self, nf):
         L = nf.num_layers
+        self._bump_drop_step()
         if self.preprocess:
             # graphsage_nssc.py:75-87: every layer carries 'features' and a pre-aggregated 'neigh'
             for i in range(L):
@@ -82,8 +85,12 @@ class GraphSageSampling(nn.Module):
         for lid, layer in enumerate(self.layers):
             for i in range(lid, L - 1):
                 d = nf.layers[i].data
-                d['h'] = self.dropout(d.pop('h'))
-                nf.block_compute(i, fn.copy_src(src='h', out='m'), red('m', 'neigh'), layer)
+                # the dropped 'h' is read by this aggregation only (layer i's self term was consumed by block
+                # i - 1 already), so the mask can be applied inside the kernel (tag: one per (lid, i) call site)
+                drop = self._drop_spec(lid * 16 + i, d['h'])
+                if drop is None:
+                    d['h'] = self.dropout(d.pop('h'))
+                nf.block_compute(i, fn.copy_src(src='h', out='m'), red('m', 'neigh'), layer, dropout=drop)
             for i in range(lid + 1, L):
                 d = nf.layers[i].data
                 d['h'] = d.pop('activation')

@@ -1,4 +1,6 @@
 """autograd wrappers over the HIP aggregation kernels (pagraph_amd/csrc/pg_spmm.hip)."""
+import ctypes
+
 import torch
 
 from . import _lib as L
@@ -6,38 +8,90 @@ from . import _lib as L
 _REDUCE = {"mean": L.PG_REDUCE_MEAN, "sum": L.PG_REDUCE_SUM}
 
 
+class DropoutSpec:
+    """nn.Dropout folded into the aggregation that consumes its output (pg_dropout_t, include/pagraph_hip.h):
+    p quantised to threshold / 65536, counter-based mask keyed by (seed, tag, *step) — `step` is a device int64
+    tensor the owner bumps once per forward, so a replayed hipGraph draws a fresh mask every step."""
+    __slots__ = ("threshold", "seed", "tag", "step")
+
+    def __init__(self, p, seed, tag, step):
+        self.threshold = min(65535, int(round(float(p) * 65536.0)))
+        self.seed, self.tag, self.step = int(seed) & 0xFFFFFFFFFFFFFFFF, int(tag) & 0xFFFFFFFF, step
+
+    def struct(self):
+        return L.PgDropout(self.threshold, self.tag, self.seed, L.ptr(self.step))
+
+    @staticmethod
+    def fusable(h):
+        return (h.is_cuda and h.dtype == torch.float32 and h.dim() == 2 and h.size(1) % 4 == 0 and h.stride(1) == 1
+                and h.stride(0) % 4 == 0 and h.data_ptr() % 16 == 0)
+
+
 class _BlockAggregate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, indptr, src, h, n_dst, reduce):
+    def forward(ctx, indptr, src, h, n_dst, reduce, drop, tptr, tdst, heavy):
         lib = L.load()
         h = h.contiguous()
         out = torch.empty((n_dst, h.size(1)), dtype=torch.float32, device=h.device)
         with torch.cuda.device(h.device):
-            L.check(lib.pg_spmm_fwd(L.ptr(indptr), L.ptr(src), L.ptr(h), h.stride(0), n_dst, h.size(1),
-                                    _REDUCE[reduce], L.ptr(out), out.stride(0), L.stream_ptr()), "pg_spmm_fwd")
-        ctx.save_for_backward(indptr, src)
-        ctx.n_src, ctx.reduce = h.size(0), reduce
+            if drop is None:
+                L.check(lib.pg_spmm_fwd(L.ptr(indptr), L.ptr(src), L.ptr(h), h.stride(0), n_dst, h.size(1),
+                                        _REDUCE[reduce], L.ptr(out), out.stride(0), L.stream_ptr()), "pg_spmm_fwd")
+            else:
+                d = drop.struct()
+                L.check(lib.pg_spmm_fwd_drop(L.ptr(indptr), L.ptr(src), L.ptr(h), h.stride(0), n_dst, h.size(1),
+                                             _REDUCE[reduce], L.ptr(out), out.stride(0), ctypes.byref(d),
+                                             L.stream_ptr()), "pg_spmm_fwd_drop")
+        if tptr is not None and tptr.numel() == h.size(0) + 1:
+            ctx.save_for_backward(indptr, src, tptr, tdst, heavy)
+        else:
+            ctx.save_for_backward(indptr, src)
+        ctx.n_src, ctx.reduce, ctx.drop = h.size(0), reduce, drop
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        indptr, src = ctx.saved_tensors
         if not ctx.needs_input_grad[2]:
-            return None, None, None, None, None
+            return (None,) * 9
         lib = L.load()
         go = grad_out.contiguous()
+        if len(ctx.saved_tensors) == 5:          # gather form over the block's source-major copy
+            indptr, src, tptr, tdst, heavy = ctx.saved_tensors
+            gh = torch.empty((ctx.n_src, go.size(1)), dtype=torch.float32, device=go.device)
+            d = ctx.drop.struct() if ctx.drop is not None else None
+            with torch.cuda.device(go.device):
+                L.check(lib.pg_spmm_bwd_gather(L.ptr(tptr), L.ptr(tdst), L.ptr(indptr), L.ptr(go), go.stride(0), ctx.n_src,
+                                               go.size(1), _REDUCE[ctx.reduce], L.ptr(gh), gh.stride(0), L.ptr(heavy),
+                                               heavy.numel() - 1 if heavy is not None else 0,
+                                               ctypes.byref(d) if d is not None else None, L.stream_ptr()),
+                        "pg_spmm_bwd_gather")
+            return (None, None, gh) + (None,) * 6
+        indptr, src = ctx.saved_tensors
         gh = torch.zeros((ctx.n_src, go.size(1)), dtype=torch.float32, device=go.device)
         with torch.cuda.device(go.device):
-            L.check(lib.pg_spmm_bwd(L.ptr(indptr), L.ptr(src), L.ptr(go), go.stride(0), go.size(0), go.size(1),
-                                    _REDUCE[ctx.reduce], L.ptr(gh), gh.stride(0), L.stream_ptr()), "pg_spmm_bwd")
-        return None, None, gh, None, None
+            if ctx.drop is None:
+                L.check(lib.pg_spmm_bwd(L.ptr(indptr), L.ptr(src), L.ptr(go), go.stride(0), go.size(0), go.size(1),
+                                        _REDUCE[ctx.reduce], L.ptr(gh), gh.stride(0), L.stream_ptr()), "pg_spmm_bwd")
+            else:
+                d = ctx.drop.struct()
+                L.check(lib.pg_spmm_bwd_drop(L.ptr(indptr), L.ptr(src), L.ptr(go), go.stride(0), go.size(0),
+                                             go.size(1), _REDUCE[ctx.reduce], L.ptr(gh), gh.stride(0),
+                                             ctypes.byref(d), L.stream_ptr()), "pg_spmm_bwd_drop")
+        return (None, None, gh) + (None,) * 6
 
 
-def block_aggregate(indptr, src, h, n_dst, reduce="mean"):
-    """out[v] = reduce_{e in block, dst(e)=v} h[src(e)]  (DGL copy_src + mean|sum)"""
+def block_aggregate(indptr, src, h, n_dst, reduce="mean", dropout=None, transpose=None):
+    """out[v] = reduce_{e in block, dst(e)=v} dropout(h)[src(e)]  (DGL copy_src + mean|sum; `dropout` is a
+    DropoutSpec or None; `transpose` = (tptr, tdst[, heavy]), the block's source-major copy (and hub list) from
+    the sampler, lets the backward run as a gather instead of fp32 atomics)"""
     if h.dtype != torch.float32 or not h.is_cuda:
         raise L.PgError("block_aggregate needs fp32 CUDA tensors (no CPU fallback)")
-    return _BlockAggregate.apply(indptr, src, h, int(n_dst), reduce)
+    if dropout is not None and (dropout.threshold == 0 or not DropoutSpec.fusable(h)):
+        if dropout.threshold:
+            raise L.PgError("fused dropout needs a row-aligned fp32 input with dim % 4 == 0 (check DropoutSpec.fusable)")
+        dropout = None
+    tptr, tdst, heavy = (tuple(transpose) + (None,))[:3] if transpose is not None else (None, None, None)
+    return _BlockAggregate.apply(indptr, src, h, int(n_dst), reduce, dropout, tptr, tdst, heavy)
 
 
 ACT_NONE, ACT_RELU, ACT_CONCAT = 0, 1, 2
@@ -85,14 +139,15 @@ class _SkinnyLinear(torch.autograd.Function):
         N, K = weight.shape
         gz = gy if act == ACT_NONE else None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            buf = torch.zeros(N * K + N, dtype=torch.float32, device=x.device)   # one fill for dW and db
+            buf = torch.empty(N * K + N, dtype=torch.float32, device=x.device)
+            part = torch.empty(lib.pg_linear_bwd_w_scratch(x.size(0), K, N), dtype=torch.float32, device=x.device)
             gw = buf[:N * K].view(N, K)
             gb = buf[N * K:] if ctx.has_bias else None
             dz = torch.empty((x.size(0), N), dtype=torch.float32, device=x.device) if act != ACT_NONE else None
             with torch.cuda.device(x.device):
                 L.check(lib.pg_linear_bwd_w(L.ptr(gy), gy.stride(0), L.ptr(x), x.stride(0), x.size(0), K, N,
                                             L.ptr(gw), L.ptr(gb), L.ptr(y), y.stride(0) if y is not None else 0, act,
-                                            L.ptr(dz), L.stream_ptr()), "pg_linear_bwd_w")
+                                            L.ptr(dz), L.ptr(part), L.stream_ptr()), "pg_linear_bwd_w")
             if dz is not None:
                 gz = dz
         if ctx.needs_input_grad[0]:
@@ -110,3 +165,64 @@ def linear(x, module, act=ACT_NONE):
             and x.stride(1) == 1):
         return _SkinnyLinear.apply(x, w, b, act)
     return _apply_act(module(x), act)
+
+
+class _CrossEntropy(torch.autograd.Function):
+    """loss head: row pass + one-block reduction forward, one scale backward (pg_loss.hip)"""
+
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        lib = L.load()
+        n, C = logits.shape
+        if logits.stride(1) != 1:
+            logits = logits.contiguous()
+        labels = labels.contiguous()
+        need_grad = ctx.needs_input_grad[0]
+        dl = torch.empty((n, C), dtype=torch.float32, device=logits.device) if need_grad else None
+        scratch = torch.empty(n + 2, dtype=torch.float32, device=logits.device)
+        meta = scratch[n:]
+        with torch.cuda.device(logits.device):
+            L.check(lib.pg_xent_fwd(L.ptr(logits), logits.stride(0), L.ptr(labels), n, C, int(ignore_index),
+                                    L.ptr(dl), C, L.ptr(scratch), L.ptr(meta), L.stream_ptr()), "pg_xent_fwd")
+        if need_grad:
+            ctx.save_for_backward(dl, meta)
+        return meta[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dl, meta = ctx.saved_tensors
+        lib = L.load()
+        gx = torch.empty_like(dl)
+        g = g.contiguous().to(torch.float32)
+        with torch.cuda.device(dl.device):
+            L.check(lib.pg_xent_bwd(L.ptr(dl), dl.stride(0), dl.size(0), dl.size(1), L.ptr(meta), L.ptr(g), L.ptr(gx),
+                                    gx.stride(0), L.stream_ptr()), "pg_xent_bwd")
+        return gx, None, None
+
+
+def cross_entropy(logits, labels, ignore_index=-100):
+    """torch.nn.functional.cross_entropy(logits, labels) (mean, no class weights) on the HIP loss head"""
+    if (not logits.is_cuda or logits.dtype != torch.float32 or logits.dim() != 2 or labels.dtype != torch.int64
+            or labels.dim() != 1 or labels.size(0) != logits.size(0) or logits.size(0) == 0):
+        raise L.PgError("cross_entropy needs fp32 CUDA logits [n, C] and int64 labels [n] (no CPU fallback)")
+    return _CrossEntropy.apply(logits, labels, ignore_index)
+
+
+class CrossEntropyLoss(torch.nn.Module):
+    """drop-in for the trainer scripts' `torch.nn.CrossEntropyLoss()` (pa_gcn.py:80)"""
+
+    def __init__(self, ignore_index=-100):
+        super().__init__()
+        self.ignore_index = ignore_index
+
+    def forward(self, logits, labels):
+        return cross_entropy(logits, labels, self.ignore_index)
+
+
+def fused_loss(loss_fcn):
+    """the HIP loss head when `loss_fcn` is a plain torch.nn.CrossEntropyLoss (mean, unweighted, no label
+    smoothing) — what pa_gcn.py / pa_gs.py construct — otherwise `loss_fcn` itself"""
+    if (type(loss_fcn) is torch.nn.CrossEntropyLoss and loss_fcn.weight is None and loss_fcn.reduction == 'mean'
+            and getattr(loss_fcn, 'label_smoothing', 0.0) == 0.0):
+        return CrossEntropyLoss(loss_fcn.ignore_index)
+    return loss_fcn

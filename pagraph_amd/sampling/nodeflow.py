@@ -108,6 +108,11 @@ class NodeFlow:
         self.num_blocks = self.num_layers - 1
         self.blk_indptr = blk_indptr
         self.blk_src = blk_src
+        # source-major copy of a block (sampler option `transpose`): tptr int32 [|L(i)|+1], tdst int32 [edges] =
+        # positions of the destinations inside layer i+1, ascending per source; None where not built
+        self.blk_tptr = [None] * self.num_blocks
+        self.blk_tdst = [None] * self.num_blocks
+        self.blk_theavy = [None] * self.num_blocks   # [count, hub sources...] (more than PG_HEAVY_ROW edges)
         self._node_frames = [None] * self.num_layers
         self.layers = _Layers(self)
         self.padded = False      # True: fixed-shape layout, ids < 0 are padding (sampler static=True)
@@ -131,14 +136,17 @@ class NodeFlow:
     def block_size(self, i):
         return int(self.blk_src[i].numel())
 
-    def block_compute(self, i, message_func, reduce_func, apply_node_func=None):
+    def block_compute(self, i, message_func, reduce_func, apply_node_func=None, dropout=None):
         """DGL's nf.block_compute for the builtin pair copy_src + mean|sum
         (gcn_nssc.py:71-74,139-142; graphsage_nssc.py:98-111): aggregate layer i's
-        `src` field over block i into layer i+1's `out` field, then run the node UDF on layer i+1."""
+        `src` field over block i into layer i+1's `out` field, then run the node UDF on layer i+1.
+        `dropout` (an ops.DropoutSpec, not in DGL) applies the model's dropout to the source field inside
+        the aggregation kernel."""
         src_field = message_func.src
         assert reduce_func.msg == message_func.out, "reduce must consume the message field"
         h = self.layers[i].data[src_field]
-        agg = block_aggregate(self.blk_indptr[i], self.blk_src[i], h, self.layer_size(i + 1), reduce_func.op)
+        agg = block_aggregate(self.blk_indptr[i], self.blk_src[i], h, self.layer_size(i + 1), reduce_func.op,
+                              dropout=dropout, transpose=(self.blk_tptr[i], self.blk_tdst[i], self.blk_theavy[i]))
         dst = self.layers[i + 1].data
         dst[reduce_func.out] = agg
         if apply_node_func is not None:

@@ -16,7 +16,7 @@ from .nodeflow import NodeFlow
 
 
 class _Slot:
-    def __init__(self, lib, handle, hops, device, padded=False):
+    def __init__(self, lib, handle, hops, device, padded=False, transpose_mask=0):
         cap_nodes = L.c_i64()
         rows = (L.c_i64 * L.PG_MAX_LAYERS)()
         edges = (L.c_i64 * L.PG_MAX_LAYERS)()
@@ -36,6 +36,21 @@ class _Slot:
             sc += edges[b]
         self.blk_indptr = torch.empty(ip, dtype=torch.int32, device=device)
         self.blk_src = torch.empty(max(1, sc), dtype=torch.int32, device=device)
+        # source-major copies of the blocks in `transpose_mask` (gather-form backward aggregation)
+        self.transpose_mask = int(transpose_mask)
+        self.tp_off = []
+        tp = 0
+        for b in range(hops):
+            self.tp_off.append(tp)
+            tp += self.layer_caps[b] + 1
+        self.blk_tptr = torch.zeros(tp, dtype=torch.int32, device=device) if transpose_mask else None
+        self.blk_tdst = torch.zeros(max(1, sc), dtype=torch.int32, device=device) if transpose_mask else None
+        # hub lists: [count, sources with more than PG_HEAVY_ROW edges in the block ...]
+        self.hv_off, hv = [], 0
+        for b in range(hops):
+            self.hv_off.append(hv)
+            hv += 1 + edges[b] // L.PG_HEAVY_ROW
+        self.blk_theavy = torch.zeros(hv, dtype=torch.int32, device=device) if transpose_mask else None
         self.sizes = torch.zeros(2 * L.PG_MAX_LAYERS, dtype=torch.int32).pin_memory()
         self.ready = torch.cuda.Event()
         self.free = torch.cuda.Event()
@@ -52,12 +67,20 @@ class _Slot:
         for b in range(hops):
             d.blk_indptr_off[b] = self.ip_off[b]
             d.blk_src_off[b] = self.src_off[b]
+            d.blk_tptr_off[b] = self.tp_off[b]
+            d.blk_theavy_off[b] = self.hv_off[b]
+        if transpose_mask:
+            d.transpose_mask = self.transpose_mask
+            d.blk_tptr = self.blk_tptr.data_ptr()
+            d.blk_tdst = self.blk_tdst.data_ptr()
+            d.blk_theavy = self.blk_theavy.data_ptr()
         self.desc = d
 
 
 class NeighborSampler:
     def __init__(self, g, batch_size, expand_factor, num_hops=1, neighbor_type='in', seed_nodes=None,
-                 shuffle=False, num_workers=1, prefetch=False, seed=0, copy_out=True, static=False, ring=None):
+                 shuffle=False, num_workers=1, prefetch=False, seed=0, copy_out=True, static=False, ring=None,
+                 transpose='auto'):
         if neighbor_type != 'in':
             raise L.PgError("only neighbor_type='in' is on the hot path (pa_gcn.py:72)")
         self.lib = L.load()
@@ -94,7 +117,14 @@ class NeighborSampler:
         # True: the consumer calls release(nf) itself once the work that reads the NodeFlow is enqueued
         # (needed when it holds several prepared batches at once); False: released when the iterator advances
         self.manual_release = False
-        self.slots = [_Slot(self.lib, self.handle, self.num_hops, self.device, padded=self.static)
+        # transpose: blocks that also come out source-major (NodeFlow.blk_tptr / blk_tdst) so that the backward
+        # aggregation is a gather. 'auto' = every block whose input can carry a gradient (all but block 0,
+        # whose input is the raw feature frame); or an iterable of block indices; None = none.
+        if transpose == 'auto':
+            transpose = range(1, self.num_hops)
+        self.transpose_mask = sum(1 << int(b) for b in (transpose or ()) if 0 <= int(b) < self.num_hops)
+        self.slots = [_Slot(self.lib, self.handle, self.num_hops, self.device, padded=self.static,
+                            transpose_mask=self.transpose_mask)
                       for _ in range(ring if ring else (4 if self.static else 3))]
 
     def __del__(self):
@@ -154,6 +184,11 @@ class NeighborSampler:
         ips = [slot.blk_indptr[slot.ip_off[b]:slot.ip_off[b] + slot.layer_caps[b + 1] + 1] for b in range(self.num_hops)]
         srcs = [slot.blk_src[slot.src_off[b]:slot.src_off[b] + slot.edge_caps[b]] for b in range(self.num_hops)]
         nf = NodeFlow(slot.node_mapping[:offs[-1]], offs, ips, srcs)
+        for b in range(self.num_hops):
+            if (slot.transpose_mask >> b) & 1:
+                nf.blk_tptr[b] = slot.blk_tptr[slot.tp_off[b]:slot.tp_off[b] + slot.layer_caps[b] + 1]
+                nf.blk_tdst[b] = slot.blk_tdst[slot.src_off[b]:slot.src_off[b] + slot.edge_caps[b]]
+                nf.blk_theavy[b] = slot.blk_theavy[slot.hv_off[b]:slot.hv_off[b] + 1 + slot.edge_caps[b] // L.PG_HEAVY_ROW]
         nf.padded = True
         nf.num_seeds = n_seeds
         nf._slot = slot
@@ -177,12 +212,23 @@ class NeighborSampler:
             ne = sizes[L.PG_MAX_LAYERS + b]
             ips.append(slot.blk_indptr[slot.ip_off[b]:slot.ip_off[b] + nd + 1])
             srcs.append(slot.blk_src[slot.src_off[b]:slot.src_off[b] + ne])
+        tps, tds, hvs = [None] * self.num_hops, [None] * self.num_hops, [None] * self.num_hops
+        for b in range(self.num_hops):
+            if (slot.transpose_mask >> b) & 1:
+                tps[b] = slot.blk_tptr[slot.tp_off[b]:slot.tp_off[b] + sizes[b] + 1]
+                tds[b] = slot.blk_tdst[slot.src_off[b]:slot.src_off[b] + sizes[L.PG_MAX_LAYERS + b]]
+                hvs[b] = slot.blk_theavy[slot.hv_off[b]:slot.hv_off[b] + 1 + slot.edge_caps[b] // L.PG_HEAVY_ROW]
         if self.copy_out:
             # detach from the ring so a NodeFlow stays valid after the iterator moves on
             nm = nm.clone()
             ips = [t.clone() for t in ips]
             srcs = [t.clone() for t in srcs]
-        return NodeFlow(nm, offs, ips, srcs)
+            tps = [None if t is None else t.clone() for t in tps]
+            tds = [None if t is None else t.clone() for t in tds]
+            hvs = [None if t is None else t.clone() for t in hvs]
+        nf = NodeFlow(nm, offs, ips, srcs)
+        nf.blk_tptr, nf.blk_tdst, nf.blk_theavy = tps, tds, hvs
+        return nf
 
     def __iter__(self):
         epoch = self.epoch

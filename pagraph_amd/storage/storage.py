@@ -62,6 +62,10 @@ def _table(graph, name):
     return graph._node_frame._frame[name].data
 
 
+class _FetchPlan:
+    __slots__ = ("names", "row_lo", "rows", "out", "fields", "n_fields", "optrs", "ostr", "cache_epoch")
+
+
 class GraphCacheServer:
     """Manage graph features: static top-out-degree HBM cache + hit/miss gather."""
 
@@ -107,6 +111,8 @@ class GraphCacheServer:
         # miss_mode == "async": libpagraph's worker-thread miss queue (pg_missq_*), one slot per in-flight batch
         self._missq = None
         self._missq_rows = 0
+        self._missq_bufs = {}            # slot -> (miss_pos, miss_fullid, miss_count) pointers
+        self._cache_epoch = 0            # bumped whenever the cache contents / layout change (invalidates fetch plans)
         self.missq_slots = 4
 
     # -- reference-shaped views of the fused slot map --------------------------
@@ -205,6 +211,7 @@ class GraphCacheServer:
         self._fused_cache = fused
         self.gpu_fix_cache = dict(views)
         self.full_cached = is_full
+        self._cache_epoch += 1
 
     # -- storage.py:107-132 ---------------------------------------------------
     def get_feat_from_server(self, nids, embed_names, to_gpu=False):
@@ -353,8 +360,85 @@ class GraphCacheServer:
                 keep = names if need is None else [n for n in names if n in need[i]]
                 nodeflow._node_frames[i] = {name: out[name][offsets[i] - row_lo:offsets[i + 1] - row_lo] for name in keep}
 
+    # -- fixed-shape fast path (hipGraph pipelines) ---------------------------------------------
+    def plan_fetch(self, layer_offsets, out, need=None):
+        """Everything fetch_data derives from (layer offsets, output frames, `need`) computed once, for callers
+        that fetch the same shapes into the same frames every step (GraphedTrainer): the per-step call is
+        then fetch_planned(plan, ...) = two or three C-ABI calls and no tensor slicing — at ~0.2 ms per
+        step the launch thread is the bottleneck, not the GPU. Not for miss_mode 'staged' (which
+        synchronises with the host anyway)."""
+        if self.miss_mode == "staged" and not self.full_cached:
+            raise L.PgError("plan_fetch: miss_mode 'staged' has no asynchronous fast path")
+        plan = _FetchPlan()
+        names = list(self.dims)
+        offsets = [int(x) for x in layer_offsets]
+        lo, hi = offsets[0], offsets[-1]
+        if need is not None:
+            layers = sorted(need)
+            assert layers == list(range(layers[0], layers[-1] + 1)), "needed layers must be contiguous"
+            wanted = set(n for l in layers for n in need[l])
+            names = [n for n in names if n in wanted]
+            lo, hi = offsets[layers[0]], offsets[layers[-1] + 1]
+        plan.names, plan.row_lo, plan.rows = names, lo, hi - lo
+        plan.out = {n: out[n][lo:hi] for n in names}
+        plan.fields, plan.n_fields = L.make_fields(
+            (self.gpu_fix_cache.get(name), plan.out[name], self.dims[name],
+             self.gpu_fix_cache[name].stride(0) if name in self.gpu_fix_cache else self.dims[name],
+             plan.out[name].stride(0)) for name in names)
+        plan.optrs = (L.vp * L.PG_MAX_FIELDS)()
+        plan.ostr = (L.c_i32 * L.PG_MAX_FIELDS)()
+        for f, name in enumerate(self.dims):          # queue fields are in self.dims order
+            if name in plan.out:
+                plan.optrs[f] = plan.out[name].data_ptr()
+                plan.ostr[f] = plan.out[name].stride(0)
+        plan.cache_epoch = self._cache_epoch
+        return plan
+
+    def fetch_planned(self, plan, node_mapping, stream, slot=None):
+        """fetch_data for a plan: node_mapping = the NodeFlow's id tensor (device int64), rows
+        [plan.row_lo, plan.row_lo + plan.rows) of it are gathered into the plan's frames on `stream`."""
+        if plan.cache_epoch != self._cache_epoch:
+            raise L.PgError("fetch_planned: the cache changed after plan_fetch (re-plan after auto_cache)")
+        R = plan.rows
+        sp = ctypes.c_void_p(stream.cuda_stream)
+        ids = ctypes.c_void_p(node_mapping.data_ptr() + 8 * plan.row_lo)
+        if self.full_cached and not self.log:
+            L.check(self.lib.pg_gather_rows_full(ids, R, plan.fields, plan.n_fields, sp), "pg_gather_rows_full")
+            return
+        self._ensure_capacity(R)
+        if self.miss_mode == "async" and not self.full_cached:
+            if slot is None:
+                raise L.PgError("miss_mode='async' needs fetch_planned(..., slot=k)")
+            miss_pos, miss_fullid, miss_count = self._missq_buffers(slot, R)
+        else:
+            miss_pos, miss_fullid, miss_count = L.ptr(self._miss_pos), L.ptr(self._miss_fullid), L.ptr(self._miss_count)
+        timer = None
+        if self.profile is not None:
+            timer = L.vp()
+            L.check(self.lib.pg_timer_create(ctypes.byref(timer)), "pg_timer_create")
+        L.check(self.lib.pg_gather_rows(ids, R, L.ptr(self.slot_map), L.ptr(self.nid_map), plan.fields, plan.n_fields,
+                                        miss_pos, miss_fullid, miss_count, L.ptr(self._slots),
+                                        L.ptr(self._stats) if self.log else None, timer, sp), "pg_gather_rows")
+        if timer is not None:
+            self.profile.append([timer, R, None])
+        if self.full_cached:
+            return                       # every row was a hit (the general kernel ran only for the hit counters)
+        if self.miss_mode == "async":
+            L.check(self.lib.pg_missq_submit(self._missq, slot, plan.optrs, plan.ostr, sp), "pg_missq_submit")
+        else:
+            for name in plan.names:
+                tab = _table(self.graph, name)
+                o = plan.out[name]
+                L.check(self.lib.pg_scatter_rows_from_host(
+                    L.ptr(tab), tab.stride(0), L.ptr(self._miss_pos), L.ptr(self._miss_fullid), R,
+                    L.ptr(self._miss_count), self.dims[name], L.ptr(o), o.stride(0), sp), "pg_scatter_rows_from_host")
+
     def _missq_buffers(self, slot, rows):
+        hit = self._missq_bufs.get(slot)
+        if hit is not None and rows <= self._missq_rows:
+            return hit
         if self._missq is None or rows > self._missq_rows:
+            self._missq_bufs = {}
             if self._missq is not None:
                 L.check(self.lib.pg_missq_destroy(self._missq), "pg_missq_destroy")
             cap = max(int(rows * 1.25), 4096)
@@ -369,6 +453,7 @@ class GraphCacheServer:
         pos, full, cnt = L.vp(), L.vp(), L.vp()
         L.check(self.lib.pg_missq_slot_buffers(self._missq, slot, ctypes.byref(pos), ctypes.byref(full),
                                                ctypes.byref(cnt)), "pg_missq_slot_buffers")
+        self._missq_bufs[slot] = (pos, full, cnt)
         return pos, full, cnt
 
     def wait_misses(self, slot, stream=None, host_blocking=False):

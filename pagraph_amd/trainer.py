@@ -9,13 +9,18 @@ The host enqueues the compute of batch k first (asynchronous), then prepares bat
 k+1 — so the only host-blocking part (the staged miss path's wait for the miss list
 and its CPU row gather) runs while the GPU computes batch k.
 """
+import ctypes
 import time
 
 import torch
 
+from . import _lib as L
+from . import ops
+
 
 def _record_stream(nf, stream):
     ts = [nf._node_mapping.tousertensor()] + list(nf.blk_indptr) + list(nf.blk_src)
+    ts += [t for t in list(nf.blk_tptr) + list(nf.blk_tdst) + list(nf.blk_theavy) if t is not None]
     for fr in nf._node_frames:
         if fr:
             ts += list(fr.values())
@@ -31,7 +36,7 @@ class Prepared:
 class MinibatchTrainer:
     def __init__(self, model, loss_fcn, optimizer, cacher, sampler, labels, device, overlap=True, need=None):
         self.need = need             # fetch_data(need=...): None = every layer and field, like the reference
-        self.model, self.loss_fcn, self.optimizer = model, loss_fcn, optimizer
+        self.model, self.loss_fcn, self.optimizer = model, ops.fused_loss(loss_fcn), optimizer
         self.cacher, self.sampler, self.labels = cacher, sampler, labels
         self.device = device
         self.overlap = overlap
@@ -154,8 +159,13 @@ class GraphedTrainer:
     (shared) = optimizer.step().  Initial parameters are broadcast from rank 0 like DDP does."""
 
     def __init__(self, model, loss_fcn, optimizer, cacher, sampler, labels, device, warmup_eager=3, need=None,
-                 process_group=None, world_size=1):
+                 process_group=None, world_size=1, keep_losses=True):
         self.need = need
+        # True: compute() returns a private copy of the step's loss (one more launch per step). False: it
+        # returns the slot's static loss tensor, valid until that slot's graph is replayed again
+        # (len(sampler.slots) steps later) — enough for a trainer that prints the loss every N steps.
+        self.keep_losses = bool(keep_losses)
+        self._on_main = False            # run_steps made the compute stream current for the whole loop
         self.world = int(world_size)
         self.pg = process_group
         self.flat = None
@@ -171,7 +181,7 @@ class GraphedTrainer:
                 p.grad = self.flat[o:o + p.numel()].view_as(p)
                 o += p.numel()
         assert sampler.static, "GraphedTrainer needs NeighborSampler(static=True)"
-        self.model, self.loss_fcn, self.optimizer = model, loss_fcn, optimizer
+        self.model, self.loss_fcn, self.optimizer = model, ops.fused_loss(loss_fcn), optimizer
         self.cacher, self.sampler, self.labels = cacher, sampler, labels
         self.device = device
         # high priority: the short HBM-bound gather should not queue behind the compute stream's GEMMs
@@ -186,6 +196,8 @@ class GraphedTrainer:
         # must have finished batch k+1 (GPU publishes the miss list -> CPU gather -> copy enqueued) by the time
         # the host wants to enqueue compute(k+1), i.e. one whole step after it was submitted.
         self.lookahead = 2 if cacher.miss_mode == "async" else 1
+        self._lib = L.load()
+        self.labels = labels.to(device, torch.int64).contiguous()
         assert self.lookahead + 2 <= len(sampler.slots)   # prepared (+1 transient) + the sampler's own prefetch
         self._prepared = []
         self.slots = {}
@@ -195,6 +207,7 @@ class GraphedTrainer:
         self.after_first_step = None
         self._first_done = False
         self.last_loss = None
+        self._gseed = None
 
     class _Slot:
         pass
@@ -210,6 +223,8 @@ class GraphedTrainer:
         s.graph = None
         s.nf = None
         s.loss = None
+        s.plan = None
+        s.slot_index = None
         return s
 
     def prepare(self, nf):
@@ -217,33 +232,50 @@ class GraphedTrainer:
         if key not in self.slots:
             self.slots[key] = self._make_slot(nf)
         s = self.slots[key]
-        with torch.cuda.stream(self.load_stream):
-            dbg = getattr(self, "debug_events", None)
-            if dbg is not None:
-                ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-                ev[0].record(self.load_stream)
-            self.load_stream.wait_event(nf._slot.ready)  # the sampler wrote this NodeFlow on its own stream
-            if dbg is not None:
-                ev[1].record(self.load_stream)
-            if s.done_recorded:
-                self.load_stream.wait_event(s.done)      # the graph that read these buffers has finished
-            if dbg is not None:
-                ev[2].record(self.load_stream)
+        ls = self.load_stream
+        dbg = getattr(self, "debug_events", None)
+        if dbg is not None:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record(ls)
+        ls.wait_event(nf._slot.ready)            # the sampler wrote this NodeFlow on its own stream
+        if dbg is not None:
+            ev[1].record(ls)
+        if s.done_recorded:
+            ls.wait_event(s.done)                # the graph that read these buffers has finished
+        if dbg is not None:
+            ev[2].record(ls)
+        # no `with torch.cuda.stream(...)`, no tensor ops: everything below is a C-ABI call given the stream
+        # explicitly (the launch thread is the bottleneck of a ~0.2 ms step)
+        ids = nf._node_mapping.tousertensor()
+        if s.plan is None or (s.plan is not False and s.plan.cache_epoch != self.cacher._cache_epoch):
+            # first use of the slot, or the cache was (re)built since (auto_cache after the first step)
             s.slot_index = self.sampler.slots.index(nf._slot)
-            self.cacher.fetch_data(nf, out=s.out, need=self.need, slot=s.slot_index)
-            ids = nf.layer_parent_nid(-1)
-            lab = self.labels[ids.clamp(min=0)]
-            torch.where(ids >= 0, lab, torch.full_like(lab, -100), out=s.label)
-            s.ready.record(self.load_stream)
-            if dbg is not None:
-                ev[3].record(self.load_stream)
-                dbg.append(ev)
+            s.plan = self._plan_for(nf, s)
+        if s.plan is not False:
+            self.cacher.fetch_planned(s.plan, ids, ls, slot=s.slot_index)
+        else:
+            with torch.cuda.stream(ls):
+                self.cacher.fetch_data(nf, out=s.out, need=self.need, slot=s.slot_index)
+        o0, o1 = nf._layer_offsets[-2], nf._layer_offsets[-1]
+        sp = ctypes.c_void_p(ls.cuda_stream)
+        L.check(self._lib.pg_gather_labels(ctypes.c_void_p(ids.data_ptr() + 8 * o0), o1 - o0, L.ptr(self.labels),
+                                           self.labels.numel(), -100, L.ptr(s.label), sp), "pg_gather_labels")
+        s.ready.record(ls)
+        if dbg is not None:
+            ev[3].record(ls)
+            dbg.append(ev)
         # the static NodeFlow views of a slot are rebuilt per batch but alias the same memory:
         # keep the first one (the graph captured ITS tensors) and only refresh the frames
         if s.nf is None:
             s.nf = nf
         s.nf_cur = nf
         return s
+
+    def _plan_for(self, nf, s):
+        """fetch plan of this slot (False: the cacher's mode has no planned path)"""
+        if self.cacher.miss_mode == "staged" and not self.cacher.full_cached:
+            return False
+        return self.cacher.plan_fetch(nf._layer_offsets, s.out, self.need)
 
     def _step_body(self, s):
         for i in range(s.nf.num_layers):
@@ -252,11 +284,13 @@ class GraphedTrainer:
                                     if self.need is None or n in self.need.get(i, ())}
         pred = self.model(s.nf)
         loss = self.loss_fcn(pred, s.label)
+        if self._gseed is None:                 # persistent d loss / d loss: no ones_like fill (nor a divide) per step
+            self._gseed = torch.full_like(loss.detach(), 1.0 / self.world)
         if self.world > 1:
             self.flat.zero_()
-            (loss / self.world).backward()      # the SUM all-reduce then yields DDP's mean gradient
+            loss.backward(self._gseed)          # loss / world: the SUM all-reduce then yields DDP's mean gradient
         else:
-            loss.backward()
+            loss.backward(self._gseed)
             self.optimizer.step()
         return loss
 
@@ -279,26 +313,31 @@ class GraphedTrainer:
         main = self.compute_stream
         main.wait_event(s.ready)
         self.cacher.wait_misses(s.slot_index, main)
-        with torch.cuda.stream(main):
-            warm = self.steps_done < self.warmup_eager
-            if s.graph is not None:
-                s.graph.replay()
-            elif warm:
-                if self.world == 1:
-                    self.optimizer.zero_grad(set_to_none=True)
-                s.loss = self._step_body(s).detach()
-            else:
-                g = torch.cuda.CUDAGraph()
-                if self.world == 1:
-                    self.optimizer.zero_grad(set_to_none=True)
-                # thread_local: RCCL's watchdog thread may touch the runtime while this thread captures
-                with torch.cuda.graph(g, stream=main, capture_error_mode="thread_local"):
+        if s.graph is not None and self.world == 1 and self._on_main:
+            s.graph.replay()                                  # steady state: one launch
+            loss = s.loss.clone() if self.keep_losses else s.loss
+        else:
+            with torch.cuda.stream(main):
+                warm = self.steps_done < self.warmup_eager
+                if s.graph is not None:
+                    s.graph.replay()
+                elif warm:
+                    if self.world == 1:
+                        self.optimizer.zero_grad(set_to_none=True)
                     s.loss = self._step_body(s).detach()
-                s.graph = g
-                g.replay()                                   # capture does not execute
-            if self.world > 1:
-                self._sync_and_step(capture_ok=not warm)
-            loss = s.loss.clone()        # the slot's static loss tensor is overwritten 4 steps later
+                else:
+                    g = torch.cuda.CUDAGraph()
+                    if self.world == 1:
+                        self.optimizer.zero_grad(set_to_none=True)
+                    # thread_local: RCCL's watchdog thread may touch the runtime while this thread captures
+                    with torch.cuda.graph(g, stream=main, capture_error_mode="thread_local"):
+                        s.loss = self._step_body(s).detach()
+                    s.graph = g
+                    g.replay()                                   # capture does not execute
+                if self.world > 1:
+                    self._sync_and_step(capture_ok=not warm)
+                # the slot's static loss tensor is overwritten when its graph is replayed again
+                loss = s.loss.clone() if self.keep_losses else s.loss
         s.done.record(main)
         s.done_recorded = True
         # NOTE: the returned loss lives on the compute stream. No wait is queued on the caller's (default)
@@ -313,6 +352,18 @@ class GraphedTrainer:
         self.compute_stream.synchronize()
 
     def run_steps(self, it, steps=None):
+        # the compute stream is made current for the whole loop (a graph replays on the current stream;
+        # entering a stream context per step costs more launch-thread time than the replay itself)
+        prev = torch.cuda.current_stream(self.device)
+        torch.cuda.set_stream(self.compute_stream)
+        self._on_main = True
+        try:
+            return self._run_steps(it, steps)
+        finally:
+            self._on_main = False
+            torch.cuda.set_stream(prev)
+
+    def _run_steps(self, it, steps=None):
         done = 0
 
         def prepare_one():

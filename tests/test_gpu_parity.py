@@ -722,3 +722,247 @@ def test_server_preprocess_vs_scipy(dev, hiplib):
     has = deg > 0
     assert np.allclose(got[has], (want[has] * norm[has]).astype(np.float32), rtol=1e-5, atol=1e-5)
     assert np.all(np.isnan(got[~has]))                                   # 0 * inf, exactly what the reference computes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,C,ignored", [(6000, 60, 0), (6000, 60, 311), (1000, 41, 0), (777, 200, 50), (3, 5, 0), (1, 2, 0)])
+def test_loss_head_vs_oracle(dev, hiplib, oracle, n, C, ignored):
+    """pg_xent_fwd / pg_xent_bwd (the trainers' CrossEntropyLoss, pa_gcn.py:80) vs the float64 restatement and
+    vs torch's own op: loss and d loss / d logits within 1e-4; padded seeds (label -100) contribute nothing."""
+    from pagraph_amd import ops
+    g = torch.Generator().manual_seed(n * 31 + C)
+    logits = ((torch.rand((n, C), generator=g) - 0.5) * 8).to(dev).requires_grad_(True)
+    labels = torch.randint(0, C, (n,), generator=g)
+    if ignored:
+        labels[torch.randperm(n, generator=g)[:ignored]] = -100
+    labels = labels.to(dev)
+    loss = ops.cross_entropy(logits, labels)
+    assert "CrossEntropy" in type(loss.grad_fn).__name__
+    (loss * 3.0).backward()
+    ref_loss, ref_grad = oracle.cross_entropy(logits.detach().cpu().numpy(), labels.cpu().numpy())
+    assert abs(float(loss) - ref_loss) < TOL * max(1.0, abs(ref_loss))
+    assert np.abs(logits.grad.cpu().numpy() - 3.0 * ref_grad).max() < TOL * max(1e-3, np.abs(ref_grad).max() * 3)
+    lt = logits.detach().clone().requires_grad_(True)
+    tl = torch.nn.functional.cross_entropy(lt, labels)
+    (tl * 3.0).backward()
+    assert abs(float(tl) - float(loss)) < 1e-5 * max(1.0, abs(float(tl)))
+    assert float((lt.grad - logits.grad).abs().max()) < 1e-6
+    # deterministic: a second call gives the same bits
+    assert float(ops.cross_entropy(logits.detach(), labels)) == float(loss)
+    # the trainers swap a plain torch CrossEntropyLoss for the HIP head, and nothing else
+    assert isinstance(ops.fused_loss(torch.nn.CrossEntropyLoss()), ops.CrossEntropyLoss)
+    w = torch.nn.CrossEntropyLoss(reduction='sum')
+    assert ops.fused_loss(w) is w
+    # all rows ignored -> nan, like torch
+    assert torch.isnan(ops.cross_entropy(logits.detach(), torch.full_like(labels, -100)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_dst,n_src,deg,dim,reduce,p", [(500, 900, 2, 600, "mean", 0.5), (6000, 12000, 2, 64, "mean", 0.5),
+                                                           (300, 400, 4, 1100, "sum", 0.1), (64, 64, 3, 8, "mean", 0.9),
+                                                           (200, 300, 2, 2048, "mean", 0.25)])
+def test_spmm_with_fused_dropout_vs_oracle(dev, hiplib, oracle, n_dst, n_src, deg, dim, reduce, p):
+    """pg_spmm_fwd_drop / pg_spmm_bwd_drop = aggregate(dropout(h)): the keep-mask is BIT exact against the
+    oracle's restatement of the counter-based spec (pg_dropout_t), values within 1e-4; a new step draws a new
+    mask; threshold 0 is the plain aggregation."""
+    from pagraph_amd import ops
+    rng = np.random.default_rng(n_dst * 7 + dim)
+    seed, tag = 0x1234_5678_9ABC_DEF0, 3
+    step = torch.tensor([41], dtype=torch.int64, device=dev)
+    spec = ops.DropoutSpec(p, seed, tag, step)
+    assert spec.threshold == oracle.dropout_threshold(p)
+    # (1) the mask itself: identity block, h = 1, sum -> out = mask * scale exactly
+    n = 257
+    ident_ip = torch.arange(n + 1, dtype=torch.int32, device=dev)
+    ident_src = torch.arange(n, dtype=torch.int32, device=dev)
+    out = ops.block_aggregate(ident_ip, ident_src, torch.ones((n, dim), device=dev), n, "sum", dropout=spec)
+    keep, scale = oracle.dropout_mask(n, dim, spec.threshold, seed, tag, 41)
+    assert np.array_equal(out.cpu().numpy(), keep.astype(np.float32) * scale)
+    assert abs(keep.mean() - (1 - p)) < 0.02
+    # (2) random block, forward and backward
+    cnt = rng.integers(0, deg + 1, n_dst)
+    indptr = np.zeros(n_dst + 1, np.int32); indptr[1:] = np.cumsum(cnt)
+    src = rng.integers(0, n_src, int(indptr[-1])).astype(np.int32)
+    h = rng.standard_normal((n_src, dim)).astype(np.float32)
+    keep, scale = oracle.dropout_mask(n_src, dim, spec.threshold, seed, tag, 41)
+    hd = np.where(keep, h * scale, np.float32(0)).astype(np.float32)
+    want = oracle.spmm_fwd(indptr, src, hd, n_dst, reduce)
+    th = torch.from_numpy(h).to(dev).requires_grad_(True)
+    tip, tsr = torch.from_numpy(indptr).to(dev), torch.from_numpy(src).to(dev)
+    out = ops.block_aggregate(tip, tsr, th, n_dst, reduce, dropout=spec)
+    assert np.allclose(out.detach().cpu().numpy(), want, rtol=1e-6, atol=1e-6)
+    go = rng.standard_normal((n_dst, dim)).astype(np.float32)
+    out.backward(torch.from_numpy(go).to(dev))
+    want_g = oracle.spmm_bwd(indptr, src, go, n_src, reduce) * keep * scale
+    assert np.allclose(th.grad.cpu().numpy(), want_g, rtol=0, atol=TOL * max(1.0, float(scale)))
+    # (3) the step counter changes the mask; threshold 0 = no dropout
+    step.add_(1)
+    out2 = ops.block_aggregate(tip, tsr, th.detach(), n_dst, reduce, dropout=spec)
+    keep2, _ = oracle.dropout_mask(n_src, dim, spec.threshold, seed, tag, 42)
+    assert (keep2 != keep).mean() > 0.05
+    assert np.allclose(out2.cpu().numpy(), oracle.spmm_fwd(indptr, src, np.where(keep2, h * scale, np.float32(0)).astype(np.float32), n_dst, reduce), rtol=1e-6, atol=1e-6)
+    plain = ops.block_aggregate(tip, tsr, th.detach(), n_dst, reduce, dropout=ops.DropoutSpec(0.0, seed, tag, step))
+    assert np.array_equal(plain.cpu().numpy(), oracle.spmm_fwd(indptr, src, h, n_dst, reduce))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ["gcn", "sage"])
+def test_models_fold_dropout_into_aggregation(dev, hiplib, oracle, arch):
+    """training-mode forward with dropout: no nn.Dropout kernel runs on the aggregated inputs (the fused
+    path is taken), two consecutive forwards differ (step counter), eval mode is the deterministic forward,
+    and the result equals the same model with dropout applied OUTSIDE through the oracle's mask."""
+    from pagraph_amd import ops
+    from pagraph_amd.model import GCNSampling, GraphSageSampling
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    from pagraph_amd.data import synthetic as syn
+    V, E, B, Fd, C = 20000, 200000, 512, 64, 7
+    ip, ix = syn.rmat_graph(V, E, seed=5, device=dev)
+    g = DeviceGraph.from_csc(ip, ix, V)
+    torch.manual_seed(1234)
+    if arch == "gcn":
+        model = GCNSampling(Fd, 16, C, 1, torch.relu, 0.5).to(dev)
+    else:
+        model = GraphSageSampling(Fd, 16, C, 1, torch.relu, 0.5, 'mean').to(dev)
+    smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=False, num_hops=2,
+                          seed_nodes=torch.arange(4 * B, device=dev), prefetch=True, seed=3)
+    nf = next(iter(smp))
+    feats = syn.random_features_device(V, Fd, seed=9, device=dev)
+
+    def load():
+        for i in range(nf.num_layers):
+            nf.layers[i].data.clear()
+            nf.layers[i].data['features'] = feats[nf.layer_parent_nid(i)]
+
+    model.train()
+    calls = []
+    orig = torch.nn.Dropout.forward
+    torch.nn.Dropout.forward = lambda self, x: (calls.append(tuple(x.shape)), orig(self, x))[1]
+    try:
+        load(); y1 = model(nf)
+        load(); y2 = model(nf)
+    finally:
+        torch.nn.Dropout.forward = orig
+    assert calls == []                                   # nn.Dropout never ran: the aggregation applied it
+    assert int(model._drop_step) == 2
+    assert float((y1 - y2).abs().max()) > 1e-3
+    # the same forward with the fusion off and nn.Dropout replaced by the oracle's mask for step 3
+    step_now = 3
+    seed = model._drop_seed
+
+    class _OracleDrop(torch.nn.Dropout):
+        tags = []
+
+        def forward(self, x):
+            if not self.training:
+                return x
+            tag = _OracleDrop.tags.pop(0)
+            keep, scale = oracle.dropout_mask(x.size(0), x.size(1), oracle.dropout_threshold(self.p), seed, tag, step_now)
+            return x * torch.from_numpy(keep.astype(np.float32) * scale).to(x.device)
+
+    load(); y3 = model(nf)                               # fused, step 3
+    model.fuse_dropout = False
+    model.dropout = _OracleDrop(0.5)
+    _OracleDrop.tags = [0, 1] if arch == "gcn" else [0, 1, 17]      # (lid * 16 + i) call sites, in call order
+    load(); y4 = model(nf)
+    assert float((y3 - y4).abs().max()) < TOL * max(1.0, float(y4.abs().max()))
+    model.eval()
+    load(); e1 = model(nf)
+    load(); e2 = model(nf)
+    assert torch.equal(e1, e2)
+
+
+def _transpose_ref(indptr, src, n_src):
+    """source-major copy of a destination-major block: (tptr, tdst), destinations ascending per source"""
+    indptr = np.asarray(indptr, np.int64)
+    dst = np.repeat(np.arange(len(indptr) - 1), np.diff(indptr))
+    order = np.lexsort((dst, src))
+    tptr = np.zeros(n_src + 1, np.int64)
+    np.add.at(tptr, np.asarray(src, np.int64) + 1, 1)
+    return np.cumsum(tptr), dst[order]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("static", [False, True])
+def test_sampler_emits_source_major_blocks(dev, hiplib, static):
+    """sampler option `transpose`: blocks >= 1 (and on request block 0) also come out source-major, exactly the
+    stable transposition of the destination-major block; padded rows are empty"""
+    from pagraph_amd.data import synthetic as syn
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    V, E, B = 50000, 600000, 1000
+    ip, ix = syn.rmat_graph(V, E, seed=21, device=dev)
+    g = DeviceGraph.from_csc(ip, ix, V)
+    # 900 copies of one seed: its neighbours become hubs (what utils.py:34 does to isolated train vertices)
+    seeds = torch.cat([torch.arange(3 * B + 17 - 900), torch.full((900,), 12345)])
+    smp = NeighborSampler(g, B, 3, neighbor_type='in', shuffle=True, num_hops=3, seed_nodes=seeds,
+                          prefetch=True, seed=5, static=static, transpose=(0, 1, 2))
+    auto = NeighborSampler(g, B, 3, neighbor_type='in', num_hops=3, seed_nodes=torch.arange(B), static=static)
+    nfa = next(iter(auto))
+    assert nfa.blk_tptr[0] is None and nfa.blk_tptr[1] is not None and nfa.blk_tptr[2] is not None
+    seen = hubs = 0
+    for nf in smp:
+        torch.cuda.synchronize()
+        sizes, edges = nf.actual_sizes() if static else ([nf.layer_size(i) for i in range(4)], [nf.block_size(i) for i in range(3)])
+        for b in range(3):
+            ipb = nf.blk_indptr[b].cpu().numpy()[:sizes[b + 1] + 1]
+            srb = nf.blk_src[b].cpu().numpy()[:edges[b]]
+            tptr, tdst = _transpose_ref(ipb, srb, sizes[b])
+            got_p = nf.blk_tptr[b].cpu().numpy()
+            assert np.array_equal(got_p[:sizes[b] + 1], tptr)
+            assert np.all(got_p[sizes[b]:] == edges[b])                  # padding rows are empty
+            assert np.array_equal(nf.blk_tdst[b].cpu().numpy()[:edges[b]], tdst)
+            hv = nf.blk_theavy[b].cpu().numpy()
+            want_hv = np.nonzero(np.diff(tptr) > 32)[0]
+            assert hv[0] == len(want_hv) and np.array_equal(np.sort(hv[1:1 + hv[0]]), want_hv)
+            hubs += len(want_hv)
+        seen += 1
+    assert seen == 4 and hubs > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_dst,n_src,deg,dim,reduce,p", [(6000, 17000, 2, 64, "mean", 0.5), (6000, 17000, 2, 64, "mean", 0.0),
+                                                           (300, 200, 5, 33, "sum", 0.0), (500, 900, 3, 600, "mean", 0.25),
+                                                           (100, 4000, 2, 16, "sum", 0.5), (50, 60, 0, 32, "mean", 0.5),
+                                                           (6000, 9000, -2, 64, "mean", 0.5), (3000, 500, -3, 600, "sum", 0.0),
+                                                           (2000, 300, -2, 33, "mean", 0.0)])
+def test_spmm_backward_gather_form_vs_oracle(dev, hiplib, oracle, n_dst, n_src, deg, dim, reduce, p):
+    """pg_spmm_bwd_gather (no atomics, no zero fill) == the scatter-form gradient of the oracle, with and
+    without the folded dropout mask; two runs are bit-identical (fixed summation order)"""
+    from pagraph_amd import ops
+    rng = np.random.default_rng(n_dst + 3 * dim)
+    hubs = deg < 0                                  # negative degree: 15 % of the edges go to three hub sources
+    deg = abs(deg)
+    cnt = rng.integers(0, deg + 1, n_dst) if deg else np.zeros(n_dst, np.int64)
+    indptr = np.zeros(n_dst + 1, np.int32); indptr[1:] = np.cumsum(cnt)
+    src = rng.integers(0, n_src, int(indptr[-1])).astype(np.int32)
+    if hubs:
+        pick = rng.random(src.size) < 0.15
+        src[pick] = rng.choice(np.array([7, n_src - 1, n_src // 2], np.int32), int(pick.sum()))
+    tptr, tdst = _transpose_ref(indptr, src, n_src)
+    h = rng.standard_normal((n_src, dim)).astype(np.float32)
+    go = rng.standard_normal((n_dst, dim)).astype(np.float32)
+    step = torch.tensor([9], dtype=torch.int64, device=dev)
+    spec = ops.DropoutSpec(p, 77, 5, step) if p else None
+    tip, tsr = torch.from_numpy(indptr).to(dev), torch.from_numpy(src).to(dev)
+    heavy_rows = np.nonzero(np.diff(tptr) > 32)[0]
+    assert (len(heavy_rows) == 3) == hubs
+    heavy = np.zeros(1 + max(1, src.size // 32), np.int32)
+    heavy[0] = len(heavy_rows); heavy[1:1 + len(heavy_rows)] = heavy_rows[::-1]
+    tr = (torch.from_numpy(tptr.astype(np.int32)).to(dev), torch.from_numpy(tdst.astype(np.int32)).to(dev),
+          torch.from_numpy(heavy).to(dev))
+    grads = []
+    for _ in range(2):
+        th = torch.from_numpy(h).to(dev).requires_grad_(True)
+        out = ops.block_aggregate(tip, tsr, th, n_dst, reduce, dropout=spec, transpose=tr)
+        out.backward(torch.from_numpy(go).to(dev))
+        grads.append(th.grad.cpu().numpy())
+    want = oracle.spmm_bwd(indptr, src, go, n_src, reduce)
+    scale = 1.0
+    if p:
+        keep, scale = oracle.dropout_mask(n_src, dim, spec.threshold, 77, 5, 9)
+        want = want * keep * scale
+    assert np.allclose(grads[0], want, rtol=0, atol=TOL * max(1.0, float(scale)))
+    assert np.array_equal(grads[0], grads[1])
+    # and it agrees with the scatter form of the same library
+    th = torch.from_numpy(h).to(dev).requires_grad_(True)
+    ops.block_aggregate(tip, tsr, th, n_dst, reduce, dropout=spec).backward(torch.from_numpy(go).to(dev))
+    assert np.allclose(th.grad.cpu().numpy(), grads[0], rtol=0, atol=TOL * max(1.0, float(scale)))

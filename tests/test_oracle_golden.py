@@ -99,3 +99,28 @@ def test_g6_closure(oracle, path):
     assert np.array_equal(sub2full, z["sub2full"])
     assert np.array_equal(subtrain, z["subtrainid"])
     assert np.array_equal(ip, z["sub_indptr"]) and np.array_equal(ix, z["sub_indices"])
+
+
+def test_vectorised_philox_matches_the_scalar_one(oracle):
+    rng = np.random.default_rng(0)
+    c = rng.integers(0, 2 ** 32, (50, 4), dtype=np.uint64)
+    k = (0xDEADBEEF, 0x12345678)
+    got = oracle.philox4x32_10_np(c[:, 0], c[:, 1], c[:, 2], c[:, 3], *k)
+    for i in range(50):
+        assert [int(g[i]) for g in got] == oracle.philox4x32_10(c[i], k)
+
+
+def test_dropout_mask_spec(oracle):
+    """keep rate, determinism, and that every (row, column) gets its own 16 bits"""
+    keep, scale = oracle.dropout_mask(200, 600, oracle.dropout_threshold(0.5), 7, 1, 5)
+    assert keep.shape == (200, 600) and abs(keep.mean() - 0.5) < 0.01 and scale == np.float32(2.0)
+    again, _ = oracle.dropout_mask(200, 600, oracle.dropout_threshold(0.5), 7, 1, 5)
+    assert np.array_equal(keep, again)
+    other, _ = oracle.dropout_mask(200, 600, oracle.dropout_threshold(0.5), 7, 1, 6)
+    assert 0.4 < (keep != other).mean() < 0.6
+    cols = keep.astype(np.float64) - keep.mean()
+    corr = (cols.T @ cols) / 200
+    off = corr - np.diag(np.diag(corr))
+    assert np.abs(off).max() < 0.12           # no two columns share their bits
+    k1, s1 = oracle.dropout_mask(50, 64, oracle.dropout_threshold(0.1), 7, 1, 5)
+    assert abs(k1.mean() - 0.9) < 0.03 and abs(float(s1) - 1 / 0.9) < 1e-3

@@ -1,0 +1,23 @@
+"""kernel sequence of one replayed step on the busiest queue, durations averaged over the steps that have
+the modal kernel count.  usage: trace_seq.py <rocprofv3 kernel_trace.csv>"""
+import csv, sys
+from collections import Counter
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+cq = Counter(r["Queue_Id"] for r in rows if "k_wait_landed" in r["Kernel_Name"] or "k_linear_fwd" in r["Kernel_Name"]).most_common(1)[0][0]
+q = [r for r in rows if r["Queue_Id"] == cq]
+mark = "k_wait_landed" if any("k_wait_landed" in r["Kernel_Name"] for r in q) else "k_linear_fwd"
+idx = [i for i, r in enumerate(q) if mark in r["Kernel_Name"]]
+steps = [q[a:b] for a, b in zip(idx[:-1], idx[1:])]
+L = Counter(len(s) for s in steps).most_common(1)[0][0]
+steps = [s for s in steps if len(s) == L][5:]
+tot = 0.0
+for pos in range(L):
+    n = steps[0][pos]["Kernel_Name"]
+    d = sum(int(s[pos]["End_Timestamp"]) - int(s[pos]["Start_Timestamp"]) for s in steps) / len(steps) / 1e3
+    tot += d
+    for k in ("FillFunctor", "fused_dropout", "multi_tensor_apply", "nll_loss", "softmax", "Cijk", "masked_scale", "elementwise_kernel", "reduce_kernel", "CatArray"):
+        if k in n: n = k + " :: " + n[n.find("<"):][:60]; break
+    print(f"{d:7.1f} us  {n[:110]}")
+span = sum(int(s[-1]["End_Timestamp"]) - int(s[0]["Start_Timestamp"]) for s in steps) / len(steps) / 1e3
+print(f"sum {tot:.1f} us, first-start..last-end {span:.1f} us, over {len(steps)} steps of {L} kernels")
