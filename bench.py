@@ -77,6 +77,8 @@ def parse():
     p.add_argument("--ring", type=int, default=None, help="sampler ring slots (in-flight minibatches)")
     p.add_argument("--no-graph", action="store_true", help="eager reference-style loop instead of hipGraph replay")
     p.add_argument("--timeline", action="store_true", help="print a per-stream event timeline of a few steps (stderr)")
+    p.add_argument("--lookahead", type=int, default=None, help="batches prepared ahead of the one being computed "
+                   "(default 2 with the async miss queue, else 1); the sampler ring needs lookahead + 2 slots")
     p.add_argument("--profile-host", action="store_true", help="cProfile the timed region (stderr)")
     p.add_argument("--dist-backend", default="nccl", help="gloo lets two ranks share one GPU (testing only)")
     return p.parse_args()
@@ -362,13 +364,13 @@ def run():
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu])
     sampler = NeighborSampler(g, B, k, neighbor_type='in', shuffle=True, num_workers=16, num_hops=num_hops,
                               seed_nodes=subtrain, prefetch=True, seed=rank, copy_out=True, static=use_graph,
-                              ring=args.ring)
+                              ring=args.ring if args.ring else (args.lookahead + 2 if args.lookahead else None))
     steps_per_epoch = parallel.equalize_steps(len(sampler), device=dev)
     K = args.steps if args.steps is not None else 400
     W = args.warmup
     if use_graph:
         trainer = GraphedTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, need=need, world_size=world,
-                                 keep_losses=False)
+                                 keep_losses=False, lookahead=args.lookahead)
         W = max(W, 3 + 2 * len(sampler.slots))           # eager warm-up + one capture per ring slot, all untimed
     else:
         trainer = MinibatchTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, overlap=not args.no_overlap,

@@ -272,11 +272,16 @@ int pg_spmm_bwd_gather(const int32_t* tptr, const int32_t* tdst, const int32_t* 
 
 /* Skinny dense step of the first layer — NodeUpdate.forward at PaGraph/model/gcn_nssc.py:18-23 and
  * graphsage_nssc.py:24-29 — on fp32 MFMA: Z = X[n,K] * W^T + bias with W = nn.Linear's weight [N,K],
- * N <= 32, K % 8 == 0, X / W 16-byte aligned, x_stride % 4 == 0. The epilogue applies NodeUpdate's
+ * N <= 64, K % 8 == 0, X / W 16-byte aligned, x_stride % 4 == 0. The epilogue applies NodeUpdate's
  * activation: act 0: Y = Z; 1: Y = relu(Z); 2: Y = [Z | relu(Z)] (2N columns, the skip connection).
  * Returns PG_ERR_UNSUPPORTED outside that envelope (callers then use the library GEMM).            */
 int pg_linear_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, float* Y,
                   int32_t y_stride, int64_t n, int32_t K, int32_t N, int32_t act, pg_stream_t stream);
+/* GraphSAGE's NodeUpdate, `fc_self(h) + fc_neigh(neigh)` then the activation (graphsage_nssc.py:24-29), in one
+ * pass: Z = X W^T + bias + X2 W2^T + bias2 (W [N,K], W2 [N,K2]; same envelope for both operand pairs).      */
+int pg_linear2_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, int32_t K,
+                   const float* X2, int32_t x2_stride, const float* W2, const float* bias2, int32_t K2,
+                   float* Y, int32_t y_stride, int64_t n, int32_t N, int32_t act, pg_stream_t stream);
 /* dW[N,K] = dZ^T X and (db != NULL) db[N] = column sums of dZ, any N and K, where dZ is derived from
  * G = dL/dY and the saved output Yout according to `act` (act 0: dZ = G, Yout may be NULL). dW (contiguous)
  * and db are overwritten. dz_scratch: device fp32 [n, N], required when act != 0; it holds dZ afterwards

@@ -1,5 +1,5 @@
-// Skinny dense step of the first GNN layer: Y[n, N] = X[n, K] · Wᵀ + b with N <= 32
-// (hidden 32 for GCN, 16 for GraphSAGE; pa_gcn.py:130, pa_gs.py:134) and K = feature size —
+// Skinny dense step of the GNN layers: Y[n, N] = X[n, K] · Wᵀ + b with N <= 64
+// (hidden 32 for GCN, 16 for GraphSAGE, 41-60 classes; pa_gcn.py:130, pa_gs.py:134) and K = feature size —
 // NodeUpdate.forward's nn.Linear (PaGraph/model/gcn_nssc.py:18, graphsage_nssc.py:24).
 //
 // This is the one place the path uses the matrix cores (north star: "MFMA only for the dense
@@ -34,28 +34,43 @@ constexpr int kTile = 32;
 
 // act: 0 = none, 1 = relu, 2 = concat(z, relu(z)) -> Y has 2N columns (NodeUpdate's skip connection,
 // gcn_nssc.py:20-21). W is the nn.Linear weight as stored: [N, K] row-major.
+// Optional second operand pair (X2, W2, bias2): Z = X W^T + X2 W2^T + bias + bias2 — GraphSAGE's NodeUpdate
+// `fc_self(h) + fc_neigh(neigh)` (graphsage_nssc.py:24) in one pass, the K range being the concatenation.
+// blockIdx.y selects the 32-column tile of N (N <= 64 needs two).
 __global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ X, int32_t x_stride,
                                                     const float* __restrict__ W /* [N][K] */,
                                                     const float* __restrict__ bias /* [N] or null */,
+                                                    const float* __restrict__ X2, int32_t x2_stride,
+                                                    const float* __restrict__ W2 /* [N][K2] */,
+                                                    const float* __restrict__ bias2, int32_t K2,
                                                     float* __restrict__ Y, int32_t y_stride, int64_t n, int32_t K,
                                                     int32_t N, int32_t act) {
   __shared__ float red[4][kTile][kTile + 1];
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
   const int64_t r0 = (int64_t)blockIdx.x * kTile;
+  const int n0 = (int)blockIdx.y * kTile;             // first output column of this block
   const int64_t row = r0 + (lane & 31);
   const int half = lane >> 5;
-  const int octets = K / 8;
+  const int oct1 = K / 8, octets = oct1 + K2 / 8;
   const int o_beg = (octets * w) / 4, o_end = (octets * (w + 1)) / 4;
   const bool row_ok = row < n;
-  const bool col_ok = (lane & 31) < N;
+  const int col = n0 + (lane & 31);
+  const bool col_ok = col < N;
   const float* xr = X + (row_ok ? row : 0) * x_stride + 4 * half;
   // B operand: lane (col, half) needs W[col][kk + 4*half + j], j = 0..3 -> one 16-byte load per octet
-  const float* wr = W + (int64_t)(col_ok ? (lane & 31) : 0) * K + 4 * half;
+  const float* wr = W + (int64_t)(col_ok ? col : 0) * K + 4 * half;
+  const float* xr2 = X2 ? X2 + (row_ok ? row : 0) * x2_stride + 4 * half : nullptr;
+  const float* wr2 = W2 ? W2 + (int64_t)(col_ok ? col : 0) * K2 + 4 * half : nullptr;
   f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int o = o_beg; o < o_end; ++o) {
-    const int kk = o * 8;
-    df4 a = *reinterpret_cast<const df4*>(xr + kk);
-    df4 b = *reinterpret_cast<const df4*>(wr + kk);
+    df4 a, b;
+    if (o < oct1) {
+      a = *reinterpret_cast<const df4*>(xr + o * 8);
+      b = *reinterpret_cast<const df4*>(wr + o * 8);
+    } else {
+      a = *reinterpret_cast<const df4*>(xr2 + (o - oct1) * 8);
+      b = *reinterpret_cast<const df4*>(wr2 + (o - oct1) * 8);
+    }
     if (!row_ok) a = df4{0.f, 0.f, 0.f, 0.f};
     if (!col_ok) b = df4{0.f, 0.f, 0.f, 0.f};
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
@@ -74,10 +89,11 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ X,
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       v[j] = red[0][orow][oc + j] + red[1][orow][oc + j] + red[2][orow][oc + j] + red[3][orow][oc + j];
-      if (bias && oc + j < N) v[j] += bias[oc + j];
+      if (bias && n0 + oc + j < N) v[j] += bias[n0 + oc + j];
+      if (bias2 && n0 + oc + j < N) v[j] += bias2[n0 + oc + j];
     }
-    float* yr = Y + (r0 + orow) * y_stride + oc;
-    const bool vec_ok = (N & 3) == 0 && (y_stride & 3) == 0 && oc + 3 < N;
+    float* yr = Y + (r0 + orow) * y_stride + n0 + oc;
+    const bool vec_ok = (N & 3) == 0 && (y_stride & 3) == 0 && n0 + oc + 3 < N;
     if (act == 1) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
@@ -90,14 +106,13 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ X,
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (oc + j < N) {
+        if (n0 + oc + j < N) {
           yr[j] = v[j];
           if (act == 2) yr[N + j] = v[j] > 0.f ? v[j] : 0.f;
         }
     }
   }
 }
-
 
 // gradient of the pre-activation z w.r.t. the loss, from the gradient G of the (activated) output and the
 // saved output Yout: act 0: G; act 1 (relu): G * (Yout > 0); act 2 (concat): G[:, :N] + G[:, N:] * (Yout[:, :N] > 0)
@@ -244,18 +259,36 @@ using namespace pg;
 
 extern "C" {
 
-int pg_linear_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, float* Y, int32_t y_stride,
-                  int64_t n, int32_t K, int32_t N, int32_t act, pg_stream_t stream) {
-  if (n < 0 || K <= 0 || N <= 0 || x_stride < K || act < 0 || act > 2 || y_stride < (act == 2 ? 2 * N : N))
+static int linear_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, const float* X2,
+                      int32_t x2_stride, const float* W2, const float* bias2, int32_t K2, float* Y, int32_t y_stride,
+                      int64_t n, int32_t K, int32_t N, int32_t act, pg_stream_t stream) {
+  if (n < 0 || K <= 0 || N <= 0 || K2 < 0 || x_stride < K || act < 0 || act > 2 || y_stride < (act == 2 ? 2 * N : N))
     return PG_ERR_INVALID;
-  if (N > kTile || (K & 7) || (x_stride & 3)) return PG_ERR_UNSUPPORTED;
+  if (K2 > 0 && (!X2 || !W2 || x2_stride < K2)) return PG_ERR_INVALID;
+  if (N > 2 * kTile || (K & 7) || (x_stride & 3) || (K2 & 7) || (K2 > 0 && (x2_stride & 3))) return PG_ERR_UNSUPPORTED;
   if (n == 0) return PG_OK;
   if (!X || !W || !Y) return PG_ERR_INVALID;
   if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return PG_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_linear_fwd, dim3((unsigned)ceil_div<int64_t>(n, kTile)), dim3(256), 0, as_stream(stream), X,
-                     x_stride, W, bias, Y, y_stride, n, K, N, act);
+  if (K2 > 0 && ((reinterpret_cast<uintptr_t>(X2) & 15) || (reinterpret_cast<uintptr_t>(W2) & 15)))
+    return PG_ERR_UNSUPPORTED;
+  if (K2 == 0) X2 = W2 = bias2 = nullptr;
+  hipLaunchKernelGGL(k_linear_fwd, dim3((unsigned)ceil_div<int64_t>(n, kTile), (unsigned)ceil_div<int>(N, kTile)),
+                     dim3(256), 0, as_stream(stream), X, x_stride, W, bias, X2, x2_stride, W2, bias2, K2, Y, y_stride, n,
+                     K, N, act);
   PG_LAUNCH_CHECK();
   return PG_OK;
+}
+
+int pg_linear_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, float* Y, int32_t y_stride,
+                  int64_t n, int32_t K, int32_t N, int32_t act, pg_stream_t stream) {
+  return linear_fwd(X, x_stride, W, bias, nullptr, 0, nullptr, nullptr, 0, Y, y_stride, n, K, N, act, stream);
+}
+
+int pg_linear2_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, int32_t K, const float* X2,
+                   int32_t x2_stride, const float* W2, const float* bias2, int32_t K2, float* Y, int32_t y_stride,
+                   int64_t n, int32_t N, int32_t act, pg_stream_t stream) {
+  if (K2 <= 0) return PG_ERR_INVALID;
+  return linear_fwd(X, x_stride, W, bias, X2, x2_stride, W2, bias2, K2, Y, y_stride, n, K, N, act, stream);
 }
 
 int64_t pg_linear_bwd_w_scratch(int64_t n, int32_t K, int32_t N) {

@@ -25,11 +25,17 @@ class NodeUpdate(nn.Module):
         nn.init.xavier_uniform_(self.fc_self.weight, gain=gain)
 
     def forward(self, node):
-        h = ops.linear(node.data['h'], self.fc_self) + ops.linear(node.data['neigh'], self.fc_neigh)
-        if self.concat:
-            h = torch.cat((h, self.activation(h)), dim=1)
-        elif self.activation:
-            h = self.activation(h)
+        relu = self.activation in (torch.relu, torch.nn.functional.relu)
+        if self.concat and relu:                 # both GEMMs, the add and the skip-concat in one kernel
+            h = ops.linear2(node.data['h'], self.fc_self, node.data['neigh'], self.fc_neigh, ops.ACT_CONCAT)
+        elif relu:
+            h = ops.linear2(node.data['h'], self.fc_self, node.data['neigh'], self.fc_neigh, ops.ACT_RELU)
+        else:
+            h = ops.linear2(node.data['h'], self.fc_self, node.data['neigh'], self.fc_neigh)
+            if self.concat:
+                h = torch.cat((h, self.activation(h)), dim=1)
+            elif self.activation:
+                h = self.activation(h)
         return {'activation': h}
 
 

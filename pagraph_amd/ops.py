@@ -107,7 +107,7 @@ def _apply_act(z, act):
 
 class _SkinnyLinear(torch.autograd.Function):
     """NodeUpdate's dense step y = act(x @ W.T + b) with the tall-skinny pieces on the fp32-MFMA kernels
-    of pg_dense.hip: forward (bias + activation / skip-concat fused in the epilogue) when out_features <= 32
+    of pg_dense.hip: forward (bias + activation / skip-concat fused in the epilogue) when out_features <= 64
     and K % 8 == 0; weight / bias gradient (a reduction over all rows into a tiny [N, K] matrix, the
     activation's derivative applied on the fly) always."""
 
@@ -116,7 +116,7 @@ class _SkinnyLinear(torch.autograd.Function):
         lib = L.load()
         n, K = x.shape
         N = weight.size(0)
-        if (N <= 32 and K % 8 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and weight.is_contiguous()
+        if (N <= 64 and K % 8 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and weight.is_contiguous()
                 and weight.data_ptr() % 16 == 0):
             y = torch.empty((n, 2 * N if act == ACT_CONCAT else N), dtype=torch.float32, device=x.device)
             with torch.cuda.device(x.device):
@@ -155,6 +155,70 @@ class _SkinnyLinear(torch.autograd.Function):
                 gz = gy * (y > 0) if act == ACT_RELU else gy[:, :N] + gy[:, N:] * (y[:, :N] > 0)
             gx = gz @ weight
         return gx, gw, gb, None
+
+
+def _bwd_w(lib, g, x, K, N, y, act, want_bias):
+    """(dW [N, K], db [N] or None, dZ) through pg_linear_bwd_w"""
+    buf = torch.empty(N * K + N, dtype=torch.float32, device=x.device)
+    part = torch.empty(lib.pg_linear_bwd_w_scratch(x.size(0), K, N), dtype=torch.float32, device=x.device)
+    gw = buf[:N * K].view(N, K)
+    gb = buf[N * K:] if want_bias else None
+    dz = torch.empty((x.size(0), N), dtype=torch.float32, device=x.device) if act != ACT_NONE else None
+    with torch.cuda.device(x.device):
+        L.check(lib.pg_linear_bwd_w(L.ptr(g), g.stride(0), L.ptr(x), x.stride(0), x.size(0), K, N, L.ptr(gw), L.ptr(gb),
+                                    L.ptr(y), y.stride(0) if y is not None else 0, act, L.ptr(dz), L.ptr(part),
+                                    L.stream_ptr()), "pg_linear_bwd_w")
+    return gw, gb, (dz if dz is not None else g)
+
+
+class _DualLinear(torch.autograd.Function):
+    """GraphSAGE's NodeUpdate dense step y = act(x1 @ W1.T + b1 + x2 @ W2.T + b2) (graphsage_nssc.py:24-29) in
+    one MFMA pass (pg_linear2_fwd) instead of two GEMMs, an add, and the activation / concat kernels; the
+    backward derives dZ once and runs the weight-gradient kernel per operand."""
+
+    @staticmethod
+    def forward(ctx, x1, w1, b1, x2, w2, b2, act):
+        lib = L.load()
+        n, K1 = x1.shape
+        K2 = x2.size(1)
+        N = w1.size(0)
+        y = torch.empty((n, 2 * N if act == ACT_CONCAT else N), dtype=torch.float32, device=x1.device)
+        with torch.cuda.device(x1.device):
+            L.check(lib.pg_linear2_fwd(L.ptr(x1), x1.stride(0), L.ptr(w1), L.ptr(b1), K1, L.ptr(x2), x2.stride(0),
+                                       L.ptr(w2), L.ptr(b2), K2, L.ptr(y), y.stride(0), n, N, act, L.stream_ptr()),
+                    "pg_linear2_fwd")
+        ctx.save_for_backward(x1, w1, x2, w2, y if act != ACT_NONE else None)
+        ctx.bias = (b1 is not None, b2 is not None)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x1, w1, x2, w2, y = ctx.saved_tensors
+        lib = L.load()
+        gy = gy.contiguous()
+        N = w1.size(0)
+        need = ctx.needs_input_grad
+        gw1, gb1, dz = _bwd_w(lib, gy, x1, w1.size(1), N, y, ctx.act, ctx.bias[0])
+        gw2, gb2, _ = _bwd_w(lib, dz, x2, w2.size(1), N, None, ACT_NONE, ctx.bias[1])
+        gx1 = dz @ w1 if need[0] else None
+        gx2 = dz @ w2 if need[3] else None
+        return gx1, gw1, gb1, gx2, gw2, gb2, None
+
+
+def _skinny_ok(x, w):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and w.size(0) <= 64 and x.size(0) >= 1024
+            and x.stride(1) == 1 and w.size(1) % 8 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+            and w.is_contiguous() and w.data_ptr() % 16 == 0)
+
+
+def linear2(x1, mod1, x2, mod2, act=ACT_NONE):
+    """act(mod1(x1) + mod2(x2)) — GraphSAGE's NodeUpdate — on one MFMA pass when both operands fit the
+    skinny envelope, else through the modules"""
+    if x1.size(0) == x2.size(0) and mod1.weight.size(0) == mod2.weight.size(0) and _skinny_ok(x1, mod1.weight) \
+            and _skinny_ok(x2, mod2.weight):
+        return _DualLinear.apply(x1, mod1.weight, mod1.bias, x2, mod2.weight, mod2.bias, act)
+    return _apply_act(linear(x1, mod1) + linear(x2, mod2), act)
 
 
 def linear(x, module, act=ACT_NONE):

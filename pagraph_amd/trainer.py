@@ -159,7 +159,7 @@ class GraphedTrainer:
     (shared) = optimizer.step().  Initial parameters are broadcast from rank 0 like DDP does."""
 
     def __init__(self, model, loss_fcn, optimizer, cacher, sampler, labels, device, warmup_eager=3, need=None,
-                 process_group=None, world_size=1, keep_losses=True):
+                 process_group=None, world_size=1, keep_losses=True, lookahead=None):
         self.need = need
         # True: compute() returns a private copy of the step's loss (one more launch per step). False: it
         # returns the slot's static loss tensor, valid until that slot's graph is replayed again
@@ -195,7 +195,7 @@ class GraphedTrainer:
         # batches prepared ahead of the one being computed. The async miss path needs 2: its worker thread
         # must have finished batch k+1 (GPU publishes the miss list -> CPU gather -> copy enqueued) by the time
         # the host wants to enqueue compute(k+1), i.e. one whole step after it was submitted.
-        self.lookahead = 2 if cacher.miss_mode == "async" else 1
+        self.lookahead = int(lookahead) if lookahead else (2 if cacher.miss_mode == "async" else 1)
         self._lib = L.load()
         self.labels = labels.to(device, torch.int64).contiguous()
         assert self.lookahead + 2 <= len(sampler.slots)   # prepared (+1 transient) + the sampler's own prefetch

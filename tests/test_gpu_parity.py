@@ -966,3 +966,35 @@ def test_spmm_backward_gather_form_vs_oracle(dev, hiplib, oracle, n_dst, n_src, 
     th = torch.from_numpy(h).to(dev).requires_grad_(True)
     ops.block_aggregate(tip, tsr, th, n_dst, reduce, dropout=spec).backward(torch.from_numpy(go).to(dev))
     assert np.allclose(th.grad.cpu().numpy(), grads[0], rtol=0, atol=TOL * max(1.0, float(scale)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,K1,K2,N,act", [(17000, 600, 600, 16, 2), (6000, 32, 32, 60, 0), (5000, 600, 64, 32, 1),
+                                           (2049, 8, 600, 41, 0), (4096, 64, 64, 64, 2)])
+def test_dual_linear_vs_torch(dev, hiplib, n, K1, K2, N, act):
+    """pg_linear2_fwd (GraphSAGE NodeUpdate: fc_self(h) + fc_neigh(neigh), activation / skip-concat fused) and
+    its backward vs float64 torch: output, both weight / bias gradients and both input gradients within 1e-4"""
+    from pagraph_amd import ops
+    torch.manual_seed(n + K1 + N)
+    l1, l2 = torch.nn.Linear(K1, N).to(dev), torch.nn.Linear(K2, N).to(dev)
+    x1 = (torch.rand((n, K1), device=dev) - 0.4).requires_grad_(True)
+    x2 = (torch.rand((n, K2), device=dev) - 0.6).requires_grad_(True)
+    y = ops.linear2(x1, l1, x2, l2, act)
+    assert "DualLinear" in type(y.grad_fn).__name__
+    d1, d2 = x1.detach().double().requires_grad_(True), x2.detach().double().requires_grad_(True)
+    w1, w2 = l1.weight.detach().double().requires_grad_(True), l2.weight.detach().double().requires_grad_(True)
+    b1, b2 = l1.bias.detach().double().requires_grad_(True), l2.bias.detach().double().requires_grad_(True)
+    z = torch.nn.functional.linear(d1, w1, b1) + torch.nn.functional.linear(d2, w2, b2)
+    ref = z if act == 0 else torch.relu(z) if act == 1 else torch.cat((z, torch.relu(z)), 1)
+    scale = max(1.0, float(ref.abs().max()))
+    assert y.shape == ref.shape and float((y.double() - ref).abs().max()) < TOL * scale
+    g = torch.rand_like(y) - 0.5
+    y.backward(g)
+    ref.backward(g.double())
+    for got, want in ((l1.weight.grad, w1.grad), (l2.weight.grad, w2.grad), (l1.bias.grad, b1.grad), (l2.bias.grad, b2.grad),
+                      (x1.grad, d1.grad), (x2.grad, d2.grad)):
+        assert float((got.double() - want).abs().max()) < TOL * max(1.0, float(want.abs().max()))
+    # small inputs go through the modules
+    ys = ops.linear2(x1[:100], l1, x2[:100], l2, act)
+    assert "DualLinear" not in type(ys.grad_fn).__name__
+    assert float((ys.double() - ref[:100]).abs().max()) < TOL * scale
