@@ -358,7 +358,11 @@ def run():
     model = model.to(dev)
     loss_fcn = torch.nn.CrossEntropyLoss()
     use_graph = not args.no_graph
-    optimizer = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=0, capturable=use_graph, fused=True)
+    if use_graph:
+        from pagraph_amd.optim import Adam                    # torch.optim.Adam's arithmetic in one launch
+        optimizer = Adam(model.parameters(), lr=lr, weight_decay=0)
+    else:
+        optimizer = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=0, fused=True)
     need = None if args.fetch_all else model.required_inputs(num_hops + 1)
     if world > 1 and not use_graph:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu])

@@ -64,8 +64,11 @@ def trainer(rank, world_size, args, arch, backend='nccl'):
                                   'mean', args.preprocess)
     loss_fcn = torch.nn.CrossEntropyLoss()
     model.cuda(rank)
-    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay,
-                                 capturable=args.graph, fused=True)
+    if args.graph:
+        from pagraph_amd.optim import Adam                    # torch.optim.Adam's arithmetic, one launch per step
+        optimizer = Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+    else:
+        optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay, fused=True)
     need = model.required_inputs(num_hops + 1) if args.fetch_needed else None
     if not args.graph:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[rank])

@@ -305,6 +305,17 @@ int pg_xent_fwd(const float* logits, int32_t stride, const int64_t* labels, int6
 int pg_xent_bwd(const float* dlogits, int32_t d_stride, int64_t n, int32_t C, const float* meta,
                 const float* grad_out, float* gx, int32_t gx_stride, pg_stream_t stream);
 
+/* Optimiser step — torch.optim.Adam(model.parameters(), lr, weight_decay) of examples/profile/pa_gcn.py:137-139
+ * (amsgrad off, maximize off), same arithmetic as torch's: g += wd * p; m = b1 m + (1 - b1) g;
+ * v = b2 v + (1 - b2) g^2; p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps), t = *step_dev + 1.
+ * One launch for up to PG_ADAM_MAX_TENSORS fp32 tensors (host arrays of device pointers + element counts).
+ * *step_dev (device int64, completed steps) is advanced by the kernel; ticket_dev is one device uint32 the
+ * caller zeroes once.                                                                                 */
+#define PG_ADAM_MAX_TENSORS 16
+int pg_adam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                 float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int64_t* step_dev, uint32_t* ticket_dev, pg_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * 4. Offline partitioning (host)  —  PaGraph/partition/dg.py:59-103
  * ------------------------------------------------------------------------

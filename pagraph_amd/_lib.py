@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libpagraph_hip.so")
 PG_MAX_FIELDS = 4
 PG_MAX_LAYERS = 8
 PG_HEAVY_ROW = 32
+PG_ADAM_MAX_TENSORS = 16
 PG_REDUCE_MEAN = 0
 PG_REDUCE_SUM = 1
 
@@ -87,6 +88,8 @@ _SIGS = {
     "pg_linear_bwd_w": (ctypes.c_int, [vp, c_i32, vp, c_i32, c_i64, c_i32, c_i32, vp, vp, vp, c_i32, c_i32, vp, vp, vp]),
     "pg_xent_fwd": (ctypes.c_int, [vp, c_i32, vp, c_i64, c_i32, c_i64, vp, c_i32, vp, vp, vp]),
     "pg_xent_bwd": (ctypes.c_int, [vp, c_i32, c_i64, c_i32, vp, vp, vp, c_i32, vp]),
+    "pg_adam_step": (ctypes.c_int, [c_i32, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                    ctypes.c_float, ctypes.c_float, vp, vp, vp]),
     "pg_dg_partition": (ctypes.c_int, [c_i64, vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp]),
     "pg_rmat_edges": (ctypes.c_int, [c_u64, c_i32, c_u32, c_u32, c_u32, c_i64, c_i64, vp, vp, vp]),
     "pg_random_features": (ctypes.c_int, [c_u64, c_i64, c_i64, c_i32, vp, c_i64, vp]),

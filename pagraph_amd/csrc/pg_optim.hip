@@ -1,0 +1,92 @@
+// Adam step of the trainer scripts (examples/profile/pa_gcn.py:137-139: torch.optim.Adam(model.parameters(),
+// lr, weight_decay)) for the handful of small parameter tensors of the sampled GCN / GraphSAGE models
+// (23 K - 40 K scalars in 4 - 8 tensors).  torch's capturable fused Adam spends two launches on it
+// (per-tensor step counters += 1, then a multi-tensor kernel that gives each 65536-element chunk to ONE
+// block: 4 blocks for these models, 15 us); here one launch spreads the elements over ~100 blocks and keeps
+// ONE step counter on the device, bumped by the last block to finish (so that a replayed hipGraph
+// advances it without the host).
+#include "pg_common.h"
+
+namespace pg {
+
+struct AdamArgs {
+  float* p[PG_ADAM_MAX_TENSORS];
+  const float* g[PG_ADAM_MAX_TENSORS];
+  float* m[PG_ADAM_MAX_TENSORS];
+  float* v[PG_ADAM_MAX_TENSORS];
+  int64_t end[PG_ADAM_MAX_TENSORS];   // exclusive prefix ends of the tensors' element ranges
+  int32_t n_tensors;
+  float lr, beta1, beta2, eps, weight_decay;
+  int64_t* step;                      // device: completed steps
+  uint32_t* ticket;                   // device, zero between launches
+};
+
+__global__ __launch_bounds__(256) void k_adam(const AdamArgs a) {
+  const int64_t total = a.end[a.n_tensors - 1];
+  const double t = (double)(*a.step + 1);
+  const float bc1 = (float)(1.0 - pow((double)a.beta1, t));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, t));
+  const float step_size = a.lr / bc1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    // tensor of element i: constant-index selects only (a per-lane index into the by-value struct would
+    // send it to scratch)
+    float* pp = a.p[0];
+    const float* gp = a.g[0];
+    float *mp = a.m[0], *vp = a.v[0];
+    int64_t base = 0;
+#pragma unroll
+    for (int j = 1; j < PG_ADAM_MAX_TENSORS; ++j) {
+      if (j < a.n_tensors && i >= a.end[j - 1]) {
+        pp = a.p[j]; gp = a.g[j]; mp = a.m[j]; vp = a.v[j];
+        base = a.end[j - 1];
+      }
+    }
+    const int64_t o = i - base;
+    float g = gp[o];
+    const float p = pp[o];
+    if (a.weight_decay != 0.f) g += a.weight_decay * p;
+    const float m = a.beta1 * mp[o] + (1.f - a.beta1) * g;
+    const float v = a.beta2 * vp[o] + (1.f - a.beta2) * g * g;
+    mp[o] = m;
+    vp[o] = v;
+    const float denom = sqrtf(v) / bc2_sqrt + a.eps;
+    pp[o] = p - step_size * (m / denom);
+  }
+  // every block has read *step before the last one bumps it
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t done = atomicAdd(a.ticket, 1u) + 1;
+    if (done == gridDim.x) {
+      *a.step += 1;
+      *a.ticket = 0;
+    }
+  }
+}
+
+}  // namespace pg
+
+using namespace pg;
+
+extern "C" int pg_adam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                            float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, int64_t* step_dev, uint32_t* ticket_dev,
+                            pg_stream_t stream) {
+  if (n_tensors <= 0 || n_tensors > PG_ADAM_MAX_TENSORS || !params || !grads || !exp_avg || !exp_avg_sq || !numel ||
+      !step_dev || !ticket_dev)
+    return PG_ERR_INVALID;
+  AdamArgs a{};
+  int64_t tot = 0;
+  for (int i = 0; i < n_tensors; ++i) {
+    if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] <= 0) return PG_ERR_INVALID;
+    a.p[i] = params[i]; a.g[i] = grads[i]; a.m[i] = exp_avg[i]; a.v[i] = exp_avg_sq[i];
+    tot += numel[i];
+    a.end[i] = tot;
+  }
+  a.n_tensors = n_tensors;
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+  a.step = step_dev; a.ticket = ticket_dev;
+  int64_t g = ceil_div<int64_t>(tot, 256);
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, as_stream(stream), a);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}

@@ -1,0 +1,66 @@
+"""torch.optim.Adam for the trainer scripts (examples/profile/pa_gcn.py:137-139) as ONE HIP launch per step
+(pg_adam_step, pagraph_amd/csrc/pg_optim.hip): same constructor, same arithmetic as torch's Adam
+(amsgrad / maximize / foreach-only options are not offered), state_dict-compatible keys (`step`, `exp_avg`,
+`exp_avg_sq`). The step counter lives on the device and is advanced by the kernel, so the optimiser can be
+captured into a hipGraph as is (torch needs capturable=True and spends two launches: 7 + 15 us)."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError("invalid Adam hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._lib = L.load()
+        self._dev_state = {}      # per group: (step int64[1], ticket int32[1]) on the group's device
+
+    def _group_state(self, gi, device):
+        st = self._dev_state.get(gi)
+        if st is None:
+            st = (torch.zeros(1, dtype=torch.int64, device=device), torch.zeros(1, dtype=torch.int32, device=device))
+            self._dev_state[gi] = st
+        return st
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group['params'] if p.grad is not None]
+            if not ps:
+                continue
+            dev = ps[0].device
+            if not ps[0].is_cuda:
+                raise L.PgError("pagraph_amd.optim.Adam runs on the GPU only (no CPU fallback)")
+            step_dev, ticket = self._group_state(gi, dev)
+            for p in ps:
+                st = self.state[p]
+                if not st:
+                    st['step'] = step_dev          # shared by the group's tensors (torch keeps one per tensor)
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise L.PgError("pagraph_amd.optim.Adam needs contiguous fp32 parameters and gradients")
+            b1, b2 = group['betas']
+            for c0 in range(0, len(ps), L.PG_ADAM_MAX_TENSORS):
+                chunk = ps[c0:c0 + L.PG_ADAM_MAX_TENSORS]
+                n = len(chunk)
+                arr = lambda xs: (ctypes.c_void_p * n)(*[x.data_ptr() for x in xs])
+                numel = (ctypes.c_int64 * n)(*[p.numel() for p in chunk])
+                last = c0 + L.PG_ADAM_MAX_TENSORS >= len(ps)
+                # only the last chunk of a group advances the shared step counter
+                sd = step_dev if last else step_dev.clone()
+                with torch.cuda.device(dev):
+                    L.check(self._lib.pg_adam_step(n, arr(chunk), arr([p.grad for p in chunk]),
+                                                   arr([self.state[p]['exp_avg'] for p in chunk]),
+                                                   arr([self.state[p]['exp_avg_sq'] for p in chunk]), numel,
+                                                   float(group['lr']), float(b1), float(b2), float(group['eps']),
+                                                   float(group['weight_decay']), L.ptr(sd), L.ptr(ticket),
+                                                   L.stream_ptr()), "pg_adam_step")
+        return loss

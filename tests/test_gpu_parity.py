@@ -998,3 +998,54 @@ def test_dual_linear_vs_torch(dev, hiplib, n, K1, K2, N, act):
     ys = ops.linear2(x1[:100], l1, x2[:100], l2, act)
     assert "DualLinear" not in type(ys.grad_fn).__name__
     assert float((ys.double() - ref[:100]).abs().max()) < TOL * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wd", [0.0, 5e-4])
+def test_adam_step_matches_torch(dev, hiplib, wd):
+    """pagraph_amd.optim.Adam (one pg_adam_step launch) follows torch.optim.Adam's trajectory: 25 steps on the
+    GCN's parameter shapes (+ a 17-tensor group to cross the 16-tensor chunk), eager and replayed from a
+    hipGraph (the device-side step counter advances per replay)."""
+    from pagraph_amd.optim import Adam
+    torch.manual_seed(5)
+    shapes = [(32, 600), (32,), (60, 64), (60,)] + [(7, 3)] * 13
+    ref_p = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    our_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    ref = torch.optim.Adam(ref_p, lr=3e-2, weight_decay=wd)
+    our = Adam(our_p, lr=3e-2, weight_decay=wd)
+    grads = [[torch.randn(s, device=dev) * (0.1 + 0.05 * t) for s in shapes] for t in range(25)]
+    for t in range(25):
+        for p, q, g in zip(ref_p, our_p, grads[t]):
+            p.grad = g.clone()
+            q.grad = g.clone()
+        ref.step()
+        our.step()
+        err = max(float((p - q).abs().max()) for p, q in zip(ref_p, our_p))
+        assert err < 2e-6, (t, err)
+    assert int(our.state[our_p[0]]['step']) == 25
+    # captured: static gradient buffers refreshed before every replay
+    cap_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p[:4]]
+    ref2_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p[:4]]
+    cap = Adam(cap_p, lr=1e-2, weight_decay=wd)
+    ref2 = torch.optim.Adam(ref2_p, lr=1e-2, weight_decay=wd)
+    static_g = [torch.zeros(s, device=dev) for s in shapes[:4]]
+    for p, g in zip(cap_p, static_g):
+        p.grad = g
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        cap.step()                                   # warm-up (state allocation) outside the capture
+        for p, g in zip(ref2_p, static_g):
+            p.grad = g.clone()
+        ref2.step()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            cap.step()
+        for t in range(10):
+            for g, src, q in zip(static_g, grads[t][:4], ref2_p):
+                g.copy_(src)
+                q.grad = src.clone()
+            graph.replay()
+            ref2.step()
+    torch.cuda.synchronize()
+    assert max(float((p - q).abs().max()) for p, q in zip(ref2_p, cap_p)) < 2e-6
+    assert int(cap.state[cap_p[0]]['step']) == 11
