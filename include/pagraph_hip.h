@@ -90,8 +90,9 @@ int pg_slot_map_export(const int32_t* slot_map, int64_t node_num, uint8_t* gpu_f
  * there (coalesced) and the copy pass reads it back instead of repeating the random lookup.
  * stats: optional device uint64[2], ACCUMULATED (not reset): [0] += rows looked up (ids >= 0),
  * [1] += misses — the reference's try_num / miss_num (storage.py:219-221) without a host sync.
- * timer: optional (pg_timer_create); HIP events are recorded on `stream` immediately before and
- * after the copy kernel only (not the split pass), so pg_timer_elapsed_ms == rocprofv3's k_gather. */
+ * timer: optional (pg_timer_create); its HIP events are attached to the dispatch of the copy kernel itself
+ * (hipExtLaunchKernelGGL start / stop events; not the split pass), so pg_timer_elapsed_ms reads that kernel's
+ * own begin-to-end time on `stream`, like rocprofv3's k_gather row.                                    */
 typedef struct pg_timer pg_timer_t;
 int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
                    const pg_field_t* fields, int n_fields, int32_t* miss_pos, int64_t* miss_fullid,

@@ -11,9 +11,6 @@ namespace pg {
 thread_local int g_last_hip_error = 0;
 }
 
-struct pg_timer {
-  hipEvent_t start, stop;
-};
 
 extern "C" {
 

@@ -5,6 +5,12 @@
 
 #include "../../include/pagraph_hip.h"
 
+// a pair of HIP events (pg_timer_*): either recorded around a launch (pg_timer_start / _stop) or attached
+// to the launch itself (hipExtLaunchKernelGGL: begin / end of that dispatch only)
+struct pg_timer {
+  hipEvent_t start, stop;
+};
+
 namespace pg {
 
 constexpr int kWave = 64;

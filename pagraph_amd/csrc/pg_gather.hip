@@ -29,6 +29,8 @@
 //   * narrow fields (e.g. 'norm', dim 1) are copied lane-per-row.
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "pg_common.h"
 
 namespace pg {
@@ -274,15 +276,25 @@ static inline int grid_1d(int64_t n, int block, int cap = 4096) {
 }
 
 template <bool FULL>
-static int launch_gather(GatherArgs& a, hipStream_t st) {
+static int launch_gather(GatherArgs& a, hipStream_t st, pg_timer* timer = nullptr) {
+  // timer: its events are attached to THIS dispatch (hipExtLaunchKernelGGL), i.e. they read the kernel's own
+  // begin / end timestamps — what rocprofv3 reports — not the gaps to neighbouring event packets
   // tile height: 8 rows/block once the launch has >= 32K blocks anyway, 4 rows/block at the
   // minibatch shape (~34K rows -> ~8.5K blocks) to keep every CU fed through the tail.
   if (a.n >= (int64_t)1 << 18) {
     const int64_t blocks = ceil_div<int64_t>(a.n, 8);
-    hipLaunchKernelGGL((k_gather<8, 4, FULL>), dim3((unsigned)blocks), dim3(kGatherBlock), 0, st, a);
+    if (timer)
+      hipExtLaunchKernelGGL((k_gather<8, 4, FULL>), dim3((unsigned)blocks), dim3(kGatherBlock), 0, st, timer->start,
+                            timer->stop, 0, a);
+    else
+      hipLaunchKernelGGL((k_gather<8, 4, FULL>), dim3((unsigned)blocks), dim3(kGatherBlock), 0, st, a);
   } else {
     const int64_t blocks = ceil_div<int64_t>(a.n, 4);
-    hipLaunchKernelGGL((k_gather<4, 3, FULL>), dim3((unsigned)blocks), dim3(kGatherBlock), 0, st, a);
+    if (timer)
+      hipExtLaunchKernelGGL((k_gather<4, 3, FULL>), dim3((unsigned)blocks), dim3(kGatherBlock), 0, st, timer->start,
+                            timer->stop, 0, a);
+    else
+      hipLaunchKernelGGL((k_gather<4, 3, FULL>), dim3((unsigned)blocks), dim3(kGatherBlock), 0, st, a);
   }
   PG_LAUNCH_CHECK();
   return PG_OK;
@@ -367,13 +379,8 @@ int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const
                      miss_pos, miss_fullid, miss_count, slot_scratch,
                      reinterpret_cast<unsigned long long*>(stats));
   PG_LAUNCH_CHECK();
-  if (timer) {  // bracket ONLY the copy kernel (what rocprofv3 reports as pg::k_gather)
-    rc = pg_timer_start(timer, stream);
-    if (rc != PG_OK) return rc;
-  }
-  rc = launch_gather<false>(a, st);
-  if (rc == PG_OK && timer) rc = pg_timer_stop(timer, stream);
-  return rc;
+  // the timer brackets ONLY the copy kernel (what rocprofv3 reports as pg::k_gather)
+  return launch_gather<false>(a, st, timer);
 }
 
 int pg_gather_rows_full(const int64_t* ids, int64_t n, const pg_field_t* fields, int n_fields,
