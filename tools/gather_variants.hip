@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void copy4(const vf4* __restrict__ a, vf4* __r
 int main(int argc, char** argv) {
   const int dim = 600;
   const int64_t NC = 2560000;                      // cached rows (30% of 8.5M)
-  std::vector<int64_t> Rs = {34000, 1 << 20};
+  std::vector<int64_t> Rs = {18700, 42000};
   float *cache, *cnorm, *out, *onorm;
   int32_t* slot_map; int64_t* ids;
   const int64_t Rmax = 1 << 20;
@@ -290,6 +290,8 @@ int main(int argc, char** argv) {
 #define V3B(T, U, BS) run("v3<" #T "," #U ",nts,BS=" #BS ">", [&] { hipLaunchKernelGGL((v3<T, U, true, false, BS>), dim3((unsigned)((R + T - 1) / T)), dim3(BS), 0, 0, ids, slot_map, cache, cnorm, out, onorm, R, dim); })
       V3(8, 4, true, false); V3(8, 5, true, false); V3(4, 3, true, false); V3(6, 4, true, false); V3(10, 6, true, false); V3(8, 3, true, false); V3(8, 2, true, false);
       V3(5, 3, true, false); V3(7, 4, true, false); V3(2, 2, true, false); V3(3, 2, true, false);
+#define V4(T, U, G) run("v4<" #T "," #U ",grid=" #G ">", [&] { hipLaunchKernelGGL((v4<T, U, true>), dim3(G), dim3(256), 0, 0, ids, slot_map, cache, cnorm, out, onorm, R, dim); })
+      V4(4, 3, 2048); V4(4, 3, 1024); V4(2, 2, 2048); V4(8, 4, 1024); V4(4, 3, 4096);
       V3B(4, 5, 128); V3B(8, 5, 128); V3B(4, 3, 128); V3B(16, 5, 512); V3B(8, 3, 512); V3B(16, 3, 512); V3B(3, 4, 128); V3B(2, 5, 64); V3B(1, 3, 64);
     }
   }
