@@ -104,9 +104,11 @@ int pg_gather_rows_full(const int64_t* ids, int64_t n, const pg_field_t* fields,
                         pg_stream_t stream);
 
 /* batch_labels = labels[batch_nids] (examples/profile/pa_gcn.py:99-100): out[i] = labels[ids[i]], or
- * `fill` where ids[i] is outside [0, n_labels) (padding ids of a fixed-shape NodeFlow are -1).      */
+ * `fill` where ids[i] is outside [0, n_labels) (padding ids of a fixed-shape NodeFlow are -1).
+ * n_valid_out (device int32, may be NULL): number of i with out[i] != fill and >= 0 — the rows a loss with
+ * ignore_index = fill will count (pg_gcn_head reads it).                                             */
 int pg_gather_labels(const int64_t* ids, int64_t n, const int64_t* labels, int64_t n_labels, int64_t fill,
-                     int64_t* out, pg_stream_t stream);
+                     int64_t* out, int32_t* n_valid_out, pg_stream_t stream);
 
 /* storage.py:199-200 — out[pos[j], :] = staged[j, :] for j < n (n from host, or *n_dev when n_dev != NULL
  * in which case `n` is the launch upper bound). `staged` is device memory, row stride = dim.        */
@@ -206,8 +208,9 @@ int pg_sampler_capacity(const pg_sampler_t* s, int64_t* cap_nodes, int64_t* cap_
  * `out` names an output slot (a set of caller-owned buffers). The launch sequence for a slot is fixed, so from
  * the second call into the same slot on the same stream it is replayed as ONE hipGraph launch (the call's
  * scalars travel through a pinned parameter block; PG_SAMPLER_NO_GRAPH=1 keeps the ~30 individual launches).
- * A slot may be sampled into again only after the previous sample into it has completed on the device
- * (ring of slots, as pagraph_amd.sampling.NeighborSampler does).                                       */
+ * The call blocks the host until the previous sample into the SAME slot has completed on the device (its
+ * parameter block is about to be rewritten): with a ring of slots, as pagraph_amd.sampling.NeighborSampler
+ * uses, that is one ring revolution ago and bounds how far the launch thread can run ahead of the GPU.   */
 int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, uint64_t seed,
                       uint32_t epoch, uint32_t batch, const pg_nodeflow_desc_t* out, pg_stream_t stream);
 
@@ -305,6 +308,20 @@ int pg_xent_fwd(const float* logits, int32_t stride, const int64_t* labels, int6
 /* gx = dlogits * meta[1] * (*grad_out)  (grad_out: device scalar, NULL = 1)                         */
 int pg_xent_bwd(const float* dlogits, int32_t d_stride, int64_t n, int32_t C, const float* meta,
                 const float* grad_out, float* gx, int32_t gx_stride, pg_stream_t stream);
+
+/* Output head of the sampled GCN in one pass (pg_head.hip): the last block's aggregation with the model's
+ * dropout (gcn_nssc.py:66-74), the output NodeUpdate z = W agg + b (gcn_nssc.py:18,58: no activation), the
+ * CrossEntropyLoss of pa_gcn.py:80,101-104 and their gradients. h [n_src, K] (K <= 64), W [C, K] (C <= 64).
+ *   logits [n_dst, C] (may be NULL)     dagg [n_dst, K] = d loss / d agg (feed pg_spmm_bwd_gather / _bwd with it;
+ *   dW [C, K], db_loss [C + 1] = db then the mean loss.   Everything is already scaled by *grad_scale_dev / #counted (device
+ *   scalar = d(objective)/d(loss), NULL = 1), #counted read from *n_valid_dev (pg_gather_labels); labels outside [0, C) other than ignore_index are
+ *   not counted. partials: pg_gcn_head_scratch(n_dst, K, C) floats. drop may be NULL. Deterministic.          */
+int64_t pg_gcn_head_scratch(int64_t n_dst, int32_t K, int32_t C);
+int pg_gcn_head(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
+                const float* W, const float* bias, int32_t C, const int64_t* labels, int64_t ignore_index,
+                const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
+                int64_t n_dst, float* logits, float* dagg, float* partials, float* dW, float* db_loss,
+                pg_stream_t stream);
 
 /* Optimiser step — torch.optim.Adam(model.parameters(), lr, weight_decay) of examples/profile/pa_gcn.py:137-139
  * (amsgrad off, maximize off), same arithmetic as torch's: g += wd * p; m = b1 m + (1 - b1) g;

@@ -295,6 +295,35 @@ def cross_entropy(logits, labels, ignore_index=-100):
     return loss, grad / max(cnt, 1)
 
 
+def gcn_head(indptr, src, h, W, b, labels, ignore_index=-100, grad_scale=1.0, reduce="mean", keep=None, scale=1.0):
+    """output head of the sampled GCN in float64: agg = reduce(dropout(h)[src]) (gcn_nssc.py:66-74), z = agg W^T + b
+    (:18,58), CrossEntropyLoss (pa_gcn.py:80,101-104) and the gradients w.r.t. h, W, b, all times grad_scale.
+    keep/scale: the dropout keep-mask over h's elements (dropout_mask) or None."""
+    h = np.asarray(h, np.float64)
+    hd = h if keep is None else np.where(keep, h * float(scale), 0.0)
+    indptr = np.asarray(indptr, np.int64)
+    n_dst = len(indptr) - 1
+    deg = np.diff(indptr)
+    dst = np.repeat(np.arange(n_dst), deg)
+    agg = np.zeros((n_dst, h.shape[1]))
+    np.add.at(agg, dst, hd[np.asarray(src, np.int64)])
+    wgt = np.ones(n_dst)
+    if reduce == "mean":
+        wgt = np.where(deg > 0, 1.0 / np.maximum(deg, 1), 1.0)
+        agg = agg * wgt[:, None]
+    z = agg @ np.asarray(W, np.float64).T + (0 if b is None else np.asarray(b, np.float64))
+    loss, dz = cross_entropy(z, labels, ignore_index)
+    dz = dz * grad_scale
+    dagg = dz @ np.asarray(W, np.float64)
+    dW = dz.T @ agg
+    db = dz.sum(0)
+    dh = np.zeros_like(h)
+    np.add.at(dh, np.asarray(src, np.int64), dagg[dst] * wgt[dst][:, None])
+    if keep is not None:
+        dh = np.where(keep, dh * float(scale), 0.0)
+    return loss, z, dh, dW, db
+
+
 def gcn_forward(nf, feats0, params, n_layers=1):
     """GCNSampling.forward, dropout off (gcn_nssc.py:60-77) with NodeUpdate (:14-24).
     params: list of (W[out,in], b[out]) per layer; nf from sample_nodeflow; feats0 = layer-0 features."""

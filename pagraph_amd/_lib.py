@@ -59,7 +59,7 @@ _SIGS = {
     "pg_slot_map_export": (ctypes.c_int, [vp, c_i64, vp, vp, vp]),
     "pg_gather_rows": (ctypes.c_int, [vp, c_i64, vp, vp, ctypes.POINTER(PgField), ctypes.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "pg_gather_rows_full": (ctypes.c_int, [vp, c_i64, ctypes.POINTER(PgField), ctypes.c_int, vp]),
-    "pg_gather_labels": (ctypes.c_int, [vp, c_i64, vp, c_i64, c_i64, vp, vp]),
+    "pg_gather_labels": (ctypes.c_int, [vp, c_i64, vp, c_i64, c_i64, vp, vp, vp]),
     "pg_scatter_rows": (ctypes.c_int, [vp, vp, c_i64, vp, c_i32, vp, c_i32, vp]),
     "pg_host_gather_rows": (ctypes.c_int, [vp, c_i64, c_i32, vp, c_i64, vp, ctypes.c_int]),
     "pg_scatter_rows_from_host": (ctypes.c_int, [vp, c_i64, vp, vp, c_i64, vp, c_i32, vp, c_i32, vp]),
@@ -88,6 +88,9 @@ _SIGS = {
     "pg_linear_bwd_w": (ctypes.c_int, [vp, c_i32, vp, c_i32, c_i64, c_i32, c_i32, vp, vp, vp, c_i32, c_i32, vp, vp, vp]),
     "pg_xent_fwd": (ctypes.c_int, [vp, c_i32, vp, c_i64, c_i32, c_i64, vp, c_i32, vp, vp, vp]),
     "pg_xent_bwd": (ctypes.c_int, [vp, c_i32, c_i64, c_i32, vp, vp, vp, c_i32, vp]),
+    "pg_gcn_head_scratch": (c_i64, [c_i64, c_i32, c_i32]),
+    "pg_gcn_head": (ctypes.c_int, [vp, vp, vp, c_i32, c_i32, vp, vp, c_i32, vp, c_i64, vp, vp, vp, ctypes.c_int,
+                                   c_i64, vp, vp, vp, vp, vp, vp]),
     "pg_adam_step": (ctypes.c_int, [c_i32, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                     ctypes.c_float, ctypes.c_float, vp, vp, vp]),
     "pg_dg_partition": (ctypes.c_int, [c_i64, vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp]),

@@ -11,6 +11,10 @@ struct pg_timer {
   hipEvent_t start, stop;
 };
 
+// internal (pg_dense.hip): ordered sum of per-chunk partial tiles
+extern "C" int pg_sum_partials(const float* partials, int32_t chunks, int64_t nk, int32_t N, float* dW, float* db,
+                               pg_stream_t stream);
+
 namespace pg {
 
 constexpr int kWave = 64;

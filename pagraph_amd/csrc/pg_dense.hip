@@ -291,6 +291,16 @@ int pg_linear2_fwd(const float* X, int32_t x_stride, const float* W, const float
   return linear_fwd(X, x_stride, W, bias, X2, x2_stride, W2, bias2, K2, Y, y_stride, n, K, N, act, stream);
 }
 
+/* out[j] = sum over chunks of part[c][j] (chunk order), j < nk -> dW[j], nk <= j < nk + N -> db[j - nk] */
+int pg_sum_partials(const float* partials, int32_t chunks, int64_t nk, int32_t N, float* dW, float* db,
+                    pg_stream_t stream) {
+  if (!partials || chunks <= 0 || nk <= 0 || N < 0 || !dW) return PG_ERR_INVALID;
+  hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)ceil_div<int64_t>(nk + N, 64)), dim3(256), 0, as_stream(stream),
+                     partials, chunks, nk, N, dW, db);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
 int64_t pg_linear_bwd_w_scratch(int64_t n, int32_t K, int32_t N) {
   if (n <= 0 || K <= 0 || N <= 0) return 0;
   return ceil_div<int64_t>(n, 4 * bwd_rows_per_wave(n, K, N)) * ((int64_t)N * K + N);

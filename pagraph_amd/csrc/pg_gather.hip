@@ -317,10 +317,19 @@ static int fill_args(GatherArgs& a, const pg_field_t* fields, int n_fields, bool
 // fixed-shape NodeFlow and get `fill` (the loss's ignore_index)
 __global__ __launch_bounds__(256) void k_gather_labels(const int64_t* __restrict__ ids, int64_t n,
                                                        const int64_t* __restrict__ labels, int64_t n_labels,
-                                                       int64_t fill, int64_t* __restrict__ out) {
+                                                       int64_t fill, int64_t* __restrict__ out,
+                                                       int32_t* __restrict__ n_valid) {
+  int mine = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t v = ids[i];
-    out[i] = (v >= 0 && v < n_labels) ? labels[v] : fill;
+    const int64_t l = (v >= 0 && v < n_labels) ? labels[v] : fill;
+    out[i] = l;
+    mine += (l != fill && l >= 0) ? 1 : 0;
+  }
+  if (n_valid) {   // rows the loss will count (label != fill): one atomic per wave
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0 && mine) atomicAdd(n_valid, mine);
   }
 }
 
@@ -396,13 +405,14 @@ int pg_gather_rows_full(const int64_t* ids, int64_t n, const pg_field_t* fields,
 }
 
 int pg_gather_labels(const int64_t* ids, int64_t n, const int64_t* labels, int64_t n_labels, int64_t fill,
-                     int64_t* out, pg_stream_t stream) {
+                     int64_t* out, int32_t* n_valid_out, pg_stream_t stream) {
   if (n < 0 || n_labels < 0) return PG_ERR_INVALID;
+  if (n_valid_out) PG_HIP(hipMemsetAsync(n_valid_out, 0, sizeof(int32_t), as_stream(stream)));
   if (n == 0) return PG_OK;
   if (!ids || !out || (!labels && n_labels > 0)) return PG_ERR_INVALID;
   int64_t g = ceil_div<int64_t>(n, 256);
   hipLaunchKernelGGL(k_gather_labels, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, as_stream(stream), ids, n,
-                     labels, n_labels, fill, out);
+                     labels, n_labels, fill, out, n_valid_out);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }

@@ -1,0 +1,183 @@
+// Output head of the sampled GCN in one pass: the last NodeFlow block's aggregation (with the model's
+// dropout), the output NodeUpdate (a [C, K] linear layer, no activation: gcn_nssc.py:58), the loss
+// (torch.nn.CrossEntropyLoss, pa_gcn.py:80,101-104) and every gradient that hangs off them:
+//     agg[v]   = mean_{e of v} dropout(h)[src(e)]                     (gcn_nssc.py:66-74)
+//     z[v]     = W agg[v] + b                                         (gcn_nssc.py:18)
+//     loss     = mean_{counted v} (logsumexp z[v] - z[v][label v])
+//     dZ       = (softmax(z) - onehot) * grad_scale / #counted
+//     dAgg     = dZ W,   dW = dZ^T agg,   db = sum dZ
+// As separate kernels this chain is nine launches of 5-8 us each on 6000 x 64 numbers (aggregate, GEMM,
+// three for the loss, weight gradient + its reduction, input-gradient GEMM): ~55 us of a ~230 us step.
+// Here a wave owns a destination row at a time: lane = input column for the aggregation and dAgg, lane =
+// class for z / softmax / dZ / the dW row; W lives in registers both row- and column-wise; agg and dZ
+// cross between the two lane roles through LDS. Per-block partial sums of dW, db and the loss go to
+// scratch and k_sum_partials (pg_dense.hip) adds them in block order: deterministic.
+#include "pg_common.h"
+
+namespace pg {
+
+constexpr int kHeadMax = 64;   // K (input width) and C (classes) both fit one wave
+
+struct HeadDrop {
+  uint32_t thr, tag, k0, k1;
+  const uint64_t* step;
+  float scale;
+};
+
+__device__ __forceinline__ float hw_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+__device__ __forceinline__ float hw_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ indptr, const int32_t* __restrict__ src,
+                                                  const float* __restrict__ h, int32_t h_stride, int32_t K,
+                                                  const float* __restrict__ W, const float* __restrict__ bias,
+                                                  int32_t C, const int64_t* __restrict__ labels,
+                                                  int64_t ignore_index, const int32_t* __restrict__ n_valid_dev,
+                                                  const float* __restrict__ grad_scale_dev, HeadDrop d, int reduce, int64_t n_dst,
+                                                  float* __restrict__ logits, float* __restrict__ dagg,
+                                                  float* __restrict__ part, int32_t rows_per_wave) {
+  __shared__ __attribute__((aligned(16))) float s_agg[4][kHeadMax];
+  __shared__ __attribute__((aligned(16))) float s_dl[4][kHeadMax];
+  __shared__ float s_red[kHeadMax * kHeadMax + kHeadMax + 1];
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+  const int64_t wave_g = (int64_t)blockIdx.x * 4 + w;
+  const bool is_c = lane < C, is_k = lane < K;
+  // W row of class `lane` and W column of input `lane`, zero padded to 64
+  float wrow[kHeadMax], wcol[kHeadMax], accw[kHeadMax];
+#pragma unroll
+  for (int k = 0; k < kHeadMax; ++k) {
+    wrow[k] = (is_c && k < K) ? W[(int64_t)lane * K + k] : 0.f;
+    wcol[k] = (is_k && k < C) ? W[(int64_t)k * K + lane] : 0.f;
+    accw[k] = 0.f;
+  }
+  const float bz = (is_c && bias) ? bias[lane] : 0.f;
+  const int nv = *n_valid_dev;
+  const float inv = nv > 0 ? 1.f / (float)nv : 0.f;
+  const float grad_scale = grad_scale_dev ? *grad_scale_dev : 1.f;
+  const uint32_t step = (d.thr && d.step) ? (uint32_t)*d.step : 0u;
+  const int piece = lane >> 2, j4 = lane & 3;
+  const uint32_t q = (uint32_t)(((piece >> 7) << 6) | (piece & 63));
+  const int half = (piece >> 6) & 1;
+  float accb = 0.f, lsum = 0.f;
+  for (int it = 0; it < rows_per_wave; ++it) {          // same trip count for every wave: barriers inside
+    const int64_t v = wave_g * rows_per_wave + it;
+    const bool live = v < n_dst;
+    float a = 0.f;
+    if (live && is_k) {
+      const int32_t beg = indptr[v], end = indptr[v + 1];
+      for (int32_t e = beg; e < end; ++e) {
+        const int32_t sr = src[e];
+        float x = h[(int64_t)sr * h_stride + lane];
+        if (d.thr) {
+          uint32_t o[4];
+          Philox::gen((uint32_t)sr, q, d.tag, step, d.k0, d.k1, o);
+          const uint32_t wd = (j4 >> 1) ? (half ? o[3] : o[1]) : (half ? o[2] : o[0]);
+          const uint32_t u = (j4 & 1) ? (wd >> 16) : (wd & 0xffffu);
+          x = u >= d.thr ? x * d.scale : 0.f;
+        }
+        a += x;
+      }
+      if (reduce == PG_REDUCE_MEAN && end > beg) a /= (float)(end - beg);
+    }
+    s_agg[w][lane] = a;
+    __syncthreads();
+    // z[class = lane]
+    float z = bz;
+#pragma unroll
+    for (int k = 0; k < kHeadMax; k += 4) {
+      const float4 g = *reinterpret_cast<const float4*>(&s_agg[w][k]);
+      z += wrow[k] * g.x + wrow[k + 1] * g.y + wrow[k + 2] * g.z + wrow[k + 3] * g.w;
+    }
+    if (live && is_c && logits) logits[v * C + lane] = z;
+    const float m = hw_max(is_c ? z : -INFINITY);
+    const float ssum = hw_sum(is_c ? expf(z - m) : 0.f);
+    const float lse = m + logf(ssum);
+    const int64_t lab = live ? labels[v] : ignore_index;
+    const bool counted = live && lab != ignore_index && lab >= 0 && lab < C;
+    const float zl = __shfl(z, counted ? (int)lab : 0, kWave);
+    float dl = 0.f;
+    if (counted && is_c) dl = (expf(z - lse) - (lane == (int)lab ? 1.f : 0.f)) * (inv * grad_scale);
+    if (counted && lane == 0) lsum += lse - zl;
+    s_dl[w][lane] = dl;
+    __syncthreads();
+    // dAgg[input = lane] and the dW row of class `lane`
+    float gk = 0.f;
+#pragma unroll
+    for (int c = 0; c < kHeadMax; c += 4) {
+      const float4 g = *reinterpret_cast<const float4*>(&s_dl[w][c]);
+      gk += wcol[c] * g.x + wcol[c + 1] * g.y + wcol[c + 2] * g.z + wcol[c + 3] * g.w;
+    }
+    if (live && is_k) dagg[v * K + lane] = gk;
+#pragma unroll
+    for (int k = 0; k < kHeadMax; k += 4) {
+      const float4 g = *reinterpret_cast<const float4*>(&s_agg[w][k]);
+      accw[k] += dl * g.x; accw[k + 1] += dl * g.y; accw[k + 2] += dl * g.z; accw[k + 3] += dl * g.w;
+    }
+    accb += dl;
+    __syncthreads();   // s_agg / s_dl are rewritten by the next row
+  }
+  // block partial: the four waves add into s_red one after the other (fixed order)
+  const int len = C * K + C + 1;
+  for (int wv = 0; wv < 4; ++wv) {
+    if (w == wv) {
+      if (is_c) {
+#pragma unroll
+        for (int k = 0; k < kHeadMax; ++k)
+          if (k < K) s_red[lane * K + k] = (wv ? s_red[lane * K + k] : 0.f) + accw[k];
+        s_red[C * K + lane] = (wv ? s_red[C * K + lane] : 0.f) + accb;
+      }
+      if (lane == 0) s_red[C * K + C] = (wv ? s_red[C * K + C] : 0.f) + lsum * inv;
+    }
+    __syncthreads();
+  }
+  float* mine = part + (int64_t)blockIdx.x * len;
+  for (int t = threadIdx.x; t < len; t += 256) mine[t] = s_red[t];
+}
+
+}  // namespace pg
+
+using namespace pg;
+
+extern "C" {
+
+int64_t pg_gcn_head_scratch(int64_t n_dst, int32_t K, int32_t C) {
+  if (n_dst <= 0 || K <= 0 || C <= 0) return 0;
+  const int rpw = 4;
+  return ceil_div<int64_t>(n_dst, 4 * rpw) * ((int64_t)C * K + C + 1);
+}
+
+int pg_gcn_head(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
+                const float* W, const float* bias, int32_t C, const int64_t* labels, int64_t ignore_index,
+                const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
+                int64_t n_dst,
+                float* logits, float* dagg, float* partials, float* dW, float* db_loss, pg_stream_t stream) {
+  if (n_dst <= 0 || K <= 0 || C <= 0 || h_stride < K) return PG_ERR_INVALID;
+  if (K > kHeadMax || C > kHeadMax) return PG_ERR_UNSUPPORTED;
+  if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return PG_ERR_INVALID;
+  if (!indptr || !h || !W || !labels || !n_valid_dev || !dagg || !partials || !dW || !db_loss) return PG_ERR_INVALID;
+  if (drop && drop->threshold > 65535u) return PG_ERR_INVALID;
+  HeadDrop d{};
+  if (drop && drop->threshold) {
+    d.thr = drop->threshold; d.tag = drop->tag;
+    d.k0 = (uint32_t)drop->seed; d.k1 = (uint32_t)(drop->seed >> 32);
+    d.step = drop->step;
+    d.scale = 65536.f / (float)(65536u - drop->threshold);
+  }
+  const int rpw = 4;
+  const int64_t blocks = ceil_div<int64_t>(n_dst, 4 * rpw);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(k_gcn_head, dim3((unsigned)blocks), dim3(256), 0, st, indptr, src, h, h_stride, K, W, bias, C,
+                     labels, ignore_index, n_valid_dev, grad_scale_dev, d, reduce, n_dst, logits, dagg, partials, rpw);
+  PG_LAUNCH_CHECK();
+  // dW [C*K], then db [C] and the loss (db_loss[C]) contiguous behind it in the partial layout
+  return pg_sum_partials(partials, (int32_t)blocks, (int64_t)C * K, C + 1, dW, db_loss, stream);
+}
+
+}  // extern "C"

@@ -384,6 +384,7 @@ struct pg_sampler {
     hipGraphExec_t exec = nullptr;
     int64_t calls = 0;
     bool graph_failed = false;
+    hipEvent_t done = nullptr;       // recorded after every launch into this slot
   };
   std::vector<SlotState*> slot_states;
   SampleParams* prm_d = nullptr;     // device copy of the running call's parameters
@@ -430,6 +431,7 @@ static void sampler_free(pg_sampler* s) {
     if (c->exec) (void)hipGraphExecDestroy(c->exec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
     if (c->prm_h) (void)hipHostFree(c->prm_h);
+    if (c->done) (void)hipEventDestroy(c->done);
     delete c;
   }
   if (s->aux) (void)hipStreamDestroy(s->aux);
@@ -623,7 +625,9 @@ int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, ui
   if (!ss) {
     ss = new (std::nothrow) pg_sampler::SlotState;
     if (!ss) return PG_ERR_NOMEM;
-    if (hipHostMalloc(&ss->prm_h, sizeof(SampleParams), hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(&ss->prm_h, sizeof(SampleParams), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&ss->done, hipEventDisableTiming) != hipSuccess) {
+      if (ss->prm_h) (void)hipHostFree(ss->prm_h);
       delete ss;
       return PG_ERR_NOMEM;
     }
@@ -632,39 +636,56 @@ int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, ui
     ss->desc = *o;
     s->slot_states.push_back(ss);
   }
-  // the caller reuses a slot only after its previous NodeFlow was consumed, i.e. long after the previous
-  // launch for this slot read its parameter block
+  // The parameter block is read by the device when k_seed_layer RUNS, which can be long after this call
+  // returned: a launch thread that runs several minibatches ahead of the GPU would overwrite it under
+  // the feet of the previous sample into the same slot (seen as a wrong loss trajectory once the host got
+  // 4 calls ahead). So: wait until the previous launch into this slot has finished on the device — one
+  // ring revolution ago, normally long done; otherwise this is the back-pressure that bounds the run-ahead.
+  if (ss->calls > 0) PG_HIP(hipEventSynchronize(ss->done));
   SampleParams* prm = ss->prm_h;
   prm->seeds = seeds; prm->n_seeds = n_seeds;
   prm->seed_lo = (uint32_t)seed; prm->seed_hi = (uint32_t)(seed >> 32);
   prm->epoch = epoch; prm->batch = batch;
   ++ss->calls;
   static const bool no_graph = getenv("PG_SAMPLER_NO_GRAPH") != nullptr;
+  int rc = PG_OK;
+  bool launched = false;
   if (ss->exec) {
     PG_HIP(hipGraphLaunch(ss->exec, st));
-    return PG_OK;
+    launched = true;
+  } else if (no_graph || ss->graph_failed || ss->calls < 2) {
+    rc = enqueue_chain(s, o, st, ss);
+    launched = true;
   }
-  if (no_graph || ss->graph_failed || ss->calls < 2) return enqueue_chain(s, o, st, ss);
+  if (launched) {
+    if (rc == PG_OK) PG_HIP(hipEventRecord(ss->done, st));
+    return rc;
+  }
   // second call into this slot: capture the chain (~25-35 launches) once, then replay it with one launch
   if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
     (void)hipGetLastError();
     ss->graph_failed = true;
-    return enqueue_chain(s, o, st, ss);
+    rc = enqueue_chain(s, o, st, ss);
+    if (rc == PG_OK) PG_HIP(hipEventRecord(ss->done, st));
+    return rc;
   }
-  const int rc = enqueue_chain(s, o, st, ss);
+  rc = enqueue_chain(s, o, st, ss);
   hipGraph_t graph = nullptr;
   const hipError_t e_end = hipStreamEndCapture(st, &graph);
   if (rc == PG_OK && e_end == hipSuccess && graph &&
       hipGraphInstantiate(&ss->exec, graph, nullptr, nullptr, 0) == hipSuccess) {
     ss->graph = graph;
     PG_HIP(hipGraphLaunch(ss->exec, st));
+    PG_HIP(hipEventRecord(ss->done, st));
     return PG_OK;
   }
   (void)hipGetLastError();
   if (graph) (void)hipGraphDestroy(graph);
   ss->exec = nullptr;
   ss->graph_failed = true;
-  return enqueue_chain(s, o, st, ss);   // nothing ran during the failed capture
+  rc = enqueue_chain(s, o, st, ss);   // nothing ran during the failed capture
+  if (rc == PG_OK) PG_HIP(hipEventRecord(ss->done, st));
+  return rc;
 }
 
 int pg_frontier_mark_neighbors(const int64_t* indptr, const int32_t* indices, const int64_t* frontier, int64_t n,

@@ -93,6 +93,38 @@ class _GCNBase(FusedDropoutMixin, nn.Module):
             return self._propagate(nf, self._input_transform(nf))
         return self._propagate(nf, nf.layers[0].data['features'])
 
+    def forward_loss(self, nf, labels, n_valid, grad_seed=None, ignore_index=-100, want_logits=False):
+        """CrossEntropyLoss(self(nf), labels) with the output layer, the loss and their gradients in ONE kernel
+        (ops.gcn_head): everything up to the last block runs as in forward(), then the last aggregation
+        (+ dropout), the output NodeUpdate (gcn_nssc.py:58: plain linear) and the loss are fused. Returns the
+        loss (or (loss, logits)), or None when the fused kernel does not apply (inference model, > 64
+        classes / hidden columns, CPU tensors) — the caller then uses forward() and its loss function.
+        n_valid: device int32[1] = number of labels != ignore_index."""
+        last = self.layers[-1]
+        if self.uses_norm or last.test or last.concat or last.activation is not None or not labels.is_cuda:
+            return None
+        self._bump_drop_step()
+        h = self._input_transform(nf) if self.preprocess else nf.layers[0].data['features']
+        n = len(self.layers)
+        for i, layer in enumerate(self.layers[:-1]):
+            drop = None
+            if getattr(self, 'dropout', None) and not self.preprocess:
+                drop = self._drop_spec(i, h)
+                if drop is None:
+                    h = self.dropout(h)
+            nf.layers[i].data['h'] = h
+            nf.block_compute(i, fn.copy_src(src='h', out='m'), self.reducer(msg='m', out='h'), layer, dropout=drop)
+            h = nf.layers[i + 1].data.pop('activation')
+        i = n - 1
+        drop = None
+        if getattr(self, 'dropout', None) and not self.preprocess and self.training:
+            drop = self._drop_spec(i, h)
+            if drop is None:
+                h = self.dropout(h)
+        return ops.gcn_head(nf.blk_indptr[i], nf.blk_src[i], h, last.linear, labels, n_valid, grad_seed, ignore_index,
+                            self.reducer(msg='m', out='h').op, drop,
+                            (nf.blk_tptr[i], nf.blk_tdst[i], nf.blk_theavy[i]), want_logits)
+
 
 class GCNSampling(_GCNBase):
     """gcn_nssc.py:27-100 — mean aggregation, dropout before every aggregation"""

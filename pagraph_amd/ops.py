@@ -290,3 +290,84 @@ def fused_loss(loss_fcn):
             and getattr(loss_fcn, 'label_smoothing', 0.0) == 0.0):
         return CrossEntropyLoss(loss_fcn.ignore_index)
     return loss_fcn
+
+
+class _GCNHead(torch.autograd.Function):
+    """last aggregation (+ dropout) -> output linear layer -> CrossEntropyLoss and all their gradients in one
+    pass (pg_gcn_head). The gradients are computed in the forward, already multiplied by `grad_seed` (a device
+    scalar: d objective / d loss); backward hands them out when it is called with that very tensor and
+    rescales otherwise."""
+
+    @staticmethod
+    def forward(ctx, indptr, src, h, weight, bias, labels, n_valid, grad_seed, ignore_index, reduce, drop, tptr, tdst,
+                heavy, want_logits):
+        lib = L.load()
+        h = h.contiguous()
+        n_dst = labels.numel()
+        C, K = weight.shape
+        buf = torch.empty(C * K + C + 1, dtype=torch.float32, device=h.device)
+        gw, gbl = buf[:C * K].view(C, K), buf[C * K:]
+        dagg = torch.empty((n_dst, K), dtype=torch.float32, device=h.device)
+        logits = torch.empty((n_dst, C), dtype=torch.float32, device=h.device) if want_logits else None
+        part = torch.empty(lib.pg_gcn_head_scratch(n_dst, K, C), dtype=torch.float32, device=h.device)
+        d = drop.struct() if drop is not None and drop.threshold else None
+        with torch.cuda.device(h.device):
+            L.check(lib.pg_gcn_head(L.ptr(indptr), L.ptr(src), L.ptr(h), h.stride(0), K, L.ptr(weight), L.ptr(bias), C,
+                                    L.ptr(labels), int(ignore_index), L.ptr(n_valid), L.ptr(grad_seed),
+                                    ctypes.byref(d) if d is not None else None, _REDUCE[reduce], n_dst, L.ptr(logits),
+                                    L.ptr(dagg), L.ptr(part), L.ptr(gw), L.ptr(gbl), L.stream_ptr()), "pg_gcn_head")
+        use_t = tptr is not None and tptr.numel() == h.size(0) + 1
+        ctx.save_for_backward(indptr, src, dagg, gw, gbl, grad_seed, *((tptr, tdst, heavy) if use_t else ()))
+        ctx.use_t, ctx.n_src, ctx.reduce, ctx.drop = use_t, h.size(0), reduce, (drop if d is not None else None)
+        ctx.has_bias = bias is not None
+        loss = gbl[C]
+        if want_logits:
+            ctx.mark_non_differentiable(logits)
+            return loss, logits
+        return loss
+
+    @staticmethod
+    def backward(ctx, g, *unused):
+        saved = ctx.saved_tensors
+        indptr, src, dagg, gw, gbl, seed = saved[:6]
+        if seed is None or g.data_ptr() != seed.data_ptr():
+            k = g if seed is None else g / seed             # not the registered seed: rescale (extra launches)
+            dagg, gw, gbl = dagg * k, gw * k, gbl * k
+        lib = L.load()
+        gh = None
+        if ctx.needs_input_grad[2]:
+            K = dagg.size(1)
+            d = ctx.drop.struct() if ctx.drop is not None else None
+            dp = ctypes.byref(d) if d is not None else None
+            with torch.cuda.device(dagg.device):
+                if ctx.use_t:
+                    tptr, tdst, heavy = saved[6:9]
+                    gh = torch.empty((ctx.n_src, K), dtype=torch.float32, device=dagg.device)
+                    L.check(lib.pg_spmm_bwd_gather(L.ptr(tptr), L.ptr(tdst), L.ptr(indptr), L.ptr(dagg), K, ctx.n_src, K,
+                                                   _REDUCE[ctx.reduce], L.ptr(gh), K, L.ptr(heavy),
+                                                   heavy.numel() - 1 if heavy is not None else 0, dp, L.stream_ptr()),
+                            "pg_spmm_bwd_gather")
+                else:
+                    gh = torch.zeros((ctx.n_src, K), dtype=torch.float32, device=dagg.device)
+                    L.check(lib.pg_spmm_bwd_drop(L.ptr(indptr), L.ptr(src), L.ptr(dagg), K, dagg.size(0), K,
+                                                 _REDUCE[ctx.reduce], L.ptr(gh), K, dp, L.stream_ptr()), "pg_spmm_bwd_drop")
+        C = gw.size(0)
+        return (None, None, gh, gw, gbl[:C] if ctx.has_bias else None) + (None,) * 10
+
+
+def gcn_head(indptr, src, h, linear, labels, n_valid, grad_seed=None, ignore_index=-100, reduce="mean", dropout=None,
+             transpose=None, want_logits=False):
+    """loss (and optionally logits) of the sampled GCN's output layer over the last NodeFlow block:
+    CrossEntropyLoss(linear(aggregate(dropout(h)))) with every gradient produced in the same pass.
+    n_valid: device int32[1], number of labels != ignore_index (pg_gather_labels). Returns None when the
+    shapes are outside the kernel's envelope (callers then run the unfused path)."""
+    w, b = linear.weight, linear.bias
+    if not (h.is_cuda and h.dtype == torch.float32 and h.dim() == 2 and h.stride(1) == 1 and w.size(1) == h.size(1)
+            and w.size(1) <= 64 and w.size(0) <= 64 and w.is_contiguous() and labels.dtype == torch.int64
+            and labels.numel() > 0):
+        return None
+    if dropout is not None and dropout.threshold and h.size(1) % 4:
+        return None
+    tptr, tdst, heavy = (tuple(transpose) + (None,))[:3] if transpose is not None else (None, None, None)
+    return _GCNHead.apply(indptr, src, h, w, b, labels.contiguous(), n_valid, grad_seed, ignore_index, reduce, dropout,
+                          tptr, tdst, heavy, want_logits)

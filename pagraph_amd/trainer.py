@@ -166,6 +166,7 @@ class GraphedTrainer:
         # (len(sampler.slots) steps later) — enough for a trainer that prints the loss every N steps.
         self.keep_losses = bool(keep_losses)
         self._on_main = False            # run_steps made the compute stream current for the whole loop
+        self.fuse_head = True            # use model.forward_loss (fused output layer + loss) when the model has one
         self.world = int(world_size)
         self.pg = process_group
         self.flat = None
@@ -217,6 +218,7 @@ class GraphedTrainer:
         R = nf._node_mapping.tousertensor().numel()
         s.out = {n: torch.zeros((R, d), dtype=torch.float32, device=self.device) for n, d in self.cacher.dims.items()}
         s.label = torch.full((nf.layer_size(-1),), -100, dtype=torch.int64, device=self.device)
+        s.n_valid = torch.zeros(1, dtype=torch.int32, device=self.device)   # labels the loss will count
         s.ready = torch.cuda.Event()
         s.done = torch.cuda.Event()
         s.done_recorded = False
@@ -259,7 +261,8 @@ class GraphedTrainer:
         o0, o1 = nf._layer_offsets[-2], nf._layer_offsets[-1]
         sp = ctypes.c_void_p(ls.cuda_stream)
         L.check(self._lib.pg_gather_labels(ctypes.c_void_p(ids.data_ptr() + 8 * o0), o1 - o0, L.ptr(self.labels),
-                                           self.labels.numel(), -100, L.ptr(s.label), sp), "pg_gather_labels")
+                                           self.labels.numel(), -100, L.ptr(s.label), L.ptr(s.n_valid), sp),
+                "pg_gather_labels")
         s.ready.record(ls)
         if dbg is not None:
             ev[3].record(ls)
@@ -282,10 +285,15 @@ class GraphedTrainer:
             o0, o1 = s.nf._layer_offsets[i], s.nf._layer_offsets[i + 1]
             s.nf._node_frames[i] = {n: t[o0:o1] for n, t in s.out.items()
                                     if self.need is None or n in self.need.get(i, ())}
-        pred = self.model(s.nf)
-        loss = self.loss_fcn(pred, s.label)
         if self._gseed is None:                 # persistent d loss / d loss: no ones_like fill (nor a divide) per step
-            self._gseed = torch.full_like(loss.detach(), 1.0 / self.world)
+            self._gseed = torch.full((), 1.0 / self.world, dtype=torch.float32, device=self.device)
+        loss = None
+        if self.fuse_head and isinstance(self.loss_fcn, ops.CrossEntropyLoss) and hasattr(self.model, 'forward_loss'):
+            # output layer + loss + their gradients in one kernel (GCN); None = not applicable
+            loss = self.model.forward_loss(s.nf, s.label, s.n_valid, self._gseed, self.loss_fcn.ignore_index)
+        if loss is None:
+            pred = self.model(s.nf)
+            loss = self.loss_fcn(pred, s.label)
         if self.world > 1:
             self.flat.zero_()
             loss.backward(self._gseed)          # loss / world: the SUM all-reduce then yields DDP's mean gradient

@@ -1049,3 +1049,117 @@ def test_adam_step_matches_torch(dev, hiplib, wd):
     torch.cuda.synchronize()
     assert max(float((p - q).abs().max()) for p, q in zip(ref2_p, cap_p)) < 2e-6
     assert int(cap.state[cap_p[0]]['step']) == 11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_dst,n_src,deg,K,C,p,ignored,hubs", [(6000, 9500, 2, 64, 60, 0.5, 0, True), (6000, 9500, 2, 64, 60, 0.0, 300, True),
+                                                                  (1000, 700, 3, 32, 41, 0.25, 10, False), (33, 20, 1, 64, 7, 0.0, 0, False),
+                                                                  (500, 2000, 4, 16, 64, 0.9, 0, False)])
+def test_gcn_output_head_vs_oracle(dev, hiplib, oracle, n_dst, n_src, deg, K, C, p, ignored, hubs):
+    """pg_gcn_head (aggregation + dropout + output linear layer + CrossEntropyLoss + all gradients in one pass)
+    vs the float64 restatement and vs the unfused ops of this library; gather-form and scatter-form backward;
+    bit-identical between two runs."""
+    from pagraph_amd import ops
+    rng = np.random.default_rng(n_dst + K * C)
+    cnt = rng.integers(0, deg + 1, n_dst)
+    indptr = np.zeros(n_dst + 1, np.int32); indptr[1:] = np.cumsum(cnt)
+    src = rng.integers(0, n_src, int(indptr[-1])).astype(np.int32)
+    if hubs:
+        pick = rng.random(src.size) < 0.15
+        src[pick] = rng.choice(np.array([3, n_src - 2], np.int32), int(pick.sum()))
+    tptr, tdst = _transpose_ref(indptr, src, n_src)
+    heavy_rows = np.nonzero(np.diff(tptr) > 32)[0]
+    heavy = np.zeros(1 + max(1, src.size // 32), np.int32)
+    heavy[0] = len(heavy_rows); heavy[1:1 + len(heavy_rows)] = heavy_rows
+    h = rng.standard_normal((n_src, K)).astype(np.float32)
+    labels = rng.integers(0, C, n_dst)
+    if ignored:
+        labels[rng.permutation(n_dst)[:ignored]] = -100
+    lin = torch.nn.Linear(K, C).to(dev)
+    tip, tsr = torch.from_numpy(indptr).to(dev), torch.from_numpy(src).to(dev)
+    tr = tuple(torch.from_numpy(a.astype(np.int32)).to(dev) for a in (tptr, tdst, heavy))
+    tl = torch.from_numpy(labels).to(dev)
+    n_valid = torch.tensor([int((labels != -100).sum())], dtype=torch.int32, device=dev)
+    seed_t = torch.tensor(0.5, device=dev)                       # d objective / d loss (1 / world_size 2)
+    step = torch.tensor([4], dtype=torch.int64, device=dev)
+    spec = ops.DropoutSpec(p, 99, 1, step) if p else None
+    keep, scale = oracle.dropout_mask(n_src, K, spec.threshold, 99, 1, 4) if p else (None, 1.0)
+    want = oracle.gcn_head(indptr, src, h, lin.weight.detach().cpu().numpy(), lin.bias.detach().cpu().numpy(), labels,
+                           -100, 0.5, "mean", keep, scale)
+    results = []
+    for transpose in (tr, None, tr):
+        lin.zero_grad()
+        th = torch.from_numpy(h).to(dev).requires_grad_(True)
+        loss, logits = ops.gcn_head(tip, tsr, th, lin, tl, n_valid, seed_t, -100, "mean", spec, transpose, want_logits=True)
+        assert "GCNHead" in type(loss.grad_fn).__name__
+        loss.backward(seed_t)
+        got = (float(loss), logits.cpu().numpy(), th.grad.cpu().numpy(), lin.weight.grad.cpu().numpy(), lin.bias.grad.cpu().numpy())
+        results.append(got)
+        sc = max(1.0, float(scale))
+        assert abs(got[0] - want[0]) < TOL * max(1.0, abs(want[0]))
+        assert np.abs(got[1] - want[1]).max() < TOL * max(1.0, np.abs(want[1]).max())
+        for g, w in zip(got[2:], want[2:]):
+            assert np.abs(g - w).max() < TOL * sc * max(1e-3, np.abs(w).max()), (np.abs(g - w).max(), np.abs(w).max())
+    for a, b in zip(results[0], results[2]):                      # deterministic
+        assert np.array_equal(a, b)
+    # a gradient seed other than the registered one is honoured too (rescaled)
+    lin.zero_grad()
+    th = torch.from_numpy(h).to(dev).requires_grad_(True)
+    loss = ops.gcn_head(tip, tsr, th, lin, tl, n_valid, seed_t, -100, "mean", spec, tr)
+    (loss * 3.0).backward()
+    assert np.abs(lin.weight.grad.cpu().numpy() - 6.0 * want[3]).max() < TOL * 6 * max(1e-3, np.abs(want[3]).max()) * max(1.0, float(scale))
+    # and the unfused ops of the library agree
+    lin.zero_grad()
+    th2 = torch.from_numpy(h).to(dev).requires_grad_(True)
+    agg = ops.block_aggregate(tip, tsr, th2, n_dst, "mean", dropout=spec, transpose=tr)
+    l2 = ops.cross_entropy(torch.nn.functional.linear(agg, lin.weight, lin.bias), tl)
+    l2.backward(seed_t)
+    assert abs(float(l2) - results[0][0]) < 1e-5 * max(1.0, abs(float(l2)))
+    assert np.abs(th2.grad.cpu().numpy() - results[0][2]).max() < TOL * max(1e-3, np.abs(results[0][2]).max())
+
+
+@pytest.mark.gpu
+def test_gcn_forward_loss_matches_forward_plus_loss(dev, hiplib):
+    """GCNSampling.forward_loss == CrossEntropyLoss(model(nf)) in value and in every parameter gradient, with
+    dropout (same step counter) and without; inference models and CPU labels decline (None)."""
+    from pagraph_amd import ops
+    from pagraph_amd.data import synthetic as syn
+    from pagraph_amd.model import GCNSampling, GCNInfer
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    V, E, B, Fd, C = 30000, 300000, 1500, 64, 11
+    ip, ix = syn.rmat_graph(V, E, seed=8, device=dev)
+    g = DeviceGraph.from_csc(ip, ix, V)
+    smp = NeighborSampler(g, B, 2, neighbor_type='in', num_hops=2, seed_nodes=torch.arange(2 * B, device=dev), seed=1)
+    nf = next(iter(smp))
+    feats = syn.random_features_device(V, Fd, seed=2, device=dev)
+    labels = torch.randint(0, C, (nf.layer_size(-1),), device=dev)
+    labels[::7] = -100
+    n_valid = (labels != -100).sum().to(torch.int32).reshape(1)
+    for pdrop in (0.0, 0.5):
+        torch.manual_seed(3)
+        model = GCNSampling(Fd, 16, C, 1, torch.relu, pdrop).to(dev).train()
+
+        def load():
+            for i in range(nf.num_layers):
+                nf.layers[i].data.clear()
+            nf.layers[0].data['features'] = feats[nf.layer_parent_nid(0)]
+
+        load()
+        model._drop_step.fill_(10)
+        ref = ops.cross_entropy(model(nf), labels)
+        ref.backward()
+        gref = [p.grad.clone() for p in model.parameters()]
+        model.zero_grad()
+        load()
+        model._drop_step.fill_(10)
+        out = model.forward_loss(nf, labels, n_valid, None, -100, want_logits=True)
+        assert out is not None
+        loss, logits = out
+        loss.backward()
+        assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+        for p, gr in zip(model.parameters(), gref):
+            assert float((p.grad - gr).abs().max()) < TOL * max(1e-3, float(gr.abs().max()))
+    infer = GCNInfer(Fd, 16, C, 1, torch.relu).to(dev)
+    load()
+    assert infer.forward_loss(nf, labels, n_valid) is None
+    assert model.forward_loss(nf, labels.cpu(), n_valid) is None
