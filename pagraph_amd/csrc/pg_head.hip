@@ -35,26 +35,37 @@ __device__ __forceinline__ float hw_sum(float v) {
   return v;
 }
 
+// RPW = destination rows per wave; the host picks the smallest that keeps the launch within one round of
+// resident blocks (the per-block costs — staging W, reducing the partial sums — are amortised over 4 * RPW rows).
+template <int kHeadRows>
 __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ indptr, const int32_t* __restrict__ src,
                                                   const float* __restrict__ h, int32_t h_stride, int32_t K,
                                                   const float* __restrict__ W, const float* __restrict__ bias,
                                                   int32_t C, const int64_t* __restrict__ labels,
                                                   int64_t ignore_index, const int32_t* __restrict__ n_valid_dev,
-                                                  const float* __restrict__ grad_scale_dev, HeadDrop d, int reduce, int64_t n_dst,
-                                                  float* __restrict__ logits, float* __restrict__ dagg,
-                                                  float* __restrict__ part, int32_t rows_per_wave) {
-  __shared__ __attribute__((aligned(16))) float s_agg[4][kHeadMax];
+                                                  const float* __restrict__ grad_scale_dev, HeadDrop d, int reduce,
+                                                  int64_t n_dst, float* __restrict__ logits,
+                                                  float* __restrict__ dagg, float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float s_rows[4][kHeadRows][kHeadMax];   // the waves' aggregated rows
+  __shared__ int s_lab[4][kHeadRows];
   __shared__ __attribute__((aligned(16))) float s_dl[4][kHeadMax];
-  __shared__ float s_red[kHeadMax * kHeadMax + kHeadMax + 1];
+  // W staged with coalesced loads, zero padded to 64 x 64, row stride 65 (conflict-free row AND column reads);
+  // the block's partial sums laid out [k][class] so that the 64 lanes of a wave hit 64 banks
+  __shared__ float s_w[kHeadMax * (kHeadMax + 1)];
+  __shared__ float s_big[kHeadMax * kHeadMax + 2 * kHeadMax];
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
   const int64_t wave_g = (int64_t)blockIdx.x * 4 + w;
   const bool is_c = lane < C, is_k = lane < K;
+  for (int t = threadIdx.x; t < kHeadMax * (kHeadMax + 1); t += 256) s_w[t] = 0.f;
+  __syncthreads();
+  for (int t = threadIdx.x; t < C * K; t += 256) s_w[(t / K) * (kHeadMax + 1) + (t % K)] = W[t];
+  __syncthreads();
   // W row of class `lane` and W column of input `lane`, zero padded to 64
-  float wrow[kHeadMax], wcol[kHeadMax], accw[kHeadMax];
+  // (the column stays in LDS: three 64-register arrays per lane would leave one wave per SIMD)
+  float wrow[kHeadMax], accw[kHeadMax];
 #pragma unroll
   for (int k = 0; k < kHeadMax; ++k) {
-    wrow[k] = (is_c && k < K) ? W[(int64_t)lane * K + k] : 0.f;
-    wcol[k] = (is_k && k < C) ? W[(int64_t)k * K + lane] : 0.f;
+    wrow[k] = s_w[lane * (kHeadMax + 1) + k];
     accw[k] = 0.f;
   }
   const float bz = (is_c && bias) ? bias[lane] : 0.f;
@@ -65,45 +76,79 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
   const int piece = lane >> 2, j4 = lane & 3;
   const uint32_t q = (uint32_t)(((piece >> 7) << 6) | (piece & 63));
   const int half = (piece >> 6) & 1;
-  float accb = 0.f, lsum = 0.f;
-  for (int it = 0; it < rows_per_wave; ++it) {          // same trip count for every wave: barriers inside
-    const int64_t v = wave_g * rows_per_wave + it;
+  // phase 1: aggregate the wave's rows. Software-pipelined by hand: all rows' indptr loads, then all rows'
+  // first two source ids, then all rows' feature loads are issued together — three memory round trips for
+  // the wave instead of three per row (a data-dependent edge loop per row serialises them: 21 us of 32).
+  int64_t lab[kHeadRows];
+  int32_t beg[kHeadRows], end[kHeadRows], s0[kHeadRows], s1[kHeadRows];
+#pragma unroll
+  for (int it = 0; it < kHeadRows; ++it) {
+    const int64_t v = wave_g * kHeadRows + it;
     const bool live = v < n_dst;
+    beg[it] = live ? indptr[v] : 0;
+    end[it] = live ? indptr[v + 1] : 0;
+    lab[it] = live ? labels[v] : ignore_index;
+  }
+#pragma unroll
+  for (int it = 0; it < kHeadRows; ++it) {
+    s0[it] = beg[it] < end[it] ? src[beg[it]] : -1;
+    s1[it] = beg[it] + 1 < end[it] ? src[beg[it] + 1] : -1;
+  }
+  float x0[kHeadRows], x1[kHeadRows];
+#pragma unroll
+  for (int it = 0; it < kHeadRows; ++it) {
+    x0[it] = (s0[it] >= 0 && is_k) ? h[(int64_t)s0[it] * h_stride + lane] : 0.f;
+    x1[it] = (s1[it] >= 0 && is_k) ? h[(int64_t)s1[it] * h_stride + lane] : 0.f;
+  }
+  auto dropped = [&](int32_t sr, float x) {
+    if (!d.thr) return x;
+    uint32_t o[4];
+    Philox::gen((uint32_t)sr, q, d.tag, step, d.k0, d.k1, o);
+    const uint32_t wd = (j4 >> 1) ? (half ? o[3] : o[1]) : (half ? o[2] : o[0]);
+    const uint32_t u = (j4 & 1) ? (wd >> 16) : (wd & 0xffffu);
+    return u >= d.thr ? x * d.scale : 0.f;
+  };
+#pragma unroll
+  for (int it = 0; it < kHeadRows; ++it) {
     float a = 0.f;
-    if (live && is_k) {
-      const int32_t beg = indptr[v], end = indptr[v + 1];
-      for (int32_t e = beg; e < end; ++e) {
+    if (is_k) {
+      if (s0[it] >= 0) a += dropped(s0[it], x0[it]);
+      if (s1[it] >= 0) a += dropped(s1[it], x1[it]);
+      for (int32_t e = beg[it] + 2; e < end[it]; ++e) {     // fan-out > 2: the rest of the row, one by one
         const int32_t sr = src[e];
-        float x = h[(int64_t)sr * h_stride + lane];
-        if (d.thr) {
-          uint32_t o[4];
-          Philox::gen((uint32_t)sr, q, d.tag, step, d.k0, d.k1, o);
-          const uint32_t wd = (j4 >> 1) ? (half ? o[3] : o[1]) : (half ? o[2] : o[0]);
-          const uint32_t u = (j4 & 1) ? (wd >> 16) : (wd & 0xffffu);
-          x = u >= d.thr ? x * d.scale : 0.f;
-        }
-        a += x;
+        a += dropped(sr, h[(int64_t)sr * h_stride + lane]);
       }
-      if (reduce == PG_REDUCE_MEAN && end > beg) a /= (float)(end - beg);
+      if (reduce == PG_REDUCE_MEAN && end[it] > beg[it]) a /= (float)(end[it] - beg[it]);
     }
-    s_agg[w][lane] = a;
-    __syncthreads();
+    s_rows[w][it][lane] = a;
+    if (lane == 0) {
+      const int64_t l = lab[it];
+      s_lab[w][it] = (l != ignore_index && l >= 0 && l < C) ? (int)l : -1;
+    }
+  }
+  __syncthreads();
+  float accb = 0.f, lsum = 0.f;
+#pragma unroll 1      // not unrolled: keeps the kernel at ~100 VGPRs (4 waves per SIMD) instead of 256 (one)
+  for (int it = 0; it < kHeadRows; ++it) {              // same trip count for every wave: barriers inside
+    const int64_t v = wave_g * kHeadRows + it;
+    const bool live = v < n_dst;
+    const float* arow = s_rows[w][it];
     // z[class = lane]
     float z = bz;
 #pragma unroll
     for (int k = 0; k < kHeadMax; k += 4) {
-      const float4 g = *reinterpret_cast<const float4*>(&s_agg[w][k]);
+      const float4 g = *reinterpret_cast<const float4*>(arow + k);
       z += wrow[k] * g.x + wrow[k + 1] * g.y + wrow[k + 2] * g.z + wrow[k + 3] * g.w;
     }
     if (live && is_c && logits) logits[v * C + lane] = z;
     const float m = hw_max(is_c ? z : -INFINITY);
     const float ssum = hw_sum(is_c ? expf(z - m) : 0.f);
     const float lse = m + logf(ssum);
-    const int64_t lab = live ? labels[v] : ignore_index;
-    const bool counted = live && lab != ignore_index && lab >= 0 && lab < C;
-    const float zl = __shfl(z, counted ? (int)lab : 0, kWave);
+    const int lb = s_lab[w][it];
+    const bool counted = live && lb >= 0;
+    const float zl = __shfl(z, counted ? lb : 0, kWave);
     float dl = 0.f;
-    if (counted && is_c) dl = (expf(z - lse) - (lane == (int)lab ? 1.f : 0.f)) * (inv * grad_scale);
+    if (counted && is_c) dl = (expf(z - lse) - (lane == lb ? 1.f : 0.f)) * (inv * grad_scale);
     if (counted && lane == 0) lsum += lse - zl;
     s_dl[w][lane] = dl;
     __syncthreads();
@@ -112,45 +157,54 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
 #pragma unroll
     for (int c = 0; c < kHeadMax; c += 4) {
       const float4 g = *reinterpret_cast<const float4*>(&s_dl[w][c]);
-      gk += wcol[c] * g.x + wcol[c + 1] * g.y + wcol[c + 2] * g.z + wcol[c + 3] * g.w;
+      const float* wc = s_w + c * (kHeadMax + 1) + lane;          // W[c .. c+3][lane]: consecutive banks
+      gk += wc[0] * g.x + wc[kHeadMax + 1] * g.y + wc[2 * (kHeadMax + 1)] * g.z + wc[3 * (kHeadMax + 1)] * g.w;
     }
     if (live && is_k) dagg[v * K + lane] = gk;
 #pragma unroll
     for (int k = 0; k < kHeadMax; k += 4) {
-      const float4 g = *reinterpret_cast<const float4*>(&s_agg[w][k]);
+      const float4 g = *reinterpret_cast<const float4*>(arow + k);
       accw[k] += dl * g.x; accw[k + 1] += dl * g.y; accw[k + 2] += dl * g.z; accw[k + 3] += dl * g.w;
     }
     accb += dl;
-    __syncthreads();   // s_agg / s_dl are rewritten by the next row
+    __syncthreads();   // s_dl is rewritten by the next row
   }
-  // block partial: the four waves add into s_red one after the other (fixed order)
-  const int len = C * K + C + 1;
+  // block partial: the four waves add into s_big[k][class] one after the other (fixed order)
+  float* s_b = s_big + kHeadMax * kHeadMax;            // [class] bias sums, then the loss
   for (int wv = 0; wv < 4; ++wv) {
     if (w == wv) {
-      if (is_c) {
 #pragma unroll
-        for (int k = 0; k < kHeadMax; ++k)
-          if (k < K) s_red[lane * K + k] = (wv ? s_red[lane * K + k] : 0.f) + accw[k];
-        s_red[C * K + lane] = (wv ? s_red[C * K + lane] : 0.f) + accb;
-      }
-      if (lane == 0) s_red[C * K + C] = (wv ? s_red[C * K + C] : 0.f) + lsum * inv;
+      for (int k = 0; k < kHeadMax; ++k) s_big[k * kHeadMax + lane] = (wv ? s_big[k * kHeadMax + lane] : 0.f) + accw[k];
+      s_b[lane] = (wv ? s_b[lane] : 0.f) + accb;
+      if (lane == 0) s_b[kHeadMax] = (wv ? s_b[kHeadMax] : 0.f) + lsum * inv;
     }
     __syncthreads();
   }
+  const int len = C * K + C + 1;
   float* mine = part + (int64_t)blockIdx.x * len;
-  for (int t = threadIdx.x; t < len; t += 256) mine[t] = s_red[t];
+  for (int t = threadIdx.x; t < len; t += 256) {
+    float val;
+    if (t < C * K) val = s_big[(t % K) * kHeadMax + (t / K)];
+    else if (t < C * K + C) val = s_b[t - C * K];
+    else val = s_b[kHeadMax];
+    mine[t] = val;
+  }
 }
 
 }  // namespace pg
 
 using namespace pg;
 
+static int head_rows(int64_t n_dst) {
+  for (int r : {1, 2, 4}) if (ceil_div<int64_t>(n_dst, 4 * r) <= 512) return r;   // 2 blocks per CU resident (~200 VGPRs)
+  return 8;
+}
+
 extern "C" {
 
 int64_t pg_gcn_head_scratch(int64_t n_dst, int32_t K, int32_t C) {
   if (n_dst <= 0 || K <= 0 || C <= 0) return 0;
-  const int rpw = 4;
-  return ceil_div<int64_t>(n_dst, 4 * rpw) * ((int64_t)C * K + C + 1);
+  return ceil_div<int64_t>(n_dst, 4 * head_rows(n_dst)) * ((int64_t)C * K + C + 1);
 }
 
 int pg_gcn_head(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
@@ -170,11 +224,17 @@ int pg_gcn_head(const int32_t* indptr, const int32_t* src, const float* h, int32
     d.step = drop->step;
     d.scale = 65536.f / (float)(65536u - drop->threshold);
   }
-  const int rpw = 4;
+  const int rpw = head_rows(n_dst);
   const int64_t blocks = ceil_div<int64_t>(n_dst, 4 * rpw);
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(k_gcn_head, dim3((unsigned)blocks), dim3(256), 0, st, indptr, src, h, h_stride, K, W, bias, C,
-                     labels, ignore_index, n_valid_dev, grad_scale_dev, d, reduce, n_dst, logits, dagg, partials, rpw);
+#define PG_HEAD(R)                                                                                                   \
+  hipLaunchKernelGGL(k_gcn_head<R>, dim3((unsigned)blocks), dim3(256), 0, st, indptr, src, h, h_stride, K, W, bias, C, \
+                     labels, ignore_index, n_valid_dev, grad_scale_dev, d, reduce, n_dst, logits, dagg, partials)
+  if (rpw == 1) PG_HEAD(1);
+  else if (rpw == 2) PG_HEAD(2);
+  else if (rpw == 4) PG_HEAD(4);
+  else PG_HEAD(8);
+#undef PG_HEAD
   PG_LAUNCH_CHECK();
   // dW [C*K], then db [C] and the loss (db_loss[C]) contiguous behind it in the partial layout
   return pg_sum_partials(partials, (int32_t)blocks, (int64_t)C * K, C + 1, dW, db_loss, stream);
