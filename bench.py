@@ -63,7 +63,8 @@ def parse():
     p.add_argument("--num-neighbors", type=int, default=2)
     p.add_argument("--cache-ratio", type=float, default=0.30)
     p.add_argument("--miss-mode", default="async", choices=["staged", "zerocopy", "async"])
-    p.add_argument("--host-threads", type=int, default=32)
+    p.add_argument("--host-threads", type=int, default=None, help="threads of the miss path's CPU row gather "
+                   "(default: from the process's CPU quota, see storage.default_host_threads)")
     p.add_argument("--no-overlap", action="store_true")
     p.add_argument("--skip-cpu-baseline", action="store_true")
     p.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
@@ -287,6 +288,7 @@ def run():
     from pagraph_amd.partition.utils import closure_device
     from pagraph_amd.sampling import DeviceGraph, NeighborSampler
     from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    from pagraph_amd.storage.storage import default_host_threads
     from pagraph_amd.trainer import GraphedTrainer, MinibatchTrainer, cycle_batches
     L.load()
 
@@ -344,7 +346,8 @@ def run():
         fields["norm"] = norm_tab
         embed_names = ["features", "norm"]                    # pa_gcn.py:46
     store = HostFeatureStore(fields, pin=False)               # both tables are already pinned / registered
-    cacher = GraphCacheServer(store, Vs, sub2full, gpu, miss_mode=args.miss_mode, host_threads=args.host_threads)
+    cacher = GraphCacheServer(store, Vs, sub2full, gpu, miss_mode=args.miss_mode,
+                              host_threads=args.host_threads or default_host_threads(world))
     cacher.init_field(embed_names)
     cacher.log = True
     D = cacher.total_dim

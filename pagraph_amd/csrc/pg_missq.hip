@@ -63,73 +63,98 @@ __global__ void k_wait_landed(const uint32_t* landed, uint32_t seq, uint32_t* ti
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
-// minimal persistent thread pool: parallel_for over [0, n) in contiguous chunks
+// Persistent thread pool for the miss path's row gather: parallel_for over [0, n) in chunks of kChunk rows
+// that the threads CLAIM from an atomic counter. A job arrives every ~0.25 ms and is ~50-100 us of work, so
+// how fast the threads start matters as much as how fast they copy: after a job they spin on the generation
+// counter for PG_MISSQ_SPIN_US microseconds (default 100) before they sleep on a condition variable. Keep the
+// thread count well under the CPU quota of the process (the GPU boxes give 16 CPUs: 31 spinning threads
+// starved the launch thread and the step got 2x slower; 8 are fine).
 class Pool {
  public:
+  static constexpr int64_t kChunk = 32;
   explicit Pool(int n) : n_(n < 1 ? 1 : n) {
-    for (int i = 1; i < n_; ++i) th_.emplace_back([this, i] { loop(i); });
+    const char* e = getenv("PG_MISSQ_SPIN_US");
+    spin_us_ = e ? atoi(e) : 100;
+    for (int i = 1; i < n_; ++i) th_.emplace_back([this] { loop(); });
   }
   ~Pool() {
+    stop_.store(true, std::memory_order_release);
+    gen_.fetch_add(1, std::memory_order_release);
     {
       std::lock_guard<std::mutex> l(m_);
-      stop_ = true;
-      ++gen_;
     }
     cv_.notify_all();
     for (auto& t : th_) t.join();
   }
   void parallel_for(int64_t n, const std::function<void(int64_t, int64_t)>& f) {
     if (n <= 0) return;
-    const int parts = (int)std::min<int64_t>(n_, (n + 127) / 128);
-    if (parts <= 1) {
+    const int64_t chunks = (n + kChunk - 1) / kChunk;
+    if (chunks <= 1 || n_ == 1) {
       f(0, n);
       return;
     }
-    {
-      std::lock_guard<std::mutex> l(m_);
-      fn_ = &f;
-      total_ = n;
-      parts_ = parts;
-      pending_ = parts - 1;
-      ++gen_;
+    // publish order: job description, then the counters, then the generation (workers acquire on left_)
+    fn_ = &f;
+    total_ = n;
+    done_.store(0, std::memory_order_relaxed);
+    left_.store(chunks, std::memory_order_release);
+    gen_.fetch_add(1, std::memory_order_release);
+    if (sleepers_.load(std::memory_order_acquire) > 0) {
+      {
+        std::lock_guard<std::mutex> l(m_);
+      }
+      cv_.notify_all();
     }
-    cv_.notify_all();
-    run_part(0);
-    std::unique_lock<std::mutex> l(m_);
-    done_cv_.wait(l, [this] { return pending_ == 0; });
+    work();
+    while (done_.load(std::memory_order_acquire) < chunks) cpu_relax();
+    // every chunk has been executed. The claim counter counts DOWN, so a straggler's claim is valid or not
+    // by its sign alone — it never compares against a chunk count that the next job may have replaced.
   }
 
  private:
-  void run_part(int i) {
-    const int64_t per = (total_ + parts_ - 1) / parts_;
-    const int64_t lo = std::min<int64_t>(total_, i * per), hi = std::min<int64_t>(total_, (i + 1) * per);
-    if (hi > lo) (*fn_)(lo, hi);
-  }
-  void loop(int i) {
-    uint64_t seen = 0;
+  static inline void cpu_relax() { __builtin_ia32_pause(); }
+  void work() {
     for (;;) {
-      std::unique_lock<std::mutex> l(m_);
-      cv_.wait(l, [&] { return gen_ != seen; });
-      seen = gen_;
-      if (stop_) return;
-      const bool mine = i < parts_;
-      l.unlock();
-      if (mine) {
-        run_part(i);
-        std::lock_guard<std::mutex> g(m_);
-        if (--pending_ == 0) done_cv_.notify_one();
+      const int64_t c = left_.fetch_sub(1, std::memory_order_acq_rel) - 1;
+      if (c < 0) return;
+      const int64_t lo = c * kChunk, hi = std::min<int64_t>(total_, lo + kChunk);
+      (*fn_)(lo, hi);
+      done_.fetch_add(1, std::memory_order_acq_rel);
+    }
+  }
+  void loop() {
+    uint64_t seen = gen_.load(std::memory_order_acquire);
+    for (;;) {
+      const auto t0 = std::chrono::steady_clock::now();
+      uint64_t g;
+      int polls = 0;
+      while ((g = gen_.load(std::memory_order_acquire)) == seen) {
+        cpu_relax();
+        if ((++polls & 63) == 0 &&
+            std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >=
+                spin_us_) {
+          std::unique_lock<std::mutex> l(m_);
+          sleepers_.fetch_add(1, std::memory_order_acq_rel);
+          cv_.wait(l, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+          sleepers_.fetch_sub(1, std::memory_order_acq_rel);
+        }
       }
+      seen = g;
+      if (stop_.load(std::memory_order_acquire)) return;
+      work();
     }
   }
   int n_;
+  int spin_us_ = 100;
   std::vector<std::thread> th_;
   std::mutex m_;
-  std::condition_variable cv_, done_cv_;
+  std::condition_variable cv_;
   const std::function<void(int64_t, int64_t)>* fn_ = nullptr;
   int64_t total_ = 0;
-  int parts_ = 0, pending_ = 0;
-  uint64_t gen_ = 0;
-  bool stop_ = false;
+  std::atomic<int64_t> left_{0}, done_{0};
+  std::atomic<uint64_t> gen_{0};
+  std::atomic<int> sleepers_{0};
+  std::atomic<bool> stop_{false};
 };
 
 }  // namespace pg
@@ -219,8 +244,16 @@ static void missq_worker(pg_missq* q) {
         const int64_t* ids = s.fullid_h;
         const auto ta = now();
         q->pool->parallel_for(m, [&](int64_t lo, int64_t hi) {   // storage.py:128 table[nids]
-          for (int64_t j = lo; j < hi; ++j)
+          for (int64_t j = lo; j < hi; ++j) {
+            if (j + 2 < hi) {   // rows are random DRAM pages: start the one after next while this one streams
+              const char* nx = reinterpret_cast<const char*>(fd.table + ids[j + 2] * fd.table_stride);
+              __builtin_prefetch(nx);
+              __builtin_prefetch(nx + 64);
+              __builtin_prefetch(nx + 128);
+              __builtin_prefetch(nx + 192);
+            }
             std::memcpy(stg + j * fd.dim, fd.table + ids[j] * fd.table_stride, row_bytes);
+          }
         });
         const auto tb = now();
         tg += us(ta, tb);
