@@ -216,13 +216,15 @@ def gather_microbench(cacher, g, dev, rows_list=(42000, 1 << 20)):
     names = list(cacher.dims)
     D = sum(cacher.dims.values())
     cached_ids = torch.nonzero(cacher.slot_map >= 0).squeeze(1)
-    w = g.out_degrees()[cached_ids].float() + 1.0
+    # degree-proportional draw by inverse CDF (torch.multinomial stops at 2^24 categories; config 5 caches 24.5 M rows)
+    cdf = torch.cumsum(g.out_degrees()[cached_ids].double() + 1.0, 0)
     gen = torch.Generator(device=dev).manual_seed(0)
     res = {}
     stream = torch.cuda.current_stream(dev)
     sp = L.stream_ptr(stream)
     for R in rows_list:
-        ids = cached_ids[torch.multinomial(w, R, replacement=True, generator=gen)].contiguous()
+        u = torch.rand(R, dtype=torch.float64, device=dev, generator=gen) * cdf[-1]
+        ids = cached_ids[torch.searchsorted(cdf, u).clamp_(max=cached_ids.numel() - 1)].contiguous()
         out = {n: torch.empty((R, cacher.dims[n]), dtype=torch.float32, device=dev) for n in names}
         mpos = torch.empty(R, dtype=torch.int32, device=dev)
         mfull = torch.empty(R, dtype=torch.int64, device=dev)
@@ -328,6 +330,10 @@ def run():
     del g_full, indptr, indices
     torch.cuda.empty_cache()
     g = DeviceGraph.from_csc(sub_indptr, sub_indices, Vs)
+    # the reference's cache-size rule (storage.py:70-84) subtracts the PEAK allocation; building the synthetic
+    # graph on the GPU is not part of the trainer process it was written for
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(dev)
     log(f"[bench] rank {rank}: closure V_sub={Vs} nnz_sub={sub_indices.numel()} train={subtrain.numel()} in {time.time()-t0:.1f}s")
     # labels in local-id space (pa_gcn.py:38-41)
     labels = torch.zeros(int(subtrain.max().item()) + 1, dtype=torch.int64, device=dev)

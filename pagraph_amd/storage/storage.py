@@ -170,7 +170,9 @@ class GraphCacheServer:
         peak_cached_mem = torch.cuda.max_memory_reserved(device=self.device)
         total_mem = torch.cuda.get_device_properties(self.device).total_memory
         available = total_mem - peak_allocated_mem - peak_cached_mem - 1024 * 1024 * 1024
-        self.capability = int(available / (self.total_dim * 4))
+        self.capability = max(0, int(available / (self.total_dim * 4)))   # the rule goes negative when the peaks
+        # (which count freed set-up memory, and count it twice) exceed the device: cache nothing then, do not
+        # slice from the end of the degree order
         if cache_ratio is not None:
             self.capability = min(self.capability, int(self.node_num * cache_ratio))
         print('Cache Memory: {:.2f}G. Capability: {}'.format(available / 1024 / 1024 / 1024, self.capability))
