@@ -78,6 +78,8 @@ def parse():
     p.add_argument("--ring", type=int, default=None, help="sampler ring slots (in-flight minibatches)")
     p.add_argument("--no-graph", action="store_true", help="eager reference-style loop instead of hipGraph replay")
     p.add_argument("--timeline", action="store_true", help="print a per-stream event timeline of a few steps (stderr)")
+    p.add_argument("--no-transpose", action="store_true", help="sampler does not emit source-major blocks "
+                   "(backward aggregation falls back to the atomic scatter form)")
     p.add_argument("--lookahead", type=int, default=None, help="batches prepared ahead of the one being computed "
                    "(default 2 with the async miss queue, else 1); the sampler ring needs lookahead + 2 slots")
     p.add_argument("--profile-host", action="store_true", help="cProfile the timed region (stderr)")
@@ -377,7 +379,8 @@ def run():
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu])
     sampler = NeighborSampler(g, B, k, neighbor_type='in', shuffle=True, num_workers=16, num_hops=num_hops,
                               seed_nodes=subtrain, prefetch=True, seed=rank, copy_out=True, static=use_graph,
-                              ring=args.ring if args.ring else (args.lookahead + 2 if args.lookahead else None))
+                              ring=args.ring if args.ring else (args.lookahead + 2 if args.lookahead else None),
+                              transpose=None if args.no_transpose else 'auto')
     steps_per_epoch = parallel.equalize_steps(len(sampler), device=dev)
     K = args.steps if args.steps is not None else 400
     W = args.warmup

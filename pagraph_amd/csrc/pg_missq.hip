@@ -223,12 +223,18 @@ static void missq_worker(pg_missq* q) {
     if (hipEventSynchronize(s.filled) != hipSuccess) rc = PG_ERR_HIP;
     const auto t1 = now();
     // wait for the GPU to publish the miss list of this submission
-    while (__atomic_load_n(s.flag_h, __ATOMIC_ACQUIRE) != job.second) {
-      {
-        std::lock_guard<std::mutex> l(q->m);
-        if (q->stop) return;
+    // poll: the list arrives 50-150 us after the job was queued. sleep_for(5 us) really sleeps ~55 us (timer
+    // slack), a whole extra stage of latency per minibatch, so spin first and only fall back to sleeping
+    // when nothing has come for a millisecond (idle queue).
+    for (int64_t spins = 0; __atomic_load_n(s.flag_h, __ATOMIC_ACQUIRE) != job.second; ++spins) {
+      if ((spins & 1023) == 1023) {
+        {
+          std::lock_guard<std::mutex> l(q->m);
+          if (q->stop) return;
+        }
+        if (us(t1, now()) > 1000.0) std::this_thread::sleep_for(std::chrono::microseconds(50));
       }
-      std::this_thread::sleep_for(std::chrono::microseconds(5));
+      __builtin_ia32_pause();
     }
     const int64_t m = *s.count_h;
     const auto t2 = now();

@@ -155,3 +155,63 @@ def test_wrapped_batches():
     from pagraph_amd.parallel import wrapped_batches
     assert wrapped_batches(3, 5) == [0, 1, 2, 0, 1]
     assert wrapped_batches(0, 2) == [0, 0]
+
+
+def test_default_host_threads_respects_the_cpu_quota(monkeypatch, tmp_path):
+    """the miss path's gather pool is sized from what the process may really use, split between ranks"""
+    import builtins
+    import os
+    from pagraph_amd.storage import storage as st
+    real_open = builtins.open
+
+    def fake(quota):
+        def _open(path, *a, **k):
+            if path == "/sys/fs/cgroup/cpu.max":
+                f = tmp_path / "cpu.max"
+                f.write_text(quota)
+                return real_open(f, *a, **k)
+            return real_open(path, *a, **k)
+        return _open
+
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)), raising=False)
+    monkeypatch.setattr(builtins, "open", fake("1600000 100000\n"))
+    assert st.default_host_threads() == 12             # 16-CPU quota on a 256-core box
+    assert st.default_host_threads(8) == 2             # eight ranks share it
+    monkeypatch.setattr(builtins, "open", fake("max 100000\n"))
+    assert st.default_host_threads() == 16             # no quota: capped
+    assert st.default_host_threads(8) == 16
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(8)), raising=False)
+    assert st.default_host_threads() == 4
+
+
+def test_fused_loss_only_replaces_the_plain_cross_entropy():
+    import torch
+    from pagraph_amd import ops
+    assert isinstance(ops.fused_loss(torch.nn.CrossEntropyLoss()), ops.CrossEntropyLoss)
+    assert ops.fused_loss(torch.nn.CrossEntropyLoss(ignore_index=7)).ignore_index == 7
+    for other in (torch.nn.CrossEntropyLoss(reduction="sum"), torch.nn.CrossEntropyLoss(weight=torch.ones(3)),
+                  torch.nn.CrossEntropyLoss(label_smoothing=0.1), torch.nn.NLLLoss()):
+        assert ops.fused_loss(other) is other
+
+
+def test_gpu_only_ops_refuse_cpu_tensors(hiplib):
+    """no CPU fallback: the HIP-backed ops fail loudly on host tensors instead of computing something else"""
+    import pytest
+    import torch
+    from pagraph_amd import _lib, ops
+    from pagraph_amd.optim import Adam
+    with pytest.raises(_lib.PgError):
+        ops.cross_entropy(torch.zeros(4, 3), torch.zeros(4, dtype=torch.int64))
+    with pytest.raises(_lib.PgError):
+        ops.block_aggregate(torch.zeros(2, dtype=torch.int32), torch.zeros(1, dtype=torch.int32), torch.zeros(3, 4), 1)
+    p = torch.nn.Parameter(torch.zeros(3))
+    p.grad = torch.ones(3)
+    with pytest.raises(_lib.PgError):
+        Adam([p]).step()
+    lin = torch.nn.Linear(8, 4)
+    assert ops.gcn_head(None, None, torch.zeros(5, 8), lin, torch.zeros(2, dtype=torch.int64), None) is None
+    # small / CPU inputs of the dense wrappers go through the module itself
+    y = ops.linear(torch.ones(3, 8), lin)
+    assert torch.allclose(y, lin(torch.ones(3, 8)))
+    y2 = ops.linear2(torch.ones(3, 8), lin, torch.ones(3, 8), lin, ops.ACT_RELU)
+    assert torch.allclose(y2, torch.relu(2 * lin(torch.ones(3, 8))))
