@@ -210,9 +210,10 @@ def cpu_baseline(args, g, sub2full_h, seeds_h, feat_tab, norm_tab, labels_dense_
 
 
 # ----------------------------------------------------------------------------- gather micro-benchmark
-def gather_microbench(cacher, g, dev, rows_list=(42000, 1 << 20)):
-    """cached-feature gather (all hits) at the real step shape and at >= 1M rows; ids drawn
-    degree-proportionally from the cached set (seed 0). HIP events on the launch stream."""
+def gather_microbench(cacher, g, dev, rows_list=(42000, 1 << 18, 1 << 20, 1 << 22)):
+    """cached-feature gather (all hits) at the sizes SURVEY 8d names — the real step shape, 262 144, 1 048 576
+    and 4 194 304 rows — ids drawn (i) degree-proportionally and (ii) uniformly from the cached set (seed 0).
+    HIP events attached to each dispatch on the launch stream. Keys: rows (degree-proportional), (rows, 'uniform')."""
     from pagraph_amd import _lib as L
     lib = L.load()
     names = list(cacher.dims)
@@ -224,9 +225,12 @@ def gather_microbench(cacher, g, dev, rows_list=(42000, 1 << 20)):
     res = {}
     stream = torch.cuda.current_stream(dev)
     sp = L.stream_ptr(stream)
-    for R in rows_list:
-        u = torch.rand(R, dtype=torch.float64, device=dev, generator=gen) * cdf[-1]
-        ids = cached_ids[torch.searchsorted(cdf, u).clamp_(max=cached_ids.numel() - 1)].contiguous()
+    for R, dist_name in [(R, d) for R in rows_list for d in ("degree", "uniform")]:
+        if dist_name == "degree":
+            u = torch.rand(R, dtype=torch.float64, device=dev, generator=gen) * cdf[-1]
+            ids = cached_ids[torch.searchsorted(cdf, u).clamp_(max=cached_ids.numel() - 1)].contiguous()
+        else:
+            ids = cached_ids[torch.randint(0, cached_ids.numel(), (R,), device=dev, generator=gen)].contiguous()
         out = {n: torch.empty((R, cacher.dims[n]), dtype=torch.float32, device=dev) for n in names}
         mpos = torch.empty(R, dtype=torch.int32, device=dev)
         mfull = torch.empty(R, dtype=torch.int64, device=dev)
@@ -251,7 +255,8 @@ def gather_microbench(cacher, g, dev, rows_list=(42000, 1 << 20)):
         assert int(mcnt.item()) == 0
         avg = float(np.mean(ms))
         bytes_ = R * (8 * D + 17)
-        res[R] = {"rows": R, "avg_ms": avg, "GBps": bytes_ / avg / 1e6, "frac": bytes_ / avg / 1e6 / HBM_PEAK_GBPS}
+        res[R if dist_name == "degree" else (R, "uniform")] = {
+            "rows": R, "ids": dist_name, "avg_ms": avg, "GBps": bytes_ / avg / 1e6, "frac": bytes_ / avg / 1e6 / HBM_PEAK_GBPS}
         del out
     return res
 
@@ -508,8 +513,9 @@ def run():
     micro = None
     if not args.skip_microbench and rank == 0 and cacher.cached_num > 0 and not cacher.full_cached:
         micro = gather_microbench(cacher, g, dev)
-        roofline["large"] = micro[max(micro)]
-        roofline["step_shape_all_hits"] = micro[min(micro)]
+        roofline["large"] = micro[1 << 20]
+        roofline["step_shape_all_hits"] = micro[42000]
+        roofline["sizes"] = [micro[k] for k in sorted(micro, key=lambda k: (k[0], 1) if isinstance(k, tuple) else (k, 0))]
 
     opt_hit = deg_hit = None
     if rank == 0 and not args.skip_opt_hit:
@@ -547,7 +553,7 @@ def run():
                        "fetch": "all layers+fields (reference)" if need is None else "only what the model reads"},
             "cache_hit_pct": 100.0 * (1.0 - miss_rate),
             "cache_hit_oracle_upper_bound_pct": opt_hit, "cache_hit_degree_policy_on_trace_pct": deg_hit,
-            "feat_gather_GBps": (micro[max(micro)]["GBps"] if micro else achieved),
+            "feat_gather_GBps": (micro[1 << 20]["GBps"] if micro else achieved),
             "seeds_per_s": seeds_total / elapsed,
             "host_issue_ms_per_step": t_issued / K * 1e3,     # launch thread's share; == ms_per_step when it is the bottleneck
             "roofline": roofline,
