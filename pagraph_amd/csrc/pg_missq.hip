@@ -63,6 +63,21 @@ __global__ void k_wait_landed(const uint32_t* landed, uint32_t seq, uint32_t* ti
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
+// One row of the host table into the pinned staging buffer. The staging buffer is only ever read by the copy
+// engine, so the stores go around the cache (movntps): no read-for-ownership of the destination lines and
+// no eviction of the gather threads' working set. Falls back to memcpy for rows that are not 16-byte multiples.
+static inline void copy_row_stream(float* dst, const float* src, size_t bytes) {
+  if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) | bytes) & 15) == 0) {
+    typedef float v4f __attribute__((vector_size(16)));
+    const v4f* s = reinterpret_cast<const v4f*>(src);
+    v4f* d = reinterpret_cast<v4f*>(dst);
+    const size_t n = bytes / 16;
+    for (size_t i = 0; i < n; ++i) __builtin_nontemporal_store(s[i], d + i);
+  } else {
+    std::memcpy(dst, src, bytes);
+  }
+}
+
 // Persistent thread pool for the miss path's row gather: parallel_for over [0, n) in chunks of kChunk rows
 // that the threads CLAIM from an atomic counter. A job arrives every ~0.25 ms and is ~50-100 us of work, so
 // how fast the threads start matters as much as how fast they copy: after a job they spin on the generation
@@ -258,8 +273,9 @@ static void missq_worker(pg_missq* q) {
               __builtin_prefetch(nx + 128);
               __builtin_prefetch(nx + 192);
             }
-            std::memcpy(stg + j * fd.dim, fd.table + ids[j] * fd.table_stride, row_bytes);
+            copy_row_stream(stg + j * fd.dim, fd.table + ids[j] * fd.table_stride, row_bytes);
           }
+          __builtin_ia32_sfence();   // the streaming stores must be globally visible before the chunk counts as done
         });
         const auto tb = now();
         tg += us(ta, tb);
