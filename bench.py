@@ -80,6 +80,8 @@ def parse():
     p.add_argument("--timeline", action="store_true", help="print a per-stream event timeline of a few steps (stderr)")
     p.add_argument("--no-transpose", action="store_true", help="sampler does not emit source-major blocks "
                    "(backward aggregation falls back to the atomic scatter form)")
+    p.add_argument("--cpu-share", type=float, default=1.0, help="async miss path: share of every miss list that goes "
+                   "through the worker thread; the rest is read by the device over PCIe (1.0 = all)")
     p.add_argument("--lookahead", type=int, default=None, help="batches prepared ahead of the one being computed "
                    "(default 2 with the async miss queue, else 1); the sampler ring needs lookahead + 2 slots")
     p.add_argument("--profile-host", action="store_true", help="cProfile the timed region (stderr)")
@@ -363,6 +365,7 @@ def run():
                               host_threads=args.host_threads or default_host_threads(world))
     cacher.init_field(embed_names)
     cacher.log = True
+    cacher.cpu_share = args.cpu_share
     D = cacher.total_dim
 
     # ---- model ------------------------------------------------------------------------------

@@ -125,6 +125,12 @@ int pg_host_gather_rows(const float* table, int64_t table_stride, int32_t dim, c
 int pg_scatter_rows_from_host(const float* table_pinned, int64_t table_stride, const int32_t* pos,
                               const int64_t* fullid, int64_t n_max, const int32_t* n_dev, int32_t dim,
                               float* out, int32_t out_stride, pg_stream_t stream);
+/* the same for rows j >= count * start_num / 256 only (count = *n_dev): the device-read tail of a miss list
+ * whose head the CPU miss queue moves (pg_missq_set_cpu_share).                                         */
+int pg_scatter_rows_from_host_tail(const float* table_pinned, int64_t table_stride, const int32_t* pos,
+                                   const int64_t* fullid, int64_t n_max, const int32_t* n_dev,
+                                   int32_t start_num, int32_t dim, float* out, int32_t out_stride,
+                                   pg_stream_t stream);
 
 /* Asynchronous miss path (storage.py:117-131,196-200 off the trainer's critical path): a worker
  * thread owned by the handle waits for the GPU to publish a slot's miss list, gathers table[fullid]
@@ -153,6 +159,10 @@ int pg_missq_wait(pg_missq_t* q, int slot, pg_stream_t stream, int32_t* miss_cou
 /* same ordering guarantee without ever blocking the host: a one-wave kernel on `stream` sleeps on a device
  * flag the worker's copy stream raises after the scatter (gives up after 3 s -> pg_missq_timed_out).   */
 int pg_missq_wait_device(pg_missq_t* q, int slot, pg_stream_t stream);
+/* Split every miss list between the two paths: rows [0, count * share / 256) go through the worker (CPU gather +
+ * copy engine), the caller reads the rest over PCIe with pg_scatter_rows_from_host_tail(start_num = share) on
+ * its own stream. Default 256 = everything through the worker.                                            */
+int pg_missq_set_cpu_share(pg_missq_t* q, int32_t share_of_256);
 int pg_missq_timed_out(pg_missq_t* q, int* out);
 
 /* ------------------------------------------------------------------------

@@ -63,6 +63,8 @@ _SIGS = {
     "pg_scatter_rows": (ctypes.c_int, [vp, vp, c_i64, vp, c_i32, vp, c_i32, vp]),
     "pg_host_gather_rows": (ctypes.c_int, [vp, c_i64, c_i32, vp, c_i64, vp, ctypes.c_int]),
     "pg_scatter_rows_from_host": (ctypes.c_int, [vp, c_i64, vp, vp, c_i64, vp, c_i32, vp, c_i32, vp]),
+    "pg_scatter_rows_from_host_tail": (ctypes.c_int, [vp, c_i64, vp, vp, c_i64, vp, c_i32, c_i32, vp, c_i32, vp]),
+    "pg_missq_set_cpu_share": (ctypes.c_int, [vp, c_i32]),
     "pg_missq_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_i64, ctypes.POINTER(PgMissqField), ctypes.c_int,
                                        ctypes.c_int, ctypes.POINTER(vp)]),
     "pg_missq_destroy": (ctypes.c_int, [vp]),

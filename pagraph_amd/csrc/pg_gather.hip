@@ -216,13 +216,15 @@ __global__ __launch_bounds__(256) void k_scatter_host(const float* __restrict__ 
                                                       const int32_t* __restrict__ pos,
                                                       const int64_t* __restrict__ fullid, int64_t n,
                                                       const int32_t* __restrict__ n_dev, int32_t dim,
-                                                      float* __restrict__ out, int32_t out_stride) {
+                                                      float* __restrict__ out, int32_t out_stride,
+                                                      int32_t start_num) {
   using V = typename VecT<VEC>::type;
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t nn = n_dev ? (int64_t)*n_dev : n;
+  const int64_t j0 = nn * start_num / 256;      // rows [0, j0) belong to the CPU worker (pg_missq_set_cpu_share)
   const int64_t waves = (int64_t)gridDim.x * (blockDim.x / kWave);
   const int pieces = dim / VEC;
-  for (int64_t j = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; j < nn; j += 2 * waves) {
+  for (int64_t j = j0 + (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; j < nn; j += 2 * waves) {
     const int64_t j2 = j + waves;
     const bool two = j2 < nn;
     const V* src0 = reinterpret_cast<const V*>(table + fullid[j] * table_stride);
@@ -437,7 +439,15 @@ int pg_scatter_rows(const float* staged, const int32_t* pos, int64_t n, const in
 int pg_scatter_rows_from_host(const float* table, int64_t table_stride, const int32_t* pos,
                               const int64_t* fullid, int64_t n_max, const int32_t* n_dev, int32_t dim,
                               float* out, int32_t out_stride, pg_stream_t stream) {
-  if (n_max < 0 || dim <= 0 || out_stride < dim || table_stride < dim) return PG_ERR_INVALID;
+  return pg_scatter_rows_from_host_tail(table, table_stride, pos, fullid, n_max, n_dev, 0, dim, out, out_stride,
+                                        stream);
+}
+
+int pg_scatter_rows_from_host_tail(const float* table, int64_t table_stride, const int32_t* pos,
+                                   const int64_t* fullid, int64_t n_max, const int32_t* n_dev, int32_t start_num,
+                                   int32_t dim, float* out, int32_t out_stride, pg_stream_t stream) {
+  if (n_max < 0 || dim <= 0 || out_stride < dim || table_stride < dim || start_num < 0 || start_num > 256)
+    return PG_ERR_INVALID;
   if (n_max == 0) return PG_OK;
   if (!table || !pos || !fullid || !out) return PG_ERR_INVALID;
   hipStream_t st = as_stream(stream);
@@ -449,13 +459,13 @@ int pg_scatter_rows_from_host(const float* table, int64_t table_stride, const in
   const int grid = grid_1d(n_max, 8, kHostBlocks);
   if (dim % 4 == 0 && out_stride % 4 == 0 && table_stride % 4 == 0 && aligned(table, 16) && aligned(out, 16))
     hipLaunchKernelGGL(k_scatter_host<4>, dim3(grid), dim3(256), 0, st, table, table_stride, pos, fullid, n_max,
-                       n_dev, dim, out, out_stride);
+                       n_dev, dim, out, out_stride, start_num);
   else if (dim % 2 == 0 && out_stride % 2 == 0 && table_stride % 2 == 0 && aligned(table, 8) && aligned(out, 8))
     hipLaunchKernelGGL(k_scatter_host<2>, dim3(grid), dim3(256), 0, st, table, table_stride, pos, fullid, n_max,
-                       n_dev, dim, out, out_stride);
+                       n_dev, dim, out, out_stride, start_num);
   else
     hipLaunchKernelGGL(k_scatter_host<1>, dim3(grid), dim3(256), 0, st, table, table_stride, pos, fullid, n_max,
-                       n_dev, dim, out, out_stride);
+                       n_dev, dim, out, out_stride, start_num);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }

@@ -208,6 +208,7 @@ struct pg_missq {
   std::deque<std::pair<int, uint32_t>> jobs;
   bool stop = false;
   int error = PG_OK;
+  std::atomic<int> cpu_share{256};   // of 256: the leading share of every miss list that the CPU path moves
   // PG_MISSQ_DEBUG=1: accumulated worker phase times (us) printed at destroy
   double t_sync = 0, t_flag = 0, t_gather = 0, t_enqueue = 0, t_copy = 0, t_sub2flag = 0, t_sub2pop = 0;
   int64_t n_jobs = 0, n_rows = 0;
@@ -251,7 +252,9 @@ static void missq_worker(pg_missq* q) {
       }
       __builtin_ia32_pause();
     }
-    const int64_t m = *s.count_h;
+    const int64_t m_all = *s.count_h;
+    // rows [0, m) are this worker's; the tail is read by the device itself (pg_scatter_rows_from_host_tail)
+    const int64_t m = m_all * q->cpu_share.load(std::memory_order_relaxed) / 256;
     const auto t2 = now();
     q->t_sub2flag += us(s.t_submit, t2);
     q->t_sub2pop += us(s.t_submit, t0);
@@ -462,6 +465,12 @@ int pg_missq_wait_device(pg_missq_t* q, int slot, pg_stream_t stream) {
   if (seq == 0) return PG_OK;
   hipLaunchKernelGGL(k_wait_landed, dim3(1), dim3(1), 0, as_stream(stream), s.landed_d, seq, q->timeout_d);
   PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+int pg_missq_set_cpu_share(pg_missq_t* q, int32_t share_of_256) {
+  if (!q || share_of_256 < 0 || share_of_256 > 256) return PG_ERR_INVALID;
+  q->cpu_share.store(share_of_256, std::memory_order_relaxed);
   return PG_OK;
 }
 

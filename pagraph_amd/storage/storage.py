@@ -129,8 +129,12 @@ class GraphCacheServer:
         self._missq = None
         self._missq_rows = 0
         self._missq_bufs = {}            # slot -> (miss_pos, miss_fullid, miss_count) pointers
+        self._missq_share = None
         self._cache_epoch = 0            # bumped whenever the cache contents / layout change (invalidates fetch plans)
         self.missq_slots = 4
+        # miss_mode 'async': the leading share of every miss list goes through the worker thread (CPU gather + copy
+        # engine), the rest is read by the device over PCIe on the fetching stream; 1.0 = all through the worker
+        self.cpu_share = 1.0
 
     # -- reference-shaped views of the fused slot map --------------------------
     def _export(self):
@@ -342,6 +346,8 @@ class GraphCacheServer:
                         optrs[f] = out[name].data_ptr()
                         ostr[f] = out[name].stride(0)
                 L.check(self.lib.pg_missq_submit(self._missq, slot, optrs, ostr, sp), "pg_missq_submit")
+                if self._missq_share < 256:
+                    self._device_tail(names, out, miss_pos, miss_fullid, miss_count, R, sp)
             elif self.miss_mode == "zerocopy":
                 for name in names:
                     tab = _table(self.graph, name)
@@ -444,6 +450,8 @@ class GraphCacheServer:
             return                       # every row was a hit (the general kernel ran only for the hit counters)
         if self.miss_mode == "async":
             L.check(self.lib.pg_missq_submit(self._missq, slot, plan.optrs, plan.ostr, sp), "pg_missq_submit")
+            if self._missq_share < 256:
+                self._device_tail(plan.names, plan.out, miss_pos, miss_fullid, miss_count, R, sp)
         else:
             for name in plan.names:
                 tab = _table(self.graph, name)
@@ -451,6 +459,15 @@ class GraphCacheServer:
                 L.check(self.lib.pg_scatter_rows_from_host(
                     L.ptr(tab), tab.stride(0), L.ptr(self._miss_pos), L.ptr(self._miss_fullid), R,
                     L.ptr(self._miss_count), self.dims[name], L.ptr(o), o.stride(0), sp), "pg_scatter_rows_from_host")
+
+    def _device_tail(self, names, out, miss_pos, miss_fullid, miss_count, R, sp):
+        """the share of the miss list the worker leaves alone: read over PCIe by the device, on the fetching stream"""
+        for name in names:
+            tab = _table(self.graph, name)
+            o = out[name]
+            L.check(self.lib.pg_scatter_rows_from_host_tail(L.ptr(tab), tab.stride(0), miss_pos, miss_fullid, R, miss_count,
+                                                            self._missq_share, self.dims[name], L.ptr(o), o.stride(0), sp),
+                    "pg_scatter_rows_from_host_tail")
 
     def _missq_buffers(self, slot, rows):
         hit = self._missq_bufs.get(slot)
@@ -469,6 +486,11 @@ class GraphCacheServer:
             L.check(self.lib.pg_missq_create(self.device.index, self.missq_slots, cap, arr, len(self.dims),
                                              self.host_threads, ctypes.byref(h)), "pg_missq_create")
             self._missq, self._missq_rows = h, cap
+            self._missq_share = None
+        share = max(0, min(256, int(round(self.cpu_share * 256))))
+        if share != self._missq_share:
+            L.check(self.lib.pg_missq_set_cpu_share(self._missq, share), "pg_missq_set_cpu_share")
+            self._missq_share = share
         pos, full, cnt = L.vp(), L.vp(), L.vp()
         L.check(self.lib.pg_missq_slot_buffers(self._missq, slot, ctypes.byref(pos), ctypes.byref(full),
                                                ctypes.byref(cnt)), "pg_missq_slot_buffers")

@@ -37,12 +37,14 @@ def _cacher(z, dev, mode="staged"):
     return c
 
 
-@pytest.mark.parametrize("mode", ["staged", "zerocopy", "async"])
+@pytest.mark.parametrize("mode", ["staged", "zerocopy", "async", "async-split", "async-device-only"])
 @pytest.mark.parametrize("F", [8, 600, 602])
 def test_fetch_data_vs_reference_golden(dev, hiplib, golden_dir, F, mode):
-    """G1/G2: GraphCacheServer.fetch_data == the reference's outputs, bit for bit"""
+    """G1/G2: GraphCacheServer.fetch_data == the reference's outputs, bit for bit (every miss path; 'async-split'
+    = the worker thread moves the head of each miss list, the device reads the tail over PCIe)"""
     z = np.load(os.path.join(golden_dir, f"g1_fetch_data_F{F}.npz"))
-    c = _cacher(z, dev, mode)
+    c = _cacher(z, dev, "async" if mode.startswith("async") else mode)
+    c.cpu_share = {"async-split": 0.4, "async-device-only": 0.0}.get(mode, 1.0)
     c.log = True
     nids = torch.from_numpy(z["cached_nids"]).to(dev)
     c.cache_fix_data(nids, c.get_feat_from_server(nids, ["features", "norm"], to_gpu=True), is_full=False)
