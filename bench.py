@@ -62,7 +62,11 @@ def parse():
     p.add_argument("--batch-size", type=int, default=6000)
     p.add_argument("--num-neighbors", type=int, default=2)
     p.add_argument("--cache-ratio", type=float, default=0.30)
-    p.add_argument("--miss-mode", default="async", choices=["staged", "zerocopy", "async"])
+    p.add_argument("--miss-mode", default=None, choices=["staged", "zerocopy", "async"],
+                   help="default: async (worker-thread queue) on one GPU; zerocopy when --gpus > 1 — the async path "
+                        "parks a spin-wait kernel on the compute stream's hardware queue, and on a single GPU one more "
+                        "busy stream beside it (RCCL adds some) was measured to make the step 3x slower; the "
+                        "multi-GPU runs cannot be tried here, so they take the path without device-side waits")
     p.add_argument("--host-threads", type=int, default=None, help="threads of the miss path's CPU row gather "
                    "(default: from the process's CPU quota, see storage.default_host_threads)")
     p.add_argument("--no-overlap", action="store_true")
@@ -350,6 +354,8 @@ def run():
 
     # ---- feature provider (pa_server.py:38-54) --------------------------------------------
     feat_tab, table_device_visible = make_host_table(V, Fdim, rank, local_rank, world, dev, "feat")
+    if args.miss_mode is None:
+        args.miss_mode = "async" if world == 1 else "zerocopy"
     if not table_device_visible and args.miss_mode == "zerocopy":
         log(f"[bench] rank {rank}: host table is not device-addressable -> staged miss path")
         args.miss_mode = "staged"                       # a zero-copy read of unregistered memory would fault

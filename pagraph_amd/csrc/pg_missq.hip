@@ -208,6 +208,7 @@ struct pg_missq {
   std::deque<std::pair<int, uint32_t>> jobs;
   bool stop = false;
   int error = PG_OK;
+  int64_t n_wait_event = 0, n_wait_spin = 0;   // how pg_missq_wait_device ordered the consumer (under m)
   std::atomic<int> cpu_share{256};   // of 256: the leading share of every miss list that the CPU path moves
   // PG_MISSQ_DEBUG=1: accumulated worker phase times (us) printed at destroy
   double t_sync = 0, t_flag = 0, t_gather = 0, t_enqueue = 0, t_copy = 0, t_sub2flag = 0, t_sub2pop = 0;
@@ -318,6 +319,9 @@ static void missq_free(pg_missq* q) {
     fprintf(stderr, "[missq] jobs %ld rows/job %.0f | per job us: event-sync %.1f flag-wait %.1f cpu-gather %.1f enqueue %.1f copy-drain(dbg2) %.1f | submit->pop %.1f submit->flag %.1f\n",
             (long)q->n_jobs, (double)q->n_rows / q->n_jobs, q->t_sync / q->n_jobs, q->t_flag / q->n_jobs,
             q->t_gather / q->n_jobs, q->t_enqueue / q->n_jobs, q->t_copy / q->n_jobs, q->t_sub2pop / q->n_jobs, q->t_sub2flag / q->n_jobs);
+  if (getenv("PG_MISSQ_DEBUG") && q->n_jobs)
+    fprintf(stderr, "[missq] consumer waits: %ld by event (copy already enqueued), %ld by the spin kernel\n",
+            (long)q->n_wait_event, (long)q->n_wait_spin);
   if (q->worker.joinable()) {
     {
       std::lock_guard<std::mutex> l(q->m);
@@ -457,12 +461,21 @@ int pg_missq_wait_device(pg_missq_t* q, int slot, pg_stream_t stream) {
   if (!q || slot < 0 || slot >= q->n_slots) return PG_ERR_INVALID;
   pg_missq_slot& s = q->slots[slot];
   uint32_t seq;
+  bool enqueued;
   {
     std::lock_guard<std::mutex> l(q->m);
     if (q->error != PG_OK) return q->error;
     seq = s.submitted;
+    enqueued = s.done == s.submitted;   // the worker has already put this submission's copy on its stream
+    if (enqueued) ++q->n_wait_event; else ++q->n_wait_spin;
   }
   if (seq == 0) return PG_OK;
+  if (enqueued) {
+    // the usual case with two batches of look-ahead: an ordinary event dependency, no kernel parked on the
+    // consumer's hardware queue (a spinning kernel stalls whatever else the runtime multiplexes onto that queue)
+    PG_HIP(hipStreamWaitEvent(as_stream(stream), s.filled, 0));
+    return PG_OK;
+  }
   hipLaunchKernelGGL(k_wait_landed, dim3(1), dim3(1), 0, as_stream(stream), s.landed_d, seq, q->timeout_d);
   PG_LAUNCH_CHECK();
   return PG_OK;

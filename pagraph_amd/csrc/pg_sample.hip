@@ -408,10 +408,6 @@ struct pg_sampler {
   void* tsort_tmp = nullptr;    // rocPRIM radix sort scratch
   size_t tsort_bytes = 0;
   int64_t max_edges = 0;
-  // the transposes run on their own stream, forked right after a block is relabelled, so that block b's
-  // transposition overlaps the sampling of blocks b-1 .. 0 (every kernel here is latency bound)
-  hipStream_t aux = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 static void sampler_free(pg_sampler* s) {
@@ -434,9 +430,6 @@ static void sampler_free(pg_sampler* s) {
     if (c->done) (void)hipEventDestroy(c->done);
     delete c;
   }
-  if (s->aux) (void)hipStreamDestroy(s->aux);
-  if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
-  if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   delete s;
 }
 
@@ -483,9 +476,6 @@ int pg_sampler_create(int64_t V, const int64_t* indptr, const int32_t* indices, 
                                     (hipStream_t) nullptr) == hipSuccess;
     if (ok) ok &= hipMalloc(&s->tsort_tmp, s->tsort_bytes ? s->tsort_bytes : 4) == hipSuccess;
   }
-  ok &= hipStreamCreateWithPriority(&s->aux, hipStreamNonBlocking, -1) == hipSuccess;
-  ok &= hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess;
-  ok &= hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     sampler_free(s);
     return PG_ERR_NOMEM;
@@ -520,7 +510,6 @@ static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t
   int32_t* lcnt = s->counters;
   int32_t* ecnt = s->counters + PG_MAX_LAYERS;
 
-  bool forked = false;
   hipLaunchKernelGGL(k_seed_layer, dim3(grid_for(s->B, 256, 64)), dim3(256), 0, st, ss->prm_h, s->prm_d,
                      s->layer_ids[L], lcnt + L);
   PG_LAUNCH_CHECK();
@@ -552,19 +541,11 @@ static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t
     hipLaunchKernelGGL(k_clear_words, dim3(grid_for(s->cap[b], 256, 1024)), dim3(256), 0, st, s->bitmap,
                        s->layer_ids[b], lcnt + b);
     PG_LAUNCH_CHECK();
-    // source-major copy of this block (gather-form backward aggregation), on the side stream
+    // source-major copy of this block (gather-form backward aggregation). Running it on a forked side stream
+    // (overlapping the sampling of the remaining blocks) was tried: with the miss queue's spin-wait kernel in
+    // flight a fifth busy stream made the whole pipeline 3x slower, so it stays in line.
     if (o->blk_tptr && o->blk_tdst && ((o->transpose_mask >> b) & 1u)) {
-      // PG_SAMPLER_FORK=1: transposes on a side stream, overlapping the sampling of the remaining blocks.
-      // Off by default: with the asynchronous miss queue's spin-wait kernel in flight the extra stream made
-      // the whole pipeline 3x slower on MI355X (streams sharing a hardware queue with a spinning kernel).
-      static const bool fork = getenv("PG_SAMPLER_FORK") != nullptr;
       hipStream_t ax = st;
-      if (fork) {
-        PG_HIP(hipEventRecord(s->ev_fork, st));
-        PG_HIP(hipStreamWaitEvent(s->aux, s->ev_fork, 0));
-        forked = true;
-        ax = s->aux;
-      }
       int32_t* tptr_b = o->blk_tptr + o->blk_tptr_off[b];
       int32_t* tdst_b = o->blk_tdst + o->blk_src_off[b];
       int32_t* heavy_b = o->blk_theavy ? o->blk_theavy + o->blk_theavy_off[b] : nullptr;
@@ -588,10 +569,6 @@ static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t
         PG_LAUNCH_CHECK();
       }
     }
-  }
-  if (forked) {  // the transposes must be complete before the NodeFlow is published
-    PG_HIP(hipEventRecord(s->ev_join, s->aux));
-    PG_HIP(hipStreamWaitEvent(st, s->ev_join, 0));
   }
   PackArgs p{};
   for (int l = 0; l <= L; ++l) {
