@@ -13,6 +13,7 @@ HBM layout
   gpu_fix_cache[name] fp32 [cached_num, dim] row-major, row = slot (storage.py:151)
 """
 import ctypes
+import os
 
 import torch
 
@@ -77,6 +78,12 @@ def default_host_threads(world_size=1):
     except (OSError, ValueError):
         pass
     return max(2, min(16, (cpus - 4 * max(1, world_size)) // max(1, world_size) if cpus > 8 else cpus // 2))
+
+
+# PG_MISSQ_HOST_WAIT=1: never park the spin-wait kernel on the consumer stream; wait for the worker on the host
+# instead (slower pipeline, but safe under tools that serialise all kernels — rocprofv3 --pmc — where the
+# spinning kernel blocks the very copy it waits for until its 3 s timeout)
+_HOST_WAIT = bool(os.environ.get("PG_MISSQ_HOST_WAIT"))
 
 
 class _FetchPlan:
@@ -504,7 +511,7 @@ class GraphCacheServer:
         if self.miss_mode != "async" or self._missq is None or self.full_cached:
             return
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
-        if host_blocking:
+        if host_blocking or _HOST_WAIT:
             L.check(self.lib.pg_missq_wait(self._missq, slot, L.stream_ptr(st), None), "pg_missq_wait")
         else:
             L.check(self.lib.pg_missq_wait_device(self._missq, slot, L.stream_ptr(st)), "pg_missq_wait_device")
