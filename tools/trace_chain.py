@@ -20,7 +20,7 @@ for r in rows:
     if tag: ev.append((s, e, q, tag))
 # compute stream = the queue with the most kernels
 from collections import Counter
-cq = Counter(r["Queue_Id"] for r in rows).most_common(1)[0][0]
+cq = Counter(r["Queue_Id"] for r in rows if "k_wait_landed" in r["Kernel_Name"] or "k_linear_fwd" in r["Kernel_Name"]).most_common(1)[0][0]
 comp = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if r["Queue_Id"] == cq and t0 <= int(r["Start_Timestamp"]) <= t1 and "k_wait_landed" not in r["Kernel_Name"]]
 # group compute kernels into bursts separated by > 20 us gaps
 burst_s = None; last_e = None
