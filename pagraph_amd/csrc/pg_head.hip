@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
 #pragma unroll
       for (int k = 0; k < kHeadMax; ++k) s_big[k * kHeadMax + lane] = (wv ? s_big[k * kHeadMax + lane] : 0.f) + accw[k];
       s_b[lane] = (wv ? s_b[lane] : 0.f) + accb;
-      if (lane == 0) s_b[kHeadMax] = (wv ? s_b[kHeadMax] : 0.f) + lsum * inv;
+      // no counted row at all: the mean over zero rows is nan, as torch's CrossEntropyLoss returns
+      if (lane == 0) s_b[kHeadMax] = (wv ? s_b[kHeadMax] : 0.f) + (nv > 0 ? lsum * inv : NAN);
     }
     __syncthreads();
   }

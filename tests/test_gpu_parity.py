@@ -1110,6 +1110,10 @@ def test_gcn_output_head_vs_oracle(dev, hiplib, oracle, n_dst, n_src, deg, K, C,
     loss = ops.gcn_head(tip, tsr, th, lin, tl, n_valid, seed_t, -100, "mean", spec, tr)
     (loss * 3.0).backward()
     assert np.abs(lin.weight.grad.cpu().numpy() - 6.0 * want[3]).max() < TOL * 6 * max(1e-3, np.abs(want[3]).max()) * max(1.0, float(scale))
+    # no counted label at all: nan loss (torch's convention), zero gradients
+    none_valid = torch.zeros(1, dtype=torch.int32, device=dev)
+    l0 = ops.gcn_head(tip, tsr, torch.from_numpy(h).to(dev), lin, torch.full_like(tl, -100), none_valid, seed_t, -100, "mean", spec, tr)
+    assert torch.isnan(l0)
     # and the unfused ops of the library agree
     lin.zero_grad()
     th2 = torch.from_numpy(h).to(dev).requires_grad_(True)
