@@ -86,6 +86,8 @@ def parse():
                    "(backward aggregation falls back to the atomic scatter form)")
     p.add_argument("--cpu-share", type=float, default=1.0, help="async miss path: share of every miss list that goes "
                    "through the worker thread; the rest is read by the device over PCIe (1.0 = all)")
+    p.add_argument("--inline-transpose", action="store_true", help="build the source-major blocks inside the sampler's "
+                   "chain instead of on the trainer's load stream")
     p.add_argument("--lookahead", type=int, default=None, help="batches prepared ahead of the one being computed "
                    "(default 2 with the async miss queue, else 1); the sampler ring needs lookahead + 2 slots")
     p.add_argument("--profile-host", action="store_true", help="cProfile the timed region (stderr)")
@@ -394,7 +396,8 @@ def run():
     sampler = NeighborSampler(g, B, k, neighbor_type='in', shuffle=True, num_workers=16, num_hops=num_hops,
                               seed_nodes=subtrain, prefetch=True, seed=rank, copy_out=True, static=use_graph,
                               ring=args.ring if args.ring else (args.lookahead + 2 if args.lookahead else None),
-                              transpose=None if args.no_transpose else 'auto')
+                              transpose=None if args.no_transpose else 'auto',
+                              defer_transpose=use_graph and not args.inline_transpose)
     steps_per_epoch = parallel.equalize_steps(len(sampler), device=dev)
     K = args.steps if args.steps is not None else 400
     W = args.warmup

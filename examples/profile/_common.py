@@ -75,7 +75,7 @@ def trainer(rank, world_size, args, arch, backend='nccl'):
 
     sampler = NeighborSampler(g, args.batch_size, args.num_neighbors, neighbor_type='in', shuffle=True,
                               num_workers=args.num_workers, num_hops=num_hops, seed_nodes=train_nid, prefetch=True,
-                              seed=rank, static=args.graph)
+                              seed=rank, static=args.graph, defer_transpose=args.graph)
     steps = parallel.equalize_steps(len(sampler), device=dev)     # partitions differ in size
     if args.graph:      # hipGraph-replayed step over fixed-shape NodeFlows (no DDP wrapper: one flat all-reduce)
         loop = GraphedTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, need=need, world_size=world_size,

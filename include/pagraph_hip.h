@@ -203,6 +203,10 @@ typedef struct pg_nodeflow_desc {
                               with more than PG_HEAVY_ROW edges, [1..] those sources (any order); room for
                               1 + cap_edges(b) / PG_HEAVY_ROW entries                               */
   int64_t blk_theavy_off[PG_MAX_LAYERS];
+  int32_t* sizes_dev;      /* may be NULL: device copy of sizes_pinned (needed by pg_sampler_transpose)         */
+  int32_t defer_transpose; /* 1: pg_sampler_sample does NOT build the source-major copies; the caller runs
+                              pg_sampler_transpose(s, desc, its_stream) once the sample is complete           */
+  int32_t _pad2;
 } pg_nodeflow_desc_t;
 
 /* indptr/indices: CSC of the partition (in-neighbours of v = indices[indptr[v]:indptr[v+1]],
@@ -223,6 +227,11 @@ int pg_sampler_capacity(const pg_sampler_t* s, int64_t* cap_nodes, int64_t* cap_
  * uses, that is one ring revolution ago and bounds how far the launch thread can run ahead of the GPU.   */
 int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, uint64_t seed,
                       uint32_t epoch, uint32_t batch, const pg_nodeflow_desc_t* out, pg_stream_t stream);
+/* The source-major block copies of a sampled slot (transpose_mask, blk_tptr / blk_tdst / blk_theavy) on `stream`,
+ * which must already be ordered after the sample (defer_transpose = 1, sizes_dev set). The 8 latency-bound launches
+ * then leave the sampler's chain — the stage that bounds the pipeline once the features are cached — for a stream
+ * with slack (the trainer's load stream). One caller at a time per sampler handle (shared scratch).          */
+int pg_sampler_transpose(pg_sampler_t* s, const pg_nodeflow_desc_t* out, pg_stream_t stream);
 
 /* Full-neighbour frontier expansion used by the L-hop closure (PaGraph/partition/utils.py:11-28):
  * marks every in-neighbour of frontier[0:n] in `bitmap` (uint64 words, bit v = vertex v) and

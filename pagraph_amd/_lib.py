@@ -34,7 +34,8 @@ class PgNodeflowDesc(ctypes.Structure):
                 ("sizes_pinned", vp), ("cap_nodes", c_i64),
                 ("blk_indptr_off", c_i64 * PG_MAX_LAYERS), ("blk_src_off", c_i64 * PG_MAX_LAYERS),
                 ("padded", c_i32), ("transpose_mask", c_u32), ("blk_tptr", vp), ("blk_tdst", vp),
-                ("blk_tptr_off", c_i64 * PG_MAX_LAYERS), ("blk_theavy", vp), ("blk_theavy_off", c_i64 * PG_MAX_LAYERS)]
+                ("blk_tptr_off", c_i64 * PG_MAX_LAYERS), ("blk_theavy", vp), ("blk_theavy_off", c_i64 * PG_MAX_LAYERS),
+                ("sizes_dev", vp), ("defer_transpose", c_i32), ("_pad2", c_i32)]
 
 
 class PgMissqField(ctypes.Structure):
@@ -77,6 +78,7 @@ _SIGS = {
     "pg_sampler_destroy": (ctypes.c_int, [vp]),
     "pg_sampler_capacity": (ctypes.c_int, [vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "pg_sampler_sample": (ctypes.c_int, [vp, vp, c_i32, c_u64, c_u32, c_u32, ctypes.POINTER(PgNodeflowDesc), vp]),
+    "pg_sampler_transpose": (ctypes.c_int, [vp, ctypes.POINTER(PgNodeflowDesc), vp]),
     "pg_frontier_mark_neighbors": (ctypes.c_int, [vp, vp, vp, c_i64, vp, ctypes.c_int, vp]),
     "pg_bitmap_to_ids": (ctypes.c_int, [vp, c_i64, vp, c_i64, vp, vp, vp, vp]),
     "pg_spmm_fwd": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp]),

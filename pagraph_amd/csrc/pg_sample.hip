@@ -255,6 +255,7 @@ struct PackArgs {
   int64_t* node_mapping;
   int32_t* layer_offsets;
   int32_t* sizes_pinned;
+  int32_t* sizes_dev;                 // optional device copy of the same numbers
   int64_t cap_nodes;
   int32_t num_layers;
   int32_t padded;                     // 1: layer l starts at pad_off[l], unused entries = -1
@@ -288,6 +289,10 @@ __global__ __launch_bounds__(256) void k_pack(const PackArgs a) {
       if (l <= a.num_layers) a.layer_offsets[l] = a.padded ? a.pad_off[l] : off[l];
       if (l < a.num_layers) a.sizes_pinned[l] = cnt[l];
       if (l + 1 < a.num_layers) a.sizes_pinned[PG_MAX_LAYERS + l] = *a.blk_edges[l];
+      if (a.sizes_dev) {
+        if (l < a.num_layers) a.sizes_dev[l] = cnt[l];
+        if (l + 1 < a.num_layers) a.sizes_dev[PG_MAX_LAYERS + l] = *a.blk_edges[l];
+      }
     }
     __threadfence_system();
   }
@@ -404,6 +409,7 @@ struct pg_sampler {
   int32_t* nbr = nullptr;       // ELL picks of the current block (reused)
   int32_t* cnt = nullptr;
   int32_t* tcnt = nullptr;      // per-source edge counts while a block is transposed (zero between uses)
+  int32_t* tdummy = nullptr;    // sink for the scan's total when the transposes run outside the sampling chain
   int32_t* tkey = nullptr;      // [2][cap edges] sort keys in / out, then [cap edges] values in
   void* tsort_tmp = nullptr;    // rocPRIM radix sort scratch
   size_t tsort_bytes = 0;
@@ -420,6 +426,7 @@ static void sampler_free(pg_sampler* s) {
   (void)hipFree(s->nbr);
   (void)hipFree(s->cnt);
   (void)hipFree(s->tcnt);
+  (void)hipFree(s->tdummy);
   (void)hipFree(s->tkey);
   (void)hipFree(s->tsort_tmp);
   (void)hipFree(s->prm_d);
@@ -465,6 +472,7 @@ int pg_sampler_create(int64_t V, const int64_t* indptr, const int32_t* indices, 
   ok &= hipMalloc(&s->cnt, max_dst * 4) == hipSuccess;
   ok &= hipMalloc(&s->prm_d, sizeof(SampleParams)) == hipSuccess;
   ok &= hipMalloc(&s->tcnt, (s->cap[0] + 1) * 4) == hipSuccess;
+  ok &= hipMalloc(&s->tdummy, 4) == hipSuccess;
   if (ok) ok &= hipMemset(s->bitmap, 0, s->n_words * 8) == hipSuccess;
   if (ok) ok &= hipMemset(s->counters, 0, 2 * PG_MAX_LAYERS * 4) == hipSuccess;
   if (ok) ok &= hipMemset(s->tcnt, 0, (s->cap[0] + 1) * 4) == hipSuccess;
@@ -497,6 +505,37 @@ int pg_sampler_capacity(const pg_sampler_t* s, int64_t* cap_nodes, int64_t* cap_
   for (int b = 0; b < s->hops; ++b) {
     if (cap_blk_rows) cap_blk_rows[b] = s->cap[b + 1];
     if (cap_blk_edges) cap_blk_edges[b] = s->cap[b + 1] * s->k;
+  }
+  return PG_OK;
+}
+
+// source-major copy of block b of the slot `o`. n_dst / n_src / nnz: DEVICE counters of that NodeFlow (the
+// sampler's own while it is still sampling the slot, the slot's sizes_dev copy afterwards).
+static int transpose_block(pg_sampler* s, const pg_nodeflow_desc_t* o, int b, const int32_t* n_dst, const int32_t* n_src,
+                           const int32_t* nnz, int32_t* scan_total_dummy, hipStream_t ax) {
+  const int32_t* indptr_b = o->blk_indptr + o->blk_indptr_off[b];
+  const int32_t* src_b = o->blk_src + o->blk_src_off[b];
+  int32_t* tptr_b = o->blk_tptr + o->blk_tptr_off[b];
+  int32_t* tdst_b = o->blk_tdst + o->blk_src_off[b];
+  int32_t* heavy_b = o->blk_theavy ? o->blk_theavy + o->blk_theavy_off[b] : nullptr;
+  const int32_t cap_edges = (int32_t)(s->cap[b + 1] * s->k);
+  const int32_t pad_key = (int32_t)s->cap[b];
+  int32_t *key_in = s->tkey, *key_out = s->tkey + s->max_edges, *val_in = s->tkey + 2 * s->max_edges;
+  hipLaunchKernelGGL(k_t_keys, dim3(grid_for(s->cap[b + 1], 256, 1024)), dim3(256), 0, ax, indptr_b, src_b, n_dst, nnz,
+                     cap_edges, pad_key, key_in, val_in, s->tcnt, heavy_b);
+  PG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_scan_cnt<true>, dim3(1), dim3(kScanThreads), 0, ax, s->tcnt, n_src, tptr_b, scan_total_dummy,
+                     (int32_t)s->cap[b]);
+  PG_LAUNCH_CHECK();
+  int bits = 1;
+  while ((1ll << bits) <= pad_key) ++bits;
+  size_t bytes = s->tsort_bytes;
+  PG_HIP(rocprim::radix_sort_pairs(s->tsort_tmp, bytes, key_in, key_out, val_in, tdst_b, (size_t)cap_edges, 0,
+                                   (unsigned)bits, ax));
+  if (heavy_b) {
+    hipLaunchKernelGGL(k_t_heavy, dim3(grid_for(s->cap[b], 256, 1024)), dim3(256), 0, ax, tptr_b, n_src, heavy_b,
+                       (int32_t)(cap_edges / PG_HEAVY_ROW));
+    PG_LAUNCH_CHECK();
   }
   return PG_OK;
 }
@@ -541,33 +580,11 @@ static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t
     hipLaunchKernelGGL(k_clear_words, dim3(grid_for(s->cap[b], 256, 1024)), dim3(256), 0, st, s->bitmap,
                        s->layer_ids[b], lcnt + b);
     PG_LAUNCH_CHECK();
-    // source-major copy of this block (gather-form backward aggregation). Running it on a forked side stream
-    // (overlapping the sampling of the remaining blocks) was tried: with the miss queue's spin-wait kernel in
-    // flight a fifth busy stream made the whole pipeline 3x slower, so it stays in line.
-    if (o->blk_tptr && o->blk_tdst && ((o->transpose_mask >> b) & 1u)) {
-      hipStream_t ax = st;
-      int32_t* tptr_b = o->blk_tptr + o->blk_tptr_off[b];
-      int32_t* tdst_b = o->blk_tdst + o->blk_src_off[b];
-      int32_t* heavy_b = o->blk_theavy ? o->blk_theavy + o->blk_theavy_off[b] : nullptr;
-      const int32_t cap_edges = (int32_t)(s->cap[b + 1] * s->k);
-      const int32_t pad_key = (int32_t)s->cap[b];
-      int32_t *key_in = s->tkey, *key_out = s->tkey + s->max_edges, *val_in = s->tkey + 2 * s->max_edges;
-      hipLaunchKernelGGL(k_t_keys, dim3(grid_for(s->cap[b + 1], 256, 1024)), dim3(256), 0, ax, indptr_b, src_b,
-                         lcnt + b + 1, ecnt + b, cap_edges, pad_key, key_in, val_in, s->tcnt, heavy_b);
-      PG_LAUNCH_CHECK();
-      hipLaunchKernelGGL(k_scan_cnt<true>, dim3(1), dim3(kScanThreads), 0, ax, s->tcnt, lcnt + b, tptr_b,
-                         s->counters + 2 * PG_MAX_LAYERS - 1, (int32_t)s->cap[b]);
-      PG_LAUNCH_CHECK();
-      int bits = 1;
-      while ((1ll << bits) <= pad_key) ++bits;
-      size_t bytes = s->tsort_bytes;
-      PG_HIP(rocprim::radix_sort_pairs(s->tsort_tmp, bytes, key_in, key_out, val_in, tdst_b, (size_t)cap_edges, 0,
-                                       (unsigned)bits, ax));
-      if (heavy_b) {
-        hipLaunchKernelGGL(k_t_heavy, dim3(grid_for(s->cap[b], 256, 1024)), dim3(256), 0, ax, tptr_b, lcnt + b, heavy_b,
-                           (int32_t)(cap_edges / PG_HEAVY_ROW));
-        PG_LAUNCH_CHECK();
-      }
+    // source-major copy of this block (gather-form backward aggregation) in line, unless the caller asked to
+    // run it later on a stream of its own choice (pg_sampler_transpose)
+    if (!o->defer_transpose && o->blk_tptr && o->blk_tdst && ((o->transpose_mask >> b) & 1u)) {
+      const int rc = transpose_block(s, o, b, lcnt + b + 1, lcnt + b, ecnt + b, s->counters + 2 * PG_MAX_LAYERS - 1, st);
+      if (rc != PG_OK) return rc;
     }
   }
   PackArgs p{};
@@ -577,6 +594,7 @@ static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t
   }
   for (int b = 0; b < L; ++b) p.blk_edges[b] = ecnt + b;
   p.node_mapping = o->node_mapping; p.layer_offsets = o->layer_offsets; p.sizes_pinned = o->sizes_pinned;
+  p.sizes_dev = o->sizes_dev;
   p.cap_nodes = o->cap_nodes; p.num_layers = L + 1;
   p.padded = o->padded ? 1 : 0;
   p.pad_off[0] = 0;
@@ -663,6 +681,19 @@ int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, ui
   rc = enqueue_chain(s, o, st, ss);   // nothing ran during the failed capture
   if (rc == PG_OK) PG_HIP(hipEventRecord(ss->done, st));
   return rc;
+}
+
+int pg_sampler_transpose(pg_sampler_t* s, const pg_nodeflow_desc_t* o, pg_stream_t stream) {
+  if (!s || !o || !o->blk_indptr || !o->blk_src) return PG_ERR_INVALID;
+  if (!o->transpose_mask) return PG_OK;
+  if (!o->blk_tptr || !o->blk_tdst || !o->sizes_dev) return PG_ERR_INVALID;
+  for (int b = 0; b < s->hops; ++b) {
+    if (!((o->transpose_mask >> b) & 1u)) continue;
+    const int rc = transpose_block(s, o, b, o->sizes_dev + b + 1, o->sizes_dev + b, o->sizes_dev + PG_MAX_LAYERS + b,
+                                   s->tdummy, as_stream(stream));
+    if (rc != PG_OK) return rc;
+  }
+  return PG_OK;
 }
 
 int pg_frontier_mark_neighbors(const int64_t* indptr, const int32_t* indices, const int64_t* frontier, int64_t n,

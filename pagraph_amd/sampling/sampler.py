@@ -16,7 +16,7 @@ from .nodeflow import NodeFlow
 
 
 class _Slot:
-    def __init__(self, lib, handle, hops, device, padded=False, transpose_mask=0):
+    def __init__(self, lib, handle, hops, device, padded=False, transpose_mask=0, defer_transpose=False):
         cap_nodes = L.c_i64()
         rows = (L.c_i64 * L.PG_MAX_LAYERS)()
         edges = (L.c_i64 * L.PG_MAX_LAYERS)()
@@ -52,6 +52,7 @@ class _Slot:
             hv += 1 + edges[b] // L.PG_HEAVY_ROW
         self.blk_theavy = torch.zeros(hv, dtype=torch.int32, device=device) if transpose_mask else None
         self.sizes = torch.zeros(2 * L.PG_MAX_LAYERS, dtype=torch.int32).pin_memory()
+        self.sizes_dev = torch.zeros(2 * L.PG_MAX_LAYERS, dtype=torch.int32, device=device)
         self.ready = torch.cuda.Event()
         self.free = torch.cuda.Event()
         self.free_recorded = False
@@ -62,6 +63,8 @@ class _Slot:
         d.blk_indptr = self.blk_indptr.data_ptr()
         d.blk_src = self.blk_src.data_ptr()
         d.sizes_pinned = self.sizes.data_ptr()
+        d.sizes_dev = self.sizes_dev.data_ptr()
+        d.defer_transpose = 1 if (defer_transpose and transpose_mask) else 0
         d.cap_nodes = self.cap_nodes
         d.padded = 1 if padded else 0
         for b in range(hops):
@@ -80,7 +83,7 @@ class _Slot:
 class NeighborSampler:
     def __init__(self, g, batch_size, expand_factor, num_hops=1, neighbor_type='in', seed_nodes=None,
                  shuffle=False, num_workers=1, prefetch=False, seed=0, copy_out=True, static=False, ring=None,
-                 transpose='auto'):
+                 transpose='auto', defer_transpose=False):
         if neighbor_type != 'in':
             raise L.PgError("only neighbor_type='in' is on the hot path (pa_gcn.py:72)")
         self.lib = L.load()
@@ -123,8 +126,14 @@ class NeighborSampler:
         if transpose == 'auto':
             transpose = range(1, self.num_hops)
         self.transpose_mask = sum(1 << int(b) for b in (transpose or ()) if 0 <= int(b) < self.num_hops)
+        # defer_transpose: the source-major copies are NOT built inside sample(); the consumer calls
+        # transpose_blocks(nf, stream) on a stream ordered after the sample (GraphedTrainer: its load stream).
+        # The 8 launches then leave the sampler's chain, which bounds the pipeline once misses are cheap.
+        self.defer_transpose = bool(defer_transpose) and self.transpose_mask != 0
+        if self.defer_transpose and not self.static:
+            raise L.PgError("defer_transpose needs static=True (fixed-shape NodeFlows)")
         self.slots = [_Slot(self.lib, self.handle, self.num_hops, self.device, padded=self.static,
-                            transpose_mask=self.transpose_mask)
+                            transpose_mask=self.transpose_mask, defer_transpose=self.defer_transpose)
                       for _ in range(ring if ring else (4 if self.static else 3))]
 
     def __del__(self):
@@ -137,6 +146,14 @@ class NeighborSampler:
 
     def __len__(self):
         return self.num_batches
+
+    def transpose_blocks(self, nf, stream):
+        """build the deferred source-major block copies of `nf` (a NodeFlow of this sampler) on `stream`, which the
+        caller has ordered after the sample (stream.wait_event(nf._slot.ready))"""
+        if self.defer_transpose:
+            with torch.cuda.device(self.device):
+                L.check(self.lib.pg_sampler_transpose(self.handle, ctypes.byref(nf._slot.desc),
+                                                      ctypes.c_void_p(stream.cuda_stream)), "pg_sampler_transpose")
 
     def _release_slot(self, slot):
         slot.free.record(self.consumer_stream or torch.cuda.current_stream(self.device))

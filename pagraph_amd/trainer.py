@@ -258,6 +258,8 @@ class GraphedTrainer:
         else:
             with torch.cuda.stream(ls):
                 self.cacher.fetch_data(nf, out=s.out, need=self.need, slot=s.slot_index)
+        if self.sampler.defer_transpose:
+            self.sampler.transpose_blocks(nf, ls)     # after the gather: the miss path starts first
         o0, o1 = nf._layer_offsets[-2], nf._layer_offsets[-1]
         sp = ctypes.c_void_p(ls.cuda_stream)
         L.check(self._lib.pg_gather_labels(ctypes.c_void_p(ids.data_ptr() + 8 * o0), o1 - o0, L.ptr(self.labels),

@@ -884,7 +884,7 @@ def _transpose_ref(indptr, src, n_src):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("static", [False, True])
+@pytest.mark.parametrize("static", [False, True, "deferred"])
 def test_sampler_emits_source_major_blocks(dev, hiplib, static):
     """sampler option `transpose`: blocks >= 1 (and on request block 0) also come out source-major, exactly the
     stable transposition of the destination-major block; padded rows are empty"""
@@ -895,13 +895,19 @@ def test_sampler_emits_source_major_blocks(dev, hiplib, static):
     g = DeviceGraph.from_csc(ip, ix, V)
     # 900 copies of one seed: its neighbours become hubs (what utils.py:34 does to isolated train vertices)
     seeds = torch.cat([torch.arange(3 * B + 17 - 900), torch.full((900,), 12345)])
+    deferred = static == "deferred"          # the consumer builds the copies later, on a stream of its own
+    static = bool(static)
     smp = NeighborSampler(g, B, 3, neighbor_type='in', shuffle=True, num_hops=3, seed_nodes=seeds,
-                          prefetch=True, seed=5, static=static, transpose=(0, 1, 2))
+                          prefetch=True, seed=5, static=static, transpose=(0, 1, 2), defer_transpose=deferred)
+    side = torch.cuda.Stream()
     auto = NeighborSampler(g, B, 3, neighbor_type='in', num_hops=3, seed_nodes=torch.arange(B), static=static)
     nfa = next(iter(auto))
     assert nfa.blk_tptr[0] is None and nfa.blk_tptr[1] is not None and nfa.blk_tptr[2] is not None
     seen = hubs = 0
     for nf in smp:
+        if deferred:
+            side.wait_event(nf._slot.ready)
+            smp.transpose_blocks(nf, side)
         torch.cuda.synchronize()
         sizes, edges = nf.actual_sizes() if static else ([nf.layer_size(i) for i in range(4)], [nf.block_size(i) for i in range(3)])
         for b in range(3):
