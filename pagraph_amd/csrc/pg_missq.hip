@@ -209,6 +209,7 @@ struct pg_missq {
   bool stop = false;
   int error = PG_OK;
   int64_t n_wait_event = 0, n_wait_spin = 0;   // how pg_missq_wait_device ordered the consumer (under m)
+  bool wait_value = getenv("PG_MISSQ_WAITVALUE") != nullptr;
   std::atomic<int> cpu_share{256};   // of 256: the leading share of every miss list that the CPU path moves
   // PG_MISSQ_DEBUG=1: accumulated worker phase times (us) printed at destroy
   double t_sync = 0, t_flag = 0, t_gather = 0, t_enqueue = 0, t_copy = 0, t_sub2flag = 0, t_sub2pop = 0;
@@ -292,7 +293,10 @@ static void missq_worker(pg_missq* q) {
         te += us(tb, now());
       }
     }
-    hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, q->copy_stream, s.landed_d, job.second);
+    if (q->wait_value) {
+      if (hipStreamWriteValue32(q->copy_stream, s.landed_d, job.second, 0) != hipSuccess) rc = PG_ERR_HIP;
+    } else
+      hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, q->copy_stream, s.landed_d, job.second);
     if (hipGetLastError() != hipSuccess) rc = PG_ERR_HIP;
     if (hipEventRecord(s.filled, q->copy_stream) != hipSuccess) rc = PG_ERR_HIP;
     static const bool dbg_copy = getenv("PG_MISSQ_DEBUG") && atoi(getenv("PG_MISSQ_DEBUG")) >= 2;
@@ -371,7 +375,8 @@ int pg_missq_create(int device, int n_slots, int64_t max_rows, const pg_missq_fi
     ok = ok && hipHostMalloc((void**)&s.flag_h, 64, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMalloc((void**)&s.pos_d, max_rows * 4) == hipSuccess;
     ok = ok && hipMalloc((void**)&s.count_d, 64) == hipSuccess;
-    ok = ok && hipMalloc((void**)&s.landed_d, 64) == hipSuccess;
+    ok = ok && (q->wait_value ? hipExtMallocWithFlags((void**)&s.landed_d, 8, hipMallocSignalMemory)
+                              : hipMalloc((void**)&s.landed_d, 64)) == hipSuccess;
     for (int f = 0; f < n_fields && ok; ++f) {
       const size_t bytes = (size_t)max_rows * fields[f].dim * sizeof(float);
       ok = ok && hipHostMalloc((void**)&s.staging_h[f], bytes, hipHostMallocDefault) == hipSuccess;
@@ -382,7 +387,7 @@ int pg_missq_create(int device, int n_slots, int64_t max_rows, const pg_missq_fi
     *s.flag_h = 0;
     *s.count_h = 0;
     ok = ok && hipMemset(s.count_d, 0, 64) == hipSuccess;
-    ok = ok && hipMemset(s.landed_d, 0, 64) == hipSuccess;
+    ok = ok && hipMemset(s.landed_d, 0, 8) == hipSuccess;
     ok = ok && hipEventRecord(s.filled, q->copy_stream) == hipSuccess;
   }
   if (!ok) {
@@ -474,6 +479,11 @@ int pg_missq_wait_device(pg_missq_t* q, int slot, pg_stream_t stream) {
     // the usual case with two batches of look-ahead: an ordinary event dependency, no kernel parked on the
     // consumer's hardware queue (a spinning kernel stalls whatever else the runtime multiplexes onto that queue)
     PG_HIP(hipStreamWaitEvent(as_stream(stream), s.filled, 0));
+    return PG_OK;
+  }
+  if (q->wait_value) {
+    // experiment (PG_MISSQ_WAITVALUE=1): the command processor waits on the value, no kernel spins
+    PG_HIP(hipStreamWaitValue32(as_stream(stream), s.landed_d, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
     return PG_OK;
   }
   hipLaunchKernelGGL(k_wait_landed, dim3(1), dim3(1), 0, as_stream(stream), s.landed_d, seq, q->timeout_d);
