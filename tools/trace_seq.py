@@ -6,9 +6,11 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 cq = Counter(r["Queue_Id"] for r in rows if "k_wait_landed" in r["Kernel_Name"] or "k_linear_fwd" in r["Kernel_Name"]).most_common(1)[0][0]
 q = [r for r in rows if r["Queue_Id"] == cq]
-mark = "k_wait_landed" if any("k_wait_landed" in r["Kernel_Name"] for r in q) else "k_linear_fwd"
-idx = [i for i, r in enumerate(q) if mark in r["Kernel_Name"]]
-steps = [q[a:b] for a, b in zip(idx[:-1], idx[1:])]
+# a step ends with the optimiser kernel (the wait kernel at its start is skipped when the miss rows are already
+# on their way: pg_missq_wait_device then uses an event)
+end = "k_adam" if any("k_adam" in r["Kernel_Name"] for r in q) else "multi_tensor_apply"
+idx = [i for i, r in enumerate(q) if end in r["Kernel_Name"] and "FusedOptimizer" in r["Kernel_Name"] or "k_adam" in r["Kernel_Name"]]
+steps = [q[a + 1:b + 1] for a, b in zip(idx[:-1], idx[1:])]
 L = Counter(len(s) for s in steps).most_common(1)[0][0]
 steps = [s for s in steps if len(s) == L][5:]
 tot = 0.0
