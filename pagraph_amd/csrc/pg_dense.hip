@@ -62,8 +62,7 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ X,
   const float* xr2 = X2 ? X2 + (row_ok ? row : 0) * x2_stride + 4 * half : nullptr;
   const float* wr2 = W2 ? W2 + (int64_t)(col_ok ? col : 0) * K2 + 4 * half : nullptr;
   f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int o = o_beg; o < o_end; ++o) {
-    df4 a, b;
+  auto load = [&](int o, df4& a, df4& b) {
     if (o < oct1) {
       a = *reinterpret_cast<const df4*>(xr + o * 8);
       b = *reinterpret_cast<const df4*>(wr + o * 8);
@@ -73,10 +72,31 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ X,
     }
     if (!row_ok) a = df4{0.f, 0.f, 0.f, 0.f};
     if (!col_ok) b = df4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto mma = [&](const df4& a, const df4& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  };
+  // four octets (8 x 16-byte loads per lane) in flight per iteration: the wave is otherwise one load
+  // round trip per 4 MFMAs
+  int o = o_beg;
+  for (; o + 3 < o_end; o += 4) {
+    df4 a0, b0, a1, b1, a2, b2, a3, b3;
+    load(o, a0, b0);
+    load(o + 1, a1, b1);
+    load(o + 2, a2, b2);
+    load(o + 3, a3, b3);
+    mma(a0, b0);
+    mma(a1, b1);
+    mma(a2, b2);
+    mma(a3, b3);
+  }
+  for (; o < o_end; ++o) {
+    df4 a, b;
+    load(o, a, b);
+    mma(a, b);
   }
   // C layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
