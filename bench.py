@@ -63,10 +63,10 @@ def parse():
     p.add_argument("--num-neighbors", type=int, default=2)
     p.add_argument("--cache-ratio", type=float, default=0.30)
     p.add_argument("--miss-mode", default=None, choices=["staged", "zerocopy", "async"],
-                   help="default: async (worker-thread queue) on one GPU; zerocopy when --gpus > 1 — the async path "
-                        "parks a spin-wait kernel on the compute stream's hardware queue, and on a single GPU one more "
-                        "busy stream beside it (RCCL adds some) was measured to make the step 3x slower; the "
-                        "multi-GPU runs cannot be tried here, so they take the path without device-side waits")
+                   help="default: async (worker-thread queue) on one GPU. With --gpus > 1 both zerocopy and async are "
+                        "timed for 40 steps after the warm-up and every rank keeps the faster one: on a single GPU one "
+                        "more busy stream beside the async path (RCCL adds some) was measured to make the step 1.5-3x "
+                        "slower, and the multi-GPU runs cannot be tried from the build container")
     p.add_argument("--host-threads", type=int, default=None, help="threads of the miss path's CPU row gather "
                    "(default: from the process's CPU quota, see storage.default_host_threads)")
     p.add_argument("--no-overlap", action="store_true")
@@ -88,6 +88,8 @@ def parse():
                    "through the worker thread; the rest is read by the device over PCIe (1.0 = all)")
     p.add_argument("--inline-transpose", action="store_true", help="build the source-major blocks inside the sampler's "
                    "chain instead of on the trainer's load stream")
+    p.add_argument("--probe-miss-mode", action="store_true", help="time a few steps with the zero-copy and with the async "
+                   "miss path after the warm-up and keep the faster one (default when --gpus > 1 and no --miss-mode)")
     p.add_argument("--lookahead", type=int, default=None, help="batches prepared ahead of the one being computed "
                    "(default 2 with the async miss queue, else 1); the sampler ring needs lookahead + 2 slots")
     p.add_argument("--profile-host", action="store_true", help="cProfile the timed region (stderr)")
@@ -356,8 +358,11 @@ def run():
 
     # ---- feature provider (pa_server.py:38-54) --------------------------------------------
     feat_tab, table_device_visible = make_host_table(V, Fdim, rank, local_rank, world, dev, "feat")
+    probe_modes = args.probe_miss_mode or (args.miss_mode is None and world > 1)
     if args.miss_mode is None:
         args.miss_mode = "async" if world == 1 else "zerocopy"
+    if probe_modes:
+        args.miss_mode = "zerocopy"                          # start here; the async path is tried after the warm-up
     if not table_device_visible and args.miss_mode == "zerocopy":
         log(f"[bench] rank {rank}: host table is not device-addressable -> staged miss path")
         args.miss_mode = "staged"                       # a zero-copy read of unregistered memory would fault
@@ -410,7 +415,8 @@ def run():
                                    need=need)
     trainer.after_first_step = lambda: cacher.auto_cache(g, embed_names, cache_ratio=args.cache_ratio)  # pa_gcn.py:99-100
     model.train()
-    it = cycle_batches(sampler, W + K + 1)
+    PROBE = 40
+    it = cycle_batches(sampler, W + K + 1 + (4 * PROBE + 64 if probe_modes else 0))
 
     # ---- warmup (untimed; the cache is filled after its first step, as in the reference) ----
     t0 = time.time()
@@ -420,6 +426,32 @@ def run():
         cacher.auto_cache(g, embed_names, cache_ratio=args.cache_ratio)
     torch.cuda.synchronize()
     log(f"[bench] rank {rank}: warmup {W} steps + cache fill ({cacher.cached_num} rows) in {time.time()-t0:.1f}s")
+    # ---- which miss path? (multi-GPU default) ------------------------------------------------
+    # The async queue is the faster path on one GPU, but it is sensitive to how many streams are busy (a fifth one
+    # made it 1.5-3x slower) and RCCL brings its own; that cannot be tried from the build container, so with
+    # --gpus > 1 both paths are timed here, on the real system, and every rank keeps the faster one.
+    probe = None
+    if probe_modes and use_graph and cacher.miss_mode == "zerocopy" and not cacher.full_cached:
+        def timed(n):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t_ = time.time()
+            trainer.run_steps(it, n)
+            torch.cuda.synchronize()
+            return parallel.max_over_ranks(time.time() - t_, device=dev) / n * 1e3
+        t_zero = timed(PROBE)
+        cacher.miss_mode, trainer.lookahead = "async", 2
+        trainer.run_steps(it, 16)                              # pipeline refill, miss-queue creation
+        t_async = timed(PROBE)
+        probe = {"zerocopy_ms_per_step": t_zero, "async_ms_per_step": t_async}
+        if t_zero < t_async:
+            cacher.miss_mode, trainer.lookahead = "zerocopy", 1
+            trainer.run_steps(it, 8)                           # the batches prepared under the async path drain
+            torch.cuda.synchronize()
+            cacher.shutdown_miss_queue()                       # no worker / gather threads left behind
+        args.miss_mode = cacher.miss_mode
+        log(f"[bench] rank {rank}: miss path probe zerocopy {t_zero:.3f} ms/step, async {t_async:.3f} ms/step -> {args.miss_mode}")
     cacher._stats.zero_()                                      # reset the try/miss counters
 
     # ---- timed region ------------------------------------------------------------------------
@@ -560,7 +592,8 @@ def run():
                                    f"batch {B}, fan-out {k}, {int(args.cache_ratio*100)}% hot-degree cache, "
                                    f"{('dg(hops=%d)' % args.dg_hops) if world > 1 else '1naive'} partition x{world}, closure hops {num_hops}",
                        "steps_per_epoch": steps_per_epoch, "epoch_time_extrapolated_from_steps": K,
-                       "miss_mode": args.miss_mode, "overlap": not args.no_overlap, "partition_vertices": Vs,
+                       "miss_mode": args.miss_mode, "miss_mode_probe": probe, "overlap": not args.no_overlap,
+                       "partition_vertices": Vs,
                        "hip_graph_step": use_graph,
                        "fetch": "all layers+fields (reference)" if need is None else "only what the model reads"},
             "cache_hit_pct": 100.0 * (1.0 - miss_rate),

@@ -508,13 +508,22 @@ class GraphCacheServer:
         """miss_mode == 'async': order `stream` (default: current) after the slot's miss rows. By default
         the wait happens on the GPU (a one-wave kernel sleeping on a flag) and the host returns at once;
         host_blocking=True waits for the worker on the CPU and then uses an event."""
-        if self.miss_mode != "async" or self._missq is None or self.full_cached:
+        # (not keyed on miss_mode: a caller may switch paths between batches — bench.py probes both — and a batch
+        # submitted to the queue must be waited for whatever the mode is by the time it is consumed)
+        if self._missq is None or self.full_cached:
             return
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
         if host_blocking or _HOST_WAIT:
             L.check(self.lib.pg_missq_wait(self._missq, slot, L.stream_ptr(st), None), "pg_missq_wait")
         else:
             L.check(self.lib.pg_missq_wait_device(self._missq, slot, L.stream_ptr(st)), "pg_missq_wait_device")
+
+    def shutdown_miss_queue(self):
+        """stop the async queue's worker and gather threads and free its buffers (every submitted batch must have
+        been consumed: synchronise the device first)"""
+        if self._missq is not None:
+            L.check(self.lib.pg_missq_destroy(self._missq), "pg_missq_destroy")
+            self._missq, self._missq_rows, self._missq_bufs, self._missq_share = None, 0, {}, None
 
     def misses_timed_out(self):
         if self._missq is None:
