@@ -52,7 +52,7 @@ def log(*a):
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=None, help="timed steps (default: 400)")
+    p.add_argument("--steps", type=int, default=None, help="timed steps (default: one whole epoch of the rank's seeds)")
     p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--model", default="gcn", choices=["gcn", "graphsage"])
     p.add_argument("--vertices", type=int, default=10_000_000)
@@ -404,7 +404,8 @@ def run():
                               transpose=None if args.no_transpose else 'auto',
                               defer_transpose=use_graph and not args.inline_transpose)
     steps_per_epoch = parallel.equalize_steps(len(sampler), device=dev)
-    K = args.steps if args.steps is not None else 400
+    # default: one whole epoch of this rank's seeds (1084 steps at N = 1: a quarter of a second), nothing extrapolated
+    K = args.steps if args.steps is not None else min(steps_per_epoch, 5000)
     W = args.warmup
     if use_graph:
         trainer = GraphedTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, need=need, world_size=world,
