@@ -431,7 +431,7 @@ def run():
     # The async queue is the faster path on one GPU, but it is sensitive to how many streams are busy (a fifth one
     # made it 1.5-3x slower) and RCCL brings its own; that cannot be tried from the build container, so with
     # --gpus > 1 both paths are timed here, on the real system, and every rank keeps the faster one.
-    probe = None
+    mode_probe = None
     if probe_modes and use_graph and cacher.miss_mode == "zerocopy" and not cacher.full_cached:
         def timed(n):
             if world > 1:
@@ -445,7 +445,7 @@ def run():
         cacher.miss_mode, trainer.lookahead = "async", 2
         trainer.run_steps(it, 16)                              # pipeline refill, miss-queue creation
         t_async = timed(PROBE)
-        probe = {"zerocopy_ms_per_step": t_zero, "async_ms_per_step": t_async}
+        mode_probe = {"zerocopy_ms_per_step": t_zero, "async_ms_per_step": t_async}
         if t_zero < t_async:
             cacher.miss_mode, trainer.lookahead = "zerocopy", 1
             trainer.run_steps(it, 8)                           # the batches prepared under the async path drain
@@ -593,7 +593,7 @@ def run():
                                    f"batch {B}, fan-out {k}, {int(args.cache_ratio*100)}% hot-degree cache, "
                                    f"{('dg(hops=%d)' % args.dg_hops) if world > 1 else '1naive'} partition x{world}, closure hops {num_hops}",
                        "steps_per_epoch": steps_per_epoch, "epoch_time_extrapolated_from_steps": K,
-                       "miss_mode": args.miss_mode, "miss_mode_probe": probe, "overlap": not args.no_overlap,
+                       "miss_mode": args.miss_mode, "miss_mode_probe": mode_probe, "overlap": not args.no_overlap,
                        "partition_vertices": Vs,
                        "hip_graph_step": use_graph,
                        "fetch": "all layers+fields (reference)" if need is None else "only what the model reads"},
