@@ -1176,3 +1176,29 @@ def test_gcn_forward_loss_matches_forward_plus_loss(dev, hiplib):
     load()
     assert infer.forward_loss(nf, labels, n_valid) is None
     assert model.forward_loss(nf, labels.cpu(), n_valid) is None
+
+
+@pytest.mark.gpu
+def test_bench_default_path_end_to_end_small(dev, hiplib):
+    """`python bench.py` with every default phase on (timed loop, gather micro-benchmark, cache-policy analysis,
+    CPU baseline) at a small size: exactly one JSON line on stdout carrying the contract's keys"""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--vertices", "300000", "--edges", "3000000",
+                        "--steps", "30", "--cpu-baseline-seconds", "2"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 30 and d["higher_is_better"] is False and d["vs_baseline"] is None
+    assert "workload" in d["config"] and d["config"]["miss_mode"] == "async"
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and 0 < rf["frac"] < 1 and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert 0 < d["cache_hit_pct"] <= 100
