@@ -157,6 +157,41 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_cnt(int32_t* __restrict__
   if (threadIdx.x == 0) *total_out = carry;
 }
 
+// the block's two single-block scans in one launch (both latency bound, one less link in the sampler's chain):
+// per-destination pick counts -> indptr (as k_scan_cnt) and per-word-block popcounts -> exclusive offsets + layer
+// size (as k_bm_scan)
+__global__ __launch_bounds__(kScanThreads) void k_scan2(const int32_t* __restrict__ cnt,
+                                                        const int32_t* __restrict__ n_dev,
+                                                        int32_t* __restrict__ indptr, int32_t* __restrict__ total_out,
+                                                        int32_t cap_rows, int32_t* __restrict__ partial, int n_blocks,
+                                                        int32_t* __restrict__ count_out) {
+  __shared__ int lds[16];
+  const int n = *n_dev;
+  int carry = 0;
+  for (int base = 0; base < n; base += kScanThreads) {
+    const int i = base + threadIdx.x;
+    const int v = i < n ? cnt[i] : 0;
+    int tot;
+    const int ex = block_excl_scan(v, lds, &tot);
+    if (i < n) indptr[i] = carry + ex;
+    carry += tot;
+  }
+  // rows n..cap_rows are empty: a fixed-shape consumer (hipGraph replay) may run over all cap_rows
+  for (int i = n + threadIdx.x; i <= cap_rows; i += kScanThreads) indptr[i] = carry;
+  if (threadIdx.x == 0) *total_out = carry;
+  __syncthreads();
+  carry = 0;
+  for (int base = 0; base < n_blocks; base += kScanThreads) {
+    const int i = base + threadIdx.x;
+    const int v = i < n_blocks ? partial[i] : 0;
+    int tot;
+    const int ex = block_excl_scan(v, lds, &tot);
+    if (i < n_blocks) partial[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) *count_out = carry;
+}
+
 // ---- bitmap -> ascending ids ------------------------------------------------
 __global__ __launch_bounds__(256) void k_bm_count(const unsigned long long* __restrict__ bm, int64_t n_words,
                                                   int32_t* __restrict__ partial) {
@@ -563,13 +598,10 @@ static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t
     PG_LAUNCH_CHECK();
     int32_t* indptr_b = o->blk_indptr + o->blk_indptr_off[b];
     int32_t* src_b = o->blk_src + o->blk_src_off[b];
-    hipLaunchKernelGGL(k_scan_cnt<false>, dim3(1), dim3(kScanThreads), 0, st, s->cnt, lcnt + b + 1, indptr_b, ecnt + b,
-                       (int32_t)cap_dst);
-    PG_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bm_count, dim3(s->n_bm_blocks), dim3(256), 0, st, s->bitmap, s->n_words, s->partial);
     PG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bm_scan, dim3(1), dim3(kScanThreads), 0, st, s->partial, s->n_bm_blocks, lcnt + b,
-                       (int64_t*)nullptr);
+    hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kScanThreads), 0, st, s->cnt, lcnt + b + 1, indptr_b, ecnt + b,
+                       (int32_t)cap_dst, s->partial, s->n_bm_blocks, lcnt + b);
     PG_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bm_emit, dim3(s->n_bm_blocks), dim3(256), 0, st, s->bitmap, s->n_words, s->partial,
                        s->layer_ids[b], s->cap[b], s->word_rank);
