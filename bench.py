@@ -49,11 +49,38 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def host_info(cacher=None):
+    """what the host side of the step had to work with: CPU model, cores visible, cgroup CPU quota,
+    threads of the miss path's row gather"""
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else int(q) / int(per)
+    except (OSError, ValueError):
+        pass
+    return {"cpu_model": model, "cpus_online": os.cpu_count(),
+            "cpus_affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+            "cgroup_cpu_quota": quota, "miss_gather_threads": getattr(cacher, "host_threads", None)}
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=None, help="timed steps (default: one whole epoch of the rank's seeds)")
-    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=10, help="untimed steady-state steps right before the timed region "
+                   "(honoured as given; the one-off set-up steps — eager warm-up, hipGraph capture per ring slot, cache "
+                   "fill after the first step — come before them and are reported as config.setup_steps)")
+    p.add_argument("--window", type=int, default=20, help="steps per entry of ms_per_step_windows")
+    p.add_argument("--cold-start", action="store_true", help="drain the pipeline before the timed region (every batch of "
+                   "the timed region pays the sample -> gather -> miss-path latency from an empty pipeline; diagnosis only)")
     p.add_argument("--model", default="gcn", choices=["gcn", "graphsage"])
     p.add_argument("--vertices", type=int, default=10_000_000)
     p.add_argument("--edges", type=int, default=100_000_000)
@@ -407,26 +434,31 @@ def run():
     # default: one whole epoch of this rank's seeds (1084 steps at N = 1: a quarter of a second), nothing extrapolated
     K = args.steps if args.steps is not None else min(steps_per_epoch, 5000)
     W = args.warmup
+    S = 1                                                # set-up steps: the cache is filled after the first one
     if use_graph:
         trainer = GraphedTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, need=need, world_size=world,
                                  keep_losses=False, lookahead=args.lookahead)
-        W = max(W, 3 + 2 * len(sampler.slots))           # eager warm-up + one capture per ring slot, all untimed
+        S = 3 + 2 * len(sampler.slots)                   # eager warm-up + one capture and first replay per ring slot
+        trainer.keep_primed = not args.cold_start
     else:
         trainer = MinibatchTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, overlap=not args.no_overlap,
                                    need=need)
     trainer.after_first_step = lambda: cacher.auto_cache(g, embed_names, cache_ratio=args.cache_ratio)  # pa_gcn.py:99-100
     model.train()
     PROBE = 40
-    it = cycle_batches(sampler, W + K + 1 + (4 * PROBE + 64 if probe_modes else 0))
+    it = cycle_batches(sampler, S + W + K + 8 + (4 * PROBE + 64 if probe_modes else 0))
 
-    # ---- warmup (untimed; the cache is filled after its first step, as in the reference) ----
+    # ---- set-up (untimed, one-off: the cache is filled after its first step, as in the reference; graph capture) ----
     t0 = time.time()
-    if W > 0:
-        trainer.run_steps(it, W)
+    trainer.run_steps(it, S)
     if cacher.cached_num == 0:
         cacher.auto_cache(g, embed_names, cache_ratio=args.cache_ratio)
     torch.cuda.synchronize()
-    log(f"[bench] rank {rank}: warmup {W} steps + cache fill ({cacher.cached_num} rows) in {time.time()-t0:.1f}s")
+    log(f"[bench] rank {rank}: set-up {S} steps + cache fill ({cacher.cached_num} rows) in {time.time()-t0:.1f}s")
+    # ---- warm-up: W steady-state steps, untimed ----
+    if W > 0:
+        trainer.run_steps(it, W)
+        torch.cuda.synchronize()
     # ---- which miss path? (multi-GPU default) ------------------------------------------------
     # The async queue is the faster path on one GPU, but it is sensitive to how many streams are busy (a fifth one
     # made it 1.5-3x slower) and RCCL brings its own; that cannot be tried from the build container, so with
@@ -499,13 +531,46 @@ def run():
         import cProfile
         prof_host = cProfile.Profile()
         prof_host.enable()
+    # per-window step times: one event on the compute stream every `window` steps (first one = start of the region)
+    win = max(1, min(args.window, K))
+    cstream = trainer.compute_stream if use_graph else torch.cuda.current_stream(dev)
+    wev = [torch.cuda.Event(enable_timing=True)]
+    def on_step(done_, loss_):
+        if done_ % win == 0 or done_ == K:
+            e_ = torch.cuda.Event(enable_timing=True)
+            e_.record(cstream)
+            wev.append(e_)
+    trainer.on_step = on_step
+    mq0 = cacher.miss_queue_stats()
+    wev[0].record(cstream)
     t0 = time.time()
     done = trainer.run_steps(it, K)
     t_issued = time.time() - t0          # launch thread done; ~= elapsed when the host is the bottleneck
-    torch.cuda.synchronize()
+    if not os.environ.get("PG_BENCH_NO_DRAIN"):
+        cacher.drain_misses()            # worker's outstanding copies enqueued (host-side wait, no HIP call) ...
+    torch.cuda.synchronize()             # ... then the device
     if world > 1:
         dist.barrier()
     elapsed = time.time() - t0
+    trainer.on_step = None
+    windows = []
+    for i_ in range(1, len(wev)):
+        n_ = min(i_ * win, K) - (i_ - 1) * win
+        windows.append(round(wev[i_ - 1].elapsed_time(wev[i_]) / max(1, n_), 5))
+    timed_out = bool(cacher.misses_timed_out())
+    copy_windows = None
+    if os.environ.get("PG_MISSQ_COPYLOG"):
+        cl = cacher.miss_copy_log()[-K:]
+        if os.environ.get("PG_MISSQ_COPYLOG") == "2":
+            log("[copylog] " + " ".join(f"{b / max(1e-9, m) / 1e6:.0f}" for b, m in cl))
+        copy_windows = [round(sum(b for b, _ in cl[i:i + win]) / max(1e-9, sum(m for _, m in cl[i:i + win])) / 1e6, 2)
+                        for i in range(0, len(cl), win)]       # GB/s of the H2D copies per window
+    mq_stats = cacher.miss_queue_stats()
+    if mq_stats and mq0:
+        mq_stats["timed_region"] = {k_: mq_stats[k_] - mq0[k_] for k_ in ("jobs", "waits_by_event", "waits_by_spin_kernel")}
+    if timed_out:
+        raise SystemExit("bench.py: the async miss queue's device-side wait timed out (worker thread dead?) — "
+                         "the timed steps trained on rows that never landed; no number is reported")
     if tl and getattr(trainer, "debug_events", None):
         for ev in trainer.debug_events[30:42]:
             log(f"[load-stream] wait(sampler ready) {ev[0].elapsed_time(ev[1])*1e3:8.1f} us | wait(slot done) {ev[1].elapsed_time(ev[2])*1e3:8.1f} us | work {ev[2].elapsed_time(ev[3])*1e3:8.1f} us")
@@ -593,6 +658,7 @@ def run():
                                    f"batch {B}, fan-out {k}, {int(args.cache_ratio*100)}% hot-degree cache, "
                                    f"{('dg(hops=%d)' % args.dg_hops) if world > 1 else '1naive'} partition x{world}, closure hops {num_hops}",
                        "steps_per_epoch": steps_per_epoch, "epoch_time_extrapolated_from_steps": K,
+                       "setup_steps": S, "pipeline": "cold (drained before the timed region)" if args.cold_start else "primed",
                        "miss_mode": args.miss_mode, "miss_mode_probe": mode_probe, "overlap": not args.no_overlap,
                        "partition_vertices": Vs,
                        "hip_graph_step": use_graph,
@@ -602,6 +668,9 @@ def run():
             "feat_gather_GBps": (micro[1 << 20]["GBps"] if micro else achieved),
             "seeds_per_s": seeds_total / elapsed,
             "host_issue_ms_per_step": t_issued / K * 1e3,     # launch thread's share; == ms_per_step when it is the bottleneck
+            "ms_per_step_windows": windows, "window_steps": win,
+            "warmup_requested": args.warmup, "misses_timed_out": timed_out,
+            "host": host_info(cacher), "miss_queue": mq_stats, "miss_copy_GBps_windows": copy_windows,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -164,6 +164,22 @@ int pg_missq_wait_device(pg_missq_t* q, int slot, pg_stream_t stream);
  * its own stream. Default 256 = everything through the worker.                                            */
 int pg_missq_set_cpu_share(pg_missq_t* q, int32_t share_of_256);
 int pg_missq_timed_out(pg_missq_t* q, int* out);
+/* blocks the HOST until every submitted job has left the worker (its copy is enqueued); makes no HIP call, so
+ * it is safe to call right before a device-wide synchronise (a worker that still has to enqueue a copy while
+ * the trainer thread sits in hipDeviceSynchronize with a spin-wait kernel parked behind it was measured to
+ * cost 15 ms).                                                                                         */
+int pg_missq_drain(pg_missq_t* q);
+/* counters since creation: out[0] jobs, out[1] rows moved, out[2] consumer waits ordered by event (copy already
+ * enqueued), out[3] consumer waits by the spin kernel, out[4..7] mean per-job microseconds: submit->miss list
+ * published, CPU row gather, copy enqueue, submit->job done                                             */
+int pg_missq_stats(pg_missq_t* q, double out[8]);
+/* which SDMA engine the worker's host->device copies go to (hsa_amd_sdma_engine_id_t bit; 0 = the HIP runtime's
+ * own choice through hipMemcpyAsync) and the host->device GB/s every engine reached in the calibration at creation
+ * (0 = engine not offered). The worker submits its copies to the fastest one directly (see pg_missq.hip).   */
+int pg_missq_copy_engine(pg_missq_t* q, uint32_t* engine_mask, double GBps[16]);
+/* diagnosis (env PG_MISSQ_COPYLOG=1 at creation): the last `cap` host->device copies of the worker's wide field as
+ * (bytes, milliseconds on the copy stream), oldest first; *n_out = entries written                        */
+int pg_missq_copy_log(pg_missq_t* q, int64_t* bytes, float* ms, int64_t cap, int64_t* n_out);
 
 /* ------------------------------------------------------------------------
  * 2. Neighbour sampler  —  dgl.contrib.sampling.NeighborSampler as called at

@@ -31,6 +31,10 @@
 #include <thread>
 #include <vector>
 
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include <hsa/amd_hsa_signal.h>
+
 #include "pg_common.h"
 
 namespace pg {
@@ -61,6 +65,31 @@ __global__ void k_wait_landed(const uint32_t* landed, uint32_t seq, uint32_t* ti
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// The host->device copy of the miss rows is submitted straight to ONE chosen SDMA engine through ROCr
+// (hsa_amd_memory_async_copy_on_engine) instead of hipMemcpyAsync: the HIP runtime re-picks "the lowest free
+// engine" for a stream every ~170 commands, and when engine 0 happens to be busy at that moment (always, once the
+// step is PCIe bound) it moves the stream to engine 1 for the next ~170 copies — which reads host memory at 23 GB/s
+// instead of 53 GB/s on this part (measured per copy, AMD_LOG_MASK=0x300: copy_engine=0x1 -> 53-54 GB/s,
+// copy_engine=0x2 -> 23.0 GB/s, strictly bimodal). That was the "slow mode" of the pipeline: a GraphSAGE step
+// 0.40 -> 0.90 ms, a GCN step 0.20 -> 0.36 ms for a few hundred steps at a time. The copy's completion signal is
+// an amd_signal_t in GPU-visible system memory; the copy stream waits for it with a one-wave kernel.
+//
+// The signal lives in HOST memory, so every poll is a PCIe read, and a kernel with PCIe reads in flight makes every
+// kernel boundary of the other streams ~1 us slower (tools/exp_overlap2.py): polling back to back cost the GCN
+// step 0.197 -> 0.204 ms. `poll_sleeps` x ~3.9 us between polls (default 3: the read is in flight ~10 % of the
+// time, the copy's completion is seen ~6 us late on average — 1.5 % of a 20 MB copy).
+__global__ void k_wait_hsa_signal(const volatile int64_t* value, uint32_t* timed_out, int poll_sleeps) {
+  const unsigned long long t0 = wall_clock64();   // 100 MHz
+  while (__hip_atomic_load(const_cast<const int64_t*>(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) > 0) {
+    for (int i = 0; i < poll_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    if (wall_clock64() - t0 > 300000000ull) {     // 3 s
+      *timed_out = 1;
+      break;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
 // One row of the host table into the pinned staging buffer. The staging buffer is only ever read by the copy
@@ -186,6 +215,10 @@ struct pg_missq_slot {
   float* staging_h[PG_MAX_FIELDS] = {nullptr};  // pinned [max_rows * dim]
   float* staged_d[PG_MAX_FIELDS] = {nullptr};   // device [max_rows * dim]
   hipEvent_t filled = nullptr;
+  hipEvent_t cp0 = nullptr, cp1 = nullptr;   // PG_MISSQ_COPYLOG: brackets of the slot's last H2D copy
+  hsa_signal_t sig[PG_MAX_FIELDS] = {};      // direct SDMA path: completion signal of field f's copy
+  int cp_field = -1;
+  int64_t cp_bytes = 0;
   uint32_t submitted = 0;  // last sequence number handed to the worker (trainer thread)
   uint32_t done = 0;       // last sequence number whose copy has been enqueued (worker, under mutex)
   int32_t last_count = 0;
@@ -213,8 +246,86 @@ struct pg_missq {
   std::atomic<int> cpu_share{256};   // of 256: the leading share of every miss list that the CPU path moves
   // PG_MISSQ_DEBUG=1: accumulated worker phase times (us) printed at destroy
   double t_sync = 0, t_flag = 0, t_gather = 0, t_enqueue = 0, t_copy = 0, t_sub2flag = 0, t_sub2pop = 0;
+  double t_total = 0;
+  bool copy_log = getenv("PG_MISSQ_COPYLOG") != nullptr;
+  // direct SDMA path (see k_wait_hsa_signal)
+  bool hsa_ok = false;
+  hsa_agent_t gpu_agent = {}, cpu_agent = {};
+  uint32_t engine = 0;            // hsa_amd_sdma_engine_id_t bit
+  double engine_GBps[16] = {0};   // calibration at creation: host->device rate of every engine that reported free
+  uint64_t ts_freq = 0;
+  std::vector<std::pair<int64_t, float>> copies;   // (bytes, ms) per job, resolved when the slot is reused
   int64_t n_jobs = 0, n_rows = 0;
 };
+
+// ---- direct SDMA path: agents, engine calibration, per-slot signals -------------------------------------------
+static bool hsa_copy_sync(pg_missq* q, void* dst, const void* src, size_t bytes, uint32_t engine, hsa_signal_t sig,
+                          double* seconds) {
+  hsa_signal_store_relaxed(sig, 1);
+  const auto t0 = std::chrono::steady_clock::now();
+  if (hsa_amd_memory_async_copy_on_engine(dst, q->gpu_agent, src, q->cpu_agent, bytes, 0, nullptr, sig,
+                                          (hsa_amd_sdma_engine_id_t)engine, true) != HSA_STATUS_SUCCESS)
+    return false;
+  // bounded wait (1 s): an engine that never completes must not hang creation
+  if (hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, 1, 1000000000ull, HSA_WAIT_STATE_ACTIVE) > 0) return false;
+  if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return true;
+}
+
+static void hsa_copy_init(pg_missq* q) {
+  const char* e = getenv("PG_MISSQ_HSA_COPY");
+  if (e && atoi(e) == 0) return;
+  if (hsa_init() != HSA_STATUS_SUCCESS) return;   // reference counted; the HIP runtime holds its own
+  pg_missq_slot& s0 = q->slots[0];
+  hsa_amd_pointer_info_t pi_d, pi_h;
+  memset(&pi_d, 0, sizeof(pi_d)); memset(&pi_h, 0, sizeof(pi_h));
+  pi_d.size = sizeof(pi_d); pi_h.size = sizeof(pi_h);
+  if (hsa_amd_pointer_info(s0.staged_d[0], &pi_d, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS ||
+      hsa_amd_pointer_info(s0.staging_h[0], &pi_h, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS)
+    return;
+  if (pi_d.type == HSA_EXT_POINTER_TYPE_UNKNOWN || pi_h.type == HSA_EXT_POINTER_TYPE_UNKNOWN) return;
+  q->gpu_agent = pi_d.agentOwner;
+  q->cpu_agent = pi_h.agentOwner;
+  hsa_device_type_t tg, tc;
+  if (hsa_agent_get_info(q->gpu_agent, HSA_AGENT_INFO_DEVICE, &tg) != HSA_STATUS_SUCCESS || tg != HSA_DEVICE_TYPE_GPU) return;
+  if (hsa_agent_get_info(q->cpu_agent, HSA_AGENT_INFO_DEVICE, &tc) != HSA_STATUS_SUCCESS || tc != HSA_DEVICE_TYPE_CPU) return;
+  for (auto& s : q->slots)
+    for (int f = 0; f < q->n_fields; ++f)
+      if (hsa_signal_create(0, 0, nullptr, &s.sig[f]) != HSA_STATUS_SUCCESS) return;
+  (void)hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &q->ts_freq);
+  uint32_t mask = 0;
+  if (hsa_amd_memory_copy_engine_status(q->gpu_agent, q->cpu_agent, &mask) != HSA_STATUS_SUCCESS || mask == 0) return;
+  // calibrate: the widest field's staging buffer of slot 0, up to 16 MiB, twice per engine (first = warm-up)
+  int fw = 0;
+  for (int f = 1; f < q->n_fields; ++f)
+    if (q->fields[f].dim > q->fields[fw].dim) fw = f;
+  const size_t bytes = std::min<size_t>((size_t)q->max_rows * q->fields[fw].dim * sizeof(float), (size_t)16 << 20);
+  const char* force = getenv("PG_MISSQ_ENGINE");
+  double best = 0;
+  for (int b = 0; b < 16; ++b) {
+    if (!((mask >> b) & 1u)) continue;
+    if (force && atoi(force) != b) continue;
+    double sec = 0;
+    if (!hsa_copy_sync(q, s0.staged_d[fw], s0.staging_h[fw], bytes, 1u << b, s0.sig[0], nullptr)) continue;
+    if (!hsa_copy_sync(q, s0.staged_d[fw], s0.staging_h[fw], bytes, 1u << b, s0.sig[0], &sec) || sec <= 0) continue;
+    q->engine_GBps[b] = bytes / sec / 1e9;
+    if (q->engine_GBps[b] > best * 1.03) {   // ties go to the lower engine id
+      best = q->engine_GBps[b];
+      q->engine = 1u << b;
+    }
+  }
+  if (!q->engine) return;
+  if (q->copy_log) (void)hsa_amd_profiling_async_copy_enable(true);
+  for (auto& s : q->slots)
+    for (int f = 0; f < q->n_fields; ++f) hsa_signal_store_relaxed(s.sig[f], 0);
+  q->hsa_ok = true;
+  if (getenv("PG_MISSQ_DEBUG")) {
+    fprintf(stderr, "[missq] direct SDMA copies on engine mask 0x%x; host->device GB/s per engine:", q->engine);
+    for (int b = 0; b < 16; ++b)
+      if (q->engine_GBps[b] > 0) fprintf(stderr, " %d:%.1f", b, q->engine_GBps[b]);
+    fprintf(stderr, "\n");
+  }
+}
 
 static void missq_worker(pg_missq* q) {
   if (hipSetDevice(q->device) != hipSuccess) {
@@ -239,6 +350,21 @@ static void missq_worker(pg_missq* q) {
     const auto t0 = now();
     // the previous copy out of this slot's staging buffers must have drained (4 steps ago: a formality)
     if (hipEventSynchronize(s.filled) != hipSuccess) rc = PG_ERR_HIP;
+    if (q->copy_log && s.cp_bytes > 0 && q->hsa_ok && s.cp_field >= 0) {
+      hsa_amd_profiling_async_copy_time_t t;
+      if (hsa_amd_profiling_get_async_copy_time(s.sig[s.cp_field], &t) == HSA_STATUS_SUCCESS && q->ts_freq) {
+        std::lock_guard<std::mutex> l(q->m);
+        q->copies.emplace_back(s.cp_bytes, (float)((double)(t.end - t.start) * 1e3 / (double)q->ts_freq));
+      }
+      s.cp_bytes = 0;
+    } else if (q->copy_log && s.cp_bytes > 0) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, s.cp0, s.cp1) == hipSuccess) {
+        std::lock_guard<std::mutex> l(q->m);
+        q->copies.emplace_back(s.cp_bytes, ms);
+      }
+      s.cp_bytes = 0;
+    }
     const auto t1 = now();
     // wait for the GPU to publish the miss list of this submission
     // poll: the list arrives 50-150 us after the job was queued. sleep_for(5 us) really sleeps ~55 us (timer
@@ -284,9 +410,39 @@ static void missq_worker(pg_missq* q) {
         });
         const auto tb = now();
         tg += us(ta, tb);
-        if (hipMemcpyAsync(s.staged_d[f], stg, (size_t)m * row_bytes, hipMemcpyHostToDevice, q->copy_stream) !=
-            hipSuccess)
-          rc = PG_ERR_HIP;
+        const bool logc = q->copy_log && row_bytes >= 256;
+        bool direct = false;
+        if (q->hsa_ok) {
+          // straight to the calibrated SDMA engine; the copy stream then waits for the completion signal on the device
+          hsa_signal_store_relaxed(s.sig[f], 1);
+          direct = hsa_amd_memory_async_copy_on_engine(s.staged_d[f], q->gpu_agent, stg, q->cpu_agent, (size_t)m * row_bytes,
+                                                       0, nullptr, s.sig[f], (hsa_amd_sdma_engine_id_t)q->engine,
+                                                       true) == HSA_STATUS_SUCCESS;
+          if (direct) {
+            const volatile int64_t* val = &reinterpret_cast<amd_signal_t*>(s.sig[f].handle)->value;
+            static const int poll_sleeps = getenv("PG_MISSQ_POLL_SLEEPS") ? atoi(getenv("PG_MISSQ_POLL_SLEEPS")) : 3;
+            hipLaunchKernelGGL(k_wait_hsa_signal, dim3(1), dim3(1), 0, q->copy_stream, val, q->timeout_d, poll_sleeps);
+            if (hipGetLastError() != hipSuccess) rc = PG_ERR_HIP;
+            if (logc) {
+              s.cp_bytes = (int64_t)m * (int64_t)row_bytes;
+              s.cp_field = f;
+            }
+          } else {
+            hsa_signal_store_relaxed(s.sig[f], 0);
+            q->hsa_ok = false;   // ROCr refused: back to the runtime's copy for good
+          }
+        }
+        if (!direct) {
+          if (logc) (void)hipEventRecord(s.cp0, q->copy_stream);
+          if (hipMemcpyAsync(s.staged_d[f], stg, (size_t)m * row_bytes, hipMemcpyHostToDevice, q->copy_stream) !=
+              hipSuccess)
+            rc = PG_ERR_HIP;
+          if (logc) {
+            (void)hipEventRecord(s.cp1, q->copy_stream);
+            s.cp_bytes = (int64_t)m * (int64_t)row_bytes;
+            s.cp_field = -1;
+          }
+        }
         if (rc == PG_OK)
           rc = pg_scatter_rows(s.staged_d[f], s.pos_d, m, nullptr, fd.dim, s.out[f], s.out_stride[f],
                                (pg_stream_t)q->copy_stream);                 // storage.py:199-200
@@ -311,6 +467,7 @@ static void missq_worker(pg_missq* q) {
       s.last_count = (int32_t)m;
       q->t_sync += us(t0, t1); q->t_flag += us(t1, t2); q->t_gather += tg; q->t_enqueue += te;
       q->n_jobs += 1; q->n_rows += m;
+      q->t_total += us(s.t_submit, now());
       if (rc != PG_OK) q->error = rc;
     }
     q->cv_done.notify_all();
@@ -346,6 +503,10 @@ static void missq_free(pg_missq* q) {
       (void)hipFree(s.staged_d[f]);
     }
     if (s.filled) (void)hipEventDestroy(s.filled);
+    for (int f = 0; f < PG_MAX_FIELDS; ++f)
+      if (s.sig[f].handle) (void)hsa_signal_destroy(s.sig[f]);
+    if (s.cp0) (void)hipEventDestroy(s.cp0);
+    if (s.cp1) (void)hipEventDestroy(s.cp1);
   }
   (void)hipFree(q->timeout_d);
   if (q->copy_stream) (void)hipStreamDestroy(q->copy_stream);
@@ -383,6 +544,7 @@ int pg_missq_create(int device, int n_slots, int64_t max_rows, const pg_missq_fi
       ok = ok && hipMalloc((void**)&s.staged_d[f], bytes) == hipSuccess;
     }
     ok = ok && hipEventCreateWithFlags(&s.filled, hipEventDisableTiming) == hipSuccess;
+    if (q->copy_log) ok = ok && hipEventCreate(&s.cp0) == hipSuccess && hipEventCreate(&s.cp1) == hipSuccess;
     if (!ok) break;
     *s.flag_h = 0;
     *s.count_h = 0;
@@ -399,6 +561,7 @@ int pg_missq_create(int device, int n_slots, int64_t max_rows, const pg_missq_fi
     missq_free(q);
     return PG_ERR_NOMEM;
   }
+  hsa_copy_init(q);
   q->worker = std::thread(missq_worker, q);
   *out = q;
   return PG_OK;
@@ -503,6 +666,49 @@ int pg_missq_timed_out(pg_missq_t* q, int* out) {
   uint32_t v = 0;
   PG_HIP(hipMemcpy(&v, q->timeout_d, 4, hipMemcpyDeviceToHost));
   *out = (int)v;
+  return PG_OK;
+}
+
+int pg_missq_drain(pg_missq_t* q) {
+  if (!q) return PG_ERR_INVALID;
+  std::unique_lock<std::mutex> l(q->m);
+  q->cv_done.wait(l, [&] {
+    if (q->error != PG_OK) return true;
+    for (auto& s : q->slots)
+      if (s.done != s.submitted) return false;
+    return true;
+  });
+  return q->error;
+}
+
+int pg_missq_copy_log(pg_missq_t* q, int64_t* bytes, float* ms, int64_t cap, int64_t* n_out) {
+  if (!q || !n_out || cap < 0 || (cap > 0 && (!bytes || !ms))) return PG_ERR_INVALID;
+  std::lock_guard<std::mutex> l(q->m);
+  const int64_t n = std::min<int64_t>(cap, (int64_t)q->copies.size());
+  const size_t first = q->copies.size() - (size_t)n;
+  for (int64_t i = 0; i < n; ++i) {
+    bytes[i] = q->copies[first + i].first;
+    ms[i] = q->copies[first + i].second;
+  }
+  *n_out = n;
+  return PG_OK;
+}
+
+int pg_missq_stats(pg_missq_t* q, double out[8]) {
+  if (!q || !out) return PG_ERR_INVALID;
+  std::lock_guard<std::mutex> l(q->m);
+  const double n = q->n_jobs ? (double)q->n_jobs : 1.0;
+  out[0] = (double)q->n_jobs; out[1] = (double)q->n_rows;
+  out[2] = (double)q->n_wait_event; out[3] = (double)q->n_wait_spin;
+  out[4] = q->t_sub2flag / n; out[5] = q->t_gather / n; out[6] = q->t_enqueue / n; out[7] = q->t_total / n;
+  return PG_OK;
+}
+
+int pg_missq_copy_engine(pg_missq_t* q, uint32_t* engine_mask, double GBps[16]) {
+  if (!q || !engine_mask) return PG_ERR_INVALID;
+  *engine_mask = q->hsa_ok ? q->engine : 0u;
+  if (GBps)
+    for (int b = 0; b < 16; ++b) GBps[b] = q->engine_GBps[b];
   return PG_OK;
 }
 

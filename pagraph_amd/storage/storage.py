@@ -525,6 +525,40 @@ class GraphCacheServer:
             L.check(self.lib.pg_missq_destroy(self._missq), "pg_missq_destroy")
             self._missq, self._missq_rows, self._missq_bufs, self._missq_share = None, 0, {}, None
 
+    def drain_misses(self):
+        """block the host until the async queue's worker has enqueued the copy of every submitted batch (no HIP
+        call). Call before a device-wide synchronise: see pg_missq_drain."""
+        if self._missq is not None:
+            L.check(self.lib.pg_missq_drain(self._missq), "pg_missq_drain")
+
+    def miss_queue_stats(self):
+        """async queue counters since its creation (None without a queue): jobs, rows, how the consumer was ordered
+        after the rows (event vs spin kernel), mean per-job microseconds of the worker's phases"""
+        if self._missq is None:
+            return None
+        v = (ctypes.c_double * 8)()
+        L.check(self.lib.pg_missq_stats(self._missq, v), "pg_missq_stats")
+        eng = L.c_u32(0)
+        rate = (ctypes.c_double * 16)()
+        L.check(self.lib.pg_missq_copy_engine(self._missq, ctypes.byref(eng), rate), "pg_missq_copy_engine")
+        return {"jobs": int(v[0]), "rows_per_job": v[1] / max(1.0, v[0]), "waits_by_event": int(v[2]),
+                "waits_by_spin_kernel": int(v[3]), "us_submit_to_published": v[4], "us_cpu_gather": v[5],
+                "us_enqueue": v[6], "us_submit_to_done": v[7],
+                "sdma_engine_mask": int(eng.value),      # 0 = hipMemcpyAsync (the runtime picks the engine)
+                "sdma_engine_h2d_GBps": {b: round(rate[b], 1) for b in range(16) if rate[b] > 0}}
+
+    def miss_copy_log(self, cap=1 << 16):
+        """(bytes, ms) of the worker's last host->device copies (needs PG_MISSQ_COPYLOG=1 in the environment)"""
+        if self._missq is None:
+            return []
+        import numpy as np
+        b = np.zeros(cap, np.int64)
+        m = np.zeros(cap, np.float32)
+        n = L.c_i64(0)
+        L.check(self.lib.pg_missq_copy_log(self._missq, b.ctypes.data, m.ctypes.data, cap, ctypes.byref(n)),
+                "pg_missq_copy_log")
+        return list(zip(b[:n.value].tolist(), m[:n.value].tolist()))
+
     def misses_timed_out(self):
         if self._missq is None:
             return False

@@ -209,6 +209,10 @@ class GraphedTrainer:
         self._first_done = False
         self.last_loss = None
         self._gseed = None
+        # True: run_steps(it, n) keeps `lookahead` batches prepared when it returns (as long as `it` has more), so
+        # the next run_steps call starts on a primed pipeline instead of paying sample -> gather -> miss-path
+        # latency for its first batches again. False: every call drains what it prepared.
+        self.keep_primed = True
 
     class _Slot:
         pass
@@ -359,6 +363,9 @@ class GraphedTrainer:
         return loss
 
     def synchronize(self):
+        """wait for everything enqueued so far: first (on the host, without touching the runtime) for the miss
+        queue's worker to enqueue its outstanding copies, then for the device"""
+        self.cacher.drain_misses()
         self.compute_stream.synchronize()
 
     def run_steps(self, it, steps=None):
@@ -388,7 +395,7 @@ class GraphedTrainer:
         while self._prepared and (steps is None or done < steps):
             # top the pipeline up BEFORE (possibly) blocking on the oldest batch's miss rows: the sampler
             # and the load stream of later batches must never wait for the host
-            if steps is None or done + len(self._prepared) < steps:
+            if steps is None or self.keep_primed or done + len(self._prepared) < steps:
                 prepare_one()
             cur = self._prepared.pop(0)
             loss = self.compute(cur)
