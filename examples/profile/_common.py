@@ -101,7 +101,9 @@ def trainer(rank, world_size, args, arch, backend='nccl'):
         torch.cuda.synchronize(dev)
         epoch_start_time = time.time()
         loop.run_steps(cycle_batches(sampler, steps), steps)
-        torch.cuda.synchronize(dev)   # the reference does not sync here; without it the time is meaningless
+        cacher.drain_misses()         # the miss queue's worker has enqueued its outstanding copies ...
+        torch.cuda.synchronize(dev)   # ... (the reference does not sync here; without it the time is meaningless)
+        cacher.check_misses()         # raises if any step consumed rows that never landed
         if rank == 0:
             epoch_dur.append(time.time() - epoch_start_time)
             print('Epoch average time: {:.4f}'.format(np.mean(np.array(epoch_dur[2:]))))

@@ -18,6 +18,17 @@ What is pinned by the reference itself:
       fed by a stand-in full-neighbour sampler (DGL's own C++ sampler is NOT
       available: that part of G6 is this build's reading of DGL 0.4.1 and is
       "parity unpinned").
+  G7  GCNSampling.forward / preprocess_forward, GCNInfer.forward / preprocess_forward
+      with NodeUpdate                    (PaGraph/model/gcn_nssc.py:6-164)
+  G8  GraphSageSampling.forward ('mean', 'gcn'; with and without preprocess)
+      with NodeUpdate                    (PaGraph/model/graphsage_nssc.py:6-134)
+      G7/G8 run the reference's model classes (layer stack, skip-concat, norm
+      scaling, preprocess branches, parameter names, autograd) on a stand-in
+      NodeFlow whose block_compute applies a STAND-IN copy_src + mean|sum reducer
+      (torch index_add over the block's edges, zero rows for destinations without
+      in-edges) in place of DGL's fused message-passing kernel, which is not
+      available. Outputs: logits and every parameter gradient of
+      sum(logits * G) for a stored G.
 
 numpy note (G4): dg.py:31 calls np.argsort with the default, UNSTABLE kind. On
 CPUs with AVX2/AVX-512 numpy >= 2.0 dispatches it to x86-simd-sort, whose tie
@@ -71,6 +82,12 @@ def install_stubs():
     frame.Frame, frame.FrameRef = _Frame, _FrameRef
     utils = types.ModuleType("dgl.utils")
     fn = types.ModuleType("dgl.function")
+    # the builtin message / reduce descriptors the models pass to block_compute (gcn_nssc.py:72-73,
+    # graphsage_nssc.py:99-110): plain records, interpreted by StandInBlockNodeFlow.block_compute
+    fn.copy_src = lambda src, out: types.SimpleNamespace(kind="copy_src", src=src, out=out)
+    fn.mean = lambda msg, out: types.SimpleNamespace(kind="mean", msg=msg, out=out)
+    fn.sum = lambda msg, out: types.SimpleNamespace(kind="sum", msg=msg, out=out)
+    fn.max = lambda msg, out: types.SimpleNamespace(kind="max", msg=msg, out=out)
     contrib = types.ModuleType("dgl.contrib")
     sampling = types.ModuleType("dgl.contrib.sampling")
     contrib.sampling = sampling
@@ -318,6 +335,125 @@ def gen_closure(dgl, utils):
                 idx += 1
 
 
+# --------------------------------------------------------------------------
+# G7/G8: the reference's model classes on a stand-in NodeFlow
+# --------------------------------------------------------------------------
+class StandInBlockNodeFlow:
+    """The NodeFlow surface the reference models touch (gcn_nssc.py:62-76,
+    graphsage_nssc.py:75-133): `layers[i].data` dicts, `num_layers`, `block_compute`.
+    block_compute is a STAND-IN for DGL 0.4.1's fused copy_src + mean|sum kernel (NOT reference
+    code): out[v] = reduce over block i's in-edges of v of src_field[u], zeros when v has none;
+    then the reference's own node UDF runs on layer i+1, as DGL's apply_node_func does."""
+
+    def __init__(self, layer_sizes, blocks):
+        self.num_layers = len(layer_sizes)
+        self.layers = [types.SimpleNamespace(data={}) for _ in layer_sizes]
+        self.layer_sizes = list(layer_sizes)
+        self.blocks = blocks            # per block: (indptr int64 [n_dst+1], src positions int64 [edges])
+
+    def block_compute(self, i, message_func, reduce_func, apply_node_func=None):
+        assert message_func.kind == "copy_src" and reduce_func.msg == message_func.out
+        assert reduce_func.kind in ("mean", "sum")
+        indptr, src = self.blocks[i]
+        h = self.layers[i].data[message_func.src]
+        n_dst = self.layer_sizes[i + 1]
+        deg = indptr[1:] - indptr[:-1]
+        dst = torch.repeat_interleave(torch.arange(n_dst), deg)
+        out = torch.zeros((n_dst, h.shape[1]), dtype=h.dtype).index_add(0, dst, h[src])
+        if reduce_func.kind == "mean":
+            out = out / deg.clamp(min=1).to(h.dtype).unsqueeze(1)
+        d = self.layers[i + 1].data
+        d[reduce_func.out] = out
+        if apply_node_func is not None:
+            d.update(apply_node_func(types.SimpleNamespace(data=d)))
+
+
+def _rand_nodeflow(rng, sizes, max_deg):
+    """random block structure: destinations get 0..max_deg in-edges (some none, some duplicates)"""
+    blocks = []
+    for b in range(len(sizes) - 1):
+        deg = rng.integers(0, max_deg + 1, size=sizes[b + 1])
+        deg[rng.integers(0, sizes[b + 1])] = 0                       # at least one destination without in-edges
+        indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        src = rng.integers(0, sizes[b], size=int(indptr[-1])).astype(np.int64)
+        blocks.append((indptr, src))
+    return blocks
+
+
+def _run_model_case(name, model, sizes, blocks, frames, rng, extra):
+    nf = StandInBlockNodeFlow(sizes, [(torch.from_numpy(ip), torch.from_numpy(sr)) for ip, sr in blocks])
+    for i, fr in enumerate(frames):
+        for k, v in fr.items():
+            nf.layers[i].data[k] = torch.from_numpy(v)
+    model.train()        # dropout p = 0: train mode is the path pa_gcn.py runs
+    logits = model(nf)
+    G = rng.standard_normal(tuple(logits.shape)).astype(np.float32)
+    (logits * torch.from_numpy(G)).sum().backward()
+    out = dict(extra)
+    out["num_layers"] = np.int64(len(sizes))
+    out["layer_sizes"] = np.asarray(sizes, np.int64)
+    for b, (ip, sr) in enumerate(blocks):
+        out[f"blk{b}_indptr"] = ip
+        out[f"blk{b}_src"] = sr
+    for i, fr in enumerate(frames):
+        for k, v in fr.items():
+            out[f"layer{i}_{k}"] = v
+    for k, v in model.state_dict().items():
+        out[f"param:{k}"] = v.detach().numpy().copy()
+    for k, v in model.named_parameters():
+        out[f"grad:{k}"] = (v.grad if v.grad is not None else torch.zeros_like(v)).numpy().copy()
+    out["logits"] = logits.detach().numpy().copy()
+    out["G"] = G
+    np.savez(os.path.join(OUT, name), **out)
+
+
+def gen_models(gcn, sage):
+    import torch.nn.functional as Fn
+    rng = np.random.default_rng(70807)
+    Fdim, H, C = 40, 32, 7
+    # ---- G7: gcn_nssc.py ---------------------------------------------------------------
+    cases = [("gcn_L1", dict(n_layers=1, preprocess=False, infer=False), [90, 40, 16]),
+             ("gcn_L2", dict(n_layers=2, preprocess=False, infer=False), [120, 70, 30, 12]),
+             ("gcn_pre_L1", dict(n_layers=1, preprocess=True, infer=False), [60, 20]),
+             ("gcn_pre_L2", dict(n_layers=2, preprocess=True, infer=False), [90, 40, 16]),
+             ("infer_L1", dict(n_layers=1, preprocess=False, infer=True), [90, 40, 16]),
+             ("infer_pre_L1", dict(n_layers=1, preprocess=True, infer=True), [60, 20])]
+    for idx, (tag, cfg, sizes) in enumerate(cases):
+        torch.manual_seed(100 + idx)
+        if cfg["infer"]:
+            model = gcn.GCNInfer(Fdim, H, C, cfg["n_layers"], Fn.relu, preprocess=cfg["preprocess"])
+        else:
+            model = gcn.GCNSampling(Fdim, H, C, cfg["n_layers"], Fn.relu, 0.0, preprocess=cfg["preprocess"])
+        blocks = _rand_nodeflow(rng, sizes, 5)
+        frames = [{"features": rng.random((sizes[0], Fdim), dtype=np.float32)}] + [{} for _ in sizes[1:]]
+        if cfg["infer"]:
+            for i in range(len(sizes)):
+                frames[i]["norm"] = (1.0 / rng.integers(1, 30, size=(sizes[i], 1))).astype(np.float32)
+        _run_model_case(f"g7_{tag}.npz", model, sizes, blocks, frames, rng,
+                        dict(arch=np.str_("gcn_infer" if cfg["infer"] else "gcn"), n_layers=np.int64(cfg["n_layers"]),
+                             preprocess=np.bool_(cfg["preprocess"]), in_feats=np.int64(Fdim), n_hidden=np.int64(H),
+                             n_classes=np.int64(C)))
+    # ---- G8: graphsage_nssc.py -----------------------------------------------------------
+    H = 16
+    cases = [("sage_mean_L1", dict(n_layers=1, preprocess=False, agg="mean"), [90, 40, 16]),
+             ("sage_mean_L2", dict(n_layers=2, preprocess=False, agg="mean"), [120, 70, 30, 12]),
+             ("sage_gcn_L1", dict(n_layers=1, preprocess=False, agg="gcn"), [90, 40, 16]),
+             ("sage_mean_pre_L1", dict(n_layers=1, preprocess=True, agg="mean"), [60, 20]),
+             ("sage_mean_pre_L2", dict(n_layers=2, preprocess=True, agg="mean"), [90, 40, 16])]
+    for idx, (tag, cfg, sizes) in enumerate(cases):
+        torch.manual_seed(200 + idx)
+        model = sage.GraphSageSampling(Fdim, H, C, cfg["n_layers"], Fn.relu, 0.0, cfg["agg"], cfg["preprocess"])
+        blocks = _rand_nodeflow(rng, sizes, 5)
+        frames = [{"features": rng.random((n, Fdim), dtype=np.float32)} for n in sizes]
+        if cfg["preprocess"]:
+            for i, n in enumerate(sizes):
+                frames[i]["neigh"] = rng.random((n, Fdim), dtype=np.float32)
+        _run_model_case(f"g8_{tag}.npz", model, sizes, blocks, frames, rng,
+                        dict(arch=np.str_("sage"), n_layers=np.int64(cfg["n_layers"]), preprocess=np.bool_(cfg["preprocess"]),
+                             aggregator=np.str_(cfg["agg"]), in_feats=np.int64(Fdim), n_hidden=np.int64(H),
+                             n_classes=np.int64(C)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     dgl = install_stubs()
@@ -329,6 +465,7 @@ def main():
     dgmod = importlib.import_module("dg")           # PaGraph/partition/dg.py
     gen_dg(dgmod)
     gen_closure(dgl, utils)
+    gen_models(importlib.import_module("PaGraph.model.gcn_nssc"), importlib.import_module("PaGraph.model.graphsage_nssc"))
     n = len([f for f in os.listdir(OUT) if f.endswith(".npz")])
     sz = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"wrote {n} fixtures, {sz/1e6:.2f} MB -> {os.path.normpath(OUT)}")

@@ -324,53 +324,95 @@ def gcn_head(indptr, src, h, W, b, labels, ignore_index=-100, grad_scale=1.0, re
     return loss, z, dh, dW, db
 
 
-def gcn_forward(nf, feats0, params, n_layers=1):
-    """GCNSampling.forward, dropout off (gcn_nssc.py:60-77) with NodeUpdate (:14-24).
-    params: list of (W[out,in], b[out]) per layer; nf from sample_nodeflow; feats0 = layer-0 features."""
-    offs = nf["layer_offsets"]
-    h = feats0
+def _act(z, concat, has_act):
+    """NodeUpdate's tail (gcn_nssc.py:19-23, graphsage_nssc.py:25-29): skip-concat, else activation (ReLU), else none"""
+    if concat:
+        return np.concatenate([z, _relu(z)], axis=1)
+    return _relu(z) if has_act else z
+
+
+def _lin(state, prefix, x):
+    return x @ np.asarray(state[prefix + ".weight"], np.float32).T + np.asarray(state[prefix + ".bias"], np.float32)
+
+
+def gcn_model_forward(blocks, layer_sizes, frames, state, n_layers, preprocess=False, infer=False):
+    """GCNSampling.forward / preprocess_forward (gcn_nssc.py:60-100) and GCNInfer.forward / preprocess_forward
+    (:130-164) with NodeUpdate (:14-24), dropout off, activation = ReLU. Pinned by tests/golden/g7_*.
+    blocks[i] = (indptr, src positions) of block i; frames[l] = {field: array} of NodeFlow layer l;
+    state = {reference parameter name: array} ('layers.N.linear.weight', 'linear.weight', ...)."""
+    reduce = "sum" if infer else "mean"                               # :72-73 vs :140-141
+    L = len(layer_sizes)
+    h = np.asarray(frames[0]["features"], np.float32)                 # :62 / :81
+    if preprocess:
+        z = _lin(state, "linear", h)                                  # :84
+        h = _act(z, n_layers == 1, True)                              # :86-90
+    n_upd = n_layers + 1 - (1 if preprocess else 0)                   # :45-58: len(self.layers)
+    assert n_upd == L - 1, "one NodeUpdate per block"
     acts = []
-    n = len(params)
-    for i, (W, b) in enumerate(params):
-        ip, sr = nf["blocks"][i]
-        nd = offs[i + 2] - offs[i + 1]
-        agg = spmm_fwd(ip, sr, h, nd, "mean")                     # :71-74
-        z = agg @ W.T + b                                         # :18
-        if i == n - 1:
-            h = z                                                 # output layer: no activation (:58)
-        elif i == n_layers - 1:
-            h = np.concatenate([z, _relu(z)], axis=1)             # :20-21 skip concat
-        else:
-            h = _relu(z)                                          # :22-23
+    for i in range(n_upd):
+        ip, sr = blocks[i]
+        agg = spmm_fwd(ip, sr, h, layer_sizes[i + 1], reduce)         # :71-74 / :94-97
+        if infer:
+            agg = agg * np.asarray(frames[i + 1]["norm"], np.float32)  # :16-17 (test=True)
+        z = _lin(state, f"layers.{i}.linear", agg)                    # :18
+        last = i == n_upd - 1                                         # :58 output layer: no activation, no concat
+        lid = i + (1 if preprocess else 0)                            # index in the reference's layer numbering
+        h = z if last else _act(z, lid == n_layers - 1, True)         # :52,56 skip_start
         acts.append(h)
     return h, acts
 
 
-def sage_forward(nf, feats_by_layer, params, n_layers=1):
-    """GraphSageSampling.forward, aggregator 'mean', dropout off
-    (graphsage_nssc.py:74-134, NodeUpdate :21-30). params: list of
-    (W_self, b_self, W_neigh, b_neigh). feats_by_layer[l] = features of NodeFlow layer l."""
+def gcn_forward(nf, feats0, params, n_layers=1):
+    """GCNSampling.forward, dropout off (gcn_nssc.py:60-77). params: list of (W[out,in], b[out]) per NodeUpdate;
+    nf from sample_nodeflow; feats0 = layer-0 features. Thin wrapper over gcn_model_forward."""
     offs = nf["layer_offsets"]
-    L = len(offs) - 1                                             # nf.num_layers
-    h = [np.asarray(f, dtype=np.float32) for f in feats_by_layer]  # :89-90
-    n = len(params)
-    for lid, (Ws, bs, Wn, bn) in enumerate(params):               # :92
+    sizes = [offs[i + 1] - offs[i] for i in range(len(params) + 1)]
+    state = {}
+    for i, (W, b) in enumerate(params):
+        state[f"layers.{i}.linear.weight"], state[f"layers.{i}.linear.bias"] = W, b
+    frames = [{"features": feats0}] + [{} for _ in sizes[1:]]
+    return gcn_model_forward(nf["blocks"], sizes, frames, state, n_layers)
+
+
+def sage_model_forward(blocks, layer_sizes, frames, state, n_layers, aggregator="mean", preprocess=False):
+    """GraphSageSampling.forward (graphsage_nssc.py:74-134) with NodeUpdate (:21-30), aggregators 'mean' (:98-101)
+    and 'gcn' (:102-106), dropout off, activation = ReLU. Pinned by tests/golden/g8_*. Arguments as
+    gcn_model_forward; under preprocess every layer's frame also holds 'neigh' (:77)."""
+    reduce = {"mean": "mean", "gcn": "sum"}[aggregator]
+    L = len(layer_sizes)                                              # nf.num_layers
+    if preprocess:
+        h = []
+        for i in range(L):                                            # :76-87
+            z = _lin(state, "fc_self", np.asarray(frames[i]["features"], np.float32)) + \
+                _lin(state, "fc_neigh", np.asarray(frames[i]["neigh"], np.float32))
+            h.append(_act(z, n_layers == 1, True))
+    else:
+        h = [np.asarray(frames[i]["features"], np.float32) for i in range(L)]   # :89-90
+    n_upd = n_layers + 1 - (1 if preprocess else 0)
+    for lid in range(n_upd):                                          # :92
         act = {}
-        for i in range(lid, L - 1):                               # :93
-            ip, sr = nf["blocks"][i]
-            nd = offs[i + 2] - offs[i + 1]
-            neigh = spmm_fwd(ip, sr, h[i], nd, "mean")            # :98-101
-            z = h[i + 1] @ Ws.T + bs + neigh @ Wn.T + bn          # :24
-            if lid == n - 1:
-                a = z
-            elif lid == n_layers - 1:
-                a = np.concatenate([z, _relu(z)], axis=1)
-            else:
-                a = _relu(z)
-            act[i + 1] = a
-        for i in range(lid + 1, L):                               # :129-131
+        for i in range(lid, L - 1):                                   # :93
+            ip, sr = blocks[i]
+            neigh = spmm_fwd(ip, sr, h[i], layer_sizes[i + 1], reduce)
+            z = _lin(state, f"layers.{lid}.fc_self", h[i + 1]) + _lin(state, f"layers.{lid}.fc_neigh", neigh)   # :24
+            last = lid == n_upd - 1                                   # :71 output layer
+            ref_lid = lid + (1 if preprocess else 0)
+            act[i + 1] = z if last else _act(z, ref_lid == n_layers - 1, True)
+        for i in range(lid + 1, L):                                   # :129-131
             h[i] = act[i]
-    return h[L - 1]
+    return h[L - 1]                                                   # :133
+
+
+def sage_forward(nf, feats_by_layer, params, n_layers=1):
+    """GraphSageSampling.forward, aggregator 'mean', dropout off. params: list of (W_self, b_self, W_neigh, b_neigh);
+    feats_by_layer[l] = features of NodeFlow layer l. Thin wrapper over sage_model_forward."""
+    offs = nf["layer_offsets"]
+    sizes = [offs[i + 1] - offs[i] for i in range(len(feats_by_layer))]
+    state = {}
+    for i, (Ws, bs, Wn, bn) in enumerate(params):
+        state[f"layers.{i}.fc_self.weight"], state[f"layers.{i}.fc_self.bias"] = Ws, bs
+        state[f"layers.{i}.fc_neigh.weight"], state[f"layers.{i}.fc_neigh.bias"] = Wn, bn
+    return sage_model_forward(nf["blocks"], sizes, [{"features": f} for f in feats_by_layer], state, n_layers, "mean")
 
 
 # --------------------------------------------------------------------------

@@ -136,6 +136,7 @@ class GraphCacheServer:
         self._missq = None
         self._missq_rows = 0
         self._missq_bufs = {}            # slot -> (miss_pos, miss_fullid, miss_count) pointers
+        self._missq_pending = set()      # slots submitted to the queue and not yet waited for by their consumer
         self._missq_share = None
         self._cache_epoch = 0            # bumped whenever the cache contents / layout change (invalidates fetch plans)
         self.missq_slots = 4
@@ -353,6 +354,7 @@ class GraphCacheServer:
                         optrs[f] = out[name].data_ptr()
                         ostr[f] = out[name].stride(0)
                 L.check(self.lib.pg_missq_submit(self._missq, slot, optrs, ostr, sp), "pg_missq_submit")
+                self._missq_pending.add(slot)
                 if self._missq_share < 256:
                     self._device_tail(names, out, miss_pos, miss_fullid, miss_count, R, sp)
             elif self.miss_mode == "zerocopy":
@@ -457,6 +459,7 @@ class GraphCacheServer:
             return                       # every row was a hit (the general kernel ran only for the hit counters)
         if self.miss_mode == "async":
             L.check(self.lib.pg_missq_submit(self._missq, slot, plan.optrs, plan.ostr, sp), "pg_missq_submit")
+            self._missq_pending.add(slot)
             if self._missq_share < 256:
                 self._device_tail(plan.names, plan.out, miss_pos, miss_fullid, miss_count, R, sp)
         else:
@@ -483,6 +486,11 @@ class GraphCacheServer:
         if self._missq is None or rows > self._missq_rows:
             self._missq_bufs = {}
             if self._missq is not None:
+                # batches in flight on other slots still own the old queue's buffers: let the worker enqueue their
+                # copies, let the device finish them, only then free (a growing NodeFlow in the eager trainer)
+                L.check(self.lib.pg_missq_drain(self._missq), "pg_missq_drain")
+                torch.cuda.synchronize(self.device)
+                self._missq_pending.clear()
                 L.check(self.lib.pg_missq_destroy(self._missq), "pg_missq_destroy")
             cap = max(int(rows * 1.25), 4096)
             arr = (L.PgMissqField * len(self.dims))()
@@ -510,8 +518,12 @@ class GraphCacheServer:
         host_blocking=True waits for the worker on the CPU and then uses an event."""
         # (not keyed on miss_mode: a caller may switch paths between batches — bench.py probes both — and a batch
         # submitted to the queue must be waited for whatever the mode is by the time it is consumed)
-        if self._missq is None or self.full_cached:
+        # decided per slot, not from full_cached: a batch submitted while the cache was still empty (GraphedTrainer
+        # prepares its look-ahead batches before the first step's auto_cache) must be waited for even though every
+        # later batch is a pure cache hit
+        if self._missq is None or slot not in self._missq_pending:
             return
+        self._missq_pending.discard(slot)
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
         if host_blocking or _HOST_WAIT:
             L.check(self.lib.pg_missq_wait(self._missq, slot, L.stream_ptr(st), None), "pg_missq_wait")
@@ -524,6 +536,7 @@ class GraphCacheServer:
         if self._missq is not None:
             L.check(self.lib.pg_missq_destroy(self._missq), "pg_missq_destroy")
             self._missq, self._missq_rows, self._missq_bufs, self._missq_share = None, 0, {}, None
+            self._missq_pending.clear()
 
     def drain_misses(self):
         """block the host until the async queue's worker has enqueued the copy of every submitted batch (no HIP
@@ -565,6 +578,13 @@ class GraphCacheServer:
         v = ctypes.c_int(0)
         L.check(self.lib.pg_missq_timed_out(self._missq, ctypes.byref(v)), "pg_missq_timed_out")
         return bool(v.value)
+
+    def check_misses(self):
+        """raise if a device-side wait for miss rows ever gave up (the worker thread died or stalled > 3 s): the steps
+        since then trained on rows that never landed. Synchronises the device; the trainers call it once per epoch."""
+        if self.misses_timed_out():
+            raise L.PgError("async miss queue: a device-side wait for miss rows timed out (worker thread dead or "
+                            "stalled); feature rows of at least one minibatch never landed")
 
     def __del__(self):
         try:

@@ -119,8 +119,11 @@ class MinibatchTrainer:
         torch.cuda.synchronize(self.device)
         t0 = time.time()
         n = self.run_steps(iter(self.sampler))
+        self.cacher.drain_misses()
         torch.cuda.synchronize(self.device)
-        return n, time.time() - t0
+        dt = time.time() - t0
+        self.cacher.check_misses()
+        return n, dt
 
 
 def cycle_batches(sampler, steps):

@@ -1202,3 +1202,73 @@ def test_bench_default_path_end_to_end_small(dev, hiplib):
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert 0 < d["cache_hit_pct"] <= 100
+
+
+# ---- G7 / G8: the HIP models against the reference's own model classes -----------------------------------------
+def _nf_from_fixture(z, dev):
+    from pagraph_amd.sampling.nodeflow import NodeFlow
+    sizes = [int(x) for x in z["layer_sizes"]]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    nf = NodeFlow(torch.arange(int(offs[-1]), device=dev), offs,
+                  [torch.from_numpy(z[f"blk{b}_indptr"].astype(np.int32)).to(dev) for b in range(len(sizes) - 1)],
+                  [torch.from_numpy(z[f"blk{b}_src"].astype(np.int32)).to(dev) for b in range(len(sizes) - 1)])
+    for i in range(len(sizes)):
+        nf._node_frames[i] = {k[len(f"layer{i}_"):]: torch.from_numpy(z[k]).to(dev) for k in z.files
+                              if k.startswith(f"layer{i}_") and k != "layer_sizes"}
+    return nf
+
+
+def _check_against_reference_model(z, model, dev):
+    state = {k[len("param:"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param:")}
+    assert set(state) == set(model.state_dict()), "parameter names differ from the reference's"
+    model.load_state_dict(state)
+    model = model.to(dev).train()
+    logits = model(_nf_from_fixture(z, dev))
+    want = z["logits"]
+    assert tuple(logits.shape) == want.shape
+    err = np.abs(logits.detach().cpu().numpy() - want).max()
+    assert err <= TOL * max(1.0, np.abs(want).max()), err
+    (logits * torch.from_numpy(z["G"]).to(dev)).sum().backward()
+    for name, p in model.named_parameters():
+        g_want = z[f"grad:{name}"]
+        g_got = (p.grad if p.grad is not None else torch.zeros_like(p)).cpu().numpy()
+        assert np.abs(g_got - g_want).max() <= TOL * max(1.0, np.abs(g_want).max()), name
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "g7_*.npz"))), ids=os.path.basename)
+def test_gcn_models_vs_reference_golden(dev, hiplib, path):
+    """GCNSampling / GCNInfer (HIP aggregation + fp32-MFMA dense step) == logits and parameter gradients of the
+    reference's gcn_nssc.py classes (G7), 1e-4"""
+    from pagraph_amd.model import GCNInfer, GCNSampling
+    z = np.load(path)
+    a = (int(z["in_feats"]), int(z["n_hidden"]), int(z["n_classes"]), int(z["n_layers"]), torch.nn.functional.relu)
+    if str(z["arch"]) == "gcn_infer":
+        model = GCNInfer(*a, preprocess=bool(z["preprocess"]))
+    else:
+        model = GCNSampling(*a, 0.0, preprocess=bool(z["preprocess"]))
+    _check_against_reference_model(z, model, dev)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "g8_*.npz"))), ids=os.path.basename)
+def test_sage_models_vs_reference_golden(dev, hiplib, path):
+    """GraphSageSampling == the reference's graphsage_nssc.py class (G8), 1e-4"""
+    from pagraph_amd.model import GraphSageSampling
+    z = np.load(path)
+    model = GraphSageSampling(int(z["in_feats"]), int(z["n_hidden"]), int(z["n_classes"]), int(z["n_layers"]),
+                              torch.nn.functional.relu, 0.0, str(z["aggregator"]), bool(z["preprocess"]))
+    _check_against_reference_model(z, model, dev)
+
+
+# ---- a-13: the dg partitioner is host C++ inside the product library; its parity tests live in test_host_logic.py
+# (CPU suite) and are re-run here so that the GPU tier executes them against the library it loaded -------------
+from tests import test_host_logic as _host   # noqa: E402
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "g4_*.npz"))), ids=os.path.basename)
+def test_dg_vs_reference_golden_on_gpu_box(hiplib, path):
+    _host.test_dg_product_vs_reference_golden(hiplib, path)
+
+
+@pytest.mark.parametrize("V,E,P,hops", [(3000, 20000, 4, 1), (3000, 12000, 8, 2), (1500, 6000, 3, 3), (2000, 9000, 16, 2)])
+def test_dg_vs_oracle_medium_on_gpu_box(hiplib, oracle, V, E, P, hops):
+    _host.test_dg_product_vs_oracle_medium(hiplib, oracle, V, E, P, hops)

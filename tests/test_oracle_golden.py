@@ -124,3 +124,39 @@ def test_dropout_mask_spec(oracle):
     assert np.abs(off).max() < 0.12           # no two columns share their bits
     k1, s1 = oracle.dropout_mask(50, 64, oracle.dropout_threshold(0.1), 7, 1, 5)
     assert abs(k1.mean() - 0.9) < 0.03 and abs(float(s1) - 1 / 0.9) < 1e-3
+
+
+# ---- G7 / G8: the reference's model classes (gcn_nssc.py, graphsage_nssc.py) -----------------------------
+def _model_case(z):
+    sizes = [int(x) for x in z["layer_sizes"]]
+    blocks = [(z[f"blk{b}_indptr"], z[f"blk{b}_src"]) for b in range(len(sizes) - 1)]
+    frames = [{k[len(f"layer{i}_"):]: z[k] for k in z.files if k.startswith(f"layer{i}_") and k != "layer_sizes"}
+              for i in range(len(sizes))]
+    state = {k[len("param:"):]: z[k] for k in z.files if k.startswith("param:")}
+    return sizes, blocks, frames, state
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "g7_*.npz"))),
+                         ids=os.path.basename)
+def test_g7_gcn_models_vs_reference(oracle, path):
+    """oracle.gcn_model_forward == the reference's GCNSampling / GCNInfer (all four forward variants)"""
+    z = np.load(path)
+    sizes, blocks, frames, state = _model_case(z)
+    got, _ = oracle.gcn_model_forward(blocks, sizes, frames, state, int(z["n_layers"]), bool(z["preprocess"]),
+                                      infer=str(z["arch"]) == "gcn_infer")
+    want = z["logits"]
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "g8_*.npz"))),
+                         ids=os.path.basename)
+def test_g8_sage_models_vs_reference(oracle, path):
+    """oracle.sage_model_forward == the reference's GraphSageSampling ('mean', 'gcn', preprocess)"""
+    z = np.load(path)
+    sizes, blocks, frames, state = _model_case(z)
+    got = oracle.sage_model_forward(blocks, sizes, frames, state, int(z["n_layers"]), str(z["aggregator"]),
+                                    bool(z["preprocess"]))
+    want = z["logits"]
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
