@@ -400,7 +400,8 @@ def run():
         norm_tab = (1.0 / in_deg).unsqueeze(1).cpu().pin_memory()   # pa_server.py:43 (inf for isolated vertices, as there)
         fields["norm"] = norm_tab
         embed_names = ["features", "norm"]                    # pa_gcn.py:46
-    store = HostFeatureStore(fields, pin=False)               # both tables are already pinned / registered
+    store = HostFeatureStore(fields, pin=False,               # both tables are already pinned / registered
+                             device_visible={"features": table_device_visible, "norm": True})
     cacher = GraphCacheServer(store, Vs, sub2full, gpu, miss_mode=args.miss_mode,
                               host_threads=args.host_threads or default_host_threads(world))
     cacher.init_field(embed_names)

@@ -12,10 +12,12 @@ import numpy as np
 import scipy.sparse
 
 
-def get_graph_data(dataname):
+def get_graph_data(dataname, mmap=False):
+    """get_data.py:8-27. mmap=True maps feat.npy instead of reading it (the feature provider copies it straight
+    into its pinned / shared table: no second full-size copy in host memory)"""
     adj = scipy.sparse.load_npz(os.path.join(dataname, 'adj.npz'))
     try:
-        feat = np.load(os.path.join(dataname, 'feat.npy'))
+        feat = np.load(os.path.join(dataname, 'feat.npy'), mmap_mode='r' if mmap else None)
     except FileNotFoundError:
         print('random generate feat...')
         import torch

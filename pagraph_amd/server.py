@@ -36,9 +36,15 @@ def preprocess_features(csc, features, norm, chunk_rows=1 << 20):
     return out
 
 
-def load_store(dataset, model='gcn', preprocess=False, pin=True):
-    coo_adj, feat = data.get_graph_data(dataset)
-    features = torch.as_tensor(np.asarray(feat), dtype=torch.float32)
+def _build_fields(dataset, model, preprocess):
+    coo_adj, feat = data.get_graph_data(dataset, mmap=True)
+    if isinstance(feat, torch.Tensor):
+        features = feat
+    else:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")      # read-only memmap: the table is only ever read from here on
+            features = torch.as_tensor(np.asarray(feat), dtype=torch.float32)
     fields = {}
     if model == 'gcn':
         csc = spsp.csc_matrix(coo_adj)
@@ -53,8 +59,25 @@ def load_store(dataset, model='gcn', preprocess=False, pin=True):
     elif model == 'graphsage':
         if preprocess:
             print('preprocessing: warning: jusy copy')
-            fields['neigh'] = features
+            fields['neigh'] = features          # the same tensor: HostFeatureStore keeps ONE host copy for both names
         fields['features'] = features
     else:
         raise ValueError(model)
-    return HostFeatureStore(fields, pin=pin)
+    return fields
+
+
+def load_store(dataset, model='gcn', preprocess=False, pin=True, shared=None, local_rank=None):
+    """the feature tables of pa_server.py:38-54. `shared` (default: whenever a process group with more than one rank
+    is up): the tables exist ONCE per node in shared memory — local rank 0 loads / preprocesses and publishes,
+    the other ranks attach (HostFeatureStore.shared) — instead of one pinned copy per rank."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if shared is None:
+        shared = multi
+    if shared and multi:
+        if local_rank is None:
+            import os
+            local_rank = int(os.environ.get("LOCAL_RANK", dist.get_rank()))
+        return HostFeatureStore.shared(lambda: _build_fields(dataset, model, preprocess), local_rank,
+                                       tag="store", register=pin)
+    return HostFeatureStore(_build_fields(dataset, model, preprocess), pin=pin)

@@ -35,28 +35,102 @@ class HostFeatureStore:
     attaches to (server/pa_server.py:33-54, examples/profile/pa_gcn.py:33): a
     name -> host tensor table.  Tables are pinned when possible so the miss path
     can DMA / zero-copy from them.  `_node_frame._frame[name].data` is the
-    attribute path the reference reads (storage.py:128)."""
+    attribute path the reference reads (storage.py:128).
 
-    def __init__(self, fields, pin=True):
+    Fields that are the SAME tensor (GraphSAGE --preprocess publishes `features` twice, as 'features' and
+    'neigh') stay one host allocation. `pinned[name]` says whether the device may address the table
+    (page-locked by torch or registered with hipHostRegister); `device_visible` overrides the probe for
+    tables the caller registered itself."""
+
+    def __init__(self, fields, pin=True, device_visible=None):
         cols = {}
         self.pinned = {}
+        done = {}                          # data_ptr of the caller's tensor -> (prepared tensor, pinned?)
         for name, t in fields.items():
             t = torch.as_tensor(t)
-            if t.dim() == 1:
-                t = t.unsqueeze(1)
-            t = t.to(torch.float32).contiguous()
-            if pin and torch.cuda.is_available() and not t.is_pinned():
-                try:
-                    t = t.pin_memory()
-                except RuntimeError:
-                    pass  # too large to pin: staged miss path still works from pageable memory
-            self.pinned[name] = t.is_pinned()
-            cols[name] = _Col(t)
+            key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()))
+            if key not in done:
+                u = t.unsqueeze(1) if t.dim() == 1 else t
+                u = u.to(torch.float32).contiguous()
+                if pin and torch.cuda.is_available() and not u.is_pinned():
+                    try:
+                        u = u.pin_memory()
+                    except RuntimeError:
+                        pass  # too large to pin: the staged / async miss paths still work from pageable memory
+                vis = u.is_pinned() if torch.cuda.is_available() else False
+                done[key] = (u, vis)
+            u, vis = done[key]
+            if device_visible is not None and name in device_visible:
+                vis = bool(device_visible[name])
+            self.pinned[name] = vis
+            cols[name] = _Col(u)
         self._node_frame = _NodeFrame(cols)
 
     @property
     def ndata(self):
         return {k: c.data for k, c in self._node_frame._frame.items()}
+
+    @classmethod
+    def shared(cls, build_fields, local_rank, tag="store", register=True):
+        """ONE host copy of every table per node, mapped by all of its ranks — what the reference's shared-memory
+        graph store is (pa_server.py:33-54: one server process publishes, every trainer attaches). Collective over
+        the default process group: local rank 0 calls `build_fields()` -> {name: tensor} and copies each distinct
+        tensor into a /dev/shm file; the other ranks never build or load anything, they map the files. The files
+        are unlinked as soon as everyone holds a mapping (nothing is left behind if the job dies). Each process
+        then page-locks its mapping with hipHostRegister so the copy engines / zero-copy kernels may read it."""
+        import torch.distributed as dist
+        assert dist.is_available() and dist.is_initialized(), "HostFeatureStore.shared needs an initialised process group"
+        port = os.environ.get("MASTER_PORT", "0")
+        meta = [None]
+        maps = {}
+        if local_rank == 0:
+            fields = build_fields()
+            uniq, metas = {}, []
+            for name, t in fields.items():
+                t = torch.as_tensor(t)
+                u = t.unsqueeze(1) if t.dim() == 1 else t
+                key = (t.data_ptr(), tuple(u.shape))
+                if key not in uniq:
+                    path = f"/dev/shm/pagraph_{tag}_{port}_{len(uniq)}.bin"
+                    m = torch.from_file(path, shared=True, size=u.numel(), dtype=torch.float32).view(u.shape)
+                    m.copy_(u)                      # converts to fp32 on the way; the source may be a numpy memmap
+                    uniq[key] = (path, m)
+                path, m = uniq[key]
+                maps[name] = m
+                metas.append((name, path, tuple(u.shape)))
+            del fields
+            meta = [metas]
+        # node-local broadcast: ranks of other nodes would have their own local rank 0; single-node here
+        dist.broadcast_object_list(meta, src=0)
+        if local_rank != 0:
+            opened = {}
+            for name, path, shape in meta[0]:
+                if path not in opened:
+                    n = 1
+                    for d in shape:
+                        n *= d
+                    opened[path] = torch.from_file(path, shared=True, size=n, dtype=torch.float32).view(shape)
+                maps[name] = opened[path]
+        dist.barrier()
+        if local_rank == 0:
+            for path in set(p for _, p, _ in meta[0]):
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
+        vis = {}
+        seen = {}
+        for name, t in maps.items():
+            if t.data_ptr() not in seen:
+                ok = False
+                if register and torch.cuda.is_available():
+                    try:
+                        ok = int(torch.cuda.cudart().cudaHostRegister(t.data_ptr(), t.numel() * 4, 0)) == 0
+                    except Exception:
+                        ok = False
+                seen[t.data_ptr()] = ok
+            vis[name] = seen[t.data_ptr()]
+        return cls(maps, pin=False, device_visible=vis)
 
 
 def _table(graph, name):
@@ -117,6 +191,13 @@ class GraphCacheServer:
 
         # miss path state
         assert miss_mode in ("staged", "zerocopy", "async")
+        pinned = getattr(graph, "pinned", None)
+        if miss_mode == "zerocopy" and pinned is not None and not all(pinned.values()):
+            # a kernel reading pageable host memory faults. The async queue gathers on the CPU and works from
+            # pageable tables (and is the faster path anyway): use it, and say so.
+            print("GraphCacheServer: host table(s) {} are not page-locked; miss_mode 'zerocopy' -> 'async'".format(
+                [n for n, v in pinned.items() if not v]))
+            miss_mode = "async"
         self.miss_mode = miss_mode
         self.host_threads = int(host_threads) if host_threads else default_host_threads()
         self._cap = 0
@@ -188,17 +269,41 @@ class GraphCacheServer:
         if cache_ratio is not None:
             self.capability = min(self.capability, int(self.node_num * cache_ratio))
         print('Cache Memory: {:.2f}G. Capability: {}'.format(available / 1024 / 1024 / 1024, self.capability))
+        # The rule budgets capability * total_dim * 4 bytes, which is what the reference allocates. This build's
+        # rows are padded to whole 128-byte lines (601 -> 608 floats) and the fill stages each chunk on the
+        # device, so the same row count needs up to 6 % + one chunk more: never ask for more rows than the
+        # memory that is really free right now can hold.
+        fit, chunk_rows = self._physical_fit(min(self.capability, self.node_num), embed_names)
+        if fit < min(self.capability, self.node_num):
+            print('Capability limited by free device memory: {} -> {}'.format(self.capability, fit))
+            self.capability = fit
         if self.capability >= self.node_num:
             print('cache the full graph...')
             full_nids = torch.arange(self.node_num, device=self.device)
-            self._fill_cache(full_nids, embed_names, is_full=True)
+            self._fill_cache(full_nids, embed_names, is_full=True, chunk_rows=chunk_rows)
         else:
             print('cache the part of graph... caching percentage: {:.4f}'.format(self.capability / self.node_num))
             out_degrees = torch.as_tensor(dgl_g.out_degrees()).to(self.device)
             # descending by out-degree; ties -> lower id first (the reference's torch.argsort is unstable)
             sort_nid = torch.argsort(out_degrees, descending=True, stable=True)
             cache_nid = sort_nid[:self.capability]
-            self._fill_cache(cache_nid, embed_names, is_full=False)
+            self._fill_cache(cache_nid, embed_names, is_full=False, chunk_rows=chunk_rows)
+
+    def _physical_fit(self, want_rows, embed_names, reserve=1 << 30):
+        """(rows, chunk_rows): how many of `want_rows` fused cache rows fit into the device memory that is free now
+        (driver-free + what torch's allocator holds unused), next to the fill's per-chunk device staging, keeping
+        `reserve` bytes back; the chunk shrinks before the cache does."""
+        total_dim = sum(self.dims[n] for n in embed_names)
+        row_bytes = self._row_stride(total_dim) * 4
+        free, _ = torch.cuda.mem_get_info(self.device)
+        free += torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+        budget = free - reserve
+        for chunk_rows in (1 << 20, 1 << 18, 1 << 16, 1 << 14):
+            chunk_rows = max(1, min(chunk_rows, want_rows))
+            rows = (budget - chunk_rows * total_dim * 4) // row_bytes
+            if rows >= want_rows:
+                return want_rows, chunk_rows
+        return max(0, int(rows)), chunk_rows
 
     @staticmethod
     def _row_stride(total_dim):
@@ -503,6 +608,10 @@ class GraphCacheServer:
             self._missq, self._missq_rows = h, cap
             self._missq_share = None
         share = max(0, min(256, int(round(self.cpu_share * 256))))
+        pinned = getattr(self.graph, "pinned", None)
+        if share < 256 and pinned is not None and not all(pinned.get(n, False) for n in self.dims):
+            raise L.PgError("cpu_share < 1 lets the device read the tail of every miss list from the host table, "
+                            "which needs page-locked tables")
         if share != self._missq_share:
             L.check(self.lib.pg_missq_set_cpu_share(self._missq, share), "pg_missq_set_cpu_share")
             self._missq_share = share

@@ -1272,3 +1272,34 @@ def test_dg_vs_reference_golden_on_gpu_box(hiplib, path):
 @pytest.mark.parametrize("V,E,P,hops", [(3000, 20000, 4, 1), (3000, 12000, 8, 2), (1500, 6000, 3, 3), (2000, 9000, 16, 2)])
 def test_dg_vs_oracle_medium_on_gpu_box(hiplib, oracle, V, E, P, hops):
     _host.test_dg_product_vs_oracle_medium(hiplib, oracle, V, E, P, hops)
+
+
+def test_auto_cache_never_outgrows_free_memory(dev, hiplib, monkeypatch):
+    """the reference's rule budgets capability * total_dim * 4 bytes; padded rows + the fill's device staging need more.
+    With little free memory the cache (and the fill chunk) shrink instead of running out of memory."""
+    import types
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    rng = np.random.default_rng(3)
+    V, Fd = 40000, 600
+    feats = rng.random((V, Fd), dtype=np.float32)
+    norm = rng.random((V, 1), dtype=np.float32)
+    c = GraphCacheServer(HostFeatureStore({"features": torch.from_numpy(feats), "norm": torch.from_numpy(norm)}), V,
+                         torch.arange(V), 0)
+    c.init_field(["features", "norm"])
+    stride_bytes = c._row_stride(601) * 4
+    assert stride_bytes == 608 * 4
+    # pretend 30 000 rows' worth of the reference's budget is free: 30 000 * 2404 B (+ the 1 GiB reserve)
+    free = 30000 * 601 * 4 + (1 << 30)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda device=None: (free, 1 << 40))
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda device=None: 0)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda device=None: 0)
+    g = types.SimpleNamespace(out_degrees=lambda: torch.arange(V))
+    c.auto_cache(g, ["features", "norm"])
+    assert not c.full_cached and 0 < c.cached_num < 30000
+    # what was allocated fits the pretend budget: padded rows + the largest staging chunk the fill used
+    fit, chunk = c._physical_fit(30000, ["features", "norm"])
+    assert c.cached_num * stride_bytes + chunk * 601 * 4 <= free - (1 << 30)
+    want = torch.argsort(torch.arange(V), descending=True)[:c.cached_num]
+    assert torch.equal(torch.nonzero(c.gpu_flag.cpu()).squeeze(1), torch.sort(want).values)
+    got = c.gpu_fix_cache["features"][c.localid2cacheid[want.to(dev)]].cpu().numpy()
+    assert np.array_equal(got, feats[want.numpy()])
