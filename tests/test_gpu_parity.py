@@ -1303,3 +1303,23 @@ def test_auto_cache_never_outgrows_free_memory(dev, hiplib, monkeypatch):
     assert torch.equal(torch.nonzero(c.gpu_flag.cpu()).squeeze(1), torch.sort(want).values)
     got = c.gpu_fix_cache["features"][c.localid2cacheid[want.to(dev)]].cpu().numpy()
     assert np.array_equal(got, feats[want.numpy()])
+
+
+@pytest.mark.timeout(600)
+def test_bench_short_window_reports_steady_state(dev, hiplib):
+    """the driver's invocation (`--steps 20 --warmup 5`) must report the same per-step time as a long run
+    (r01: 0.996 vs 0.197 ms/step — the copy stream had been moved to a slow SDMA engine): within 1.3x of a 400-step line"""
+    import json
+    import subprocess
+    import sys
+    flags = ["--skip-microbench", "--skip-cpu-baseline", "--skip-opt-hit", "--skip-reference-equivalent"]
+    def run(steps):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(steps),
+                            "--warmup", "5"] + flags, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    short, long_ = run(20), run(400)
+    assert short["warmup"] == 5 and short["steps"] == 20 and not short["misses_timed_out"]
+    assert short["ms_per_step"] <= 1.3 * long_["ms_per_step"], (short["ms_per_step"], long_["ms_per_step"])
+    assert max(long_["ms_per_step_windows"]) <= 2.0 * min(long_["ms_per_step_windows"]), long_["ms_per_step_windows"]
+    assert short["miss_queue"]["sdma_engine_mask"] != 0          # the direct-SDMA copy path is the one that ran
