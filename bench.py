@@ -33,12 +33,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def pmc_traffic():
-    """HBM bytes per in-loop k_gather launch from the committed rocprofv3 PMC passes
-    (profiles/rNN/pmc_gather_inloop.json: FETCH_SIZE x2 + WRITE_SIZE, KiB, separate passes —
-    MI355X_MICROARCH.md §HBM). bench.py cannot collect PMC counters itself; None when absent."""
+def pmc_traffic(kernel="k_gather"):
+    """HBM bytes per in-loop launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/rNN/pmc_<kernel>_inloop.json: FETCH_SIZE x2 + WRITE_SIZE, KiB, separate passes —
+    MI355X_MICROARCH.md §HBM). bench.py cannot collect PMC counters itself; None when absent. The figure belongs
+    to the default workload (10M/100M GCN, 30 % cache): other workloads get None."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_gather_inloop.json")))
+    name = {"k_gather": "pmc_gather_inloop.json", "k_spmm_fwd_rows": "pmc_spmm_fwd_rows_inloop.json"}[kernel]
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)))
     if not files:
         return None, None
     d = json.load(open(files[-1]))
@@ -107,6 +109,8 @@ def parse():
                    help="fetch every layer and field like the reference (default: only what the model reads, SURVEY 8f-2)")
     p.add_argument("--skip-reference-equivalent", action="store_true", help="skip the short run that fetches every layer "
                    "and field like the reference and counts the cache-hit rate its way")
+    p.add_argument("--no-fuse-gather", action="store_true", help="materialise layer 0 (pg_gather_rows + pg_spmm_fwd_drop) "
+                   "instead of aggregating it straight from the cache (pg_spmm_fwd_rows)")
     p.add_argument("--skip-opt-hit", action="store_true", help="skip the oracle cache-hit upper bound (opt_cache_hit.py)")
     p.add_argument("--ring", type=int, default=None, help="sampler ring slots (in-flight minibatches)")
     p.add_argument("--no-graph", action="store_true", help="eager reference-style loop instead of hipGraph replay")
@@ -313,13 +317,16 @@ def gather_launch_stats_from(tries_total, miss_total, prof, D):
     lib = L.load()
     n_launch = max(1, len(prof))
     ms = []
-    for timer, _, _ in prof:
+    share = 1.0
+    for entry in prof:
         v = ctypes.c_float()
-        L.check(lib.pg_timer_elapsed_ms(timer, ctypes.byref(v)))
-        lib.pg_timer_destroy(timer)
+        L.check(lib.pg_timer_elapsed_ms(entry[0], ctypes.byref(v)))
+        lib.pg_timer_destroy(entry[0])
         ms.append(v.value)
-    R = tries_total / n_launch
-    m = miss_total / n_launch
+        if len(entry) > 3:          # the copy kernel covered only the layers that are read row by row (the leading
+            share = entry[3]        # ones are aggregated in place): scale the counters of the whole split to it
+    R = tries_total / n_launch * share
+    m = miss_total / n_launch * share
     nbytes = (R - m) * 8 * D + R * 17 + m * 12               # algorithmic bytes of one launch
     return (float(np.mean(ms)) if ms else float("nan")), R, m, nbytes
 
@@ -473,6 +480,10 @@ def run():
     cacher.log = True
     cacher.cpu_share = args.cpu_share
     D = cacher.total_dim
+    PROF_RING = 1 << 14
+    fuse_gather = not args.no_graph and not args.fetch_all and not args.no_fuse_gather
+    if fuse_gather:        # the fused gather+aggregate kernel stamps its own start / end / edge count per launch
+        cacher.rows_prof = (torch.zeros(3 * PROF_RING, dtype=torch.int64, device=dev), PROF_RING)
 
     # ---- model ------------------------------------------------------------------------------
     torch.manual_seed(rank)
@@ -506,6 +517,7 @@ def run():
                                  keep_losses=False, lookahead=args.lookahead)
         S = 3 + 2 * len(sampler.slots)                   # eager warm-up + one capture and first replay per ring slot
         trainer.keep_primed = not args.cold_start
+        trainer.fuse_gather = fuse_gather
     else:
         trainer = MinibatchTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, overlap=not args.no_overlap,
                                    need=need)
@@ -608,6 +620,7 @@ def run():
             wev.append(e_)
     trainer.on_step = on_step
     mq0 = cacher.miss_queue_stats()
+    drop_step0 = int(model._drop_step.item()) if hasattr(model, "_drop_step") else 0
     wev[0].record(cstream)
     t0 = time.time()
     done = trainer.run_steps(it, K)
@@ -662,14 +675,47 @@ def run():
     ms_per_step = elapsed * 1e3 / K
     epoch_s = ms_per_step * steps_per_epoch / 1e3
 
-    # ---- in-loop gather kernel time (HIP events on the load stream) ---------------------------
+    # ---- in-loop time of the dominant HBM-bound kernel --------------------------------------------------
     avg_ms, rows_per_launch, miss_per_launch, bytes_per_launch = gather_launch_stats_from(tries_total, miss_total, prof, D)
     achieved = bytes_per_launch / avg_ms / 1e6 if prof else float("nan")
-    traffic, traffic_src = pmc_traffic()
-    roofline = {"kernel": "k_gather", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_ms": avg_ms,
-                "rows_per_launch": rows_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch}
+    gather_rec = {"kernel": "k_gather", "achieved": achieved, "frac": achieved / HBM_PEAK_GBPS, "avg_launch_ms": avg_ms,
+                  "rows_per_launch": rows_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
+                  "timing": "HIP events attached to each dispatch on the load stream"} if prof else None
+    fused_rec = None
+    drop_step1 = int(model._drop_step.item()) if hasattr(model, "_drop_step") else 0
+    if fuse_gather and cacher.rows_prof is not None and drop_step1 > drop_step0:
+        # pg_spmm_fwd_rows (gather fused into the layer-0 aggregation) runs inside the replayed hipGraph, where HIP
+        # events cannot be attached to one kernel: it stamps the device wall clock (100 MHz) at its start and end
+        # into ring entry (dropout step % ring); entries [drop_step0+1, drop_step1] are the timed steps
+        ring = cacher.rows_prof[0].view(-1, 3)
+        idx = torch.arange(drop_step0 + 1, drop_step1 + 1, device=dev) % PROF_RING
+        st = ring[idx].cpu().numpy().astype(np.int64)
+        st = st[(st[:, 1] > st[:, 0]) & (st[:, 0] > 0)]
+        if len(st):
+            f_ms = float(np.mean(st[:, 1] - st[:, 0])) / 1e5                 # 100 MHz ticks -> ms
+            edges = float(np.mean(st[:, 2]))
+            n_dst = float(np.mean([sl.sizes[1].item() for sl in sampler.slots]))     # |layer 1| of the last samples
+            Fw = args.feat_size
+            # per edge one source row read (4 F) + its position and slot (4 + 4); per destination one row
+            # written (4 F) + its indptr entry (4). Rows that miss are read from the staged block instead of the cache
+            # (same bytes). Padding destinations of the fixed-shape block write zeros: not counted.
+            f_bytes = edges * (4 * Fw + 8) + n_dst * (4 * Fw + 4)
+            fused_rec = {"kernel": "k_spmm_fwd_rows", "achieved": f_bytes / f_ms / 1e6, "frac": f_bytes / f_ms / 1e6 / HBM_PEAK_GBPS,
+                         "avg_launch_ms": f_ms, "launches_timed": int(len(st)), "edges_per_launch": edges,
+                         "destinations_per_launch": n_dst, "algorithmic_bytes_per_launch": f_bytes,
+                         "timing": "device wall-clock stamps written by the kernel itself (first block's start, last "
+                                   "blocks' end): it runs inside a replayed hipGraph"}
+    traffic, traffic_src = pmc_traffic("k_spmm_fwd_rows" if fused_rec else "k_gather")
+    default_workload = (V, E, Fdim, B, k, args.model, args.cache_ratio) == (10_000_000, 100_000_000, 600, 6000, 2, "gcn", 0.30)
+    if not default_workload or world > 1:
+        traffic, traffic_src = None, "no PMC pass committed for this workload"
+
+    dom = fused_rec or gather_rec or {"kernel": "k_gather", "achieved": float("nan"), "frac": float("nan")}
+    roofline = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": dom["frac"], "traffic": traffic, "traffic_source": traffic_src}
+    roofline.update({k_: v_ for k_, v_ in dom.items() if k_ not in ("kernel", "achieved", "frac")})
+    if fused_rec and gather_rec:
+        roofline["k_gather_in_loop"] = gather_rec       # GraphSAGE: layers 1.. are still materialised
 
     micro = None
     if not args.skip_microbench and rank == 0 and cacher.cached_num > 0 and not cacher.full_cached:

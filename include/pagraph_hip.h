@@ -99,6 +99,19 @@ int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const
                    int32_t* miss_count, int32_t* slot_scratch, uint64_t* stats, pg_timer_t* timer,
                    pg_stream_t stream);
 
+/* The two halves of pg_gather_rows on their own, for callers that do not materialise every row:
+ * pg_split_rows = the hit/miss split only (storage.py:176-182): slots_out[r] (device int32[n], required) receives
+ *   slot_map[id] for a hit, -(j + 3) for the row that became entry j of the miss list, -2 for padding (id < 0);
+ *   miss list / miss_count / stats exactly as pg_gather_rows.
+ * pg_gather_rows_presplit = the copy only, for n rows whose slots are given (slots[r] >= 0: out_f[r,:] =
+ *   cache_f[slots[r],:]; anything else leaves the row untouched). `slots` / `fields[].out` may point into the middle
+ *   of a NodeFlow's arrays: rows of layers whose features are consumed in place (pg_spmm_fwd_rows) are skipped. */
+int pg_split_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map, int32_t* miss_pos,
+                  int64_t* miss_fullid, int32_t* miss_count, int32_t* slots_out, uint64_t* stats,
+                  pg_stream_t stream);
+int pg_gather_rows_presplit(const int32_t* slots, int64_t n, const pg_field_t* fields, int n_fields,
+                            pg_timer_t* timer, pg_stream_t stream);
+
 /* storage.py:207-216 (fetch_from_cache): full cache, slot == local id. out_f[r,:] = cache_f[ids[r],:] */
 int pg_gather_rows_full(const int64_t* ids, int64_t n, const pg_field_t* fields, int n_fields,
                         pg_stream_t stream);
@@ -114,6 +127,11 @@ int pg_gather_labels(const int64_t* ids, int64_t n, const int64_t* labels, int64
  * in which case `n` is the launch upper bound). `staged` is device memory, row stride = dim.        */
 int pg_scatter_rows(const float* staged, const int32_t* pos, int64_t n, const int32_t* n_dev,
                     int32_t dim, float* out, int32_t out_stride, pg_stream_t stream);
+
+/* the same for miss rows at positions >= pos_lo only: out[(pos[j] - pos_lo), :] = staged[j, :]; rows below pos_lo
+ * stay in the staged block for a consumer that reads them there (pg_spmm_fwd_rows).                      */
+int pg_scatter_rows_range(const float* staged, const int32_t* pos, int64_t n, const int32_t* n_dev,
+                          int32_t dim, float* out, int32_t out_stride, int32_t pos_lo, pg_stream_t stream);
 
 /* storage.py:128 — the server-side `table[nids]` on host memory, multi-threaded:
  * staged[j, 0:dim] = table[fullids[j], 0:dim]. Pure host function (blocks until done).             */
@@ -153,6 +171,15 @@ int pg_missq_slot_buffers(pg_missq_t* q, int slot, int32_t** miss_pos_dev, int64
  * worker. out_ptrs[f] / out_strides[f]: destination of field f's rows (NULL = field not wanted).   */
 int pg_missq_submit(pg_missq_t* q, int slot, float* const* out_ptrs, const int32_t* out_strides,
                     pg_stream_t stream);
+/* the same with a per-field first scattered position: miss rows at positions >= pos_lo[f] go to
+ * out_ptrs[f][(pos - pos_lo[f]) * stride]; rows below it are only copied to the slot's device staging block
+ * (pg_missq_slot_staged), where pg_spmm_fwd_rows reads them. out_ptrs[f] == NULL with out_strides[f] == -1:
+ * nothing of field f is scattered (copy only); NULL with stride 0: field not wanted.                  */
+int pg_missq_submit_range(pg_missq_t* q, int slot, float* const* out_ptrs, const int32_t* out_strides,
+                          const int32_t* pos_lo, pg_stream_t stream);
+/* device staging block of (slot, field): [max_rows, dim] floats, row j = entry j of the slot's miss list once
+ * the slot's wait (pg_missq_wait / _wait_device) has passed                                              */
+int pg_missq_slot_staged(pg_missq_t* q, int slot, int field, float** staged_dev);
 /* makes `stream` wait until the slot's miss rows have landed; blocks the HOST only until the worker has
  * enqueued the copy. miss_count_out (optional) receives the number of rows.                         */
 int pg_missq_wait(pg_missq_t* q, int slot, pg_stream_t stream, int32_t* miss_count_out);
@@ -293,6 +320,27 @@ typedef struct pg_dropout {
 int pg_spmm_fwd_drop(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride,
                      int64_t n_dst, int32_t dim, int reduce, float* out, int32_t out_stride,
                      const pg_dropout_t* drop, pg_stream_t stream);
+/* Aggregation straight from the feature cache — fetch_data (storage.py:176-204) fused into the layer-0
+ * block_compute (gcn_nssc.py:66-74, graphsage_nssc.py:98-101): the source layer's rows are never
+ * materialised. Row p of the source layer is read where it lies: slots[p] >= 0 -> cache[slots[p], :];
+ * slots[p] <= -3 -> staged[-slots[p] - 3, :] (the block of miss rows the miss path copied to the device, in
+ * miss-list order: pg_split_rows + pg_missq with a staged-only field); -1 / -2 contribute nothing. Bit-identical
+ * to pg_gather_rows + pg_spmm_fwd_drop (same summation order, same dropout counters: row index = p).
+ * Needs dim % 4 == 0, dim >= 256, 16-byte aligned rows (else PG_ERR_UNSUPPORTED). drop may be NULL.
+ * prof (device uint64[3 * prof_ring], may be NULL): entry i = (*drop->step, or 0) % prof_ring receives the
+ * device wall clock (100 MHz ticks) at [3i] kernel start and [3i+1] kernel end, and [3i+2] the number of edges
+ * aggregated — the kernel usually runs inside a replayed hipGraph, where HIP events cannot be attached to it;
+ * zero [3i+1] before reuse.                                                                             */
+typedef struct pg_row_source {
+  const int32_t* slots;   /* device int32 [rows of the source layer] */
+  const float* cache;     /* device; may be NULL when nothing is cached */
+  const float* staged;    /* device; may be NULL when nothing can miss (full cache) */
+  int32_t cache_stride;   /* floats */
+  int32_t staged_stride;  /* floats */
+} pg_row_source_t;
+int pg_spmm_fwd_rows(const int32_t* indptr, const int32_t* src, const pg_row_source_t* rows, int64_t n_dst,
+                     int32_t dim, int reduce, float* out, int32_t out_stride, const pg_dropout_t* drop,
+                     uint64_t* prof, int32_t prof_ring, pg_stream_t stream);
 /* grad_h[src[e],:] += grad_out[v,:] * (mean ? 1/deg(v) : 1) * mask(src[e],:) * scale; grad_h zeroed by caller */
 int pg_spmm_bwd_drop(const int32_t* indptr, const int32_t* src, const float* grad_out, int32_t go_stride,
                      int64_t n_dst, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,

@@ -42,6 +42,10 @@ class PgMissqField(ctypes.Structure):
     _fields_ = [("table", vp), ("table_stride", c_i64), ("dim", c_i32), ("_pad", c_i32)]
 
 
+class PgRowSource(ctypes.Structure):
+    _fields_ = [("slots", vp), ("cache", vp), ("staged", vp), ("cache_stride", c_i32), ("staged_stride", c_i32)]
+
+
 class PgDropout(ctypes.Structure):
     _fields_ = [("threshold", c_u32), ("tag", c_u32), ("seed", c_u64), ("step", vp)]
 
@@ -59,9 +63,12 @@ _SIGS = {
     "pg_slot_map_assign": (ctypes.c_int, [vp, vp, c_i64, vp]),
     "pg_slot_map_export": (ctypes.c_int, [vp, c_i64, vp, vp, vp]),
     "pg_gather_rows": (ctypes.c_int, [vp, c_i64, vp, vp, ctypes.POINTER(PgField), ctypes.c_int, vp, vp, vp, vp, vp, vp, vp]),
+    "pg_split_rows": (ctypes.c_int, [vp, c_i64, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "pg_gather_rows_presplit": (ctypes.c_int, [vp, c_i64, ctypes.POINTER(PgField), ctypes.c_int, vp, vp]),
     "pg_gather_rows_full": (ctypes.c_int, [vp, c_i64, ctypes.POINTER(PgField), ctypes.c_int, vp]),
     "pg_gather_labels": (ctypes.c_int, [vp, c_i64, vp, c_i64, c_i64, vp, vp, vp]),
     "pg_scatter_rows": (ctypes.c_int, [vp, vp, c_i64, vp, c_i32, vp, c_i32, vp]),
+    "pg_scatter_rows_range": (ctypes.c_int, [vp, vp, c_i64, vp, c_i32, vp, c_i32, c_i32, vp]),
     "pg_host_gather_rows": (ctypes.c_int, [vp, c_i64, c_i32, vp, c_i64, vp, ctypes.c_int]),
     "pg_scatter_rows_from_host": (ctypes.c_int, [vp, c_i64, vp, vp, c_i64, vp, c_i32, vp, c_i32, vp]),
     "pg_scatter_rows_from_host_tail": (ctypes.c_int, [vp, c_i64, vp, vp, c_i64, vp, c_i32, c_i32, vp, c_i32, vp]),
@@ -71,6 +78,9 @@ _SIGS = {
     "pg_missq_destroy": (ctypes.c_int, [vp]),
     "pg_missq_slot_buffers": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]),
     "pg_missq_submit": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(c_i32), vp]),
+    "pg_missq_submit_range": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(c_i32),
+                                             ctypes.POINTER(c_i32), vp]),
+    "pg_missq_slot_staged": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]),
     "pg_missq_wait": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.POINTER(c_i32)]),
     "pg_missq_wait_device": (ctypes.c_int, [vp, ctypes.c_int, vp]),
     "pg_missq_timed_out": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int)]),
@@ -88,6 +98,8 @@ _SIGS = {
     "pg_spmm_fwd": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp]),
     "pg_spmm_bwd": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp]),
     "pg_spmm_fwd_drop": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, vp]),
+    "pg_spmm_fwd_rows": (ctypes.c_int, [vp, vp, ctypes.POINTER(PgRowSource), c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, vp,
+                                        c_i32, vp]),
     "pg_spmm_bwd_drop": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, vp]),
     "pg_spmm_bwd_gather": (ctypes.c_int, [vp, vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, c_i32, vp, vp]),
     "pg_linear_fwd": (ctypes.c_int, [vp, c_i32, vp, vp, vp, c_i32, c_i64, c_i32, c_i32, c_i32, vp]),

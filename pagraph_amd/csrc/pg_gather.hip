@@ -137,6 +137,8 @@ __global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ ids, 
     for (int i = 0; i < w; ++i) off += s_wave[i];
     miss_pos[off] = (int32_t)row;
     miss_fullid[off] = nid_map[id];
+    // a consumer that reads rows where they lie (pg_spmm_fwd_rows) finds miss row `off` of the staged block here
+    if (slots_out) slots_out[row] = -(off + 3);
   }
 }
 
@@ -191,15 +193,17 @@ template <int VEC>
 __global__ __launch_bounds__(256) void k_scatter(const float* __restrict__ staged,
                                                  const int32_t* __restrict__ pos, int64_t n,
                                                  const int32_t* __restrict__ n_dev, int32_t dim,
-                                                 float* __restrict__ out, int32_t out_stride) {
+                                                 float* __restrict__ out, int32_t out_stride, int32_t pos_lo) {
   using V = typename VecT<VEC>::type;
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t nn = n_dev ? (int64_t)*n_dev : n;
   const int64_t waves = (int64_t)gridDim.x * (blockDim.x / kWave);
   const int pieces = dim / VEC;
   for (int64_t j = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; j < nn; j += waves) {
+    const int32_t p = pos[j] - pos_lo;
+    if (p < 0) continue;          // a row below pos_lo stays where it is: its consumer reads the staged block
     const V* src = reinterpret_cast<const V*>(staged + j * dim);
-    V* dst = reinterpret_cast<V*>(out + (int64_t)pos[j] * out_stride);
+    V* dst = reinterpret_cast<V*>(out + (int64_t)p * out_stride);
     for (int c = lane; c < pieces; c += kWave) dst[c] = src[c];
   }
 }
@@ -394,6 +398,33 @@ int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const
   return launch_gather<false>(a, st, timer);
 }
 
+int pg_split_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map, int32_t* miss_pos,
+                  int64_t* miss_fullid, int32_t* miss_count, int32_t* slots_out, uint64_t* stats,
+                  pg_stream_t stream) {
+  if (n < 0 || n > INT32_MAX || !miss_count) return PG_ERR_INVALID;
+  hipStream_t st = as_stream(stream);
+  PG_HIP(hipMemsetAsync(miss_count, 0, sizeof(int32_t), st));
+  if (n == 0) return PG_OK;
+  if (!ids || !slot_map || !nid_map || !miss_pos || !miss_fullid || !slots_out) return PG_ERR_INVALID;
+  hipLaunchKernelGGL(k_split, dim3((unsigned)ceil_div<int64_t>(n, 256)), dim3(256), 0, st, ids, n, slot_map, nid_map,
+                     miss_pos, miss_fullid, miss_count, slots_out, reinterpret_cast<unsigned long long*>(stats));
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+int pg_gather_rows_presplit(const int32_t* slots, int64_t n, const pg_field_t* fields, int n_fields,
+                            pg_timer_t* timer, pg_stream_t stream) {
+  if (n < 0 || n > INT32_MAX) return PG_ERR_INVALID;
+  if (n == 0) return PG_OK;
+  if (!slots) return PG_ERR_INVALID;
+  GatherArgs a{};
+  a.slots = slots;
+  a.n = n;
+  int rc = fill_args(a, fields, n_fields, false);
+  if (rc != PG_OK) return rc;
+  return launch_gather<false>(a, as_stream(stream), timer);
+}
+
 int pg_gather_rows_full(const int64_t* ids, int64_t n, const pg_field_t* fields, int n_fields,
                         pg_stream_t stream) {
   if (n < 0 || n > INT32_MAX) return PG_ERR_INVALID;
@@ -421,17 +452,22 @@ int pg_gather_labels(const int64_t* ids, int64_t n, const int64_t* labels, int64
 
 int pg_scatter_rows(const float* staged, const int32_t* pos, int64_t n, const int32_t* n_dev, int32_t dim,
                     float* out, int32_t out_stride, pg_stream_t stream) {
-  if (n < 0 || dim <= 0 || out_stride < dim) return PG_ERR_INVALID;
+  return pg_scatter_rows_range(staged, pos, n, n_dev, dim, out, out_stride, 0, stream);
+}
+
+int pg_scatter_rows_range(const float* staged, const int32_t* pos, int64_t n, const int32_t* n_dev, int32_t dim,
+                          float* out, int32_t out_stride, int32_t pos_lo, pg_stream_t stream) {
+  if (n < 0 || dim <= 0 || out_stride < dim || pos_lo < 0) return PG_ERR_INVALID;
   if (n == 0) return PG_OK;
   if (!staged || !pos || !out) return PG_ERR_INVALID;
   hipStream_t st = as_stream(stream);
   const int grid = grid_1d(n, 4, 8192);
   if (dim % 4 == 0 && out_stride % 4 == 0 && aligned(staged, 16) && aligned(out, 16))
-    hipLaunchKernelGGL(k_scatter<4>, dim3(grid), dim3(256), 0, st, staged, pos, n, n_dev, dim, out, out_stride);
+    hipLaunchKernelGGL(k_scatter<4>, dim3(grid), dim3(256), 0, st, staged, pos, n, n_dev, dim, out, out_stride, pos_lo);
   else if (dim % 2 == 0 && out_stride % 2 == 0 && aligned(staged, 8) && aligned(out, 8))
-    hipLaunchKernelGGL(k_scatter<2>, dim3(grid), dim3(256), 0, st, staged, pos, n, n_dev, dim, out, out_stride);
+    hipLaunchKernelGGL(k_scatter<2>, dim3(grid), dim3(256), 0, st, staged, pos, n, n_dev, dim, out, out_stride, pos_lo);
   else
-    hipLaunchKernelGGL(k_scatter<1>, dim3(grid), dim3(256), 0, st, staged, pos, n, n_dev, dim, out, out_stride);
+    hipLaunchKernelGGL(k_scatter<1>, dim3(grid), dim3(256), 0, st, staged, pos, n, n_dev, dim, out, out_stride, pos_lo);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }

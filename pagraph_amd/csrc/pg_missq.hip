@@ -223,7 +223,8 @@ struct pg_missq_slot {
   uint32_t done = 0;       // last sequence number whose copy has been enqueued (worker, under mutex)
   int32_t last_count = 0;
   float* out[PG_MAX_FIELDS] = {nullptr};
-  int32_t out_stride[PG_MAX_FIELDS] = {0};
+  int32_t out_stride[PG_MAX_FIELDS] = {0};   // -1 with out == NULL: copy to the staging block only
+  int32_t pos_lo[PG_MAX_FIELDS] = {0};       // rows below it are not scattered
   std::chrono::steady_clock::time_point t_submit;
 };
 
@@ -389,7 +390,7 @@ static void missq_worker(pg_missq* q) {
     double tg = 0, te = 0;
     if (m > 0 && rc == PG_OK) {
       for (int f = 0; f < q->n_fields && rc == PG_OK; ++f) {
-        if (!s.out[f]) continue;   // this launch did not ask for the field
+        if (!s.out[f] && s.out_stride[f] != -1) continue;   // this launch did not ask for the field
         const pg_missq_field_t& fd = q->fields[f];
         const size_t row_bytes = (size_t)fd.dim * sizeof(float);
         float* stg = s.staging_h[f];
@@ -443,9 +444,9 @@ static void missq_worker(pg_missq* q) {
             s.cp_field = -1;
           }
         }
-        if (rc == PG_OK)
-          rc = pg_scatter_rows(s.staged_d[f], s.pos_d, m, nullptr, fd.dim, s.out[f], s.out_stride[f],
-                               (pg_stream_t)q->copy_stream);                 // storage.py:199-200
+        if (rc == PG_OK && s.out[f])
+          rc = pg_scatter_rows_range(s.staged_d[f], s.pos_d, m, nullptr, fd.dim, s.out[f], s.out_stride[f],
+                                     s.pos_lo[f], (pg_stream_t)q->copy_stream);   // storage.py:199-200
         te += us(tb, now());
       }
     }
@@ -583,6 +584,17 @@ int pg_missq_slot_buffers(pg_missq_t* q, int slot, int32_t** miss_pos_dev, int64
 }
 
 int pg_missq_submit(pg_missq_t* q, int slot, float* const* out_ptrs, const int32_t* out_strides, pg_stream_t stream) {
+  return pg_missq_submit_range(q, slot, out_ptrs, out_strides, nullptr, stream);
+}
+
+int pg_missq_slot_staged(pg_missq_t* q, int slot, int field, float** staged_dev) {
+  if (!q || slot < 0 || slot >= q->n_slots || field < 0 || field >= q->n_fields || !staged_dev) return PG_ERR_INVALID;
+  *staged_dev = q->slots[slot].staged_d[field];
+  return PG_OK;
+}
+
+int pg_missq_submit_range(pg_missq_t* q, int slot, float* const* out_ptrs, const int32_t* out_strides,
+                          const int32_t* pos_lo, pg_stream_t stream) {
   if (!q || slot < 0 || slot >= q->n_slots || !out_ptrs || !out_strides) return PG_ERR_INVALID;
   pg_missq_slot& s = q->slots[slot];
   uint32_t seq;
@@ -596,6 +608,7 @@ int pg_missq_submit(pg_missq_t* q, int slot, float* const* out_ptrs, const int32
     for (int f = 0; f < q->n_fields; ++f) {
       s.out[f] = out_ptrs[f];
       s.out_stride[f] = out_strides[f];
+      s.pos_lo[f] = pos_lo ? pos_lo[f] : 0;
     }
   }
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, as_stream(stream), s.count_d, s.count_h, s.flag_h, seq);

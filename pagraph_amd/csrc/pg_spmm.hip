@@ -186,6 +186,94 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_drop(const int32_t* __restrict
   }
 }
 
+// ---- aggregation straight from the feature cache (layer 0 is never materialised) ---------------
+// out[v] = reduce over v's in-edges of dropout(row(src[e])), where row(p) is read where it lies:
+//   slots[p] >= 0  : cache + slots[p] * cache_stride          (a hit: the HBM feature cache, storage.py:191-193)
+//   slots[p] <= -3 : staged + (-slots[p] - 3) * staged_stride (a miss: row j of the block the miss path copied
+//                                                              to the device, storage.py:196-200 without the scatter)
+// Same per-destination summation order and the same dropout counters (row index = position p in the source
+// layer) as pg_gather_rows + pg_spmm_fwd_drop, so the result is bit-identical to the unfused pair — minus one
+// write and one read of the [|L0|, dim] frame (2 x 45 MB per step at the benchmark's shape).
+// One wave per destination (dim >= 256): lane e of the wave looks up edge e's position and slot, the two
+// dependent index loads of ALL of the destination's edges are in flight together, then the rows are streamed.
+// prof (optional): [3 * i], [3 * i + 1] = device wall-clock (100 MHz) when block 0 started / the last blocks
+// finished, [3 * i + 2] = edges aggregated, i = (*drop.step or 0) % prof_ring — a kernel inside a replayed
+// hipGraph cannot carry HIP events.
+template <bool DROP>
+__global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict__ indptr,
+                                                       const int32_t* __restrict__ src,
+                                                       const int32_t* __restrict__ slots,
+                                                       const float* __restrict__ cache, int32_t cache_stride,
+                                                       const float* __restrict__ staged, int32_t staged_stride,
+                                                       int64_t n_dst, int32_t dim, int reduce,
+                                                       float* __restrict__ out, int32_t out_stride, DropArgs d,
+                                                       unsigned long long* __restrict__ prof, int prof_ring) {
+  using S = SV<4>;
+  const uint32_t step = d.step ? (uint32_t)*d.step : 0u;
+  unsigned long long* pslot = prof ? prof + 3 * (size_t)(step % (uint32_t)prof_ring) : nullptr;
+  if (pslot && blockIdx.x == 0 && threadIdx.x == 0) {
+    pslot[0] = wall_clock64();
+    pslot[2] = (unsigned long long)indptr[n_dst];   // edges of this launch
+  }
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t v = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+  if (v < n_dst) {
+    const int pieces = dim / 4;
+    const int32_t beg = indptr[v], end = indptr[v + 1];
+    float4* orow = reinterpret_cast<float4*>(out + v * out_stride);
+    for (int c0 = 0; c0 < pieces; c0 += kWave * kMaxAcc) {
+      float4 acc[kMaxAcc];
+#pragma unroll
+      for (int m = 0; m < kMaxAcc; ++m) acc[m] = S::zero();
+      for (int32_t eb = beg; eb < end; eb += kWave) {
+        const int ne = end - eb < kWave ? end - eb : kWave;
+        int32_t my_p = 0, my_s = -2;
+        if (lane < ne) {
+          my_p = src[eb + lane];
+          my_s = slots[my_p];
+        }
+        for (int e = 0; e < ne; ++e) {
+          const int32_t sr = __shfl(my_p, e), sl = __shfl(my_s, e);
+          const float4* hrow = sl >= 0 ? reinterpret_cast<const float4*>(cache + (int64_t)sl * cache_stride)
+                                       : reinterpret_cast<const float4*>(staged + (int64_t)(-sl - 3) * staged_stride);
+          if (sl == -1 || sl == -2) continue;      // padding / an unresolved miss: contributes nothing
+          uint32_t o[4] = {0, 0, 0, 0};
+          int have_q = -1;
+#pragma unroll
+          for (int m = 0; m < kMaxAcc; ++m) {
+            const int c = c0 + m * kWave + lane;
+            if (c < pieces) {
+              float4 x = hrow[c];
+              if constexpr (DROP) {
+                const int q = ((c >> 7) << 6) | (c & 63);
+                if (q != have_q) {
+                  Philox::gen((uint32_t)sr, (uint32_t)q, d.tag, step, d.k0, d.k1, o);
+                  have_q = q;
+                }
+                x = drop_apply(x, o, (c >> 6) & 1, d.thr, d.scale);
+              }
+              S::add(acc[m], x);
+            }
+          }
+        }
+      }
+      const float dg = (float)(end - beg);
+#pragma unroll
+      for (int m = 0; m < kMaxAcc; ++m) {
+        const int c = c0 + m * kWave + lane;
+        if (c < pieces) {
+          if (reduce == PG_REDUCE_MEAN && end > beg) S::div(acc[m], dg);
+          orow[c] = acc[m];
+        }
+      }
+    }
+  }
+  if (pslot && blockIdx.x + 256 >= gridDim.x) {   // the tail of the grid: kernel end = the latest of these
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(pslot + 1, wall_clock64());
+  }
+}
+
 // grad_h[src[e], c] += grad_out[v, c] * scale(v) * mask(src[e], c)
 __global__ __launch_bounds__(256) void k_spmm_bwd_drop(const int32_t* __restrict__ indptr,
                                                        const int32_t* __restrict__ src,
@@ -416,6 +504,36 @@ int pg_spmm_fwd_drop(const int32_t* indptr, const int32_t* src, const float* h, 
   const int rows_per_block = 4 * (64 >> l2);
   hipLaunchKernelGGL(k_spmm_fwd_drop, dim3((unsigned)ceil_div<int64_t>(n_dst, rows_per_block)), dim3(256), 0,
                      as_stream(stream), indptr, src, h, h_stride, n_dst, dim, reduce, out, out_stride, l2, d);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+int pg_spmm_fwd_rows(const int32_t* indptr, const int32_t* src, const pg_row_source_t* rows, int64_t n_dst,
+                     int32_t dim, int reduce, float* out, int32_t out_stride, const pg_dropout_t* drop,
+                     uint64_t* prof, int32_t prof_ring, pg_stream_t stream) {
+  if (!rows || n_dst < 0 || dim <= 0 || out_stride < dim) return PG_ERR_INVALID;
+  if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return PG_ERR_INVALID;
+  if (drop && drop->threshold > 65535u) return PG_ERR_INVALID;
+  if (prof && prof_ring <= 0) return PG_ERR_INVALID;
+  // one wave per destination, 16-byte pieces: the wide feature rows this path exists for
+  if (!(dim % 4 == 0 && dim >= 256 && out_stride % 4 == 0 && al(out, 16))) return PG_ERR_UNSUPPORTED;
+  if (rows->cache && !(rows->cache_stride >= dim && rows->cache_stride % 4 == 0 && al(rows->cache, 16))) return PG_ERR_UNSUPPORTED;
+  if (rows->staged && !(rows->staged_stride >= dim && rows->staged_stride % 4 == 0 && al(rows->staged, 16))) return PG_ERR_UNSUPPORTED;
+  if (n_dst == 0) return PG_OK;
+  if (!indptr || !src || !out || !rows->slots) return PG_ERR_INVALID;
+  DropArgs d{};
+  const bool has_drop = drop_args(drop, &d);
+  if (!has_drop && drop) d.step = drop->step;     // the profiling ring is indexed by the caller's step counter
+  const unsigned grid = (unsigned)ceil_div<int64_t>(n_dst, 4);
+  unsigned long long* pr = reinterpret_cast<unsigned long long*>(prof);
+  if (has_drop)
+    hipLaunchKernelGGL(k_spmm_fwd_rows<true>, dim3(grid), dim3(256), 0, as_stream(stream), indptr, src, rows->slots,
+                       rows->cache, rows->cache_stride, rows->staged, rows->staged_stride, n_dst, dim, reduce, out,
+                       out_stride, d, pr, (int)prof_ring);
+  else
+    hipLaunchKernelGGL(k_spmm_fwd_rows<false>, dim3(grid), dim3(256), 0, as_stream(stream), indptr, src, rows->slots,
+                       rows->cache, rows->cache_stride, rows->staged, rows->staged_stride, n_dst, dim, reduce, out,
+                       out_stride, d, pr, (int)prof_ring);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }

@@ -35,3 +35,14 @@ class FusedDropoutMixin:
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             rank = torch.distributed.get_rank()
         return ops.DropoutSpec(mod.p, self._drop_seed, (rank << 8) | (layer & 0xFF), self._drop_step)
+
+    def _dropout_or_raise(self, h):
+        """nn.Dropout for an input the aggregation kernel could not take the mask for; rows that were never
+        materialised (ops.RowSource) have no tensor to drop from: identity when dropout is inactive, else refuse"""
+        mod = getattr(self, 'dropout', None)
+        if isinstance(h, ops.RowSource):
+            if self.training and isinstance(mod, torch.nn.Dropout) and mod.p > 0.0:
+                raise ops.L.PgError("dropout on un-materialised feature rows needs the fused mask (fuse_dropout=True, "
+                                    "dim % 4 == 0); fetch the layer densely instead (virtual=None)")
+            return h
+        return mod(h) if mod is not None else h

@@ -1,8 +1,10 @@
 """2-layer sampled GCN with skip-concat — same constructor, parameter names
 (`layers.N.linear.{weight,bias}`, `linear.*` under preprocess) and maths as
 PaGraph/model/gcn_nssc.py:6-164, running on pagraph_amd's NodeFlow: the
-aggregation is the HIP SpMM (pg_spmm.hip), the dense step stays nn.Linear
-(hipBLASLt / MFMA through PyTorch-ROCm)."""
+aggregation is the HIP SpMM (pg_spmm.hip; layer 0 straight from the feature cache when
+the cacher hands over an ops.RowSource), the skinny dense step the fp32-MFMA kernels of
+pg_dense.hip (ops.linear), the training output layer + loss one kernel (pg_head.hip).
+Pinned against the reference's classes by tests/golden/g7_*."""
 import torch
 import torch.nn as nn
 
@@ -65,6 +67,15 @@ class _GCNBase(FusedDropoutMixin, nn.Module):
             need = {l: need.get(l, []) for l in range(num_layers)}
         return need
 
+    def virtual_inputs(self, num_layers):
+        """{layer: [fields]} this model only ever AGGREGATES (never reads row by row): the cacher may hand those over
+        as ops.RowSource — the rows stay in the cache / the staged miss block and the layer-0 aggregation reads them
+        there (gcn_nssc.py:64-74 fused with storage.py:176-204). Without preprocessing that is layer 0's 'features';
+        with it the raw features feed a dense transform first (:81-84)."""
+        if self.preprocess or len(self.layers) < 2:
+            return {}
+        return {0: ['features']}
+
     def _input_transform(self, nf):
         """gcn_nssc.py:80-90: dense transform of the raw features before any aggregation"""
         h = nf.layers[0].data['features']
@@ -81,7 +92,7 @@ class _GCNBase(FusedDropoutMixin, nn.Module):
             if getattr(self, 'dropout', None) and not self.preprocess:
                 drop = self._drop_spec(i, h)             # dropout inside the aggregation kernel ...
                 if drop is None:
-                    h = self.dropout(h)                  # ... or nn.Dropout where that cannot be done
+                    h = self._dropout_or_raise(h)        # ... or nn.Dropout where that cannot be done
             nf.layers[i].data['h'] = h
             nf.block_compute(i, fn.copy_src(src='h', out='m'), self.reducer(msg='m', out='h'), layer, dropout=drop)
             h = nf.layers[i + 1].data.pop('activation')
@@ -111,7 +122,7 @@ class _GCNBase(FusedDropoutMixin, nn.Module):
             if getattr(self, 'dropout', None) and not self.preprocess:
                 drop = self._drop_spec(i, h)
                 if drop is None:
-                    h = self.dropout(h)
+                    h = self._dropout_or_raise(h)
             nf.layers[i].data['h'] = h
             nf.block_compute(i, fn.copy_src(src='h', out='m'), self.reducer(msg='m', out='h'), layer, dropout=drop)
             h = nf.layers[i + 1].data.pop('activation')

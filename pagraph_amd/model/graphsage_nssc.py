@@ -71,6 +71,12 @@ class GraphSageSampling(FusedDropoutMixin, nn.Module):
         f = ['features', 'neigh'] if self.preprocess else ['features']
         return {l: list(f) for l in range(num_layers)}
 
+    def virtual_inputs(self, num_layers):
+        """layer 0 is only ever a source of block 0's aggregation (its self term belongs to no NodeUpdate,
+        graphsage_nssc.py:92-111): its 'features' may stay un-materialised (ops.RowSource). Not under preprocess
+        (every layer goes through fc_self / fc_neigh first, :76-87)."""
+        return {} if self.preprocess else {0: ['features']}
+
     def forward(self, nf):
         L = nf.num_layers
         self._bump_drop_step()
@@ -95,7 +101,7 @@ class GraphSageSampling(FusedDropoutMixin, nn.Module):
                 # i - 1 already), so the mask can be applied inside the kernel (tag: one per (lid, i) call site)
                 drop = self._drop_spec(lid * 16 + i, d['h'])
                 if drop is None:
-                    d['h'] = self.dropout(d.pop('h'))
+                    d['h'] = self._dropout_or_raise(d.pop('h'))
                 nf.block_compute(i, fn.copy_src(src='h', out='m'), red('m', 'neigh'), layer, dropout=drop)
             for i in range(lid + 1, L):
                 d = nf.layers[i].data

@@ -23,8 +23,57 @@ class DropoutSpec:
 
     @staticmethod
     def fusable(h):
+        if isinstance(h, RowSource):
+            return h.dim % 4 == 0
         return (h.is_cuda and h.dtype == torch.float32 and h.dim() == 2 and h.size(1) % 4 == 0 and h.stride(1) == 1
                 and h.stride(0) % 4 == 0 and h.data_ptr() % 16 == 0)
+
+
+class RowSource:
+    """Rows of a NodeFlow layer that were never materialised (pg_row_source_t): row p lives in the HBM feature cache
+    (slots[p] >= 0) or in the block of miss rows the miss path copied to the device (slots[p] <= -3). What
+    GraphCacheServer hands the model in place of a dense [rows, dim] frame when the model only aggregates the field
+    (SURVEY 8f-2); block_aggregate consumes it with pg_spmm_fwd_rows. Not differentiable (raw features)."""
+
+    def __init__(self, slots, cache, staged_ptr, staged_stride, dim, keep=(), prof=None):
+        self.slots = slots                    # device int32 [rows]
+        self.cache = cache                    # device fp32 [cached_rows, dim] column view of the fused cache, or None
+        self.staged_ptr = int(staged_ptr or 0)
+        self.staged_stride = int(staged_stride)
+        self.dim = int(dim)
+        self.keep = keep                      # whatever owns the staged block
+        self.prof = prof                      # (device uint64 [3 * ring], ring) or None: kernel self-timing
+        self.is_cuda, self.dtype, self.device = True, torch.float32, slots.device
+        self.requires_grad = False
+
+    @property
+    def shape(self):
+        return (self.slots.numel(), self.dim)
+
+    def size(self, i=None):
+        return self.shape if i is None else self.shape[i]
+
+    def dim_(self):
+        return 2
+
+    def struct(self):
+        return L.PgRowSource(self.slots.data_ptr(), self.cache.data_ptr() if self.cache is not None else 0,
+                             self.staged_ptr, self.cache.stride(0) if self.cache is not None else self.dim,
+                             self.staged_stride)
+
+
+def aggregate_rows(indptr, src, rows, n_dst, reduce="mean", dropout=None):
+    """block_aggregate for a RowSource: gather + (dropout) + aggregate in one kernel, no [rows, dim] frame"""
+    lib = L.load()
+    out = torch.empty((int(n_dst), rows.dim), dtype=torch.float32, device=rows.device)
+    rs = rows.struct()
+    d = dropout.struct() if dropout is not None else None
+    prof, ring = rows.prof if rows.prof is not None else (None, 0)
+    with torch.cuda.device(rows.device):
+        L.check(lib.pg_spmm_fwd_rows(L.ptr(indptr), L.ptr(src), ctypes.byref(rs), int(n_dst), rows.dim, _REDUCE[reduce],
+                                     L.ptr(out), out.stride(0), ctypes.byref(d) if d is not None else None,
+                                     L.ptr(prof), ring, L.stream_ptr()), "pg_spmm_fwd_rows")
+    return out
 
 
 class _BlockAggregate(torch.autograd.Function):
@@ -84,6 +133,10 @@ def block_aggregate(indptr, src, h, n_dst, reduce="mean", dropout=None, transpos
     """out[v] = reduce_{e in block, dst(e)=v} dropout(h)[src(e)]  (DGL copy_src + mean|sum; `dropout` is a
     DropoutSpec or None; `transpose` = (tptr, tdst[, heavy]), the block's source-major copy (and hub list) from
     the sampler, lets the backward run as a gather instead of fp32 atomics)"""
+    if isinstance(h, RowSource):
+        if dropout is not None and dropout.threshold == 0:
+            dropout = None
+        return aggregate_rows(indptr, src, h, n_dst, reduce, dropout)
     if h.dtype != torch.float32 or not h.is_cuda:
         raise L.PgError("block_aggregate needs fp32 CUDA tensors (no CPU fallback)")
     if dropout is not None and (dropout.threshold == 0 or not DropoutSpec.fusable(h)):

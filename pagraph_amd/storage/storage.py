@@ -161,7 +161,9 @@ _HOST_WAIT = bool(os.environ.get("PG_MISSQ_HOST_WAIT"))
 
 
 class _FetchPlan:
-    __slots__ = ("names", "row_lo", "rows", "out", "fields", "n_fields", "optrs", "ostr", "cache_epoch")
+    __slots__ = ("names", "row_lo", "rows", "out", "fields", "n_fields", "optrs", "ostr", "cache_epoch",
+                 # fused layer-0 path (virtual rows): per-plan slot array, dense sub-range, RowSources by (layer, field)
+                 "slots", "dense_lo", "dense_rows", "poslo", "row_sources", "virtual")
 
 
 class GraphCacheServer:
@@ -218,6 +220,8 @@ class GraphCacheServer:
         self._missq_rows = 0
         self._missq_bufs = {}            # slot -> (miss_pos, miss_fullid, miss_count) pointers
         self._missq_pending = set()      # slots submitted to the queue and not yet waited for by their consumer
+        # bench.py: (device int64 [3 * ring], ring) — the fused gather+aggregate kernel stamps its own start / end
+        self.rows_prof = None
         self._missq_share = None
         self._cache_epoch = 0            # bumped whenever the cache contents / layout change (invalidates fetch plans)
         self.missq_slots = 4
@@ -393,7 +397,7 @@ class GraphCacheServer:
         self._cap = cap
 
     # -- storage.py:157-204 ---------------------------------------------------
-    def fetch_data(self, nodeflow, out=None, need=None, slot=None):
+    def fetch_data(self, nodeflow, out=None, need=None, slot=None, virtual=None):
         """Fill nodeflow._node_frames[i][name] for every layer and field: hits from the HBM
         cache, misses from the host store. One gather launch for all layers; rows of layer i are
         the slice [offsets[i], offsets[i+1]) of one [R, dim] buffer per field.
@@ -405,6 +409,10 @@ class GraphCacheServer:
         reference does.
         `slot` (miss_mode == "async"): index of the in-flight batch; the miss rows land asynchronously,
         call wait_misses(slot) on the consuming stream before reading the frames."""
+        if virtual and (self.full_cached or self.miss_mode == "async"):
+            # `virtual` (a model's virtual_inputs()): the leading layers' rows are not materialised; their frames
+            # hold ops.RowSource objects the aggregation reads in place (see plan_fetch)
+            return self._fetch_data_virtual(nodeflow, out, need, slot, virtual)
         if self.full_cached:
             self.fetch_from_cache(nodeflow, out=out)
             return
@@ -499,19 +507,49 @@ class GraphCacheServer:
                 keep = names if need is None else [n for n in names if n in need[i]]
                 nodeflow._node_frames[i] = {name: out[name][offsets[i] - row_lo:offsets[i + 1] - row_lo] for name in keep}
 
+    def _fetch_data_virtual(self, nodeflow, out, need, slot, virtual):
+        nf_nids = nodeflow._node_mapping.tousertensor().to(self.device, torch.int64)
+        offsets = nodeflow._layer_offsets
+        R = offsets[-1]
+        names = list(self.dims) if need is None else [n for n in self.dims if any(n in v for v in need.values())]
+        if out is None:
+            out = {n: torch.empty((R, self.dims[n]), dtype=torch.float32, device=self.device) for n in names}
+        plan = self.plan_fetch(offsets, out, need, virtual, slot=slot)
+        if not plan.virtual:
+            return self.fetch_data(nodeflow, out=out, need=need, slot=slot)
+        self.fetch_planned(plan, nf_nids, torch.cuda.current_stream(self.device), slot=slot)
+        lo = plan.row_lo + plan.dense_lo
+        for i in range(nodeflow.num_layers):
+            if need is not None and i not in need:
+                nodeflow._node_frames[i] = {}
+                continue
+            keep = plan.names if need is None else [n for n in plan.names if n in need[i]]
+            fr = {}
+            for name in keep:
+                rs = plan.row_sources.get((i, name))
+                fr[name] = rs if rs is not None else plan.out[name][offsets[i] - lo:offsets[i + 1] - lo]
+            nodeflow._node_frames[i] = fr
+        nodeflow._fetch_plan = plan        # keeps the slot array alive as long as the NodeFlow
+
     # -- fixed-shape fast path (hipGraph pipelines) ---------------------------------------------
-    def plan_fetch(self, layer_offsets, out, need=None):
+    def plan_fetch(self, layer_offsets, out, need=None, virtual=None, slot=None):
         """Everything fetch_data derives from (layer offsets, output frames, `need`) computed once, for callers
         that fetch the same shapes into the same frames every step (GraphedTrainer): the per-step call is
         then fetch_planned(plan, ...) = two or three C-ABI calls and no tensor slicing — at ~0.2 ms per
         step the launch thread is the bottleneck, not the GPU. Not for miss_mode 'staged' (which
-        synchronises with the host anyway)."""
+        synchronises with the host anyway).
+        `virtual` ({layer: [fields]}, a model's virtual_inputs()): fields of the FIRST needed layers that the model
+        only aggregates. Their rows are not gathered: plan.row_sources[(layer, field)] is an ops.RowSource over the
+        cache and the slot's staged miss block, which the aggregation kernel reads in place. Needs the
+        async miss queue (`slot` = its slot index for this plan) or a full cache; silently ignored otherwise."""
         if self.miss_mode == "staged" and not self.full_cached:
             raise L.PgError("plan_fetch: miss_mode 'staged' has no asynchronous fast path")
+        from ..ops import RowSource
         plan = _FetchPlan()
         names = list(self.dims)
         offsets = [int(x) for x in layer_offsets]
         lo, hi = offsets[0], offsets[-1]
+        layers = list(range(len(offsets) - 1))
         if need is not None:
             layers = sorted(need)
             assert layers == list(range(layers[0], layers[-1] + 1)), "needed layers must be contiguous"
@@ -519,17 +557,56 @@ class GraphCacheServer:
             names = [n for n in names if n in wanted]
             lo, hi = offsets[layers[0]], offsets[layers[-1] + 1]
         plan.names, plan.row_lo, plan.rows = names, lo, hi - lo
-        plan.out = {n: out[n][lo:hi] for n in names}
+        # ---- which leading layers stay un-materialised -------------------------------------------------------
+        vlayers = []
+        if virtual and (self.full_cached or self.miss_mode == "async") and (self.full_cached or slot is not None):
+            per_layer = [set(need[l]) if need is not None else set(names) for l in layers]
+            same_everywhere = all(f == per_layer[0] for f in per_layer)
+            for l in layers:
+                want = per_layer[layers.index(l)]
+                v = set(virtual.get(l, ()))
+                wide = all(self.dims[n] % 4 == 0 and self.dims[n] >= 256 for n in want)
+                if want and want <= v and wide and l == layers[0] + len(vlayers) and (same_everywhere or len(layers) == 1):
+                    vlayers.append(l)
+                else:
+                    break
+        plan.virtual = bool(vlayers)
+        plan.dense_lo = offsets[vlayers[-1] + 1] - lo if vlayers else 0
+        plan.dense_rows = plan.rows - plan.dense_lo
+        plan.slots = torch.empty(max(1, plan.rows), dtype=torch.int32, device=self.device) if vlayers else None
+        plan.out = {n: out[n][lo + plan.dense_lo:hi] for n in names}
         plan.fields, plan.n_fields = L.make_fields(
             (self.gpu_fix_cache.get(name), plan.out[name], self.dims[name],
              self.gpu_fix_cache[name].stride(0) if name in self.gpu_fix_cache else self.dims[name],
              plan.out[name].stride(0)) for name in names)
         plan.optrs = (L.vp * L.PG_MAX_FIELDS)()
         plan.ostr = (L.c_i32 * L.PG_MAX_FIELDS)()
+        plan.poslo = (L.c_i32 * L.PG_MAX_FIELDS)()
         for f, name in enumerate(self.dims):          # queue fields are in self.dims order
             if name in plan.out:
-                plan.optrs[f] = plan.out[name].data_ptr()
-                plan.ostr[f] = plan.out[name].stride(0)
+                plan.poslo[f] = plan.dense_lo
+                if plan.dense_rows > 0:
+                    plan.optrs[f] = plan.out[name].data_ptr()
+                    plan.ostr[f] = plan.out[name].stride(0)
+                else:
+                    plan.optrs[f] = None
+                    plan.ostr[f] = -1                 # every needed row is read in place: copy to the staged block only
+        plan.row_sources = {}
+        if vlayers:
+            staged = {}
+            if not self.full_cached:
+                self._missq_buffers(slot, plan.rows)  # creates the queue if need be
+                for f, name in enumerate(self.dims):
+                    if name in names:
+                        sp_ = L.vp()
+                        L.check(self.lib.pg_missq_slot_staged(self._missq, slot, f, ctypes.byref(sp_)), "pg_missq_slot_staged")
+                        staged[name] = sp_.value
+            for l in vlayers:
+                a, b = offsets[l] - lo, offsets[l + 1] - lo
+                for name in (need[l] if need is not None else names):
+                    plan.row_sources[(l, name)] = RowSource(plan.slots[a:b], self.gpu_fix_cache.get(name), staged.get(name, 0),
+                                                            self.dims[name], self.dims[name], keep=(self, plan),
+                                                            prof=self.rows_prof)
         plan.cache_epoch = self._cache_epoch
         return plan
 
@@ -541,6 +618,8 @@ class GraphCacheServer:
         R = plan.rows
         sp = ctypes.c_void_p(stream.cuda_stream)
         ids = ctypes.c_void_p(node_mapping.data_ptr() + 8 * plan.row_lo)
+        if plan.virtual:
+            return self._fetch_virtual(plan, ids, sp, slot)
         if self.full_cached and not self.log:
             L.check(self.lib.pg_gather_rows_full(ids, R, plan.fields, plan.n_fields, sp), "pg_gather_rows_full")
             return
@@ -575,6 +654,36 @@ class GraphCacheServer:
                     L.ptr(tab), tab.stride(0), L.ptr(self._miss_pos), L.ptr(self._miss_fullid), R,
                     L.ptr(self._miss_count), self.dims[name], L.ptr(o), o.stride(0), sp), "pg_scatter_rows_from_host")
 
+    def _fetch_virtual(self, plan, ids, sp, slot):
+        """split every needed row (slots + miss list), gather only the rows of the layers that are read row by row,
+        hand the miss list to the queue: rows of the leading layers stay in the cache / the staged block"""
+        R = plan.rows
+        use_q = self.miss_mode == "async" and not self.full_cached
+        if use_q:
+            if slot is None:
+                raise L.PgError("miss_mode='async' needs fetch_planned(..., slot=k)")
+            miss_pos, miss_fullid, miss_count = self._missq_buffers(slot, R)
+        else:
+            self._ensure_capacity(R)
+            miss_pos, miss_fullid, miss_count = L.ptr(self._miss_pos), L.ptr(self._miss_fullid), L.ptr(self._miss_count)
+        L.check(self.lib.pg_split_rows(ids, R, L.ptr(self.slot_map), L.ptr(self.nid_map), miss_pos, miss_fullid,
+                                       miss_count, L.ptr(plan.slots), L.ptr(self._stats) if self.log else None, sp),
+                "pg_split_rows")
+        if plan.dense_rows > 0:
+            timer = None
+            if self.profile is not None:
+                timer = L.vp()
+                L.check(self.lib.pg_timer_create(ctypes.byref(timer)), "pg_timer_create")
+            L.check(self.lib.pg_gather_rows_presplit(ctypes.c_void_p(plan.slots.data_ptr() + 4 * plan.dense_lo),
+                                                     plan.dense_rows, plan.fields, plan.n_fields, timer, sp),
+                    "pg_gather_rows_presplit")
+            if timer is not None:   # 4th item: share of the split rows this copy launch covers
+                self.profile.append([timer, plan.dense_rows, None, plan.dense_rows / max(1, plan.rows)])
+        if use_q:
+            L.check(self.lib.pg_missq_submit_range(self._missq, slot, plan.optrs, plan.ostr, plan.poslo, sp),
+                    "pg_missq_submit_range")
+            self._missq_pending.add(slot)
+
     def _device_tail(self, names, out, miss_pos, miss_fullid, miss_count, R, sp):
         """the share of the miss list the worker leaves alone: read over PCIe by the device, on the fetching stream"""
         for name in names:
@@ -590,6 +699,7 @@ class GraphCacheServer:
             return hit
         if self._missq is None or rows > self._missq_rows:
             self._missq_bufs = {}
+            recreated = self._missq is not None
             if self._missq is not None:
                 # batches in flight on other slots still own the old queue's buffers: let the worker enqueue their
                 # copies, let the device finish them, only then free (a growing NodeFlow in the eager trainer)
@@ -607,6 +717,8 @@ class GraphCacheServer:
                                              self.host_threads, ctypes.byref(h)), "pg_missq_create")
             self._missq, self._missq_rows = h, cap
             self._missq_share = None
+            if recreated:
+                self._cache_epoch += 1   # fetch plans hold pointers into the old queue's staging blocks
         share = max(0, min(256, int(round(self.cpu_share * 256))))
         pinned = getattr(self.graph, "pinned", None)
         if share < 256 and pinned is not None and not all(pinned.get(n, False) for n in self.dims):

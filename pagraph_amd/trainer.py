@@ -23,7 +23,7 @@ def _record_stream(nf, stream):
     ts += [t for t in list(nf.blk_tptr) + list(nf.blk_tdst) + list(nf.blk_theavy) if t is not None]
     for fr in nf._node_frames:
         if fr:
-            ts += list(fr.values())
+            ts += [v.slots if isinstance(v, ops.RowSource) else v for v in fr.values()]
     for t in ts:
         if t.is_cuda:
             t.record_stream(stream)
@@ -45,6 +45,14 @@ class MinibatchTrainer:
         self.after_first_step = None  # callback() — pa_gcn.py:99-100 (auto_cache)
         self._first_done = False
         self._nprep = 0
+        # with `need`: layers the model only aggregates stay un-materialised (model.virtual_inputs)
+        self.fuse_gather = True
+
+    def _virtual(self, nf):
+        m = getattr(self.model, 'module', self.model)
+        if self.fuse_gather and self.need is not None and hasattr(m, 'virtual_inputs'):
+            return m.virtual_inputs(nf.num_layers)
+        return None
 
     # -- 'gpu-load' (pa_gcn.py:87-91) ----------------------------------------
     def prepare(self, nf):
@@ -54,14 +62,14 @@ class MinibatchTrainer:
         self._nprep += 1
         if self.load_stream is None:
             with torch.autograd.profiler.record_function('gpu-load'):
-                self.cacher.fetch_data(nf, need=self.need, slot=p.slot)
+                self.cacher.fetch_data(nf, need=self.need, slot=p.slot, virtual=self._virtual(nf))
                 p.label = self.labels[nf.layer_parent_nid(-1)]
             p.event = None
             return p
         main = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(self.load_stream):
             with torch.autograd.profiler.record_function('gpu-load'):
-                self.cacher.fetch_data(nf, need=self.need, slot=p.slot)
+                self.cacher.fetch_data(nf, need=self.need, slot=p.slot, virtual=self._virtual(nf))
                 p.label = self.labels[nf.layer_parent_nid(-1)]
             p.event = torch.cuda.Event()
             p.event.record(self.load_stream)
@@ -170,6 +178,9 @@ class GraphedTrainer:
         self.keep_losses = bool(keep_losses)
         self._on_main = False            # run_steps made the compute stream current for the whole loop
         self.fuse_head = True            # use model.forward_loss (fused output layer + loss) when the model has one
+        # layer-0 features are aggregated straight from the cache (never materialised) when the model says it only
+        # aggregates them (model.virtual_inputs) and `need` is given — SURVEY 8f-2
+        self.fuse_gather = True
         self.world = int(world_size)
         self.pg = process_group
         self.flat = None
@@ -230,6 +241,7 @@ class GraphedTrainer:
         s.done = torch.cuda.Event()
         s.done_recorded = False
         s.graph = None
+        s.graph_epoch = -1
         s.nf = None
         s.loss = None
         s.plan = None
@@ -287,12 +299,19 @@ class GraphedTrainer:
         """fetch plan of this slot (False: the cacher's mode has no planned path)"""
         if self.cacher.miss_mode == "staged" and not self.cacher.full_cached:
             return False
-        return self.cacher.plan_fetch(nf._layer_offsets, s.out, self.need)
+        virtual = None
+        if self.fuse_gather and self.need is not None and hasattr(self._bare_model(), 'virtual_inputs'):
+            virtual = self._bare_model().virtual_inputs(nf.num_layers)
+        return self.cacher.plan_fetch(nf._layer_offsets, s.out, self.need, virtual=virtual, slot=s.slot_index)
+
+    def _bare_model(self):
+        return getattr(self.model, 'module', self.model)
 
     def _step_body(self, s):
+        rs = s.plan.row_sources if s.plan else {}
         for i in range(s.nf.num_layers):
             o0, o1 = s.nf._layer_offsets[i], s.nf._layer_offsets[i + 1]
-            s.nf._node_frames[i] = {n: t[o0:o1] for n, t in s.out.items()
+            s.nf._node_frames[i] = {n: (rs[(i, n)] if (i, n) in rs else t[o0:o1]) for n, t in s.out.items()
                                     if self.need is None or n in self.need.get(i, ())}
         if self._gseed is None:                 # persistent d loss / d loss: no ones_like fill (nor a divide) per step
             self._gseed = torch.full((), 1.0 / self.world, dtype=torch.float32, device=self.device)
@@ -330,6 +349,8 @@ class GraphedTrainer:
         main = self.compute_stream
         main.wait_event(s.ready)
         self.cacher.wait_misses(s.slot_index, main)
+        if s.graph is not None and s.graph_epoch != self.cacher._cache_epoch:
+            s.graph = None               # the captured step reads the cache in place: re-capture after the cache changed
         if s.graph is not None and self.world == 1 and self._on_main:
             s.graph.replay()                                  # steady state: one launch
             loss = s.loss.clone() if self.keep_losses else s.loss
@@ -350,6 +371,7 @@ class GraphedTrainer:
                     with torch.cuda.graph(g, stream=main, capture_error_mode="thread_local"):
                         s.loss = self._step_body(s).detach()
                     s.graph = g
+                    s.graph_epoch = self.cacher._cache_epoch
                     g.replay()                                   # capture does not execute
                 if self.world > 1:
                     self._sync_and_step(capture_ok=not warm)

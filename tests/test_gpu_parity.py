@@ -1323,3 +1323,118 @@ def test_bench_short_window_reports_steady_state(dev, hiplib):
     assert short["ms_per_step"] <= 1.3 * long_["ms_per_step"], (short["ms_per_step"], long_["ms_per_step"])
     assert max(long_["ms_per_step_windows"]) <= 2.0 * min(long_["ms_per_step_windows"]), long_["ms_per_step_windows"]
     assert short["miss_queue"]["sdma_engine_mask"] != 0          # the direct-SDMA copy path is the one that ran
+
+
+# ---- f-2: gather fused into the layer-0 aggregation (pg_split_rows + pg_spmm_fwd_rows) -------------------------
+@pytest.mark.parametrize("ratio,p_drop,reduce", [(0.3, 0.0, "mean"), (0.3, 0.25, "mean"), (0.0, 0.25, "sum"),
+                                                 (1.0, 0.0, "mean"), (0.6, 0.5, "sum")])
+def test_fused_gather_aggregate_vs_oracle(dev, hiplib, oracle, ratio, p_drop, reduce):
+    """pg_split_rows + pg_spmm_fwd_rows through the raw C-ABI: hits read from the cache, misses from a staged block in
+    miss-list order, dropout keep-mask by source position — equal BIT FOR BIT to the oracle's gather -> dropout ->
+    aggregate (and therefore to the unfused pg_gather_rows + pg_spmm_fwd_drop pair)"""
+    from pagraph_amd import _lib as L
+    rng = np.random.default_rng(int(ratio * 10) + int(p_drop * 100))
+    V, N, Fd, n_src, n_dst = 4000, 6000, 600, 3000, 1100
+    table = rng.random((N, Fd), dtype=np.float32)
+    nid_map = np.sort(rng.choice(N, V, replace=False)).astype(np.int64)
+    st = oracle.CacheState(V, nid_map)
+    cached = rng.permutation(V)[:int(V * ratio)].astype(np.int64)
+    st.cache_fix_data(cached, {"f": table}, ratio == 1.0)
+    ids = rng.choice(V, n_src, replace=False).astype(np.int64)
+    ids[-7:] = -1                                             # padding of a fixed-shape NodeFlow
+    deg = rng.integers(0, 6, n_dst); deg[5] = 0; deg[17] = 150     # an empty destination, one with > 64 edges
+    indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    src = rng.integers(0, n_src - 7, int(indptr[-1])).astype(np.int32)
+    # oracle: materialise, drop, aggregate
+    rows = np.zeros((n_src, Fd), np.float32)
+    rows[:-7] = st.fetch_layer(ids[:-7], {"f": table})["f"]
+    thr = oracle.dropout_threshold(p_drop)
+    seed, tag, step = 0x1234567, 3, 9
+    h = rows
+    if thr:
+        keep, scale = oracle.dropout_mask(n_src, Fd, thr, seed, tag, step)
+        h = np.where(keep, rows * scale, np.float32(0)).astype(np.float32)
+    want = oracle.spmm_fwd(indptr, src, h, n_dst, reduce)
+    # device
+    sp = L.stream_ptr()
+    d_ids = torch.from_numpy(ids).to(dev)
+    slot_map = torch.empty(V, dtype=torch.int32, device=dev)
+    L.check(hiplib.pg_slot_map_reset(L.ptr(slot_map), V, sp))
+    d_cached, d_nid_map = torch.from_numpy(cached).to(dev), torch.from_numpy(nid_map).to(dev)
+    d_indptr, d_src = torch.from_numpy(indptr).to(dev), torch.from_numpy(src).to(dev)
+    if len(cached):
+        L.check(hiplib.pg_slot_map_assign(L.ptr(slot_map), L.ptr(d_cached), len(cached), sp))
+    cache = torch.from_numpy(st.cache["f"]).to(dev) if len(cached) else None
+    slots = torch.empty(n_src, dtype=torch.int32, device=dev)
+    mpos = torch.empty(n_src, dtype=torch.int32, device=dev)
+    mfull = torch.empty(n_src, dtype=torch.int64, device=dev)
+    mcnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    stats = torch.zeros(2, dtype=torch.int64, device=dev)
+    L.check(hiplib.pg_split_rows(L.ptr(d_ids), n_src, L.ptr(slot_map), L.ptr(d_nid_map), L.ptr(mpos),
+                                 L.ptr(mfull), L.ptr(mcnt), L.ptr(slots), L.ptr(stats), sp))
+    m = int(mcnt.item())
+    assert stats.tolist() == [n_src - 7, m] and m == int((~st.gpu_flag[ids[:-7]].astype(bool)).sum())
+    sl = slots.cpu().numpy()
+    assert np.array_equal(np.sort(-sl[sl <= -3] - 3), np.arange(m)) and np.all(sl[-7:] == -2)
+    staged = torch.from_numpy(table[mfull[:m].cpu().numpy()]).to(dev) if m else None       # the miss path's copy
+    rs = L.PgRowSource(slots.data_ptr(), cache.data_ptr() if cache is not None else 0, staged.data_ptr() if m else 0,
+                       cache.stride(0) if cache is not None else Fd, Fd)
+    out = torch.empty((n_dst, Fd), dtype=torch.float32, device=dev)
+    stepd = torch.tensor([step], dtype=torch.int64, device=dev)
+    drop = L.PgDropout(thr, tag, seed, L.ptr(stepd))
+    prof = torch.zeros(3 * 16, dtype=torch.int64, device=dev)
+    L.check(hiplib.pg_spmm_fwd_rows(L.ptr(d_indptr), L.ptr(d_src),
+                                    ctypes.byref(rs), n_dst, Fd, 0 if reduce == "mean" else 1, L.ptr(out), Fd,
+                                    ctypes.byref(drop), L.ptr(prof), 16, sp))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    t0, t1, ne = prof[3 * (step % 16):3 * (step % 16) + 3].tolist()
+    assert 0 < t1 - t0 < 100_000_000 and ne == int(indptr[-1])   # the kernel stamped its own start / end (100 MHz ticks)
+
+
+@pytest.mark.parametrize("arch", ["gcn", "sage"])
+@pytest.mark.parametrize("mode", ["async", "full"])
+def test_virtual_layer0_matches_materialised(dev, hiplib, arch, mode):
+    """fetch_data(virtual=model.virtual_inputs()): logits and gradients equal the materialised path bit for bit,
+    with dropout on (same Philox counters), for a partial cache over the async miss queue and for a full cache"""
+    import torch.nn.functional as Fn
+    from pagraph_amd.model import GCNSampling, GraphSageSampling
+    from pagraph_amd.ops import RowSource
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    rng = np.random.default_rng(12)
+    V, Fd, C, B, k = 5000, 600, 11, 300, 2
+    adj = _rand_csc(rng, V, 40000)
+    g = DeviceGraph(adj)
+    feats = rng.random((V, Fd), dtype=np.float32)
+    store = HostFeatureStore({"features": torch.from_numpy(feats)})
+    c = GraphCacheServer(store, V, torch.arange(V), 0, miss_mode="async")
+    c.init_field(["features"])
+    c.auto_cache(g, ["features"], cache_ratio=1.0 if mode == "full" else 0.3)
+    assert c.full_cached == (mode == "full")
+    torch.manual_seed(5)
+    model = (GCNSampling(Fd, 32, C, 1, Fn.relu, 0.3) if arch == "gcn" else GraphSageSampling(Fd, 16, C, 1, Fn.relu, 0.3, 'mean'))
+    model = model.to(dev).train()
+    need = model.required_inputs(3)
+    virt = model.virtual_inputs(3)
+    assert virt == {0: ['features']}
+    smp = NeighborSampler(g, B, k, neighbor_type='in', shuffle=False, num_hops=2, seed_nodes=np.arange(0, V, 2), seed=1)
+    it = iter(smp)
+    for rep in range(2):
+        nf = next(it)
+        outs = []
+        for v in (None, virt):
+            model._drop_step.fill_(7 + rep)                  # both runs draw the same dropout masks
+            model.zero_grad(set_to_none=True)
+            c.fetch_data(nf, need=need, slot=rep, virtual=v)
+            c.wait_misses(rep)
+            assert isinstance(nf._node_frames[0]["features"], RowSource) == (v is not None)
+            if arch == "sage":
+                assert all(torch.is_tensor(nf._node_frames[i]["features"]) for i in (1, 2))
+            y = model(nf)
+            y.square().sum().backward()
+            torch.cuda.synchronize()
+            outs.append((y.detach().clone(), [p.grad.clone() for p in model.parameters()]))
+        assert torch.equal(outs[0][0], outs[1][0])
+        for a, b in zip(outs[0][1], outs[1][1]):
+            assert torch.equal(a, b)
