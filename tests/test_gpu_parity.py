@@ -1438,3 +1438,103 @@ def test_virtual_layer0_matches_materialised(dev, hiplib, arch, mode):
         assert torch.equal(outs[0][0], outs[1][0])
         for a, b in zip(outs[0][1], outs[1][1]):
             assert torch.equal(a, b)
+
+
+# ---- config 3 at full size: RMAT 10 M vertices / 100 M undirected edges, feat 600, GraphSAGE, 30 % cache -----------
+@pytest.mark.timeout(1200)
+def test_config3_full_size_sampler_and_fetch(dev, hiplib, oracle):
+    """BASELINE.json configs[2] at its real size (V = 10^7, nnz = 2 x 10^8, 24 GB host table): the sampler's
+    structural invariants on the GPU, node ids / blocks bit-exact against the C oracle for two minibatches, and
+    fetch_data (GraphSAGE `need`, async miss queue, materialised and with layer 0 left in place) equal to
+    table[nid_map[ids]] bit for bit."""
+    import torch.nn.functional as Fn
+    from pagraph_amd.data import synthetic as syn
+    from pagraph_amd.model import GraphSageSampling
+    from pagraph_amd.ops import RowSource
+    from pagraph_amd.partition.utils import closure_device
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    free_host = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    if free_host < 40 << 30:
+        pytest.skip("needs ~30 GB of free host memory for the 10M x 600 feature table")
+    V, E, Fd, B, k, hops = 10_000_000, 100_000_000, 600, 6000, 2, 2
+    indptr, indices = syn.rmat_graph(V, E, device=dev)
+    assert indices.numel() == 2 * E and int(indptr[-1]) == 2 * E
+    train_mask, _, _ = syn.split_dataset(V)
+    train = torch.nonzero(train_mask).squeeze(1)
+    g_full = DeviceGraph.from_csc(indptr, indices, V)
+    sub_indptr, sub_indices, sub2full, subtrain = closure_device(g_full, train, hops)
+    del g_full, indptr, indices
+    torch.cuda.empty_cache()
+    Vs = sub2full.numel()
+    assert Vs > 8_000_000 and subtrain.numel() == train.numel() - 1 or subtrain.numel() == train.numel()
+    g = DeviceGraph.from_csc(sub_indptr, sub_indices, Vs)
+    table = torch.empty((V, Fd), dtype=torch.float32, pin_memory=True)
+    syn.fill_random_features(table, device=dev)
+    cacher = GraphCacheServer(HostFeatureStore({"features": table}, pin=False, device_visible={"features": True}), Vs,
+                              sub2full, 0, miss_mode="async")
+    cacher.init_field(["features"])
+    cacher.log = True
+    torch.cuda.reset_peak_memory_stats(dev)
+    cacher.auto_cache(g, ["features"], cache_ratio=0.30)
+    assert cacher.cached_num == int(Vs * 0.30) and not cacher.full_cached
+    sampler = NeighborSampler(g, B, k, neighbor_type='in', shuffle=True, num_hops=hops, seed_nodes=subtrain, seed=0)
+    seeds_h = sampler.seeds.cpu().numpy()
+    indptr_h, indices_h = g.indptr.cpu().numpy(), g.indices.cpu().numpy()
+    indeg = g.indptr[1:] - g.indptr[:-1]
+    # every CSC entry as one sorted key (column-major, rows ascending inside a column)
+    col = torch.repeat_interleave(torch.arange(Vs, device=dev), indeg)
+    all_keys = col * Vs + g.indices.long()
+    del col
+    model = GraphSageSampling(Fd, 16, 60, 1, Fn.relu, 0.2, 'mean').to(dev)
+    need, virt = model.required_inputs(hops + 1), model.virtual_inputs(hops + 1)
+    sub2full_h = sub2full.cpu()
+    it = iter(sampler)
+    for b in range(3):
+        nf = next(it)
+        nm = nf._node_mapping.tousertensor()
+        o = nf._layer_offsets
+        assert o[-1] - o[-2] == B and torch.equal(nm[o[-2]:o[-1]], sampler.seeds[b * B:(b + 1) * B])
+        for l in range(hops):                              # non-seed layers: ascending and unique
+            lay = nm[o[l]:o[l + 1]]
+            assert bool((lay[1:] > lay[:-1]).all()) and int(lay[0]) >= 0 and int(lay[-1]) < Vs
+        for blk in range(hops):
+            ip, sr = nf.blk_indptr[blk].long(), nf.blk_src[blk].long()
+            dst_ids = nm[o[blk + 1]:o[blk + 2]]
+            cnt = ip[1:] - ip[:-1]
+            assert torch.equal(cnt, torch.minimum(indeg[dst_ids], torch.full_like(cnt, k)))     # min(k, deg) picks
+            u = nm[o[blk]:o[blk + 1]][sr]
+            v = torch.repeat_interleave(dst_ids, cnt)
+            key = v * Vs + u
+            pos = torch.searchsorted(all_keys, key)
+            assert bool((all_keys[pos.clamp(max=all_keys.numel() - 1)] == key).all())            # sampled edge exists
+            # distinct picks per destination POSITION (the seed layer repeats vertex 0: utils.py:34 maps every
+            # isolated train vertex there)
+            pkey = torch.repeat_interleave(torch.arange(cnt.numel(), device=dev), cnt) * Vs + u
+            assert torch.unique(pkey).numel() == pkey.numel()
+        if b < 2:                                          # node ids and blocks bit-exact against the C oracle
+            ref = oracle.sample_nodeflow(indptr_h, indices_h, seeds_h[b * B:(b + 1) * B], k, hops, 0, 0, b)
+            assert np.array_equal(nm.cpu().numpy(), ref["node_mapping"])
+            assert list(o) == list(ref["layer_offsets"][:hops + 2])
+            for blk in range(hops):
+                assert np.array_equal(nf.blk_indptr[blk].cpu().numpy(), ref["blocks"][blk][0])
+                assert np.array_equal(nf.blk_src[blk].cpu().numpy(), ref["blocks"][blk][1])
+        want = table[sub2full_h[nm.cpu()]]                 # the reference's miss-path op on every row (storage.py:128)
+        for v in (None, virt):
+            cacher.fetch_data(nf, need=need, slot=b, virtual=v)
+            cacher.wait_misses(b)
+            torch.cuda.synchronize()
+            for l in range(hops + 1):
+                fr = nf._node_frames[l]["features"]
+                if isinstance(fr, RowSource):
+                    assert l == 0 and v is not None
+                    # read the un-materialised rows the way the kernel does: an identity block, reduce = sum
+                    n0 = o[1] - o[0]
+                    from pagraph_amd import ops
+                    ident_ip = torch.arange(n0 + 1, dtype=torch.int32, device=dev)
+                    ident_src = torch.arange(n0, dtype=torch.int32, device=dev)
+                    fr = ops.aggregate_rows(ident_ip, ident_src, fr, n0, "sum")
+                assert torch.equal(fr.cpu(), want[o[l]:o[l + 1]]), (b, l)
+    miss_rate = cacher.get_miss_rate()
+    assert 0.15 < miss_rate < 0.35                          # BASELINE: ~24 % of all rows miss with the 30 % degree cache
+    cacher.check_misses()
