@@ -110,6 +110,12 @@ def trainer(rank, world_size, args, arch, backend='nccl'):
         if cacher.log:
             miss_rate = cacher.get_miss_rate()
             print('Epoch average miss rate: {:.4f}'.format(miss_rate))
+        if args.ckpt and rank == 0:
+            # what examples/eval.py loads: <ckpt>/<arch>_<epoch> (eval.py:30-32); parameters in module order
+            os.makedirs(args.ckpt, exist_ok=True)
+            bare = getattr(model, 'module', model)
+            torch.save({k_: v_.detach().cpu() for k_, v_ in bare.named_parameters()},
+                       os.path.join(args.ckpt, ('gcn-nssc' if arch == 'gcn' else 'gs-nssc') + '_' + str(epoch)))
     toc = time.time()
     print('Total Time: {:.4f}s'.format(toc - tic))
     dist.destroy_process_group()
@@ -143,6 +149,7 @@ def main(arch, description, n_hidden, lr):
     parser.add_argument("--fetch-needed", action="store_true",
                         help="fetch only the layers/fields the model reads instead of everything (SURVEY 8f-2)")
     parser.add_argument("--log-miss-rate", action="store_true")
+    parser.add_argument("--ckpt", type=str, default=None, help="directory for one checkpoint per epoch (examples/eval.py)")
     args = parser.parse_args()
     if args.remote_sample:
         print('--remote-sample: sampling already runs on the GPU; flag ignored')

@@ -29,6 +29,8 @@ What is pinned by the reference itself:
       in-edges) in place of DGL's fused message-passing kernel, which is not
       available. Outputs: logits and every parameter gradient of
       sum(logits * G) for a stored G.
+  G9  count_vertex_freq / optimal_cache_hit (examples/opt_cache_hit.py:22-31) and
+      count_nf_vnum (examples/count_vnum.py:16-20) on a fixed trace of NodeFlows
 
 numpy note (G4): dg.py:31 calls np.argsort with the default, UNSTABLE kind. On
 CPUs with AVX2/AVX-512 numpy >= 2.0 dispatches it to x86-simd-sort, whose tie
@@ -454,6 +456,39 @@ def gen_models(gcn, sage):
                              n_classes=np.int64(C)))
 
 
+# --------------------------------------------------------------------------
+# G9: cache-policy analysis helpers of examples/opt_cache_hit.py and examples/count_vnum.py
+# --------------------------------------------------------------------------
+def gen_analysis():
+    sys.path.insert(0, os.path.join(REF, "examples"))
+    och = importlib.import_module("opt_cache_hit")      # count_vertex_freq, optimal_cache_hit, count_nf_vnum
+    cvn = importlib.import_module("count_vnum")
+    rng = np.random.default_rng(909)
+    V = 500
+    w = 1.0 / np.arange(1, V + 1) ** 1.1
+    w /= w.sum()
+    freq = np.zeros(V, dtype=np.int64)
+    out = {"V": np.int64(V)}
+    vnum = 0
+    n_nf = 12
+    for t in range(n_nf):
+        layers = [np.unique(rng.choice(V, 160, p=w)), np.unique(rng.choice(V, 60, p=w)),
+                  rng.choice(V, 25, p=w)]              # seed layer: in seed order, WITH repeats
+        nf = types.SimpleNamespace(num_layers=3,
+                                   layer_parent_nid=lambda i, L=layers: torch.from_numpy(L[i]),
+                                   layer_nid=lambda i, L=layers: torch.from_numpy(L[i]))
+        och.count_vertex_freq(nf, freq)
+        vnum += cvn.count_nf_vnum(nf)
+        for i, l in enumerate(layers):
+            out[f"nf{t}_layer{i}"] = l.astype(np.int64)
+    out["num_nodeflows"] = np.int64(n_nf)
+    out["freq"] = freq.copy()
+    out["vnum"] = np.int64(vnum)
+    for r in (0.05, 0.2, 0.5):
+        out[f"opt_hit_{int(r * 100):02d}"] = np.float64(och.optimal_cache_hit(freq, r))
+    np.savez(os.path.join(OUT, "g9_cache_analysis.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     dgl = install_stubs()
@@ -466,6 +501,7 @@ def main():
     gen_dg(dgmod)
     gen_closure(dgl, utils)
     gen_models(importlib.import_module("PaGraph.model.gcn_nssc"), importlib.import_module("PaGraph.model.graphsage_nssc"))
+    gen_analysis()
     n = len([f for f in os.listdir(OUT) if f.endswith(".npz")])
     sz = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"wrote {n} fixtures, {sz/1e6:.2f} MB -> {os.path.normpath(OUT)}")

@@ -416,6 +416,30 @@ def sage_forward(nf, feats_by_layer, params, n_layers=1):
 
 
 # --------------------------------------------------------------------------
+# cache-policy analysis (examples/opt_cache_hit.py, examples/count_vnum.py) — pinned by tests/golden/g9_*
+# --------------------------------------------------------------------------
+def count_nf_vnum(layers):
+    """count_vnum.py:16-20: rows of one NodeFlow, every layer"""
+    return int(sum(len(l) for l in layers))
+
+
+def count_vertex_freq(layers, freq):
+    """opt_cache_hit.py:22-24: `freq[nf.layer_parent_nid(lid)] += 1` — numpy's fancy-index add counts a vertex once
+    per layer even when the layer lists it several times"""
+    for ids in layers:
+        freq[np.asarray(ids, np.int64)] += 1
+
+
+def optimal_cache_hit(freq, cached):
+    """opt_cache_hit.py:26-31"""
+    num = int(freq.shape[0] * cached)
+    total = np.sum(freq)
+    sorted_freq = np.sort(freq)
+    hit_time = np.sum(sorted_freq[-num:])
+    return hit_time / total
+
+
+# --------------------------------------------------------------------------
 # partitioning (PaGraph/partition/dg.py, utils.py) — small-case Python restatements
 # --------------------------------------------------------------------------
 def dg_partition(P, indptr, indices, V, train_nids, hops):

@@ -20,7 +20,9 @@ def access_frequency(sampler, num_nodes=None, max_batches=None, layers=None):
                 continue
             ids = nf.layer_parent_nid(lid)
             ids = ids[ids >= 0]
-            freq += torch.bincount(ids, minlength=n)
+            # `freq[ids] += 1` (opt_cache_hit.py:24) counts a vertex ONCE per layer however often the layer repeats
+            # it (numpy fancy-index add does not accumulate); count_nf_vnum (count_vnum.py:19) counts every row
+            freq[torch.unique(ids)] += 1
             loaded += int(ids.numel())
     return freq, loaded
 

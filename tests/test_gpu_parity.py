@@ -1538,3 +1538,89 @@ def test_config3_full_size_sampler_and_fetch(dev, hiplib, oracle):
     miss_rate = cacher.get_miss_rate()
     assert 0.15 < miss_rate < 0.35                          # BASELINE: ~24 % of all rows miss with the 30 % degree cache
     cacher.check_misses()
+
+
+# ---- f-4: cache-policy analysis and evaluation tooling -------------------------------------------------------------
+def test_cache_analysis_vs_reference_golden(dev, hiplib, golden_dir):
+    """pagraph_amd.analysis (access_frequency / optimal_cache_hit) and examples/count_vnum.count_nf_vnum == the
+    reference's opt_cache_hit.py / count_vnum.py functions on the G9 trace (seed layers repeat vertices: counted once
+    per layer for the frequency, every row for the vertex count)"""
+    import importlib.util
+    import types
+    from pagraph_amd import analysis
+    from pagraph_amd.sampling.nodeflow import NodeFlow
+    z = np.load(os.path.join(golden_dir, "g9_cache_analysis.npz"))
+    V = int(z["V"])
+    nfs = []
+    for t in range(int(z["num_nodeflows"])):
+        layers = [z[f"nf{t}_layer{i}"] for i in range(3)]
+        offs = np.concatenate([[0], np.cumsum([len(l) for l in layers])])
+        empty = [torch.zeros(len(layers[i + 1]) + 1, dtype=torch.int32, device=dev) for i in range(2)]
+        nfs.append(NodeFlow(torch.from_numpy(np.concatenate(layers)).to(dev), offs, empty,
+                            [torch.zeros(0, dtype=torch.int32, device=dev)] * 2))
+    fake = types.SimpleNamespace(g=types.SimpleNamespace(number_of_nodes=lambda: V), device=dev, __iter__=None)
+    class _S:
+        g = fake.g
+        device = dev
+        def __iter__(self):
+            return iter(nfs)
+    freq, loaded = analysis.access_frequency(_S())
+    assert np.array_equal(freq.cpu().numpy(), z["freq"]) and loaded == int(z["vnum"])
+    for r in (0.05, 0.2, 0.5):
+        assert abs(analysis.optimal_cache_hit(freq, r) - float(z[f"opt_hit_{int(r * 100):02d}"])) < 1e-12
+    spec = importlib.util.spec_from_file_location("count_vnum", os.path.join(ROOT, "examples", "count_vnum.py"))
+    cv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cv)
+    assert sum(cv.count_nf_vnum(nf) for nf in nfs) == int(z["vnum"])
+
+
+def test_eval_and_count_vnum_scripts(dev, hiplib, oracle, tmp_path):
+    """examples/profile/pa_gcn.py --ckpt -> examples/eval.py (eval.py:13-46): the accuracy it prints equals the one
+    computed from the oracle's GCNInfer restatement on a numpy full-neighbour NodeFlow; examples/count_vnum.py runs"""
+    import subprocess, sys
+    from pagraph_amd import data
+    ds = tmp_path / "tiny"
+    ds.mkdir()
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_PORT="29671")
+    run = lambda *a: subprocess.run([sys.executable, *a], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    r = run("-m", "pagraph_amd.data.preprocess", "--dataset", str(ds), "--gen-rmat", "6000", "30000", "--gen-feature",
+            "--feat-size", "32", "--gen-label", "--class-num", "5", "--gen-set")
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = run("-m", "pagraph_amd.partition.hash", "--dataset", str(ds), "--partition", "1", "--num-hops", "2")
+    assert r.returncode == 0, r.stderr[-2000:]
+    ck = tmp_path / "ck"
+    r = run(os.path.join("examples", "profile", "pa_gcn.py"), "--dataset", str(ds), "--gpu", "0", "--feat-size", "32",
+            "--n-classes", "5", "--n-epochs", "2", "--batch-size", "500", "--cache-ratio", "0.3", "--miss-mode", "async",
+            "--ckpt", str(ck))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert (ck / "gcn-nssc_0").exists() and (ck / "gcn-nssc_1").exists()
+    r = run(os.path.join("examples", "eval.py"), "--dataset", str(ds), "--gpu", "0", "--feat-size", "32", "--ckpt", str(ck),
+            "--start", "0", "--end", "2", "--interval", "1")
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    accs = {int(l.split("]")[0][1:]): float(l.split()[-1]) for l in r.stdout.splitlines() if "Test Accuracy" in l}
+    assert set(accs) == {0, 1}
+    # the same number from the oracle: numpy full-neighbour NodeFlow + gcn_model_forward(infer=True)
+    adj = data.get_struct(str(ds))
+    csc = spsp.csc_matrix(adj); csc.sum_duplicates(); csc.sort_indices()
+    feat = np.load(ds / "feat.npy").astype(np.float32)
+    labels = data.get_labels(str(ds))
+    test_nid = np.nonzero(data.get_masks(str(ds))[2])[0].astype(np.int64)
+    with np.errstate(divide="ignore"):
+        norm = (1.0 / np.diff(csc.indptr).astype(np.float32)).reshape(-1, 1)       # pa_server.py:43 (inf when isolated)
+    layers, blocks = [test_nid], []
+    for _ in range(2):
+        dst = layers[0]
+        below = np.unique(np.concatenate([csc.indices[csc.indptr[v]:csc.indptr[v + 1]] for v in dst] + [np.zeros(0, np.int32)]))
+        ip = np.concatenate([[0], np.cumsum([csc.indptr[v + 1] - csc.indptr[v] for v in dst])]).astype(np.int32)
+        sr = np.searchsorted(below, np.concatenate([csc.indices[csc.indptr[v]:csc.indptr[v + 1]] for v in dst] + [np.zeros(0, np.int32)])).astype(np.int32)
+        layers.insert(0, below.astype(np.int64)); blocks.insert(0, (ip, sr))
+    frames = [{"features": feat[l], "norm": norm[l]} for l in layers]
+    for ep in (0, 1):
+        state = {f"{k}": v.numpy() for k, v in torch.load(ck / f"gcn-nssc_{ep}").items()}
+        logits, _ = oracle.gcn_model_forward(blocks, [len(l) for l in layers], frames, state, 1, False, infer=True)
+        ok = np.isfinite(logits).all(axis=1)
+        want = float((logits.argmax(1) == labels[test_nid]).sum()) / len(test_nid)
+        assert abs(accs[ep] - want) <= 2.0 / len(test_nid) + 1e-4, (ep, accs[ep], want)    # argmax ties / nan rows
+    r = run(os.path.join("examples", "count_vnum.py"), "--dataset", str(ds), "--n-epochs", "1", "--batch-size", "500")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert int(r.stdout.split("Epoch loaded vertex#:")[1].split()[0]) > len(np.nonzero(data.get_masks(str(ds))[0])[0])

@@ -160,3 +160,18 @@ def test_g8_sage_models_vs_reference(oracle, path):
     want = z["logits"]
     assert got.shape == want.shape
     assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+
+
+def test_g9_cache_analysis_vs_reference(oracle, golden_dir):
+    """count_vertex_freq / optimal_cache_hit (examples/opt_cache_hit.py:22-31) and count_nf_vnum
+    (examples/count_vnum.py:16-20) restated in the oracle == the reference's functions on a fixed trace"""
+    z = np.load(os.path.join(golden_dir, "g9_cache_analysis.npz"))
+    freq = np.zeros(int(z["V"]), dtype=np.int64)
+    vnum = 0
+    for t in range(int(z["num_nodeflows"])):
+        layers = [z[f"nf{t}_layer{i}"] for i in range(3)]
+        oracle.count_vertex_freq(layers, freq)
+        vnum += oracle.count_nf_vnum(layers)
+    assert np.array_equal(freq, z["freq"]) and vnum == int(z["vnum"])
+    for r in (0.05, 0.2, 0.5):
+        assert oracle.optimal_cache_hit(freq, r) == float(z[f"opt_hit_{int(r * 100):02d}"])
