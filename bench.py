@@ -102,9 +102,11 @@ def parse():
     p.add_argument("--skip-cpu-baseline", action="store_true")
     p.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     p.add_argument("--skip-microbench", action="store_true")
-    p.add_argument("--dg-hops", type=int, default=1,
-                   help="hops used by dg's affinity score (dg.py --num-hops; README default 1). hops=2 on the 10M/100M "
-                        "graph walks sum(deg^2)=4.7e10 neighbours sequentially: ~500 s on the host (measured)")
+    p.add_argument("--dg-hops", type=int, default=None,
+                   help="hops used by dg's affinity score (dg.py --num-hops). Default: 2 (README.md:117, the value for a "
+                        "2-layer model without preprocessing = BASELINE configs[3]) up to 2e7 vertices — sum(deg^2) = "
+                        "4.7e10 adjacency entries on the 10M/100M graph, ~1 min with the builder/committer threads of "
+                        "pg_dg_partition_mt (500 s in one thread) — and 1 beyond that (config 5's graph would take >10 min)")
     p.add_argument("--fetch-all", action="store_true",
                    help="fetch every layer and field like the reference (default: only what the model reads, SURVEY 8f-2)")
     p.add_argument("--skip-reference-equivalent", action="store_true", help="skip the short run that fetches every layer "
@@ -411,6 +413,8 @@ def run():
     L.load()
 
     V, E, Fdim, C, B, k = args.vertices, args.edges, args.feat_size, args.n_classes, args.batch_size, args.num_neighbors
+    if args.dg_hops is None:
+        args.dg_hops = 2 if V <= 20_000_000 else 1
     n_layers = 1
     num_hops = n_layers + 1                                   # pa_gcn.py:52
     hidden = 32 if args.model == "gcn" else 16                # pa_gcn.py:130 / pa_gs.py:134
@@ -776,7 +780,7 @@ def run():
                        "steps_per_epoch": steps_per_epoch, "epoch_time_extrapolated_from_steps": K,
                        "setup_steps": S, "pipeline": "cold (drained before the timed region)" if args.cold_start else "primed",
                        "miss_mode": args.miss_mode, "miss_mode_probe": mode_probe, "overlap": not args.no_overlap,
-                       "partition_vertices": Vs,
+                       "partition_vertices": Vs, "dg_hops": args.dg_hops if world > 1 else None,
                        "hip_graph_step": use_graph,
                        "fetch": "all layers+fields (reference)" if need is None else "only what the model reads"},
             # headline = the reference's counting (every row of every layer, storage.py:203-204,219-227): from the

@@ -425,6 +425,12 @@ int pg_adam_step(int32_t n_tensors, float* const* params, const float* const* gr
 int pg_dg_partition(int64_t V, const int64_t* indptr, const int32_t* indices, const int64_t* train_nids,
                     int64_t n_train, int32_t P, int32_t hops, int8_t* belongs_out, uint8_t* r_mask_out,
                     int64_t* p_vnum_out, int64_t* r_vnum_out);
+/* the same with n_threads host threads when hops == 2: n_threads - 1 builders construct the two-hop neighbour sets
+ * (which depend on the graph only) ahead of ONE committer that applies dg.py:71-83 strictly in train order, so the
+ * partition is bit-identical. Other hops values and n_threads <= 1 run the sequential code. pg_dg_partition = this with n_threads from env PG_DG_THREADS (default 1). */
+int pg_dg_partition_mt(int64_t V, const int64_t* indptr, const int32_t* indices, const int64_t* train_nids,
+                       int64_t n_train, int32_t P, int32_t hops, int8_t* belongs_out, uint8_t* r_mask_out,
+                       int64_t* p_vnum_out, int64_t* r_vnum_out, int32_t n_threads);
 
 /* ------------------------------------------------------------------------
  * 5. Synthetic inputs  —  PaGraph/data/preprocess.py:50-114 + PaRMAT (README.md:36-41)

@@ -20,18 +20,33 @@ def _csc_arrays(adj):
             csc.shape[0])
 
 
-def dg_raw(partition_num, indptr, indices, vnum, train_nids, hops):
-    """-> (belongs int8 [V], r_mask uint8 [P, V], p_vnum, r_vnum)"""
+def default_threads():
+    """host threads for the hops == 2 team: the CPUs this process may use (affinity and cgroup quota), at most 32"""
+    cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cpus = min(cpus, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(32, cpus))
+
+
+def dg_raw(partition_num, indptr, indices, vnum, train_nids, hops, threads=None):
+    """-> (belongs int8 [V], r_mask uint8 [P, V], p_vnum, r_vnum). threads: host threads sharing the work inside
+    each vertex when hops == 2 (default: every CPU the process may use; the result does not depend on it)"""
     lib = L.load()
+    if threads is None:
+        threads = int(os.environ.get("PG_DG_THREADS", 0)) or default_threads()
     train = np.ascontiguousarray(train_nids, dtype=np.int64)
     belongs = np.empty(vnum, dtype=np.int8)
     r_mask = np.empty((partition_num, vnum), dtype=np.uint8)
     p_vnum = np.zeros(partition_num, dtype=np.int64)
     r_vnum = np.zeros(partition_num, dtype=np.int64)
     vp = ctypes.c_void_p
-    L.check(lib.pg_dg_partition(vnum, vp(indptr.ctypes.data), vp(indices.ctypes.data), vp(train.ctypes.data),
-                                len(train), partition_num, hops, vp(belongs.ctypes.data), vp(r_mask.ctypes.data),
-                                vp(p_vnum.ctypes.data), vp(r_vnum.ctypes.data)), "pg_dg_partition")
+    L.check(lib.pg_dg_partition_mt(vnum, vp(indptr.ctypes.data), vp(indices.ctypes.data), vp(train.ctypes.data),
+                                   len(train), partition_num, hops, vp(belongs.ctypes.data), vp(r_mask.ctypes.data),
+                                   vp(p_vnum.ctypes.data), vp(r_vnum.ctypes.data), int(threads)), "pg_dg_partition_mt")
     return belongs, r_mask, p_vnum, r_vnum
 
 

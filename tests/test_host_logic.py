@@ -215,3 +215,25 @@ def test_gpu_only_ops_refuse_cpu_tensors(hiplib):
     assert torch.allclose(y, lin(torch.ones(3, 8)))
     y2 = ops.linear2(torch.ones(3, 8), lin, torch.ones(3, 8), lin, ops.ACT_RELU)
     assert torch.allclose(y2, torch.relu(2 * lin(torch.ones(3, 8))))
+
+
+@pytest.mark.parametrize("P,threads", [(2, 2), (4, 3), (8, 6)])
+def test_dg_hops2_threaded_equals_sequential(hiplib, P, threads):
+    """pg_dg_partition_mt (builders + one committer) == the sequential code, bit for bit: power-law graph with hubs,
+    isolated vertices, a train list in non-ascending order with a repeated vertex"""
+    from pagraph_amd.partition.dg import dg_raw
+    rng = np.random.default_rng(P * 31 + threads)
+    V, E = 6000, 60000
+    w = 1.0 / np.arange(1, V + 1) ** 1.0
+    w /= w.sum()
+    s = rng.choice(V, E, p=w); d = rng.choice(V, E, p=w)
+    adj = spsp.coo_matrix((np.ones(2 * E, np.int8), (np.concatenate([s, d]), np.concatenate([d, s]))), shape=(V, V)).tocsc()
+    adj.sum_duplicates(); adj.sort_indices()
+    train = rng.permutation(V)[:int(V * 0.65)].astype(np.int64)
+    train[100] = train[7]                                       # a repeat: assigned at its first turn only
+    ip, ix = adj.indptr.astype(np.int64), adj.indices.astype(np.int32)
+    a = dg_raw(P, ip, ix, V, train, 2, threads=1)
+    b = dg_raw(P, ip, ix, V, train, 2, threads=threads)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert a[2].sum() == len(np.unique(train))
