@@ -461,9 +461,11 @@ def run():
 
     # ---- feature provider (pa_server.py:38-54) --------------------------------------------
     feat_tab, table_device_visible = make_host_table(V, Fdim, rank, local_rank, world, dev, "feat")
-    probe_modes = args.probe_miss_mode or (args.miss_mode is None and world > 1)
+    # one GPU or many: the async queue (worker thread + one calibrated SDMA engine) unless told otherwise. The
+    # zero-copy / async comparison that used to run at the start of every multi-GPU run is now opt-in.
+    probe_modes = args.probe_miss_mode
     if args.miss_mode is None:
-        args.miss_mode = "async" if world == 1 else "zerocopy"
+        args.miss_mode = "zerocopy" if probe_modes else "async"
     if probe_modes:
         args.miss_mode = "zerocopy"                          # start here; the async path is tried after the warm-up
     if not table_device_visible and args.miss_mode == "zerocopy":
@@ -741,8 +743,8 @@ def run():
         del probe, freq
 
     ref_eq = None
-    if use_graph and not args.skip_reference_equivalent and need is not None and not cacher.full_cached:
-        # every rank runs it (it may all-reduce gradients); rank 0 reports
+    if world == 1 and use_graph and not args.skip_reference_equivalent and need is not None and not cacher.full_cached:
+        # single-GPU lines only (like cpu_baseline): a second trainer would re-bind the flat gradient buffer
         ref_eq = reference_equivalent_leg(args, model, loss_fcn, optimizer, cacher, g, subtrain, labels, dev, world, rank)
         ref_eq["roofline_frac_optimised_path_for_comparison"] = roofline["frac"]
     elif need is None:
@@ -782,6 +784,7 @@ def run():
                        "miss_mode": args.miss_mode, "miss_mode_probe": mode_probe, "overlap": not args.no_overlap,
                        "partition_vertices": Vs, "dg_hops": args.dg_hops if world > 1 else None,
                        "hip_graph_step": use_graph,
+                       "allreduce_in_graph": getattr(trainer, "allreduce_in_graph", None) if world > 1 else None,
                        "fetch": "all layers+fields (reference)" if need is None else "only what the model reads"},
             # headline = the reference's counting (every row of every layer, storage.py:203-204,219-227): from the
             # reference-equivalent leg when the timed loop itself fetches only what the model reads

@@ -185,6 +185,11 @@ class GraphedTrainer:
         self.pg = process_group
         self.flat = None
         self.graph_b = None
+        # world > 1: is the gradient all-reduce captured INSIDE the step's graph (one launch per step) or issued
+        # eagerly between two graphs (three launches)? None = not probed yet; see _probe_graph_allreduce.
+        # PG_GRAPH_ALLREDUCE=0 forces the eager collective.
+        import os as _os
+        self.allreduce_in_graph = False if _os.environ.get("PG_GRAPH_ALLREDUCE") == "0" else None
         if self.world > 1:
             import torch.distributed as dist
             params = [p for p in model.parameters() if p.requires_grad]
@@ -241,6 +246,7 @@ class GraphedTrainer:
         s.done = torch.cuda.Event()
         s.done_recorded = False
         s.graph = None
+        s.graph_synced = False
         s.graph_epoch = -1
         s.nf = None
         s.loss = None
@@ -325,10 +331,69 @@ class GraphedTrainer:
         if self.world > 1:
             self.flat.zero_()
             loss.backward(self._gseed)          # loss / world: the SUM all-reduce then yields DDP's mean gradient
+            if self.allreduce_in_graph:         # the collective and the optimizer belong to the same captured step
+                import torch.distributed as dist
+                dist.all_reduce(self.flat, group=self.pg)
+                self.optimizer.step()
         else:
             loss.backward(self._gseed)
             self.optimizer.step()
         return loss
+
+    def _probe_graph_allreduce(self):
+        """Can this process group's all-reduce live inside a captured graph? RCCL's can (as NCCL's); gloo's cannot.
+        Every rank captures a tiny all-reduce; the ranks AGREE (eager MIN) that all captures succeeded before
+        anyone replays — a rank replaying a collective its peers never enqueue would hang — then the replayed
+        result is checked twice. Any failure -> the eager collective between two graphs (the known-good path)."""
+        import torch.distributed as dist
+        if str(dist.get_backend(self.pg)).lower() != "nccl":
+            return False                 # gloo & co. synchronise with the host inside the collective: not capturable
+        rank = dist.get_rank(self.pg)
+        t = torch.full((8,), float(rank + 1), dtype=torch.float32, device=self.device)
+        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        ok = 1
+        g = torch.cuda.CUDAGraph()
+        probe_stream = torch.cuda.Stream(device=self.device)     # a failed capture must not wedge the compute stream
+        try:
+            with torch.cuda.stream(self.compute_stream):
+                dist.all_reduce(t.clone(), group=self.pg)          # communicator set-up happens outside the capture
+            self.compute_stream.synchronize()
+            with torch.cuda.stream(probe_stream):
+                g.capture_begin(capture_error_mode="thread_local")
+                try:
+                    dist.all_reduce(t, group=self.pg)
+                except Exception:
+                    ok = 0
+                finally:
+                    try:
+                        g.capture_end()                            # always leave capture mode
+                    except Exception:
+                        ok = 0
+        except Exception:
+            ok = 0
+        flag.fill_(ok)
+        with torch.cuda.stream(self.compute_stream):
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+        self.compute_stream.synchronize()
+        if int(flag.item()) == 0:
+            return False
+        want = float(self.world * (self.world + 1) // 2)
+        good = 1
+        try:
+            for _ in range(2):
+                with torch.cuda.stream(probe_stream):
+                    t.fill_(float(rank + 1))
+                    g.replay()
+                probe_stream.synchronize()
+                if not bool((t == want).all()):
+                    good = 0
+        except Exception:
+            good = 0
+        flag.fill_(good)
+        with torch.cuda.stream(self.compute_stream):
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+        self.compute_stream.synchronize()
+        return int(flag.item()) == 1
 
     def _sync_and_step(self, capture_ok):
         """world > 1: all-reduce the flat gradient (eager), then the optimizer step (graph B)"""
@@ -351,19 +416,23 @@ class GraphedTrainer:
         self.cacher.wait_misses(s.slot_index, main)
         if s.graph is not None and s.graph_epoch != self.cacher._cache_epoch:
             s.graph = None               # the captured step reads the cache in place: re-capture after the cache changed
-        if s.graph is not None and self.world == 1 and self._on_main:
+        if s.graph is not None and (self.world == 1 or s.graph_synced) and self._on_main:
             s.graph.replay()                                  # steady state: one launch
             loss = s.loss.clone() if self.keep_losses else s.loss
         else:
             with torch.cuda.stream(main):
                 warm = self.steps_done < self.warmup_eager
+                synced = bool(self.allreduce_in_graph)       # did the body below already all-reduce and step?
                 if s.graph is not None:
                     s.graph.replay()
+                    synced = s.graph_synced
                 elif warm:
                     if self.world == 1:
                         self.optimizer.zero_grad(set_to_none=True)
                     s.loss = self._step_body(s).detach()
                 else:
+                    if self.world > 1 and self.allreduce_in_graph is None:
+                        self.allreduce_in_graph = self._probe_graph_allreduce()
                     g = torch.cuda.CUDAGraph()
                     if self.world == 1:
                         self.optimizer.zero_grad(set_to_none=True)
@@ -372,8 +441,9 @@ class GraphedTrainer:
                         s.loss = self._step_body(s).detach()
                     s.graph = g
                     s.graph_epoch = self.cacher._cache_epoch
+                    s.graph_synced = synced = bool(self.allreduce_in_graph)
                     g.replay()                                   # capture does not execute
-                if self.world > 1:
+                if self.world > 1 and not synced:
                     self._sync_and_step(capture_ok=not warm)
                 # the slot's static loss tensor is overwritten when its graph is replayed again
                 loss = s.loss.clone() if self.keep_losses else s.loss
