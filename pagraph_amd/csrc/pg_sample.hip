@@ -442,6 +442,7 @@ struct pg_sampler {
     hipEvent_t done = nullptr;       // recorded after every launch into this slot
   };
   std::vector<SlotState*> slot_states;
+  std::vector<SlotState*> tslot_states;   // pg_sampler_transpose's per-(slot, stream) graphs
   SampleParams* prm_d = nullptr;     // device copy of the running call's parameters
   int64_t V = 0;
   const int64_t* indptr = nullptr;
@@ -482,6 +483,11 @@ static void sampler_free(pg_sampler* s) {
   (void)hipFree(s->tkey);
   (void)hipFree(s->tsort_tmp);
   (void)hipFree(s->prm_d);
+  for (auto* c : s->tslot_states) {
+    if (c->exec) (void)hipGraphExecDestroy(c->exec);
+    if (c->graph) (void)hipGraphDestroy(c->graph);
+    delete c;
+  }
   for (auto* c : s->slot_states) {
     if (c->exec) (void)hipGraphExecDestroy(c->exec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
@@ -737,17 +743,60 @@ int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, ui
   return rc;
 }
 
+static int enqueue_transposes(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t st) {
+  for (int b = 0; b < s->hops; ++b) {
+    if (!((o->transpose_mask >> b) & 1u)) continue;
+    const int rc = transpose_block(s, o, b, o->sizes_dev + b + 1, o->sizes_dev + b, o->sizes_dev + PG_MAX_LAYERS + b,
+                                   s->tdummy, st);
+    if (rc != PG_OK) return rc;
+  }
+  return PG_OK;
+}
+
 int pg_sampler_transpose(pg_sampler_t* s, const pg_nodeflow_desc_t* o, pg_stream_t stream) {
   if (!s || !o || !o->blk_indptr || !o->blk_src) return PG_ERR_INVALID;
   if (!o->transpose_mask) return PG_OK;
   if (!o->blk_tptr || !o->blk_tdst || !o->sizes_dev) return PG_ERR_INVALID;
-  for (int b = 0; b < s->hops; ++b) {
-    if (!((o->transpose_mask >> b) & 1u)) continue;
-    const int rc = transpose_block(s, o, b, o->sizes_dev + b + 1, o->sizes_dev + b, o->sizes_dev + PG_MAX_LAYERS + b,
-                                   s->tdummy, as_stream(stream));
-    if (rc != PG_OK) return rc;
+  hipStream_t st = as_stream(stream);
+  // like the sampling chain, the launch sequence into a given slot from a given stream is fixed (all sizes are read
+  // from the slot's device counters): from the second call it is one hipGraph launch instead of ~8 kernel launches
+  // on the trainer's launch thread. The key differs from the sampling chain's by the stream.
+  static const bool no_graph = getenv("PG_SAMPLER_NO_GRAPH") != nullptr;
+  pg_sampler::SlotState* ss = nullptr;
+  for (auto* c : s->tslot_states)
+    if (c->key == o->node_mapping && c->stream == st && memcmp(&c->desc, o, sizeof(*o)) == 0) ss = c;
+  if (!ss) {
+    ss = new (std::nothrow) pg_sampler::SlotState;
+    if (!ss) return PG_ERR_NOMEM;
+    ss->key = o->node_mapping;
+    ss->stream = st;
+    ss->desc = *o;
+    s->tslot_states.push_back(ss);
   }
-  return PG_OK;
+  ++ss->calls;
+  if (ss->exec) {
+    PG_HIP(hipGraphLaunch(ss->exec, st));
+    return PG_OK;
+  }
+  if (no_graph || ss->graph_failed || ss->calls < 2) return enqueue_transposes(s, o, st);
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    ss->graph_failed = true;
+    return enqueue_transposes(s, o, st);
+  }
+  int rc = enqueue_transposes(s, o, st);
+  hipGraph_t graph = nullptr;
+  const hipError_t e_end = hipStreamEndCapture(st, &graph);
+  if (rc == PG_OK && e_end == hipSuccess && graph && hipGraphInstantiate(&ss->exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+    ss->graph = graph;
+    PG_HIP(hipGraphLaunch(ss->exec, st));
+    return PG_OK;
+  }
+  (void)hipGetLastError();
+  if (graph) (void)hipGraphDestroy(graph);
+  ss->exec = nullptr;
+  ss->graph_failed = true;
+  return enqueue_transposes(s, o, st);   // nothing ran during the failed capture
 }
 
 int pg_frontier_mark_neighbors(const int64_t* indptr, const int32_t* indices, const int64_t* frontier, int64_t n,

@@ -113,7 +113,8 @@ class NeighborSampler:
                                                min(self.fanout, 2 ** 31 - 1), self.num_hops, ctypes.byref(h)),
                     "pg_sampler_create")
         self.handle = h
-        self.stream = torch.cuda.Stream(device=self.device, priority=-1)   # ~15 tiny latency-bound launches
+        import os as _os
+        self.stream = torch.cuda.Stream(device=self.device, priority=int(_os.environ.get("PG_PRIO_SAMPLER", -1)))   # ~12 tiny latency-bound launches
         # stream on which the consumer finishes with a NodeFlow (None = current stream at hand-back);
         # a ring slot is re-sampled only after the event recorded there
         self.consumer_stream = None
@@ -195,6 +196,13 @@ class NeighborSampler:
             # the CURRENT stream wait here would also stall every stream that implicitly synchronises
             # with the legacy default stream
             torch.cuda.current_stream(self.device).wait_event(slot.ready)
+        nf = getattr(slot, "static_nf", None)
+        if nf is not None:
+            # the fixed-shape NodeFlow of a ring slot is the same set of views every time (~30 us of tensor slicing on
+            # the launch thread per minibatch): hand the same object out again with empty frames
+            nf._node_frames = [None] * nf.num_layers
+            nf.num_seeds = n_seeds
+            return nf
         offs = [0]
         for c in slot.layer_caps:
             offs.append(offs[-1] + c)
@@ -209,6 +217,7 @@ class NeighborSampler:
         nf.padded = True
         nf.num_seeds = n_seeds
         nf._slot = slot
+        slot.static_nf = nf
         return nf
 
     def _finalize(self, slot):

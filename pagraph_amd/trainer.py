@@ -205,10 +205,11 @@ class GraphedTrainer:
         self.cacher, self.sampler, self.labels = cacher, sampler, labels
         self.device = device
         # high priority: the short HBM-bound gather should not queue behind the compute stream's GEMMs
-        self.load_stream = torch.cuda.Stream(device=device, priority=-1)
+        import os as _os
+        self.load_stream = torch.cuda.Stream(device=device, priority=int(_os.environ.get("PG_PRIO_LOAD", -1)))
         # eager warm-up, capture and replay all run on ONE non-default stream, so autograd's
         # AccumulateGrad nodes and the captured graphs agree on the stream
-        self.compute_stream = torch.cuda.Stream(device=device)
+        self.compute_stream = torch.cuda.Stream(device=device, priority=int(_os.environ.get("PG_PRIO_COMPUTE", 0)))
         sampler.consumer_stream = self.compute_stream   # ring slots are recycled after the graph that read them
         sampler.manual_release = True
         cacher.missq_slots = len(sampler.slots)
