@@ -337,7 +337,13 @@ typedef struct pg_row_source {
   const float* staged;    /* device; may be NULL when nothing can miss (full cache) */
   int32_t cache_stride;   /* floats */
   int32_t staged_stride;  /* floats */
+  const int32_t* edge_slots; /* optional, device int32 [edges of the block]: slots[src[e]] per edge, composed beforehand
+                              * (pg_compose_edge_slots, off the consumer's stream): one dependent index load less */
 } pg_row_source_t;
+/* edge_slots[e] = slots[src[e]] for e < n_edges (-2 where src[e] is outside [0, n_src): the unused tail of a
+ * fixed-shape block)                                                                                    */
+int pg_compose_edge_slots(const int32_t* src, int64_t n_edges, const int32_t* slots, int64_t n_src,
+                          int32_t* edge_slots, pg_stream_t stream);
 int pg_spmm_fwd_rows(const int32_t* indptr, const int32_t* src, const pg_row_source_t* rows, int64_t n_dst,
                      int32_t dim, int reduce, float* out, int32_t out_stride, const pg_dropout_t* drop,
                      uint64_t* prof, int32_t prof_ring, pg_stream_t stream);

@@ -43,7 +43,8 @@ class PgMissqField(ctypes.Structure):
 
 
 class PgRowSource(ctypes.Structure):
-    _fields_ = [("slots", vp), ("cache", vp), ("staged", vp), ("cache_stride", c_i32), ("staged_stride", c_i32)]
+    _fields_ = [("slots", vp), ("cache", vp), ("staged", vp), ("cache_stride", c_i32), ("staged_stride", c_i32),
+                ("edge_slots", vp)]
 
 
 class PgDropout(ctypes.Structure):
@@ -100,6 +101,7 @@ _SIGS = {
     "pg_spmm_fwd_drop": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, vp]),
     "pg_spmm_fwd_rows": (ctypes.c_int, [vp, vp, ctypes.POINTER(PgRowSource), c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, vp,
                                         c_i32, vp]),
+    "pg_compose_edge_slots": (ctypes.c_int, [vp, c_i64, vp, c_i64, vp, vp]),
     "pg_spmm_bwd_drop": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, vp]),
     "pg_spmm_bwd_gather": (ctypes.c_int, [vp, vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, c_i32, vp, vp]),
     "pg_linear_fwd": (ctypes.c_int, [vp, c_i32, vp, vp, vp, c_i32, c_i64, c_i32, c_i32, c_i32, vp]),

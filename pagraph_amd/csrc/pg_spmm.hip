@@ -199,10 +199,13 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_drop(const int32_t* __restrict
 // prof (optional): [3 * i], [3 * i + 1] = device wall-clock (100 MHz) when block 0 started / the last blocks
 // finished, [3 * i + 2] = edges aggregated, i = (*drop.step or 0) % prof_ring — a kernel inside a replayed
 // hipGraph cannot carry HIP events.
+constexpr int kRowsBatch = 4;   // source rows whose loads are in flight together per wave
+
 template <bool DROP>
 __global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict__ indptr,
                                                        const int32_t* __restrict__ src,
                                                        const int32_t* __restrict__ slots,
+                                                       const int32_t* __restrict__ edge_slots,
                                                        const float* __restrict__ cache, int32_t cache_stride,
                                                        const float* __restrict__ staged, int32_t staged_stride,
                                                        int64_t n_dst, int32_t dim, int reduce,
@@ -227,32 +230,53 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict
       for (int m = 0; m < kMaxAcc; ++m) acc[m] = S::zero();
       for (int32_t eb = beg; eb < end; eb += kWave) {
         const int ne = end - eb < kWave ? end - eb : kWave;
+        // lane e holds edge e's source position and slot: the index loads of all of the destination's edges are in
+        // flight together (edge_slots: slots[src[e]] composed per edge beforehand — one dependent load less)
         int32_t my_p = 0, my_s = -2;
         if (lane < ne) {
           my_p = src[eb + lane];
-          my_s = slots[my_p];
+          my_s = edge_slots ? edge_slots[eb + lane] : slots[my_p];
         }
-        for (int e = 0; e < ne; ++e) {
-          const int32_t sr = __shfl(my_p, e), sl = __shfl(my_s, e);
-          const float4* hrow = sl >= 0 ? reinterpret_cast<const float4*>(cache + (int64_t)sl * cache_stride)
-                                       : reinterpret_cast<const float4*>(staged + (int64_t)(-sl - 3) * staged_stride);
-          if (sl == -1 || sl == -2) continue;      // padding / an unresolved miss: contributes nothing
-          uint32_t o[4] = {0, 0, 0, 0};
-          int have_q = -1;
+        for (int e0 = 0; e0 < ne; e0 += kRowsBatch) {
+          // the loads of up to kRowsBatch source rows are issued before the first is consumed; the accumulation
+          // below still runs in edge order (bit-identical to one row at a time)
+          float4 x[kRowsBatch][kMaxAcc];
+          int32_t srp[kRowsBatch];
+          bool ok[kRowsBatch];
 #pragma unroll
-          for (int m = 0; m < kMaxAcc; ++m) {
-            const int c = c0 + m * kWave + lane;
-            if (c < pieces) {
-              float4 x = hrow[c];
-              if constexpr (DROP) {
-                const int q = ((c >> 7) << 6) | (c & 63);
-                if (q != have_q) {
-                  Philox::gen((uint32_t)sr, (uint32_t)q, d.tag, step, d.k0, d.k1, o);
-                  have_q = q;
+          for (int j = 0; j < kRowsBatch; ++j) {
+            const int e = e0 + j < ne ? e0 + j : ne - 1;
+            const int32_t sl = __shfl(my_s, e);
+            srp[j] = __shfl(my_p, e);
+            ok[j] = e0 + j < ne && sl != -1 && sl != -2;      // padding / an unresolved miss contributes nothing
+            const float4* hrow = sl >= 0 ? reinterpret_cast<const float4*>(cache + (int64_t)sl * cache_stride)
+                                         : reinterpret_cast<const float4*>(staged + (int64_t)(-sl - 3) * staged_stride);
+#pragma unroll
+            for (int m = 0; m < kMaxAcc; ++m) {
+              const int c = c0 + m * kWave + lane;
+              x[j][m] = (ok[j] && c < pieces) ? hrow[c] : S::zero();
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < kRowsBatch; ++j) {
+            if (!ok[j]) continue;
+            uint32_t o[4] = {0, 0, 0, 0};
+            int have_q = -1;
+#pragma unroll
+            for (int m = 0; m < kMaxAcc; ++m) {
+              const int c = c0 + m * kWave + lane;
+              if (c < pieces) {
+                float4 xv = x[j][m];
+                if constexpr (DROP) {
+                  const int q = ((c >> 7) << 6) | (c & 63);
+                  if (q != have_q) {
+                    Philox::gen((uint32_t)srp[j], (uint32_t)q, d.tag, step, d.k0, d.k1, o);
+                    have_q = q;
+                  }
+                  xv = drop_apply(xv, o, (c >> 6) & 1, d.thr, d.scale);
                 }
-                x = drop_apply(x, o, (c >> 6) & 1, d.thr, d.scale);
+                S::add(acc[m], xv);
               }
-              S::add(acc[m], x);
             }
           }
         }
@@ -271,6 +295,16 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict
   if (pslot && blockIdx.x + 256 >= gridDim.x) {   // the tail of the grid: kernel end = the latest of these
     __syncthreads();
     if (threadIdx.x == 0) atomicMax(pslot + 1, wall_clock64());
+  }
+}
+
+// edge_slots[e] = slots[src[e]] for the block's edges (entries whose source position is out of range: -2)
+__global__ __launch_bounds__(256) void k_compose_edge_slots(const int32_t* __restrict__ src, int64_t n_edges,
+                                                            const int32_t* __restrict__ slots, int64_t n_src,
+                                                            int32_t* __restrict__ edge_slots) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t p = src[e];
+    edge_slots[e] = (p >= 0 && p < n_src) ? slots[p] : -2;
   }
 }
 
@@ -528,12 +562,24 @@ int pg_spmm_fwd_rows(const int32_t* indptr, const int32_t* src, const pg_row_sou
   unsigned long long* pr = reinterpret_cast<unsigned long long*>(prof);
   if (has_drop)
     hipLaunchKernelGGL(k_spmm_fwd_rows<true>, dim3(grid), dim3(256), 0, as_stream(stream), indptr, src, rows->slots,
-                       rows->cache, rows->cache_stride, rows->staged, rows->staged_stride, n_dst, dim, reduce, out,
+                       rows->edge_slots, rows->cache, rows->cache_stride, rows->staged, rows->staged_stride, n_dst, dim, reduce, out,
                        out_stride, d, pr, (int)prof_ring);
   else
     hipLaunchKernelGGL(k_spmm_fwd_rows<false>, dim3(grid), dim3(256), 0, as_stream(stream), indptr, src, rows->slots,
-                       rows->cache, rows->cache_stride, rows->staged, rows->staged_stride, n_dst, dim, reduce, out,
+                       rows->edge_slots, rows->cache, rows->cache_stride, rows->staged, rows->staged_stride, n_dst, dim, reduce, out,
                        out_stride, d, pr, (int)prof_ring);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+int pg_compose_edge_slots(const int32_t* src, int64_t n_edges, const int32_t* slots, int64_t n_src,
+                          int32_t* edge_slots, pg_stream_t stream) {
+  if (n_edges < 0 || n_src < 0) return PG_ERR_INVALID;
+  if (n_edges == 0) return PG_OK;
+  if (!src || !slots || !edge_slots) return PG_ERR_INVALID;
+  int64_t g = ceil_div<int64_t>(n_edges, 256);
+  hipLaunchKernelGGL(k_compose_edge_slots, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, as_stream(stream), src,
+                     n_edges, slots, n_src, edge_slots);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }

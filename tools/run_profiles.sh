@@ -7,29 +7,41 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 R=$PWD
 
-# 1. the headline line + the other bench lines
+# 1. the headline line exactly as the driver runs it, the default (whole-epoch) line, and the other bench lines
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver_invocation.json" 2> "$OUT/bench_driver_invocation.err"
 timeout 600 python bench.py > "$OUT/bench_final.json" 2> "$OUT/bench_final.err"
 timeout 600 python bench.py --model graphsage --skip-opt-hit > "$OUT/bench_graphsage.json" 2>/dev/null
 timeout 600 python bench.py --vertices 232965 --edges 57300000 --feat-size 602 --n-classes 41 --cache-ratio 1.0 \
         --steps 260 --skip-opt-hit > "$OUT/bench_config2_reddit_shape_full_cache.json" 2>/dev/null
+timeout 600 python bench.py --no-fuse-gather --skip-opt-hit --skip-cpu-baseline > "$OUT/bench_unfused_gather.json" 2>/dev/null
 
 # 2. per-kernel time of the same command + the kernel sequence of one replayed step
 ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o b -- \
-      python "$R/bench.py" --skip-cpu-baseline --skip-opt-hit > /tmp/prof_stats.log 2>&1 )
+      python "$R/bench.py" --skip-cpu-baseline --skip-opt-hit --skip-reference-equivalent > /tmp/prof_stats.log 2>&1 )
 cp /tmp/prof_stats/*kernel_stats.csv "$OUT/bench_kernel_stats_final.csv"
 python tools/trace_seq.py /tmp/prof_stats/b_kernel_trace.csv > "$OUT/step_sequence_final.txt"
 
-# 3. HBM bytes per kernel (FETCH_SIZE x2, WRITE_SIZE, KiB): eager loop, zero-copy misses (rocprofv3 --pmc serialises
-#    all kernels; the async queue's spin-wait kernel would sit out its 3 s timeout every step)
+# 3. HBM bytes per kernel (FETCH_SIZE x2, WRITE_SIZE, KiB): eager loop (rocprofv3 --pmc serialises all kernels), async
+#    miss queue with the consumer waiting for the worker on the host (a spin-wait kernel parked on the compute stream
+#    would sit out its timeout under serialisation)
 for c in FETCH_SIZE WRITE_SIZE; do
-  ( cd /tmp && PG_SAMPLER_NO_GRAPH=1 timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- \
-        python "$R/bench.py" --steps 60 --skip-cpu-baseline --skip-opt-hit --skip-microbench --no-graph \
-        --miss-mode zerocopy > /tmp/pmc_$c.log 2>&1 )
+  ( cd /tmp && PG_SAMPLER_NO_GRAPH=1 PG_MISSQ_HOST_WAIT=1 timeout 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- \
+        python "$R/bench.py" --steps 60 --skip-cpu-baseline --skip-opt-hit --skip-microbench --skip-reference-equivalent --no-graph \
+        > /tmp/pmc_$c.log 2>&1 )
 done
 python tools/pmc_summarize.py /tmp/pmc_FETCH_SIZE/p_counter_collection.csv /tmp/pmc_WRITE_SIZE/p_counter_collection.csv \
-       "$OUT/pmc_bench_per_kernel_raw.json" > /dev/null
+       "$OUT/pmc_bench_per_kernel_raw.json" > "$OUT/pmc_bench_per_kernel.txt"
+# the gather micro-benchmark at 1 M rows with a calibration copy (pmc_gather_1M.md of r01)
+for c in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcg_$c -o p -- \
+        python "$R/tools/pmc_gather.py" > /tmp/pmcg_$c.log 2>&1 )
+done
+python tools/pmc_summarize.py /tmp/pmcg_FETCH_SIZE/p_counter_collection.csv /tmp/pmcg_WRITE_SIZE/p_counter_collection.csv \
+       "$OUT/pmc_gather_1M_raw.json" > "$OUT/pmc_gather_1M.txt"
 
 # 4. config 5's graph on one GPU (needs ~250 GB of host memory)
+if [ "${SKIP_SCALE:-0}" != "1" ]; then
 timeout 1200 python bench.py --vertices 100000000 --edges 1000000000 --steps 400 --skip-cpu-baseline --skip-opt-hit \
         > "$OUT/scale_100M_1B_single_gpu.json" 2>/dev/null
+fi
 ls -la "$OUT"
