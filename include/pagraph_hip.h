@@ -406,6 +406,17 @@ int pg_xent_bwd(const float* dlogits, int32_t d_stride, int64_t n, int32_t C, co
  *   scalar = d(objective)/d(loss), NULL = 1), #counted read from *n_valid_dev (pg_gather_labels); labels outside [0, C) other than ignore_index are
  *   not counted. partials: pg_gcn_head_scratch(n_dst, K, C) floats. drop may be NULL. Deterministic.          */
 int64_t pg_gcn_head_scratch(int64_t n_dst, int32_t K, int32_t C);
+/* pg_gcn_head_ex / pg_linear_bwd_w_ex: the same with `sum_partials` = 0 leaving the per-block / per-chunk partial rows
+ * un-summed in `partials` ([rows][C*K + C + 1] resp. [rows][N*K + N], rows = scratch size / row length) for
+ * pg_adam_step_partials; dW / db(_loss) are then not written.                                            */
+int pg_gcn_head_ex(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
+                   const float* W, const float* bias, int32_t C, const int64_t* labels, int64_t ignore_index,
+                   const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
+                   int64_t n_dst, float* logits, float* dagg, float* partials, float* dW, float* db_loss,
+                   int32_t sum_partials, pg_stream_t stream);
+int pg_linear_bwd_w_ex(const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n, int32_t K,
+                       int32_t N, float* dW, float* db, const float* Yout, int32_t yo_stride, int32_t act,
+                       float* dz_scratch, float* partials, int32_t sum_partials, pg_stream_t stream);
 int pg_gcn_head(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
                 const float* W, const float* bias, int32_t C, const int64_t* labels, int64_t ignore_index,
                 const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
@@ -422,6 +433,16 @@ int pg_gcn_head(const int32_t* indptr, const int32_t* src, const float* h, int32
 int pg_adam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                  float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int64_t* step_dev, uint32_t* ticket_dev, pg_stream_t stream);
+/* The same step with the ordered partial sums of pg_linear_bwd_w_ex / pg_gcn_head_ex (sum_partials = 0) folded in:
+ * tensor i's gradient element o = grads[i][o] when partials[i] == NULL, else the sum over part_chunks[i] rows of
+ * partials[i][c * part_len[i] + part_off[i] + o], added in exactly pg_sum_partials' order (bit-identical result) and
+ * stored to grads[i]. is_adam[i] == 0: reduce only (params / exp_avg / exp_avg_sq [i] may be NULL) — pg_gcn_head's
+ * loss scalar. Three launches of the replayed GCN step (two partial sums + Adam) become one.              */
+int pg_adam_step_partials(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                          float* const* exp_avg_sq, const int64_t* numel, const float* const* partials,
+                          const int32_t* part_chunks, const int32_t* part_len, const int32_t* part_off,
+                          const int32_t* is_adam, float lr, float beta1, float beta2, float eps, float weight_decay,
+                          int64_t* step_dev, uint32_t* ticket_dev, pg_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 4. Offline partitioning (host)  —  PaGraph/partition/dg.py:59-103

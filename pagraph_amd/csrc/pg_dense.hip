@@ -329,6 +329,13 @@ int64_t pg_linear_bwd_w_scratch(int64_t n, int32_t K, int32_t N) {
 int pg_linear_bwd_w(const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n, int32_t K,
                     int32_t N, float* dW, float* db, const float* Yout, int32_t yo_stride, int32_t act,
                     float* dz_scratch, float* partials, pg_stream_t stream) {
+  return pg_linear_bwd_w_ex(dY, dy_stride, X, x_stride, n, K, N, dW, db, Yout, yo_stride, act, dz_scratch, partials, 1,
+                            stream);
+}
+
+int pg_linear_bwd_w_ex(const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n, int32_t K,
+                       int32_t N, float* dW, float* db, const float* Yout, int32_t yo_stride, int32_t act,
+                       float* dz_scratch, float* partials, int32_t sum_partials, pg_stream_t stream) {
   if (n < 0 || K <= 0 || N <= 0 || x_stride < K || act < 0 || act > 2 || dy_stride < (act == 2 ? 2 * N : N))
     return PG_ERR_INVALID;
   if (act != 0 && (!Yout || yo_stride < N || !dz_scratch)) return PG_ERR_INVALID;
@@ -350,6 +357,7 @@ int pg_linear_bwd_w(const float* dY, int32_t dy_stride, const float* X, int32_t 
   hipLaunchKernelGGL(k_linear_bwd_w, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), dY, dy_stride, X, x_stride,
                      n, K, N, partials, db ? 1 : 0, rpw, (int32_t)items, (int32_t)chunks);
   PG_LAUNCH_CHECK();
+  if (!sum_partials) return PG_OK;   // the consumer (pg_adam_step_partials) adds the chunks up itself
   const int64_t nk = (int64_t)N * K;
   hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)ceil_div<int64_t>(nk + N, 64)), dim3(256), 0, as_stream(stream),
                      partials, (int32_t)chunks, nk, N, dW, db);

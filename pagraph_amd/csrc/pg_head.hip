@@ -213,6 +213,15 @@ int pg_gcn_head(const int32_t* indptr, const int32_t* src, const float* h, int32
                 const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
                 int64_t n_dst,
                 float* logits, float* dagg, float* partials, float* dW, float* db_loss, pg_stream_t stream) {
+  return pg_gcn_head_ex(indptr, src, h, h_stride, K, W, bias, C, labels, ignore_index, n_valid_dev, grad_scale_dev, drop,
+                        reduce, n_dst, logits, dagg, partials, dW, db_loss, 1, stream);
+}
+
+int pg_gcn_head_ex(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
+                   const float* W, const float* bias, int32_t C, const int64_t* labels, int64_t ignore_index,
+                   const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
+                   int64_t n_dst, float* logits, float* dagg, float* partials, float* dW, float* db_loss,
+                   int32_t sum_partials, pg_stream_t stream) {
   if (n_dst <= 0 || K <= 0 || C <= 0 || h_stride < K) return PG_ERR_INVALID;
   if (K > kHeadMax || C > kHeadMax) return PG_ERR_UNSUPPORTED;
   if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return PG_ERR_INVALID;
@@ -237,6 +246,7 @@ int pg_gcn_head(const int32_t* indptr, const int32_t* src, const float* h, int32
   else PG_HEAD(8);
 #undef PG_HEAD
   PG_LAUNCH_CHECK();
+  if (!sum_partials) return PG_OK;   // pg_adam_step_partials adds the blocks' partials up
   // dW [C*K], then db [C] and the loss (db_loss[C]) contiguous behind it in the partial layout
   return pg_sum_partials(partials, (int32_t)blocks, (int64_t)C * K, C + 1, dW, db_loss, stream);
 }

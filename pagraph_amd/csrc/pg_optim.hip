@@ -63,6 +63,97 @@ __global__ __launch_bounds__(256) void k_adam(const AdamArgs a) {
   }
 }
 
+// The same step with the ordered partial sums of the weight-gradient kernels folded in (k_sum_partials x 2 + k_adam
+// = 3 launches of 8-10 us each in the replayed GCN step -> 1): tensor i's gradient element o is either g[i][o] or
+// the sum over `chunks[i]` partial rows of part[i][c * len[i] + off[i] + o], added in EXACTLY k_sum_partials' order
+// (4 chunk groups x 8 rotating accumulators, pairwise combine) so that the trajectory is bit-identical to the
+// three-launch version; the sum is also written to g[i] (p.grad stays meaningful). adam[i] == 0: reduce only (the
+// loss scalar of pg_gcn_head lives in the same partial rows). Block = 64 elements x 4 chunk groups.
+struct AdamPartArgs {
+  float* p[PG_ADAM_MAX_TENSORS];
+  float* g[PG_ADAM_MAX_TENSORS];
+  float* m[PG_ADAM_MAX_TENSORS];
+  float* v[PG_ADAM_MAX_TENSORS];
+  const float* part[PG_ADAM_MAX_TENSORS];
+  int64_t end[PG_ADAM_MAX_TENSORS];
+  int32_t chunks[PG_ADAM_MAX_TENSORS];
+  int32_t len[PG_ADAM_MAX_TENSORS];
+  int32_t off[PG_ADAM_MAX_TENSORS];
+  int32_t adam[PG_ADAM_MAX_TENSORS];
+  int32_t n_tensors;
+  float lr, beta1, beta2, eps, weight_decay;
+  int64_t* step;
+  uint32_t* ticket;
+};
+
+__global__ __launch_bounds__(256) void k_adam_partials(const AdamPartArgs a) {
+  __shared__ float red[4][64];
+  const int64_t total = a.end[a.n_tensors - 1];
+  const double t = (double)(*a.step + 1);
+  const float bc1 = (float)(1.0 - pow((double)a.beta1, t));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, t));
+  const float step_size = a.lr / bc1;
+  const int tx = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + tx;
+  const bool ok = i < total;
+  float* pp = a.p[0];
+  float* gp = a.g[0];
+  float *mp = a.m[0], *vp = a.v[0];
+  const float* part = a.part[0];
+  int chunks = a.chunks[0], len = a.len[0], off = a.off[0], is_adam = a.adam[0];
+  int64_t base = 0;
+#pragma unroll
+  for (int j = 1; j < PG_ADAM_MAX_TENSORS; ++j) {
+    if (j < a.n_tensors && i >= a.end[j - 1]) {
+      pp = a.p[j]; gp = a.g[j]; mp = a.m[j]; vp = a.v[j];
+      part = a.part[j]; chunks = a.chunks[j]; len = a.len[j]; off = a.off[j]; is_adam = a.adam[j];
+      base = a.end[j - 1];
+    }
+  }
+  const int64_t o = i - base;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (ok && part) {
+    const int per = (chunks + 3) / 4;
+    const int cb = grp * per, ce = (cb + per < chunks) ? cb + per : chunks;
+    const float* col = part + off + o;
+    int c = cb;
+    for (; c + 7 < ce; c += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += col[(int64_t)(c + u) * len];
+    }
+    for (; c < ce; ++c) acc[0] += col[(int64_t)c * len];
+  }
+  red[grp][tx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (grp == 0 && ok) {
+    float g;
+    if (part) {
+      g = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+      gp[o] = g;
+    } else {
+      g = gp[o];
+    }
+    if (is_adam) {
+      const float p = pp[o];
+      if (a.weight_decay != 0.f) g += a.weight_decay * p;
+      const float m = a.beta1 * mp[o] + (1.f - a.beta1) * g;
+      const float v = a.beta2 * vp[o] + (1.f - a.beta2) * g * g;
+      mp[o] = m;
+      vp[o] = v;
+      const float denom = sqrtf(v) / bc2_sqrt + a.eps;
+      pp[o] = p - step_size * (m / denom);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t done = atomicAdd(a.ticket, 1u) + 1;
+    if (done == gridDim.x) {
+      *a.step += 1;
+      *a.ticket = 0;
+    }
+  }
+}
+
 }  // namespace pg
 
 using namespace pg;
@@ -87,6 +178,35 @@ extern "C" int pg_adam_step(int32_t n_tensors, float* const* params, const float
   a.step = step_dev; a.ticket = ticket_dev;
   int64_t g = ceil_div<int64_t>(tot, 256);
   hipLaunchKernelGGL(k_adam, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, as_stream(stream), a);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+extern "C" int pg_adam_step_partials(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                                     float* const* exp_avg_sq, const int64_t* numel, const float* const* partials,
+                                     const int32_t* part_chunks, const int32_t* part_len, const int32_t* part_off,
+                                     const int32_t* is_adam, float lr, float beta1, float beta2, float eps,
+                                     float weight_decay, int64_t* step_dev, uint32_t* ticket_dev, pg_stream_t stream) {
+  if (n_tensors <= 0 || n_tensors > PG_ADAM_MAX_TENSORS || !params || !grads || !exp_avg || !exp_avg_sq || !numel ||
+      !partials || !part_chunks || !part_len || !part_off || !is_adam || !step_dev || !ticket_dev)
+    return PG_ERR_INVALID;
+  AdamPartArgs a{};
+  int64_t tot = 0;
+  for (int i = 0; i < n_tensors; ++i) {
+    if (!grads[i] || numel[i] <= 0) return PG_ERR_INVALID;
+    if (is_adam[i] && (!params[i] || !exp_avg[i] || !exp_avg_sq[i])) return PG_ERR_INVALID;
+    if (partials[i] && (part_chunks[i] <= 0 || part_off[i] < 0 || (int64_t)part_off[i] + numel[i] > part_len[i]))
+      return PG_ERR_INVALID;
+    a.p[i] = params[i]; a.g[i] = grads[i]; a.m[i] = exp_avg[i]; a.v[i] = exp_avg_sq[i];
+    a.part[i] = partials[i]; a.chunks[i] = part_chunks[i]; a.len[i] = part_len[i]; a.off[i] = part_off[i];
+    a.adam[i] = is_adam[i];
+    tot += numel[i];
+    a.end[i] = tot;
+  }
+  a.n_tensors = n_tensors;
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+  a.step = step_dev; a.ticket = ticket_dev;
+  hipLaunchKernelGGL(k_adam_partials, dim3((unsigned)ceil_div<int64_t>(tot, 64)), dim3(256), 0, as_stream(stream), a);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }

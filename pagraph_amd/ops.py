@@ -150,6 +150,41 @@ def block_aggregate(indptr, src, h, n_dst, reduce="mean", dropout=None, transpos
 ACT_NONE, ACT_RELU, ACT_CONCAT = 0, 1, 2
 
 
+class DeferredPartials:
+    """While one of these is active (`with ops.defer_partials() as reg:`), the weight-gradient kernels leave their
+    per-chunk partial rows un-summed and register them here, keyed by the parameter's storage; the optimiser
+    (pagraph_amd.optim.Adam.step(deferred=reg)) adds them up — in pg_sum_partials' exact order — inside its own single
+    launch (pg_adam_step_partials). Two k_sum_partials launches of the replayed GCN step disappear. Only valid when
+    every parameter receives exactly ONE gradient contribution per step and nothing reads the gradients (or the fused
+    head's loss value) before the optimiser has run."""
+
+    def __init__(self):
+        self.by_param = {}     # parameter data_ptr -> (partials tensor, chunks, row length, offset, numel)
+        self.extra = []        # reduce-only outputs: (destination tensor, partials, chunks, row length, offset)
+        self.conflict = False
+
+    def add(self, param, part, chunks, rowlen, off):
+        if param.data_ptr() in self.by_param:
+            self.conflict = True            # a second contribution to the same parameter: cannot be deferred
+        self.by_param[param.data_ptr()] = (part, int(chunks), int(rowlen), int(off), param.numel())
+
+
+_DEFER = None
+
+
+class defer_partials:
+    def __enter__(self):
+        global _DEFER
+        self.prev = _DEFER
+        _DEFER = DeferredPartials()
+        return _DEFER
+
+    def __exit__(self, *exc):
+        global _DEFER
+        _DEFER = self.prev
+        return False
+
+
 def _apply_act(z, act):
     if act == ACT_RELU:
         return torch.relu(z)
@@ -179,6 +214,7 @@ class _SkinnyLinear(torch.autograd.Function):
             y = _apply_act(torch.nn.functional.linear(x, weight, bias), act)
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
         ctx.act = act
         return y
 
@@ -197,10 +233,16 @@ class _SkinnyLinear(torch.autograd.Function):
             gw = buf[:N * K].view(N, K)
             gb = buf[N * K:] if ctx.has_bias else None
             dz = torch.empty((x.size(0), N), dtype=torch.float32, device=x.device) if act != ACT_NONE else None
+            defer = _DEFER is not None and ctx.has_bias
             with torch.cuda.device(x.device):
-                L.check(lib.pg_linear_bwd_w(L.ptr(gy), gy.stride(0), L.ptr(x), x.stride(0), x.size(0), K, N,
-                                            L.ptr(gw), L.ptr(gb), L.ptr(y), y.stride(0) if y is not None else 0, act,
-                                            L.ptr(dz), L.ptr(part), L.stream_ptr()), "pg_linear_bwd_w")
+                L.check(lib.pg_linear_bwd_w_ex(L.ptr(gy), gy.stride(0), L.ptr(x), x.stride(0), x.size(0), K, N,
+                                               L.ptr(gw), L.ptr(gb), L.ptr(y), y.stride(0) if y is not None else 0, act,
+                                               L.ptr(dz), L.ptr(part), 0 if defer else 1, L.stream_ptr()),
+                        "pg_linear_bwd_w")
+            if defer:
+                rowlen = N * K + N
+                _DEFER.add(weight, part, part.numel() // rowlen, rowlen, 0)
+                _DEFER.add(ctx.bias_ref, part, part.numel() // rowlen, rowlen, N * K)
             if dz is not None:
                 gz = dz
         if ctx.needs_input_grad[0]:
@@ -364,11 +406,20 @@ class _GCNHead(torch.autograd.Function):
         logits = torch.empty((n_dst, C), dtype=torch.float32, device=h.device) if want_logits else None
         part = torch.empty(lib.pg_gcn_head_scratch(n_dst, K, C), dtype=torch.float32, device=h.device)
         d = drop.struct() if drop is not None and drop.threshold else None
+        # deferral needs the registered gradient seed (the gradients leave the kernel already scaled) and a bias
+        defer = _DEFER is not None and bias is not None and grad_seed is not None
         with torch.cuda.device(h.device):
-            L.check(lib.pg_gcn_head(L.ptr(indptr), L.ptr(src), L.ptr(h), h.stride(0), K, L.ptr(weight), L.ptr(bias), C,
-                                    L.ptr(labels), int(ignore_index), L.ptr(n_valid), L.ptr(grad_seed),
-                                    ctypes.byref(d) if d is not None else None, _REDUCE[reduce], n_dst, L.ptr(logits),
-                                    L.ptr(dagg), L.ptr(part), L.ptr(gw), L.ptr(gbl), L.stream_ptr()), "pg_gcn_head")
+            L.check(lib.pg_gcn_head_ex(L.ptr(indptr), L.ptr(src), L.ptr(h), h.stride(0), K, L.ptr(weight), L.ptr(bias), C,
+                                       L.ptr(labels), int(ignore_index), L.ptr(n_valid), L.ptr(grad_seed),
+                                       ctypes.byref(d) if d is not None else None, _REDUCE[reduce], n_dst, L.ptr(logits),
+                                       L.ptr(dagg), L.ptr(part), L.ptr(gw), L.ptr(gbl), 0 if defer else 1, L.stream_ptr()),
+                    "pg_gcn_head")
+        if defer:
+            rowlen = C * K + C + 1
+            chunks = part.numel() // rowlen
+            _DEFER.add(weight, part, chunks, rowlen, 0)
+            _DEFER.add(bias, part, chunks, rowlen, C * K)
+            _DEFER.extra.append((gbl[C:C + 1], part, chunks, rowlen, C * K + C))     # the loss value
         use_t = tptr is not None and tptr.numel() == h.size(0) + 1
         ctx.save_for_backward(indptr, src, dagg, gw, gbl, grad_seed, *((tptr, tdst, heavy) if use_t else ()))
         ctx.use_t, ctx.n_src, ctx.reduce, ctx.drop = use_t, h.size(0), reduce, (drop if d is not None else None)

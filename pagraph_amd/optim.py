@@ -26,7 +26,13 @@ class Adam(torch.optim.Optimizer):
         return st
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, deferred=None):
+        """deferred: an ops.DeferredPartials registry — gradients whose per-chunk partial rows were left un-summed by
+        the weight-gradient kernels are added up (pg_sum_partials' order) inside this step's single launch"""
+        if deferred is not None and not deferred.conflict and (deferred.by_param or deferred.extra):
+            return self._step_deferred(deferred)
+        if deferred is not None and deferred.conflict:
+            raise L.PgError("deferred partial sums: a parameter received two gradient contributions in one step")
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -64,3 +70,49 @@ class Adam(torch.optim.Optimizer):
                                                    float(group['weight_decay']), L.ptr(sd), L.ptr(ticket),
                                                    L.stream_ptr()), "pg_adam_step")
         return loss
+
+    @torch.no_grad()
+    def _step_deferred(self, reg):
+        groups = [g for g in self.param_groups if any(p.grad is not None for p in g['params'])]
+        if len(groups) != 1:
+            raise L.PgError("deferred partial sums need exactly one parameter group")
+        group = groups[0]
+        gi = self.param_groups.index(group)
+        ps = [p for p in group['params'] if p.grad is not None]
+        dev = ps[0].device
+        step_dev, ticket = self._group_state(gi, dev)
+        for p in ps:
+            st = self.state[p]
+            if not st:
+                st['step'] = step_dev
+                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                raise L.PgError("pagraph_amd.optim.Adam needs contiguous fp32 parameters and gradients")
+        n = len(ps) + len(reg.extra)
+        if n > L.PG_ADAM_MAX_TENSORS:
+            raise L.PgError("too many tensors for one pg_adam_step_partials launch")
+        vp, i32 = ctypes.c_void_p, ctypes.c_int32
+        P, G, M, V, PT = (vp * n)(), (vp * n)(), (vp * n)(), (vp * n)(), (vp * n)()
+        numel = (ctypes.c_int64 * n)()
+        chunks, rowlen, off, adam = (i32 * n)(), (i32 * n)(), (i32 * n)(), (i32 * n)()
+        for k, p in enumerate(ps):
+            P[k], G[k] = p.data_ptr(), p.grad.data_ptr()
+            M[k], V[k] = self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr()
+            numel[k], adam[k] = p.numel(), 1
+            e = reg.by_param.get(p.data_ptr())
+            if e is not None:
+                if e[4] != p.numel():
+                    raise L.PgError("deferred partial sums: registered size differs from the parameter's")
+                PT[k], chunks[k], rowlen[k], off[k] = e[0].data_ptr(), e[1], e[2], e[3]
+        for j, (dst, part, ch, rl, of) in enumerate(reg.extra):
+            k = len(ps) + j
+            G[k], PT[k], numel[k] = dst.data_ptr(), part.data_ptr(), dst.numel()
+            chunks[k], rowlen[k], off[k], adam[k] = ch, rl, of, 0
+        b1, b2 = group['betas']
+        with torch.cuda.device(dev):
+            L.check(self._lib.pg_adam_step_partials(n, P, G, M, V, numel, PT, chunks, rowlen, off, adam, float(group['lr']),
+                                                    float(b1), float(b2), float(group['eps']),
+                                                    float(group['weight_decay']), L.ptr(step_dev), L.ptr(ticket),
+                                                    L.stream_ptr()), "pg_adam_step_partials")
+        return None

@@ -181,6 +181,10 @@ class GraphedTrainer:
         # layer-0 features are aggregated straight from the cache (never materialised) when the model says it only
         # aggregates them (model.virtual_inputs) and `need` is given — SURVEY 8f-2
         self.fuse_gather = True
+        # the two ordered partial sums of the weight-gradient kernels ride in the optimiser's launch (ops.defer_partials)
+        # when the model says every parameter gets ONE gradient contribution per step (GCN; not GraphSAGE, whose
+        # NodeUpdate is applied to several blocks) and the optimiser is pagraph_amd.optim.Adam on one GPU
+        self.fuse_partials = True
         self.world = int(world_size)
         self.pg = process_group
         self.flat = None
@@ -341,6 +345,32 @@ class GraphedTrainer:
             self.optimizer.step()
         return loss
 
+    def _can_defer_partials(self):
+        from .optim import Adam
+        m = self._bare_model()
+        return (self.fuse_partials and self.world == 1 and isinstance(self.optimizer, Adam)
+                and getattr(m, "single_use_parameters", False) and len(self.optimizer.param_groups) == 1)
+
+    def _step_body_deferred(self, s):
+        """_step_body for one GPU with the partial sums folded into the optimiser's launch"""
+        with ops.defer_partials() as reg:
+            rs = s.plan.row_sources if s.plan else {}
+            for i in range(s.nf.num_layers):
+                o0, o1 = s.nf._layer_offsets[i], s.nf._layer_offsets[i + 1]
+                s.nf._node_frames[i] = {n: (rs[(i, n)] if (i, n) in rs else t[o0:o1]) for n, t in s.out.items()
+                                        if self.need is None or n in self.need.get(i, ())}
+            if self._gseed is None:
+                self._gseed = torch.full((), 1.0, dtype=torch.float32, device=self.device)
+            loss = None
+            if self.fuse_head and isinstance(self.loss_fcn, ops.CrossEntropyLoss) and hasattr(self.model, 'forward_loss'):
+                loss = self.model.forward_loss(s.nf, s.label, s.n_valid, self._gseed, self.loss_fcn.ignore_index)
+            if loss is None:
+                pred = self.model(s.nf)
+                loss = self.loss_fcn(pred, s.label)
+            loss.backward(self._gseed)
+        self.optimizer.step(deferred=reg)
+        return loss
+
     def _probe_graph_allreduce(self):
         """Can this process group's all-reduce live inside a captured graph? RCCL's can (as NCCL's); gloo's cannot.
         Every rank captures a tiny all-reduce; the ranks AGREE (eager MIN) that all captures succeeded before
@@ -430,7 +460,7 @@ class GraphedTrainer:
                 elif warm:
                     if self.world == 1:
                         self.optimizer.zero_grad(set_to_none=True)
-                    s.loss = self._step_body(s).detach()
+                    s.loss = (self._step_body_deferred(s) if self._can_defer_partials() else self._step_body(s)).detach()
                 else:
                     if self.world > 1 and self.allreduce_in_graph is None:
                         self.allreduce_in_graph = self._probe_graph_allreduce()
@@ -439,7 +469,7 @@ class GraphedTrainer:
                         self.optimizer.zero_grad(set_to_none=True)
                     # thread_local: RCCL's watchdog thread may touch the runtime while this thread captures
                     with torch.cuda.graph(g, stream=main, capture_error_mode="thread_local"):
-                        s.loss = self._step_body(s).detach()
+                        s.loss = (self._step_body_deferred(s) if self._can_defer_partials() else self._step_body(s)).detach()
                     s.graph = g
                     s.graph_epoch = self.cacher._cache_epoch
                     s.graph_synced = synced = bool(self.allreduce_in_graph)

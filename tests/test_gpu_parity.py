@@ -1624,3 +1624,55 @@ def test_eval_and_count_vnum_scripts(dev, hiplib, oracle, tmp_path):
     r = run(os.path.join("examples", "count_vnum.py"), "--dataset", str(ds), "--n-epochs", "1", "--batch-size", "500")
     assert r.returncode == 0, r.stderr[-2000:]
     assert int(r.stdout.split("Epoch loaded vertex#:")[1].split()[0]) > len(np.nonzero(data.get_masks(str(ds))[0])[0])
+
+
+def test_adam_with_deferred_partial_sums_is_bit_identical(dev, hiplib):
+    """ops.defer_partials + Adam.step(deferred=...) (pg_adam_step_partials: the two ordered partial sums of the replayed
+    GCN step folded into the optimiser's launch) == the three-launch path, bit for bit, over several steps: parameters,
+    Adam state, gradients left in p.grad, and the fused head's loss value"""
+    import torch.nn.functional as Fn
+    from pagraph_amd import ops
+    from pagraph_amd.model import GCNSampling
+    from pagraph_amd.optim import Adam
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    rng = np.random.default_rng(21)
+    V, Fd, C, B = 6000, 600, 60, 3000
+    g = DeviceGraph(_rand_csc(rng, V, 60000))
+    feats = torch.from_numpy(rng.random((V, Fd), dtype=np.float32)).to(dev)
+    labels_all = torch.from_numpy(rng.integers(0, C, V)).to(dev)
+    smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=False, num_hops=2, seed_nodes=np.arange(0, V, 2), seed=2)
+    nfs = [nf for _, nf in zip(range(3), smp)]
+    runs = []
+    for deferred in (False, True):
+        torch.manual_seed(3)
+        model = GCNSampling(Fd, 32, C, 1, Fn.relu, 0.2).to(dev).train()
+        opt = Adam(model.parameters(), lr=3e-2)
+        seed = torch.ones((), device=dev)
+        losses = []
+        for it, nf in enumerate(nfs):
+            ids = nf._node_mapping.tousertensor()
+            o = nf._layer_offsets
+            for i in range(nf.num_layers):
+                nf._node_frames[i] = {"features": feats[ids[o[i]:o[i + 1]]]} if i == 0 else {}
+            lab = labels_all[ids[o[-2]:o[-1]]].contiguous()
+            n_valid = torch.tensor([lab.numel()], dtype=torch.int32, device=dev)
+            model._drop_step.fill_(10 + it)
+            opt.zero_grad(set_to_none=True)
+            if deferred:
+                with ops.defer_partials() as reg:
+                    loss = model.forward_loss(nf, lab, n_valid, seed)
+                    loss.backward(seed)
+                assert len(reg.by_param) == 4 and len(reg.extra) == 1 and not reg.conflict
+                opt.step(deferred=reg)
+            else:
+                loss = model.forward_loss(nf, lab, n_valid, seed)
+                loss.backward(seed)
+                opt.step()
+            torch.cuda.synchronize()
+            losses.append(loss.detach().clone())
+        runs.append((losses, [p.detach().clone() for p in model.parameters()], [p.grad.clone() for p in model.parameters()],
+                     [opt.state[p]['exp_avg_sq'].clone() for p in model.parameters()]))
+    for a, b in zip(runs[0], runs[1]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert all(torch.isfinite(l) for l in runs[0][0])
