@@ -694,7 +694,9 @@ def run():
         # events cannot be attached to one kernel: it stamps the device wall clock (100 MHz) at its start and end
         # into ring entry (dropout step % ring); entries [drop_step0+1, drop_step1] are the timed steps
         ring = cacher.rows_prof[0].view(-1, 3)
-        idx = torch.arange(drop_step0 + 1, drop_step1 + 1, device=dev) % PROF_RING
+        # (when the optimiser's launch advances the counter it holds the value the NEXT forward uses: shift by one)
+        shift = 0 if getattr(model, "_drop_step_external", False) else 1
+        idx = torch.arange(drop_step0 + shift, drop_step1 + shift, device=dev) % PROF_RING
         st = ring[idx].cpu().numpy().astype(np.int64)
         st = st[(st[:, 1] > st[:, 0]) & (st[:, 0] > 0)]
         if len(st):

@@ -437,12 +437,14 @@ int pg_adam_step(int32_t n_tensors, float* const* params, const float* const* gr
  * tensor i's gradient element o = grads[i][o] when partials[i] == NULL, else the sum over part_chunks[i] rows of
  * partials[i][c * part_len[i] + part_off[i] + o], added in exactly pg_sum_partials' order (bit-identical result) and
  * stored to grads[i]. is_adam[i] == 0: reduce only (params / exp_avg / exp_avg_sq [i] may be NULL) — pg_gcn_head's
- * loss scalar. Three launches of the replayed GCN step (two partial sums + Adam) become one.              */
+ * loss scalar. Three launches of the replayed GCN step (two partial sums + Adam) become one. bump_dev (device
+ * int64, may be NULL) is advanced by one together with *step_dev: the model's dropout step counter, which saves the
+ * step's separate counter-increment launch.                                                             */
 int pg_adam_step_partials(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                           float* const* exp_avg_sq, const int64_t* numel, const float* const* partials,
                           const int32_t* part_chunks, const int32_t* part_len, const int32_t* part_off,
                           const int32_t* is_adam, float lr, float beta1, float beta2, float eps, float weight_decay,
-                          int64_t* step_dev, uint32_t* ticket_dev, pg_stream_t stream);
+                          int64_t* step_dev, uint32_t* ticket_dev, int64_t* bump_dev, pg_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 4. Offline partitioning (host)  —  PaGraph/partition/dg.py:59-103

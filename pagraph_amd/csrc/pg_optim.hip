@@ -84,6 +84,7 @@ struct AdamPartArgs {
   float lr, beta1, beta2, eps, weight_decay;
   int64_t* step;
   uint32_t* ticket;
+  int64_t* bump;                        // optional: one more device counter advanced with the step (the model's dropout step)
 };
 
 __global__ __launch_bounds__(256) void k_adam_partials(const AdamPartArgs a) {
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(256) void k_adam_partials(const AdamPartArgs a) {
     if (done == gridDim.x) {
       *a.step += 1;
       *a.ticket = 0;
+      if (a.bump) *a.bump += 1;
     }
   }
 }
@@ -186,7 +188,8 @@ extern "C" int pg_adam_step_partials(int32_t n_tensors, float* const* params, fl
                                      float* const* exp_avg_sq, const int64_t* numel, const float* const* partials,
                                      const int32_t* part_chunks, const int32_t* part_len, const int32_t* part_off,
                                      const int32_t* is_adam, float lr, float beta1, float beta2, float eps,
-                                     float weight_decay, int64_t* step_dev, uint32_t* ticket_dev, pg_stream_t stream) {
+                                     float weight_decay, int64_t* step_dev, uint32_t* ticket_dev, int64_t* bump_dev,
+                                     pg_stream_t stream) {
   if (n_tensors <= 0 || n_tensors > PG_ADAM_MAX_TENSORS || !params || !grads || !exp_avg || !exp_avg_sq || !numel ||
       !partials || !part_chunks || !part_len || !part_off || !is_adam || !step_dev || !ticket_dev)
     return PG_ERR_INVALID;
@@ -205,7 +208,7 @@ extern "C" int pg_adam_step_partials(int32_t n_tensors, float* const* params, fl
   }
   a.n_tensors = n_tensors;
   a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
-  a.step = step_dev; a.ticket = ticket_dev;
+  a.step = step_dev; a.ticket = ticket_dev; a.bump = bump_dev;
   hipLaunchKernelGGL(k_adam_partials, dim3((unsigned)ceil_div<int64_t>(tot, 64)), dim3(256), 0, as_stream(stream), a);
   PG_LAUNCH_CHECK();
   return PG_OK;

@@ -440,11 +440,23 @@ __global__ __launch_bounds__(kHeavyThreads) void k_spmm_bwd_heavy(const int32_t*
         }
         __syncthreads();
         if (c < pieces) {
-#pragma unroll 4
-          for (int k = el; k < n; k += n_el) {
-            V g = reinterpret_cast<const V*>(go + (int64_t)s_v[k] * go_stride)[c];
-            if (reduce == PG_REDUCE_MEAN) S::div(g, s_w[k]);
-            S::add(acc, g);
+          // 16 rows' loads in flight per lane, then added in the same (ascending k) order as a plain loop: a hub's
+          // few hundred edges cost one or two memory round trips per lane instead of one per four edges
+          for (int k0 = el; k0 < n; k0 += 16 * n_el) {
+            V g[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+              const int k = k0 + u * n_el;
+              g[u] = k < n ? reinterpret_cast<const V*>(go + (int64_t)s_v[k] * go_stride)[c] : S::zero();
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+              const int k = k0 + u * n_el;
+              if (k < n) {
+                if (reduce == PG_REDUCE_MEAN) S::div(g[u], s_w[k]);
+                S::add(acc, g[u]);
+              }
+            }
           }
         }
       }

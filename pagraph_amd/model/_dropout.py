@@ -17,10 +17,20 @@ class FusedDropoutMixin:
         self.register_buffer('_drop_step', torch.zeros(1, dtype=torch.int64), persistent=False)
         self._drop_seed = None
         self.fuse_dropout = True
+        # True: somebody else advances _drop_step once per training step (GraphedTrainer lets the optimiser's launch do
+        # it: one kernel less per replayed step). The counter then holds the value the NEXT forward uses.
+        self._drop_step_external = False
 
     def _bump_drop_step(self):
-        if self.training and self._drop_step.is_cuda:
+        if self.training and self._drop_step.is_cuda and not self._drop_step_external:
             self._drop_step.add_(1)
+
+    def externalise_drop_step(self):
+        """hand the once-per-step increment over to the caller; the sequence of values the forwards see stays 1, 2, ..."""
+        if not self._drop_step_external:
+            self._drop_step_external = True
+            self._drop_step.add_(1)
+        return self._drop_step
 
     def _drop_spec(self, layer, h):
         """DropoutSpec for aggregating `h` as the input of block `layer`, or None (use nn.Dropout)"""

@@ -26,11 +26,11 @@ class Adam(torch.optim.Optimizer):
         return st
 
     @torch.no_grad()
-    def step(self, closure=None, deferred=None):
+    def step(self, closure=None, deferred=None, bump=None):
         """deferred: an ops.DeferredPartials registry — gradients whose per-chunk partial rows were left un-summed by
         the weight-gradient kernels are added up (pg_sum_partials' order) inside this step's single launch"""
         if deferred is not None and not deferred.conflict and (deferred.by_param or deferred.extra):
-            return self._step_deferred(deferred)
+            return self._step_deferred(deferred, bump)
         if deferred is not None and deferred.conflict:
             raise L.PgError("deferred partial sums: a parameter received two gradient contributions in one step")
         loss = None
@@ -72,7 +72,8 @@ class Adam(torch.optim.Optimizer):
         return loss
 
     @torch.no_grad()
-    def _step_deferred(self, reg):
+    def _step_deferred(self, reg, bump=None):
+        """bump: optional device int64[1] advanced by the same launch (the model's dropout step counter)"""
         groups = [g for g in self.param_groups if any(p.grad is not None for p in g['params'])]
         if len(groups) != 1:
             raise L.PgError("deferred partial sums need exactly one parameter group")
@@ -114,5 +115,5 @@ class Adam(torch.optim.Optimizer):
             L.check(self._lib.pg_adam_step_partials(n, P, G, M, V, numel, PT, chunks, rowlen, off, adam, float(group['lr']),
                                                     float(b1), float(b2), float(group['eps']),
                                                     float(group['weight_decay']), L.ptr(step_dev), L.ptr(ticket),
-                                                    L.stream_ptr()), "pg_adam_step_partials")
+                                                    L.ptr(bump), L.stream_ptr()), "pg_adam_step_partials")
         return None

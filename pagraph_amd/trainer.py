@@ -352,7 +352,10 @@ class GraphedTrainer:
                 and getattr(m, "single_use_parameters", False) and len(self.optimizer.param_groups) == 1)
 
     def _step_body_deferred(self, s):
-        """_step_body for one GPU with the partial sums folded into the optimiser's launch"""
+        """_step_body for one GPU with the partial sums (and the dropout step counter's increment) folded into the
+        optimiser's launch"""
+        m = self._bare_model()
+        bump = m.externalise_drop_step() if (m.training and hasattr(m, "externalise_drop_step")) else None
         with ops.defer_partials() as reg:
             rs = s.plan.row_sources if s.plan else {}
             for i in range(s.nf.num_layers):
@@ -368,7 +371,7 @@ class GraphedTrainer:
                 pred = self.model(s.nf)
                 loss = self.loss_fcn(pred, s.label)
             loss.backward(self._gseed)
-        self.optimizer.step(deferred=reg)
+        self.optimizer.step(deferred=reg, bump=bump)
         return loss
 
     def _probe_graph_allreduce(self):
