@@ -529,7 +529,16 @@ int pg_missq_create(int device, int n_slots, int64_t max_rows, const pg_missq_fi
   q->device = device; q->n_slots = n_slots; q->n_fields = n_fields; q->max_rows = max_rows;
   for (int f = 0; f < n_fields; ++f) q->fields[f] = fields[f];
   q->slots.resize(n_slots);
-  bool ok = hipStreamCreateWithFlags(&q->copy_stream, hipStreamNonBlocking) == hipSuccess;
+  // The consumer (compute) stream may have a spin-wait kernel parked on it until this stream's k_signal has run. HIP
+  // multiplexes streams of ONE priority class onto a few hardware queues, and a kernel behind a spinning kernel in the
+  // same hardware queue never starts: with every stream at normal priority the pipeline deadlocked until the 3 s
+  // time-out (measured: PG_PRIO_LOAD=0 PG_PRIO_SAMPLER=0). The copy stream therefore lives in the HIGH priority class,
+  // whose hardware queues are separate from those of the normal-priority compute stream. (PG_PRIO_COPY overrides.)
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  const char* pe = getenv("PG_PRIO_COPY");
+  const int prio = pe ? atoi(pe) : prio_hi;
+  bool ok = hipStreamCreateWithPriority(&q->copy_stream, hipStreamNonBlocking, prio) == hipSuccess;
   ok = ok && hipMalloc((void**)&q->timeout_d, 64) == hipSuccess && hipMemset(q->timeout_d, 0, 64) == hipSuccess;
   for (auto& s : q->slots) {
     ok = ok && hipHostMalloc((void**)&s.fullid_h, max_rows * 8, hipHostMallocDefault) == hipSuccess;

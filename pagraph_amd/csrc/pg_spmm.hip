@@ -348,6 +348,14 @@ __global__ __launch_bounds__(256) void k_spmm_bwd_drop(const int32_t* __restrict
 //   grad_h[s, :] = mask(s, :) * scale * sum_{t in [tptr[s], tptr[s+1])} grad_out[tdst[t], :] / deg(tdst[t])
 // Every row of grad_h is written (no zero fill), nothing is atomic (the scatter form manages ~30 G fp32
 // atomics/s: 26 us for the 12K-edge output block) and the sum runs in ascending destination order.
+template <int VEC, bool DROP, int T>
+__device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, int32_t heavy_cap,
+                                           const int32_t* __restrict__ tptr, const int32_t* __restrict__ tdst,
+                                           const int32_t* __restrict__ indptr, const float* __restrict__ go,
+                                           int32_t go_stride, int32_t dim, int reduce, float* __restrict__ gh,
+                                           int32_t gh_stride, int lpr_log2, DropArgs d, int first, int stride);
+
+// (blocks >= n_row_blocks of the launch are the hub blocks: heavy_rows below)
 template <int VEC, bool DROP>
 __global__ __launch_bounds__(256) void k_spmm_bwd_gather(const int32_t* __restrict__ tptr,
                                                          const int32_t* __restrict__ tdst,
@@ -355,9 +363,15 @@ __global__ __launch_bounds__(256) void k_spmm_bwd_gather(const int32_t* __restri
                                                          const float* __restrict__ go, int32_t go_stride,
                                                          int64_t n_src, int32_t dim, int reduce,
                                                          float* __restrict__ gh, int32_t gh_stride, int lpr_log2,
-                                                         int skip_heavy, DropArgs d) {
+                                                         int skip_heavy, DropArgs d, const int32_t* __restrict__ heavy,
+                                                         int32_t heavy_cap, int32_t n_row_blocks) {
   using S = SV<VEC>;
   using V = typename S::type;
+  if ((int)blockIdx.x >= n_row_blocks) {
+    heavy_rows<VEC, DROP, 256>(heavy, heavy_cap, tptr, tdst, indptr, go, go_stride, dim, reduce, gh, gh_stride, lpr_log2, d,
+                               (int)blockIdx.x - n_row_blocks, (int)gridDim.x - n_row_blocks);
+    return;
+  }
   const int lpr = 1 << lpr_log2;
   const int lane = threadIdx.x & (kWave - 1);
   const int gl = lane & (lpr - 1);
@@ -398,25 +412,24 @@ __global__ __launch_bounds__(256) void k_spmm_bwd_gather(const int32_t* __restri
   }
 }
 
-// hubs (sources with more than PG_HEAVY_ROW edges, listed by the sampler): a 1024-thread block per hub.
-// Per chunk of 1024 edges: (destination, degree) staged in LDS with coalesced loads, then 1024 / lpr edge
-// lanes accumulate strided edges — independent loads, so the few hundred edges of a hub cost a handful of
-// memory round trips instead of one per edge — and the partial sums are combined through LDS in lane order
-// (deterministic).
-constexpr int kHeavyThreads = 1024;
+// hubs (sources with more than PG_HEAVY_ROW edges, listed by the sampler): a whole block per hub.
+// Per chunk of T edges: (destination, degree) staged in LDS with coalesced loads, then T / lpr edge lanes accumulate
+// strided edges — independent loads, 16 in flight per lane — and the partial sums are combined through LDS in lane
+// order (deterministic). Runs as EXTRA BLOCKS of the k_spmm_bwd_gather launch (T = 256): two hub rows used to cost a
+// launch of their own, 13-14 us of dependent latencies on the replayed step's critical path.
+template <int VEC, bool DROP, int T>
+__device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, int32_t heavy_cap,
+                                           const int32_t* __restrict__ tptr, const int32_t* __restrict__ tdst,
+                                           const int32_t* __restrict__ indptr, const float* __restrict__ go,
+                                           int32_t go_stride, int32_t dim, int reduce, float* __restrict__ gh,
+                                           int32_t gh_stride, int lpr_log2, DropArgs d, int first, int stride) {
+  constexpr int kHeavyThreads = T;
 
-template <int VEC, bool DROP>
-__global__ __launch_bounds__(kHeavyThreads) void k_spmm_bwd_heavy(const int32_t* __restrict__ heavy, int32_t heavy_cap,
-                                                                  const int32_t* __restrict__ tptr,
-                                                                  const int32_t* __restrict__ tdst,
-                                                                  const int32_t* __restrict__ indptr,
-                                                                  const float* __restrict__ go, int32_t go_stride,
-                                                                  int32_t dim, int reduce, float* __restrict__ gh,
-                                                                  int32_t gh_stride, int lpr_log2, DropArgs d) {
   using S = SV<VEC>;
   using V = typename S::type;
-  __shared__ int32_t s_v[kHeavyThreads];
-  __shared__ float s_w[kHeavyThreads];
+  constexpr int kStage = 1024;              // edges staged per round, whatever the block size
+  __shared__ int32_t s_v[kStage];
+  __shared__ float s_w[kStage];
   __shared__ V red[kHeavyThreads];
   int n_heavy = heavy[0];
   if (n_heavy > heavy_cap) n_heavy = heavy_cap;
@@ -424,19 +437,19 @@ __global__ __launch_bounds__(kHeavyThreads) void k_spmm_bwd_heavy(const int32_t*
   const int el = threadIdx.x >> lpr_log2, n_el = kHeavyThreads >> lpr_log2, gl = threadIdx.x & (lpr - 1);
   const int pieces = dim / VEC;
   const uint32_t step = (DROP && d.step) ? (uint32_t)*d.step : 0u;
-  for (int hi = blockIdx.x; hi < n_heavy; hi += gridDim.x) {
+  for (int hi = first; hi < n_heavy; hi += stride) {
     const int sr = heavy[1 + hi];
     const int32_t beg = tptr[sr], end = tptr[sr + 1];
     for (int c0 = 0; c0 < pieces; c0 += lpr) {
       const int c = c0 + gl;
       V acc = S::zero();
-      for (int32_t base = beg; base < end; base += kHeavyThreads) {
-        const int n = end - base < kHeavyThreads ? end - base : kHeavyThreads;
+      for (int32_t base = beg; base < end; base += kStage) {
+        const int n = end - base < kStage ? end - base : kStage;
         __syncthreads();
-        if ((int)threadIdx.x < n) {
-          const int32_t v = tdst[base + threadIdx.x];
-          s_v[threadIdx.x] = v;
-          s_w[threadIdx.x] = reduce == PG_REDUCE_MEAN ? (float)(indptr[v + 1] - indptr[v]) : 1.f;
+        for (int t = threadIdx.x; t < n; t += kHeavyThreads) {     // independent per t: all in flight together
+          const int32_t v = tdst[base + t];
+          s_v[t] = v;
+          s_w[t] = reduce == PG_REDUCE_MEAN ? (float)(indptr[v + 1] - indptr[v]) : 1.f;
         }
         __syncthreads();
         if (c < pieces) {
@@ -630,29 +643,21 @@ int pg_spmm_bwd_gather(const int32_t* tptr, const int32_t* tdst, const int32_t* 
   const int pieces = v4 ? dim / 4 : dim;
   int l2 = log2_ceil_pow2(pieces < 64 ? pieces : 64);
   const int rows_per_block = 4 * (64 >> l2);
-  const dim3 grid((unsigned)ceil_div<int64_t>(n_src, rows_per_block));
+  const int64_t row_blocks = ceil_div<int64_t>(n_src, rows_per_block);
+  const bool hubs = heavy && heavy_cap > 0;
+  // hub rows: up to 16 extra blocks of the same launch (hub i goes to extra block i % 16)
+  const int hub_blocks = hubs ? (heavy_cap < 16 ? heavy_cap : 16) : 0;
+  const dim3 grid((unsigned)(row_blocks + hub_blocks));
   hipStream_t st = as_stream(stream);
 #define PG_BWD_GATHER(VEC, DROP)                                                                                 \
   hipLaunchKernelGGL((k_spmm_bwd_gather<VEC, DROP>), grid, dim3(256), 0, st, tptr, tdst, indptr, grad_out, go_stride, \
-                     n_src, dim, reduce, grad_h, gh_stride, l2, (heavy && heavy_cap > 0) ? 1 : 0, d)
+                     n_src, dim, reduce, grad_h, gh_stride, l2, hubs ? 1 : 0, d, heavy, heavy_cap, (int32_t)row_blocks)
   if (v4 && dr) PG_BWD_GATHER(4, true);
   else if (v4) PG_BWD_GATHER(4, false);
   else if (dr) PG_BWD_GATHER(1, true);
   else PG_BWD_GATHER(1, false);
 #undef PG_BWD_GATHER
   PG_LAUNCH_CHECK();
-  if (heavy && heavy_cap > 0) {
-    const unsigned hgrid = heavy_cap < 64 ? (unsigned)heavy_cap : 64u;
-#define PG_BWD_HEAVY(VEC, DROP)                                                                                   \
-  hipLaunchKernelGGL((k_spmm_bwd_heavy<VEC, DROP>), dim3(hgrid), dim3(kHeavyThreads), 0, st, heavy, heavy_cap, tptr, \
-                     tdst, indptr, grad_out, go_stride, dim, reduce, grad_h, gh_stride, l2, d)
-    if (v4 && dr) PG_BWD_HEAVY(4, true);
-    else if (v4) PG_BWD_HEAVY(4, false);
-    else if (dr) PG_BWD_HEAVY(1, true);
-    else PG_BWD_HEAVY(1, false);
-#undef PG_BWD_HEAVY
-    PG_LAUNCH_CHECK();
-  }
   return PG_OK;
 }
 

@@ -355,7 +355,10 @@ class GraphedTrainer:
         """_step_body for one GPU with the partial sums (and the dropout step counter's increment) folded into the
         optimiser's launch"""
         m = self._bare_model()
-        bump = m.externalise_drop_step() if (m.training and hasattr(m, "externalise_drop_step")) else None
+        import os as _os
+        bump = None
+        if m.training and hasattr(m, "externalise_drop_step") and not _os.environ.get("PG_KEEP_BUMP_KERNEL"):
+            bump = m.externalise_drop_step()
         with ops.defer_partials() as reg:
             rs = s.plan.row_sources if s.plan else {}
             for i in range(s.nf.num_layers):
