@@ -51,6 +51,15 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def cgroup_cpu_stat():
+    """(nr_throttled, throttled_usec, usage_usec) of this process's cgroup, or None"""
+    try:
+        d = dict(line.split() for line in open("/sys/fs/cgroup/cpu.stat"))
+        return int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0)), int(d.get("usage_usec", 0))
+    except (OSError, ValueError):
+        return None
+
+
 def host_info(cacher=None):
     """what the host side of the step had to work with: CPU model, cores visible, cgroup CPU quota,
     threads of the miss path's row gather"""
@@ -635,13 +644,16 @@ def run():
     win = max(1, min(args.window, K))
     cstream = trainer.compute_stream if use_graph else torch.cuda.current_stream(dev)
     wev = [torch.cuda.Event(enable_timing=True)]
+    host_t = []
     def on_step(done_, loss_):
+        host_t.append(time.perf_counter())
         if done_ % win == 0 or done_ == K:
             e_ = torch.cuda.Event(enable_timing=True)
             e_.record(cstream)
             wev.append(e_)
     trainer.on_step = on_step
     mq0 = cacher.miss_queue_stats()
+    cg0 = cgroup_cpu_stat()
     drop_step0 = int(model._drop_step.item()) if hasattr(model, "_drop_step") else 0
     wev[0].record(cstream)
     t0 = time.time()
@@ -654,10 +666,19 @@ def run():
         dist.barrier()
     elapsed = time.time() - t0
     trainer.on_step = None
+    cg1 = cgroup_cpu_stat()
+    cpu_quota = None
+    if cg0 and cg1:      # was the process throttled by its CPU quota inside the timed region? how many CPUs did it use?
+        cpu_quota = {"nr_throttled": cg1[0] - cg0[0], "throttled_ms": (cg1[1] - cg0[1]) / 1e3,
+                     "cpus_used": (cg1[2] - cg0[2]) / 1e6 / max(1e-9, elapsed)}
     windows = []
     for i_ in range(1, len(wev)):
         n_ = min(i_ * win, K) - (i_ - 1) * win
         windows.append(round(wev[i_ - 1].elapsed_time(wev[i_]) / max(1, n_), 5))
+    # the launch thread's three longest iterations (ms, step index): a stall of the host shows here, one of the GPU /
+    # miss path only in ms_per_step_windows
+    hd = np.diff(np.asarray(host_t)) * 1e3 if len(host_t) > 1 else np.zeros(0)
+    host_longest = [[round(float(hd[i_]), 3), int(i_) + 1] for i_ in np.argsort(-hd)[:3]] if len(hd) else []
     timed_out = bool(cacher.misses_timed_out())
     copy_windows = None
     if os.environ.get("PG_MISSQ_COPYLOG"):
@@ -817,9 +838,9 @@ def run():
             "feat_gather_GBps": (micro[1 << 20]["GBps"] if micro else achieved),
             "seeds_per_s": seeds_total / elapsed,
             "host_issue_ms_per_step": t_issued / K * 1e3,     # launch thread's share; == ms_per_step when it is the bottleneck
-            "ms_per_step_windows": windows, "window_steps": win,
+            "ms_per_step_windows": windows, "window_steps": win, "host_longest_iterations_ms": host_longest,
             "warmup_requested": args.warmup, "misses_timed_out": timed_out,
-            "host": host_info(cacher), "miss_queue": mq_stats, "miss_copy_GBps_windows": copy_windows,
+            "host": dict(host_info(cacher), timed_region_cgroup=cpu_quota), "miss_queue": mq_stats, "miss_copy_GBps_windows": copy_windows,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -154,14 +154,17 @@ def default_host_threads(world_size=1):
     return max(2, min(16, (cpus - 4 * max(1, world_size)) // max(1, world_size) if cpus > 8 else cpus // 2))
 
 
-# How a consumer stream is ordered after the async queue's miss rows. Default (round 2): the trainer thread waits on the
-# HOST until the worker has enqueued the slot's copy (it was submitted two batches earlier: normally no wait at all) and
-# then makes the stream wait on the copy's event — no spin-wait kernel is ever parked on the consuming stream. With the
-# copies pinned to one SDMA engine this is as fast as the device-side wait (GCN 0.167 vs 0.168 ms/step, GraphSAGE 0.383
-# vs 0.403 with a 1 ms/step episode under the device-side wait), cannot dead-lock when the runtime maps the consuming
-# stream and the copy stream onto one hardware queue (observed with equal stream priorities: 3 s time-outs), and survives
-# tools that serialise kernels (rocprofv3 --pmc). PG_MISSQ_DEVICE_WAIT=1 restores the device-side spin-wait kernel.
-_HOST_WAIT = bool(os.environ.get("PG_MISSQ_HOST_WAIT")) or not os.environ.get("PG_MISSQ_DEVICE_WAIT")
+# How a consumer stream is ordered after the async queue's miss rows. Default: on the DEVICE — an event when the worker has
+# already enqueued the slot's copy, else a one-wave kernel sleeping on the flag the copy stream raises; the trainer thread
+# never waits. PG_MISSQ_HOST_WAIT=1 (GraphCacheServer.host_wait): the trainer thread waits on the host until the worker
+# has enqueued the copy, then the stream waits on its event — no spin kernel is ever parked on the consuming stream.
+# Measured over 8 + 8 whole-epoch runs on one box (GCN, 10M/100M): same median step (0.168 vs 0.169 ms), but a stall of the
+# launch thread now stalls the step directly: 5 of 8 runs had a 20-step window at 0.4-0.7 ms/step (2 of 8 with the
+# device-side wait), and in an earlier batch 2 of 8 runs sat at 0.278 ms/step for the whole epoch (the "just in time"
+# cycle round 1 described). The host-side wait cannot dead-lock when the runtime maps the consuming stream and the copy
+# stream onto one hardware queue, which is why the copy stream lives in another priority class (pg_missq.hip) and
+# why bench.py falls back to it when a device-side wait timed out; it is also what rocprofv3 --pmc needs.
+_HOST_WAIT = bool(os.environ.get("PG_MISSQ_HOST_WAIT"))
 
 
 class _FetchPlan:

@@ -237,6 +237,7 @@ class GraphedTrainer:
         # the next run_steps call starts on a primed pipeline instead of paying sample -> gather -> miss-path
         # latency for its first batches again. False: every call drains what it prepared.
         self.keep_primed = True
+        self.keep_gc = False             # True: leave the interpreter's cyclic garbage collector on inside run_steps
 
     class _Slot:
         pass
@@ -506,9 +507,17 @@ class GraphedTrainer:
         prev = torch.cuda.current_stream(self.device)
         torch.cuda.set_stream(self.compute_stream)
         self._on_main = True
+        # the launch thread has ~0.3 ms of slack (two prepared batches): a cyclic-GC pass of the interpreter (10 ms with
+        # torch's object graph) drains the pipeline — seen as an isolated 20-step window at 0.5-0.7 ms/step
+        import gc
+        gc_on = gc.isenabled() and not self.keep_gc
+        if gc_on:
+            gc.disable()
         try:
             return self._run_steps(it, steps)
         finally:
+            if gc_on:
+                gc.enable()
             self._on_main = False
             torch.cuda.set_stream(prev)
 
