@@ -286,12 +286,6 @@ __global__ __launch_bounds__(256) void k_relabel(const int32_t* __restrict__ nbr
   }
 }
 
-__global__ void k_clear_words(unsigned long long* bm, const int64_t* ids, const int32_t* n_dev) {
-  const int n = *n_dev;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    bm[ids[i] >> 6] = 0ull;
-}
-
 struct PackArgs {
   const int64_t* layer_ids[PG_MAX_LAYERS];
   const int32_t* layer_cnt[PG_MAX_LAYERS];

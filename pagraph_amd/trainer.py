@@ -253,6 +253,7 @@ class GraphedTrainer:
         s.done_recorded = False
         s.graph = None
         s.graph_synced = False
+        s.graph_plan = None
         s.graph_epoch = -1
         s.nf = None
         s.loss = None
@@ -452,8 +453,10 @@ class GraphedTrainer:
         main = self.compute_stream
         main.wait_event(s.ready)
         self.cacher.wait_misses(s.slot_index, main)
-        if s.graph is not None and s.graph_epoch != self.cacher._cache_epoch:
-            s.graph = None               # the captured step reads the cache in place: re-capture after the cache changed
+        if s.graph is not None and s.graph_plan is not s.plan:
+            # the captured step reads the cache / the slot array / the staged block of the fetch plan it was captured
+            # over: a new plan (the cache changed, the miss queue was rebuilt) needs a new capture
+            s.graph = None
         if s.graph is not None and (self.world == 1 or s.graph_synced) and self._on_main:
             s.graph.replay()                                  # steady state: one launch
             loss = s.loss.clone() if self.keep_losses else s.loss
@@ -479,6 +482,7 @@ class GraphedTrainer:
                         s.loss = (self._step_body_deferred(s) if self._can_defer_partials() else self._step_body(s)).detach()
                     s.graph = g
                     s.graph_epoch = self.cacher._cache_epoch
+                    s.graph_plan = s.plan
                     s.graph_synced = synced = bool(self.allreduce_in_graph)
                     g.replay()                                   # capture does not execute
                 if self.world > 1 and not synced:

@@ -1676,3 +1676,58 @@ def test_adam_with_deferred_partial_sums_is_bit_identical(dev, hiplib):
         for x, y in zip(a, b):
             assert torch.equal(x, y)
     assert all(torch.isfinite(l) for l in runs[0][0])
+
+
+def test_zerocopy_refused_on_pageable_table_and_recapture_after_cache_change(dev, hiplib):
+    """(1) ADVICE r1: a kernel reading a pageable host table faults — GraphCacheServer falls back from 'zerocopy' to the
+    async queue when a table is not page-locked, and refuses cpu_share < 1 there. (2) A GraphedTrainer slot's graph reads
+    the cache in place (fused gather): after the cache contents change (second auto_cache) the graph is re-captured and
+    the loss trajectory still equals a trainer that never cached anything."""
+    import torch.nn.functional as Fn
+    from pagraph_amd import _lib as L
+    from pagraph_amd.model import GCNSampling
+    from pagraph_amd.optim import Adam
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    from pagraph_amd.trainer import GraphedTrainer, cycle_batches
+    rng = np.random.default_rng(8)
+    V, Fd, C, B = 4000, 600, 9, 500
+    feats = torch.from_numpy(rng.random((V, Fd), dtype=np.float32))
+    store = HostFeatureStore({"features": feats}, pin=False)
+    assert store.pinned == {"features": False}
+    c = GraphCacheServer(store, V, torch.arange(V), 0, miss_mode="zerocopy")
+    assert c.miss_mode == "async"
+    c.init_field(["features"])
+    c.cpu_share = 0.5
+    with pytest.raises(L.PgError):
+        c._missq_buffers(0, 1000)
+    # (2)
+    g = DeviceGraph(_rand_csc(rng, V, 30000))
+    labels = torch.from_numpy(rng.integers(0, C, V)).to(dev)
+    losses = []
+    for recache in (False, True):
+        store2 = HostFeatureStore({"features": feats})
+        cc = GraphCacheServer(store2, V, torch.arange(V), 0, miss_mode="async")
+        cc.init_field(["features"])
+        torch.manual_seed(4)
+        model = GCNSampling(Fd, 32, C, 1, Fn.relu, 0.2).to(dev).train()
+        smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=True, num_hops=2, seed_nodes=np.arange(0, V, 2), seed=6,
+                              static=True, defer_transpose=True)
+        tr = GraphedTrainer(model, torch.nn.CrossEntropyLoss(), Adam(model.parameters(), lr=1e-2), cc, smp, labels, dev,
+                            need=model.required_inputs(3), keep_losses=True)
+        out = []
+        tr.on_step = lambda k, l: out.append(l)
+        it = cycle_batches(smp, 40)
+        tr.run_steps(it, 14)                       # eager warm-up + captures, nothing cached: every row is a miss
+        if recache:
+            tr.synchronize(); torch.cuda.synchronize()
+            cc.auto_cache(g, ["features"], cache_ratio=0.4)      # cache epoch changes: plans and graphs are rebuilt
+            ep = cc._cache_epoch
+        tr.run_steps(it, 12)
+        tr.synchronize(); torch.cuda.synchronize()
+        if recache:
+            assert all(s.graph is not None and s.graph_plan is s.plan and s.plan.cache_epoch == ep for s in tr.slots.values())
+            assert cc.cached_num == int(V * 0.4)
+        losses.append(torch.stack([l.detach().float().cpu() for l in out]))
+        cc.check_misses()
+    assert torch.equal(losses[0], losses[1])       # features are features, wherever they are read from
