@@ -362,6 +362,14 @@ int pg_spmm_bwd_gather(const int32_t* tptr, const int32_t* tdst, const int32_t* 
                        int32_t go_stride, int64_t n_src, int32_t dim, int reduce, float* grad_h,
                        int32_t gh_stride, const int32_t* heavy, int32_t heavy_cap, const pg_dropout_t* drop,
                        pg_stream_t stream);
+/* the same + dZ of the NodeUpdate that produced the aggregated rows, when that was a skip-concat y = [z | relu(z)]
+ * (gcn_nssc.py:20-21; dim = 2 N): dz[s, j] = grad_h[s, j] + (act_out[s, j] > 0 ? grad_h[s, N + j] : 0), j < N — what
+ * pg_linear_bwd_w(act = 2) derives with a launch of its own. act_out = the forward input of the aggregation (row stride
+ * act_stride), dz [n_src, N] dense. Needs 16-byte pieces and dim / 4 <= 64 (else PG_ERR_UNSUPPORTED).     */
+int pg_spmm_bwd_gather_dz(const int32_t* tptr, const int32_t* tdst, const int32_t* indptr, const float* grad_out,
+                          int32_t go_stride, int64_t n_src, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,
+                          const int32_t* heavy, int32_t heavy_cap, const pg_dropout_t* drop, const float* act_out,
+                          int32_t act_stride, float* dz, pg_stream_t stream);
 
 /* Skinny dense step of the first layer — NodeUpdate.forward at PaGraph/model/gcn_nssc.py:18-23 and
  * graphsage_nssc.py:24-29 — on fp32 MFMA: Z = X[n,K] * W^T + bias with W = nn.Linear's weight [N,K],

@@ -104,6 +104,8 @@ _SIGS = {
     "pg_compose_edge_slots": (ctypes.c_int, [vp, c_i64, vp, c_i64, vp, vp]),
     "pg_spmm_bwd_drop": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, vp]),
     "pg_spmm_bwd_gather": (ctypes.c_int, [vp, vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, c_i32, vp, vp]),
+    "pg_spmm_bwd_gather_dz": (ctypes.c_int, [vp, vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, c_i32, vp, vp,
+                                             c_i32, vp, vp]),
     "pg_linear_fwd": (ctypes.c_int, [vp, c_i32, vp, vp, vp, c_i32, c_i64, c_i32, c_i32, c_i32, vp]),
     "pg_linear2_fwd": (ctypes.c_int, [vp, c_i32, vp, vp, c_i32, vp, c_i32, vp, vp, c_i32, vp, c_i32, c_i64, c_i32, c_i32, vp]),
     "pg_linear_bwd_w_scratch": (c_i64, [c_i64, c_i32, c_i32]),

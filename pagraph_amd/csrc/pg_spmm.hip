@@ -12,6 +12,8 @@
 // deterministic (and bit-equal to the sequential oracle).
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+#include <cstdlib>
+
 #include "pg_common.h"
 
 namespace pg {
@@ -348,12 +350,30 @@ __global__ __launch_bounds__(256) void k_spmm_bwd_drop(const int32_t* __restrict
 //   grad_h[s, :] = mask(s, :) * scale * sum_{t in [tptr[s], tptr[s+1])} grad_out[tdst[t], :] / deg(tdst[t])
 // Every row of grad_h is written (no zero fill), nothing is atomic (the scatter form manages ~30 G fp32
 // atomics/s: 26 us for the 12K-edge output block) and the sum runs in ascending destination order.
+// Optional second output of the backward aggregation: when grad_h is the gradient of a NodeUpdate's skip-concat output
+// y = [z | relu(z)] (gcn_nssc.py:20-21, 2N columns), dZ[s, j] = grad_h[s, j] + (y[s, j] > 0 ? grad_h[s, N + j] : 0) is what
+// the layer's weight gradient needs (k_dz of pg_dense.hip: one launch of the replayed step). The lane that holds piece c of a
+// row gets piece c + N/4 from its neighbour in the row's lane group and writes dZ next to grad_h.
+struct DzOut {
+  const float* y;   // the activation output the aggregation consumed (its forward input h)
+  float* dz;        // [n_src, N]
+  int32_t y_stride, N;
+};
+
+__device__ __forceinline__ float4 dz_piece(float4 lo, float4 hi, float4 y) {
+  lo.x += y.x > 0.f ? hi.x : 0.f;
+  lo.y += y.y > 0.f ? hi.y : 0.f;
+  lo.z += y.z > 0.f ? hi.z : 0.f;
+  lo.w += y.w > 0.f ? hi.w : 0.f;
+  return lo;
+}
+
 template <int VEC, bool DROP, int T>
 __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, int32_t heavy_cap,
                                            const int32_t* __restrict__ tptr, const int32_t* __restrict__ tdst,
                                            const int32_t* __restrict__ indptr, const float* __restrict__ go,
                                            int32_t go_stride, int32_t dim, int reduce, float* __restrict__ gh,
-                                           int32_t gh_stride, int lpr_log2, DropArgs d, int first, int stride);
+                                           int32_t gh_stride, int lpr_log2, DropArgs d, int first, int stride, DzOut z);
 
 // (blocks >= n_row_blocks of the launch are the hub blocks: heavy_rows below)
 template <int VEC, bool DROP>
@@ -364,12 +384,12 @@ __global__ __launch_bounds__(256) void k_spmm_bwd_gather(const int32_t* __restri
                                                          int64_t n_src, int32_t dim, int reduce,
                                                          float* __restrict__ gh, int32_t gh_stride, int lpr_log2,
                                                          int skip_heavy, DropArgs d, const int32_t* __restrict__ heavy,
-                                                         int32_t heavy_cap, int32_t n_row_blocks) {
+                                                         int32_t heavy_cap, int32_t n_row_blocks, DzOut z) {
   using S = SV<VEC>;
   using V = typename S::type;
   if ((int)blockIdx.x >= n_row_blocks) {
     heavy_rows<VEC, DROP, 256>(heavy, heavy_cap, tptr, tdst, indptr, go, go_stride, dim, reduce, gh, gh_stride, lpr_log2, d,
-                               (int)blockIdx.x - n_row_blocks, (int)gridDim.x - n_row_blocks);
+                               (int)blockIdx.x - n_row_blocks, (int)gridDim.x - n_row_blocks, z);
     return;
   }
   const int lpr = 1 << lpr_log2;
@@ -384,6 +404,7 @@ __global__ __launch_bounds__(256) void k_spmm_bwd_gather(const int32_t* __restri
   const int32_t beg = tptr[sr], end = tptr[sr + 1];
   if (skip_heavy && end - beg > PG_HEAVY_ROW) return;   // a hub: k_spmm_bwd_heavy gives it a whole block
   V* grow = reinterpret_cast<V*>(gh + sr * gh_stride);
+  V last = S::zero();       // this lane's piece of the row (the dZ epilogue needs it; pieces <= lpr there)
   for (int c = gl; c < pieces; c += lpr) {
     V acc = S::zero();
     for (int32_t t = beg; t < end; ++t) {
@@ -409,6 +430,21 @@ __global__ __launch_bounds__(256) void k_spmm_bwd_gather(const int32_t* __restri
       }
     }
     grow[c] = acc;
+    last = acc;
+  }
+  if constexpr (VEC == 4) {
+    if (z.dz) {   // host side guarantees pieces <= lpr, dim == 2 N: piece c pairs with piece c + N/4 of the same row
+      const int hp = z.N / 4;
+      float4 hi;
+      hi.x = __shfl_down(last.x, hp, lpr);
+      hi.y = __shfl_down(last.y, hp, lpr);
+      hi.z = __shfl_down(last.z, hp, lpr);
+      hi.w = __shfl_down(last.w, hp, lpr);
+      if (gl < hp) {
+        const float4 yv = reinterpret_cast<const float4*>(z.y + sr * z.y_stride)[gl];
+        reinterpret_cast<float4*>(z.dz + sr * z.N)[gl] = dz_piece(last, hi, yv);
+      }
+    }
   }
 }
 
@@ -422,7 +458,7 @@ __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, in
                                            const int32_t* __restrict__ tptr, const int32_t* __restrict__ tdst,
                                            const int32_t* __restrict__ indptr, const float* __restrict__ go,
                                            int32_t go_stride, int32_t dim, int reduce, float* __restrict__ gh,
-                                           int32_t gh_stride, int lpr_log2, DropArgs d, int first, int stride) {
+                                           int32_t gh_stride, int lpr_log2, DropArgs d, int first, int stride, DzOut z) {
   constexpr int kHeavyThreads = T;
 
   using S = SV<VEC>;
@@ -431,6 +467,7 @@ __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, in
   __shared__ int32_t s_v[kStage];
   __shared__ float s_w[kStage];
   __shared__ V red[kHeavyThreads];
+  __shared__ float4 zrow[64];               // the finished row, for the dZ epilogue
   int n_heavy = heavy[0];
   if (n_heavy > heavy_cap) n_heavy = heavy_cap;
   const int lpr = 1 << lpr_log2;                  // lanes across the row's pieces
@@ -493,6 +530,20 @@ __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, in
           }
         }
         reinterpret_cast<V*>(gh + (int64_t)sr * gh_stride)[c] = tot;
+        if constexpr (VEC == 4) {
+          if (z.dz) zrow[gl] = tot;
+        }
+      }
+      if constexpr (VEC == 4) {
+        if (z.dz) {        // pieces <= lpr (one c0 pass): piece c pairs with piece c + N/4
+          __syncthreads();
+          const int hp = z.N / 4;
+          if (el == 0 && gl < hp) {
+            const float4 lo = zrow[gl], hi = zrow[gl + hp];
+            const float4 yv = reinterpret_cast<const float4*>(z.y + (int64_t)sr * z.y_stride)[gl];
+            reinterpret_cast<float4*>(z.dz + (int64_t)sr * z.N)[gl] = dz_piece(lo, hi, yv);
+          }
+        }
       }
     }
   }
@@ -631,6 +682,14 @@ int pg_spmm_bwd_drop(const int32_t* indptr, const int32_t* src, const float* gra
 int pg_spmm_bwd_gather(const int32_t* tptr, const int32_t* tdst, const int32_t* indptr, const float* grad_out,
                        int32_t go_stride, int64_t n_src, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,
                        const int32_t* heavy, int32_t heavy_cap, const pg_dropout_t* drop, pg_stream_t stream) {
+  return pg_spmm_bwd_gather_dz(tptr, tdst, indptr, grad_out, go_stride, n_src, dim, reduce, grad_h, gh_stride, heavy,
+                               heavy_cap, drop, nullptr, 0, nullptr, stream);
+}
+
+int pg_spmm_bwd_gather_dz(const int32_t* tptr, const int32_t* tdst, const int32_t* indptr, const float* grad_out,
+                          int32_t go_stride, int64_t n_src, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,
+                          const int32_t* heavy, int32_t heavy_cap, const pg_dropout_t* drop, const float* act_out,
+                          int32_t act_stride, float* dz, pg_stream_t stream) {
   if (n_src < 0 || dim <= 0 || go_stride < dim || gh_stride < dim) return PG_ERR_INVALID;
   if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return PG_ERR_INVALID;
   if (drop && drop->threshold > 65535u) return PG_ERR_INVALID;
@@ -643,6 +702,13 @@ int pg_spmm_bwd_gather(const int32_t* tptr, const int32_t* tdst, const int32_t* 
   const int pieces = v4 ? dim / 4 : dim;
   int l2 = log2_ceil_pow2(pieces < 64 ? pieces : 64);
   const int rows_per_block = 4 * (64 >> l2);
+  DzOut z{};
+  if (dz) {
+    // dZ of a skip-concat NodeUpdate (2 N columns): 16-byte pieces, the whole row inside one lane group
+    if (!act_out || !v4 || dim % 8 || pieces > (1 << l2) || act_stride < dim || act_stride % 4 || !al(act_out, 16) || !al(dz, 16))
+      return PG_ERR_UNSUPPORTED;
+    z.y = act_out; z.dz = dz; z.y_stride = act_stride; z.N = dim / 2;
+  }
   const int64_t row_blocks = ceil_div<int64_t>(n_src, rows_per_block);
   const bool hubs = heavy && heavy_cap > 0;
   // hub rows: up to 16 extra blocks of the same launch (hub i goes to extra block i % 16)
@@ -651,7 +717,7 @@ int pg_spmm_bwd_gather(const int32_t* tptr, const int32_t* tdst, const int32_t* 
   hipStream_t st = as_stream(stream);
 #define PG_BWD_GATHER(VEC, DROP)                                                                                 \
   hipLaunchKernelGGL((k_spmm_bwd_gather<VEC, DROP>), grid, dim3(256), 0, st, tptr, tdst, indptr, grad_out, go_stride, \
-                     n_src, dim, reduce, grad_h, gh_stride, l2, hubs ? 1 : 0, d, heavy, heavy_cap, (int32_t)row_blocks)
+                     n_src, dim, reduce, grad_h, gh_stride, l2, hubs ? 1 : 0, d, heavy, heavy_cap, (int32_t)row_blocks, z)
   if (v4 && dr) PG_BWD_GATHER(4, true);
   else if (v4) PG_BWD_GATHER(4, false);
   else if (dr) PG_BWD_GATHER(1, true);

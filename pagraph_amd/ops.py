@@ -1,5 +1,6 @@
 """autograd wrappers over the HIP aggregation kernels (pagraph_amd/csrc/pg_spmm.hip)."""
 import ctypes
+import os
 
 import torch
 
@@ -78,7 +79,7 @@ def aggregate_rows(indptr, src, rows, n_dst, reduce="mean", dropout=None):
 
 class _BlockAggregate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, indptr, src, h, n_dst, reduce, drop, tptr, tdst, heavy):
+    def forward(ctx, indptr, src, h, n_dst, reduce, drop, tptr, tdst, heavy, dz_n=0):
         lib = L.load()
         h = h.contiguous()
         out = torch.empty((n_dst, h.size(1)), dtype=torch.float32, device=h.device)
@@ -91,8 +92,13 @@ class _BlockAggregate(torch.autograd.Function):
                 L.check(lib.pg_spmm_fwd_drop(L.ptr(indptr), L.ptr(src), L.ptr(h), h.stride(0), n_dst, h.size(1),
                                              _REDUCE[reduce], L.ptr(out), out.stride(0), ctypes.byref(d),
                                              L.stream_ptr()), "pg_spmm_fwd_drop")
+        ctx.dz_n = 0
         if tptr is not None and tptr.numel() == h.size(0) + 1:
-            ctx.save_for_backward(indptr, src, tptr, tdst, heavy)
+            if _dz_fusable(h, dz_n):
+                ctx.dz_n = dz_n
+                ctx.save_for_backward(indptr, src, tptr, tdst, heavy, h)
+            else:
+                ctx.save_for_backward(indptr, src, tptr, tdst, heavy)
         else:
             ctx.save_for_backward(indptr, src)
         ctx.n_src, ctx.reduce, ctx.drop = h.size(0), reduce, drop
@@ -101,20 +107,25 @@ class _BlockAggregate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         if not ctx.needs_input_grad[2]:
-            return (None,) * 9
+            return (None,) * 10
         lib = L.load()
         go = grad_out.contiguous()
-        if len(ctx.saved_tensors) == 5:          # gather form over the block's source-major copy
-            indptr, src, tptr, tdst, heavy = ctx.saved_tensors
+        if len(ctx.saved_tensors) >= 5:          # gather form over the block's source-major copy
+            indptr, src, tptr, tdst, heavy = ctx.saved_tensors[:5]
             gh = torch.empty((ctx.n_src, go.size(1)), dtype=torch.float32, device=go.device)
             d = ctx.drop.struct() if ctx.drop is not None else None
+            y = ctx.saved_tensors[5] if ctx.dz_n else None
+            dz = torch.empty((ctx.n_src, ctx.dz_n), dtype=torch.float32, device=go.device) if ctx.dz_n else None
             with torch.cuda.device(go.device):
-                L.check(lib.pg_spmm_bwd_gather(L.ptr(tptr), L.ptr(tdst), L.ptr(indptr), L.ptr(go), go.stride(0), ctx.n_src,
-                                               go.size(1), _REDUCE[ctx.reduce], L.ptr(gh), gh.stride(0), L.ptr(heavy),
-                                               heavy.numel() - 1 if heavy is not None else 0,
-                                               ctypes.byref(d) if d is not None else None, L.stream_ptr()),
-                        "pg_spmm_bwd_gather")
-            return (None, None, gh) + (None,) * 6
+                L.check(lib.pg_spmm_bwd_gather_dz(L.ptr(tptr), L.ptr(tdst), L.ptr(indptr), L.ptr(go), go.stride(0), ctx.n_src,
+                                                  go.size(1), _REDUCE[ctx.reduce], L.ptr(gh), gh.stride(0), L.ptr(heavy),
+                                                  heavy.numel() - 1 if heavy is not None else 0,
+                                                  ctypes.byref(d) if d is not None else None, L.ptr(y),
+                                                  y.stride(0) if y is not None else 0, L.ptr(dz), L.stream_ptr()),
+                        "pg_spmm_bwd_gather_dz")
+            if dz is not None:
+                _stash_dz(gh, dz)
+            return (None, None, gh) + (None,) * 7
         indptr, src = ctx.saved_tensors
         gh = torch.zeros((ctx.n_src, go.size(1)), dtype=torch.float32, device=go.device)
         with torch.cuda.device(go.device):
@@ -126,7 +137,7 @@ class _BlockAggregate(torch.autograd.Function):
                 L.check(lib.pg_spmm_bwd_drop(L.ptr(indptr), L.ptr(src), L.ptr(go), go.stride(0), go.size(0),
                                              go.size(1), _REDUCE[ctx.reduce], L.ptr(gh), gh.stride(0),
                                              ctypes.byref(d), L.stream_ptr()), "pg_spmm_bwd_drop")
-        return (None, None, gh) + (None,) * 6
+        return (None, None, gh) + (None,) * 7
 
 
 def block_aggregate(indptr, src, h, n_dst, reduce="mean", dropout=None, transpose=None):
@@ -144,10 +155,40 @@ def block_aggregate(indptr, src, h, n_dst, reduce="mean", dropout=None, transpos
             raise L.PgError("fused dropout needs a row-aligned fp32 input with dim % 4 == 0 (check DropoutSpec.fusable)")
         dropout = None
     tptr, tdst, heavy = (tuple(transpose) + (None,))[:3] if transpose is not None else (None, None, None)
-    return _BlockAggregate.apply(indptr, src, h, int(n_dst), reduce, dropout, tptr, tdst, heavy)
+    return _BlockAggregate.apply(indptr, src, h, int(n_dst), reduce, dropout, tptr, tdst, heavy,
+                                 int(getattr(h, '_pg_concat_n', 0)))
 
 
 ACT_NONE, ACT_RELU, ACT_CONCAT = 0, 1, 2
+
+# dZ side channel: when the rows an aggregation consumed were a skip-concat NodeUpdate's output y = [z | relu(z)]
+# (ops.linear tags such a y with `_pg_concat_n`), the aggregation's backward (pg_spmm_bwd_gather_dz) writes
+# dZ = g[:, :N] + g[:, N:] * (z > 0) next to its grad_h and parks it here; the NodeUpdate's backward, called by autograd with
+# that very grad_h, picks it up and skips pg_linear_bwd_w's own dZ launch. The entry holds grad_h itself, so no other live
+# tensor can have its address; a summed gradient (y consumed twice) is a different tensor and simply misses.
+_DZ_STASH = []
+
+
+def _stash_dz(gh, dz):
+    del _DZ_STASH[:-3]
+    _DZ_STASH.append((gh, dz))
+
+
+def _take_dz(gy, rows, N):
+    for i, (gh, dz) in enumerate(_DZ_STASH):
+        if gh.data_ptr() == gy.data_ptr() and gh.shape == gy.shape and dz.shape == (rows, N):
+            del _DZ_STASH[i]
+            return dz
+    return None
+
+
+FUSE_DZ = os.environ.get("PG_FUSE_DZ", "1") != "0"
+
+
+def _dz_fusable(h, dz_n):
+    """pg_spmm_bwd_gather_dz's envelope: [rows, 2 N] fp32 rows of 16-byte pieces, a whole row inside one lane group"""
+    return FUSE_DZ and bool(dz_n) and h.size(1) == 2 * dz_n and h.size(1) % 8 == 0 and h.size(1) <= 256 and h.stride(0) % 4 == 0 \
+        and h.data_ptr() % 16 == 0
 
 
 class DeferredPartials:
@@ -232,13 +273,20 @@ class _SkinnyLinear(torch.autograd.Function):
             part = torch.empty(lib.pg_linear_bwd_w_scratch(x.size(0), K, N), dtype=torch.float32, device=x.device)
             gw = buf[:N * K].view(N, K)
             gb = buf[N * K:] if ctx.has_bias else None
-            dz = torch.empty((x.size(0), N), dtype=torch.float32, device=x.device) if act != ACT_NONE else None
             defer = _DEFER is not None and ctx.has_bias
+            ready = _take_dz(gy, x.size(0), N) if act == ACT_CONCAT else None
             with torch.cuda.device(x.device):
-                L.check(lib.pg_linear_bwd_w_ex(L.ptr(gy), gy.stride(0), L.ptr(x), x.stride(0), x.size(0), K, N,
-                                               L.ptr(gw), L.ptr(gb), L.ptr(y), y.stride(0) if y is not None else 0, act,
-                                               L.ptr(dz), L.ptr(part), 0 if defer else 1, L.stream_ptr()),
-                        "pg_linear_bwd_w")
+                if ready is not None:        # dZ came with the gradient (pg_spmm_bwd_gather_dz): plain dY = dZ, no act
+                    dz = ready
+                    L.check(lib.pg_linear_bwd_w_ex(L.ptr(dz), dz.stride(0), L.ptr(x), x.stride(0), x.size(0), K, N,
+                                                   L.ptr(gw), L.ptr(gb), None, 0, ACT_NONE, None, L.ptr(part),
+                                                   0 if defer else 1, L.stream_ptr()), "pg_linear_bwd_w")
+                else:
+                    dz = torch.empty((x.size(0), N), dtype=torch.float32, device=x.device) if act != ACT_NONE else None
+                    L.check(lib.pg_linear_bwd_w_ex(L.ptr(gy), gy.stride(0), L.ptr(x), x.stride(0), x.size(0), K, N,
+                                                   L.ptr(gw), L.ptr(gb), L.ptr(y), y.stride(0) if y is not None else 0, act,
+                                                   L.ptr(dz), L.ptr(part), 0 if defer else 1, L.stream_ptr()),
+                            "pg_linear_bwd_w")
             if defer:
                 rowlen = N * K + N
                 _DEFER.add(weight, part, part.numel() // rowlen, rowlen, 0)
@@ -322,7 +370,10 @@ def linear(x, module, act=ACT_NONE):
     w, b = module.weight, module.bias
     if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and w.size(0) <= 64 and x.size(0) >= 1024
             and x.stride(1) == 1):
-        return _SkinnyLinear.apply(x, w, b, act)
+        y = _SkinnyLinear.apply(x, w, b, act)
+        if act == ACT_CONCAT:
+            y._pg_concat_n = w.size(0)         # lets the consumer's backward produce this layer's dZ (see _DZ_STASH)
+        return y
     return _apply_act(module(x), act)
 
 
@@ -395,7 +446,7 @@ class _GCNHead(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, indptr, src, h, weight, bias, labels, n_valid, grad_seed, ignore_index, reduce, drop, tptr, tdst,
-                heavy, want_logits):
+                heavy, want_logits, dz_n=0):
         lib = L.load()
         h = h.contiguous()
         n_dst = labels.numel()
@@ -421,7 +472,9 @@ class _GCNHead(torch.autograd.Function):
             _DEFER.add(bias, part, chunks, rowlen, C * K)
             _DEFER.extra.append((gbl[C:C + 1], part, chunks, rowlen, C * K + C))     # the loss value
         use_t = tptr is not None and tptr.numel() == h.size(0) + 1
-        ctx.save_for_backward(indptr, src, dagg, gw, gbl, grad_seed, *((tptr, tdst, heavy) if use_t else ()))
+        ctx.dz_n = dz_n if use_t and _dz_fusable(h, dz_n) else 0
+        ctx.save_for_backward(indptr, src, dagg, gw, gbl, grad_seed, *((tptr, tdst, heavy) if use_t else ()),
+                              *((h,) if ctx.dz_n else ()))
         ctx.use_t, ctx.n_src, ctx.reduce, ctx.drop = use_t, h.size(0), reduce, (drop if d is not None else None)
         ctx.has_bias = bias is not None
         loss = gbl[C]
@@ -447,16 +500,21 @@ class _GCNHead(torch.autograd.Function):
                 if ctx.use_t:
                     tptr, tdst, heavy = saved[6:9]
                     gh = torch.empty((ctx.n_src, K), dtype=torch.float32, device=dagg.device)
-                    L.check(lib.pg_spmm_bwd_gather(L.ptr(tptr), L.ptr(tdst), L.ptr(indptr), L.ptr(dagg), K, ctx.n_src, K,
-                                                   _REDUCE[ctx.reduce], L.ptr(gh), K, L.ptr(heavy),
-                                                   heavy.numel() - 1 if heavy is not None else 0, dp, L.stream_ptr()),
-                            "pg_spmm_bwd_gather")
+                    y = saved[9] if ctx.dz_n else None
+                    dz = torch.empty((ctx.n_src, ctx.dz_n), dtype=torch.float32, device=dagg.device) if ctx.dz_n else None
+                    L.check(lib.pg_spmm_bwd_gather_dz(L.ptr(tptr), L.ptr(tdst), L.ptr(indptr), L.ptr(dagg), K, ctx.n_src, K,
+                                                      _REDUCE[ctx.reduce], L.ptr(gh), K, L.ptr(heavy),
+                                                      heavy.numel() - 1 if heavy is not None else 0, dp, L.ptr(y),
+                                                      y.stride(0) if y is not None else 0, L.ptr(dz), L.stream_ptr()),
+                            "pg_spmm_bwd_gather_dz")
+                    if dz is not None:
+                        _stash_dz(gh, dz)
                 else:
                     gh = torch.zeros((ctx.n_src, K), dtype=torch.float32, device=dagg.device)
                     L.check(lib.pg_spmm_bwd_drop(L.ptr(indptr), L.ptr(src), L.ptr(dagg), K, dagg.size(0), K,
                                                  _REDUCE[ctx.reduce], L.ptr(gh), K, dp, L.stream_ptr()), "pg_spmm_bwd_drop")
         C = gw.size(0)
-        return (None, None, gh, gw, gbl[:C] if ctx.has_bias else None) + (None,) * 10
+        return (None, None, gh, gw, gbl[:C] if ctx.has_bias else None) + (None,) * 11
 
 
 def gcn_head(indptr, src, h, linear, labels, n_valid, grad_seed=None, ignore_index=-100, reduce="mean", dropout=None,
@@ -474,4 +532,4 @@ def gcn_head(indptr, src, h, linear, labels, n_valid, grad_seed=None, ignore_ind
         return None
     tptr, tdst, heavy = (tuple(transpose) + (None,))[:3] if transpose is not None else (None, None, None)
     return _GCNHead.apply(indptr, src, h, w, b, labels.contiguous(), n_valid, grad_seed, ignore_index, reduce, dropout,
-                          tptr, tdst, heavy, want_logits)
+                          tptr, tdst, heavy, want_logits, int(getattr(h, '_pg_concat_n', 0)))

@@ -1132,6 +1132,71 @@ def test_gcn_output_head_vs_oracle(dev, hiplib, oracle, n_dst, n_src, deg, K, C,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_dst,n_src,N,p,consumer", [(6000, 9500, 32, 0.5, "head"), (6000, 9500, 32, 0.0, "agg"),
+                                                       (3000, 4000, 16, 0.25, "agg"), (2500, 3100, 8, 0.0, "head"),
+                                                       (1500, 2000, 24, 0.5, "head")])
+def test_dz_from_backward_gather_bit_identical(dev, hiplib, monkeypatch, n_dst, n_src, N, p, consumer):
+    """pg_spmm_bwd_gather_dz: the skip-concat NodeUpdate's dZ written by the aggregation's backward (regular rows through
+    the lane-group shuffle, hub rows through LDS) == the unfused k_dz path bit for bit, in dZ's consumers: the layer's
+    weight / bias gradient and the gradient of its input. A gradient that is not the stashed tensor misses the stash."""
+    from pagraph_amd import ops
+    rng = np.random.default_rng(n_dst + N)
+    cnt = rng.integers(0, 4, n_dst)
+    indptr = np.zeros(n_dst + 1, np.int32); indptr[1:] = np.cumsum(cnt)
+    src = rng.integers(0, n_src, int(indptr[-1])).astype(np.int32)
+    pick = rng.random(src.size) < 0.2
+    src[pick] = rng.choice(np.array([5, n_src - 3, n_src // 2], np.int32), int(pick.sum()))     # three hubs
+    tptr, tdst = _transpose_ref(indptr, src, n_src)
+    heavy_rows = np.nonzero(np.diff(tptr) > 32)[0]
+    assert len(heavy_rows) == 3
+    heavy = np.zeros(1 + max(1, src.size // 32), np.int32)
+    heavy[0] = len(heavy_rows); heavy[1:1 + len(heavy_rows)] = heavy_rows
+    K_in, C = 48, 13
+    x = torch.from_numpy(rng.standard_normal((n_src, K_in)).astype(np.float32)).to(dev)
+    labels = torch.from_numpy(rng.integers(0, C, n_dst)).to(dev)
+    n_valid = torch.tensor([n_dst], dtype=torch.int32, device=dev)
+    seed_t = torch.tensor(1.0, device=dev)
+    tip, tsr = torch.from_numpy(indptr).to(dev), torch.from_numpy(src).to(dev)
+    tr = tuple(torch.from_numpy(a.astype(np.int32)).to(dev) for a in (tptr, tdst, heavy))
+    torch.manual_seed(5)
+    hidden = torch.nn.Linear(K_in, N).to(dev)
+    out = torch.nn.Linear(2 * N, C).to(dev)
+    step = torch.tensor([7], dtype=torch.int64, device=dev)
+    spec = ops.DropoutSpec(p, 11, 3, step) if p else None
+
+    def run(fuse, twice=False):
+        monkeypatch.setattr(ops, "FUSE_DZ", fuse)
+        del ops._DZ_STASH[:]
+        hidden.zero_grad(); out.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        y = ops.linear(xi, hidden, ops.ACT_CONCAT)
+        assert getattr(y, "_pg_concat_n", 0) == N
+        if consumer == "head":
+            loss = ops.gcn_head(tip, tsr, y, out, labels, n_valid, seed_t, -100, "mean", spec, tr)
+        else:
+            agg = ops.block_aggregate(tip, tsr, y, n_dst, "mean", dropout=spec, transpose=tr)
+            loss = ops.cross_entropy(torch.nn.functional.linear(agg, out.weight, out.bias), labels)
+        if twice:
+            loss = loss + 0.5 * y.sum()          # y consumed twice: the NodeUpdate sees a summed gradient
+        loss.backward(seed_t if not twice else None)
+        left = len(ops._DZ_STASH)
+        return [t.detach().cpu().numpy().copy() for t in (xi.grad, hidden.weight.grad, hidden.bias.grad)], left
+
+    plain, left0 = run(False)
+    fused, left1 = run(True)
+    assert left0 == 0 and left1 == 0                    # produced and consumed
+    for a, b in zip(plain, fused):
+        assert np.array_equal(a, b)
+    assert np.abs(plain[1]).max() > 0
+    plain2, _ = run(False, twice=True)
+    fused2, left2 = run(True, twice=True)
+    assert left2 == 1                                   # stashed, not taken: the gradient was a sum
+    for a, b in zip(plain2, fused2):
+        assert np.array_equal(a, b)
+    del ops._DZ_STASH[:]
+
+
+@pytest.mark.gpu
 def test_gcn_forward_loss_matches_forward_plus_loss(dev, hiplib):
     """GCNSampling.forward_loss == CrossEntropyLoss(model(nf)) in value and in every parameter gradient, with
     dropout (same step counter) and without; inference models and CPU labels decline (None)."""
