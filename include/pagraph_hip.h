@@ -417,11 +417,16 @@ int64_t pg_gcn_head_scratch(int64_t n_dst, int32_t K, int32_t C);
 /* pg_gcn_head_ex / pg_linear_bwd_w_ex: the same with `sum_partials` = 0 leaving the per-block / per-chunk partial rows
  * un-summed in `partials` ([rows][C*K + C + 1] resp. [rows][N*K + N], rows = scratch size / row length) for
  * pg_adam_step_partials; dW / db(_loss) are then not written.                                            */
+/* pg_gcn_head_ex's flags: PG_HEAD_SUM_PARTIALS as above; PG_HEAD_DAGG_PER_EDGE: under PG_REDUCE_MEAN dagg[v] leaves
+ * already divided by v's in-degree in the block (what each in-edge carries back) — feed it to pg_spmm_bwd_gather /
+ * pg_spmm_bwd_drop with PG_REDUCE_SUM: same operations in the same order, without the backward's degree loads.  */
+#define PG_HEAD_SUM_PARTIALS 1
+#define PG_HEAD_DAGG_PER_EDGE 2
 int pg_gcn_head_ex(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
                    const float* W, const float* bias, int32_t C, const int64_t* labels, int64_t ignore_index,
                    const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
                    int64_t n_dst, float* logits, float* dagg, float* partials, float* dW, float* db_loss,
-                   int32_t sum_partials, pg_stream_t stream);
+                   int32_t flags, pg_stream_t stream);
 int pg_linear_bwd_w_ex(const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n, int32_t K,
                        int32_t N, float* dW, float* db, const float* Yout, int32_t yo_stride, int32_t act,
                        float* dz_scratch, float* partials, int32_t sum_partials, pg_stream_t stream);

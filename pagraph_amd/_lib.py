@@ -17,6 +17,7 @@ PG_MAX_FIELDS = 4
 PG_MAX_LAYERS = 8
 PG_HEAVY_ROW = 32
 PG_ADAM_MAX_TENSORS = 16
+PG_HEAD_SUM_PARTIALS, PG_HEAD_DAGG_PER_EDGE = 1, 2
 PG_REDUCE_MEAN = 0
 PG_REDUCE_SUM = 1
 

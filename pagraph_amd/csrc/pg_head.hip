@@ -45,9 +45,10 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
                                                   int64_t ignore_index, const int32_t* __restrict__ n_valid_dev,
                                                   const float* __restrict__ grad_scale_dev, HeadDrop d, int reduce,
                                                   int64_t n_dst, float* __restrict__ logits,
-                                                  float* __restrict__ dagg, float* __restrict__ part) {
+                                                  float* __restrict__ dagg, float* __restrict__ part, int dagg_per_edge) {
   __shared__ __attribute__((aligned(16))) float s_rows[4][kHeadRows][kHeadMax];   // the waves' aggregated rows
   __shared__ int s_lab[4][kHeadRows];
+  __shared__ float s_deg[4][kHeadRows];      // what dAgg is divided by when it leaves per edge (dagg_per_edge)
   __shared__ __attribute__((aligned(16))) float s_dl[4][kHeadMax];
   // W staged with coalesced loads, zero padded to 64 x 64, row stride 65 (conflict-free row AND column reads);
   // the block's partial sums laid out [k][class] so that the 64 lanes of a wave hit 64 banks
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
     if (lane == 0) {
       const int64_t l = lab[it];
       s_lab[w][it] = (l != ignore_index && l >= 0 && l < C) ? (int)l : -1;
+      s_deg[w][it] = (dagg_per_edge && reduce == PG_REDUCE_MEAN && end[it] > beg[it]) ? (float)(end[it] - beg[it]) : 0.f;
     }
   }
   __syncthreads();
@@ -160,7 +162,10 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
       const float* wc = s_w + c * (kHeadMax + 1) + lane;          // W[c .. c+3][lane]: consecutive banks
       gk += wc[0] * g.x + wc[kHeadMax + 1] * g.y + wc[2 * (kHeadMax + 1)] * g.z + wc[3 * (kHeadMax + 1)] * g.w;
     }
-    if (live && is_k) dagg[v * K + lane] = gk;
+    // per edge: what every in-edge of v carries back under the mean — the backward aggregation then runs as a plain
+    // sum and never loads the destinations' degrees (same division, same operands: bit-identical gradients)
+    const float dg = s_deg[w][it];
+    if (live && is_k) dagg[v * K + lane] = dg > 0.f ? gk / dg : gk;
 #pragma unroll
     for (int k = 0; k < kHeadMax; k += 4) {
       const float4 g = *reinterpret_cast<const float4*>(arow + k);
@@ -221,7 +226,9 @@ int pg_gcn_head_ex(const int32_t* indptr, const int32_t* src, const float* h, in
                    const float* W, const float* bias, int32_t C, const int64_t* labels, int64_t ignore_index,
                    const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
                    int64_t n_dst, float* logits, float* dagg, float* partials, float* dW, float* db_loss,
-                   int32_t sum_partials, pg_stream_t stream) {
+                   int32_t flags, pg_stream_t stream) {
+  const int32_t sum_partials = flags & PG_HEAD_SUM_PARTIALS;
+  if (flags & ~(PG_HEAD_SUM_PARTIALS | PG_HEAD_DAGG_PER_EDGE)) return PG_ERR_INVALID;
   if (n_dst <= 0 || K <= 0 || C <= 0 || h_stride < K) return PG_ERR_INVALID;
   if (K > kHeadMax || C > kHeadMax) return PG_ERR_UNSUPPORTED;
   if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return PG_ERR_INVALID;
@@ -239,7 +246,8 @@ int pg_gcn_head_ex(const int32_t* indptr, const int32_t* src, const float* h, in
   hipStream_t st = as_stream(stream);
 #define PG_HEAD(R)                                                                                                   \
   hipLaunchKernelGGL(k_gcn_head<R>, dim3((unsigned)blocks), dim3(256), 0, st, indptr, src, h, h_stride, K, W, bias, C, \
-                     labels, ignore_index, n_valid_dev, grad_scale_dev, d, reduce, n_dst, logits, dagg, partials)
+                     labels, ignore_index, n_valid_dev, grad_scale_dev, d, reduce, n_dst, logits, dagg, partials,          \
+                     (flags & PG_HEAD_DAGG_PER_EDGE) ? 1 : 0)
   if (rpw == 1) PG_HEAD(1);
   else if (rpw == 2) PG_HEAD(2);
   else if (rpw == 4) PG_HEAD(4);

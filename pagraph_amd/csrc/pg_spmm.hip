@@ -375,6 +375,8 @@ __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, in
                                            int32_t go_stride, int32_t dim, int reduce, float* __restrict__ gh,
                                            int32_t gh_stride, int lpr_log2, DropArgs d, int first, int stride, DzOut z);
 
+constexpr int kBwdBatch = 4;
+
 // (blocks >= n_row_blocks of the launch are the hub blocks: heavy_rows below)
 template <int VEC, bool DROP>
 __global__ __launch_bounds__(256) void k_spmm_bwd_gather(const int32_t* __restrict__ tptr,
@@ -407,11 +409,26 @@ __global__ __launch_bounds__(256) void k_spmm_bwd_gather(const int32_t* __restri
   V last = S::zero();       // this lane's piece of the row (the dZ epilogue needs it; pieces <= lpr there)
   for (int c = gl; c < pieces; c += lpr) {
     V acc = S::zero();
-    for (int32_t t = beg; t < end; ++t) {
-      const int32_t v = tdst[t];
-      V g = reinterpret_cast<const V*>(go + (int64_t)v * go_stride)[c];
-      if (reduce == PG_REDUCE_MEAN) S::div(g, (float)(indptr[v + 1] - indptr[v]));
-      S::add(acc, g);
+    // kBwdBatch edges' loads in flight together (destination ids, then their rows and degrees), added in ascending
+    // edge order as a plain loop would: a 30-edge row costs 8 x 2 memory round trips, not 30 x 2
+    for (int32_t t = beg; t < end; t += kBwdBatch) {
+      int32_t v[kBwdBatch];
+#pragma unroll
+      for (int u = 0; u < kBwdBatch; ++u) v[u] = t + u < end ? tdst[t + u] : -1;
+      V g[kBwdBatch];
+      float dg[kBwdBatch];
+#pragma unroll
+      for (int u = 0; u < kBwdBatch; ++u) {
+        g[u] = v[u] >= 0 ? reinterpret_cast<const V*>(go + (int64_t)v[u] * go_stride)[c] : S::zero();
+        dg[u] = (reduce == PG_REDUCE_MEAN && v[u] >= 0) ? (float)(indptr[v[u] + 1] - indptr[v[u]]) : 1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < kBwdBatch; ++u) {
+        if (v[u] >= 0) {
+          if (reduce == PG_REDUCE_MEAN) S::div(g[u], dg[u]);
+          S::add(acc, g[u]);
+        }
+      }
     }
     if constexpr (DROP) {
       if (end > beg) {
@@ -469,13 +486,15 @@ __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, in
   __shared__ V red[kHeavyThreads];
   __shared__ float4 zrow[64];               // the finished row, for the dZ epilogue
   int n_heavy = heavy[0];
+  int32_t sr_next = heavy[1 + first];        // (first < heavy_cap) fetched with the count, not after it
   if (n_heavy > heavy_cap) n_heavy = heavy_cap;
   const int lpr = 1 << lpr_log2;                  // lanes across the row's pieces
   const int el = threadIdx.x >> lpr_log2, n_el = kHeavyThreads >> lpr_log2, gl = threadIdx.x & (lpr - 1);
   const int pieces = dim / VEC;
   const uint32_t step = (DROP && d.step) ? (uint32_t)*d.step : 0u;
   for (int hi = first; hi < n_heavy; hi += stride) {
-    const int sr = heavy[1 + hi];
+    const int sr = sr_next;
+    if (hi + stride < n_heavy) sr_next = heavy[1 + hi + stride];
     const int32_t beg = tptr[sr], end = tptr[sr + 1];
     for (int c0 = 0; c0 < pieces; c0 += lpr) {
       const int c = c0 + gl;

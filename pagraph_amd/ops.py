@@ -463,7 +463,8 @@ class _GCNHead(torch.autograd.Function):
             L.check(lib.pg_gcn_head_ex(L.ptr(indptr), L.ptr(src), L.ptr(h), h.stride(0), K, L.ptr(weight), L.ptr(bias), C,
                                        L.ptr(labels), int(ignore_index), L.ptr(n_valid), L.ptr(grad_seed),
                                        ctypes.byref(d) if d is not None else None, _REDUCE[reduce], n_dst, L.ptr(logits),
-                                       L.ptr(dagg), L.ptr(part), L.ptr(gw), L.ptr(gbl), 0 if defer else 1, L.stream_ptr()),
+                                       L.ptr(dagg), L.ptr(part), L.ptr(gw), L.ptr(gbl),
+                                       (0 if defer else L.PG_HEAD_SUM_PARTIALS) | L.PG_HEAD_DAGG_PER_EDGE, L.stream_ptr()),
                     "pg_gcn_head")
         if defer:
             rowlen = C * K + C + 1
@@ -502,8 +503,9 @@ class _GCNHead(torch.autograd.Function):
                     gh = torch.empty((ctx.n_src, K), dtype=torch.float32, device=dagg.device)
                     y = saved[9] if ctx.dz_n else None
                     dz = torch.empty((ctx.n_src, ctx.dz_n), dtype=torch.float32, device=dagg.device) if ctx.dz_n else None
+                    # dagg left the head per edge (PG_HEAD_DAGG_PER_EDGE): the mean's backward is a plain sum of it
                     L.check(lib.pg_spmm_bwd_gather_dz(L.ptr(tptr), L.ptr(tdst), L.ptr(indptr), L.ptr(dagg), K, ctx.n_src, K,
-                                                      _REDUCE[ctx.reduce], L.ptr(gh), K, L.ptr(heavy),
+                                                      L.PG_REDUCE_SUM, L.ptr(gh), K, L.ptr(heavy),
                                                       heavy.numel() - 1 if heavy is not None else 0, dp, L.ptr(y),
                                                       y.stride(0) if y is not None else 0, L.ptr(dz), L.stream_ptr()),
                             "pg_spmm_bwd_gather_dz")
@@ -512,7 +514,7 @@ class _GCNHead(torch.autograd.Function):
                 else:
                     gh = torch.zeros((ctx.n_src, K), dtype=torch.float32, device=dagg.device)
                     L.check(lib.pg_spmm_bwd_drop(L.ptr(indptr), L.ptr(src), L.ptr(dagg), K, dagg.size(0), K,
-                                                 _REDUCE[ctx.reduce], L.ptr(gh), K, dp, L.stream_ptr()), "pg_spmm_bwd_drop")
+                                                 L.PG_REDUCE_SUM, L.ptr(gh), K, dp, L.stream_ptr()), "pg_spmm_bwd_drop")
         C = gw.size(0)
         return (None, None, gh, gw, gbl[:C] if ctx.has_bias else None) + (None,) * 11
 

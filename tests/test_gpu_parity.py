@@ -1121,6 +1121,27 @@ def test_gcn_output_head_vs_oracle(dev, hiplib, oracle, n_dst, n_src, deg, K, C,
     none_valid = torch.zeros(1, dtype=torch.int32, device=dev)
     l0 = ops.gcn_head(tip, tsr, torch.from_numpy(h).to(dev), lin, torch.full_like(tl, -100), none_valid, seed_t, -100, "mean", spec, tr)
     assert torch.isnan(l0)
+    # PG_HEAD_DAGG_PER_EDGE: dagg divided by the destination's in-degree on its way out, exactly
+    import ctypes
+    from pagraph_amd import _lib as L
+    lib = L.load()
+    th = torch.from_numpy(h).to(dev)
+    outs = []
+    for flags in (L.PG_HEAD_SUM_PARTIALS, L.PG_HEAD_SUM_PARTIALS | L.PG_HEAD_DAGG_PER_EDGE):
+        buf = torch.empty(C * K + C + 1, device=dev)
+        dagg = torch.empty((n_dst, K), device=dev)
+        part = torch.empty(lib.pg_gcn_head_scratch(n_dst, K, C), device=dev)
+        dstruct = spec.struct() if spec is not None else None
+        L.check(lib.pg_gcn_head_ex(L.ptr(tip), L.ptr(tsr), L.ptr(th), K, K, L.ptr(lin.weight), L.ptr(lin.bias), C, L.ptr(tl),
+                                   -100, L.ptr(n_valid), L.ptr(seed_t), ctypes.byref(dstruct) if dstruct is not None else None,
+                                   L.PG_REDUCE_MEAN, n_dst, None, L.ptr(dagg), L.ptr(part), L.ptr(buf), L.ptr(buf[C * K:]),
+                                   flags, L.stream_ptr()), "pg_gcn_head_ex")
+        outs.append((dagg, buf))
+    deg = torch.from_numpy(np.maximum(cnt, 1).astype(np.float32)).to(dev)[:, None]
+    assert torch.equal(outs[1][0], outs[0][0] / deg) and torch.equal(outs[1][1], outs[0][1])
+    assert lib.pg_gcn_head_ex(L.ptr(tip), L.ptr(tsr), L.ptr(th), K, K, L.ptr(lin.weight), L.ptr(lin.bias), C, L.ptr(tl), -100,
+                              L.ptr(n_valid), L.ptr(seed_t), None, L.PG_REDUCE_MEAN, n_dst, None, L.ptr(dagg), L.ptr(part),
+                              L.ptr(buf), L.ptr(buf[C * K:]), 4, L.stream_ptr()) == -1      # PG_ERR_INVALID: unknown flag
     # and the unfused ops of the library agree
     lin.zero_grad()
     th2 = torch.from_numpy(h).to(dev).requires_grad_(True)
