@@ -368,6 +368,8 @@ def reference_equivalent_leg(args, model, loss_fcn, optimizer, cacher, g, subtra
     torch.cuda.synchronize()
     dt = time.time() - t0
     prof, cacher.profile = cacher.profile, None
+    if cacher.misses_timed_out():
+        raise SystemExit("bench.py: reference-equivalent leg: a device-side wait for miss rows timed out")
     D = cacher.total_dim
     avg_ms, R, m, nbytes = gather_launch_stats(cacher, prof, D)
     miss_rate = cacher.get_miss_rate()
@@ -519,7 +521,7 @@ def run():
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu])
     sampler = NeighborSampler(g, B, k, neighbor_type='in', shuffle=True, num_workers=16, num_hops=num_hops,
                               seed_nodes=subtrain, prefetch=True, seed=rank, copy_out=True, static=use_graph,
-                              ring=args.ring if args.ring else (args.lookahead + 2 if args.lookahead else None),
+                              ring=args.ring if args.ring else (args.lookahead + 3 if args.lookahead else None),
                               transpose=None if args.no_transpose else 'auto',
                               defer_transpose=use_graph and not args.inline_transpose)
     steps_per_epoch = parallel.equalize_steps(len(sampler), device=dev)

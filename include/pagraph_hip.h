@@ -186,6 +186,12 @@ int pg_missq_wait(pg_missq_t* q, int slot, pg_stream_t stream, int32_t* miss_cou
 /* same ordering guarantee without ever blocking the host: a one-wave kernel on `stream` sleeps on a device
  * flag the worker's copy stream raises after the scatter (gives up after 3 s -> pg_missq_timed_out).   */
 int pg_missq_wait_device(pg_missq_t* q, int slot, pg_stream_t stream);
+/* blocks the HOST until the worker has left the slot's latest submission (its copy, scatter and signal sit in
+ * the copy stream's queue); touches no stream. The launch thread calls it BEFORE it enqueues — on any stream — a
+ * wait for an event recorded after that submission's consumer (frames consumed, ring slot free): a barrier
+ * packet that shares a hardware queue with the copy stream would otherwise hold back the very copy the consumer's
+ * pg_missq_wait_device kernel is spinning for (3 s stalls once a process owns more streams than hardware queues). */
+int pg_missq_wait_idle(pg_missq_t* q, int slot);
 /* Split every miss list between the two paths: rows [0, count * share / 256) go through the worker (CPU gather +
  * copy engine), the caller reads the rest over PCIe with pg_scatter_rows_from_host_tail(start_num = share) on
  * its own stream. Default 256 = everything through the worker.                                            */

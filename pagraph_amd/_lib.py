@@ -85,6 +85,7 @@ _SIGS = {
     "pg_missq_slot_staged": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]),
     "pg_missq_wait": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.POINTER(c_i32)]),
     "pg_missq_wait_device": (ctypes.c_int, [vp, ctypes.c_int, vp]),
+    "pg_missq_wait_idle": (ctypes.c_int, [vp, ctypes.c_int]),
     "pg_missq_timed_out": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int)]),
     "pg_missq_drain": (ctypes.c_int, [vp]),
     "pg_missq_stats": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double)]),

@@ -60,7 +60,8 @@ __global__ void k_wait_landed(const uint32_t* landed, uint32_t seq, uint32_t* ti
   while ((int32_t)(__hip_atomic_load(landed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
     __builtin_amdgcn_s_sleep(64);
     if (wall_clock64() - t0 > 300000000ull) {     // 3 s: the worker died; do not hang the GPU
-      *timed_out = 1;
+      timed_out[2] = seq;                         // [2]: the sequence number the consumer gave up on
+      timed_out[0] = 1;
       break;
     }
   }
@@ -85,7 +86,8 @@ __global__ void k_wait_hsa_signal(const volatile int64_t* value, uint32_t* timed
   while (__hip_atomic_load(const_cast<const int64_t*>(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) > 0) {
     for (int i = 0; i < poll_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
     if (wall_clock64() - t0 > 300000000ull) {     // 3 s
-      *timed_out = 1;
+      timed_out[1] = 1;                           // [1]: the copy engine's completion signal never came
+      timed_out[0] = 1;
       break;
     }
   }
@@ -534,11 +536,20 @@ int pg_missq_create(int device, int n_slots, int64_t max_rows, const pg_missq_fi
   // same hardware queue never starts: with every stream at normal priority the pipeline deadlocked until the 3 s
   // time-out (measured: PG_PRIO_LOAD=0 PG_PRIO_SAMPLER=0). The copy stream therefore lives in the HIGH priority class,
   // whose hardware queues are separate from those of the normal-priority compute stream. (PG_PRIO_COPY overrides.)
+  //
+  // A class of its own is not enough, though: the sampler and load streams of the SAME pipeline (high priority as
+  // well) wait — barrier packets — for events the compute stream records AFTER its spin kernel (ring slot free, frames
+  // consumed). Once a process has made more high-priority streams than the class has hardware queues (a second
+  // trainer: bench.py's reference-equivalent leg, the tail of a long pytest session) the copy stream shares a queue with
+  // one of them, and if the worker enqueues copy(j) after such a barrier went in, copy(j) sits behind a barrier that
+  // waits for the kernel that waits for copy(j): a 3 s stall per occurrence (measured: 90-1350 ms/step). The launch
+  // thread therefore calls pg_missq_wait_idle(slot) BEFORE it enqueues any wait for an event recorded after the
+  // consumer of that slot's previous job (GraphedTrainer.prepare, NeighborSampler._enqueue): by then copy(j) is in its
+  // queue, ahead of the barrier — whatever the runtime multiplexes.
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   const char* pe = getenv("PG_PRIO_COPY");
-  const int prio = pe ? atoi(pe) : prio_hi;
-  bool ok = hipStreamCreateWithPriority(&q->copy_stream, hipStreamNonBlocking, prio) == hipSuccess;
+  bool ok = hipStreamCreateWithPriority(&q->copy_stream, hipStreamNonBlocking, pe ? atoi(pe) : prio_hi) == hipSuccess;
   ok = ok && hipMalloc((void**)&q->timeout_d, 64) == hipSuccess && hipMemset(q->timeout_d, 0, 64) == hipSuccess;
   for (auto& s : q->slots) {
     ok = ok && hipHostMalloc((void**)&s.fullid_h, max_rows * 8, hipHostMallocDefault) == hipSuccess;
@@ -645,6 +656,16 @@ int pg_missq_wait(pg_missq_t* q, int slot, pg_stream_t stream, int32_t* miss_cou
   return PG_OK;
 }
 
+/* host-side: returns once the worker has left the slot's latest submission (its copy, scatter and signal are
+ * enqueued on the copy stream); no stream is touched. See the note on barrier packets in pg_missq_create. */
+int pg_missq_wait_idle(pg_missq_t* q, int slot) {
+  if (!q || slot < 0 || slot >= q->n_slots) return PG_ERR_INVALID;
+  pg_missq_slot& s = q->slots[slot];
+  std::unique_lock<std::mutex> l(q->m);
+  q->cv_done.wait(l, [&] { return s.done == s.submitted || q->error != PG_OK; });
+  return q->error;
+}
+
 /* device-side variant: enqueues a one-wave kernel on `stream` that sleeps until the slot's rows (of its
  * latest submission) are in place. Never blocks the host. */
 int pg_missq_wait_device(pg_missq_t* q, int slot, pg_stream_t stream) {
@@ -685,9 +706,12 @@ int pg_missq_set_cpu_share(pg_missq_t* q, int32_t share_of_256) {
 /* 1 if a device-side wait ever gave up (worker failure); synchronises the device */
 int pg_missq_timed_out(pg_missq_t* q, int* out) {
   if (!q || !out) return PG_ERR_INVALID;
-  uint32_t v = 0;
-  PG_HIP(hipMemcpy(&v, q->timeout_d, 4, hipMemcpyDeviceToHost));
-  *out = (int)v;
+  uint32_t v[3] = {0, 0, 0};
+  PG_HIP(hipMemcpy(v, q->timeout_d, 12, hipMemcpyDeviceToHost));
+  *out = (int)v[0];
+  if (v[0] && getenv("PG_MISSQ_DEBUG"))
+    fprintf(stderr, "[pg_missq] device-side wait timed out: %s (consumer gave up on seq %u)\n",
+            v[1] ? "copy engine's completion signal" : "rows never landed", v[2]);
   return PG_OK;
 }
 

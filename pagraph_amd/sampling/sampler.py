@@ -121,6 +121,10 @@ class NeighborSampler:
         # True: the consumer calls release(nf) itself once the work that reads the NodeFlow is enqueued
         # (needed when it holds several prepared batches at once); False: released when the iterator advances
         self.manual_release = False
+        # callable(ring slot index) run on the launch thread right before this stream is made to wait for a slot's
+        # "free" event (GraphedTrainer: GraphCacheServer.wait_worker — the barrier must not overtake the miss copy the
+        # slot's consumer is waiting for)
+        self.before_slot_reuse = None
         # transpose: blocks that also come out source-major (NodeFlow.blk_tptr / blk_tdst) so that the backward
         # aggregation is a gather. 'auto' = every block whose input can carry a gradient (all but block 0,
         # whose input is the raw feature frame); or an iterable of block indices; None = none.
@@ -135,7 +139,7 @@ class NeighborSampler:
             raise L.PgError("defer_transpose needs static=True (fixed-shape NodeFlows)")
         self.slots = [_Slot(self.lib, self.handle, self.num_hops, self.device, padded=self.static,
                             transpose_mask=self.transpose_mask, defer_transpose=self.defer_transpose)
-                      for _ in range(ring if ring else (4 if self.static else 3))]
+                      for _ in range(ring if ring else (5 if self.static else 3))]
 
     def __del__(self):
         try:
@@ -180,6 +184,8 @@ class NeighborSampler:
         lo = b * self.batch_size
         n = min(self.batch_size, self.seeds.numel() - lo)
         if slot.free_recorded:
+            if self.before_slot_reuse is not None:
+                self.before_slot_reuse((self._ring_pos - 1) % len(self.slots))
             self.stream.wait_event(slot.free)  # the consumer of the batch that used this slot is done
         with torch.cuda.device(self.device):
             L.check(self.lib.pg_sampler_sample(self.handle, ctypes.c_void_p(self.seeds.data_ptr() + lo * 8), n,

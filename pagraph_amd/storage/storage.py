@@ -225,6 +225,7 @@ class GraphCacheServer:
         # miss_mode == "async": libpagraph's worker-thread miss queue (pg_missq_*), one slot per in-flight batch
         self._missq = None
         self._missq_rows = 0
+        self._missq_nslots = 0
         self._missq_bufs = {}            # slot -> (miss_pos, miss_fullid, miss_count) pointers
         self._missq_pending = set()      # slots submitted to the queue and not yet waited for by their consumer
         # True: consumers wait for the worker on the HOST and then on an event — never a spin-wait kernel on the consuming
@@ -706,9 +707,10 @@ class GraphCacheServer:
 
     def _missq_buffers(self, slot, rows):
         hit = self._missq_bufs.get(slot)
-        if hit is not None and rows <= self._missq_rows:
+        if hit is not None and rows <= self._missq_rows and slot < self._missq_nslots:
             return hit
-        if self._missq is None or rows > self._missq_rows:
+        if self._missq is None or rows > self._missq_rows or slot >= self._missq_nslots:
+            # (a consumer with a deeper ring than the one the queue was made for needs more slots)
             self._missq_bufs = {}
             recreated = self._missq is not None
             if self._missq is not None:
@@ -718,7 +720,7 @@ class GraphCacheServer:
                 torch.cuda.synchronize(self.device)
                 self._missq_pending.clear()
                 L.check(self.lib.pg_missq_destroy(self._missq), "pg_missq_destroy")
-            cap = max(int(rows * 1.25), 4096)
+            cap = max(int(rows * 1.25), 4096, self._missq_rows)
             arr = (L.PgMissqField * len(self.dims))()
             for f, name in enumerate(self.dims):
                 tab = _table(self.graph, name)
@@ -726,7 +728,7 @@ class GraphCacheServer:
             h = L.vp()
             L.check(self.lib.pg_missq_create(self.device.index, self.missq_slots, cap, arr, len(self.dims),
                                              self.host_threads, ctypes.byref(h)), "pg_missq_create")
-            self._missq, self._missq_rows = h, cap
+            self._missq, self._missq_rows, self._missq_nslots = h, cap, self.missq_slots
             self._missq_share = None
             if recreated:
                 self._cache_epoch += 1   # fetch plans hold pointers into the old queue's staging blocks
@@ -762,12 +764,20 @@ class GraphCacheServer:
         else:
             L.check(self.lib.pg_missq_wait_device(self._missq, slot, L.stream_ptr(st)), "pg_missq_wait_device")
 
+    def wait_worker(self, slot):
+        """block the host until the async queue's worker has enqueued the copy of `slot`'s latest submission (no HIP
+        call). The launch thread calls it before it enqueues, on ANY stream, a wait for something that happens after
+        that submission's consumer (frames consumed, sampler ring slot free) — see pg_missq_wait_idle."""
+        if self._missq is not None and slot is not None and 0 <= slot < self._missq_nslots:
+            L.check(self.lib.pg_missq_wait_idle(self._missq, int(slot)), "pg_missq_wait_idle")
+
     def shutdown_miss_queue(self):
         """stop the async queue's worker and gather threads and free its buffers (every submitted batch must have
         been consumed: synchronise the device first)"""
         if self._missq is not None:
             L.check(self.lib.pg_missq_destroy(self._missq), "pg_missq_destroy")
             self._missq, self._missq_rows, self._missq_bufs, self._missq_share = None, 0, {}, None
+            self._missq_nslots = 0
             self._missq_pending.clear()
             self._cache_epoch += 1       # fetch plans (and graphs captured over them) hold pointers into the queue's blocks
 

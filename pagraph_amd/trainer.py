@@ -217,6 +217,9 @@ class GraphedTrainer:
         sampler.consumer_stream = self.compute_stream   # ring slots are recycled after the graph that read them
         sampler.manual_release = True
         cacher.missq_slots = len(sampler.slots)
+        # ring slot i of the sampler carries the batch whose miss job sits in queue slot i: before the sampler waits for
+        # "slot free" (recorded after that batch's consumer) the job's copy must be in its queue — see prepare()
+        sampler.before_slot_reuse = cacher.wait_worker
         # batches prepared ahead of the one being computed. The async miss path needs 2: its worker thread
         # must have finished batch k+1 (GPU publishes the miss list -> CPU gather -> copy enqueued) by the time
         # the host wants to enqueue compute(k+1), i.e. one whole step after it was submitted.
@@ -275,6 +278,10 @@ class GraphedTrainer:
         if dbg is not None:
             ev[1].record(ls)
         if s.done_recorded:
+            # s.done was recorded AFTER the consumer of this slot's previous miss job (possibly a spin kernel waiting for
+            # that job's copy): the worker must have enqueued that copy before this barrier goes into a queue the copy
+            # stream may share (pg_missq_wait_idle). The submit below would block for the same condition anyway.
+            self.cacher.wait_worker(s.slot_index)
             ls.wait_event(s.done)                # the graph that read these buffers has finished
         if dbg is not None:
             ev[2].record(ls)

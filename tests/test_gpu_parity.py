@@ -1817,3 +1817,59 @@ def test_zerocopy_refused_on_pageable_table_and_recapture_after_cache_change(dev
         losses.append(torch.stack([l.detach().float().cpu() for l in out]))
         cc.check_misses()
     assert torch.equal(losses[0], losses[1])       # features are features, wherever they are read from
+
+
+@pytest.mark.gpu
+def test_async_miss_path_survives_hardware_queue_sharing(dev, hiplib):
+    """Regression (round 2): once a process owns more high-priority streams than the class has hardware queues, the miss
+    queue's copy stream shares a queue with the sampler / load stream of its own pipeline; a barrier packet of theirs
+    that waits for "slot free" / "frames consumed" (recorded after the consumer's spin-wait kernel) then held back the
+    very copy that kernel was waiting for — 3 s per occurrence (bench.py's reference-equivalent leg ran at 90-1350
+    ms/step, the last test of a long session timed out). pg_missq_wait_idle orders the launch thread's waits after the
+    worker's enqueue. Here: a crowd of busy high-priority streams, then three pipelines one after the other on the same
+    process; none may stall or lose rows."""
+    import time
+    import torch.nn.functional as Fn
+    from pagraph_amd.model import GCNSampling
+    from pagraph_amd.optim import Adam
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    from pagraph_amd.trainer import GraphedTrainer, cycle_batches
+    crowd = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(9)]
+    junk = torch.zeros(1024, device=dev)
+    for s in crowd:                                  # a stream takes its hardware queue at first use
+        with torch.cuda.stream(s):
+            junk.add_(1.0)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(21)
+    V, Fd, C, B = 20000, 600, 7, 1000
+    g = DeviceGraph(_rand_csc(rng, V, 160000))
+    feats = torch.from_numpy(rng.random((V, Fd), dtype=np.float32))
+    labels = torch.from_numpy(rng.integers(0, C, V)).to(dev)
+    keep = []
+    for rep in range(3):
+        store = HostFeatureStore({"features": feats})
+        c = GraphCacheServer(store, V, torch.arange(V), 0, miss_mode="async")
+        c.init_field(["features"])
+        c.auto_cache(g, ["features"], cache_ratio=0.3)
+        torch.manual_seed(rep)
+        model = GCNSampling(Fd, 32, C, 1, Fn.relu, 0.2).to(dev).train()
+        smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=True, num_hops=2, seed_nodes=np.arange(0, V, 2), seed=rep,
+                              static=True, defer_transpose=True)
+        tr = GraphedTrainer(model, torch.nn.CrossEntropyLoss(), Adam(model.parameters(), lr=1e-2), c, smp, labels, dev,
+                            need=model.required_inputs(3), keep_losses=False)
+        it = cycle_batches(smp, 400)
+        tr.run_steps(it, 20)                          # eager warm-up + captures
+        tr.synchronize(); torch.cuda.synchronize()
+        t0 = time.time()
+        tr.run_steps(it, 300)
+        tr.synchronize(); torch.cuda.synchronize()
+        dt = time.time() - t0
+        c.check_misses()                              # raises if a device-side wait gave up
+        assert dt < 2.5, f"pipeline {rep}: 300 steps took {dt:.2f} s (a 3 s stall per lost copy)"
+        assert torch.isfinite(tr.last_loss).item()
+        keep.append((tr, smp, c))                     # their streams stay alive (and keep their hardware queues)
+        for s in crowd:
+            with torch.cuda.stream(s):
+                junk.add_(1.0)
+    torch.cuda.synchronize()
