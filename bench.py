@@ -362,6 +362,7 @@ def reference_equivalent_leg(args, model, loss_fcn, optimizer, cacher, g, subtra
     torch.cuda.synchronize()
     cacher._stats.zero_()
     cacher.profile = []
+    mq0_ = cacher.miss_queue_stats()
     t0 = time.time()
     tr.run_steps(it, steps)
     cacher.drain_misses()
@@ -376,8 +377,11 @@ def reference_equivalent_leg(args, model, loss_fcn, optimizer, cacher, g, subtra
     while tr._prepared:                     # hand the ring slots back before the sampler goes away
         tr.sampler.release(tr._prepared.pop(0).nf_cur)
     torch.cuda.synchronize()
+    mq1 = cacher.miss_queue_stats()
+    moved = (mq1["rows_per_job"] * mq1["jobs"] - mq0_["rows_per_job"] * mq0_["jobs"]) / steps if mq1 and mq0_ else None
     return {"fetch": "every layer and field (storage.py:173-204)", "steps": steps, "ms_per_step": dt / steps * 1e3,
             "rows_per_launch": R, "miss_rows_per_launch": m,
+            "miss_rows_over_pcie_per_launch_after_index_dedup": moved,
             "cache_hit_pct": 100.0 * (1.0 - miss_rate),
             "gather_avg_launch_ms": avg_ms, "gather_algorithmic_bytes_per_launch": nbytes,
             "gather_GBps": nbytes / avg_ms / 1e6, "gather_frac_of_hbm_peak": nbytes / avg_ms / 1e6 / HBM_PEAK_GBPS}
@@ -692,6 +696,9 @@ def run():
     mq_stats = cacher.miss_queue_stats()
     if mq_stats and mq0:
         mq_stats["timed_region"] = {k_: mq_stats[k_] - mq0[k_] for k_ in ("jobs", "waits_by_event", "waits_by_spin_kernel")}
+        # rows the worker really moved over PCIe (after the miss list's index dedup) per step of the timed region
+        mq_stats["timed_region"]["rows_over_pcie_per_step"] = (mq_stats["rows_per_job"] * mq_stats["jobs"]
+                                                               - mq0["rows_per_job"] * mq0["jobs"]) / max(1, K)
     if timed_out:
         raise SystemExit("bench.py: the async miss queue's device-side wait timed out (worker thread dead?) — "
                          "the timed steps trained on rows that never landed; no number is reported")
@@ -835,6 +842,8 @@ def run():
             # reference-equivalent leg when the timed loop itself fetches only what the model reads
             "cache_hit_pct": (ref_eq["cache_hit_pct"] if isinstance(ref_eq, dict) else 100.0 * (1.0 - miss_rate)),
             "cache_hit_pct_rows_fetched_by_timed_loop": 100.0 * (1.0 - miss_rate),
+            "miss_rows_per_step_reference_counting": miss_total / max(1, K),
+            "miss_list_index_dedup": bool(cacher.dedup_misses and cacher.miss_mode == "async"),
             "reference_equivalent": ref_eq,
             "cache_hit_oracle_upper_bound_pct": opt_hit, "cache_hit_degree_policy_on_trace_pct": deg_hit,
             "feat_gather_GBps": (micro[1 << 20]["GBps"] if micro else achieved),

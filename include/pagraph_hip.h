@@ -109,6 +109,37 @@ int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const
 int pg_split_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map, int32_t* miss_pos,
                   int64_t* miss_fullid, int32_t* miss_count, int32_t* slots_out, uint64_t* stats,
                   pg_stream_t stream);
+/* Miss-list index dedup (north star: "index dedup" in the gather). The reference looks every layer's ids up on
+ * their own (storage.py:173-200), so a vertex that sits in two layers of a NodeFlow is fetched from the host twice
+ * when it misses. With a pg_dedup_t the split pass keeps the FIRST occurrence of a missed id in the miss list and
+ * diverts a later one to the dup list: rows [lo[r], lo[r+1]) are layer r of the launch (lo[0] = 0, lo[n_ranges] = n);
+ * bit r of sorted_mask says layer r's ids ascend (sampler spec rule 5: every non-seed layer; the padding ids < 0 of a
+ * fixed-shape layer sit at its end). A missed row of layer r searches layers 0..r-1 (binary search over `ids`
+ * itself). A repeat: slots_out / slot_scratch[row] stays -1, it is NOT in the miss list, (row, earlier row) is
+ * appended to dup_pos / dup_src (device int32[n]) and *dup_count (device; reset by the call). stats count it as a
+ * miss, like the reference. The consumer resolves dup_src to staged rows once the split has run
+ * (pg_missq_submit_dedup does: dup_src[k] = -slots[dup_src[k]] - 3) and fills the rows with pg_scatter_rows_dups
+ * after the primary rows have landed. Same frames, bit for bit; fewer rows over PCIe.                        */
+typedef struct pg_dedup {
+  int32_t n_ranges;
+  int32_t lo[PG_MAX_LAYERS + 1];
+  uint32_t sorted_mask;
+  int32_t* dup_pos;
+  int32_t* dup_src;
+  int32_t* dup_count;
+} pg_dedup_t;
+int pg_gather_rows_dedup(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
+                         const pg_field_t* fields, int n_fields, int32_t* miss_pos, int64_t* miss_fullid,
+                         int32_t* miss_count, int32_t* slot_scratch, uint64_t* stats, pg_timer_t* timer,
+                         const pg_dedup_t* dedup, pg_stream_t stream);
+int pg_split_rows_dedup(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
+                        int32_t* miss_pos, int64_t* miss_fullid, int32_t* miss_count, int32_t* slots_out,
+                        uint64_t* stats, const pg_dedup_t* dedup, pg_stream_t stream);
+/* out[dup_pos[k] - pos_lo, :] = staged[dup_staged_row[k], :] for k < *dup_count_dev (entries below pos_lo or with a
+ * negative staged row are skipped); cap = launch upper bound                                               */
+int pg_scatter_rows_dups(const float* staged, const int32_t* dup_pos, const int32_t* dup_staged_row, int64_t cap,
+                         const int32_t* dup_count_dev, int32_t dim, float* out, int32_t out_stride, int32_t pos_lo,
+                         pg_stream_t stream);
 int pg_gather_rows_presplit(const int32_t* slots, int64_t n, const pg_field_t* fields, int n_fields,
                             pg_timer_t* timer, pg_stream_t stream);
 
@@ -177,6 +208,14 @@ int pg_missq_submit(pg_missq_t* q, int slot, float* const* out_ptrs, const int32
  * nothing of field f is scattered (copy only); NULL with stride 0: field not wanted.                  */
 int pg_missq_submit_range(pg_missq_t* q, int slot, float* const* out_ptrs, const int32_t* out_strides,
                           const int32_t* pos_lo, pg_stream_t stream);
+/* pg_missq_submit_range for a launch that was split with a pg_dedup_t over the slot's dup buffers
+ * (pg_missq_slot_dup_buffers): `slots_dev` = the slot array that split wrote (still intact at this point of
+ * `stream`). The publish step turns every dup entry's "earlier row" into that row's staged index; after the primary
+ * rows' scatter the worker fills the repeats on the device (pg_scatter_rows_dups) — they never cross PCIe. */
+int pg_missq_submit_dedup(pg_missq_t* q, int slot, float* const* out_ptrs, const int32_t* out_strides,
+                          const int32_t* pos_lo, const int32_t* slots_dev, pg_stream_t stream);
+int pg_missq_slot_dup_buffers(pg_missq_t* q, int slot, int32_t** dup_pos_dev, int32_t** dup_src_dev,
+                              int32_t** dup_count_dev);
 /* device staging block of (slot, field): [max_rows, dim] floats, row j = entry j of the slot's miss list once
  * the slot's wait (pg_missq_wait / _wait_device) has passed                                              */
 int pg_missq_slot_staged(pg_missq_t* q, int slot, int field, float** staged_dev);

@@ -48,6 +48,11 @@ class PgRowSource(ctypes.Structure):
                 ("edge_slots", vp)]
 
 
+class PgDedup(ctypes.Structure):
+    _fields_ = [("n_ranges", c_i32), ("lo", c_i32 * (PG_MAX_LAYERS + 1)), ("sorted_mask", c_u32), ("dup_pos", vp),
+                ("dup_src", vp), ("dup_count", vp)]
+
+
 class PgDropout(ctypes.Structure):
     _fields_ = [("threshold", c_u32), ("tag", c_u32), ("seed", c_u64), ("step", vp)]
 
@@ -66,6 +71,10 @@ _SIGS = {
     "pg_slot_map_export": (ctypes.c_int, [vp, c_i64, vp, vp, vp]),
     "pg_gather_rows": (ctypes.c_int, [vp, c_i64, vp, vp, ctypes.POINTER(PgField), ctypes.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "pg_split_rows": (ctypes.c_int, [vp, c_i64, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "pg_gather_rows_dedup": (ctypes.c_int, [vp, c_i64, vp, vp, ctypes.POINTER(PgField), ctypes.c_int, vp, vp, vp, vp, vp, vp,
+                                            ctypes.POINTER(PgDedup), vp]),
+    "pg_split_rows_dedup": (ctypes.c_int, [vp, c_i64, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(PgDedup), vp]),
+    "pg_scatter_rows_dups": (ctypes.c_int, [vp, vp, vp, c_i64, vp, c_i32, vp, c_i32, c_i32, vp]),
     "pg_gather_rows_presplit": (ctypes.c_int, [vp, c_i64, ctypes.POINTER(PgField), ctypes.c_int, vp, vp]),
     "pg_gather_rows_full": (ctypes.c_int, [vp, c_i64, ctypes.POINTER(PgField), ctypes.c_int, vp]),
     "pg_gather_labels": (ctypes.c_int, [vp, c_i64, vp, c_i64, c_i64, vp, vp, vp]),
@@ -82,6 +91,10 @@ _SIGS = {
     "pg_missq_submit": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(c_i32), vp]),
     "pg_missq_submit_range": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(c_i32),
                                              ctypes.POINTER(c_i32), vp]),
+    "pg_missq_submit_dedup": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(c_i32),
+                                             ctypes.POINTER(c_i32), vp, vp]),
+    "pg_missq_slot_dup_buffers": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                                 ctypes.POINTER(vp)]),
     "pg_missq_slot_staged": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]),
     "pg_missq_wait": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.POINTER(c_i32)]),
     "pg_missq_wait_device": (ctypes.c_int, [vp, ctypes.c_int, vp]),

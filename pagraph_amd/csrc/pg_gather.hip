@@ -97,14 +97,43 @@ __device__ __forceinline__ void copy_tile(const pg_field_t fd, const int32_t* s_
   }
 }
 
+// Miss-list index dedup (north star: "index dedup" in the gather; the reference fetches a vertex once per LAYER it
+// appears in, storage.py:176-200). A NodeFlow's layers are each duplicate-free, but a vertex can sit in several
+// layers; for a cache HIT the repeat costs an L2/MALL read, for a MISS it costs a second trip over PCIe — the
+// bound of the step at a partial cache (measured on the benchmark graph: 6.0 % of the miss rows of a minibatch
+// are such repeats, tools/exp_dup_census.py). Non-seed layers are sorted by id (sampler spec rule 5), so a missed
+// row of layer l looks its id up in the layers before it with a binary search over the id array itself — no hash
+// table, no extra memory. A repeat is NOT appended to the miss list; it goes to the dup list as (row, earlier row)
+// and is filled on the device from the earlier row's staged copy (pg_scatter_rows_dups) once that has landed.
+struct SplitDedup {
+  int32_t n_ranges;
+  int32_t lo[PG_MAX_LAYERS + 1];
+  uint32_t sorted_mask;
+  int32_t* dup_pos;
+  int32_t* dup_src;
+  int32_t* dup_count;
+};
+
+// first row in [lo, hi) whose id is >= `id`, ids ascending with the padding (< 0) of a fixed-shape layer at the end
+__device__ __forceinline__ int32_t lower_bound_ids(const int64_t* __restrict__ ids, int32_t lo, int32_t hi, int64_t id) {
+  while (lo < hi) {
+    const int32_t mid = (int32_t)(((int64_t)lo + hi) >> 1);
+    const int64_t v = ids[mid];
+    if (v >= 0 && v < id) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
 // hit/miss split: appends (row, nid_map[id]) of every row with slot_map[id] < 0 to the miss list
+template <bool DEDUP>
 __global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ ids, int64_t n,
                                                const int32_t* __restrict__ slot_map,
                                                const int64_t* __restrict__ nid_map, int32_t* __restrict__ miss_pos,
                                                int64_t* __restrict__ miss_fullid, int32_t* __restrict__ miss_count,
                                                int32_t* __restrict__ slots_out,
-                                               unsigned long long* __restrict__ stats) {
-  __shared__ int32_t s_wave[4], s_valid[4];
+                                               unsigned long long* __restrict__ stats, const SplitDedup dd) {
+  __shared__ int32_t s_wave[4], s_valid[4], s_dups[4];
   __shared__ int32_t s_base;
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
   const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -116,19 +145,48 @@ __global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ ids, 
     miss = s == -1;
     if (slots_out) slots_out[row] = s;  // coalesced; k_gather then skips the random slot_map lookup
   }
+  int32_t n_dup_wave = 0;
+  if constexpr (DEDUP) {
+    int32_t dup_of = -1;
+    if (miss) {
+      int r = 0;
+      while (r + 1 < dd.n_ranges && row >= dd.lo[r + 1]) ++r;
+      // earliest layer first: the row found there is a primary miss itself (it has nothing before it to repeat)
+      for (int q = 0; q < r && dup_of < 0; ++q) {
+        if (!((dd.sorted_mask >> q) & 1u)) continue;
+        const int32_t a = lower_bound_ids(ids, dd.lo[q], dd.lo[q + 1], id);
+        if (a < dd.lo[q + 1] && ids[a] == id) dup_of = a;
+      }
+    }
+    const unsigned long long dmask = __ballot(dup_of >= 0);
+    n_dup_wave = (int32_t)__popcll(dmask);
+    if (dmask) {
+      int32_t base = 0;
+      if (lane == 0) base = atomicAdd(dd.dup_count, n_dup_wave);
+      base = __shfl(base, 0);
+      if (dup_of >= 0) {
+        const int32_t k = base + (int32_t)__popcll(dmask & ((1ull << lane) - 1ull));
+        dd.dup_pos[k] = (int32_t)row;
+        dd.dup_src[k] = dup_of;
+        miss = false;            // stays out of the miss list; its slot stays -1 (k_gather skips it)
+      }
+    }
+  }
   const unsigned long long mmask = __ballot(miss);
   const unsigned long long vmask = __ballot(row < n && id >= 0);
   if (lane == 0) {
     s_wave[w] = (int32_t)__popcll(mmask);
     s_valid[w] = (int32_t)__popcll(vmask);
+    s_dups[w] = n_dup_wave;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     const int32_t tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
     s_base = tot ? atomicAdd(miss_count, tot) : 0;
-    if (stats) {  // storage.py:219-221 log_miss_rate, kept on the device
+    if (stats) {  // storage.py:219-221 log_miss_rate, kept on the device; a repeated miss counts as a miss, as there
+      const int32_t missed = tot + s_dups[0] + s_dups[1] + s_dups[2] + s_dups[3];
       atomicAdd(&stats[0], (unsigned long long)(s_valid[0] + s_valid[1] + s_valid[2] + s_valid[3]));
-      if (tot) atomicAdd(&stats[1], (unsigned long long)tot);
+      if (missed) atomicAdd(&stats[1], (unsigned long long)missed);
     }
   }
   __syncthreads();
@@ -188,12 +246,13 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(const GatherArgs a) {
   }
 }
 
-// out[pos[j], :] = staged[j, :]  — wave per row (storage.py:199-200)
+// out[pos[j], :] = staged[src_row ? src_row[j] : j, :]  — wave per row (storage.py:199-200)
 template <int VEC>
 __global__ __launch_bounds__(256) void k_scatter(const float* __restrict__ staged,
                                                  const int32_t* __restrict__ pos, int64_t n,
                                                  const int32_t* __restrict__ n_dev, int32_t dim,
-                                                 float* __restrict__ out, int32_t out_stride, int32_t pos_lo) {
+                                                 float* __restrict__ out, int32_t out_stride, int32_t pos_lo,
+                                                 const int32_t* __restrict__ src_row) {
   using V = typename VecT<VEC>::type;
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t nn = n_dev ? (int64_t)*n_dev : n;
@@ -202,7 +261,9 @@ __global__ __launch_bounds__(256) void k_scatter(const float* __restrict__ stage
   for (int64_t j = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; j < nn; j += waves) {
     const int32_t p = pos[j] - pos_lo;
     if (p < 0) continue;          // a row below pos_lo stays where it is: its consumer reads the staged block
-    const V* src = reinterpret_cast<const V*>(staged + j * dim);
+    const int64_t sj = src_row ? (int64_t)src_row[j] : j;   // dup list: staged row of the earlier occurrence
+    if (sj < 0) continue;
+    const V* src = reinterpret_cast<const V*>(staged + sj * dim);
     V* dst = reinterpret_cast<V*>(out + (int64_t)p * out_stride);
     for (int c = lane; c < pieces; c += kWave) dst[c] = src[c];
   }
@@ -339,6 +400,33 @@ __global__ __launch_bounds__(256) void k_gather_labels(const int64_t* __restrict
   }
 }
 
+static int launch_split(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map, int32_t* miss_pos,
+                        int64_t* miss_fullid, int32_t* miss_count, int32_t* slots_out, uint64_t* stats,
+                        const pg_dedup_t* dedup, hipStream_t st) {
+  SplitDedup dd{};
+  const unsigned grid = (unsigned)ceil_div<int64_t>(n, 256);
+  unsigned long long* sp = reinterpret_cast<unsigned long long*>(stats);
+  if (dedup) {
+    if (dedup->n_ranges < 1 || dedup->n_ranges > PG_MAX_LAYERS || !dedup->dup_pos || !dedup->dup_src || !dedup->dup_count)
+      return PG_ERR_INVALID;
+    if (dedup->lo[0] != 0 || dedup->lo[dedup->n_ranges] != n) return PG_ERR_INVALID;
+    for (int r = 0; r < dedup->n_ranges; ++r)
+      if (dedup->lo[r] > dedup->lo[r + 1]) return PG_ERR_INVALID;
+    dd.n_ranges = dedup->n_ranges;
+    for (int r = 0; r <= dedup->n_ranges; ++r) dd.lo[r] = dedup->lo[r];
+    dd.sorted_mask = dedup->sorted_mask;
+    dd.dup_pos = dedup->dup_pos; dd.dup_src = dedup->dup_src; dd.dup_count = dedup->dup_count;
+  }
+  if (dedup && dedup->n_ranges > 1 && (dedup->sorted_mask & ((1u << (dedup->n_ranges - 1)) - 1u)))
+    hipLaunchKernelGGL(k_split<true>, dim3(grid), dim3(256), 0, st, ids, n, slot_map, nid_map, miss_pos, miss_fullid,
+                       miss_count, slots_out, sp, dd);
+  else
+    hipLaunchKernelGGL(k_split<false>, dim3(grid), dim3(256), 0, st, ids, n, slot_map, nid_map, miss_pos, miss_fullid,
+                       miss_count, slots_out, sp, dd);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
 }  // namespace pg
 
 using namespace pg;
@@ -373,15 +461,17 @@ int pg_slot_map_export(const int32_t* slot_map, int64_t node_num, uint8_t* gpu_f
   return PG_OK;
 }
 
-int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
-                   const pg_field_t* fields, int n_fields, int32_t* miss_pos, int64_t* miss_fullid,
-                   int32_t* miss_count, int32_t* slot_scratch, uint64_t* stats, pg_timer_t* timer,
-                   pg_stream_t stream) {
+int pg_gather_rows_dedup(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
+                         const pg_field_t* fields, int n_fields, int32_t* miss_pos, int64_t* miss_fullid,
+                         int32_t* miss_count, int32_t* slot_scratch, uint64_t* stats, pg_timer_t* timer,
+                         const pg_dedup_t* dedup, pg_stream_t stream) {
   if (n < 0 || n > INT32_MAX || !miss_count) return PG_ERR_INVALID;
   hipStream_t st = as_stream(stream);
   PG_HIP(hipMemsetAsync(miss_count, 0, sizeof(int32_t), st));
+  if (dedup && dedup->dup_count) PG_HIP(hipMemsetAsync(dedup->dup_count, 0, sizeof(int32_t), st));
   if (n == 0) return PG_OK;
   if (!ids || !slot_map || !nid_map || !miss_pos || !miss_fullid) return PG_ERR_INVALID;
+  if (dedup && !slot_scratch) return PG_ERR_INVALID;      // the repeats are resolved through the slot array
   GatherArgs a{};
   a.ids = ids; a.slot_map = slot_map; a.nid_map = nid_map;
   a.miss_pos = miss_pos; a.miss_fullid = miss_fullid; a.miss_count = miss_count;
@@ -390,24 +480,53 @@ int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const
   // a partially cached server may have an empty cache (cache == NULL): every row misses
   int rc = fill_args(a, fields, n_fields, false);
   if (rc != PG_OK) return rc;
-  hipLaunchKernelGGL(k_split, dim3((unsigned)ceil_div<int64_t>(n, 256)), dim3(256), 0, st, ids, n, slot_map, nid_map,
-                     miss_pos, miss_fullid, miss_count, slot_scratch,
-                     reinterpret_cast<unsigned long long*>(stats));
-  PG_LAUNCH_CHECK();
+  rc = launch_split(ids, n, slot_map, nid_map, miss_pos, miss_fullid, miss_count, slot_scratch, stats, dedup, st);
+  if (rc != PG_OK) return rc;
   // the timer brackets ONLY the copy kernel (what rocprofv3 reports as pg::k_gather)
   return launch_gather<false>(a, st, timer);
+}
+
+int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
+                   const pg_field_t* fields, int n_fields, int32_t* miss_pos, int64_t* miss_fullid,
+                   int32_t* miss_count, int32_t* slot_scratch, uint64_t* stats, pg_timer_t* timer,
+                   pg_stream_t stream) {
+  return pg_gather_rows_dedup(ids, n, slot_map, nid_map, fields, n_fields, miss_pos, miss_fullid, miss_count,
+                              slot_scratch, stats, timer, nullptr, stream);
 }
 
 int pg_split_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map, int32_t* miss_pos,
                   int64_t* miss_fullid, int32_t* miss_count, int32_t* slots_out, uint64_t* stats,
                   pg_stream_t stream) {
+  return pg_split_rows_dedup(ids, n, slot_map, nid_map, miss_pos, miss_fullid, miss_count, slots_out, stats, nullptr,
+                             stream);
+}
+
+int pg_split_rows_dedup(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
+                        int32_t* miss_pos, int64_t* miss_fullid, int32_t* miss_count, int32_t* slots_out,
+                        uint64_t* stats, const pg_dedup_t* dedup, pg_stream_t stream) {
   if (n < 0 || n > INT32_MAX || !miss_count) return PG_ERR_INVALID;
   hipStream_t st = as_stream(stream);
   PG_HIP(hipMemsetAsync(miss_count, 0, sizeof(int32_t), st));
+  if (dedup && dedup->dup_count) PG_HIP(hipMemsetAsync(dedup->dup_count, 0, sizeof(int32_t), st));
   if (n == 0) return PG_OK;
   if (!ids || !slot_map || !nid_map || !miss_pos || !miss_fullid || !slots_out) return PG_ERR_INVALID;
-  hipLaunchKernelGGL(k_split, dim3((unsigned)ceil_div<int64_t>(n, 256)), dim3(256), 0, st, ids, n, slot_map, nid_map,
-                     miss_pos, miss_fullid, miss_count, slots_out, reinterpret_cast<unsigned long long*>(stats));
+  return launch_split(ids, n, slot_map, nid_map, miss_pos, miss_fullid, miss_count, slots_out, stats, dedup, st);
+}
+
+int pg_scatter_rows_dups(const float* staged, const int32_t* dup_pos, const int32_t* dup_staged_row, int64_t cap,
+                         const int32_t* dup_count_dev, int32_t dim, float* out, int32_t out_stride, int32_t pos_lo,
+                         pg_stream_t stream) {
+  if (cap < 0 || dim <= 0 || out_stride < dim || pos_lo < 0) return PG_ERR_INVALID;
+  if (cap == 0) return PG_OK;
+  if (!staged || !dup_pos || !dup_staged_row || !dup_count_dev || !out) return PG_ERR_INVALID;
+  hipStream_t st = as_stream(stream);
+  const int grid = 64;     // a few hundred rows per minibatch: 256 waves take them in one or two rounds
+  if (dim % 4 == 0 && out_stride % 4 == 0 && aligned(staged, 16) && aligned(out, 16))
+    hipLaunchKernelGGL(k_scatter<4>, dim3(grid), dim3(256), 0, st, staged, dup_pos, cap, dup_count_dev, dim, out, out_stride, pos_lo, dup_staged_row);
+  else if (dim % 2 == 0 && out_stride % 2 == 0 && aligned(staged, 8) && aligned(out, 8))
+    hipLaunchKernelGGL(k_scatter<2>, dim3(grid), dim3(256), 0, st, staged, dup_pos, cap, dup_count_dev, dim, out, out_stride, pos_lo, dup_staged_row);
+  else
+    hipLaunchKernelGGL(k_scatter<1>, dim3(grid), dim3(256), 0, st, staged, dup_pos, cap, dup_count_dev, dim, out, out_stride, pos_lo, dup_staged_row);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
@@ -463,11 +582,11 @@ int pg_scatter_rows_range(const float* staged, const int32_t* pos, int64_t n, co
   hipStream_t st = as_stream(stream);
   const int grid = grid_1d(n, 4, 8192);
   if (dim % 4 == 0 && out_stride % 4 == 0 && aligned(staged, 16) && aligned(out, 16))
-    hipLaunchKernelGGL(k_scatter<4>, dim3(grid), dim3(256), 0, st, staged, pos, n, n_dev, dim, out, out_stride, pos_lo);
+    hipLaunchKernelGGL(k_scatter<4>, dim3(grid), dim3(256), 0, st, staged, pos, n, n_dev, dim, out, out_stride, pos_lo, nullptr);
   else if (dim % 2 == 0 && out_stride % 2 == 0 && aligned(staged, 8) && aligned(out, 8))
-    hipLaunchKernelGGL(k_scatter<2>, dim3(grid), dim3(256), 0, st, staged, pos, n, n_dev, dim, out, out_stride, pos_lo);
+    hipLaunchKernelGGL(k_scatter<2>, dim3(grid), dim3(256), 0, st, staged, pos, n, n_dev, dim, out, out_stride, pos_lo, nullptr);
   else
-    hipLaunchKernelGGL(k_scatter<1>, dim3(grid), dim3(256), 0, st, staged, pos, n, n_dev, dim, out, out_stride, pos_lo);
+    hipLaunchKernelGGL(k_scatter<1>, dim3(grid), dim3(256), 0, st, staged, pos, n, n_dev, dim, out, out_stride, pos_lo, nullptr);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }

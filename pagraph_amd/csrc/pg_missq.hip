@@ -46,6 +46,25 @@ __global__ void k_publish(const int32_t* __restrict__ count_dev, int32_t* count_
   __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// k_publish for a launch whose split ran with index dedup: every dup entry's "earlier row" becomes that row's
+// staged index (the split wrote -(j + 3) into the primary's slot), then the count is published as above
+__global__ __launch_bounds__(256) void k_publish_dedup(const int32_t* __restrict__ count_dev, int32_t* count_host,
+                                                       uint32_t* flag_host, uint32_t seq,
+                                                       const int32_t* __restrict__ slots, int32_t* __restrict__ dup_src,
+                                                       const int32_t* __restrict__ dup_count) {
+  const int32_t nd = *dup_count;
+  for (int32_t k = threadIdx.x; k < nd; k += blockDim.x) {
+    const int32_t s = slots[dup_src[k]];
+    dup_src[k] = s <= -3 ? -s - 3 : -1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *count_host = *count_dev;
+    __threadfence_system();
+    __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // copy stream -> consumer stream hand-off WITHOUT the host: the worker's copy stream raises `landed`
 // after the scatter kernel; the consumer stream runs a one-wave kernel that sleeps on it. The trainer
 // thread therefore never waits for the worker (a host-side wait made the whole pipeline settle in a
@@ -213,6 +232,10 @@ struct pg_missq_slot {
   uint32_t* flag_h = nullptr;    // pinned
   int32_t* pos_d = nullptr;      // device [max_rows]
   int32_t* count_d = nullptr;    // device
+  int32_t* dup_pos_d = nullptr;  // device [max_rows]: rows that repeat an earlier missed id (index dedup) ...
+  int32_t* dup_src_d = nullptr;  // device [max_rows]: ... and the earlier row, resolved to its staged row at publish
+  int32_t* dup_count_d = nullptr;
+  bool dedup = false;            // this submission carries a dup list
   uint32_t* landed_d = nullptr;  // device: last sequence number whose rows are in place (k_signal)
   float* staging_h[PG_MAX_FIELDS] = {nullptr};  // pinned [max_rows * dim]
   float* staged_d[PG_MAX_FIELDS] = {nullptr};   // device [max_rows * dim]
@@ -449,6 +472,9 @@ static void missq_worker(pg_missq* q) {
         if (rc == PG_OK && s.out[f])
           rc = pg_scatter_rows_range(s.staged_d[f], s.pos_d, m, nullptr, fd.dim, s.out[f], s.out_stride[f],
                                      s.pos_lo[f], (pg_stream_t)q->copy_stream);   // storage.py:199-200
+        if (rc == PG_OK && s.out[f] && s.dedup)    // repeats of a missed id: copied on the device, never over PCIe
+          rc = pg_scatter_rows_dups(s.staged_d[f], s.dup_pos_d, s.dup_src_d, q->max_rows, s.dup_count_d, fd.dim,
+                                    s.out[f], s.out_stride[f], s.pos_lo[f], (pg_stream_t)q->copy_stream);
         te += us(tb, now());
       }
     }
@@ -500,6 +526,9 @@ static void missq_free(pg_missq* q) {
     (void)hipHostFree(s.flag_h);
     (void)hipFree(s.pos_d);
     (void)hipFree(s.count_d);
+    (void)hipFree(s.dup_pos_d);
+    (void)hipFree(s.dup_src_d);
+    (void)hipFree(s.dup_count_d);
     (void)hipFree(s.landed_d);
     for (int f = 0; f < PG_MAX_FIELDS; ++f) {
       (void)hipHostFree(s.staging_h[f]);
@@ -557,6 +586,9 @@ int pg_missq_create(int device, int n_slots, int64_t max_rows, const pg_missq_fi
     ok = ok && hipHostMalloc((void**)&s.flag_h, 64, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMalloc((void**)&s.pos_d, max_rows * 4) == hipSuccess;
     ok = ok && hipMalloc((void**)&s.count_d, 64) == hipSuccess;
+    ok = ok && hipMalloc((void**)&s.dup_pos_d, max_rows * 4) == hipSuccess;
+    ok = ok && hipMalloc((void**)&s.dup_src_d, max_rows * 4) == hipSuccess;
+    ok = ok && hipMalloc((void**)&s.dup_count_d, 64) == hipSuccess && hipMemset(s.dup_count_d, 0, 64) == hipSuccess;
     ok = ok && (q->wait_value ? hipExtMallocWithFlags((void**)&s.landed_d, 8, hipMallocSignalMemory)
                               : hipMalloc((void**)&s.landed_d, 64)) == hipSuccess;
     for (int f = 0; f < n_fields && ok; ++f) {
@@ -615,7 +647,24 @@ int pg_missq_slot_staged(pg_missq_t* q, int slot, int field, float** staged_dev)
 
 int pg_missq_submit_range(pg_missq_t* q, int slot, float* const* out_ptrs, const int32_t* out_strides,
                           const int32_t* pos_lo, pg_stream_t stream) {
+  return pg_missq_submit_dedup(q, slot, out_ptrs, out_strides, pos_lo, nullptr, stream);
+}
+
+int pg_missq_slot_dup_buffers(pg_missq_t* q, int slot, int32_t** dup_pos_dev, int32_t** dup_src_dev,
+                              int32_t** dup_count_dev) {
+  if (!q || slot < 0 || slot >= q->n_slots) return PG_ERR_INVALID;
+  pg_missq_slot& s = q->slots[slot];
+  if (dup_pos_dev) *dup_pos_dev = s.dup_pos_d;
+  if (dup_src_dev) *dup_src_dev = s.dup_src_d;
+  if (dup_count_dev) *dup_count_dev = s.dup_count_d;
+  return PG_OK;
+}
+
+int pg_missq_submit_dedup(pg_missq_t* q, int slot, float* const* out_ptrs, const int32_t* out_strides,
+                          const int32_t* pos_lo, const int32_t* slots_dev, pg_stream_t stream) {
   if (!q || slot < 0 || slot >= q->n_slots || !out_ptrs || !out_strides) return PG_ERR_INVALID;
+  // the repeats are filled from the worker's staged rows: every primary row must go through the worker
+  if (slots_dev && q->cpu_share.load(std::memory_order_relaxed) != 256) return PG_ERR_UNSUPPORTED;
   pg_missq_slot& s = q->slots[slot];
   uint32_t seq;
   {
@@ -630,8 +679,13 @@ int pg_missq_submit_range(pg_missq_t* q, int slot, float* const* out_ptrs, const
       s.out_stride[f] = out_strides[f];
       s.pos_lo[f] = pos_lo ? pos_lo[f] : 0;
     }
+    s.dedup = slots_dev != nullptr;
   }
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, as_stream(stream), s.count_d, s.count_h, s.flag_h, seq);
+  if (slots_dev)
+    hipLaunchKernelGGL(k_publish_dedup, dim3(1), dim3(256), 0, as_stream(stream), s.count_d, s.count_h, s.flag_h, seq,
+                       slots_dev, s.dup_src_d, s.dup_count_d);
+  else
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, as_stream(stream), s.count_d, s.count_h, s.flag_h, seq);
   PG_LAUNCH_CHECK();
   {
     std::lock_guard<std::mutex> l(q->m);

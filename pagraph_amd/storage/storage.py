@@ -170,7 +170,9 @@ _HOST_WAIT = bool(os.environ.get("PG_MISSQ_HOST_WAIT"))
 class _FetchPlan:
     __slots__ = ("names", "row_lo", "rows", "out", "fields", "n_fields", "optrs", "ostr", "cache_epoch",
                  # fused layer-0 path (virtual rows): per-plan slot array, dense sub-range, RowSources by (layer, field)
-                 "slots", "dense_lo", "dense_rows", "poslo", "row_sources", "virtual")
+                 "slots", "dense_lo", "dense_rows", "poslo", "row_sources", "virtual",
+                 # miss-list index dedup: layer boundaries inside the launch, what _dedup_for needs, the pg_dedup_t
+                 "layer_lo", "first_layer", "num_layers", "same_fields", "dedup")
 
 
 class GraphCacheServer:
@@ -240,6 +242,10 @@ class GraphCacheServer:
         # miss_mode 'async': the leading share of every miss list goes through the worker thread (CPU gather + copy
         # engine), the rest is read by the device over PCIe on the fetching stream; 1.0 = all through the worker
         self.cpu_share = 1.0
+        # index dedup of the miss list (pg_dedup_t): a vertex that misses in several layers of one NodeFlow crosses PCIe
+        # once and is copied on the device for the other layers. Async queue only. PG_DEDUP_MISSES=0 turns it off.
+        self.dedup_misses = os.environ.get("PG_DEDUP_MISSES", "1") != "0"
+        self._missq_dup = {}
 
     # -- reference-shaped views of the fused slot map --------------------------
     def _export(self):
@@ -464,9 +470,16 @@ class GraphCacheServer:
             if self.profile is not None:
                 timer = L.vp()
                 L.check(self.lib.pg_timer_create(ctypes.byref(timer)), "pg_timer_create")
-            L.check(self.lib.pg_gather_rows(L.ptr(nf_nids), R, L.ptr(self.slot_map), L.ptr(self.nid_map), fields, nf,
-                                            miss_pos, miss_fullid, miss_count,
-                                            L.ptr(self._slots), L.ptr(self._stats) if self.log else None, timer, sp),
+            dd = None
+            if self.miss_mode == "async":
+                lay = sorted(need) if need is not None else list(range(nodeflow.num_layers))
+                same = need is None or all(set(need[l]) == set(need[lay[0]]) for l in lay)
+                dd = self._dedup_for(slot, [offsets[l] - row_lo for l in lay] + [offsets[lay[-1] + 1] - row_lo], lay[0],
+                                     nodeflow.num_layers, same)
+            L.check(self.lib.pg_gather_rows_dedup(L.ptr(nf_nids), R, L.ptr(self.slot_map), L.ptr(self.nid_map), fields, nf,
+                                                  miss_pos, miss_fullid, miss_count,
+                                                  L.ptr(self._slots), L.ptr(self._stats) if self.log else None, timer,
+                                                  ctypes.byref(dd) if dd is not None else None, sp),
                     "pg_gather_rows")
             if timer is not None:
                 self.profile.append([timer, R, None])
@@ -478,7 +491,8 @@ class GraphCacheServer:
                     if name in out and name in names:
                         optrs[f] = out[name].data_ptr()
                         ostr[f] = out[name].stride(0)
-                L.check(self.lib.pg_missq_submit(self._missq, slot, optrs, ostr, sp), "pg_missq_submit")
+                L.check(self.lib.pg_missq_submit_dedup(self._missq, slot, optrs, ostr, None,
+                                                       L.ptr(self._slots) if dd is not None else None, sp), "pg_missq_submit")
                 self._missq_pending.add(slot)
                 if self._missq_share < 256:
                     self._device_tail(names, out, miss_pos, miss_fullid, miss_count, R, sp)
@@ -569,6 +583,10 @@ class GraphCacheServer:
             names = [n for n in names if n in wanted]
             lo, hi = offsets[layers[0]], offsets[layers[-1] + 1]
         plan.names, plan.row_lo, plan.rows = names, lo, hi - lo
+        plan.layer_lo = [offsets[l] - lo for l in layers] + [hi - lo]
+        plan.first_layer, plan.num_layers = layers[0], len(offsets) - 1
+        plan.same_fields = need is None or all(set(need[l]) == set(need[layers[0]]) for l in layers)
+        plan.dedup = False             # False = not looked at yet (needs the slot's queue buffers); None = no dedup
         # ---- which leading layers stay un-materialised -------------------------------------------------------
         vlayers = []
         if virtual and (self.full_cached or self.miss_mode == "async") and (self.full_cached or slot is not None):
@@ -646,15 +664,18 @@ class GraphCacheServer:
         if self.profile is not None:
             timer = L.vp()
             L.check(self.lib.pg_timer_create(ctypes.byref(timer)), "pg_timer_create")
-        L.check(self.lib.pg_gather_rows(ids, R, L.ptr(self.slot_map), L.ptr(self.nid_map), plan.fields, plan.n_fields,
-                                        miss_pos, miss_fullid, miss_count, L.ptr(self._slots),
-                                        L.ptr(self._stats) if self.log else None, timer, sp), "pg_gather_rows")
+        dd = self._plan_dedup(plan, slot) if self.miss_mode == "async" and not self.full_cached else None
+        L.check(self.lib.pg_gather_rows_dedup(ids, R, L.ptr(self.slot_map), L.ptr(self.nid_map), plan.fields, plan.n_fields,
+                                              miss_pos, miss_fullid, miss_count, L.ptr(self._slots),
+                                              L.ptr(self._stats) if self.log else None, timer,
+                                              ctypes.byref(dd) if dd is not None else None, sp), "pg_gather_rows")
         if timer is not None:
             self.profile.append([timer, R, None])
         if self.full_cached:
             return                       # every row was a hit (the general kernel ran only for the hit counters)
         if self.miss_mode == "async":
-            L.check(self.lib.pg_missq_submit(self._missq, slot, plan.optrs, plan.ostr, sp), "pg_missq_submit")
+            L.check(self.lib.pg_missq_submit_dedup(self._missq, slot, plan.optrs, plan.ostr, None,
+                                                   L.ptr(self._slots) if dd is not None else None, sp), "pg_missq_submit")
             self._missq_pending.add(slot)
             if self._missq_share < 256:
                 self._device_tail(plan.names, plan.out, miss_pos, miss_fullid, miss_count, R, sp)
@@ -678,8 +699,10 @@ class GraphCacheServer:
         else:
             self._ensure_capacity(R)
             miss_pos, miss_fullid, miss_count = L.ptr(self._miss_pos), L.ptr(self._miss_fullid), L.ptr(self._miss_count)
-        L.check(self.lib.pg_split_rows(ids, R, L.ptr(self.slot_map), L.ptr(self.nid_map), miss_pos, miss_fullid,
-                                       miss_count, L.ptr(plan.slots), L.ptr(self._stats) if self.log else None, sp),
+        dd = self._plan_dedup(plan, slot) if use_q else None
+        L.check(self.lib.pg_split_rows_dedup(ids, R, L.ptr(self.slot_map), L.ptr(self.nid_map), miss_pos, miss_fullid,
+                                             miss_count, L.ptr(plan.slots), L.ptr(self._stats) if self.log else None,
+                                             ctypes.byref(dd) if dd is not None else None, sp),
                 "pg_split_rows")
         if plan.dense_rows > 0:
             timer = None
@@ -692,9 +715,16 @@ class GraphCacheServer:
             if timer is not None:   # 4th item: share of the split rows this copy launch covers
                 self.profile.append([timer, plan.dense_rows, None, plan.dense_rows / max(1, plan.rows)])
         if use_q:
-            L.check(self.lib.pg_missq_submit_range(self._missq, slot, plan.optrs, plan.ostr, plan.poslo, sp),
+            L.check(self.lib.pg_missq_submit_dedup(self._missq, slot, plan.optrs, plan.ostr, plan.poslo,
+                                                   L.ptr(plan.slots) if dd is not None else None, sp),
                     "pg_missq_submit_range")
             self._missq_pending.add(slot)
+
+    def _plan_dedup(self, plan, slot):
+        """the plan's pg_dedup_t (built at its first fetch: the slot's queue buffers exist by then), or None"""
+        if plan.dedup is False:
+            plan.dedup = self._dedup_for(slot, plan.layer_lo, plan.first_layer, plan.num_layers, plan.same_fields)
+        return plan.dedup
 
     def _device_tail(self, names, out, miss_pos, miss_fullid, miss_count, R, sp):
         """the share of the miss list the worker leaves alone: read over PCIe by the device, on the fetching stream"""
@@ -712,6 +742,7 @@ class GraphCacheServer:
         if self._missq is None or rows > self._missq_rows or slot >= self._missq_nslots:
             # (a consumer with a deeper ring than the one the queue was made for needs more slots)
             self._missq_bufs = {}
+            self._missq_dup = {}
             recreated = self._missq is not None
             if self._missq is not None:
                 # batches in flight on other slots still own the old queue's buffers: let the worker enqueue their
@@ -746,6 +777,30 @@ class GraphCacheServer:
         self._missq_bufs[slot] = (pos, full, cnt)
         return pos, full, cnt
 
+    def _dedup_for(self, slot, offsets_rel, first_layer, num_layers, same_fields=True):
+        """pg_dedup_t over the slot's dup buffers for a launch whose rows are the NodeFlow layers first_layer.. laid out at
+        offsets_rel (0-based, len = layers + 1); None when the launch cannot repeat an id (one layer), the layers read
+        different fields, or the queue splits its miss lists with the device (cpu_share < 1). Call after
+        _missq_buffers(slot, ...)."""
+        n = len(offsets_rel) - 1
+        if not (self.dedup_misses and self.miss_mode == "async" and not self.full_cached and slot is not None
+                and same_fields and 2 <= n <= L.PG_MAX_LAYERS and self._missq is not None and self._missq_share == 256):
+            return None
+        bufs = self._missq_dup.get(slot)
+        if bufs is None:
+            a, b, c = L.vp(), L.vp(), L.vp()
+            L.check(self.lib.pg_missq_slot_dup_buffers(self._missq, slot, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)),
+                    "pg_missq_slot_dup_buffers")
+            bufs = self._missq_dup[slot] = (a.value, b.value, c.value)
+        d = L.PgDedup()
+        d.n_ranges = n
+        for r in range(n + 1):
+            d.lo[r] = int(offsets_rel[r])
+        # sampler spec rule 5: every layer but the seeds' (the NodeFlow's last) ascends by id
+        d.sorted_mask = sum(1 << r for r in range(n) if first_layer + r < num_layers - 1)
+        d.dup_pos, d.dup_src, d.dup_count = bufs
+        return d
+
     def wait_misses(self, slot, stream=None, host_blocking=False):
         """miss_mode == 'async': order `stream` (default: current) after the slot's miss rows. By default
         the wait happens on the GPU (a one-wave kernel sleeping on a flag) and the host returns at once;
@@ -778,6 +833,7 @@ class GraphCacheServer:
             L.check(self.lib.pg_missq_destroy(self._missq), "pg_missq_destroy")
             self._missq, self._missq_rows, self._missq_bufs, self._missq_share = None, 0, {}, None
             self._missq_nslots = 0
+            self._missq_dup = {}
             self._missq_pending.clear()
             self._cache_epoch += 1       # fetch plans (and graphs captured over them) hold pointers into the queue's blocks
 

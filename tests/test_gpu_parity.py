@@ -1873,3 +1873,71 @@ def test_async_miss_path_survives_hardware_queue_sharing(dev, hiplib):
             with torch.cuda.stream(s):
                 junk.add_(1.0)
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F", [8, 600, 602])
+def test_miss_list_index_dedup_is_invisible_and_saves_pcie_rows(dev, hiplib, F):
+    """North star's "index dedup" where it pays: a vertex that MISSES in several layers of one NodeFlow crosses PCIe
+    once (pg_dedup_t: binary search of a missed id in the earlier, sorted layers; the repeat is filled on the device from
+    the first occurrence's staged row). Frames and the reference's miss counters are identical with and without it; the
+    worker moves exactly the first occurrences. Also: padded (fixed-shape) layers, a `need` subset, repeated slot use."""
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    rng = np.random.default_rng(100 + F)
+    V = 60000
+    feats = rng.random((V, F), dtype=np.float32)
+    norm = rng.random((V, 1), dtype=np.float32)
+    l0 = np.sort(rng.choice(V, 9000, replace=False))
+    l1 = np.sort(np.unique(np.concatenate([rng.choice(l0, 2500, replace=False), rng.choice(V, 2500, replace=False)])))
+    l2 = np.concatenate([rng.choice(l0, 700), rng.choice(l1, 700), rng.choice(V, 600), np.full(120, l0[17])])
+    rng.shuffle(l2)                                          # the seeds' layer: unsorted, with repeats of its own
+    cached = rng.choice(V, int(0.3 * V), replace=False)
+    is_cached = np.zeros(V, bool); is_cached[cached] = True
+    pad = lambda a, n: np.concatenate([a, np.full(n - len(a), -1, np.int64)])
+    cases = {"exact": [l0, l1, l2], "padded": [pad(l0, 10000), pad(l1, 6000), pad(l2, 2200)]}
+
+    def first_occurrences(layers):
+        """rows the worker must move: misses of layer r that do not appear in layers 0..r-1"""
+        seen, n = set(), 0
+        for r, a in enumerate(layers):
+            a = a[a >= 0]
+            m = a[~is_cached[a]]
+            n += int(np.sum([x not in seen for x in m.tolist()])) if r else len(m)
+            seen.update(a.tolist())
+        return n
+
+    res = {}
+    for dedup in (False, True):
+        store = HostFeatureStore({"features": torch.from_numpy(feats), "norm": torch.from_numpy(norm)})
+        c = GraphCacheServer(store, V, torch.arange(V), 0, miss_mode="async")
+        c.dedup_misses = dedup
+        c.init_field(["features", "norm"])
+        c.log = True
+        nids = torch.from_numpy(cached).to(dev)
+        c.cache_fix_data(nids, c.get_feat_from_server(nids, ["features", "norm"], to_gpu=True), is_full=False)
+        for case, layers in cases.items():
+            for need in (None, {1: ["features"], 2: ["features"]}):
+                for rep in range(3):
+                    nf = FakeNF(layers, dev)
+                    q0 = c.miss_queue_stats()
+                    c.fetch_data(nf, need=need, slot=rep % 2)
+                    c.wait_misses(rep % 2)
+                    c.drain_misses(); torch.cuda.synchronize()
+                    q1 = c.miss_queue_stats()
+                    moved = int(round(q1["rows_per_job"] * q1["jobs"] - (q0["rows_per_job"] * q0["jobs"] if q0 else 0)))
+                    lay = range(len(layers)) if need is None else sorted(need)
+                    for i in lay:
+                        valid = layers[i] >= 0
+                        for name in (("features", "norm") if need is None else need[i]):
+                            got = nf._node_frames[i][name].cpu().numpy()[valid]
+                            want = (feats if name == "features" else norm)[layers[i][valid]]
+                            assert np.array_equal(got, want), (dedup, case, need, i, name)
+                    sub = [layers[i] for i in lay]
+                    all_miss = sum(int((~is_cached[a[a >= 0]]).sum()) for a in sub)
+                    assert moved == (first_occurrences(sub) if dedup else all_miss), (dedup, case, need, moved)
+                    t, m = c._stats.tolist()
+                    c._stats.zero_()
+                    assert m == all_miss and t == sum(int((a >= 0).sum()) for a in sub)     # the reference's counting
+                    res[(dedup, case, need is None)] = moved
+        c.check_misses()
+    assert res[(True, "exact", True)] < res[(False, "exact", True)]
