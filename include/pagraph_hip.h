@@ -371,7 +371,9 @@ int pg_spmm_fwd_drop(const int32_t* indptr, const int32_t* src, const float* h, 
  * slots[p] <= -3 -> staged[-slots[p] - 3, :] (the block of miss rows the miss path copied to the device, in
  * miss-list order: pg_split_rows + pg_missq with a staged-only field); -1 / -2 contribute nothing. Bit-identical
  * to pg_gather_rows + pg_spmm_fwd_drop (same summation order, same dropout counters: row index = p).
- * Needs dim % 4 == 0, dim >= 256, 16-byte aligned rows (else PG_ERR_UNSUPPORTED). drop may be NULL.
+ * Needs dim >= 256 and 16-byte aligned rows whose strides (cache, staged, out) are multiples of 4 floats >= dim
+ * rounded up to 4 (else PG_ERR_UNSUPPORTED): dim % 4 != 0 (602) is read and written in whole 16-byte pieces, the
+ * columns past dim are masked on the way in and written as zeros. drop may be NULL.
  * prof (device uint64[3 * prof_ring], may be NULL): entry i = (*drop->step, or 0) % prof_ring receives the
  * device wall clock (100 MHz ticks) at [3i] kernel start and [3i+1] kernel end, and [3i+2] the number of edges
  * aggregated — the kernel usually runs inside a replayed hipGraph, where HIP events cannot be attached to it;
@@ -418,7 +420,8 @@ int pg_spmm_bwd_gather_dz(const int32_t* tptr, const int32_t* tdst, const int32_
 
 /* Skinny dense step of the first layer — NodeUpdate.forward at PaGraph/model/gcn_nssc.py:18-23 and
  * graphsage_nssc.py:24-29 — on fp32 MFMA: Z = X[n,K] * W^T + bias with W = nn.Linear's weight [N,K],
- * N <= 64, K % 8 == 0, X / W 16-byte aligned, x_stride % 4 == 0. The epilogue applies NodeUpdate's
+ * N <= 64, any K (Reddit's 602: the last octet is zero-filled past K; W rows are read with the widest aligned
+ * access K allows), X 16-byte aligned with x_stride % 4 == 0. The epilogue applies NodeUpdate's
  * activation: act 0: Y = Z; 1: Y = relu(Z); 2: Y = [Z | relu(Z)] (2N columns, the skip connection).
  * Returns PG_ERR_UNSUPPORTED outside that envelope (callers then use the library GEMM).            */
 int pg_linear_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, float* Y,

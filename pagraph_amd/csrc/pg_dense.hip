@@ -37,6 +37,12 @@ constexpr int kTile = 32;
 // Optional second operand pair (X2, W2, bias2): Z = X W^T + X2 W2^T + bias + bias2 — GraphSAGE's NodeUpdate
 // `fc_self(h) + fc_neigh(neigh)` (graphsage_nssc.py:24) in one pass, the K range being the concatenation.
 // blockIdx.y selects the 32-column tile of N (N <= 64 needs two).
+// WV = widest aligned access to a row of W: 4 (K % 4 == 0), 2 (K even: Reddit's 602), 1. K need not be a multiple
+// of 8: the last octet is zero-filled past K (X's rows are padded to a multiple of 4 floats, so its 16-byte load stays
+// inside the row; whatever lies in the padding is masked).
+typedef float df2 __attribute__((ext_vector_type(2)));
+
+template <int WV>
 __global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ X, int32_t x_stride,
                                                     const float* __restrict__ W /* [N][K] */,
                                                     const float* __restrict__ bias /* [N] or null */,
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ X,
   const int n0 = (int)blockIdx.y * kTile;             // first output column of this block
   const int64_t row = r0 + (lane & 31);
   const int half = lane >> 5;
-  const int oct1 = K / 8, octets = oct1 + K2 / 8;
+  const int oct1 = (K + 7) / 8, octets = oct1 + (K2 + 7) / 8;
   const int o_beg = (octets * w) / 4, o_end = (octets * (w + 1)) / 4;
   const bool row_ok = row < n;
   const int col = n0 + (lane & 31);
@@ -62,14 +68,36 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ X,
   const float* xr2 = X2 ? X2 + (row_ok ? row : 0) * x2_stride + 4 * half : nullptr;
   const float* wr2 = W2 ? W2 + (int64_t)(col_ok ? col : 0) * K2 + 4 * half : nullptr;
   f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  auto load = [&](int o, df4& a, df4& b) {
-    if (o < oct1) {
-      a = *reinterpret_cast<const df4*>(xr + o * 8);
-      b = *reinterpret_cast<const df4*>(wr + o * 8);
+  auto load1 = [&](const float* xp, const float* wp, int o, int Kx, df4& a, df4& b) {
+    const int left = Kx - (o * 8 + 4 * half);          // columns of this lane's quad that exist
+    a = df4{0.f, 0.f, 0.f, 0.f};
+    b = df4{0.f, 0.f, 0.f, 0.f};
+    if (left <= 0) return;
+    a = *reinterpret_cast<const df4*>(xp + o * 8);
+    if (WV == 4) {
+      b = *reinterpret_cast<const df4*>(wp + o * 8);
+    } else if (WV == 2) {
+      const df2 lo = *reinterpret_cast<const df2*>(wp + o * 8);
+      b.x = lo.x; b.y = lo.y;
+      if (left > 2) {
+        const df2 hi = *reinterpret_cast<const df2*>(wp + o * 8 + 2);
+        b.z = hi.x; b.w = hi.y;
+      }
     } else {
-      a = *reinterpret_cast<const df4*>(xr2 + (o - oct1) * 8);
-      b = *reinterpret_cast<const df4*>(wr2 + (o - oct1) * 8);
+      b.x = wp[o * 8];
+      if (left > 1) b.y = wp[o * 8 + 1];
+      if (left > 2) b.z = wp[o * 8 + 2];
+      if (left > 3) b.w = wp[o * 8 + 3];
     }
+    if (left < 4) {                                    // the ragged end of K: nothing from beyond it is multiplied
+      if (left < 2) { a.y = 0.f; b.y = 0.f; }
+      if (left < 3) { a.z = 0.f; b.z = 0.f; }
+      a.w = 0.f; b.w = 0.f;
+    }
+  };
+  auto load = [&](int o, df4& a, df4& b) {
+    if (o < oct1) load1(xr, wr, o, K, a, b);
+    else load1(xr2, wr2, o - oct1, K2, a, b);
     if (!row_ok) a = df4{0.f, 0.f, 0.f, 0.f};
     if (!col_ok) b = df4{0.f, 0.f, 0.f, 0.f};
   };
@@ -285,16 +313,30 @@ static int linear_fwd(const float* X, int32_t x_stride, const float* W, const fl
   if (n < 0 || K <= 0 || N <= 0 || K2 < 0 || x_stride < K || act < 0 || act > 2 || y_stride < (act == 2 ? 2 * N : N))
     return PG_ERR_INVALID;
   if (K2 > 0 && (!X2 || !W2 || x2_stride < K2)) return PG_ERR_INVALID;
-  if (N > 2 * kTile || (K & 7) || (x_stride & 3) || (K2 & 7) || (K2 > 0 && (x2_stride & 3))) return PG_ERR_UNSUPPORTED;
+  // X rows: 16-byte quads (stride a multiple of 4 floats, so the last quad of a ragged K stays inside the row)
+  if (N > 2 * kTile || (x_stride & 3) || (K2 > 0 && (x2_stride & 3))) return PG_ERR_UNSUPPORTED;
   if (n == 0) return PG_OK;
   if (!X || !W || !Y) return PG_ERR_INVALID;
-  if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return PG_ERR_UNSUPPORTED;
-  if (K2 > 0 && ((reinterpret_cast<uintptr_t>(X2) & 15) || (reinterpret_cast<uintptr_t>(W2) & 15)))
-    return PG_ERR_UNSUPPORTED;
+  if (reinterpret_cast<uintptr_t>(X) & 15) return PG_ERR_UNSUPPORTED;
+  if (K2 > 0 && (reinterpret_cast<uintptr_t>(X2) & 15)) return PG_ERR_UNSUPPORTED;
+  auto wv_of = [](const float* w, int32_t k) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(w);
+    return (k % 4 == 0 && !(a & 15)) ? 4 : ((k % 2 == 0 && !(a & 7)) ? 2 : 1);
+  };
+  int wv = wv_of(W, K);
+  if (K2 > 0) {
+    const int w2 = wv_of(W2, K2);
+    wv = w2 < wv ? w2 : wv;
+  }
   if (K2 == 0) X2 = W2 = bias2 = nullptr;
-  hipLaunchKernelGGL(k_linear_fwd, dim3((unsigned)ceil_div<int64_t>(n, kTile), (unsigned)ceil_div<int>(N, kTile)),
-                     dim3(256), 0, as_stream(stream), X, x_stride, W, bias, X2, x2_stride, W2, bias2, K2, Y, y_stride, n,
-                     K, N, act);
+  const dim3 grid((unsigned)ceil_div<int64_t>(n, kTile), (unsigned)ceil_div<int>(N, kTile));
+#define PG_LIN_FWD(WV)                                                                                               \
+  hipLaunchKernelGGL(k_linear_fwd<WV>, grid, dim3(256), 0, as_stream(stream), X, x_stride, W, bias, X2, x2_stride, W2, \
+                     bias2, K2, Y, y_stride, n, K, N, act)
+  if (wv == 4) PG_LIN_FWD(4);
+  else if (wv == 2) PG_LIN_FWD(2);
+  else PG_LIN_FWD(1);
+#undef PG_LIN_FWD
   PG_LAUNCH_CHECK();
   return PG_OK;
 }

@@ -203,7 +203,11 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_drop(const int32_t* __restrict
 // hipGraph cannot carry HIP events.
 constexpr int kRowsBatch = 4;   // source rows whose loads are in flight together per wave
 
-template <bool DROP>
+// TAIL: dim % 4 != 0 (Reddit's 602). The rows are still read and written as 16-byte pieces — every row of the fused
+// cache / of `out` is padded to a multiple of 4 floats (the host side checks the strides) — and the last piece's
+// columns >= dim (the next field of the fused cache row, or padding) are forced to zero before they are summed, so
+// `out`'s padding columns hold zeros.
+template <bool DROP, bool TAIL>
 __global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict__ indptr,
                                                        const int32_t* __restrict__ src,
                                                        const int32_t* __restrict__ slots,
@@ -223,7 +227,8 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t v = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
   if (v < n_dst) {
-    const int pieces = dim / 4;
+    const int pieces = (dim + 3) / 4;
+    const int tail = dim & 3;                        // valid columns of the last piece (TAIL only)
     const int32_t beg = indptr[v], end = indptr[v + 1];
     float4* orow = reinterpret_cast<float4*>(out + v * out_stride);
     for (int c0 = 0; c0 < pieces; c0 += kWave * kMaxAcc) {
@@ -276,6 +281,13 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict
                     have_q = q;
                   }
                   xv = drop_apply(xv, o, (c >> 6) & 1, d.thr, d.scale);
+                }
+                if constexpr (TAIL) {
+                  if (c == pieces - 1) {
+                    if (tail < 2) xv.y = 0.f;
+                    if (tail < 3) xv.z = 0.f;
+                    xv.w = 0.f;
+                  }
                 }
                 S::add(acc[m], xv);
               }
@@ -644,10 +656,12 @@ int pg_spmm_fwd_rows(const int32_t* indptr, const int32_t* src, const pg_row_sou
   if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return PG_ERR_INVALID;
   if (drop && drop->threshold > 65535u) return PG_ERR_INVALID;
   if (prof && prof_ring <= 0) return PG_ERR_INVALID;
-  // one wave per destination, 16-byte pieces: the wide feature rows this path exists for
-  if (!(dim % 4 == 0 && dim >= 256 && out_stride % 4 == 0 && al(out, 16))) return PG_ERR_UNSUPPORTED;
-  if (rows->cache && !(rows->cache_stride >= dim && rows->cache_stride % 4 == 0 && al(rows->cache, 16))) return PG_ERR_UNSUPPORTED;
-  if (rows->staged && !(rows->staged_stride >= dim && rows->staged_stride % 4 == 0 && al(rows->staged, 16))) return PG_ERR_UNSUPPORTED;
+  // one wave per destination, 16-byte pieces: the wide feature rows this path exists for. dim % 4 != 0 (602): the
+  // last piece is read / written whole, so every row must be padded to a multiple of 4 floats
+  const int32_t dim4 = (dim + 3) & ~3;
+  if (!(dim >= 256 && out_stride >= dim4 && out_stride % 4 == 0 && al(out, 16))) return PG_ERR_UNSUPPORTED;
+  if (rows->cache && !(rows->cache_stride >= dim4 && rows->cache_stride % 4 == 0 && al(rows->cache, 16))) return PG_ERR_UNSUPPORTED;
+  if (rows->staged && !(rows->staged_stride >= dim4 && rows->staged_stride % 4 == 0 && al(rows->staged, 16))) return PG_ERR_UNSUPPORTED;
   if (n_dst == 0) return PG_OK;
   if (!indptr || !src || !out || !rows->slots) return PG_ERR_INVALID;
   DropArgs d{};
@@ -655,14 +669,18 @@ int pg_spmm_fwd_rows(const int32_t* indptr, const int32_t* src, const pg_row_sou
   if (!has_drop && drop) d.step = drop->step;     // the profiling ring is indexed by the caller's step counter
   const unsigned grid = (unsigned)ceil_div<int64_t>(n_dst, 4);
   unsigned long long* pr = reinterpret_cast<unsigned long long*>(prof);
-  if (has_drop)
-    hipLaunchKernelGGL(k_spmm_fwd_rows<true>, dim3(grid), dim3(256), 0, as_stream(stream), indptr, src, rows->slots,
-                       rows->edge_slots, rows->cache, rows->cache_stride, rows->staged, rows->staged_stride, n_dst, dim, reduce, out,
-                       out_stride, d, pr, (int)prof_ring);
-  else
-    hipLaunchKernelGGL(k_spmm_fwd_rows<false>, dim3(grid), dim3(256), 0, as_stream(stream), indptr, src, rows->slots,
-                       rows->edge_slots, rows->cache, rows->cache_stride, rows->staged, rows->staged_stride, n_dst, dim, reduce, out,
-                       out_stride, d, pr, (int)prof_ring);
+#define PG_FWD_ROWS(DROP, TAIL)                                                                                         \
+  hipLaunchKernelGGL((k_spmm_fwd_rows<DROP, TAIL>), dim3(grid), dim3(256), 0, as_stream(stream), indptr, src, rows->slots, \
+                     rows->edge_slots, rows->cache, rows->cache_stride, rows->staged, rows->staged_stride, n_dst, dim,     \
+                     reduce, out, out_stride, d, pr, (int)prof_ring)
+  if (dim % 4 == 0) {
+    if (has_drop) PG_FWD_ROWS(true, false);
+    else PG_FWD_ROWS(false, false);
+  } else {
+    if (has_drop) PG_FWD_ROWS(true, true);
+    else PG_FWD_ROWS(false, true);
+  }
+#undef PG_FWD_ROWS
   PG_LAUNCH_CHECK();
   return PG_OK;
 }

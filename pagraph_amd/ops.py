@@ -25,7 +25,7 @@ class DropoutSpec:
     @staticmethod
     def fusable(h):
         if isinstance(h, RowSource):
-            return h.dim % 4 == 0
+            return h.aligned()
         return (h.is_cuda and h.dtype == torch.float32 and h.dim() == 2 and h.size(1) % 4 == 0 and h.stride(1) == 1
                 and h.stride(0) % 4 == 0 and h.data_ptr() % 16 == 0)
 
@@ -57,6 +57,17 @@ class RowSource:
     def dim_(self):
         return 2
 
+    def aligned(self):
+        """pg_spmm_fwd_rows' envelope: every row source is padded to whole 16-byte pieces (dim % 4 != 0 — Reddit's 602 —
+        is fine as long as the fused cache row / the staged block have room for the last piece)"""
+        d4 = (self.dim + 3) & ~3
+        ok = self.dim >= 256
+        if self.cache is not None:
+            ok = ok and self.cache.stride(0) % 4 == 0 and self.cache.stride(0) >= d4 and self.cache.data_ptr() % 16 == 0
+        if self.staged_ptr:
+            ok = ok and self.staged_stride % 4 == 0 and self.staged_stride >= d4 and self.staged_ptr % 16 == 0
+        return ok
+
     def struct(self):
         return L.PgRowSource(self.slots.data_ptr(), self.cache.data_ptr() if self.cache is not None else 0,
                              self.staged_ptr, self.cache.stride(0) if self.cache is not None else self.dim,
@@ -66,7 +77,10 @@ class RowSource:
 def aggregate_rows(indptr, src, rows, n_dst, reduce="mean", dropout=None):
     """block_aggregate for a RowSource: gather + (dropout) + aggregate in one kernel, no [rows, dim] frame"""
     lib = L.load()
-    out = torch.empty((int(n_dst), rows.dim), dtype=torch.float32, device=rows.device)
+    # rows padded to a multiple of 8 floats: whole 16-byte pieces for this kernel, whole octets for ops.linear's MFMA
+    # kernel behind it (the padding columns of a ragged dim — 602 — are written as zeros); the caller sees [n_dst, dim]
+    pad = (rows.dim + 7) & ~7
+    out = torch.empty((int(n_dst), pad), dtype=torch.float32, device=rows.device)[:, :rows.dim]
     rs = rows.struct()
     d = dropout.struct() if dropout is not None else None
     prof, ring = rows.prof if rows.prof is not None else (None, 0)
@@ -245,8 +259,7 @@ class _SkinnyLinear(torch.autograd.Function):
         lib = L.load()
         n, K = x.shape
         N = weight.size(0)
-        if (N <= 64 and K % 8 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and weight.is_contiguous()
-                and weight.data_ptr() % 16 == 0):
+        if N <= 64 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and weight.is_contiguous():
             y = torch.empty((n, 2 * N if act == ACT_CONCAT else N), dtype=torch.float32, device=x.device)
             with torch.cuda.device(x.device):
                 L.check(lib.pg_linear_fwd(L.ptr(x), x.stride(0), L.ptr(weight), L.ptr(bias), L.ptr(y), y.stride(0), n, K,
@@ -351,8 +364,7 @@ class _DualLinear(torch.autograd.Function):
 
 def _skinny_ok(x, w):
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and w.size(0) <= 64 and x.size(0) >= 1024
-            and x.stride(1) == 1 and w.size(1) % 8 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
-            and w.is_contiguous() and w.data_ptr() % 16 == 0)
+            and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and w.is_contiguous())
 
 
 def linear2(x1, mod1, x2, mod2, act=ACT_NONE):

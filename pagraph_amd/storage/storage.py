@@ -595,7 +595,10 @@ class GraphCacheServer:
             for l in layers:
                 want = per_layer[layers.index(l)]
                 v = set(virtual.get(l, ()))
-                wide = all(self.dims[n] % 4 == 0 and self.dims[n] >= 256 for n in want)
+                # wide rows in whole 16-byte pieces: dim % 4 == 0, or (Reddit's 602) a fused cache row with room for the last
+                # piece and no staged block to read (the queue packs its staging rows at `dim` floats)
+                wide = all(self.dims[n] >= 256 and (self.dims[n] % 4 == 0 or (self.full_cached and n in self.gpu_fix_cache
+                           and self.gpu_fix_cache[n].stride(0) >= ((self.dims[n] + 3) & ~3))) for n in want)
                 if want and want <= v and wide and l == layers[0] + len(vlayers) and (same_everywhere or len(layers) == 1):
                     vlayers.append(l)
                 else:

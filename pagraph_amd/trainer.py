@@ -248,7 +248,10 @@ class GraphedTrainer:
     def _make_slot(self, nf):
         s = GraphedTrainer._Slot()
         R = nf._node_mapping.tousertensor().numel()
-        s.out = {n: torch.zeros((R, d), dtype=torch.float32, device=self.device) for n, d in self.cacher.dims.items()}
+        # wide rows whose width is not a multiple of 8 floats (Reddit's 602) get padded rows — zeros in the padding — so that
+        # the MFMA dense kernel reads them in whole octets; the views handed to the model are [R, d]
+        s.out = {n: torch.zeros((R, (d + 7) & ~7 if d >= 64 else d), dtype=torch.float32, device=self.device)[:, :d]
+                 for n, d in self.cacher.dims.items()}
         s.label = torch.full((nf.layer_size(-1),), -100, dtype=torch.int64, device=self.device)
         s.n_valid = torch.zeros(1, dtype=torch.int32, device=self.device)   # labels the loss will count
         s.ready = torch.cuda.Event()

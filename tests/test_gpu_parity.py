@@ -1941,3 +1941,122 @@ def test_miss_list_index_dedup_is_invisible_and_saves_pcie_rows(dev, hiplib, F):
                     res[(dedup, case, need is None)] = moved
         c.check_misses()
     assert res[(True, "exact", True)] < res[(False, "exact", True)]
+
+
+# ---- ragged feature width (Reddit: feat = 602, BASELINE configs[0..1]) on the fused path -------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("Fd,p_drop,reduce", [(602, 0.0, "mean"), (602, 0.25, "mean"), (601, 0.5, "sum"), (603, 0.25, "mean")])
+def test_fused_gather_aggregate_ragged_width_vs_oracle(dev, hiplib, oracle, Fd, p_drop, reduce):
+    """pg_spmm_fwd_rows with dim % 4 != 0: rows are read as whole 16-byte pieces out of a padded fused cache row whose
+    next columns hold ANOTHER field (here: NaN) — masked on the way in; the output's padding columns are zeros; the sum
+    and the dropout keep-mask equal the oracle's bit for bit"""
+    from pagraph_amd import _lib as L
+    rng = np.random.default_rng(Fd)
+    V, n_src, n_dst, stride = 3000, 2500, 900, 608
+    table = rng.random((V, Fd), dtype=np.float32)
+    ids = rng.permutation(V)[:n_src].astype(np.int64)
+    deg = rng.integers(0, 5, n_dst); deg[3] = 0; deg[11] = 90
+    indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    src = rng.integers(0, n_src, int(indptr[-1])).astype(np.int32)
+    thr = oracle.dropout_threshold(p_drop)
+    seed, tag, step = 0x9876543, 2, 4
+    h = table[ids]
+    if thr:
+        keep, scale = oracle.dropout_mask(n_src, Fd, thr, seed, tag, step)
+        h = np.where(keep, h * scale, np.float32(0)).astype(np.float32)
+    want = oracle.spmm_fwd(indptr, src, h, n_dst, reduce)
+    fused = torch.full((V, stride), float("nan"), device=dev)          # [features | other field / padding = NaN]
+    fused[:, :Fd] = torch.from_numpy(table).to(dev)
+    slots = torch.from_numpy(ids.astype(np.int32)).to(dev)              # full cache: slot = id
+    rs = L.PgRowSource(slots.data_ptr(), fused.data_ptr(), 0, stride, Fd)
+    out = torch.full((n_dst, stride), 7.0, device=dev)
+    stepd = torch.tensor([step], dtype=torch.int64, device=dev)
+    drop = L.PgDropout(thr, tag, seed, L.ptr(stepd))
+    d_indptr, d_src = torch.from_numpy(indptr).to(dev), torch.from_numpy(src).to(dev)
+    L.check(hiplib.pg_spmm_fwd_rows(L.ptr(d_indptr), L.ptr(d_src), ctypes.byref(rs), n_dst, Fd, 0 if reduce == "mean" else 1,
+                                    L.ptr(out), stride, ctypes.byref(drop), None, 0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, :Fd], want)
+    d4 = (Fd + 3) & ~3
+    assert np.all(got[:, Fd:d4] == 0) and np.all(got[:, d4:] == 7.0)
+    # rows that are not padded to whole pieces are refused, not mis-read
+    bad = L.PgRowSource(slots.data_ptr(), fused.data_ptr(), 0, Fd, Fd)
+    assert hiplib.pg_spmm_fwd_rows(L.ptr(d_indptr), L.ptr(d_src), ctypes.byref(bad), n_dst, Fd, 0, L.ptr(out), stride,
+                                   None, None, 0, L.stream_ptr()) == -4      # PG_ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,K,N", [(6000, 602, 32), (2049, 601, 16), (3000, 70, 33), (4000, 603, 41)])
+def test_skinny_linear_ragged_K_on_the_mfma_kernel(dev, hiplib, n, K, N):
+    """pg_linear_fwd with K % 8 != 0 (padded rows, NaN in the padding): the MFMA kernel itself runs (no library
+    fall-back) and matches float64; W rows are read with float2 / scalar loads when K % 4 != 0"""
+    from pagraph_amd import _lib as L
+    from pagraph_amd import ops
+    torch.manual_seed(K)
+    pad = (K + 7) & ~7
+    buf = torch.full((n, pad), float("nan"), device=dev)
+    x = buf[:, :K]
+    x.copy_(torch.rand((n, K), device=dev) - 0.3)
+    lin = torch.nn.Linear(K, N).to(dev)
+    y = torch.empty((n, 2 * N), device=dev)
+    L.check(hiplib.pg_linear_fwd(L.ptr(x), x.stride(0), L.ptr(lin.weight), L.ptr(lin.bias), L.ptr(y), y.stride(0), n, K, N,
+                                 ops.ACT_CONCAT, L.stream_ptr()), "pg_linear_fwd")
+    z = torch.nn.functional.linear(x.double(), lin.weight.double(), lin.bias.double())
+    ref = torch.cat((z, torch.relu(z)), 1)
+    assert float((y.double() - ref).abs().max()) < TOL * max(1.0, float(ref.abs().max()))
+    # through the autograd wrapper: forward on the kernel, weight gradient too
+    y2 = ops.linear(x, lin, ops.ACT_RELU)
+    assert float((y2.double() - torch.relu(z)).abs().max()) < TOL * max(1.0, float(z.abs().max()))
+    g = torch.rand_like(y2) - 0.5
+    y2.backward(g)
+    gz = g.double() * (z > 0)
+    gw = gz.t() @ x.double()
+    assert float((lin.weight.grad.double() - gw).abs().max()) < TOL * max(1.0, float(gw.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ["gcn", "sage"])
+def test_reddit_width_runs_on_the_fused_path(dev, hiplib, arch):
+    """feat = 602, whole table cached (BASELINE configs[1]): layer 0 is aggregated straight from the cache
+    (ops.RowSource) with the kernel's own dropout mask; with dropout off the logits and gradients match the
+    materialised path (k_gather + k_spmm_fwd + library GEMM) to 1e-4"""
+    import torch.nn.functional as Fn
+    from pagraph_amd.model import GCNSampling, GraphSageSampling
+    from pagraph_amd.ops import RowSource
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    rng = np.random.default_rng(602)
+    V, Fd, C, B, k = 6000, 602, 41, 1200, 2
+    g = DeviceGraph(_rand_csc(rng, V, 50000))
+    feats = rng.random((V, Fd), dtype=np.float32)
+    norm = rng.random((V, 1), dtype=np.float32)
+    store = HostFeatureStore({"features": torch.from_numpy(feats), "norm": torch.from_numpy(norm)})
+    c = GraphCacheServer(store, V, torch.arange(V), 0, miss_mode="async")
+    c.init_field(["features", "norm"])
+    c.auto_cache(g, ["features", "norm"], cache_ratio=1.0)
+    assert c.full_cached
+    torch.manual_seed(3)
+    model = (GCNSampling(Fd, 32, C, 1, Fn.relu, 0.0) if arch == "gcn" else GraphSageSampling(Fd, 16, C, 1, Fn.relu, 0.0, 'mean'))
+    model = model.to(dev).train()
+    need, virt = model.required_inputs(3), model.virtual_inputs(3)
+    smp = NeighborSampler(g, B, k, neighbor_type='in', shuffle=False, num_hops=2, seed_nodes=np.arange(0, V, 2), seed=1)
+    nf = next(iter(smp))
+    outs = []
+    for v in (None, virt):
+        model.zero_grad(set_to_none=True)
+        c.fetch_data(nf, need=need, slot=0, virtual=v)
+        assert isinstance(nf._node_frames[0]["features"], RowSource) == (v is not None)
+        y = model(nf)
+        y.square().sum().backward()
+        torch.cuda.synchronize()
+        outs.append((y.detach().clone(), [p.grad.clone() for p in model.parameters()]))
+    sc = max(1.0, float(outs[0][0].abs().max()))
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < TOL * sc
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert float((a - b).abs().max()) < TOL * max(1.0, float(a.abs().max()))
+    # dropout on: the fused path draws the kernel's mask (no nn.Dropout fall-back) and still trains
+    model2 = GCNSampling(Fd, 32, C, 1, Fn.relu, 0.5).to(dev).train()
+    c.fetch_data(nf, need=need, slot=0, virtual=model2.virtual_inputs(3))
+    y = model2(nf)
+    assert torch.isfinite(y).all()

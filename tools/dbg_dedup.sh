@@ -1,6 +1,7 @@
 #!/bin/bash
-O=gpurun_out/dedup; mkdir -p $O
-pick='import json,sys,statistics as st; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d["reference_equivalent"]; w=d["ms_per_step_windows"]; print(round(d["ms_per_step"],4), "median window", round(st.median(w),4), "min", min(w), "rows/step", round(d["miss_queue"]["timed_region"]["rows_over_pcie_per_step"]), "us gather", round(d["miss_queue"]["us_cpu_gather"]), "| ref-eq", round(r["ms_per_step"],4) if isinstance(r,dict) else r)'
-B="python bench.py --steps 1084 --warmup 20 --skip-cpu-baseline --skip-microbench --skip-opt-hit"
-for rep in 1 2; do for d in 1 0; do echo "== graphsage dedup=$d"; PG_DEDUP_MISSES=$d timeout 300 $B --model graphsage 2> $O/last.err | python -c "$pick" || tail -5 $O/last.err; done; done
-for d in 1 0; do echo "== gcn fetch-all dedup=$d"; PG_DEDUP_MISSES=$d timeout 300 $B --fetch-all 2> $O/last.err | python -c "$pick" || tail -5 $O/last.err; done
+O=gpurun_out/ragged; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; tail -6 $O/tests.log
+pick='import json,sys,statistics as st; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); w=d["ms_per_step_windows"]; r=d["roofline"]; print(round(d["ms_per_step"],4), "median window", round(st.median(w),4), r["kernel"], round(r["frac"],3), r.get("avg_launch_ms"))'
+echo "== config 2 (reddit shape, full cache)"; timeout 600 python bench.py --vertices 232965 --edges 57300000 --feat-size 602 --n-classes 41 --cache-ratio 1.0 --steps 260 --skip-opt-hit --skip-cpu-baseline 2> $O/c2.err | python -c "$pick" || tail -8 $O/c2.err
+echo "== config 2 graphsage"; timeout 600 python bench.py --vertices 232965 --edges 57300000 --feat-size 602 --n-classes 41 --cache-ratio 1.0 --steps 260 --skip-opt-hit --skip-cpu-baseline --model graphsage 2> $O/c2s.err | python -c "$pick" || tail -8 $O/c2s.err
+echo "== default"; timeout 600 python bench.py --skip-opt-hit --skip-cpu-baseline 2> $O/d.err | python -c "$pick" || tail -8 $O/d.err
