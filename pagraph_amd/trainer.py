@@ -219,7 +219,7 @@ class GraphedTrainer:
         cacher.missq_slots = len(sampler.slots)
         # ring slot i of the sampler carries the batch whose miss job sits in queue slot i: before the sampler waits for
         # "slot free" (recorded after that batch's consumer) the job's copy must be in its queue — see prepare()
-        sampler.before_slot_reuse = cacher.wait_worker
+        sampler.before_slot_reuse = None if _os.environ.get("PG_NO_SLOT_REUSE_WAIT") else cacher.wait_worker
         # batches prepared ahead of the one being computed. The async miss path needs 2: its worker thread
         # must have finished batch k+1 (GPU publishes the miss list -> CPU gather -> copy enqueued) by the time
         # the host wants to enqueue compute(k+1), i.e. one whole step after it was submitted.

@@ -14,12 +14,19 @@ timeout 600 python bench.py --model graphsage --skip-opt-hit > "$OUT/bench_graph
 timeout 600 python bench.py --vertices 232965 --edges 57300000 --feat-size 602 --n-classes 41 --cache-ratio 1.0 \
         --steps 260 --skip-opt-hit > "$OUT/bench_config2_reddit_shape_full_cache.json" 2>/dev/null
 timeout 600 python bench.py --no-fuse-gather --skip-opt-hit --skip-cpu-baseline > "$OUT/bench_unfused_gather.json" 2>/dev/null
+timeout 600 python bench.py --cache-ratio 1.0 --skip-opt-hit --skip-cpu-baseline > "$OUT/bench_full_cache.json" 2>/dev/null
+timeout 600 python bench.py --model graphsage --cache-ratio 1.0 --skip-opt-hit --skip-cpu-baseline > "$OUT/bench_graphsage_full_cache.json" 2>/dev/null
+timeout 600 python tools/exp_dup_census.py > "$OUT/dup_census.json" 2>/dev/null
 
 # 2. per-kernel time of the same command + the kernel sequence of one replayed step
 ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o b -- \
       python "$R/bench.py" --skip-cpu-baseline --skip-opt-hit --skip-reference-equivalent > /tmp/prof_stats.log 2>&1 )
 cp /tmp/prof_stats/*kernel_stats.csv "$OUT/bench_kernel_stats_final.csv"
 python tools/trace_seq.py /tmp/prof_stats/b_kernel_trace.csv > "$OUT/step_sequence_final.txt"
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_gs -o b -- \
+      python "$R/bench.py" --model graphsage --skip-cpu-baseline --skip-opt-hit --skip-reference-equivalent --skip-microbench > /tmp/prof_gs.log 2>&1 )
+cp /tmp/prof_gs/*kernel_stats.csv "$OUT/bench_graphsage_kernel_stats.csv"
+python tools/trace_seq.py /tmp/prof_gs/b_kernel_trace.csv > "$OUT/step_sequence_graphsage.txt"
 
 # 3. HBM bytes per kernel (FETCH_SIZE x2, WRITE_SIZE, KiB): eager loop (rocprofv3 --pmc serialises all kernels), async
 #    miss queue with the consumer waiting for the worker on the host (a spin-wait kernel parked on the compute stream
