@@ -506,6 +506,17 @@ int pg_adam_step_partials(int32_t n_tensors, float* const* params, float* const*
                           const int32_t* part_chunks, const int32_t* part_len, const int32_t* part_off,
                           const int32_t* is_adam, float lr, float beta1, float beta2, float eps, float weight_decay,
                           int64_t* step_dev, uint32_t* ticket_dev, int64_t* bump_dev, pg_stream_t stream);
+/* the same with a SECOND set of partial rows per tensor (partials2[i] may be NULL): a parameter that is applied twice
+ * per step — GraphSAGE's NodeUpdate `lid` runs on every block >= lid (graphsage_nssc.py:92-131) — gets
+ * sum(partials) + sum(partials2), each summed in pg_sum_partials' order, i.e. exactly what autograd's accumulation of
+ * the two summed contributions yields (a two-term fp32 add commutes).                                       */
+int pg_adam_step_partials2(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                           float* const* exp_avg_sq, const int64_t* numel, const float* const* partials,
+                           const int32_t* part_chunks, const int32_t* part_len, const int32_t* part_off,
+                           const float* const* partials2, const int32_t* part2_chunks, const int32_t* part2_len,
+                           const int32_t* part2_off, const int32_t* is_adam, float lr, float beta1, float beta2,
+                           float eps, float weight_decay, int64_t* step_dev, uint32_t* ticket_dev, int64_t* bump_dev,
+                           pg_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 4. Offline partitioning (host)  —  PaGraph/partition/dg.py:59-103

@@ -80,6 +80,13 @@ struct AdamPartArgs {
   int32_t len[PG_ADAM_MAX_TENSORS];
   int32_t off[PG_ADAM_MAX_TENSORS];
   int32_t adam[PG_ADAM_MAX_TENSORS];
+  // a parameter that is applied twice per step (GraphSAGE's NodeUpdate `lid` runs on every block >= lid,
+  // graphsage_nssc.py:92-131) has a second set of partial rows: gradient = sum(part) + sum(part2), each in
+  // k_sum_partials' order — the value AccumulateGrad's add of the two summed contributions gives
+  const float* part2[PG_ADAM_MAX_TENSORS];
+  int32_t chunks2[PG_ADAM_MAX_TENSORS];
+  int32_t len2[PG_ADAM_MAX_TENSORS];
+  int32_t off2[PG_ADAM_MAX_TENSORS];
   int32_t n_tensors;
   float lr, beta1, beta2, eps, weight_decay;
   int64_t* step;
@@ -101,35 +108,47 @@ __global__ __launch_bounds__(256) void k_adam_partials(const AdamPartArgs a) {
   float* gp = a.g[0];
   float *mp = a.m[0], *vp = a.v[0];
   const float* part = a.part[0];
+  const float* part2 = a.part2[0];
   int chunks = a.chunks[0], len = a.len[0], off = a.off[0], is_adam = a.adam[0];
+  int chunks2 = a.chunks2[0], len2 = a.len2[0], off2 = a.off2[0];
   int64_t base = 0;
 #pragma unroll
   for (int j = 1; j < PG_ADAM_MAX_TENSORS; ++j) {
     if (j < a.n_tensors && i >= a.end[j - 1]) {
       pp = a.p[j]; gp = a.g[j]; mp = a.m[j]; vp = a.v[j];
       part = a.part[j]; chunks = a.chunks[j]; len = a.len[j]; off = a.off[j]; is_adam = a.adam[j];
+      part2 = a.part2[j]; chunks2 = a.chunks2[j]; len2 = a.len2[j]; off2 = a.off2[j];
       base = a.end[j - 1];
     }
   }
   const int64_t o = i - base;
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (ok && part) {
-    const int per = (chunks + 3) / 4;
-    const int cb = grp * per, ce = (cb + per < chunks) ? cb + per : chunks;
-    const float* col = part + off + o;
-    int c = cb;
-    for (; c + 7 < ce; c += 8) {
+  // one ordered sum per set of partial rows (4 chunk groups x 8 rotating accumulators, pairwise combine)
+  auto ordered_sum = [&](const float* pt, int nch, int rl, int of) -> float {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (ok && pt) {
+      const int per = (nch + 3) / 4;
+      const int cb = grp * per, ce = (cb + per < nch) ? cb + per : nch;
+      const float* col = pt + of + o;
+      int c = cb;
+      for (; c + 7 < ce; c += 8) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc[u] += col[(int64_t)(c + u) * len];
+        for (int u = 0; u < 8; ++u) acc[u] += col[(int64_t)(c + u) * rl];
+      }
+      for (; c < ce; ++c) acc[0] += col[(int64_t)c * rl];
     }
-    for (; c < ce; ++c) acc[0] += col[(int64_t)c * len];
-  }
-  red[grp][tx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-  __syncthreads();
+    __syncthreads();                                  // red is reused by the second set
+    red[grp][tx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    return (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+  };
+  const float g1 = ordered_sum(part, chunks, len, off);
+  // (uniform per block only when no block straddles tensors with / without a second set: every thread takes the
+  // call, the ones without a second set add nothing)
+  const float g2 = ordered_sum(part2, chunks2, len2, off2);
   if (grp == 0 && ok) {
     float g;
     if (part) {
-      g = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+      g = part2 ? g1 + g2 : g1;
       gp[o] = g;
     } else {
       g = gp[o];
@@ -190,6 +209,20 @@ extern "C" int pg_adam_step_partials(int32_t n_tensors, float* const* params, fl
                                      const int32_t* is_adam, float lr, float beta1, float beta2, float eps,
                                      float weight_decay, int64_t* step_dev, uint32_t* ticket_dev, int64_t* bump_dev,
                                      pg_stream_t stream) {
+  return pg_adam_step_partials2(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, partials, part_chunks, part_len,
+                                part_off, nullptr, nullptr, nullptr, nullptr, is_adam, lr, beta1, beta2, eps,
+                                weight_decay, step_dev, ticket_dev, bump_dev, stream);
+}
+
+extern "C" int pg_adam_step_partials2(int32_t n_tensors, float* const* params, float* const* grads,
+                                      float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                                      const float* const* partials, const int32_t* part_chunks, const int32_t* part_len,
+                                      const int32_t* part_off, const float* const* partials2,
+                                      const int32_t* part2_chunks, const int32_t* part2_len, const int32_t* part2_off,
+                                      const int32_t* is_adam, float lr, float beta1, float beta2, float eps,
+                                      float weight_decay, int64_t* step_dev, uint32_t* ticket_dev, int64_t* bump_dev,
+                                      pg_stream_t stream) {
+  if (partials2 && (!part2_chunks || !part2_len || !part2_off)) return PG_ERR_INVALID;
   if (n_tensors <= 0 || n_tensors > PG_ADAM_MAX_TENSORS || !params || !grads || !exp_avg || !exp_avg_sq || !numel ||
       !partials || !part_chunks || !part_len || !part_off || !is_adam || !step_dev || !ticket_dev)
     return PG_ERR_INVALID;
@@ -203,6 +236,11 @@ extern "C" int pg_adam_step_partials(int32_t n_tensors, float* const* params, fl
     a.p[i] = params[i]; a.g[i] = grads[i]; a.m[i] = exp_avg[i]; a.v[i] = exp_avg_sq[i];
     a.part[i] = partials[i]; a.chunks[i] = part_chunks[i]; a.len[i] = part_len[i]; a.off[i] = part_off[i];
     a.adam[i] = is_adam[i];
+    if (partials2 && partials2[i]) {
+      if (!partials[i] || part2_chunks[i] <= 0 || part2_off[i] < 0 || (int64_t)part2_off[i] + numel[i] > part2_len[i])
+        return PG_ERR_INVALID;
+      a.part2[i] = partials2[i]; a.chunks2[i] = part2_chunks[i]; a.len2[i] = part2_len[i]; a.off2[i] = part2_off[i];
+    }
     tot += numel[i];
     a.end[i] = tot;
   }

@@ -57,7 +57,7 @@ class _GCNBase(FusedDropoutMixin, nn.Module):
     uses_norm = False
     # every NodeUpdate (and the preprocess transform) is applied once per forward: each parameter receives exactly one
     # gradient contribution per step (what ops.defer_partials needs)
-    single_use_parameters = True
+    deferrable_parameters = True
 
     def required_inputs(self, num_layers):
         """{layer: [fields]} this model reads from the NodeFlow frames (for fetch_data(need=...)):

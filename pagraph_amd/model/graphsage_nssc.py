@@ -43,6 +43,14 @@ _REDUCERS = {'mean': fn.mean, 'gcn': fn.sum}
 
 
 class GraphSageSampling(FusedDropoutMixin, nn.Module):
+    @property
+    def deferrable_parameters(self):
+        """model layer `lid` is applied to every block >= lid: with n_layers == 1 (pa_gs.py:134) a parameter receives at
+        most TWO gradient contributions per step — what ops.defer_partials / pg_adam_step_partials2 fold into the
+        optimiser's launch. Deeper stacks (three and more uses) and the preprocess variant keep the separate sums."""
+        import os
+        return self.n_layers == 1 and not self.preprocess and not os.environ.get("PG_NO_DEFER_SAGE")
+
     def __init__(self, in_feats, n_hidden, n_classes, n_layers, activation=None, dropout=0.,
                  aggregator_type='pool', preprocess=False):
         super().__init__()

@@ -215,13 +215,23 @@ class DeferredPartials:
 
     def __init__(self):
         self.by_param = {}     # parameter data_ptr -> (partials tensor, chunks, row length, offset, numel)
+        self.second = {}       # parameter data_ptr -> the same for a parameter's SECOND contribution of the step
         self.extra = []        # reduce-only outputs: (destination tensor, partials, chunks, row length, offset)
         self.conflict = False
 
     def add(self, param, part, chunks, rowlen, off):
-        if param.data_ptr() in self.by_param:
-            self.conflict = True            # a second contribution to the same parameter: cannot be deferred
-        self.by_param[param.data_ptr()] = (part, int(chunks), int(rowlen), int(off), param.numel())
+        """register one contribution; returns True for a parameter's first contribution of the step — the caller hands
+        autograd its (still unsummed) gradient buffer only then and None for a later one, so that AccumulateGrad has
+        nothing to add: the optimiser's launch forms sum(first) + sum(second) (pg_adam_step_partials2)"""
+        e = (part, int(chunks), int(rowlen), int(off), param.numel())
+        k = param.data_ptr()
+        if k not in self.by_param:
+            self.by_param[k] = e
+            return True
+        if k in self.second:
+            self.conflict = True            # a third contribution to the same parameter: cannot be deferred
+        self.second[k] = e
+        return False
 
 
 _DEFER = None
@@ -302,8 +312,10 @@ class _SkinnyLinear(torch.autograd.Function):
                             "pg_linear_bwd_w")
             if defer:
                 rowlen = N * K + N
-                _DEFER.add(weight, part, part.numel() // rowlen, rowlen, 0)
-                _DEFER.add(ctx.bias_ref, part, part.numel() // rowlen, rowlen, N * K)
+                first_w = _DEFER.add(weight, part, part.numel() // rowlen, rowlen, 0)
+                first_b = _DEFER.add(ctx.bias_ref, part, part.numel() // rowlen, rowlen, N * K)
+                gw = gw if first_w else None
+                gb = gb if first_b else None
             if dz is not None:
                 gz = dz
         if ctx.needs_input_grad[0]:
@@ -313,17 +325,26 @@ class _SkinnyLinear(torch.autograd.Function):
         return gx, gw, gb, None
 
 
-def _bwd_w(lib, g, x, K, N, y, act, want_bias):
-    """(dW [N, K], db [N] or None, dZ) through pg_linear_bwd_w"""
+def _bwd_w(lib, g, x, K, N, y, act, want_bias, weight=None, bias=None):
+    """(dW [N, K], db [N] or None, dZ) through pg_linear_bwd_w. With an active ops.defer_partials() registry and the
+    parameters given, the per-chunk partial rows are left un-summed for the optimiser's launch; dW / db are then only
+    placeholders for autograd (None for a parameter's second contribution of the step)."""
     buf = torch.empty(N * K + N, dtype=torch.float32, device=x.device)
     part = torch.empty(lib.pg_linear_bwd_w_scratch(x.size(0), K, N), dtype=torch.float32, device=x.device)
     gw = buf[:N * K].view(N, K)
     gb = buf[N * K:] if want_bias else None
     dz = torch.empty((x.size(0), N), dtype=torch.float32, device=x.device) if act != ACT_NONE else None
+    defer = _DEFER is not None and weight is not None and want_bias and bias is not None
     with torch.cuda.device(x.device):
-        L.check(lib.pg_linear_bwd_w(L.ptr(g), g.stride(0), L.ptr(x), x.stride(0), x.size(0), K, N, L.ptr(gw), L.ptr(gb),
-                                    L.ptr(y), y.stride(0) if y is not None else 0, act, L.ptr(dz), L.ptr(part),
-                                    L.stream_ptr()), "pg_linear_bwd_w")
+        L.check(lib.pg_linear_bwd_w_ex(L.ptr(g), g.stride(0), L.ptr(x), x.stride(0), x.size(0), K, N, L.ptr(gw), L.ptr(gb),
+                                       L.ptr(y), y.stride(0) if y is not None else 0, act, L.ptr(dz), L.ptr(part),
+                                       0 if defer else 1, L.stream_ptr()), "pg_linear_bwd_w")
+    if defer:
+        rowlen = N * K + N
+        if not _DEFER.add(weight, part, part.numel() // rowlen, rowlen, 0):
+            gw = None
+        if not _DEFER.add(bias, part, part.numel() // rowlen, rowlen, N * K):
+            gb = None
     return gw, gb, (dz if dz is not None else g)
 
 
@@ -345,6 +366,7 @@ class _DualLinear(torch.autograd.Function):
                     "pg_linear2_fwd")
         ctx.save_for_backward(x1, w1, x2, w2, y if act != ACT_NONE else None)
         ctx.bias = (b1 is not None, b2 is not None)
+        ctx.bias_refs = (b1, b2)
         ctx.act = act
         return y
 
@@ -355,15 +377,22 @@ class _DualLinear(torch.autograd.Function):
         gy = gy.contiguous()
         N = w1.size(0)
         need = ctx.needs_input_grad
-        gw1, gb1, dz = _bwd_w(lib, gy, x1, w1.size(1), N, y, ctx.act, ctx.bias[0])
-        gw2, gb2, _ = _bwd_w(lib, dz, x2, w2.size(1), N, None, ACT_NONE, ctx.bias[1])
+        gw1, gb1, dz = _bwd_w(lib, gy, x1, w1.size(1), N, y, ctx.act, ctx.bias[0], w1, ctx.bias_refs[0])
+        gw2, gb2, _ = _bwd_w(lib, dz, x2, w2.size(1), N, None, ACT_NONE, ctx.bias[1], w2, ctx.bias_refs[1])
         gx1 = dz @ w1 if need[0] else None
         gx2 = dz @ w2 if need[3] else None
         return gx1, gw1, gb1, gx2, gw2, gb2, None
 
 
+def _rows_ok(x):
+    """tall inputs only (below ~1 K rows the library GEMM is as fast) — unless partial sums are being deferred: a
+    parameter applied twice per step must take the SAME path both times (a placeholder gradient from the deferring
+    path plus a real one from the library path would be mis-accumulated), whatever the two blocks' row counts are"""
+    return x.size(0) >= 1024 or _DEFER is not None
+
+
 def _skinny_ok(x, w):
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and w.size(0) <= 64 and x.size(0) >= 1024
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and w.size(0) <= 64 and _rows_ok(x)
             and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and w.is_contiguous())
 
 
@@ -380,7 +409,7 @@ def linear(x, module, act=ACT_NONE):
     """NodeUpdate's nn.Linear (+ activation): tall inputs (thousands of rows, <= 64 outputs) go through
     _SkinnyLinear, anything else through the module itself"""
     w, b = module.weight, module.bias
-    if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and w.size(0) <= 64 and x.size(0) >= 1024
+    if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and w.size(0) <= 64 and _rows_ok(x)
             and x.stride(1) == 1):
         y = _SkinnyLinear.apply(x, w, b, act)
         if act == ACT_CONCAT:

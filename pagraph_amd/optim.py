@@ -31,8 +31,10 @@ class Adam(torch.optim.Optimizer):
         the weight-gradient kernels are added up (pg_sum_partials' order) inside this step's single launch"""
         if deferred is not None and not deferred.conflict and (deferred.by_param or deferred.extra):
             return self._step_deferred(deferred, bump)
+        if bump is not None:
+            bump.add_(1)           # nothing was deferred (library fall-backs ran): the counter still advances once per step
         if deferred is not None and deferred.conflict:
-            raise L.PgError("deferred partial sums: a parameter received two gradient contributions in one step")
+            raise L.PgError("deferred partial sums: a parameter received more than two gradient contributions in one step")
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -97,6 +99,7 @@ class Adam(torch.optim.Optimizer):
         P, G, M, V, PT = (vp * n)(), (vp * n)(), (vp * n)(), (vp * n)(), (vp * n)()
         numel = (ctypes.c_int64 * n)()
         chunks, rowlen, off, adam = (i32 * n)(), (i32 * n)(), (i32 * n)(), (i32 * n)()
+        PT2, chunks2, rowlen2, off2 = (vp * n)(), (i32 * n)(), (i32 * n)(), (i32 * n)()
         for k, p in enumerate(ps):
             P[k], G[k] = p.data_ptr(), p.grad.data_ptr()
             M[k], V[k] = self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr()
@@ -106,14 +109,19 @@ class Adam(torch.optim.Optimizer):
                 if e[4] != p.numel():
                     raise L.PgError("deferred partial sums: registered size differs from the parameter's")
                 PT[k], chunks[k], rowlen[k], off[k] = e[0].data_ptr(), e[1], e[2], e[3]
+                e2 = reg.second.get(p.data_ptr())
+                if e2 is not None:             # applied twice this step: sum(first) + sum(second)
+                    if e2[4] != p.numel():
+                        raise L.PgError("deferred partial sums: registered size differs from the parameter's")
+                    PT2[k], chunks2[k], rowlen2[k], off2[k] = e2[0].data_ptr(), e2[1], e2[2], e2[3]
         for j, (dst, part, ch, rl, of) in enumerate(reg.extra):
             k = len(ps) + j
             G[k], PT[k], numel[k] = dst.data_ptr(), part.data_ptr(), dst.numel()
             chunks[k], rowlen[k], off[k], adam[k] = ch, rl, of, 0
         b1, b2 = group['betas']
         with torch.cuda.device(dev):
-            L.check(self._lib.pg_adam_step_partials(n, P, G, M, V, numel, PT, chunks, rowlen, off, adam, float(group['lr']),
-                                                    float(b1), float(b2), float(group['eps']),
-                                                    float(group['weight_decay']), L.ptr(step_dev), L.ptr(ticket),
-                                                    L.ptr(bump), L.stream_ptr()), "pg_adam_step_partials")
+            L.check(self._lib.pg_adam_step_partials2(n, P, G, M, V, numel, PT, chunks, rowlen, off, PT2, chunks2, rowlen2,
+                                                     off2, adam, float(group['lr']), float(b1), float(b2),
+                                                     float(group['eps']), float(group['weight_decay']), L.ptr(step_dev),
+                                                     L.ptr(ticket), L.ptr(bump), L.stream_ptr()), "pg_adam_step_partials")
         return None

@@ -182,8 +182,8 @@ class GraphedTrainer:
         # aggregates them (model.virtual_inputs) and `need` is given — SURVEY 8f-2
         self.fuse_gather = True
         # the two ordered partial sums of the weight-gradient kernels ride in the optimiser's launch (ops.defer_partials)
-        # when the model says every parameter gets ONE gradient contribution per step (GCN; not GraphSAGE, whose
-        # NodeUpdate is applied to several blocks) and the optimiser is pagraph_amd.optim.Adam on one GPU
+        # when the model says every parameter gets at most TWO gradient contributions per step (GCN: one; GraphSAGE with
+        # n_layers == 1: its first NodeUpdate runs on both blocks) and the optimiser is pagraph_amd.optim.Adam on one GPU
         self.fuse_partials = True
         self.world = int(world_size)
         self.pg = process_group
@@ -361,7 +361,7 @@ class GraphedTrainer:
         from .optim import Adam
         m = self._bare_model()
         return (self.fuse_partials and self.world == 1 and isinstance(self.optimizer, Adam)
-                and getattr(m, "single_use_parameters", False) and len(self.optimizer.param_groups) == 1)
+                and getattr(m, "deferrable_parameters", False) and len(self.optimizer.param_groups) == 1)
 
     def _step_body_deferred(self, s):
         """_step_body for one GPU with the partial sums (and the dropout step counter's increment) folded into the

@@ -2060,3 +2060,66 @@ def test_reddit_width_runs_on_the_fused_path(dev, hiplib, arch):
     c.fetch_data(nf, need=need, slot=0, virtual=model2.virtual_inputs(3))
     y = model2(nf)
     assert torch.isfinite(y).all()
+
+
+@pytest.mark.gpu
+def test_graphsage_deferred_partial_sums_two_uses_bit_identical(dev, hiplib):
+    """GraphSAGE's first NodeUpdate runs on both blocks (graphsage_nssc.py:92-131): its parameters get TWO gradient
+    contributions per step. ops.defer_partials hands autograd one placeholder and the optimiser's launch forms
+    sum(first) + sum(second) (pg_adam_step_partials2) — parameters, Adam state and p.grad equal the unfused path
+    (k_sum_partials per contribution + AccumulateGrad's add + pg_adam_step) bit for bit over several steps"""
+    import torch.nn.functional as Fn
+    from pagraph_amd import ops
+    from pagraph_amd.model import GraphSageSampling
+    from pagraph_amd.optim import Adam
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    rng = np.random.default_rng(33)
+    V, Fd, C, B = 8000, 600, 41, 3000
+    g = DeviceGraph(_rand_csc(rng, V, 80000))
+    feats = torch.from_numpy(rng.random((V, Fd), dtype=np.float32)).to(dev)
+    labels_all = torch.from_numpy(rng.integers(0, C, V)).to(dev)
+    smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=False, num_hops=2, seed_nodes=np.arange(V), seed=2)
+    nfs = [nf for _, nf in zip(range(3), smp)]           # 3000, 3000, 2000 seeds: every dense step is on the MFMA kernels
+    assert len(nfs) == 3
+    loss_fcn = ops.fused_loss(torch.nn.CrossEntropyLoss())
+    runs = []
+    for deferred in (False, True):
+        torch.manual_seed(3)
+        model = GraphSageSampling(Fd, 16, C, 1, Fn.relu, 0.2, 'mean').to(dev).train()
+        assert model.deferrable_parameters
+        opt = Adam(model.parameters(), lr=1e-2)
+        losses = []
+        for it, nf in enumerate(nfs):
+            ids = nf._node_mapping.tousertensor()
+            o = nf._layer_offsets
+            for i in range(nf.num_layers):
+                nf._node_frames[i] = {"features": feats[ids[o[i]:o[i + 1]]]}
+            lab = labels_all[ids[o[-2]:o[-1]]].contiguous()
+            model._drop_step.fill_(10 + it)
+            opt.zero_grad(set_to_none=True)
+            if deferred:
+                with ops.defer_partials() as reg:
+                    loss = loss_fcn(model(nf), lab)
+                    loss.backward()
+                # 8 parameter tensors; layers.0's four are applied to block 0 and block 1
+                assert len(reg.by_param) == 8 and len(reg.second) == 4 and not reg.conflict, \
+                    (it, len(reg.by_param), len(reg.second), reg.conflict)
+                opt.step(deferred=reg)
+            else:
+                loss = loss_fcn(model(nf), lab)
+                loss.backward()
+                opt.step()
+            torch.cuda.synchronize()
+            losses.append(loss.detach().clone())
+        runs.append((losses, [p.detach().clone() for p in model.parameters()], [p.grad.clone() for p in model.parameters()],
+                     [opt.state[p]['exp_avg_sq'].clone() for p in model.parameters()]))
+    for a, b in zip(runs[0], runs[1]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    # a third use of a parameter in one step is refused, not mis-summed
+    reg = ops.DeferredPartials()
+    w = torch.zeros(4, device=dev)
+    pt = torch.zeros(8, device=dev)
+    assert reg.add(w, pt, 2, 4, 0) and not reg.add(w, pt, 2, 4, 0) and not reg.conflict
+    reg.add(w, pt, 2, 4, 0)
+    assert reg.conflict
