@@ -9,7 +9,7 @@
 // which made it the largest item on the compute stream once the gather was fast. The shape is
 // HBM/L2-streaming bound: X (29 MB) is read once forward and once backward.
 //
-// forward   block = 4 waves on ONE 32-row tile, K split four ways (each wave: <= 19 octets of k,
+// forward   block = NW waves (4 / 8 / 16 by K) on ONE 32-row tile, K split NW ways (K = 600: 16 waves x <= 5 octets of k,
 //           4 MFMAs per octet: A = one float4 of its X row per lane, B = one float4 of its weight
 //           row per lane — W is read as stored, [N][K], no transpose pass); partial 32x32 tiles reduced
 //           through LDS; epilogue fuses bias and NodeUpdate's activation / skip-concat
@@ -22,6 +22,8 @@
 //           sat at 25-50 us whatever the tiling. Also used for the output layer (N = 60, K = 64): the library GEMM has two
 //           output tiles and a 6000-long reduction there and takes 51 us.
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include <cstdlib>
 
 #include "pg_common.h"
 
@@ -42,8 +44,11 @@ constexpr int kTile = 32;
 // inside the row; whatever lies in the padding is masked).
 typedef float df2 __attribute__((ext_vector_type(2)));
 
-template <int WV>
-__global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ X, int32_t x_stride,
+// NW = waves per 32-row tile, K split NW ways. A tile's waves are its only memory-level parallelism (12 000 rows are
+// 375 tiles — 1.5 per CU): with 4 waves and K = 600 each wave walks 19 octets in five dependent rounds of loads and the
+// kernel streams X at 1.5 TB/s; 16 waves take the same K in two rounds.
+template <int WV, int NW>
+__global__ __launch_bounds__(NW * 64) void k_linear_fwd(const float* __restrict__ X, int32_t x_stride,
                                                     const float* __restrict__ W /* [N][K] */,
                                                     const float* __restrict__ bias /* [N] or null */,
                                                     const float* __restrict__ X2, int32_t x2_stride,
@@ -51,14 +56,14 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ X,
                                                     const float* __restrict__ bias2, int32_t K2,
                                                     float* __restrict__ Y, int32_t y_stride, int64_t n, int32_t K,
                                                     int32_t N, int32_t act) {
-  __shared__ float red[4][kTile][kTile + 1];
+  __shared__ float red[NW][kTile][kTile + 1];
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
   const int64_t r0 = (int64_t)blockIdx.x * kTile;
   const int n0 = (int)blockIdx.y * kTile;             // first output column of this block
   const int64_t row = r0 + (lane & 31);
   const int half = lane >> 5;
   const int oct1 = (K + 7) / 8, octets = oct1 + (K2 + 7) / 8;
-  const int o_beg = (octets * w) / 4, o_end = (octets * (w + 1)) / 4;
+  const int o_beg = (octets * w) / NW, o_end = (octets * (w + 1)) / NW;
   const bool row_ok = row < n;
   const int col = n0 + (lane & 31);
   const bool col_ok = col < N;
@@ -130,13 +135,15 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ X,
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[w][(r & 3) + 8 * (r >> 2) + 4 * half][lane & 31] = acc[r];
   __syncthreads();
-  // 256 threads x 4 outputs: thread t -> row t / 8, cols 4 * (t % 8) .. +3
+  // 256 threads x 4 outputs: thread t -> row t / 8, cols 4 * (t % 8) .. +3; the waves' partial tiles are added in wave order
   const int orow = threadIdx.x >> 3, oc = (threadIdx.x & 7) * 4;
-  if (r0 + orow < n) {
+  if (threadIdx.x < 256 && r0 + orow < n) {
     float v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       v[j] = red[0][orow][oc + j] + red[1][orow][oc + j] + red[2][orow][oc + j] + red[3][orow][oc + j];
+#pragma unroll
+      for (int ww = 4; ww < NW; ++ww) v[j] += red[ww][orow][oc + j];
       if (bias && n0 + oc + j < N) v[j] += bias[n0 + oc + j];
       if (bias2 && n0 + oc + j < N) v[j] += bias2[n0 + oc + j];
     }
@@ -330,12 +337,22 @@ static int linear_fwd(const float* X, int32_t x_stride, const float* W, const fl
   }
   if (K2 == 0) X2 = W2 = bias2 = nullptr;
   const dim3 grid((unsigned)ceil_div<int64_t>(n, kTile), (unsigned)ceil_div<int>(N, kTile));
-#define PG_LIN_FWD(WV)                                                                                               \
-  hipLaunchKernelGGL(k_linear_fwd<WV>, grid, dim3(256), 0, as_stream(stream), X, x_stride, W, bias, X2, x2_stride, W2, \
-                     bias2, K2, Y, y_stride, n, K, N, act)
-  if (wv == 4) PG_LIN_FWD(4);
-  else if (wv == 2) PG_LIN_FWD(2);
-  else PG_LIN_FWD(1);
+  // waves per tile: enough that a wave's share of K is a round or two of loads (each round = 4 octets in flight)
+  static const int nw_force = getenv("PG_LINEAR_WAVES") ? atoi(getenv("PG_LINEAR_WAVES")) : 0;
+  const int octets = (K + 7) / 8 + (K2 + 7) / 8;
+  int nw = octets >= 64 ? 16 : (octets >= 32 ? 8 : 4);
+  if (nw_force == 4 || nw_force == 8 || nw_force == 16) nw = nw_force;
+#define PG_LIN_FWD(WV, NW)                                                                                          \
+  hipLaunchKernelGGL((k_linear_fwd<WV, NW>), grid, dim3(NW * 64), 0, as_stream(stream), X, x_stride, W, bias, X2,    \
+                     x2_stride, W2, bias2, K2, Y, y_stride, n, K, N, act)
+#define PG_LIN_FWD_NW(WV)        \
+  if (nw == 16) PG_LIN_FWD(WV, 16); \
+  else if (nw == 8) PG_LIN_FWD(WV, 8); \
+  else PG_LIN_FWD(WV, 4)
+  if (wv == 4) { PG_LIN_FWD_NW(4); }
+  else if (wv == 2) { PG_LIN_FWD_NW(2); }
+  else { PG_LIN_FWD_NW(1); }
+#undef PG_LIN_FWD_NW
 #undef PG_LIN_FWD
   PG_LAUNCH_CHECK();
   return PG_OK;

@@ -1,11 +1,49 @@
 #!/bin/bash
-O=gpurun_out/sage; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "deferred or graphed_trainer or virtual_layer0 or models_vs_reference or reddit_width or two_rank" > $O/tests.log 2>&1; tail -4 $O/tests.log
-pick='import json,sys,statistics as st; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); w=d["ms_per_step_windows"]; q=d["miss_queue"] or {}; print(round(d["ms_per_step"],4), "median window", round(st.median(w),4), "gather us", round(q.get("us_cpu_gather",0)))'
+O=gpurun_out/lin; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "linear or model or head or graphed or virtual or reddit or deferred" > $O/tests.log 2>&1; tail -3 $O/tests.log
+python - <<'PY'
+import torch, ctypes, os, sys
+sys.path.insert(0, os.getcwd())
+from pagraph_amd import _lib as L
+lib = L.load(); dev = torch.device("cuda", 0)
+def t(n, K, K2, N, act):
+    x = torch.rand((n, K), device=dev); w = torch.rand((N, K), device=dev); b = torch.rand(N, device=dev)
+    x2 = torch.rand((n, K2), device=dev) if K2 else None; w2 = torch.rand((N, K2), device=dev) if K2 else None
+    y = torch.empty((n, 2 * N), device=dev)
+    def run():
+        if K2: L.check(lib.pg_linear2_fwd(L.ptr(x), K, L.ptr(w), L.ptr(b), K, L.ptr(x2), K2, L.ptr(w2), L.ptr(b), K2, L.ptr(y), 2 * N, n, N, act, L.stream_ptr()))
+        else: L.check(lib.pg_linear_fwd(L.ptr(x), K, L.ptr(w), L.ptr(b), L.ptr(y), 2 * N, n, K, N, act, L.stream_ptr()))
+    for _ in range(10): run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(200): run()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 200 * 1e3
+    print(f"n={n} K={K}+{K2} N={N}: {us:.1f} us  {n * (K + K2) * 4 / us / 1e3:.0f} GB/s")
+for args in [(12000, 600, 0, 32, 2), (12000, 600, 600, 16, 2), (6000, 600, 600, 16, 2), (6000, 64, 0, 60, 0), (12000, 608, 0, 32, 2)]:
+    t(*args)
+PY
+for w in 4 8 16; do echo "PG_LINEAR_WAVES=$w"; PG_LINEAR_WAVES=$w python - <<'PY'
+import torch, ctypes, os, sys
+sys.path.insert(0, os.getcwd())
+from pagraph_amd import _lib as L
+lib = L.load(); dev = torch.device("cuda", 0)
+for n, K, N in [(12000, 600, 32), (6000, 1200, 16)]:
+    x = torch.rand((n, K), device=dev); w = torch.rand((N, K), device=dev); b = torch.rand(N, device=dev); y = torch.empty((n, 2 * N), device=dev)
+    run = lambda: L.check(lib.pg_linear_fwd(L.ptr(x), K, L.ptr(w), L.ptr(b), L.ptr(y), 2 * N, n, K, N, 2, L.stream_ptr()))
+    for _ in range(10): run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(200): run()
+    e1.record(); torch.cuda.synchronize()
+    print(f"  n={n} K={K}: {e0.elapsed_time(e1) / 200 * 1e3:.1f} us")
+PY
+done
+pick='import json,sys,statistics as st; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); w=d["ms_per_step_windows"]; print(round(d["ms_per_step"],4), "median window", round(st.median(w),4))'
 B="python bench.py --steps 1084 --warmup 20 --skip-cpu-baseline --skip-microbench --skip-opt-hit --skip-reference-equivalent"
-echo "== gcn"; timeout 300 $B 2> $O/last.err | python -c "$pick" || tail -5 $O/last.err
-echo "== graphsage 30%"; timeout 300 $B --model graphsage 2> $O/last.err | python -c "$pick" || tail -5 $O/last.err
-echo "== graphsage full cache"; timeout 300 $B --model graphsage --cache-ratio 1.0 2> $O/last.err | python -c "$pick" || tail -5 $O/last.err
-echo "== graphsage 30% unfused partials"; PG_NO_DEFER_SAGE=1 timeout 300 $B --model graphsage 2> $O/last.err | python -c "$pick" || tail -5 $O/last.err
-cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_gs -o b -- python $GRAFT_REPO_ROOT/bench.py --model graphsage --skip-cpu-baseline --skip-opt-hit --skip-reference-equivalent --skip-microbench > /tmp/prof_gs.log 2>&1
-cd $GRAFT_REPO_ROOT; python tools/trace_seq.py /tmp/prof_gs/b_kernel_trace.csv > $O/graphsage_step_sequence.txt 2>&1; tail -3 $O/graphsage_step_sequence.txt
+echo "== gcn full cache"; timeout 300 $B --cache-ratio 1.0 2>/dev/null | python -c "$pick"
+echo "== graphsage full cache"; timeout 300 $B --model graphsage --cache-ratio 1.0 2>/dev/null | python -c "$pick"
+echo "== gcn 30"; timeout 300 $B 2>/dev/null | python -c "$pick"
+echo "== graphsage 30"; timeout 300 $B --model graphsage 2>/dev/null | python -c "$pick"
