@@ -1,4 +1,5 @@
 #!/bin/bash
-pick='import json,sys,statistics as st; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); w=d["ms_per_step_windows"]; q=d["miss_queue"]; m=st.median(w); print(round(m,3), "SLOW" if m>0.2 else "", "gather", round(q["us_cpu_gather"]), "pub", round(q["us_submit_to_published"]), "enq", round(q["us_enqueue"],1), "done", round(q["us_submit_to_done"]), "host", round(d["host_issue_ms_per_step"],3), "ev/spin", q["timed_region"]["waits_by_event"], q["timed_region"]["waits_by_spin_kernel"], "cpus", round(d["host"]["timed_region_cgroup"]["cpus_used"],1), "win", w[:4])'
+pick='import json,sys,statistics as st; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); w=d["ms_per_step_windows"]; print(round(st.median(w),3), d["miss_queue"]["sdma_engine_mask"], end=" | ")'
 B="python bench.py --gpus 1 --steps 200 --warmup 5 --skip-microbench --skip-cpu-baseline --skip-opt-hit --skip-reference-equivalent"
-for i in $(seq 1 36); do PG_MISSQ_DEBUG=1 timeout 300 $B 2>gpurun_out/last_dbg.err | python -c "$pick" | tee /tmp/line.txt; if grep -q SLOW /tmp/line.txt; then grep "missq\]" gpurun_out/last_dbg.err | tail -4; fi; done
+for i in $(seq 1 40); do timeout 300 $B 2>/dev/null | python -c "$pick"; done; echo
+echo -n "graphsage: "; for i in $(seq 1 8); do timeout 300 $B --model graphsage 2>/dev/null | python -c "$pick"; done; echo
