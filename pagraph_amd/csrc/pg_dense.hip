@@ -45,9 +45,18 @@ constexpr int kTile = 32;
 typedef float df2 __attribute__((ext_vector_type(2)));
 
 // NW = waves per 32-row tile, K split NW ways. A tile's waves are its only memory-level parallelism (12 000 rows are
-// 375 tiles — 1.5 per CU): with 4 waves and K = 600 each wave walks 19 octets in five dependent rounds of loads and the
-// kernel streams X at 1.5 TB/s; 16 waves take the same K in two rounds.
-template <int WV, int NW>
+// 375 tiles — 1.5 per CU): with 4 waves and K = 600 each wave walks 19 octets in five dependent rounds of loads.
+// LDSX: a wave's share of X goes through LDS. Straight from global, lane (row, half) reads 16 bytes of ITS row per
+// octet — one instruction touches 32 rows = 32 cache lines and uses 32 bytes of each, and the kernel sits at 1.6 TB/s
+// whatever the wave count. With LDSX a wave fetches its [32 rows x 32 floats] slab (four octets) coalesced — 8 rows x
+// 128 bytes per instruction — parks it in its own LDS region (row stride 36 floats) and reads the MFMA operand layout
+// back from there. W (77 KB, the same for every tile) stays on the direct path: it lives in L2 — and is now the larger
+// share of the kernel's cache traffic (every 32-row tile re-reads all of W with the same 32-lines-per-instruction
+// pattern): 12 000 x 600 x 32 takes 14.7 us (2.0 TB/s of X) against 18.1 us without the slab; staging W the same way,
+// or 64-row tiles, is what is left.
+constexpr int kXsStride = 36;
+
+template <int WV, int NW, bool LDSX>
 __global__ __launch_bounds__(NW * 64) void k_linear_fwd(const float* __restrict__ X, int32_t x_stride,
                                                     const float* __restrict__ W /* [N][K] */,
                                                     const float* __restrict__ bias /* [N] or null */,
@@ -56,7 +65,9 @@ __global__ __launch_bounds__(NW * 64) void k_linear_fwd(const float* __restrict_
                                                     const float* __restrict__ bias2, int32_t K2,
                                                     float* __restrict__ Y, int32_t y_stride, int64_t n, int32_t K,
                                                     int32_t N, int32_t act) {
-  __shared__ float red[NW][kTile][kTile + 1];
+  // one LDS buffer: during the K loop wave w's X slab, afterwards wave w's partial output tile (same region, same wave)
+  __shared__ __attribute__((aligned(16))) float smem[NW * kTile * kXsStride];
+  float (*red)[kTile][kXsStride] = reinterpret_cast<float (*)[kTile][kXsStride]>(smem);
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
   const int64_t r0 = (int64_t)blockIdx.x * kTile;
   const int n0 = (int)blockIdx.y * kTile;             // first output column of this block
@@ -115,6 +126,58 @@ __global__ __launch_bounds__(NW * 64) void k_linear_fwd(const float* __restrict_
   // four octets (8 x 16-byte loads per lane) in flight per iteration: the wave is otherwise one load
   // round trip per 4 MFMAs
   int o = o_beg;
+  if constexpr (LDSX) {
+    float* xs = smem + (size_t)w * kTile * kXsStride;
+    for (; o + 3 < o_end; o += 4) {
+      const bool first = o < oct1;
+      if (first && o + 3 >= oct1) break;              // a slab never straddles the two operands: the tail loop takes it
+      const float* xb = first ? X : X2;
+      const int64_t xst = first ? x_stride : x2_stride;
+      const int Kx = first ? K : K2;
+      const int kbase = (first ? o : o - oct1) * 8;
+      // coalesced fetch: chunk c = lane + 64 i -> row c / 8, 16-byte segment c % 8 of the slab
+      df4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i, r = c >> 3, kc = kbase + (c & 7) * 4;
+        v[i] = df4{0.f, 0.f, 0.f, 0.f};
+        if (r0 + r < n && kc < Kx) {
+          v[i] = *reinterpret_cast<const df4*>(xb + (r0 + r) * xst + kc);   // rows are padded to 4 floats
+          const int left = Kx - kc;
+          if (left < 4) {
+            if (left < 2) v[i].y = 0.f;
+            if (left < 3) v[i].z = 0.f;
+            v[i].w = 0.f;
+          }
+        }
+      }
+      df4 b0, b1, b2, b3, dummy;
+      load(o, dummy, b0);          // (the direct A loads of these calls are dead code: only b is used)
+      load(o + 1, dummy, b1);
+      load(o + 2, dummy, b2);
+      load(o + 3, dummy, b3);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        *reinterpret_cast<df4*>(xs + (c >> 3) * kXsStride + (c & 7) * 4) = v[i];
+      }
+      // the slab is private to this wave: its lanes run in lock step, so all that is needed is that the writes have
+      // landed in LDS before the reads are issued
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const float* xa = xs + (lane & 31) * kXsStride + 4 * half;
+      const df4 a0 = *reinterpret_cast<const df4*>(xa);
+      const df4 a1 = *reinterpret_cast<const df4*>(xa + 8);
+      const df4 a2 = *reinterpret_cast<const df4*>(xa + 16);
+      const df4 a3 = *reinterpret_cast<const df4*>(xa + 24);
+      mma(a0, b0);
+      mma(a1, b1);
+      mma(a2, b2);
+      mma(a3, b3);
+      __builtin_amdgcn_wave_barrier();               // the next slab's writes stay behind these reads
+    }
+  }
   for (; o + 3 < o_end; o += 4) {
     df4 a0, b0, a1, b1, a2, b2, a3, b3;
     load(o, a0, b0);
@@ -340,11 +403,18 @@ static int linear_fwd(const float* X, int32_t x_stride, const float* W, const fl
   // waves per tile: enough that a wave's share of K is a round or two of loads (each round = 4 octets in flight)
   static const int nw_force = getenv("PG_LINEAR_WAVES") ? atoi(getenv("PG_LINEAR_WAVES")) : 0;
   const int octets = (K + 7) / 8 + (K2 + 7) / 8;
-  int nw = octets >= 64 ? 16 : (octets >= 32 ? 8 : 4);
+  int nw = octets >= 128 ? 16 : (octets >= 32 ? 8 : 4);   // measured: K = 600 -> 8 waves (14.7 us vs 16.5 / 17.1), K = 1200 -> 16 (13.8 vs 16.0)
   if (nw_force == 4 || nw_force == 8 || nw_force == 16) nw = nw_force;
+  static const bool no_lds = getenv("PG_LINEAR_NO_LDS") != nullptr;
 #define PG_LIN_FWD(WV, NW)                                                                                          \
-  hipLaunchKernelGGL((k_linear_fwd<WV, NW>), grid, dim3(NW * 64), 0, as_stream(stream), X, x_stride, W, bias, X2,    \
-                     x2_stride, W2, bias2, K2, Y, y_stride, n, K, N, act)
+  do {                                                                                                              \
+    if (no_lds)                                                                                                     \
+      hipLaunchKernelGGL((k_linear_fwd<WV, NW, false>), grid, dim3(NW * 64), 0, as_stream(stream), X, x_stride, W,  \
+                         bias, X2, x2_stride, W2, bias2, K2, Y, y_stride, n, K, N, act);                            \
+    else                                                                                                            \
+      hipLaunchKernelGGL((k_linear_fwd<WV, NW, true>), grid, dim3(NW * 64), 0, as_stream(stream), X, x_stride, W,   \
+                         bias, X2, x2_stride, W2, bias2, K2, Y, y_stride, n, K, N, act);                            \
+  } while (0)
 #define PG_LIN_FWD_NW(WV)        \
   if (nw == 16) PG_LIN_FWD(WV, 16); \
   else if (nw == 8) PG_LIN_FWD(WV, 8); \
