@@ -50,10 +50,9 @@ typedef float df2 __attribute__((ext_vector_type(2)));
 // octet — one instruction touches 32 rows = 32 cache lines and uses 32 bytes of each, and the kernel sits at 1.6 TB/s
 // whatever the wave count. With LDSX a wave fetches its [32 rows x 32 floats] slab (four octets) coalesced — 8 rows x
 // 128 bytes per instruction — parks it in its own LDS region (row stride 36 floats) and reads the MFMA operand layout
-// back from there. W (77 KB, the same for every tile) stays on the direct path: it lives in L2 — and is now the larger
-// share of the kernel's cache traffic (every 32-row tile re-reads all of W with the same 32-lines-per-instruction
-// pattern): 12 000 x 600 x 32 takes 14.7 us (2.0 TB/s of X) against 18.1 us without the slab; staging W the same way,
-// or 64-row tiles, is what is left.
+// back from there. W (77 KB, re-read by every 32-row tile: as much cache traffic as X itself) takes the same route when
+// its rows are 16-byte aligned (K % 4 == 0). 12 000 x 600 x 32: 18.1 us direct, 14.7 with the X slab, 13.7 with both
+// (2.1 TB/s of X); the two-operand 12 000 x (600 + 600) x 16: 28.4 -> 21.1 us.
 constexpr int kXsStride = 36;
 
 template <int WV, int NW, bool LDSX>
@@ -66,7 +65,8 @@ __global__ __launch_bounds__(NW * 64) void k_linear_fwd(const float* __restrict_
                                                     float* __restrict__ Y, int32_t y_stride, int64_t n, int32_t K,
                                                     int32_t N, int32_t act) {
   // one LDS buffer: during the K loop wave w's X slab, afterwards wave w's partial output tile (same region, same wave)
-  __shared__ __attribute__((aligned(16))) float smem[NW * kTile * kXsStride];
+  // (+ with WV == 4 a second slab per wave for its share of W)
+  __shared__ __attribute__((aligned(16))) float smem[NW * kTile * kXsStride * ((LDSX && WV == 4) ? 2 : 1)];
   float (*red)[kTile][kXsStride] = reinterpret_cast<float (*)[kTile][kXsStride]>(smem);
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
   const int64_t r0 = (int64_t)blockIdx.x * kTile;
@@ -152,10 +152,29 @@ __global__ __launch_bounds__(NW * 64) void k_linear_fwd(const float* __restrict_
         }
       }
       df4 b0, b1, b2, b3, dummy;
-      load(o, dummy, b0);          // (the direct A loads of these calls are dead code: only b is used)
-      load(o + 1, dummy, b1);
-      load(o + 2, dummy, b2);
-      load(o + 3, dummy, b3);
+      if constexpr (WV == 4) {
+        // W's [32 columns x 32 floats] slab the same way (rows of W are 16-byte aligned when K % 4 == 0): every tile
+        // re-reads all of W, so its access pattern matters as much as X's
+        const float* wb = first ? W : W2;
+        float* ws = smem + (size_t)(NW + w) * kTile * kXsStride;
+        df4 u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = lane + 64 * i, cc = n0 + (c >> 3), kc = kbase + (c & 7) * 4;
+          u[i] = df4{0.f, 0.f, 0.f, 0.f};
+          if (cc < N && kc < Kx) u[i] = *reinterpret_cast<const df4*>(wb + (int64_t)cc * Kx + kc);   // K % 4 == 0: whole quads
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = lane + 64 * i;
+          *reinterpret_cast<df4*>(ws + (c >> 3) * kXsStride + (c & 7) * 4) = u[i];
+        }
+      } else {
+        load(o, dummy, b0);          // (the direct A loads of these calls are dead code: only b is used)
+        load(o + 1, dummy, b1);
+        load(o + 2, dummy, b2);
+        load(o + 3, dummy, b3);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int c = lane + 64 * i;
@@ -166,6 +185,13 @@ __global__ __launch_bounds__(NW * 64) void k_linear_fwd(const float* __restrict_
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if constexpr (WV == 4) {
+        const float* wa = smem + (size_t)(NW + w) * kTile * kXsStride + (lane & 31) * kXsStride + 4 * half;
+        b0 = *reinterpret_cast<const df4*>(wa);
+        b1 = *reinterpret_cast<const df4*>(wa + 8);
+        b2 = *reinterpret_cast<const df4*>(wa + 16);
+        b3 = *reinterpret_cast<const df4*>(wa + 24);
+      }
       const float* xa = xs + (lane & 31) * kXsStride + 4 * half;
       const df4 a0 = *reinterpret_cast<const df4*>(xa);
       const df4 a1 = *reinterpret_cast<const df4*>(xa + 8);
@@ -403,7 +429,9 @@ static int linear_fwd(const float* X, int32_t x_stride, const float* W, const fl
   // waves per tile: enough that a wave's share of K is a round or two of loads (each round = 4 octets in flight)
   static const int nw_force = getenv("PG_LINEAR_WAVES") ? atoi(getenv("PG_LINEAR_WAVES")) : 0;
   const int octets = (K + 7) / 8 + (K2 + 7) / 8;
-  int nw = octets >= 128 ? 16 : (octets >= 32 ? 8 : 4);   // measured: K = 600 -> 8 waves (14.7 us vs 16.5 / 17.1), K = 1200 -> 16 (13.8 vs 16.0)
+  // measured with both slabs in LDS: 8 waves win from K = 600 (13.7 us vs 14.2 / 15.3) to the two-operand K = 1200
+  // (21.1 vs 23.5 / 24.7 at 12 000 rows; 13.2 vs 12.6 with 16 waves at 6 000)
+  int nw = octets >= 32 ? 8 : 4;
   if (nw_force == 4 || nw_force == 8 || nw_force == 16) nw = nw_force;
   static const bool no_lds = getenv("PG_LINEAR_NO_LDS") != nullptr;
 #define PG_LIN_FWD(WV, NW)                                                                                          \

@@ -1,10 +1,9 @@
 #!/bin/bash
 O=gpurun_out/lin; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "linear or model or head or graphed or virtual or reddit or deferred or golden" > $O/tests.log 2>&1; tail -3 $O/tests.log
-for v in "" 1; do echo "PG_LINEAR_NO_LDS=$v"; PG_LINEAR_NO_LDS=$v python - <<'PY'
+for w in 4 8 16; do echo "PG_LINEAR_WAVES=$w"; PG_LINEAR_WAVES=$w python - <<'PY'
 import torch, ctypes, os, sys
 sys.path.insert(0, os.getcwd())
-if not os.environ.get("PG_LINEAR_NO_LDS"): os.environ.pop("PG_LINEAR_NO_LDS", None)
 from pagraph_amd import _lib as L
 lib = L.load(); dev = torch.device("cuda", 0)
 def t(n, K, K2, N, act):
@@ -27,20 +26,7 @@ for args in [(12000, 600, 0, 32, 2), (12000, 602, 0, 32, 2), (12000, 600, 600, 1
     t(*args)
 PY
 done
-for w in 4 8 16; do echo "PG_LINEAR_WAVES=$w (lds)"; PG_LINEAR_WAVES=$w python - <<'PY'
-import torch, ctypes, os, sys
-sys.path.insert(0, os.getcwd())
-from pagraph_amd import _lib as L
-lib = L.load(); dev = torch.device("cuda", 0)
-for n, K, N in [(12000, 600, 32), (6000, 1200, 16)]:
-    x = torch.rand((n, K), device=dev); w = torch.rand((N, K), device=dev); b = torch.rand(N, device=dev); y = torch.empty((n, 2 * N), device=dev)
-    run = lambda: L.check(lib.pg_linear_fwd(L.ptr(x), K, L.ptr(w), L.ptr(b), L.ptr(y), 2 * N, n, K, N, 2, L.stream_ptr()))
-    for _ in range(10): run()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(200): run()
-    e1.record(); torch.cuda.synchronize()
-    print(f"  n={n} K={K}: {e0.elapsed_time(e1) / 200 * 1e3:.1f} us")
-PY
-done
+pick='import json,sys,statistics as st; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); w=d["ms_per_step_windows"]; print(round(d["ms_per_step"],4), "median window", round(st.median(w),4))'
+B="python bench.py --steps 1084 --warmup 20 --skip-cpu-baseline --skip-microbench --skip-opt-hit --skip-reference-equivalent"
+echo "== gcn full cache"; timeout 300 $B --cache-ratio 1.0 2>/dev/null | python -c "$pick"
+echo "== graphsage full cache"; timeout 300 $B --model graphsage --cache-ratio 1.0 2>/dev/null | python -c "$pick"
