@@ -135,6 +135,13 @@ int pg_gather_rows_dedup(const int64_t* ids, int64_t n, const int32_t* slot_map,
 int pg_split_rows_dedup(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
                         int32_t* miss_pos, int64_t* miss_fullid, int32_t* miss_count, int32_t* slots_out,
                         uint64_t* stats, const pg_dedup_t* dedup, pg_stream_t stream);
+/* the general form behind pg_scatter_rows / _range / _dups: out[pos[j] - pos_lo, :dim] = staged[(src_row ? src_row[j] : j)
+ * * staged_stride, :dim] for j < (n_dev ? *n_dev : n); rows below pos_lo or with a negative source are skipped.
+ * staged_stride >= dim lets the staged block keep padded rows (the miss queue pads wide rows to whole 16-byte pieces so
+ * that pg_spmm_fwd_rows can read a ragged width — 602 — in place). max_blocks > 0 caps the grid.                      */
+int pg_scatter_rows_strided(const float* staged, int32_t staged_stride, const int32_t* pos, const int32_t* src_row,
+                            int64_t n, const int32_t* n_dev, int32_t dim, float* out, int32_t out_stride, int32_t pos_lo,
+                            int32_t max_blocks, pg_stream_t stream);
 /* out[dup_pos[k] - pos_lo, :] = staged[dup_staged_row[k], :] for k < *dup_count_dev (entries below pos_lo or with a
  * negative staged row are skipped); cap = launch upper bound                                               */
 int pg_scatter_rows_dups(const float* staged, const int32_t* dup_pos, const int32_t* dup_staged_row, int64_t cap,
@@ -216,9 +223,11 @@ int pg_missq_submit_dedup(pg_missq_t* q, int slot, float* const* out_ptrs, const
                           const int32_t* pos_lo, const int32_t* slots_dev, pg_stream_t stream);
 int pg_missq_slot_dup_buffers(pg_missq_t* q, int slot, int32_t** dup_pos_dev, int32_t** dup_src_dev,
                               int32_t** dup_count_dev);
-/* device staging block of (slot, field): [max_rows, dim] floats, row j = entry j of the slot's miss list once
+/* device staging block of (slot, field): [max_rows, pg_missq_staged_stride] floats, row j = entry j of the slot's miss list once
  * the slot's wait (pg_missq_wait / _wait_device) has passed                                              */
 int pg_missq_slot_staged(pg_missq_t* q, int slot, int field, float** staged_dev);
+/* floats per row of field `field`'s staged block: dim rounded up to 4 for wide fields (dim >= 16), else dim */
+int pg_missq_staged_stride(pg_missq_t* q, int field, int32_t* stride_out);
 /* makes `stream` wait until the slot's miss rows have landed; blocks the HOST only until the worker has
  * enqueued the copy. miss_count_out (optional) receives the number of rows.                         */
 int pg_missq_wait(pg_missq_t* q, int slot, pg_stream_t stream, int32_t* miss_count_out);

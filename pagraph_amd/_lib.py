@@ -95,6 +95,8 @@ _SIGS = {
                                              ctypes.POINTER(c_i32), vp, vp]),
     "pg_missq_slot_dup_buffers": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp),
                                                  ctypes.POINTER(vp)]),
+    "pg_missq_staged_stride": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(c_i32)]),
+    "pg_scatter_rows_strided": (ctypes.c_int, [vp, c_i32, vp, vp, c_i64, vp, c_i32, vp, c_i32, c_i32, c_i32, vp]),
     "pg_missq_slot_staged": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]),
     "pg_missq_wait": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.POINTER(c_i32)]),
     "pg_missq_wait_device": (ctypes.c_int, [vp, ctypes.c_int, vp]),

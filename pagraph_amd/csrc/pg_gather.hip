@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void k_scatter(const float* __restrict__ stage
                                                  const int32_t* __restrict__ pos, int64_t n,
                                                  const int32_t* __restrict__ n_dev, int32_t dim,
                                                  float* __restrict__ out, int32_t out_stride, int32_t pos_lo,
-                                                 const int32_t* __restrict__ src_row) {
+                                                 const int32_t* __restrict__ src_row, int32_t staged_stride) {
   using V = typename VecT<VEC>::type;
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t nn = n_dev ? (int64_t)*n_dev : n;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void k_scatter(const float* __restrict__ stage
     if (p < 0) continue;          // a row below pos_lo stays where it is: its consumer reads the staged block
     const int64_t sj = src_row ? (int64_t)src_row[j] : j;   // dup list: staged row of the earlier occurrence
     if (sj < 0) continue;
-    const V* src = reinterpret_cast<const V*>(staged + sj * dim);
+    const V* src = reinterpret_cast<const V*>(staged + sj * staged_stride);
     V* dst = reinterpret_cast<V*>(out + (int64_t)p * out_stride);
     for (int c = lane; c < pieces; c += kWave) dst[c] = src[c];
   }
@@ -516,17 +516,27 @@ int pg_split_rows_dedup(const int64_t* ids, int64_t n, const int32_t* slot_map, 
 int pg_scatter_rows_dups(const float* staged, const int32_t* dup_pos, const int32_t* dup_staged_row, int64_t cap,
                          const int32_t* dup_count_dev, int32_t dim, float* out, int32_t out_stride, int32_t pos_lo,
                          pg_stream_t stream) {
-  if (cap < 0 || dim <= 0 || out_stride < dim || pos_lo < 0) return PG_ERR_INVALID;
-  if (cap == 0) return PG_OK;
-  if (!staged || !dup_pos || !dup_staged_row || !dup_count_dev || !out) return PG_ERR_INVALID;
+  if (!dup_staged_row || !dup_count_dev) return PG_ERR_INVALID;
+  return pg_scatter_rows_strided(staged, dim, dup_pos, dup_staged_row, cap, dup_count_dev, dim, out, out_stride, pos_lo, 64,
+                                 stream);
+}
+
+int pg_scatter_rows_strided(const float* staged, int32_t staged_stride, const int32_t* pos, const int32_t* src_row,
+                            int64_t n, const int32_t* n_dev, int32_t dim, float* out, int32_t out_stride, int32_t pos_lo,
+                            int32_t max_blocks, pg_stream_t stream) {
+  if (n < 0 || dim <= 0 || out_stride < dim || staged_stride < dim || pos_lo < 0) return PG_ERR_INVALID;
+  if (n == 0) return PG_OK;
+  if (!staged || !pos || !out) return PG_ERR_INVALID;
   hipStream_t st = as_stream(stream);
-  const int grid = 64;     // a few hundred rows per minibatch: 256 waves take them in one or two rounds
-  if (dim % 4 == 0 && out_stride % 4 == 0 && aligned(staged, 16) && aligned(out, 16))
-    hipLaunchKernelGGL(k_scatter<4>, dim3(grid), dim3(256), 0, st, staged, dup_pos, cap, dup_count_dev, dim, out, out_stride, pos_lo, dup_staged_row);
-  else if (dim % 2 == 0 && out_stride % 2 == 0 && aligned(staged, 8) && aligned(out, 8))
-    hipLaunchKernelGGL(k_scatter<2>, dim3(grid), dim3(256), 0, st, staged, dup_pos, cap, dup_count_dev, dim, out, out_stride, pos_lo, dup_staged_row);
-  else
-    hipLaunchKernelGGL(k_scatter<1>, dim3(grid), dim3(256), 0, st, staged, dup_pos, cap, dup_count_dev, dim, out, out_stride, pos_lo, dup_staged_row);
+  int grid = grid_1d(n, 4, 8192);
+  if (max_blocks > 0 && grid > max_blocks) grid = max_blocks;   // a dup list: a few hundred rows whatever the bound says
+#define PG_SCATTER(V)                                                                                              \
+  hipLaunchKernelGGL(k_scatter<V>, dim3(grid), dim3(256), 0, st, staged, pos, n, n_dev, dim, out, out_stride, pos_lo, \
+                     src_row, staged_stride)
+  if (dim % 4 == 0 && out_stride % 4 == 0 && staged_stride % 4 == 0 && aligned(staged, 16) && aligned(out, 16)) PG_SCATTER(4);
+  else if (dim % 2 == 0 && out_stride % 2 == 0 && staged_stride % 2 == 0 && aligned(staged, 8) && aligned(out, 8)) PG_SCATTER(2);
+  else PG_SCATTER(1);
+#undef PG_SCATTER
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
@@ -576,19 +586,7 @@ int pg_scatter_rows(const float* staged, const int32_t* pos, int64_t n, const in
 
 int pg_scatter_rows_range(const float* staged, const int32_t* pos, int64_t n, const int32_t* n_dev, int32_t dim,
                           float* out, int32_t out_stride, int32_t pos_lo, pg_stream_t stream) {
-  if (n < 0 || dim <= 0 || out_stride < dim || pos_lo < 0) return PG_ERR_INVALID;
-  if (n == 0) return PG_OK;
-  if (!staged || !pos || !out) return PG_ERR_INVALID;
-  hipStream_t st = as_stream(stream);
-  const int grid = grid_1d(n, 4, 8192);
-  if (dim % 4 == 0 && out_stride % 4 == 0 && aligned(staged, 16) && aligned(out, 16))
-    hipLaunchKernelGGL(k_scatter<4>, dim3(grid), dim3(256), 0, st, staged, pos, n, n_dev, dim, out, out_stride, pos_lo, nullptr);
-  else if (dim % 2 == 0 && out_stride % 2 == 0 && aligned(staged, 8) && aligned(out, 8))
-    hipLaunchKernelGGL(k_scatter<2>, dim3(grid), dim3(256), 0, st, staged, pos, n, n_dev, dim, out, out_stride, pos_lo, nullptr);
-  else
-    hipLaunchKernelGGL(k_scatter<1>, dim3(grid), dim3(256), 0, st, staged, pos, n, n_dev, dim, out, out_stride, pos_lo, nullptr);
-  PG_LAUNCH_CHECK();
-  return PG_OK;
+  return pg_scatter_rows_strided(staged, dim, pos, nullptr, n, n_dev, dim, out, out_stride, pos_lo, 0, stream);
 }
 
 int pg_scatter_rows_from_host(const float* table, int64_t table_stride, const int32_t* pos,

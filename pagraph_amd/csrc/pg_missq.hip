@@ -293,6 +293,7 @@ struct pg_missq {
   int device = 0, n_slots = 0, n_fields = 0;
   int64_t max_rows = 0;
   pg_missq_field_t fields[PG_MAX_FIELDS];
+  int32_t sstride[PG_MAX_FIELDS] = {0};   // floats per staged / staging row: wide rows padded to whole 16-byte pieces
   std::vector<pg_missq_slot> slots;
   hipStream_t copy_stream = nullptr;
   uint32_t* timeout_d = nullptr;
@@ -361,7 +362,7 @@ static void hsa_copy_init(pg_missq* q) {
   int fw = 0;
   for (int f = 1; f < q->n_fields; ++f)
     if (q->fields[f].dim > q->fields[fw].dim) fw = f;
-  const size_t bytes = std::min<size_t>((size_t)q->max_rows * q->fields[fw].dim * sizeof(float), (size_t)16 << 20);
+  const size_t bytes = std::min<size_t>((size_t)q->max_rows * q->sstride[fw] * sizeof(float), (size_t)16 << 20);
   const char* force = getenv("PG_MISSQ_ENGINE");
   double best = 0;
   for (int b = 0; b < 16; ++b) {
@@ -464,6 +465,8 @@ static void missq_worker(pg_missq* q) {
         if (!s.out[f] && s.out_stride[f] != -1) continue;   // this launch did not ask for the field
         const pg_missq_field_t& fd = q->fields[f];
         const size_t row_bytes = (size_t)fd.dim * sizeof(float);
+        const size_t srow = (size_t)q->sstride[f];                     // staged row stride (floats)
+        const size_t copy_bytes = (size_t)m * srow * sizeof(float);    // what crosses PCIe (padding included: < 1 %)
         float* stg = s.staging_h[f];
         const int64_t* ids = s.fullid_h;
         const auto ta = now();
@@ -476,7 +479,7 @@ static void missq_worker(pg_missq* q) {
               __builtin_prefetch(nx + 128);
               __builtin_prefetch(nx + 192);
             }
-            copy_row_stream(stg + j * fd.dim, fd.table + ids[j] * fd.table_stride, row_bytes);
+            copy_row_stream(stg + j * srow, fd.table + ids[j] * fd.table_stride, row_bytes);
           }
           __builtin_ia32_sfence();   // the streaming stores must be globally visible before the chunk counts as done
         });
@@ -487,13 +490,13 @@ static void missq_worker(pg_missq* q) {
         if (q->hsa_ok) {
           // straight to the calibrated SDMA engine; the copy stream then waits for the completion signal on the device
           hsa_signal_store_relaxed(s.sig[f], 1);
-          direct = hsa_amd_memory_async_copy_on_engine(s.staged_d[f], q->gpu_agent, stg, q->cpu_agent, (size_t)m * row_bytes,
+          direct = hsa_amd_memory_async_copy_on_engine(s.staged_d[f], q->gpu_agent, stg, q->cpu_agent, copy_bytes,
                                                        0, nullptr, s.sig[f], (hsa_amd_sdma_engine_id_t)q->engine,
                                                        true) == HSA_STATUS_SUCCESS;
           if (direct && s.direct) {
             // staged-only job: the consumer's own wait kernel watches this signal (k_wait_direct)
             if (logc) {
-              s.cp_bytes = (int64_t)m * (int64_t)row_bytes;
+              s.cp_bytes = (int64_t)copy_bytes;
               s.cp_field = f;
             }
           } else if (direct) {
@@ -502,7 +505,7 @@ static void missq_worker(pg_missq* q) {
             hipLaunchKernelGGL(k_wait_hsa_signal, dim3(1), dim3(1), 0, q->copy_stream, val, q->timeout_d, poll_sleeps);
             if (hipGetLastError() != hipSuccess) rc = PG_ERR_HIP;
             if (logc) {
-              s.cp_bytes = (int64_t)m * (int64_t)row_bytes;
+              s.cp_bytes = (int64_t)copy_bytes;
               s.cp_field = f;
             }
           } else {
@@ -512,21 +515,21 @@ static void missq_worker(pg_missq* q) {
         }
         if (!direct) {
           if (logc) (void)hipEventRecord(s.cp0, q->copy_stream);
-          if (hipMemcpyAsync(s.staged_d[f], stg, (size_t)m * row_bytes, hipMemcpyHostToDevice, q->copy_stream) !=
+          if (hipMemcpyAsync(s.staged_d[f], stg, copy_bytes, hipMemcpyHostToDevice, q->copy_stream) !=
               hipSuccess)
             rc = PG_ERR_HIP;
           if (logc) {
             (void)hipEventRecord(s.cp1, q->copy_stream);
-            s.cp_bytes = (int64_t)m * (int64_t)row_bytes;
+            s.cp_bytes = (int64_t)copy_bytes;
             s.cp_field = -1;
           }
         }
         if (rc == PG_OK && s.out[f])
-          rc = pg_scatter_rows_range(s.staged_d[f], s.pos_d, m, nullptr, fd.dim, s.out[f], s.out_stride[f],
-                                     s.pos_lo[f], (pg_stream_t)q->copy_stream);   // storage.py:199-200
+          rc = pg_scatter_rows_strided(s.staged_d[f], (int32_t)srow, s.pos_d, nullptr, m, nullptr, fd.dim, s.out[f],
+                                       s.out_stride[f], s.pos_lo[f], 0, (pg_stream_t)q->copy_stream);   // storage.py:199-200
         if (rc == PG_OK && s.out[f] && s.dedup)    // repeats of a missed id: copied on the device, never over PCIe
-          rc = pg_scatter_rows_dups(s.staged_d[f], s.dup_pos_d, s.dup_src_d, q->max_rows, s.dup_count_d, fd.dim,
-                                    s.out[f], s.out_stride[f], s.pos_lo[f], (pg_stream_t)q->copy_stream);
+          rc = pg_scatter_rows_strided(s.staged_d[f], (int32_t)srow, s.dup_pos_d, s.dup_src_d, q->max_rows, s.dup_count_d,
+                                       fd.dim, s.out[f], s.out_stride[f], s.pos_lo[f], 64, (pg_stream_t)q->copy_stream);
         te += us(tb, now());
       }
     }
@@ -624,7 +627,10 @@ int pg_missq_create(int device, int n_slots, int64_t max_rows, const pg_missq_fi
   pg_missq* q = new (std::nothrow) pg_missq;
   if (!q) return PG_ERR_NOMEM;
   q->device = device; q->n_slots = n_slots; q->n_fields = n_fields; q->max_rows = max_rows;
-  for (int f = 0; f < n_fields; ++f) q->fields[f] = fields[f];
+  for (int f = 0; f < n_fields; ++f) {
+    q->fields[f] = fields[f];
+    q->sstride[f] = fields[f].dim >= 16 ? ((fields[f].dim + 3) & ~3) : fields[f].dim;
+  }
   q->slots.resize(n_slots);
   // The consumer (compute) stream may have a spin-wait kernel parked on it until this stream's k_signal has run. HIP
   // multiplexes streams of ONE priority class onto a few hardware queues, and a kernel behind a spinning kernel in the
@@ -660,7 +666,7 @@ int pg_missq_create(int device, int n_slots, int64_t max_rows, const pg_missq_fi
     ok = ok && (q->wait_value ? hipExtMallocWithFlags((void**)&s.landed_d, 8, hipMallocSignalMemory)
                               : hipMalloc((void**)&s.landed_d, 64)) == hipSuccess;
     for (int f = 0; f < n_fields && ok; ++f) {
-      const size_t bytes = (size_t)max_rows * fields[f].dim * sizeof(float);
+      const size_t bytes = (size_t)max_rows * q->sstride[f] * sizeof(float);
       ok = ok && hipHostMalloc((void**)&s.staging_h[f], bytes, hipHostMallocDefault) == hipSuccess;
       ok = ok && hipMalloc((void**)&s.staged_d[f], bytes) == hipSuccess;
     }
@@ -710,6 +716,12 @@ int pg_missq_submit(pg_missq_t* q, int slot, float* const* out_ptrs, const int32
 int pg_missq_slot_staged(pg_missq_t* q, int slot, int field, float** staged_dev) {
   if (!q || slot < 0 || slot >= q->n_slots || field < 0 || field >= q->n_fields || !staged_dev) return PG_ERR_INVALID;
   *staged_dev = q->slots[slot].staged_d[field];
+  return PG_OK;
+}
+
+int pg_missq_staged_stride(pg_missq_t* q, int field, int32_t* stride_out) {
+  if (!q || field < 0 || field >= q->n_fields || !stride_out) return PG_ERR_INVALID;
+  *stride_out = q->sstride[field];
   return PG_OK;
 }
 

@@ -596,9 +596,10 @@ class GraphCacheServer:
                 want = per_layer[layers.index(l)]
                 v = set(virtual.get(l, ()))
                 # wide rows in whole 16-byte pieces: dim % 4 == 0, or (Reddit's 602) a fused cache row with room for the last
-                # piece and no staged block to read (the queue packs its staging rows at `dim` floats)
-                wide = all(self.dims[n] >= 256 and (self.dims[n] % 4 == 0 or (self.full_cached and n in self.gpu_fix_cache
-                           and self.gpu_fix_cache[n].stride(0) >= ((self.dims[n] + 3) & ~3))) for n in want)
+                # piece (the miss queue pads its staged rows the same way: pg_missq_staged_stride)
+                wide = all(self.dims[n] >= 256 and (self.dims[n] % 4 == 0 or n not in self.gpu_fix_cache
+                           or (self.gpu_fix_cache[n].stride(0) >= ((self.dims[n] + 3) & ~3)
+                               and self.gpu_fix_cache[n].data_ptr() % 16 == 0)) for n in want)
                 if want and want <= v and wide and l == layers[0] + len(vlayers) and (same_everywhere or len(layers) == 1):
                     vlayers.append(l)
                 else:
@@ -626,20 +627,21 @@ class GraphCacheServer:
                     plan.ostr[f] = -1                 # every needed row is read in place: copy to the staged block only
         plan.row_sources = {}
         if vlayers:
-            staged = {}
+            staged, sstride = {}, {}
             if not self.full_cached:
                 self._missq_buffers(slot, plan.rows)  # creates the queue if need be
                 for f, name in enumerate(self.dims):
                     if name in names:
-                        sp_ = L.vp()
+                        sp_, st_ = L.vp(), L.c_i32(0)
                         L.check(self.lib.pg_missq_slot_staged(self._missq, slot, f, ctypes.byref(sp_)), "pg_missq_slot_staged")
-                        staged[name] = sp_.value
+                        L.check(self.lib.pg_missq_staged_stride(self._missq, f, ctypes.byref(st_)), "pg_missq_staged_stride")
+                        staged[name], sstride[name] = sp_.value, int(st_.value)
             for l in vlayers:
                 a, b = offsets[l] - lo, offsets[l + 1] - lo
                 for name in (need[l] if need is not None else names):
                     plan.row_sources[(l, name)] = RowSource(plan.slots[a:b], self.gpu_fix_cache.get(name), staged.get(name, 0),
-                                                            self.dims[name], self.dims[name], keep=(self, plan),
-                                                            prof=self.rows_prof)
+                                                            sstride.get(name, self.dims[name]), self.dims[name],
+                                                            keep=(self, plan), prof=self.rows_prof)
         plan.cache_epoch = self._cache_epoch
         return plan
 

@@ -2016,9 +2016,11 @@ def test_skinny_linear_ragged_K_on_the_mfma_kernel(dev, hiplib, n, K, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ratio", [1.0, 0.3])
 @pytest.mark.parametrize("arch", ["gcn", "sage"])
-def test_reddit_width_runs_on_the_fused_path(dev, hiplib, arch):
-    """feat = 602, whole table cached (BASELINE configs[1]): layer 0 is aggregated straight from the cache
+def test_reddit_width_runs_on_the_fused_path(dev, hiplib, arch, ratio):
+    """feat = 602, whole table cached (BASELINE configs[1]) or 30 % of it (miss rows read in place from the queue's
+    staged block, whose rows are padded to whole 16-byte pieces): layer 0 is aggregated straight from the cache
     (ops.RowSource) with the kernel's own dropout mask; with dropout off the logits and gradients match the
     materialised path (k_gather + k_spmm_fwd + library GEMM) to 1e-4"""
     import torch.nn.functional as Fn
@@ -2034,8 +2036,8 @@ def test_reddit_width_runs_on_the_fused_path(dev, hiplib, arch):
     store = HostFeatureStore({"features": torch.from_numpy(feats), "norm": torch.from_numpy(norm)})
     c = GraphCacheServer(store, V, torch.arange(V), 0, miss_mode="async")
     c.init_field(["features", "norm"])
-    c.auto_cache(g, ["features", "norm"], cache_ratio=1.0)
-    assert c.full_cached
+    c.auto_cache(g, ["features", "norm"], cache_ratio=ratio)
+    assert c.full_cached == (ratio == 1.0)
     torch.manual_seed(3)
     model = (GCNSampling(Fd, 32, C, 1, Fn.relu, 0.0) if arch == "gcn" else GraphSageSampling(Fd, 16, C, 1, Fn.relu, 0.0, 'mean'))
     model = model.to(dev).train()
@@ -2046,6 +2048,7 @@ def test_reddit_width_runs_on_the_fused_path(dev, hiplib, arch):
     for v in (None, virt):
         model.zero_grad(set_to_none=True)
         c.fetch_data(nf, need=need, slot=0, virtual=v)
+        c.wait_misses(0)
         assert isinstance(nf._node_frames[0]["features"], RowSource) == (v is not None)
         y = model(nf)
         y.square().sum().backward()
@@ -2058,8 +2061,10 @@ def test_reddit_width_runs_on_the_fused_path(dev, hiplib, arch):
     # dropout on: the fused path draws the kernel's mask (no nn.Dropout fall-back) and still trains
     model2 = GCNSampling(Fd, 32, C, 1, Fn.relu, 0.5).to(dev).train()
     c.fetch_data(nf, need=need, slot=0, virtual=model2.virtual_inputs(3))
+    c.wait_misses(0)
     y = model2(nf)
     assert torch.isfinite(y).all()
+    c.check_misses()
 
 
 @pytest.mark.gpu
