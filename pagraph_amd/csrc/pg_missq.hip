@@ -524,10 +524,11 @@ static void missq_worker(pg_missq* q) {
             s.cp_field = -1;
           }
         }
-        if (rc == PG_OK && s.out[f])
+        // (a direct job's rows are scattered by its consumer, on the consumer's stream: scatter_on_consumer)
+        if (rc == PG_OK && s.out[f] && !s.direct)
           rc = pg_scatter_rows_strided(s.staged_d[f], (int32_t)srow, s.pos_d, nullptr, m, nullptr, fd.dim, s.out[f],
                                        s.out_stride[f], s.pos_lo[f], 0, (pg_stream_t)q->copy_stream);   // storage.py:199-200
-        if (rc == PG_OK && s.out[f] && s.dedup)    // repeats of a missed id: copied on the device, never over PCIe
+        if (rc == PG_OK && s.out[f] && s.dedup && !s.direct)    // repeats of a missed id: copied on the device, never over PCIe
           rc = pg_scatter_rows_strided(s.staged_d[f], (int32_t)srow, s.dup_pos_d, s.dup_src_d, q->max_rows, s.dup_count_d,
                                        fd.dim, s.out[f], s.out_stride[f], s.pos_lo[f], 64, (pg_stream_t)q->copy_stream);
         te += us(tb, now());
@@ -613,6 +614,21 @@ static void missq_free(pg_missq* q) {
   if (q->copy_stream) (void)hipStreamDestroy(q->copy_stream);
   delete q->pool;
   delete q;
+}
+
+// the scatter of a direct job's miss rows (and of the repeats of its index dedup), enqueued by the consumer on ITS
+// stream behind the wait for the copy (storage.py:199-200): the row count is read from the device (count_d)
+static int scatter_on_consumer(pg_missq* q, pg_missq_slot& s, pg_stream_t stream) {
+  for (int f = 0; f < q->n_fields; ++f) {
+    if (!s.out[f]) continue;
+    int rc = pg_scatter_rows_strided(s.staged_d[f], q->sstride[f], s.pos_d, nullptr, q->max_rows, s.count_d, q->fields[f].dim,
+                                     s.out[f], s.out_stride[f], s.pos_lo[f], 0, stream);
+    if (rc == PG_OK && s.dedup)
+      rc = pg_scatter_rows_strided(s.staged_d[f], q->sstride[f], s.dup_pos_d, s.dup_src_d, q->max_rows, s.dup_count_d,
+                                   q->fields[f].dim, s.out[f], s.out_stride[f], s.pos_lo[f], 64, stream);
+    if (rc != PG_OK) return rc;
+  }
+  return PG_OK;
 }
 
 extern "C" {
@@ -762,14 +778,22 @@ int pg_missq_submit_dedup(pg_missq_t* q, int slot, float* const* out_ptrs, const
     s.dedup = slots_dev != nullptr;
     // every wanted field is read in place from the staged block and the copies go straight to an SDMA engine:
     // the job never touches the copy stream (see k_wait_direct)
-    static const bool no_direct = getenv("PG_MISSQ_NO_DIRECT") != nullptr;
+    static const bool no_direct = getenv("PG_MISSQ_NO_DIRECT") != nullptr && atoi(getenv("PG_MISSQ_NO_DIRECT")) != 2;
     bool any = false, all_staged = true;
     for (int f = 0; f < q->n_fields; ++f) {
       if (!s.out[f] && s.out_stride[f] != -1) continue;
       any = true;
       if (s.out[f]) all_staged = false;
     }
-    s.direct = any && all_staged && q->hsa_ok && !no_direct && !q->wait_value;
+    // ... and a job WITH rows to scatter (GraphSAGE's layers 1-2, --fetch-all) stays off the copy stream as well: its
+    // consumer scatters them on its own stream right after its wait (scatter_on_consumer). The wait-for-SDMA kernel
+    // such a job used to park on the copy stream for the length of the copy (0.34 ms for 19 MB) held back whatever
+    // shared its hardware queue — with the load stream's k_publish behind it, gather(k+1) could not overlap copy(k):
+    // the all-layer leg read 0.52-0.58 instead of 0.36-0.38 ms/step whenever the runtime's queue assignment fell
+    // that way. PG_MISSQ_NO_DIRECT=1: everything through the copy stream; =2: only staged-only jobs are direct.
+    static const int no_direct_mode = getenv("PG_MISSQ_NO_DIRECT") ? atoi(getenv("PG_MISSQ_NO_DIRECT")) : 0;
+    const bool whole_list = q->cpu_share.load(std::memory_order_relaxed) == 256;   // the device count is the worker's count
+    s.direct = any && (all_staged || (no_direct_mode != 2 && whole_list)) && q->hsa_ok && !no_direct && !q->wait_value;
   }
   if (slots_dev)
     hipLaunchKernelGGL(k_publish_dedup, dim3(1), dim3(256), 0, as_stream(stream), s.count_d, s.count_h, s.flag_h, seq,
@@ -801,7 +825,7 @@ int pg_missq_wait(pg_missq_t* q, int slot, pg_stream_t stream, int32_t* miss_cou
       if (s.sig[f].handle &&
           hsa_signal_wait_scacquire(s.sig[f], HSA_SIGNAL_CONDITION_LT, 1, 3000000000ull, HSA_WAIT_STATE_ACTIVE) > 0)
         return PG_ERR_HIP;
-    return PG_OK;
+    return scatter_on_consumer(q, s, stream);
   }
   PG_HIP(hipStreamWaitEvent(as_stream(stream), s.filled, 0));
   return PG_OK;
@@ -841,12 +865,13 @@ int pg_missq_wait_device(pg_missq_t* q, int slot, pg_stream_t stream) {
         sg.v[f] = &reinterpret_cast<amd_signal_t*>(s.sig[f].handle)->value;
         if (enqueued && hsa_signal_load_scacquire(s.sig[f]) > 0) pending = true;
       }
-    if (!pending) return PG_OK;        // issued and already landed: nothing to wait for
-    static const int poll_sleeps = getenv("PG_MISSQ_POLL_SLEEPS") ? atoi(getenv("PG_MISSQ_POLL_SLEEPS")) : 3;
-    hipLaunchKernelGGL(k_wait_direct, dim3(1), dim3(1), 0, as_stream(stream), s.issued_h, seq, sg, q->timeout_d,
-                       poll_sleeps);
-    PG_LAUNCH_CHECK();
-    return PG_OK;
+    if (pending) {                     // (issued and already landed: nothing to wait for)
+      static const int poll_sleeps = getenv("PG_MISSQ_POLL_SLEEPS") ? atoi(getenv("PG_MISSQ_POLL_SLEEPS")) : 3;
+      hipLaunchKernelGGL(k_wait_direct, dim3(1), dim3(1), 0, as_stream(stream), s.issued_h, seq, sg, q->timeout_d,
+                         poll_sleeps);
+      PG_LAUNCH_CHECK();
+    }
+    return scatter_on_consumer(q, s, stream);
   }
   if (enqueued) {
     // the usual case with two batches of look-ahead: an ordinary event dependency, no kernel parked on the
