@@ -18,6 +18,7 @@
 //   consumer         : pg_missq_wait(slot, stream) makes the compute stream wait on that event.
 // The trainer thread never blocks on the GPU; it blocks in pg_missq_wait only if the worker has not
 // yet *enqueued* the copy of a batch that was submitted a whole step earlier.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -469,15 +470,17 @@ static void missq_worker(pg_missq* q) {
         const size_t copy_bytes = (size_t)m * srow * sizeof(float);    // what crosses PCIe (padding included: < 1 %)
         float* stg = s.staging_h[f];
         const int64_t* ids = s.fullid_h;
+        // PG_MISSQ_PREFETCH=<rows ahead>,<bytes of that row>: default 2 rows ahead, 256 bytes
+        static const int pf_dist = getenv("PG_MISSQ_PREFETCH") ? std::max(1, atoi(getenv("PG_MISSQ_PREFETCH"))) : 2;
+        static const size_t pf_cfg = (getenv("PG_MISSQ_PREFETCH") && strchr(getenv("PG_MISSQ_PREFETCH"), ','))
+                                         ? (size_t)atol(strchr(getenv("PG_MISSQ_PREFETCH"), ',') + 1) : 256;
+        const size_t pf_bytes = std::min(pf_cfg, row_bytes);
         const auto ta = now();
         q->pool->parallel_for(m, [&](int64_t lo, int64_t hi) {   // storage.py:128 table[nids]
           for (int64_t j = lo; j < hi; ++j) {
-            if (j + 2 < hi) {   // rows are random DRAM pages: start the one after next while this one streams
-              const char* nx = reinterpret_cast<const char*>(fd.table + ids[j + 2] * fd.table_stride);
-              __builtin_prefetch(nx);
-              __builtin_prefetch(nx + 64);
-              __builtin_prefetch(nx + 128);
-              __builtin_prefetch(nx + 192);
+            if (j + pf_dist < hi) {   // rows are random DRAM pages: start a later one while this one streams
+              const char* nx = reinterpret_cast<const char*>(fd.table + ids[j + pf_dist] * fd.table_stride);
+              for (size_t b = 0; b < pf_bytes; b += 64) __builtin_prefetch(nx + b, 0, 0);
             }
             copy_row_stream(stg + j * srow, fd.table + ids[j] * fd.table_stride, row_bytes);
           }

@@ -1,6 +1,5 @@
 #!/bin/bash
-O=gpurun_out/sw; mkdir -p $O
-T=tests/test_gpu_parity.py
-for i in 1 2; do timeout 600 python -m pytest $T -x -q -k test_bench_short_window > $O/alone$i.log 2>&1; tail -1 $O/alone$i.log; done
-timeout 1500 python -m pytest tests -m gpu -x -q > $O/suite_new.log 2>&1; tail -2 $O/suite_new.log; grep -n "AssertionError" $O/suite_new.log | head -3
-PG_MISSQ_NO_DIRECT=2 timeout 1500 python -m pytest tests -m gpu -x -q > $O/suite_old_scatter.log 2>&1; tail -2 $O/suite_old_scatter.log; grep -n "AssertionError" $O/suite_old_scatter.log | head -3
+pick='import json,sys,statistics as st; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); w=d["ms_per_step_windows"]; q=d["miss_queue"]; print(round(st.median(w),4), "gather us", round(q["us_cpu_gather"]))'
+B="python bench.py --steps 600 --warmup 20 --skip-cpu-baseline --skip-microbench --skip-opt-hit --skip-reference-equivalent"
+for rep in 1 2; do for cfg in "2,256" "2,2400" "3,2400" "4,2400" "1,2400" "2,1024" "4,512"; do echo -n "gcn prefetch $cfg: "; PG_MISSQ_PREFETCH=$cfg timeout 300 $B 2>/dev/null | python -c "$pick"; done; done
+for cfg in "2,256" "2,2400" "4,2400"; do echo -n "graphsage prefetch $cfg: "; PG_MISSQ_PREFETCH=$cfg timeout 300 $B --model graphsage 2>/dev/null | python -c "$pick"; done
