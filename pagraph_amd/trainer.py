@@ -163,6 +163,11 @@ class GraphedTrainer:
     and optimizer state are shared by the graphs; the optimizer must be capture-safe
     (torch.optim.Adam(..., capturable=True)).
 
+    The model must not have a LIVE autograd graph from another stream when the first step is captured (e.g. the result
+    of an eager `model(nf)` on the default stream that was never back-propagated nor dropped): autograd binds a
+    parameter's gradient accumulator to the stream of the graph that created it, and the capture then tries to record a
+    wait on that foreign stream — the runtime dies in capture_end. Evaluate under torch.no_grad() or drop the result.
+
     Multi-GPU (world_size > 1, no DDP wrapper): every parameter's .grad is a view of ONE flat
     buffer.  Graph A (per slot) = zero the flat buffer, forward, loss / world, backward (autograd
     accumulates straight into the views); then ONE eager all-reduce (RCCL) of the flat buffer —

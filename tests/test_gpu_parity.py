@@ -2135,3 +2135,82 @@ def test_graphsage_deferred_partial_sums_two_uses_bit_identical(dev, hiplib):
     assert reg.add(w, pt, 2, 4, 0) and not reg.add(w, pt, 2, 4, 0) and not reg.conflict
     reg.add(w, pt, 2, 4, 0)
     assert reg.conflict
+
+
+# ---- config 2 at full size: Reddit-shaped graph (V = 232 965, 114.6 M CSC entries), feat 602, 41 classes, full cache --
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_config2_full_size_reddit_shape(dev, hiplib, oracle):
+    """BASELINE.json configs[1] at its real size (the reference's Reddit: 232 965 vertices, mean degree 492, feat 602, 41
+    classes; synthetic RMAT edges and random features of that shape, whole table resident in HBM): the sampler's node
+    ids / blocks bit-exact against the C oracle, fetch_data (dense and with layer 0 left in the cache) equal to the
+    table bit for bit with a 100 % hit rate, GCNSampling's logits on the fused path within 1e-4 of the oracle's
+    restatement of the reference model, and a few replayed training steps that reduce the loss."""
+    import torch.nn.functional as Fn
+    from pagraph_amd.data import synthetic as syn
+    from pagraph_amd.model import GCNSampling
+    from pagraph_amd.ops import RowSource
+    from pagraph_amd.optim import Adam
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    from pagraph_amd.trainer import GraphedTrainer, cycle_batches
+    V, E, Fd, C, B, k, hops = 232_965, 57_300_000, 602, 41, 6000, 2, 2
+    indptr, indices = syn.rmat_graph(V, E, device=dev)
+    assert int(indptr[-1]) == indices.numel() and indices.numel() > 100_000_000
+    g = DeviceGraph.from_csc(indptr, indices, V)
+    train_mask, _, _ = syn.split_dataset(V)
+    train = torch.nonzero(train_mask).squeeze(1)
+    table = torch.empty((V, Fd), dtype=torch.float32, pin_memory=True)
+    syn.fill_random_features(table, device=dev)
+    labels = syn.random_labels(V, C).to(dev)
+    cacher = GraphCacheServer(HostFeatureStore({"features": table}, pin=False, device_visible={"features": True}), V,
+                              torch.arange(V), 0, miss_mode="async")
+    cacher.init_field(["features"])
+    cacher.log = True
+    cacher.auto_cache(g, ["features"], cache_ratio=1.0)
+    assert cacher.full_cached and cacher.cached_num == V
+    sampler = NeighborSampler(g, B, k, neighbor_type='in', shuffle=True, num_hops=hops, seed_nodes=train, seed=0)
+    seeds_h = sampler.seeds.cpu().numpy()
+    indptr_h, indices_h = g.indptr.cpu().numpy(), g.indices.cpu().numpy()
+    torch.manual_seed(2)
+    model = GCNSampling(Fd, 32, C, 1, Fn.relu, 0.0).to(dev).train()
+    need, virt = model.required_inputs(hops + 1), model.virtual_inputs(hops + 1)
+    state = {n_: p.detach().cpu().numpy() for n_, p in model.named_parameters()}
+    it = iter(sampler)
+    for b in range(2):
+        nf = next(it)
+        nm = nf._node_mapping.tousertensor()
+        o = nf._layer_offsets
+        ref = oracle.sample_nodeflow(indptr_h, indices_h, seeds_h[b * B:(b + 1) * B], k, hops, 0, 0, b)
+        assert np.array_equal(nm.cpu().numpy(), ref["node_mapping"]) and list(o) == list(ref["layer_offsets"][:hops + 2])
+        for blk in range(hops):
+            assert np.array_equal(nf.blk_indptr[blk].cpu().numpy(), ref["blocks"][blk][0])
+            assert np.array_equal(nf.blk_src[blk].cpu().numpy(), ref["blocks"][blk][1])
+        # every layer, dense: the reference's fetch_data
+        cacher.fetch_data(nf)
+        torch.cuda.synchronize()
+        ids_h = nm.cpu()
+        for l in range(hops + 1):
+            assert torch.equal(nf._node_frames[l]["features"].cpu(), table[ids_h[o[l]:o[l + 1]]])
+        assert cacher.get_miss_rate() == 0.0
+        # what the model reads, layer 0 left in the cache; logits vs the oracle's model
+        cacher.fetch_data(nf, need=need, slot=0, virtual=virt)
+        assert isinstance(nf._node_frames[0]["features"], RowSource)
+        with torch.no_grad():        # (a live autograd graph made on the default stream would tie the parameters' gradient
+            y = model(nf)            #  accumulators to that stream: GraphedTrainer captures on its own — see its docstring)
+        torch.cuda.synchronize()
+        frames = [{"features": table[ids_h[o[0]:o[1]]].numpy()}] + [{} for _ in range(hops)]
+        want, _ = oracle.gcn_model_forward(ref["blocks"][:hops], [o[l + 1] - o[l] for l in range(hops + 1)], frames, state, 1)
+        assert float(np.abs(y.detach().cpu().numpy() - want).max()) < TOL * max(1.0, float(np.abs(want).max()))
+    # the replayed training step at this shape
+    smp = NeighborSampler(g, B, k, neighbor_type='in', shuffle=True, num_hops=hops, seed_nodes=train, seed=1, static=True,
+                          defer_transpose=True)
+    tr = GraphedTrainer(model, torch.nn.CrossEntropyLoss(), Adam(model.parameters(), lr=3e-2), cacher, smp, labels, dev,
+                        need=need, keep_losses=True)
+    out = []
+    tr.on_step = lambda step, loss: out.append(loss)
+    tr.run_steps(cycle_batches(smp, 40), 24)
+    tr.synchronize(); torch.cuda.synchronize()
+    ls = torch.stack([l.detach().float().cpu() for l in out])
+    assert torch.isfinite(ls).all() and float(ls[-4:].mean()) < float(ls[:4].mean())
+    assert all(s_.plan.virtual for s_ in tr.slots.values())          # feat 602 ran on the fused path
