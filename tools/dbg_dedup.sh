@@ -1,5 +1,7 @@
 #!/bin/bash
-pick='import json,sys,statistics as st; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); w=d["ms_per_step_windows"]; q=d["miss_queue"]; print(round(st.median(w),4), "gather us", round(q["us_cpu_gather"]))'
-B="python bench.py --steps 600 --warmup 20 --skip-cpu-baseline --skip-microbench --skip-opt-hit --skip-reference-equivalent"
-for rep in 1 2; do for cfg in "2,256" "2,2400" "3,2400" "4,2400" "1,2400" "2,1024" "4,512"; do echo -n "gcn prefetch $cfg: "; PG_MISSQ_PREFETCH=$cfg timeout 300 $B 2>/dev/null | python -c "$pick"; done; done
-for cfg in "2,256" "2,2400" "4,2400"; do echo -n "graphsage prefetch $cfg: "; PG_MISSQ_PREFETCH=$cfg timeout 300 $B --model graphsage 2>/dev/null | python -c "$pick"; done
+O=gpurun_out/fallbacks; mkdir -p $O
+K="fetch or dedup or trainer or virtual or hardware_queue or reddit_width or config3"
+PG_MISSQ_HSA_COPY=0 timeout 1200 python -m pytest tests/test_gpu_parity.py -x -q -k "$K" > $O/nohsa.log 2>&1; echo "PG_MISSQ_HSA_COPY=0: $(tail -1 $O/nohsa.log)"
+PG_MISSQ_NO_DIRECT=1 timeout 1200 python -m pytest tests/test_gpu_parity.py -x -q -k "$K" > $O/nodirect.log 2>&1; echo "PG_MISSQ_NO_DIRECT=1: $(tail -1 $O/nodirect.log)"
+PG_MISSQ_HOST_WAIT=1 timeout 1200 python -m pytest tests/test_gpu_parity.py -x -q -k "$K" > $O/hostwait.log 2>&1; echo "PG_MISSQ_HOST_WAIT=1: $(tail -1 $O/hostwait.log)"
+PG_DEDUP_MISSES=0 timeout 1200 python -m pytest tests/test_gpu_parity.py -x -q -k "fetch or trainer or virtual" > $O/nodedup.log 2>&1; echo "PG_DEDUP_MISSES=0: $(tail -1 $O/nodedup.log)"
