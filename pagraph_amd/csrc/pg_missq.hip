@@ -129,8 +129,10 @@ __global__ void k_wait_direct(const uint32_t* issued, uint32_t seq, const Direct
                               int poll_sleeps) {
   const unsigned long long t0 = wall_clock64();   // 100 MHz
   bool ok = true;
+  // (both words live in host memory: every poll is a PCIe read, and a kernel with PCIe reads in flight makes the kernel
+  // boundaries of the other streams slower — poll sparsely; the copy that follows the issue takes >= 100 us anyway)
   while ((int32_t)(__hip_atomic_load(issued, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
-    __builtin_amdgcn_s_sleep(127);
+    for (int i = 0; i < poll_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
     if (wall_clock64() - t0 > 300000000ull) { ok = false; break; }
   }
 #pragma unroll
