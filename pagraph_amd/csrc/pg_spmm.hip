@@ -136,6 +136,25 @@ __device__ __forceinline__ float4 drop_apply(float4 x, const uint32_t (&o)[4], i
   return x;
 }
 
+// drop_apply in two steps: the 8 keep-bits of a draw (bit i: column i of the first piece, bit 4 + i: of the second) ...
+__device__ __forceinline__ uint32_t keep_bits(const uint32_t (&o)[4], uint32_t thr) {
+  uint32_t k = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    k |= ((o[i] & 0xffffu) >= thr ? 1u : 0u) << (2 * i);
+    k |= ((o[i] >> 16) >= thr ? 1u : 0u) << (2 * i + 1);
+  }
+  return k;
+}
+// ... and their application: the same products and zeros as drop_apply(x, o, half, thr, scale) with bits >> 4 * half
+__device__ __forceinline__ float4 keep_apply(float4 x, uint32_t bits, float scale) {
+  x.x = (bits & 1u) ? x.x * scale : 0.f;
+  x.y = (bits & 2u) ? x.y * scale : 0.f;
+  x.z = (bits & 4u) ? x.z * scale : 0.f;
+  x.w = (bits & 8u) ? x.w * scale : 0.f;
+  return x;
+}
+
 __global__ __launch_bounds__(256) void k_spmm_fwd_drop(const int32_t* __restrict__ indptr,
                                                        const int32_t* __restrict__ src,
                                                        const float* __restrict__ h, int32_t h_stride, int64_t n_dst,
@@ -303,6 +322,133 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict
           if (reduce == PG_REDUCE_MEAN && end > beg) S::div(acc[m], dg);
           orow[c] = acc[m];
         }
+      }
+    }
+  }
+  if (pslot && blockIdx.x + 256 >= gridDim.x) {   // the tail of the grid: kernel end = the latest of these
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(pslot + 1, wall_clock64());
+  }
+}
+
+// k_spmm_fwd_rows_w<DROP, TAIL, M>: the same arithmetic (edge order, dropout counters: bit-identical) for rows of at
+// most 64 * M pieces, laid out for the CU instead of for generality:
+//  * the destination is wave-uniform (readfirstlane), so indptr[v], the loop bounds, every source row's slot / position
+//    (readlane of the lane that looked them up) and hence the row's base address live in SGPRs: row loads are
+//    `global_load_dwordx4 v, v_lane_offset, s[base]` with the piece offset as an immediate, and "is this row a hit, a
+//    staged miss, padding" is a scalar branch;
+//  * two source rows (the sampler's fan-out) x M pieces in flight per wave and M accumulators — no dead register slots
+//    for pieces the row does not have — which is what lets 8 waves share a SIMD (the generic kernel: 126 VGPRs, 4 waves);
+//  * a row's Philox draws are issued between the loads and their first use.
+constexpr int kRowsPair = 2;
+
+template <bool DROP, bool TAIL, int M>
+__global__ __launch_bounds__(256) void k_spmm_fwd_rows_w(const int32_t* __restrict__ indptr,
+                                                         const int32_t* __restrict__ src,
+                                                         const int32_t* __restrict__ slots,
+                                                         const int32_t* __restrict__ edge_slots,
+                                                         const float* __restrict__ cache, int32_t cache_stride,
+                                                         const float* __restrict__ staged, int32_t staged_stride,
+                                                         int64_t n_dst, int32_t dim, int reduce,
+                                                         float* __restrict__ out, int32_t out_stride, DropArgs d,
+                                                         unsigned long long* __restrict__ prof, int prof_ring) {
+  using S = SV<4>;
+  const uint32_t step = d.step ? (uint32_t)*d.step : 0u;
+  unsigned long long* pslot = prof ? prof + 3 * (size_t)(step % (uint32_t)prof_ring) : nullptr;
+  if (pslot && blockIdx.x == 0 && threadIdx.x == 0) {
+    pslot[0] = wall_clock64();
+    pslot[2] = (unsigned long long)indptr[n_dst];   // edges of this launch
+  }
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t v = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+  if (v < n_dst) {
+    const int pieces = (dim + 3) / 4;
+    const int tail = dim & 3;                        // valid columns of the last piece (TAIL only)
+    const int32_t beg = indptr[v], end = indptr[v + 1];
+    float4 acc[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) acc[m] = S::zero();
+    for (int32_t eb = beg; eb < end; eb += kWave) {
+      const int ne = end - eb < kWave ? end - eb : kWave;
+      int32_t my_p = 0, my_s = -2;
+      if (lane < ne) {
+        my_p = src[eb + lane];
+        my_s = edge_slots ? edge_slots[eb + lane] : slots[my_p];
+      }
+      for (int e0 = 0; e0 < ne; e0 += kRowsPair) {
+        float4 x[kRowsPair][M];
+        int32_t srp[kRowsPair], sl[kRowsPair];
+        bool ok[kRowsPair];
+        // all of the pair's lane reads first: they wait for the index loads, and must not wait for a row load
+#pragma unroll
+        for (int j = 0; j < kRowsPair; ++j) {
+          const int e = e0 + j < ne ? e0 + j : ne - 1;
+          sl[j] = __builtin_amdgcn_readlane(my_s, e);
+          srp[j] = __builtin_amdgcn_readlane(my_p, e);
+          ok[j] = e0 + j < ne && sl[j] != -1 && sl[j] != -2;   // padding / an unresolved miss contributes nothing
+        }
+#pragma unroll
+        for (int j = 0; j < kRowsPair; ++j) {
+          if (ok[j]) {
+            const float4* hrow = sl[j] >= 0
+                                     ? reinterpret_cast<const float4*>(cache + (int64_t)sl[j] * cache_stride)
+                                     : reinterpret_cast<const float4*>(staged + (int64_t)(-sl[j] - 3) * staged_stride);
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+              const int c = m * kWave + lane;
+              if (m < M - 1 || c < pieces) x[j][m] = hrow[c];   // the launcher picks M = ceil(pieces / 64)
+            }
+          }
+        }
+        asm volatile("" ::: "memory");   // the row loads are issued HERE, not sunk to their use behind the draws
+        // every draw of both rows happens between the loads' issue and their first use; what is kept of a draw is its
+        // 8 keep-bits (two pieces x 4 columns): pieces lane + 64 mm and lane + 64 (mm + 1) share one draw (its two
+        // halves), q = (c >> 7) << 6 | (c & 63) — the counters of pg_spmm_fwd_drop
+        uint32_t keep[kRowsPair][(M + 1) / 2];
+        if constexpr (DROP) {
+#pragma unroll
+          for (int j = 0; j < kRowsPair; ++j) {
+#pragma unroll
+            for (int mm = 0; mm < M; mm += 2) {
+              keep[j][mm >> 1] = 0;
+              if (ok[j] && mm * kWave < pieces) {
+                uint32_t o[4];
+                Philox::gen((uint32_t)srp[j], (uint32_t)((mm >> 1) * kWave + lane), d.tag, step, d.k0, d.k1, o);
+                keep[j][mm >> 1] = keep_bits(o, d.thr);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < kRowsPair; ++j) {
+          if (!ok[j]) continue;
+#pragma unroll
+          for (int m = 0; m < M; ++m) {
+            const int c = m * kWave + lane;
+            if (m < M - 1 || c < pieces) {
+              float4 xv = x[j][m];
+              if constexpr (DROP) xv = keep_apply(xv, keep[j][m >> 1] >> (4 * (m & 1)), d.scale);
+              if constexpr (TAIL) {
+                if (c == pieces - 1) {
+                  if (tail < 2) xv.y = 0.f;
+                  if (tail < 3) xv.z = 0.f;
+                  xv.w = 0.f;
+                }
+              }
+              S::add(acc[m], xv);
+            }
+          }
+        }
+      }
+    }
+    const float dg = (float)(end - beg);
+    float4* orow = reinterpret_cast<float4*>(out + v * out_stride);
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int c = m * kWave + lane;
+      if (c < pieces) {
+        if (reduce == PG_REDUCE_MEAN && end > beg) S::div(acc[m], dg);
+        orow[c] = acc[m];
       }
     }
   }
@@ -673,13 +819,28 @@ int pg_spmm_fwd_rows(const int32_t* indptr, const int32_t* src, const pg_row_sou
   hipLaunchKernelGGL((k_spmm_fwd_rows<DROP, TAIL>), dim3(grid), dim3(256), 0, as_stream(stream), indptr, src, rows->slots, \
                      rows->edge_slots, rows->cache, rows->cache_stride, rows->staged, rows->staged_stride, n_dst, dim,     \
                      reduce, out, out_stride, d, pr, (int)prof_ring)
+#define PG_FWD_ROWS_W(DROP, TAIL, M)                                                                                    \
+  hipLaunchKernelGGL((k_spmm_fwd_rows_w<DROP, TAIL, M>), dim3(grid), dim3(256), 0, as_stream(stream), indptr, src,      \
+                     rows->slots, rows->edge_slots, rows->cache, rows->cache_stride, rows->staged, rows->staged_stride, \
+                     n_dst, dim, reduce, out, out_stride, d, pr, (int)prof_ring)
+#define PG_FWD_ROWS_ANY(DROP, TAIL)                                   \
+  do {                                                                \
+    if (generic || dim4 > 1024) PG_FWD_ROWS(DROP, TAIL);              \
+    else if (dim4 <= 512) PG_FWD_ROWS_W(DROP, TAIL, 2);               \
+    else if (dim4 <= 768) PG_FWD_ROWS_W(DROP, TAIL, 3);               \
+    else PG_FWD_ROWS_W(DROP, TAIL, 4);                                \
+  } while (0)
+  // rows of up to 1024 floats take the wave-uniform kernel (PG_FWD_ROWS_GENERIC=1: the generic one, for A/B runs)
+  static const bool generic = getenv("PG_FWD_ROWS_GENERIC") != nullptr;
   if (dim % 4 == 0) {
-    if (has_drop) PG_FWD_ROWS(true, false);
-    else PG_FWD_ROWS(false, false);
+    if (has_drop) PG_FWD_ROWS_ANY(true, false);
+    else PG_FWD_ROWS_ANY(false, false);
   } else {
-    if (has_drop) PG_FWD_ROWS(true, true);
-    else PG_FWD_ROWS(false, true);
+    if (has_drop) PG_FWD_ROWS_ANY(true, true);
+    else PG_FWD_ROWS_ANY(false, true);
   }
+#undef PG_FWD_ROWS_ANY
+#undef PG_FWD_ROWS_W
 #undef PG_FWD_ROWS
   PG_LAUNCH_CHECK();
   return PG_OK;

@@ -23,18 +23,22 @@ L.check(lib.pg_compose_edge_slots(L.ptr(src), src.numel(), L.ptr(slots), n_src, 
 out = torch.empty((cap_dst, F), device=dev)
 step = torch.tensor([5], dtype=torch.int64, device=dev)
 drop = L.PgDropout(13107, 1, 1234, L.ptr(step))
-def run(use_es, reps=200):
+def run(use_es, reps=200, with_drop=True):
+    dp = ctypes.byref(drop) if with_drop else None
     rs = L.PgRowSource(slots.data_ptr(), cache.data_ptr(), staged.data_ptr(), 608, F, es.data_ptr() if use_es else 0)
     for _ in range(10):
-        L.check(lib.pg_spmm_fwd_rows(L.ptr(indptr), L.ptr(src), ctypes.byref(rs), cap_dst, F, 0, L.ptr(out), F, ctypes.byref(drop), None, 0, sp))
+        L.check(lib.pg_spmm_fwd_rows(L.ptr(indptr), L.ptr(src), ctypes.byref(rs), cap_dst, F, 0, L.ptr(out), F, dp, None, 0, sp))
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        L.check(lib.pg_spmm_fwd_rows(L.ptr(indptr), L.ptr(src), ctypes.byref(rs), cap_dst, F, 0, L.ptr(out), F, ctypes.byref(drop), None, 0, sp))
+        L.check(lib.pg_spmm_fwd_rows(L.ptr(indptr), L.ptr(src), ctypes.byref(rs), cap_dst, F, 0, L.ptr(out), F, dp, None, 0, sp))
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 nbytes = 2 * n_dst * (4 * F + 8) + n_dst * (4 * F + 4)
+print("kernel:", "generic (PG_FWD_ROWS_GENERIC)" if os.environ.get("PG_FWD_ROWS_GENERIC") else "wave-uniform")
+us = run(False, with_drop=False)
+print(f"pg_spmm_fwd_rows NO dropout cap_dst={cap_dst}: {us:.1f} us back-to-back  -> {nbytes / us / 1e3:.0f} GB/s ({nbytes / us / 1e3 / 8000:.2f} of peak)")
 for use_es in (False, True):
     us = run(use_es)
     print(f"pg_spmm_fwd_rows edge_slots={use_es} cap_dst={cap_dst}: {us:.1f} us back-to-back  -> {nbytes / us / 1e3:.0f} GB/s ({nbytes / us / 1e3 / 8000:.2f} of peak)")
