@@ -23,7 +23,7 @@ for k, v in table.items():
           f"{v['avg_ns_under_pmc']/1e3:8.1f} us")
 for k, v in table.items():
     if "k_spmm_fwd_rows" in k:
-        rec = {"kernel": "pg::k_spmm_fwd_rows<true> in-loop (eager loop, layer 0 aggregated straight from the cache + staged miss rows)",
+        rec = {"kernel": k.split("(")[0] + " in-loop (eager loop, layer 0 aggregated straight from the cache + staged miss rows)",
                "launches": v["launches"], "fetch_bytes_corrected_per_launch": v["fetch_bytes_corrected_per_launch"],
                "write_bytes_per_launch": v["write_bytes_per_launch"], "hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
                "avg_ns_under_pmc": v["avg_ns_under_pmc"],

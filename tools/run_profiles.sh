@@ -38,6 +38,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python tools/pmc_summarize.py /tmp/pmc_FETCH_SIZE/p_counter_collection.csv /tmp/pmc_WRITE_SIZE/p_counter_collection.csv \
        "$OUT/pmc_bench_per_kernel_raw.json" > "$OUT/pmc_bench_per_kernel.txt"
+python tools/pmc_aggregate.py "$OUT/pmc_bench_per_kernel_raw.json" "$OUT" >> "$OUT/pmc_bench_per_kernel.txt"   # + pmc_spmm_fwd_rows_inloop.json
 # the gather micro-benchmark at 1 M rows with a calibration copy (pmc_gather_1M.md of r01)
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcg_$c -o p -- \
