@@ -29,6 +29,7 @@
 
 #include <cstring>
 
+#include <rocprim/block/block_radix_sort.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "pg_common.h"
@@ -383,6 +384,93 @@ __global__ __launch_bounds__(256) void k_t_heavy(const int32_t* __restrict__ tpt
   }
 }
 
+// The same transpose in ONE workgroup, for blocks of at most 1024 * ITEMS edges and source rows (the 12 000-edge seeds'
+// block of the benchmark's step): no global atomics (the hub's counter was one contended address), no multi-pass device sort
+// (seven small launches running beside the compute stream's HBM-bound kernel), one CU. Edges are packed
+// (source << val_bits | destination) in edge = destination order and sorted STABLY on the source bits only (LSD block radix
+// sort, 4 bits per pass) — every source's destinations stay ascending, exactly the device sort's result. tptr comes from the
+// run starts: rs[s] = first sorted position of source s (or nnz), then tptr[s] = min over s' >= s of rs[s'] (suffix-min scan).
+template <int ITEMS>
+__global__ __launch_bounds__(1024) void k_t_block(const int32_t* __restrict__ indptr, const int32_t* __restrict__ src,
+                                                  const int32_t* __restrict__ n_dst_dev,
+                                                  const int32_t* __restrict__ nnz_dev, int32_t cap_edges,
+                                                  int32_t cap_rows, int val_bits, int key_bits,
+                                                  uint32_t* __restrict__ stage, int32_t* __restrict__ tptr,
+                                                  int32_t* __restrict__ tdst, int32_t* __restrict__ heavy,
+                                                  int32_t heavy_cap) {
+  using Sort = rocprim::block_radix_sort<uint32_t, 1024, ITEMS>;
+  constexpr int kN = 1024 * ITEMS;
+  __shared__ union {
+    typename Sort::storage_type sort;
+    int32_t rs[kN + 1];
+  } lds;
+  __shared__ uint32_t edge_key[1024];
+  __shared__ int32_t wave_min[16];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
+  const int n = *n_dst_dev, nnz = *nnz_dev;
+  if (tid == 0 && heavy) heavy[0] = 0;
+  for (int v = tid; v < n; v += 1024)
+    for (int e = indptr[v]; e < indptr[v + 1]; ++e) stage[e] = ((uint32_t)src[e] << val_bits) | (uint32_t)v;
+  __syncthreads();
+  uint32_t k[ITEMS];
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    const int i = tid * ITEMS + j;
+    k[j] = i < nnz ? stage[i] : 0xFFFFFFFFu;      // padding sorts behind every source
+  }
+  Sort().sort(k, lds.sort, (unsigned)val_bits, (unsigned)(val_bits + key_bits));
+  __syncthreads();                                // lds.sort is dead from here on: rs may overwrite it
+  for (int i = tid; i <= kN; i += 1024) lds.rs[i] = nnz;
+  edge_key[tid] = k[ITEMS - 1];
+  __syncthreads();
+  const uint32_t vmask = (1u << val_bits) - 1u;
+  uint32_t prev = tid ? edge_key[tid - 1] : 0xFFFFFFFFu;
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    const int i = tid * ITEMS + j;
+    if (i < cap_edges) tdst[i] = k[j] != 0xFFFFFFFFu ? (int32_t)(k[j] & vmask) : 0;
+    const bool first = (i == 0) || (prev >> val_bits) != (k[j] >> val_bits);
+    if (k[j] != 0xFFFFFFFFu && first) lds.rs[k[j] >> val_bits] = i;
+    prev = k[j];
+  }
+  __syncthreads();
+  // suffix-min over rs[0 .. kN]: inside the thread's ITEMS entries, then across threads (wave shuffles + 16 wave minima)
+  int32_t loc[ITEMS];
+  int32_t m = 0x7fffffff;
+#pragma unroll
+  for (int j = ITEMS - 1; j >= 0; --j) {
+    const int32_t r = lds.rs[tid * ITEMS + j];
+    m = r < m ? r : m;
+    loc[j] = m;
+  }
+  int32_t incl = m;
+#pragma unroll
+  for (int dlt = 1; dlt < kWave; dlt <<= 1) {
+    const int32_t t = __shfl_down(incl, dlt);
+    if (lane + dlt < kWave) incl = t < incl ? t : incl;
+  }
+  if (lane == 0) wave_min[w] = incl;
+  int32_t after = __shfl_down(incl, 1);           // min over the later lanes of this wave
+  if (lane == kWave - 1) after = 0x7fffffff;
+  __syncthreads();
+  for (int ww = w + 1; ww < 16; ++ww) after = wave_min[ww] < after ? wave_min[ww] : after;
+  after = after < nnz ? after : nnz;              // rs[kN] = nnz closes the scan
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    const int sr = tid * ITEMS + j;
+    if (sr <= cap_rows) tptr[sr] = loc[j] < after ? loc[j] : after;
+  }
+  if (heavy) {
+    __syncthreads();                              // tptr is read back below (same workgroup)
+    for (int sr = tid; sr < cap_rows; sr += 1024) {
+      if (tptr[sr + 1] - tptr[sr] > PG_HEAVY_ROW) {
+        const int i = atomicAdd(heavy, 1);
+        if (i < heavy_cap) heavy[1 + i] = sr;
+      }
+    }
+  }
+}
+
 // copy seeds into the top layer buffer + set its count; publishes the call's parameters on the device
 __global__ void k_seed_layer(const SampleParams* __restrict__ prm_host, SampleParams* __restrict__ prm_dev,
                              int64_t* layer_ids, int32_t* layer_cnt) {
@@ -575,6 +663,25 @@ static int transpose_block(pg_sampler* s, const pg_nodeflow_desc_t* o, int b, co
   const int32_t cap_edges = (int32_t)(s->cap[b + 1] * s->k);
   const int32_t pad_key = (int32_t)s->cap[b];
   int32_t *key_in = s->tkey, *key_out = s->tkey + s->max_edges, *val_in = s->tkey + 2 * s->max_edges;
+  // small blocks (the seeds' block of a 2-layer step: 12 000 edges): one workgroup does it all (PG_T_DEVICE_SORT=1: never)
+  static const bool device_sort = getenv("PG_T_DEVICE_SORT") != nullptr;
+  const int64_t larger = cap_edges > s->cap[b] + 1 ? cap_edges : s->cap[b] + 1;
+  if (!device_sort && larger <= 1024 * 12) {
+    int vb = 1, kb = 1;
+    while ((1ll << vb) < s->cap[b + 1]) ++vb;
+    while ((1ll << kb) <= s->cap[b]) ++kb;
+    if (vb + kb <= 32) {
+      const int32_t hcap = (int32_t)(cap_edges / PG_HEAVY_ROW);
+      if (larger <= 1024 * 4)
+        hipLaunchKernelGGL(k_t_block<4>, dim3(1), dim3(1024), 0, ax, indptr_b, src_b, n_dst, nnz, cap_edges,
+                           (int32_t)s->cap[b], vb, kb, reinterpret_cast<uint32_t*>(key_in), tptr_b, tdst_b, heavy_b, hcap);
+      else
+        hipLaunchKernelGGL(k_t_block<12>, dim3(1), dim3(1024), 0, ax, indptr_b, src_b, n_dst, nnz, cap_edges,
+                           (int32_t)s->cap[b], vb, kb, reinterpret_cast<uint32_t*>(key_in), tptr_b, tdst_b, heavy_b, hcap);
+      PG_LAUNCH_CHECK();
+      return PG_OK;
+    }
+  }
   hipLaunchKernelGGL(k_t_keys, dim3(grid_for(s->cap[b + 1], 256, 1024)), dim3(256), 0, ax, indptr_b, src_b, n_dst, nnz,
                      cap_edges, pad_key, key_in, val_in, s->tcnt, heavy_b);
   PG_LAUNCH_CHECK();
