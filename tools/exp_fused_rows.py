@@ -42,6 +42,28 @@ print(f"pg_spmm_fwd_rows NO dropout cap_dst={cap_dst}: {us:.1f} us back-to-back 
 for use_es in (False, True):
     us = run(use_es)
     print(f"pg_spmm_fwd_rows edge_slots={use_es} cap_dst={cap_dst}: {us:.1f} us back-to-back  -> {nbytes / us / 1e3:.0f} GB/s ({nbytes / us / 1e3 / 8000:.2f} of peak)")
+# the same launch over ROTATING row sets: 8 x 68 MB > the 256 MB Infinity Cache, so every repetition reads rows that are
+# not resident (what the training loop does: each minibatch touches different rows); the loop above re-reads one set
+NS = 8
+sets = []
+for i in range(NS):
+    sl = torch.randint(0, ncache, (n_src,), device=dev, dtype=torch.int32, generator=g)
+    sl[miss] = -(torch.arange(m, device=dev, dtype=torch.int32) + 3)
+    sets.append((sl, L.PgRowSource(sl.data_ptr(), cache.data_ptr(), staged.data_ptr(), 608, F, 0)))
+def run_rot(reps=200, with_drop=True):
+    dp = ctypes.byref(drop) if with_drop else None
+    for i in range(16):
+        L.check(lib.pg_spmm_fwd_rows(L.ptr(indptr), L.ptr(src), ctypes.byref(sets[i % NS][1]), cap_dst, F, 0, L.ptr(out), F, dp, None, 0, sp))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(reps):
+        L.check(lib.pg_spmm_fwd_rows(L.ptr(indptr), L.ptr(src), ctypes.byref(sets[i % NS][1]), cap_dst, F, 0, L.ptr(out), F, dp, None, 0, sp))
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+for wd in (False, True):
+    us = run_rot(with_drop=wd)
+    print(f"pg_spmm_fwd_rows rotating row sets (cold rows) dropout={wd}: {us:.1f} us back-to-back -> {nbytes / us / 1e3:.0f} GB/s ({nbytes / us / 1e3 / 8000:.2f} of peak)")
 # reference: materialised frame + pg_spmm_fwd_drop
 h = torch.rand((n_src, F), device=dev)
 for _ in range(10):

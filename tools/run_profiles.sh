@@ -16,6 +16,7 @@ timeout 600 python bench.py --vertices 232965 --edges 57300000 --feat-size 602 -
 timeout 600 python bench.py --no-fuse-gather --skip-opt-hit --skip-cpu-baseline > "$OUT/bench_unfused_gather.json" 2>/dev/null
 timeout 600 python bench.py --cache-ratio 1.0 --skip-opt-hit --skip-cpu-baseline > "$OUT/bench_full_cache.json" 2>/dev/null
 timeout 600 python bench.py --model graphsage --cache-ratio 1.0 --skip-opt-hit --skip-cpu-baseline > "$OUT/bench_graphsage_full_cache.json" 2>/dev/null
+( timeout 300 python tools/exp_fused_rows.py; PG_FWD_ROWS_GENERIC=1 timeout 300 python tools/exp_fused_rows.py ) 2>&1 | grep -v amdgpu.ids > "$OUT/fused_rows_alone.txt"
 timeout 600 python tools/exp_dup_census.py > "$OUT/dup_census.json" 2>/dev/null
 
 # 2. per-kernel time of the same command + the kernel sequence of one replayed step
