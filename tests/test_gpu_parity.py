@@ -1425,9 +1425,22 @@ def test_fused_gather_aggregate_vs_oracle(dev, hiplib, oracle, ratio, p_drop, re
     """pg_split_rows + pg_spmm_fwd_rows through the raw C-ABI: hits read from the cache, misses from a staged block in
     miss-list order, dropout keep-mask by source position — equal BIT FOR BIT to the oracle's gather -> dropout ->
     aggregate (and therefore to the unfused pg_gather_rows + pg_spmm_fwd_drop pair)"""
+    _fused_gather_aggregate_case(dev, hiplib, oracle, ratio, p_drop, reduce, 600)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Fd,p_drop", [(256, 0.25), (500, 0.25), (512, 0.0), (768, 0.25), (772, 0.25), (1024, 0.5),
+                                       (1028, 0.25)])
+def test_fused_gather_aggregate_row_widths(dev, hiplib, oracle, Fd, p_drop):
+    """the same check over the row widths that pick the kernel: k_spmm_fwd_rows_w<.., M> with M = 2 (256: the second
+    piece slot empty; 500; 512: full), 3 (768: full), 4 (772, 1024: full) and the generic kernel (1028 > 1024 floats)"""
+    _fused_gather_aggregate_case(dev, hiplib, oracle, 0.3, p_drop, "mean", Fd)
+
+
+def _fused_gather_aggregate_case(dev, hiplib, oracle, ratio, p_drop, reduce, Fd):
     from pagraph_amd import _lib as L
-    rng = np.random.default_rng(int(ratio * 10) + int(p_drop * 100))
-    V, N, Fd, n_src, n_dst = 4000, 6000, 600, 3000, 1100
+    rng = np.random.default_rng(int(ratio * 10) + int(p_drop * 100) + Fd)
+    V, N, n_src, n_dst = 4000, 6000, 3000, 1100
     table = rng.random((N, Fd), dtype=np.float32)
     nid_map = np.sort(rng.choice(N, V, replace=False)).astype(np.int64)
     st = oracle.CacheState(V, nid_map)
@@ -1952,14 +1965,16 @@ def test_miss_list_index_dedup_is_invisible_and_saves_pcie_rows(dev, hiplib, F):
 
 # ---- ragged feature width (Reddit: feat = 602, BASELINE configs[0..1]) on the fused path -------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("Fd,p_drop,reduce", [(602, 0.0, "mean"), (602, 0.25, "mean"), (601, 0.5, "sum"), (603, 0.25, "mean")])
+@pytest.mark.parametrize("Fd,p_drop,reduce", [(602, 0.0, "mean"), (602, 0.25, "mean"), (601, 0.5, "sum"), (603, 0.25, "mean"),
+                                              (258, 0.25, "mean"), (510, 0.25, "sum"), (770, 0.25, "mean"), (1022, 0.5, "mean"),
+                                              (1030, 0.25, "mean")])   # M = 2, 2, 4, 4 and the generic kernel
 def test_fused_gather_aggregate_ragged_width_vs_oracle(dev, hiplib, oracle, Fd, p_drop, reduce):
     """pg_spmm_fwd_rows with dim % 4 != 0: rows are read as whole 16-byte pieces out of a padded fused cache row whose
     next columns hold ANOTHER field (here: NaN) — masked on the way in; the output's padding columns are zeros; the sum
     and the dropout keep-mask equal the oracle's bit for bit"""
     from pagraph_amd import _lib as L
     rng = np.random.default_rng(Fd)
-    V, n_src, n_dst, stride = 3000, 2500, 900, 608
+    V, n_src, n_dst, stride = 3000, 2500, 900, ((Fd + 3) & ~3) + 4     # 602 -> 608: the fused cache's padded row
     table = rng.random((V, Fd), dtype=np.float32)
     ids = rng.permutation(V)[:n_src].astype(np.int64)
     deg = rng.integers(0, 5, n_dst); deg[3] = 0; deg[11] = 90
