@@ -1290,6 +1290,35 @@ def test_bench_default_path_end_to_end_small(dev, hiplib):
     assert 0 < d["cache_hit_pct"] <= 100
 
 
+@pytest.mark.gpu
+def test_bench_two_ranks_as_the_driver_launches_it(dev, hiplib):
+    """`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`: the N > 1 path of the bench (rank 0 runs
+    dg, every rank builds the closure of its own partition, shared host table, equalised step counts, gradient all-reduce,
+    max-over-ranks timing) end to end; two ranks share the one GPU of the test box over gloo (RCCL refuses two ranks on one
+    device) — the launch line is the driver's otherwise"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "20", "--warmup", "5", "--dist-backend", "gloo",
+                        "--vertices", "300000", "--edges", "3000000"], cwd=ROOT, capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["metric"] == "epoch_time_s"
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["higher_is_better"] is False and not d["misses_timed_out"]
+    assert d["config"]["dg_hops"] == 2 and "dg(hops=2)" in d["config"]["workload"]
+    assert "roofline" in d and 0 < d["roofline"]["frac"] < 1
+
+
 # ---- G7 / G8: the HIP models against the reference's own model classes -----------------------------------------
 def _nf_from_fixture(z, dev):
     from pagraph_amd.sampling.nodeflow import NodeFlow
