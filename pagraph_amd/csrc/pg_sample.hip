@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void k_t_heavy(const int32_t* __restrict__ tpt
 // block of the benchmark's step): no global atomics (the hub's counter was one contended address), no multi-pass device sort
 // (seven small launches running beside the compute stream's HBM-bound kernel), one CU. Edges are packed
 // (source << val_bits | destination) in edge = destination order and sorted STABLY on the source bits only (LSD block radix
-// sort, 4 bits per pass) — every source's destinations stay ascending, exactly the device sort's result. tptr comes from the
+// sort) — every source's destinations stay ascending, exactly the device sort's result. tptr comes from the
 // run starts: rs[s] = first sorted position of source s (or nnz), then tptr[s] = min over s' >= s of rs[s'] (suffix-min scan).
 template <int ITEMS>
 __global__ __launch_bounds__(1024) void k_t_block(const int32_t* __restrict__ indptr, const int32_t* __restrict__ src,
@@ -403,21 +403,47 @@ __global__ __launch_bounds__(1024) void k_t_block(const int32_t* __restrict__ in
   __shared__ union {
     typename Sort::storage_type sort;
     int32_t rs[kN + 1];
+    int32_t ip[kN + 1];                           // the block's indptr while the keys are built (n_dst <= cap_edges <= kN)
   } lds;
   __shared__ uint32_t edge_key[1024];
   __shared__ int32_t wave_min[16];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
   const int n = *n_dst_dev, nnz = *nnz_dev;
   if (tid == 0 && heavy) heavy[0] = 0;
-  for (int v = tid; v < n; v += 1024)
-    for (int e = indptr[v]; e < indptr[v + 1]; ++e) stage[e] = ((uint32_t)src[e] << val_bits) | (uint32_t)v;
-  __syncthreads();
+  // keys in edge order, ITEMS consecutive edges per thread (blocked): indptr goes through LDS (one round of independent,
+  // coalesced loads), a thread's source ids are ITEMS independent loads, its first edge's destination one binary search
+  // in LDS, the following ones a walk — no dependent global-memory chain per destination
+  for (int i = tid; i <= n; i += 1024) lds.ip[i] = indptr[i];
   uint32_t k[ITEMS];
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
-    const int i = tid * ITEMS + j;
-    k[j] = i < nnz ? stage[i] : 0xFFFFFFFFu;      // padding sorts behind every source
+    const int e = tid * ITEMS + j;
+    k[j] = e < nnz ? (uint32_t)src[e] : 0u;
   }
+  __syncthreads();
+  {
+    const int e0 = tid * ITEMS;
+    int v = 0;
+    if (e0 < nnz) {
+      int lo = 0, hi = n;                         // smallest index with ip[index] > e0 (ip[n] = nnz > e0)
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (lds.ip[mid] > e0) hi = mid; else lo = mid + 1;
+      }
+      v = lo - 1;
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const int e = e0 + j;
+      if (e < nnz) {
+        while (lds.ip[v + 1] <= e) ++v;           // skips empty destinations
+        k[j] = (k[j] << val_bits) | (uint32_t)v;
+      } else {
+        k[j] = 0xFFFFFFFFu;                       // padding sorts behind every source
+      }
+    }
+  }
+  __syncthreads();                                // lds.ip is dead: the sort's storage may overwrite it
   Sort().sort(k, lds.sort, (unsigned)val_bits, (unsigned)(val_bits + key_bits));
   __syncthreads();                                // lds.sort is dead from here on: rs may overwrite it
   for (int i = tid; i <= kN; i += 1024) lds.rs[i] = nnz;
@@ -457,13 +483,21 @@ __global__ __launch_bounds__(1024) void k_t_block(const int32_t* __restrict__ in
   after = after < nnz ? after : nnz;              // rs[kN] = nnz closes the scan
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
+    loc[j] = loc[j] < after ? loc[j] : after;     // = tptr[tid * ITEMS + j]
     const int sr = tid * ITEMS + j;
-    if (sr <= cap_rows) tptr[sr] = loc[j] < after ? loc[j] : after;
+    if (sr <= cap_rows) tptr[sr] = loc[j];
   }
   if (heavy) {
-    __syncthreads();                              // tptr is read back below (same workgroup)
-    for (int sr = tid; sr < cap_rows; sr += 1024) {
-      if (tptr[sr + 1] - tptr[sr] > PG_HEAVY_ROW) {
+    // hub list from the registers: a source's edge count is the next tptr minus its own (the next thread's first one
+    // crosses through LDS)
+    edge_key[tid] = (uint32_t)loc[0];
+    __syncthreads();
+    const int32_t next_first = tid + 1 < 1024 ? (int32_t)edge_key[tid + 1] : nnz;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const int sr = tid * ITEMS + j;
+      const int32_t nxt = j + 1 < ITEMS ? loc[j + 1] : next_first;
+      if (sr < cap_rows && nxt - loc[j] > PG_HEAVY_ROW) {
         const int i = atomicAdd(heavy, 1);
         if (i < heavy_cap) heavy[1 + i] = sr;
       }
