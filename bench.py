@@ -685,6 +685,11 @@ def run():
     # miss path only in ms_per_step_windows
     hd = np.diff(np.asarray(host_t)) * 1e3 if len(host_t) > 1 else np.zeros(0)
     host_longest = [[round(float(hd[i_]), 3), int(i_) + 1] for i_ in np.argsort(-hd)[:3]] if len(hd) else []
+    launch_split = None
+    if getattr(trainer, "launch_trace", None):
+        # PG_TRACE_LAUNCH=1: [sample + prepare, compute, release] ms of the trainer's three longest iterations
+        lt = np.asarray(trainer.launch_trace)
+        launch_split = [[int(i_)] + [round(float(x), 3) for x in lt[i_]] for i_ in np.argsort(-lt.sum(1))[:3]]
     timed_out = bool(cacher.misses_timed_out())
     copy_windows = None
     if os.environ.get("PG_MISSQ_COPYLOG"):
@@ -849,7 +854,7 @@ def run():
             "feat_gather_GBps": (micro[1 << 20]["GBps"] if micro else achieved),
             "seeds_per_s": seeds_total / elapsed,
             "host_issue_ms_per_step": t_issued / K * 1e3,     # launch thread's share; == ms_per_step when it is the bottleneck
-            "ms_per_step_windows": windows, "window_steps": win, "host_longest_iterations_ms": host_longest,
+            "ms_per_step_windows": windows, "window_steps": win, "host_longest_iterations_ms": host_longest, "launch_thread_longest_split_ms": launch_split,
             "warmup_requested": args.warmup, "misses_timed_out": timed_out,
             "host": dict(host_info(cacher), timed_region_cgroup=cpu_quota), "miss_queue": mq_stats, "miss_copy_GBps_windows": copy_windows,
             "roofline": roofline,

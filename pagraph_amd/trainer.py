@@ -552,14 +552,24 @@ class GraphedTrainer:
 
         while len(self._prepared) < self.lookahead and prepare_one():
             pass
+        # PG_TRACE_LAUNCH=1 (diagnosis): per iteration, how long the launch thread spent in sample + prepare / in compute /
+        # in release — the three phases a host stall can hide in (GraphedTrainer.launch_trace: [ms, ms, ms] per step)
+        trace = self.launch_trace if getattr(self, "launch_trace", None) is not None else None
+        if trace is None and __import__("os").environ.get("PG_TRACE_LAUNCH"):
+            trace = self.launch_trace = []
         while self._prepared and (steps is None or done < steps):
             # top the pipeline up BEFORE (possibly) blocking on the oldest batch's miss rows: the sampler
             # and the load stream of later batches must never wait for the host
+            t_0 = time.perf_counter() if trace is not None else 0.0
             if steps is None or self.keep_primed or done + len(self._prepared) < steps:
                 prepare_one()
+            t_1 = time.perf_counter() if trace is not None else 0.0
             cur = self._prepared.pop(0)
             loss = self.compute(cur)
+            t_2 = time.perf_counter() if trace is not None else 0.0
             self.sampler.release(cur.nf_cur)
+            if trace is not None:
+                trace.append(((t_1 - t_0) * 1e3, (t_2 - t_1) * 1e3, (time.perf_counter() - t_2) * 1e3))
             done += 1
             if not self._first_done:
                 self._first_done = True
