@@ -346,6 +346,9 @@ int pg_bitmap_to_ids(const uint64_t* bitmap, int64_t n_words, int64_t* out_ids, 
  * ------------------------------------------------------------------------ */
 #define PG_REDUCE_MEAN 0
 #define PG_REDUCE_SUM 1
+#define PG_REDUCE_MAX 2 /* fn.max, the 'pool' aggregator (graphsage_nssc.py:106-110): element-wise maximum of the in-edge
+                         * messages; forward entry points only (pg_spmm_fwd / _fwd_drop / _fwd_rows) — its backward needs
+                         * the forward's input and output: pg_spmm_bwd_max / pg_spmm_bwd_gather_max below             */
 /* out[v,:] = reduce_{e in [indptr[v],indptr[v+1])} h[src[e],:]   (0 when v has no edge)          */
 int pg_spmm_fwd(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride,
                 int64_t n_dst, int32_t dim, int reduce, float* out, int32_t out_stride,
@@ -426,6 +429,24 @@ int pg_spmm_bwd_gather_dz(const int32_t* tptr, const int32_t* tdst, const int32_
                           int32_t go_stride, int64_t n_src, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,
                           const int32_t* heavy, int32_t heavy_cap, const pg_dropout_t* drop, const float* act_out,
                           int32_t act_stride, float* dz, pg_stream_t stream);
+
+/* Backward of the PG_REDUCE_MAX aggregation. DGL 0.4.1's rule (its ReduceMax functor's backward is `val == accum`
+ * [recollection; DGL is not in the reference checkout — parity unpinned]): a destination's gradient goes, whole, to EVERY
+ * in-edge whose message equals the maximum (ties are not split):
+ *   grad_h[s, c] (+)= sum over s's edges (s -> v) of  (x[s, c] == out[v, c] ? grad_out[v, c] : 0) * dmask(s, c)
+ * with x = dropout(h) as the forward saw it (x = h, dmask = 1 without dropout; else x = keep ? h * scale : 0 and
+ * dmask = keep ? scale : 0). h = the forward's input [n_src, dim], out = its output [n_dst, dim].
+ * pg_spmm_bwd_max: scatter form (fp32 atomics; grad_h zeroed by the caller).
+ * pg_spmm_bwd_gather_max: gather form over the block's source-major copy, destinations ascending, every row written,
+ * deterministic; heavy / heavy_cap as pg_spmm_bwd_gather; dz (may be NULL) as pg_spmm_bwd_gather_dz with act_out = h. */
+int pg_spmm_bwd_max(const int32_t* indptr, const int32_t* src, const float* grad_out, int32_t go_stride,
+                    int64_t n_dst, int32_t dim, const float* h, int32_t h_stride, const float* out,
+                    int32_t out_stride, float* grad_h, int32_t gh_stride, const pg_dropout_t* drop,
+                    pg_stream_t stream);
+int pg_spmm_bwd_gather_max(const int32_t* tptr, const int32_t* tdst, const float* grad_out, int32_t go_stride,
+                           int64_t n_src, int32_t dim, const float* h, int32_t h_stride, const float* out,
+                           int32_t out_stride, float* grad_h, int32_t gh_stride, const int32_t* heavy,
+                           int32_t heavy_cap, const pg_dropout_t* drop, float* dz, pg_stream_t stream);
 
 /* Skinny dense step of the first layer — NodeUpdate.forward at PaGraph/model/gcn_nssc.py:18-23 and
  * graphsage_nssc.py:24-29 — on fp32 MFMA: Z = X[n,K] * W^T + bias with W = nn.Linear's weight [N,K],

@@ -20,13 +20,14 @@ What is pinned by the reference itself:
       "parity unpinned").
   G7  GCNSampling.forward / preprocess_forward, GCNInfer.forward / preprocess_forward
       with NodeUpdate                    (PaGraph/model/gcn_nssc.py:6-164)
-  G8  GraphSageSampling.forward ('mean', 'gcn'; with and without preprocess)
+  G8  GraphSageSampling.forward ('mean', 'gcn', 'pool'; with and without preprocess)
       with NodeUpdate                    (PaGraph/model/graphsage_nssc.py:6-134)
       G7/G8 run the reference's model classes (layer stack, skip-concat, norm
       scaling, preprocess branches, parameter names, autograd) on a stand-in
-      NodeFlow whose block_compute applies a STAND-IN copy_src + mean|sum reducer
-      (torch index_add over the block's edges, zero rows for destinations without
-      in-edges) in place of DGL's fused message-passing kernel, which is not
+      NodeFlow whose block_compute applies a STAND-IN copy_src + mean|sum|max reducer
+      (torch index_add / index_reduce over the block's edges, zero rows for
+      destinations without in-edges; max differentiates as DGL's `val == accum`
+      [recollection]) in place of DGL's fused message-passing kernel, which is not
       available. Outputs: logits and every parameter gradient of
       sum(logits * G) for a stored G.
   G9  count_vertex_freq / optimal_cache_hit (examples/opt_cache_hit.py:22-31) and
@@ -355,19 +356,42 @@ class StandInBlockNodeFlow:
 
     def block_compute(self, i, message_func, reduce_func, apply_node_func=None):
         assert message_func.kind == "copy_src" and reduce_func.msg == message_func.out
-        assert reduce_func.kind in ("mean", "sum")
+        assert reduce_func.kind in ("mean", "sum", "max")
         indptr, src = self.blocks[i]
         h = self.layers[i].data[message_func.src]
         n_dst = self.layer_sizes[i + 1]
         deg = indptr[1:] - indptr[:-1]
         dst = torch.repeat_interleave(torch.arange(n_dst), deg)
-        out = torch.zeros((n_dst, h.shape[1]), dtype=h.dtype).index_add(0, dst, h[src])
+        if reduce_func.kind == "max":
+            out = _StandInMaxReduce.apply(h, src, dst, n_dst)
+        else:
+            out = torch.zeros((n_dst, h.shape[1]), dtype=h.dtype).index_add(0, dst, h[src])
         if reduce_func.kind == "mean":
             out = out / deg.clamp(min=1).to(h.dtype).unsqueeze(1)
         d = self.layers[i + 1].data
         d[reduce_func.out] = out
         if apply_node_func is not None:
             d.update(apply_node_func(types.SimpleNamespace(data=d)))
+
+
+class _StandInMaxReduce(torch.autograd.Function):
+    """STAND-IN for DGL 0.4.1's copy_src + max kernel (NOT reference code; DGL is absent): out[v] = element-wise maximum
+    of the in-edge messages, zeros without in-edges; backward as DGL's ReduceMax functor [recollection]: (val == accum),
+    i.e. every edge that attains the maximum receives the whole gradient."""
+
+    @staticmethod
+    def forward(ctx, h, src, dst, n_dst):
+        out = torch.full((n_dst, h.shape[1]), float("-inf"), dtype=h.dtype)
+        out = out.index_reduce(0, dst, h[src], "amax", include_self=True)
+        out = torch.where(torch.isinf(out) & (out < 0), torch.zeros_like(out), out)
+        ctx.save_for_backward(h, src, dst, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h, src, dst, out = ctx.saved_tensors
+        hit = (h[src] == out[dst]).to(g.dtype)
+        return torch.zeros_like(h).index_add(0, src, g[dst] * hit), None, None, None
 
 
 def _rand_nodeflow(rng, sizes, max_deg):
@@ -441,7 +465,11 @@ def gen_models(gcn, sage):
              ("sage_mean_L2", dict(n_layers=2, preprocess=False, agg="mean"), [120, 70, 30, 12]),
              ("sage_gcn_L1", dict(n_layers=1, preprocess=False, agg="gcn"), [90, 40, 16]),
              ("sage_mean_pre_L1", dict(n_layers=1, preprocess=True, agg="mean"), [60, 20]),
-             ("sage_mean_pre_L2", dict(n_layers=2, preprocess=True, agg="mean"), [90, 40, 16])]
+             ("sage_mean_pre_L2", dict(n_layers=2, preprocess=True, agg="mean"), [90, 40, 16]),
+             # appended in round 3 (the generator's draws for the cases above are unchanged)
+             ("sage_pool_L1", dict(n_layers=1, preprocess=False, agg="pool"), [90, 40, 16]),
+             ("sage_pool_L2", dict(n_layers=2, preprocess=False, agg="pool"), [120, 70, 30, 12]),
+             ("sage_pool_pre_L1", dict(n_layers=1, preprocess=True, agg="pool"), [60, 20])]
     for idx, (tag, cfg, sizes) in enumerate(cases):
         torch.manual_seed(200 + idx)
         model = sage.GraphSageSampling(Fdim, H, C, cfg["n_layers"], Fn.relu, 0.0, cfg["agg"], cfg["preprocess"])

@@ -46,6 +46,11 @@ def lib():
         L.pgc_spmm_bwd.restype = None
         L.pgc_spmm_bwd.argtypes = [_i32p, _i32p, _f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                    ctypes.c_int, _f32p]
+        L.pgc_spmm_fwd_max.restype = None
+        L.pgc_spmm_fwd_max.argtypes = [_i32p, _i32p, _f32p, ctypes.c_int64, ctypes.c_int32, _f32p]
+        L.pgc_spmm_bwd_max.restype = None
+        L.pgc_spmm_bwd_max.argtypes = [_i32p, _i32p, _f32p, _f32p, _f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+                                       _f32p]
         L.pgc_rmat_edges.restype = None
         L.pgc_rmat_edges.argtypes = [ctypes.c_uint64, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint32,
                                      ctypes.c_uint32, ctypes.c_int64, ctypes.c_int64, _i64p, _i64p]
@@ -258,6 +263,9 @@ def spmm_fwd(indptr, src, h, n_dst, reduce="mean"):
     indptr = _c(indptr, np.int32)
     src = _c(src, np.int32)
     out = np.empty((n_dst, h.shape[1]), dtype=np.float32)
+    if reduce == "max":
+        lib().pgc_spmm_fwd_max(_p(indptr, _i32p), _p(src, _i32p), _p(h, _f32p), n_dst, h.shape[1], _p(out, _f32p))
+        return out
     lib().pgc_spmm_fwd(_p(indptr, _i32p), _p(src, _i32p), _p(h, _f32p), n_dst, h.shape[1],
                        1 if reduce == "mean" else 0, _p(out, _f32p))
     return out
@@ -270,6 +278,19 @@ def spmm_bwd(indptr, src, grad_out, n_src, reduce="mean"):
     gh = np.empty((n_src, go.shape[1]), dtype=np.float32)
     lib().pgc_spmm_bwd(_p(indptr, _i32p), _p(src, _i32p), _p(go, _f32p), go.shape[0], n_src, go.shape[1],
                        1 if reduce == "mean" else 0, _p(gh, _f32p))
+    return gh
+
+
+def spmm_bwd_max(indptr, src, grad_out, x, out):
+    """backward of spmm_fwd(..., 'max'): x = the messages the forward aggregated [n_src, dim], out = its result"""
+    go = _c(grad_out, np.float32)
+    x = _c(x, np.float32)
+    out = _c(out, np.float32)
+    indptr = _c(indptr, np.int32)
+    src = _c(src, np.int32)
+    gh = np.empty_like(x)
+    lib().pgc_spmm_bwd_max(_p(indptr, _i32p), _p(src, _i32p), _p(go, _f32p), _p(x, _f32p), _p(out, _f32p), go.shape[0],
+                           x.shape[0], go.shape[1], _p(gh, _f32p))
     return gh
 
 
@@ -375,10 +396,10 @@ def gcn_forward(nf, feats0, params, n_layers=1):
 
 
 def sage_model_forward(blocks, layer_sizes, frames, state, n_layers, aggregator="mean", preprocess=False):
-    """GraphSageSampling.forward (graphsage_nssc.py:74-134) with NodeUpdate (:21-30), aggregators 'mean' (:98-101)
-    and 'gcn' (:102-106), dropout off, activation = ReLU. Pinned by tests/golden/g8_*. Arguments as
+    """GraphSageSampling.forward (graphsage_nssc.py:74-134) with NodeUpdate (:21-30), aggregators 'mean' (:98-101),
+    'gcn' (:102-105) and 'pool' (:106-110), dropout off, activation = ReLU. Pinned by tests/golden/g8_*. Arguments as
     gcn_model_forward; under preprocess every layer's frame also holds 'neigh' (:77)."""
-    reduce = {"mean": "mean", "gcn": "sum"}[aggregator]
+    reduce = {"mean": "mean", "gcn": "sum", "pool": "max"}[aggregator]                  # :98-110
     L = len(layer_sizes)                                              # nf.num_layers
     if preprocess:
         h = []

@@ -237,6 +237,39 @@ void pgc_spmm_fwd(const int32_t* indptr, const int32_t* src, const float* h, int
   }
 }
 
+/* DGL copy_src + max (graphsage_nssc.py:106-110, the 'pool' aggregator): out[v,:] = element-wise maximum of the
+ * in-edge messages; zeros for a destination without in-edges (this build's reading of DGL 0.4.1 — unpinned).  */
+void pgc_spmm_fwd_max(const int32_t* indptr, const int32_t* src, const float* h, int64_t n_dst, int32_t dim,
+                      float* out) {
+  for (int64_t v = 0; v < n_dst; ++v) {
+    float* o = out + v * (int64_t)dim;
+    const int32_t b = indptr[v], e = indptr[v + 1];
+    for (int c = 0; c < dim; ++c) o[c] = 0.f;
+    for (int32_t i = b; i < e; ++i) {
+      const float* hr = h + (int64_t)src[i] * dim;
+      for (int c = 0; c < dim; ++c)
+        if (i == b || hr[c] > o[c]) o[c] = hr[c];
+    }
+  }
+}
+
+/* its backward: DGL 0.4.1's ReduceMax functor differentiates as (val == accum) [recollection, unpinned]: every in-edge
+ * whose message equals the maximum receives the destination's whole gradient. x = the messages the forward saw.   */
+void pgc_spmm_bwd_max(const int32_t* indptr, const int32_t* src, const float* go, const float* x, const float* out,
+                      int64_t n_dst, int64_t n_src, int32_t dim, float* gh) {
+  memset(gh, 0, sizeof(float) * (size_t)(n_src * dim));
+  for (int64_t v = 0; v < n_dst; ++v) {
+    const float* gr = go + v * (int64_t)dim;
+    const float* o = out + v * (int64_t)dim;
+    for (int32_t i = indptr[v]; i < indptr[v + 1]; ++i) {
+      float* g = gh + (int64_t)src[i] * dim;
+      const float* xr = x + (int64_t)src[i] * dim;
+      for (int c = 0; c < dim; ++c)
+        if (xr[c] == o[c]) g[c] += gr[c];
+    }
+  }
+}
+
 /* adjoint of the above: grad_h (zeroed here) [n_src, dim] */
 void pgc_spmm_bwd(const int32_t* indptr, const int32_t* src, const float* go, int64_t n_dst, int64_t n_src,
                   int32_t dim, int mean, float* gh) {

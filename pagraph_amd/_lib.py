@@ -20,6 +20,7 @@ PG_ADAM_MAX_TENSORS = 16
 PG_HEAD_SUM_PARTIALS, PG_HEAD_DAGG_PER_EDGE = 1, 2
 PG_REDUCE_MEAN = 0
 PG_REDUCE_SUM = 1
+PG_REDUCE_MAX = 2
 
 c_i32, c_i64, c_u32, c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 vp = ctypes.c_void_p
@@ -123,6 +124,9 @@ _SIGS = {
     "pg_spmm_bwd_gather": (ctypes.c_int, [vp, vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, c_i32, vp, vp]),
     "pg_spmm_bwd_gather_dz": (ctypes.c_int, [vp, vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, c_i32, vp, vp,
                                              c_i32, vp, vp]),
+    "pg_spmm_bwd_max": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, vp, c_i32, vp, c_i32, vp, c_i32, vp, vp]),
+    "pg_spmm_bwd_gather_max": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, vp, c_i32, vp, c_i32, vp, c_i32, vp, c_i32, vp,
+                                              vp, vp]),
     "pg_linear_fwd": (ctypes.c_int, [vp, c_i32, vp, vp, vp, c_i32, c_i64, c_i32, c_i32, c_i32, vp]),
     "pg_linear2_fwd": (ctypes.c_int, [vp, c_i32, vp, vp, c_i32, vp, c_i32, vp, vp, c_i32, vp, c_i32, c_i64, c_i32, c_i32, vp]),
     "pg_linear_bwd_w_scratch": (c_i64, [c_i64, c_i32, c_i32]),

@@ -26,6 +26,13 @@ struct SV<4> {
   __device__ static inline float4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
   __device__ static inline void add(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
   __device__ static inline void div(float4& a, float d) { a.x /= d; a.y /= d; a.z /= d; a.w /= d; }
+  __device__ static inline float4 fill(float f) { return make_float4(f, f, f, f); }
+  __device__ static inline void mx(float4& a, const float4& b) { a.x = fmaxf(a.x, b.x); a.y = fmaxf(a.y, b.y); a.z = fmaxf(a.z, b.z); a.w = fmaxf(a.w, b.w); }
+  // b where x == o (component-wise), else 0: the max reducer's backward routes a destination's gradient to every in-edge
+  // whose message equals the maximum
+  __device__ static inline float4 where_eq(const float4& x, const float4& o, const float4& b) {
+    return make_float4(x.x == o.x ? b.x : 0.f, x.y == o.y ? b.y : 0.f, x.z == o.z ? b.z : 0.f, x.w == o.w ? b.w : 0.f);
+  }
 };
 template <>
 struct SV<2> {
@@ -33,6 +40,11 @@ struct SV<2> {
   __device__ static inline float2 zero() { return make_float2(0.f, 0.f); }
   __device__ static inline void add(float2& a, const float2& b) { a.x += b.x; a.y += b.y; }
   __device__ static inline void div(float2& a, float d) { a.x /= d; a.y /= d; }
+  __device__ static inline float2 fill(float f) { return make_float2(f, f); }
+  __device__ static inline void mx(float2& a, const float2& b) { a.x = fmaxf(a.x, b.x); a.y = fmaxf(a.y, b.y); }
+  __device__ static inline float2 where_eq(const float2& x, const float2& o, const float2& b) {
+    return make_float2(x.x == o.x ? b.x : 0.f, x.y == o.y ? b.y : 0.f);
+  }
 };
 template <>
 struct SV<1> {
@@ -40,11 +52,18 @@ struct SV<1> {
   __device__ static inline float zero() { return 0.f; }
   __device__ static inline void add(float& a, const float& b) { a += b; }
   __device__ static inline void div(float& a, float d) { a /= d; }
+  __device__ static inline float fill(float f) { return f; }
+  __device__ static inline void mx(float& a, const float& b) { a = fmaxf(a, b); }
+  __device__ static inline float where_eq(const float& x, const float& o, const float& b) { return x == o ? b : 0.f; }
 };
 
 constexpr int kMaxAcc = 4;
+constexpr float kNegInf = -__builtin_huge_valf();
 
-template <int VEC>
+// MAXR (PG_REDUCE_MAX, graphsage_nssc.py:106-110 'pool'): out[v] = element-wise maximum of v's in-edge messages in place of
+// their sum; a destination without in-edges gets zeros like the other reducers.
+
+template <int VEC, bool MAXR>
 __global__ __launch_bounds__(256) void k_spmm_fwd(const int32_t* __restrict__ indptr,
                                                   const int32_t* __restrict__ src,
                                                   const float* __restrict__ h, int32_t h_stride, int64_t n_dst,
@@ -65,13 +84,16 @@ __global__ __launch_bounds__(256) void k_spmm_fwd(const int32_t* __restrict__ in
   for (int c0 = 0; c0 < pieces; c0 += lpr * kMaxAcc) {
     V acc[kMaxAcc];
 #pragma unroll
-    for (int m = 0; m < kMaxAcc; ++m) acc[m] = S::zero();
+    for (int m = 0; m < kMaxAcc; ++m) acc[m] = (MAXR && end > beg) ? S::fill(kNegInf) : S::zero();
     for (int32_t e = beg; e < end; ++e) {
       const V* hrow = reinterpret_cast<const V*>(h + (int64_t)src[e] * h_stride);
 #pragma unroll
       for (int m = 0; m < kMaxAcc; ++m) {
         const int c = c0 + m * lpr + gl;
-        if (c < pieces) S::add(acc[m], hrow[c]);
+        if (c < pieces) {
+          if constexpr (MAXR) S::mx(acc[m], hrow[c]);
+          else S::add(acc[m], hrow[c]);
+        }
       }
     }
     const float d = (float)(end - beg);
@@ -79,7 +101,7 @@ __global__ __launch_bounds__(256) void k_spmm_fwd(const int32_t* __restrict__ in
     for (int m = 0; m < kMaxAcc; ++m) {
       const int c = c0 + m * lpr + gl;
       if (c < pieces) {
-        if (reduce == PG_REDUCE_MEAN && end > beg) S::div(acc[m], d);
+        if (!MAXR && reduce == PG_REDUCE_MEAN && end > beg) S::div(acc[m], d);
         orow[c] = acc[m];
       }
     }
@@ -155,6 +177,7 @@ __device__ __forceinline__ float4 keep_apply(float4 x, uint32_t bits, float scal
   return x;
 }
 
+template <bool MAXR>
 __global__ __launch_bounds__(256) void k_spmm_fwd_drop(const int32_t* __restrict__ indptr,
                                                        const int32_t* __restrict__ src,
                                                        const float* __restrict__ h, int32_t h_stride, int64_t n_dst,
@@ -175,7 +198,7 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_drop(const int32_t* __restrict
   for (int c0 = 0; c0 < pieces; c0 += lpr * kMaxAcc) {
     float4 acc[kMaxAcc];
 #pragma unroll
-    for (int m = 0; m < kMaxAcc; ++m) acc[m] = S::zero();
+    for (int m = 0; m < kMaxAcc; ++m) acc[m] = (MAXR && end > beg) ? S::fill(kNegInf) : S::zero();
     for (int32_t e = beg; e < end; ++e) {
       const int32_t sr = src[e];
       const float4* hrow = reinterpret_cast<const float4*>(h + (int64_t)sr * h_stride);
@@ -191,7 +214,8 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_drop(const int32_t* __restrict
             Philox::gen((uint32_t)sr, (uint32_t)q, d.tag, step, d.k0, d.k1, o);
             have_q = q;
           }
-          S::add(acc[m], drop_apply(x, o, (c >> 6) & 1, d.thr, d.scale));
+          if constexpr (MAXR) S::mx(acc[m], drop_apply(x, o, (c >> 6) & 1, d.thr, d.scale));
+          else S::add(acc[m], drop_apply(x, o, (c >> 6) & 1, d.thr, d.scale));
         }
       }
     }
@@ -200,7 +224,7 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_drop(const int32_t* __restrict
     for (int m = 0; m < kMaxAcc; ++m) {
       const int c = c0 + m * lpr + gl;
       if (c < pieces) {
-        if (reduce == PG_REDUCE_MEAN && end > beg) S::div(acc[m], dg);
+        if (!MAXR && reduce == PG_REDUCE_MEAN && end > beg) S::div(acc[m], dg);
         orow[c] = acc[m];
       }
     }
@@ -226,7 +250,7 @@ constexpr int kRowsBatch = 4;   // source rows whose loads are in flight togethe
 // cache / of `out` is padded to a multiple of 4 floats (the host side checks the strides) — and the last piece's
 // columns >= dim (the next field of the fused cache row, or padding) are forced to zero before they are summed, so
 // `out`'s padding columns hold zeros.
-template <bool DROP, bool TAIL>
+template <bool DROP, bool TAIL, bool MAXR>
 __global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict__ indptr,
                                                        const int32_t* __restrict__ src,
                                                        const int32_t* __restrict__ slots,
@@ -252,8 +276,9 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict
     float4* orow = reinterpret_cast<float4*>(out + v * out_stride);
     for (int c0 = 0; c0 < pieces; c0 += kWave * kMaxAcc) {
       float4 acc[kMaxAcc];
+      bool any = false;          // MAXR: a row was taken (padding / unresolved rows contribute nothing)
 #pragma unroll
-      for (int m = 0; m < kMaxAcc; ++m) acc[m] = S::zero();
+      for (int m = 0; m < kMaxAcc; ++m) acc[m] = MAXR ? S::fill(kNegInf) : S::zero();
       for (int32_t eb = beg; eb < end; eb += kWave) {
         const int ne = end - eb < kWave ? end - eb : kWave;
         // lane e holds edge e's source position and slot: the index loads of all of the destination's edges are in
@@ -286,6 +311,7 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict
 #pragma unroll
           for (int j = 0; j < kRowsBatch; ++j) {
             if (!ok[j]) continue;
+            any = true;
             uint32_t o[4] = {0, 0, 0, 0};
             int have_q = -1;
 #pragma unroll
@@ -308,7 +334,8 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict
                     xv.w = 0.f;
                   }
                 }
-                S::add(acc[m], xv);
+                if constexpr (MAXR) S::mx(acc[m], xv);
+                else S::add(acc[m], xv);
               }
             }
           }
@@ -319,7 +346,8 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict
       for (int m = 0; m < kMaxAcc; ++m) {
         const int c = c0 + m * kWave + lane;
         if (c < pieces) {
-          if (reduce == PG_REDUCE_MEAN && end > beg) S::div(acc[m], dg);
+          if (!MAXR && reduce == PG_REDUCE_MEAN && end > beg) S::div(acc[m], dg);
+          if (MAXR && !any) acc[m] = S::zero();
           orow[c] = acc[m];
         }
       }
@@ -342,7 +370,7 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict
 //  * a row's Philox draws are issued between the loads and their first use.
 constexpr int kRowsPair = 2;
 
-template <bool DROP, bool TAIL, int M>
+template <bool DROP, bool TAIL, int M, bool MAXR>
 __global__ __launch_bounds__(256) void k_spmm_fwd_rows_w(const int32_t* __restrict__ indptr,
                                                          const int32_t* __restrict__ src,
                                                          const int32_t* __restrict__ slots,
@@ -366,8 +394,9 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows_w(const int32_t* __restri
     const int tail = dim & 3;                        // valid columns of the last piece (TAIL only)
     const int32_t beg = indptr[v], end = indptr[v + 1];
     float4 acc[M];
+    bool any = false;            // MAXR: a row was taken
 #pragma unroll
-    for (int m = 0; m < M; ++m) acc[m] = S::zero();
+    for (int m = 0; m < M; ++m) acc[m] = MAXR ? S::fill(kNegInf) : S::zero();
     for (int32_t eb = beg; eb < end; eb += kWave) {
       const int ne = end - eb < kWave ? end - eb : kWave;
       int32_t my_p = 0, my_s = -2;
@@ -422,6 +451,7 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows_w(const int32_t* __restri
 #pragma unroll
         for (int j = 0; j < kRowsPair; ++j) {
           if (!ok[j]) continue;
+          if constexpr (MAXR) any = true;
 #pragma unroll
           for (int m = 0; m < M; ++m) {
             const int c = m * kWave + lane;
@@ -435,7 +465,8 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows_w(const int32_t* __restri
                   xv.w = 0.f;
                 }
               }
-              S::add(acc[m], xv);
+              if constexpr (MAXR) S::mx(acc[m], xv);
+              else S::add(acc[m], xv);
             }
           }
         }
@@ -447,7 +478,8 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows_w(const int32_t* __restri
     for (int m = 0; m < M; ++m) {
       const int c = m * kWave + lane;
       if (c < pieces) {
-        if (reduce == PG_REDUCE_MEAN && end > beg) S::div(acc[m], dg);
+        if (!MAXR && reduce == PG_REDUCE_MEAN && end > beg) S::div(acc[m], dg);
+        if (MAXR && !any) acc[m] = S::zero();
         orow[c] = acc[m];
       }
     }
@@ -526,17 +558,44 @@ __device__ __forceinline__ float4 dz_piece(float4 lo, float4 hi, float4 y) {
   return lo;
 }
 
-template <int VEC, bool DROP, int T>
+// PG_REDUCE_MAX backward (pg_spmm_bwd_gather_max): the forward's input and output
+struct MaxIn {
+  const float* h;     // [n_src, dim] the aggregation's input (before dropout)
+  const float* out;   // [n_dst, dim] its output
+  int32_t h_stride, out_stride;
+};
+
+// piece c of row sr through the dropout mask: x * scale where kept, 0 where dropped (the forward's drop_apply for a
+// float4 piece; for the scalar layout c is the column)
+template <int VEC>
+__device__ __forceinline__ typename SV<VEC>::type drop_piece(typename SV<VEC>::type x, uint32_t sr, int c, const DropArgs& d,
+                                                             uint32_t step) {
+  if constexpr (VEC == 4) {
+    uint32_t o[4];
+    Philox::gen(sr, (uint32_t)(((c >> 7) << 6) | (c & 63)), d.tag, step, d.k0, d.k1, o);
+    return drop_apply(x, o, (c >> 6) & 1, d.thr, d.scale);
+  } else {
+    const int piece = c >> 2, j = c & 3, half = (piece >> 6) & 1;
+    uint32_t o[4];
+    Philox::gen(sr, (uint32_t)(((piece >> 7) << 6) | (piece & 63)), d.tag, step, d.k0, d.k1, o);
+    const uint32_t w = (j >> 1) ? (half ? o[3] : o[1]) : (half ? o[2] : o[0]);
+    const uint32_t u = (j & 1) ? (w >> 16) : (w & 0xffffu);
+    return u >= d.thr ? x * d.scale : 0.f;
+  }
+}
+
+template <int VEC, bool DROP, int T, bool MAXR>
 __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, int32_t heavy_cap,
                                            const int32_t* __restrict__ tptr, const int32_t* __restrict__ tdst,
                                            const int32_t* __restrict__ indptr, const float* __restrict__ go,
                                            int32_t go_stride, int32_t dim, int reduce, float* __restrict__ gh,
-                                           int32_t gh_stride, int lpr_log2, DropArgs d, int first, int stride, DzOut z);
+                                           int32_t gh_stride, int lpr_log2, DropArgs d, int first, int stride, DzOut z,
+                                           MaxIn mi);
 
 constexpr int kBwdBatch = 4;
 
 // (blocks >= n_row_blocks of the launch are the hub blocks: heavy_rows below)
-template <int VEC, bool DROP>
+template <int VEC, bool DROP, bool MAXR>
 __global__ __launch_bounds__(256) void k_spmm_bwd_gather(const int32_t* __restrict__ tptr,
                                                          const int32_t* __restrict__ tdst,
                                                          const int32_t* __restrict__ indptr,
@@ -544,12 +603,12 @@ __global__ __launch_bounds__(256) void k_spmm_bwd_gather(const int32_t* __restri
                                                          int64_t n_src, int32_t dim, int reduce,
                                                          float* __restrict__ gh, int32_t gh_stride, int lpr_log2,
                                                          int skip_heavy, DropArgs d, const int32_t* __restrict__ heavy,
-                                                         int32_t heavy_cap, int32_t n_row_blocks, DzOut z) {
+                                                         int32_t heavy_cap, int32_t n_row_blocks, DzOut z, MaxIn mi) {
   using S = SV<VEC>;
   using V = typename S::type;
   if ((int)blockIdx.x >= n_row_blocks) {
-    heavy_rows<VEC, DROP, 256>(heavy, heavy_cap, tptr, tdst, indptr, go, go_stride, dim, reduce, gh, gh_stride, lpr_log2, d,
-                               (int)blockIdx.x - n_row_blocks, (int)gridDim.x - n_row_blocks, z);
+    heavy_rows<VEC, DROP, 256, MAXR>(heavy, heavy_cap, tptr, tdst, indptr, go, go_stride, dim, reduce, gh, gh_stride,
+                                     lpr_log2, d, (int)blockIdx.x - n_row_blocks, (int)gridDim.x - n_row_blocks, z, mi);
     return;
   }
   const int lpr = 1 << lpr_log2;
@@ -567,6 +626,13 @@ __global__ __launch_bounds__(256) void k_spmm_bwd_gather(const int32_t* __restri
   V last = S::zero();       // this lane's piece of the row (the dZ epilogue needs it; pieces <= lpr there)
   for (int c = gl; c < pieces; c += lpr) {
     V acc = S::zero();
+    V xd = S::zero();          // MAXR: this source's message as the forward saw it
+    if constexpr (MAXR) {
+      if (end > beg) {
+        xd = reinterpret_cast<const V*>(mi.h + sr * mi.h_stride)[c];
+        if constexpr (DROP) xd = drop_piece<VEC>(xd, (uint32_t)sr, c, d, step);
+      }
+    }
     // kBwdBatch edges' loads in flight together (destination ids, then their rows and degrees), added in ascending
     // edge order as a plain loop would: a 30-edge row costs 8 x 2 memory round trips, not 30 x 2
     for (int32_t t = beg; t < end; t += kBwdBatch) {
@@ -574,35 +640,32 @@ __global__ __launch_bounds__(256) void k_spmm_bwd_gather(const int32_t* __restri
 #pragma unroll
       for (int u = 0; u < kBwdBatch; ++u) v[u] = t + u < end ? tdst[t + u] : -1;
       V g[kBwdBatch];
+      V ov[MAXR ? kBwdBatch : 1];
       float dg[kBwdBatch];
 #pragma unroll
       for (int u = 0; u < kBwdBatch; ++u) {
         g[u] = v[u] >= 0 ? reinterpret_cast<const V*>(go + (int64_t)v[u] * go_stride)[c] : S::zero();
-        dg[u] = (reduce == PG_REDUCE_MEAN && v[u] >= 0) ? (float)(indptr[v[u] + 1] - indptr[v[u]]) : 1.f;
+        if constexpr (MAXR) {
+          ov[u] = v[u] >= 0 ? reinterpret_cast<const V*>(mi.out + (int64_t)v[u] * mi.out_stride)[c] : S::zero();
+          dg[u] = 1.f;
+        } else {
+          dg[u] = (reduce == PG_REDUCE_MEAN && v[u] >= 0) ? (float)(indptr[v[u] + 1] - indptr[v[u]]) : 1.f;
+        }
       }
 #pragma unroll
       for (int u = 0; u < kBwdBatch; ++u) {
         if (v[u] >= 0) {
-          if (reduce == PG_REDUCE_MEAN) S::div(g[u], dg[u]);
-          S::add(acc, g[u]);
+          if constexpr (MAXR) {
+            S::add(acc, S::where_eq(xd, ov[u], g[u]));
+          } else {
+            if (reduce == PG_REDUCE_MEAN) S::div(g[u], dg[u]);
+            S::add(acc, g[u]);
+          }
         }
       }
     }
     if constexpr (DROP) {
-      if (end > beg) {
-        if constexpr (VEC == 4) {
-          uint32_t o[4];
-          Philox::gen((uint32_t)sr, (uint32_t)(((c >> 7) << 6) | (c & 63)), d.tag, step, d.k0, d.k1, o);
-          acc = drop_apply(acc, o, (c >> 6) & 1, d.thr, d.scale);
-        } else {
-          const int piece = c >> 2, j = c & 3, half = (piece >> 6) & 1;
-          uint32_t o[4];
-          Philox::gen((uint32_t)sr, (uint32_t)(((piece >> 7) << 6) | (piece & 63)), d.tag, step, d.k0, d.k1, o);
-          const uint32_t w = (j >> 1) ? (half ? o[3] : o[1]) : (half ? o[2] : o[0]);
-          const uint32_t u = (j & 1) ? (w >> 16) : (w & 0xffffu);
-          acc = u >= d.thr ? acc * d.scale : 0.f;
-        }
-      }
+      if (end > beg) acc = drop_piece<VEC>(acc, (uint32_t)sr, c, d, step);
     }
     grow[c] = acc;
     last = acc;
@@ -628,12 +691,13 @@ __global__ __launch_bounds__(256) void k_spmm_bwd_gather(const int32_t* __restri
 // strided edges — independent loads, 16 in flight per lane — and the partial sums are combined through LDS in lane
 // order (deterministic). Runs as EXTRA BLOCKS of the k_spmm_bwd_gather launch (T = 256): two hub rows used to cost a
 // launch of their own, 13-14 us of dependent latencies on the replayed step's critical path.
-template <int VEC, bool DROP, int T>
+template <int VEC, bool DROP, int T, bool MAXR>
 __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, int32_t heavy_cap,
                                            const int32_t* __restrict__ tptr, const int32_t* __restrict__ tdst,
                                            const int32_t* __restrict__ indptr, const float* __restrict__ go,
                                            int32_t go_stride, int32_t dim, int reduce, float* __restrict__ gh,
-                                           int32_t gh_stride, int lpr_log2, DropArgs d, int first, int stride, DzOut z) {
+                                           int32_t gh_stride, int lpr_log2, DropArgs d, int first, int stride, DzOut z,
+                                           MaxIn mi) {
   constexpr int kHeavyThreads = T;
 
   using S = SV<VEC>;
@@ -657,13 +721,20 @@ __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, in
     for (int c0 = 0; c0 < pieces; c0 += lpr) {
       const int c = c0 + gl;
       V acc = S::zero();
+      V xd = S::zero();          // MAXR: this source's message as the forward saw it
+      if constexpr (MAXR) {
+        if (c < pieces) {
+          xd = reinterpret_cast<const V*>(mi.h + (int64_t)sr * mi.h_stride)[c];
+          if constexpr (DROP) xd = drop_piece<VEC>(xd, (uint32_t)sr, c, d, step);
+        }
+      }
       for (int32_t base = beg; base < end; base += kStage) {
         const int n = end - base < kStage ? end - base : kStage;
         __syncthreads();
         for (int t = threadIdx.x; t < n; t += kHeavyThreads) {     // independent per t: all in flight together
           const int32_t v = tdst[base + t];
           s_v[t] = v;
-          s_w[t] = reduce == PG_REDUCE_MEAN ? (float)(indptr[v + 1] - indptr[v]) : 1.f;
+          s_w[t] = (!MAXR && reduce == PG_REDUCE_MEAN) ? (float)(indptr[v + 1] - indptr[v]) : 1.f;
         }
         __syncthreads();
         if (c < pieces) {
@@ -671,17 +742,23 @@ __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, in
           // few hundred edges cost one or two memory round trips per lane instead of one per four edges
           for (int k0 = el; k0 < n; k0 += 16 * n_el) {
             V g[16];
+            V ov[MAXR ? 16 : 1];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
               const int k = k0 + u * n_el;
               g[u] = k < n ? reinterpret_cast<const V*>(go + (int64_t)s_v[k] * go_stride)[c] : S::zero();
+              if constexpr (MAXR) ov[u] = k < n ? reinterpret_cast<const V*>(mi.out + (int64_t)s_v[k] * mi.out_stride)[c] : S::zero();
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
               const int k = k0 + u * n_el;
               if (k < n) {
-                if (reduce == PG_REDUCE_MEAN) S::div(g[u], s_w[k]);
-                S::add(acc, g[u]);
+                if constexpr (MAXR) {
+                  S::add(acc, S::where_eq(xd, ov[u], g[u]));
+                } else {
+                  if (reduce == PG_REDUCE_MEAN) S::div(g[u], s_w[k]);
+                  S::add(acc, g[u]);
+                }
               }
             }
           }
@@ -692,20 +769,7 @@ __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, in
       if (el == 0 && c < pieces) {
         V tot = S::zero();
         for (int k = 0; k < n_el; ++k) S::add(tot, red[(k << lpr_log2) + gl]);
-        if constexpr (DROP) {
-          if constexpr (VEC == 4) {
-            uint32_t o[4];
-            Philox::gen((uint32_t)sr, (uint32_t)(((c >> 7) << 6) | (c & 63)), d.tag, step, d.k0, d.k1, o);
-            tot = drop_apply(tot, o, (c >> 6) & 1, d.thr, d.scale);
-          } else {
-            const int piece = c >> 2, j = c & 3, half = (piece >> 6) & 1;
-            uint32_t o[4];
-            Philox::gen((uint32_t)sr, (uint32_t)(((piece >> 7) << 6) | (piece & 63)), d.tag, step, d.k0, d.k1, o);
-            const uint32_t w = (j >> 1) ? (half ? o[3] : o[1]) : (half ? o[2] : o[0]);
-            const uint32_t u = (j & 1) ? (w >> 16) : (w & 0xffffu);
-            tot = u >= d.thr ? tot * d.scale : 0.f;
-          }
-        }
+        if constexpr (DROP) tot = drop_piece<VEC>(tot, (uint32_t)sr, c, d, step);
         reinterpret_cast<V*>(gh + (int64_t)sr * gh_stride)[c] = tot;
         if constexpr (VEC == 4) {
           if (z.dz) zrow[gl] = tot;
@@ -722,6 +786,39 @@ __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, in
           }
         }
       }
+    }
+  }
+}
+
+// scatter form of the max reducer's backward: lane group per destination row, one fp32 atomic per (edge, column) that
+// attained the maximum
+template <bool DROP>
+__global__ __launch_bounds__(256) void k_spmm_bwd_max(const int32_t* __restrict__ indptr, const int32_t* __restrict__ src,
+                                                      const float* __restrict__ go, int32_t go_stride, int64_t n_dst,
+                                                      int32_t dim, MaxIn mi, float* __restrict__ gh, int32_t gh_stride,
+                                                      int lpr_log2, DropArgs d) {
+  const int lpr = 1 << lpr_log2;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int gl = lane & (lpr - 1);
+  const int rows_per_wave = kWave >> lpr_log2;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+  const int64_t v = wave * rows_per_wave + (lane >> lpr_log2);
+  if (v >= n_dst) return;
+  const int32_t beg = indptr[v], end = indptr[v + 1];
+  if (end == beg) return;
+  const uint32_t step = (DROP && d.step) ? (uint32_t)*d.step : 0u;
+  for (int c = gl; c < dim; c += lpr) {
+    const float g = go[v * go_stride + c];
+    const float o = mi.out[v * mi.out_stride + c];
+    for (int32_t e = beg; e < end; ++e) {
+      const int32_t sr = src[e];
+      float x = mi.h[(int64_t)sr * mi.h_stride + c];
+      float gg = g;
+      if constexpr (DROP) {
+        x = drop_piece<1>(x, (uint32_t)sr, c, d, step);
+        gg = drop_piece<1>(g, (uint32_t)sr, c, d, step);
+      }
+      if (x == o && gg != 0.f) unsafeAtomicAdd(gh + (int64_t)sr * gh_stride + c, gg);
     }
   }
 }
@@ -754,7 +851,7 @@ extern "C" {
 int pg_spmm_fwd(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int64_t n_dst,
                 int32_t dim, int reduce, float* out, int32_t out_stride, pg_stream_t stream) {
   if (n_dst < 0 || dim <= 0 || h_stride < dim || out_stride < dim) return PG_ERR_INVALID;
-  if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return PG_ERR_INVALID;
+  if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM && reduce != PG_REDUCE_MAX) return PG_ERR_INVALID;
   if (n_dst == 0) return PG_OK;
   if (!indptr || !out) return PG_ERR_INVALID;  // src / h may be NULL only for an edgeless block
   hipStream_t st = as_stream(stream);
@@ -765,12 +862,13 @@ int pg_spmm_fwd(const int32_t* indptr, const int32_t* src, const float* h, int32
   int l2 = log2_ceil_pow2(pieces < 64 ? pieces : 64);
   const int rows_per_block = 4 * (64 >> l2);
   const unsigned grid = (unsigned)ceil_div<int64_t>(n_dst, rows_per_block);
-  if (vec == 4)
-    hipLaunchKernelGGL(k_spmm_fwd<4>, dim3(grid), dim3(256), 0, st, indptr, src, h, h_stride, n_dst, dim, reduce, out, out_stride, l2);
-  else if (vec == 2)
-    hipLaunchKernelGGL(k_spmm_fwd<2>, dim3(grid), dim3(256), 0, st, indptr, src, h, h_stride, n_dst, dim, reduce, out, out_stride, l2);
-  else
-    hipLaunchKernelGGL(k_spmm_fwd<1>, dim3(grid), dim3(256), 0, st, indptr, src, h, h_stride, n_dst, dim, reduce, out, out_stride, l2);
+#define PG_FWD(VEC, MAXR) \
+  hipLaunchKernelGGL((k_spmm_fwd<VEC, MAXR>), dim3(grid), dim3(256), 0, st, indptr, src, h, h_stride, n_dst, dim, reduce, out, out_stride, l2)
+  const bool mx = reduce == PG_REDUCE_MAX;
+  if (vec == 4) { if (mx) PG_FWD(4, true); else PG_FWD(4, false); }
+  else if (vec == 2) { if (mx) PG_FWD(2, true); else PG_FWD(2, false); }
+  else { if (mx) PG_FWD(1, true); else PG_FWD(1, false); }
+#undef PG_FWD
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
@@ -782,15 +880,20 @@ int pg_spmm_fwd_drop(const int32_t* indptr, const int32_t* src, const float* h, 
   if (drop && drop->threshold > 65535u) return PG_ERR_INVALID;
   if (!drop_args(drop, &d)) return pg_spmm_fwd(indptr, src, h, h_stride, n_dst, dim, reduce, out, out_stride, stream);
   if (n_dst < 0 || dim <= 0 || h_stride < dim || out_stride < dim) return PG_ERR_INVALID;
-  if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return PG_ERR_INVALID;
+  if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM && reduce != PG_REDUCE_MAX) return PG_ERR_INVALID;
   if (!(dim % 4 == 0 && h_stride % 4 == 0 && out_stride % 4 == 0 && al(h, 16) && al(out, 16))) return PG_ERR_UNSUPPORTED;
   if (n_dst == 0) return PG_OK;
   if (!indptr || !out) return PG_ERR_INVALID;
   const int pieces = dim / 4;
   int l2 = log2_ceil_pow2(pieces < 64 ? pieces : 64);
   const int rows_per_block = 4 * (64 >> l2);
-  hipLaunchKernelGGL(k_spmm_fwd_drop, dim3((unsigned)ceil_div<int64_t>(n_dst, rows_per_block)), dim3(256), 0,
-                     as_stream(stream), indptr, src, h, h_stride, n_dst, dim, reduce, out, out_stride, l2, d);
+  const dim3 grid((unsigned)ceil_div<int64_t>(n_dst, rows_per_block));
+  if (reduce == PG_REDUCE_MAX)
+    hipLaunchKernelGGL(k_spmm_fwd_drop<true>, grid, dim3(256), 0, as_stream(stream), indptr, src, h, h_stride, n_dst, dim,
+                       reduce, out, out_stride, l2, d);
+  else
+    hipLaunchKernelGGL(k_spmm_fwd_drop<false>, grid, dim3(256), 0, as_stream(stream), indptr, src, h, h_stride, n_dst, dim,
+                       reduce, out, out_stride, l2, d);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
@@ -799,7 +902,7 @@ int pg_spmm_fwd_rows(const int32_t* indptr, const int32_t* src, const pg_row_sou
                      int32_t dim, int reduce, float* out, int32_t out_stride, const pg_dropout_t* drop,
                      uint64_t* prof, int32_t prof_ring, pg_stream_t stream) {
   if (!rows || n_dst < 0 || dim <= 0 || out_stride < dim) return PG_ERR_INVALID;
-  if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return PG_ERR_INVALID;
+  if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM && reduce != PG_REDUCE_MAX) return PG_ERR_INVALID;
   if (drop && drop->threshold > 65535u) return PG_ERR_INVALID;
   if (prof && prof_ring <= 0) return PG_ERR_INVALID;
   // one wave per destination, 16-byte pieces: the wide feature rows this path exists for. dim % 4 != 0 (602): the
@@ -815,20 +918,25 @@ int pg_spmm_fwd_rows(const int32_t* indptr, const int32_t* src, const pg_row_sou
   if (!has_drop && drop) d.step = drop->step;     // the profiling ring is indexed by the caller's step counter
   const unsigned grid = (unsigned)ceil_div<int64_t>(n_dst, 4);
   unsigned long long* pr = reinterpret_cast<unsigned long long*>(prof);
-#define PG_FWD_ROWS(DROP, TAIL)                                                                                         \
-  hipLaunchKernelGGL((k_spmm_fwd_rows<DROP, TAIL>), dim3(grid), dim3(256), 0, as_stream(stream), indptr, src, rows->slots, \
-                     rows->edge_slots, rows->cache, rows->cache_stride, rows->staged, rows->staged_stride, n_dst, dim,     \
-                     reduce, out, out_stride, d, pr, (int)prof_ring)
-#define PG_FWD_ROWS_W(DROP, TAIL, M)                                                                                    \
-  hipLaunchKernelGGL((k_spmm_fwd_rows_w<DROP, TAIL, M>), dim3(grid), dim3(256), 0, as_stream(stream), indptr, src,      \
+#define PG_FWD_ROWS(DROP, TAIL, MAXR)                                                                                   \
+  hipLaunchKernelGGL((k_spmm_fwd_rows<DROP, TAIL, MAXR>), dim3(grid), dim3(256), 0, as_stream(stream), indptr, src,       \
+                     rows->slots, rows->edge_slots, rows->cache, rows->cache_stride, rows->staged, rows->staged_stride,   \
+                     n_dst, dim, reduce, out, out_stride, d, pr, (int)prof_ring)
+#define PG_FWD_ROWS_W(DROP, TAIL, M, MAXR)                                                                              \
+  hipLaunchKernelGGL((k_spmm_fwd_rows_w<DROP, TAIL, M, MAXR>), dim3(grid), dim3(256), 0, as_stream(stream), indptr, src, \
                      rows->slots, rows->edge_slots, rows->cache, rows->cache_stride, rows->staged, rows->staged_stride, \
                      n_dst, dim, reduce, out, out_stride, d, pr, (int)prof_ring)
+#define PG_FWD_ROWS_R(DROP, TAIL, MAXR)                               \
+  do {                                                                \
+    if (generic || dim4 > 1024) PG_FWD_ROWS(DROP, TAIL, MAXR);        \
+    else if (dim4 <= 512) PG_FWD_ROWS_W(DROP, TAIL, 2, MAXR);         \
+    else if (dim4 <= 768) PG_FWD_ROWS_W(DROP, TAIL, 3, MAXR);         \
+    else PG_FWD_ROWS_W(DROP, TAIL, 4, MAXR);                          \
+  } while (0)
 #define PG_FWD_ROWS_ANY(DROP, TAIL)                                   \
   do {                                                                \
-    if (generic || dim4 > 1024) PG_FWD_ROWS(DROP, TAIL);              \
-    else if (dim4 <= 512) PG_FWD_ROWS_W(DROP, TAIL, 2);               \
-    else if (dim4 <= 768) PG_FWD_ROWS_W(DROP, TAIL, 3);               \
-    else PG_FWD_ROWS_W(DROP, TAIL, 4);                                \
+    if (reduce == PG_REDUCE_MAX) PG_FWD_ROWS_R(DROP, TAIL, true);     \
+    else PG_FWD_ROWS_R(DROP, TAIL, false);                            \
   } while (0)
   // rows of up to 1024 floats take the wave-uniform kernel (PG_FWD_ROWS_GENERIC=1: the generic one, for A/B runs)
   static const bool generic = getenv("PG_FWD_ROWS_GENERIC") != nullptr;
@@ -840,6 +948,7 @@ int pg_spmm_fwd_rows(const int32_t* indptr, const int32_t* src, const pg_row_sou
     else PG_FWD_ROWS_ANY(false, true);
   }
 #undef PG_FWD_ROWS_ANY
+#undef PG_FWD_ROWS_R
 #undef PG_FWD_ROWS_W
 #undef PG_FWD_ROWS
   PG_LAUNCH_CHECK();
@@ -884,19 +993,26 @@ int pg_spmm_bwd_gather(const int32_t* tptr, const int32_t* tdst, const int32_t* 
                                heavy_cap, drop, nullptr, 0, nullptr, stream);
 }
 
-int pg_spmm_bwd_gather_dz(const int32_t* tptr, const int32_t* tdst, const int32_t* indptr, const float* grad_out,
-                          int32_t go_stride, int64_t n_src, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,
-                          const int32_t* heavy, int32_t heavy_cap, const pg_dropout_t* drop, const float* act_out,
-                          int32_t act_stride, float* dz, pg_stream_t stream) {
+static int bwd_gather_impl(const int32_t* tptr, const int32_t* tdst, const int32_t* indptr, const float* grad_out,
+                           int32_t go_stride, int64_t n_src, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,
+                           const int32_t* heavy, int32_t heavy_cap, const pg_dropout_t* drop, const float* act_out,
+                           int32_t act_stride, float* dz, const MaxIn* mx, pg_stream_t stream) {
   if (n_src < 0 || dim <= 0 || go_stride < dim || gh_stride < dim) return PG_ERR_INVALID;
-  if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return PG_ERR_INVALID;
+  if (!mx && reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return PG_ERR_INVALID;
   if (drop && drop->threshold > 65535u) return PG_ERR_INVALID;
   if (n_src == 0) return PG_OK;
-  if (!tptr || !indptr || !grad_h) return PG_ERR_INVALID;  // tdst / grad_out may be NULL only for an edgeless block
+  if (!tptr || (!mx && !indptr) || !grad_h) return PG_ERR_INVALID;  // tdst / grad_out may be NULL only for an edgeless block
   DropArgs d{};
   const bool dr = drop_args(drop, &d);
   if (dr && dim % 4) return PG_ERR_INVALID;
-  const bool v4 = dim % 4 == 0 && go_stride % 4 == 0 && gh_stride % 4 == 0 && al(grad_out, 16) && al(grad_h, 16);
+  bool v4 = dim % 4 == 0 && go_stride % 4 == 0 && gh_stride % 4 == 0 && al(grad_out, 16) && al(grad_h, 16);
+  MaxIn mi{};
+  if (mx) {
+    mi = *mx;
+    if (!mi.h || !mi.out || mi.h_stride < dim || mi.out_stride < dim) return PG_ERR_INVALID;
+    v4 = v4 && mi.h_stride % 4 == 0 && mi.out_stride % 4 == 0 && al(mi.h, 16) && al(mi.out, 16);
+    if (dr && !v4) return PG_ERR_UNSUPPORTED;     // the scalar layout's dropout indexing needs nothing else, but keep one rule
+  }
   const int pieces = v4 ? dim / 4 : dim;
   int l2 = log2_ceil_pow2(pieces < 64 ? pieces : 64);
   const int rows_per_block = 4 * (64 >> l2);
@@ -913,14 +1029,61 @@ int pg_spmm_bwd_gather_dz(const int32_t* tptr, const int32_t* tdst, const int32_
   const int hub_blocks = hubs ? (heavy_cap < 16 ? heavy_cap : 16) : 0;
   const dim3 grid((unsigned)(row_blocks + hub_blocks));
   hipStream_t st = as_stream(stream);
-#define PG_BWD_GATHER(VEC, DROP)                                                                                 \
-  hipLaunchKernelGGL((k_spmm_bwd_gather<VEC, DROP>), grid, dim3(256), 0, st, tptr, tdst, indptr, grad_out, go_stride, \
-                     n_src, dim, reduce, grad_h, gh_stride, l2, hubs ? 1 : 0, d, heavy, heavy_cap, (int32_t)row_blocks, z)
-  if (v4 && dr) PG_BWD_GATHER(4, true);
-  else if (v4) PG_BWD_GATHER(4, false);
-  else if (dr) PG_BWD_GATHER(1, true);
-  else PG_BWD_GATHER(1, false);
+#define PG_BWD_GATHER(VEC, DROP, MAXR)                                                                                 \
+  hipLaunchKernelGGL((k_spmm_bwd_gather<VEC, DROP, MAXR>), grid, dim3(256), 0, st, tptr, tdst, indptr, grad_out, go_stride, \
+                     n_src, dim, reduce, grad_h, gh_stride, l2, hubs ? 1 : 0, d, heavy, heavy_cap, (int32_t)row_blocks, z, mi)
+  if (mx) {
+    if (v4 && dr) PG_BWD_GATHER(4, true, true);
+    else if (v4) PG_BWD_GATHER(4, false, true);
+    else PG_BWD_GATHER(1, false, true);
+  } else {
+    if (v4 && dr) PG_BWD_GATHER(4, true, false);
+    else if (v4) PG_BWD_GATHER(4, false, false);
+    else if (dr) PG_BWD_GATHER(1, true, false);
+    else PG_BWD_GATHER(1, false, false);
+  }
 #undef PG_BWD_GATHER
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+int pg_spmm_bwd_gather_dz(const int32_t* tptr, const int32_t* tdst, const int32_t* indptr, const float* grad_out,
+                          int32_t go_stride, int64_t n_src, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,
+                          const int32_t* heavy, int32_t heavy_cap, const pg_dropout_t* drop, const float* act_out,
+                          int32_t act_stride, float* dz, pg_stream_t stream) {
+  return bwd_gather_impl(tptr, tdst, indptr, grad_out, go_stride, n_src, dim, reduce, grad_h, gh_stride, heavy, heavy_cap,
+                         drop, act_out, act_stride, dz, nullptr, stream);
+}
+
+int pg_spmm_bwd_gather_max(const int32_t* tptr, const int32_t* tdst, const float* grad_out, int32_t go_stride,
+                           int64_t n_src, int32_t dim, const float* h, int32_t h_stride, const float* out,
+                           int32_t out_stride, float* grad_h, int32_t gh_stride, const int32_t* heavy,
+                           int32_t heavy_cap, const pg_dropout_t* drop, float* dz, pg_stream_t stream) {
+  const MaxIn mi{h, out, h_stride, out_stride};
+  return bwd_gather_impl(tptr, tdst, nullptr, grad_out, go_stride, n_src, dim, PG_REDUCE_MAX, grad_h, gh_stride, heavy,
+                         heavy_cap, drop, h, h_stride, dz, &mi, stream);
+}
+
+int pg_spmm_bwd_max(const int32_t* indptr, const int32_t* src, const float* grad_out, int32_t go_stride, int64_t n_dst,
+                    int32_t dim, const float* h, int32_t h_stride, const float* out, int32_t out_stride, float* grad_h,
+                    int32_t gh_stride, const pg_dropout_t* drop, pg_stream_t stream) {
+  if (n_dst < 0 || dim <= 0 || go_stride < dim || gh_stride < dim || h_stride < dim || out_stride < dim) return PG_ERR_INVALID;
+  if (drop && drop->threshold > 65535u) return PG_ERR_INVALID;
+  if (n_dst == 0) return PG_OK;
+  if (!indptr || !grad_out || !out) return PG_ERR_INVALID;  // src / h / grad_h may be NULL only for an edgeless block
+  DropArgs d{};
+  const bool dr = drop_args(drop, &d);
+  if (dr && dim % 4) return PG_ERR_INVALID;
+  const MaxIn mi{h, out, h_stride, out_stride};
+  int l2 = log2_ceil_pow2(dim < 64 ? dim : 64);
+  const int rows_per_block = 4 * (64 >> l2);
+  const dim3 grid((unsigned)ceil_div<int64_t>(n_dst, rows_per_block));
+  if (dr)
+    hipLaunchKernelGGL(k_spmm_bwd_max<true>, grid, dim3(256), 0, as_stream(stream), indptr, src, grad_out, go_stride, n_dst,
+                       dim, mi, grad_h, gh_stride, l2, d);
+  else
+    hipLaunchKernelGGL(k_spmm_bwd_max<false>, grid, dim3(256), 0, as_stream(stream), indptr, src, grad_out, go_stride, n_dst,
+                       dim, mi, grad_h, gh_stride, l2, d);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }

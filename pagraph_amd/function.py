@@ -1,5 +1,5 @@
-"""The three DGL builtins the reference's models pass to block_compute
-(`import dgl.function as fn`: gcn_nssc.py:72-73,140-141; graphsage_nssc.py:99-106)."""
+"""The DGL builtins the reference's models pass to block_compute
+(`import dgl.function as fn`: gcn_nssc.py:72-73,140-141; graphsage_nssc.py:99-110)."""
 
 
 class copy_src:
@@ -20,3 +20,7 @@ class mean(_Reduce):
 
 class sum(_Reduce):  # noqa: A001  (name mirrors dgl.function.sum)
     op = "sum"
+
+
+class max(_Reduce):  # noqa: A001  (name mirrors dgl.function.max; graphsage_nssc.py:108, the 'pool' aggregator)
+    op = "max"

@@ -1,8 +1,7 @@
-"""Sampled GraphSAGE (mean / gcn aggregators) — constructor, parameter names
+"""Sampled GraphSAGE (mean / gcn / pool aggregators) — constructor, parameter names
 (`layers.N.fc_self`, `layers.N.fc_neigh`) and dataflow of
-PaGraph/model/graphsage_nssc.py:6-134 on pagraph_amd's NodeFlow.  The 'pool'
-(max) and 'lstm' aggregators are not on the benchmarked path (pa_gs.py:62 passes
-'mean') and raise."""
+PaGraph/model/graphsage_nssc.py:6-134 on pagraph_amd's NodeFlow.  'pool' (the
+constructor's default, :38) is DGL's fn.max reducer (:106-110) = PG_REDUCE_MAX."""
 import torch
 import torch.nn as nn
 
@@ -39,7 +38,7 @@ class NodeUpdate(nn.Module):
         return {'activation': h}
 
 
-_REDUCERS = {'mean': fn.mean, 'gcn': fn.sum}
+_REDUCERS = {'mean': fn.mean, 'gcn': fn.sum, 'pool': fn.max}
 
 
 class GraphSageSampling(FusedDropoutMixin, nn.Module):
@@ -54,9 +53,6 @@ class GraphSageSampling(FusedDropoutMixin, nn.Module):
     def __init__(self, in_feats, n_hidden, n_classes, n_layers, activation=None, dropout=0.,
                  aggregator_type='pool', preprocess=False):
         super().__init__()
-        if aggregator_type not in _REDUCERS:
-            raise NotImplementedError(
-                f"aggregator '{aggregator_type}': only 'mean' and 'gcn' are on the MI355X hot path")
         self.preprocess = preprocess
         self.n_layers = n_layers
         self.dropout = nn.Dropout(dropout)
@@ -64,14 +60,23 @@ class GraphSageSampling(FusedDropoutMixin, nn.Module):
         self.activation = activation
         self.aggregator_type = aggregator_type
         self.layers = nn.ModuleList()
-        self.reducer = nn.ModuleList()  # kept for state_dict compatibility (lstm only in the reference)
+        # 'lstm' (graphsage_nssc.py:58-71): the reference builds one nn.LSTM per block — same modules here, so that a
+        # state_dict moves either way — but its forward cannot run (see forward)
+        lstm = aggregator_type == 'lstm'
+        self.reducer = nn.ModuleList()
         if preprocess:
             self.fc_self = nn.Linear(in_feats, n_hidden)
             self.fc_neigh = nn.Linear(in_feats, n_hidden)
         else:
+            if lstm:
+                self.reducer.append(nn.LSTM(in_feats, in_feats, batch_first=True))
             self.layers.append(NodeUpdate(in_feats, n_hidden, activation, concat=(n_layers == 1)))
         for i in range(1, n_layers):
+            if lstm:
+                self.reducer.append(nn.LSTM(n_hidden, n_hidden, batch_first=True))
             self.layers.append(NodeUpdate(n_hidden, n_hidden, activation, concat=(i == n_layers - 1)))
+        if lstm:
+            self.reducer.append(nn.LSTM(2 * n_hidden, 2 * n_hidden, batch_first=True))
         self.layers.append(NodeUpdate(2 * n_hidden, n_classes))
 
     def required_inputs(self, num_layers):
@@ -99,6 +104,12 @@ class GraphSageSampling(FusedDropoutMixin, nn.Module):
             for i in range(L):
                 d = nf.layers[i].data
                 d['h'] = d.pop('features')
+        if self.aggregator_type == 'lstm':
+            # graphsage_nssc.py:112-121 hands block_compute a reduce UDF declared `_reducer(self, nodes)`; DGL calls reduce
+            # UDFs with the node batch alone, so the reference's own forward stops here with this very TypeError
+            raise TypeError("_reducer() missing 1 required positional argument: 'nodes'")
+        if self.aggregator_type not in _REDUCERS:
+            raise KeyError('Aggregator type {} not recognized.'.format(self.aggregator_type))     # :126-127
         red = _REDUCERS[self.aggregator_type]
         # graphsage_nssc.py:92-131: model layer `lid` is applied to every block i >= lid, so the
         # self term of a destination always has the same depth as its neighbour term.

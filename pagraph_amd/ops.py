@@ -6,7 +6,7 @@ import torch
 
 from . import _lib as L
 
-_REDUCE = {"mean": L.PG_REDUCE_MEAN, "sum": L.PG_REDUCE_SUM}
+_REDUCE = {"mean": L.PG_REDUCE_MEAN, "sum": L.PG_REDUCE_SUM, "max": L.PG_REDUCE_MAX}
 
 
 class DropoutSpec:
@@ -107,7 +107,14 @@ class _BlockAggregate(torch.autograd.Function):
                                              _REDUCE[reduce], L.ptr(out), out.stride(0), ctypes.byref(d),
                                              L.stream_ptr()), "pg_spmm_fwd_drop")
         ctx.dz_n = 0
-        if tptr is not None and tptr.numel() == h.size(0) + 1:
+        ctx.n_src, ctx.reduce, ctx.drop = h.size(0), reduce, drop
+        use_t = tptr is not None and tptr.numel() == h.size(0) + 1
+        if reduce == "max":      # its backward compares every message with the maximum: keeps input and output
+            ctx.use_t = use_t
+            ctx.dz_n = dz_n if use_t and _dz_fusable(h, dz_n) else 0
+            ctx.save_for_backward(indptr, src, h, out, *((tptr, tdst, heavy) if use_t else ()))
+            return out
+        if use_t:
             if _dz_fusable(h, dz_n):
                 ctx.dz_n = dz_n
                 ctx.save_for_backward(indptr, src, tptr, tdst, heavy, h)
@@ -115,7 +122,6 @@ class _BlockAggregate(torch.autograd.Function):
                 ctx.save_for_backward(indptr, src, tptr, tdst, heavy)
         else:
             ctx.save_for_backward(indptr, src)
-        ctx.n_src, ctx.reduce, ctx.drop = h.size(0), reduce, drop
         return out
 
     @staticmethod
@@ -124,6 +130,8 @@ class _BlockAggregate(torch.autograd.Function):
             return (None,) * 10
         lib = L.load()
         go = grad_out.contiguous()
+        if ctx.reduce == "max":
+            return (None, None, _BlockAggregate._backward_max(ctx, lib, go)) + (None,) * 7
         if len(ctx.saved_tensors) >= 5:          # gather form over the block's source-major copy
             indptr, src, tptr, tdst, heavy = ctx.saved_tensors[:5]
             gh = torch.empty((ctx.n_src, go.size(1)), dtype=torch.float32, device=go.device)
@@ -154,8 +162,33 @@ class _BlockAggregate(torch.autograd.Function):
         return (None, None, gh) + (None,) * 7
 
 
+    @staticmethod
+    def _backward_max(ctx, lib, go):
+        """pg_spmm_bwd_gather_max over the source-major copy when the sampler built one, else the scatter form"""
+        indptr, src, h, out = ctx.saved_tensors[:4]
+        d = ctx.drop.struct() if ctx.drop is not None else None
+        dp = ctypes.byref(d) if d is not None else None
+        with torch.cuda.device(go.device):
+            if ctx.use_t:
+                tptr, tdst, heavy = ctx.saved_tensors[4:7]
+                gh = torch.empty((ctx.n_src, go.size(1)), dtype=torch.float32, device=go.device)
+                dz = torch.empty((ctx.n_src, ctx.dz_n), dtype=torch.float32, device=go.device) if ctx.dz_n else None
+                L.check(lib.pg_spmm_bwd_gather_max(L.ptr(tptr), L.ptr(tdst), L.ptr(go), go.stride(0), ctx.n_src, go.size(1),
+                                                   L.ptr(h), h.stride(0), L.ptr(out), out.stride(0), L.ptr(gh), gh.stride(0),
+                                                   L.ptr(heavy), heavy.numel() - 1 if heavy is not None else 0, dp,
+                                                   L.ptr(dz), L.stream_ptr()), "pg_spmm_bwd_gather_max")
+                if dz is not None:
+                    _stash_dz(gh, dz)
+                return gh
+            gh = torch.zeros((ctx.n_src, go.size(1)), dtype=torch.float32, device=go.device)
+            L.check(lib.pg_spmm_bwd_max(L.ptr(indptr), L.ptr(src), L.ptr(go), go.stride(0), go.size(0), go.size(1),
+                                        L.ptr(h), h.stride(0), L.ptr(out), out.stride(0), L.ptr(gh), gh.stride(0), dp,
+                                        L.stream_ptr()), "pg_spmm_bwd_max")
+        return gh
+
+
 def block_aggregate(indptr, src, h, n_dst, reduce="mean", dropout=None, transpose=None):
-    """out[v] = reduce_{e in block, dst(e)=v} dropout(h)[src(e)]  (DGL copy_src + mean|sum; `dropout` is a
+    """out[v] = reduce_{e in block, dst(e)=v} dropout(h)[src(e)]  (DGL copy_src + mean|sum|max; `dropout` is a
     DropoutSpec or None; `transpose` = (tptr, tdst[, heavy]), the block's source-major copy (and hub list) from
     the sampler, lets the backward run as a gather instead of fp32 atomics)"""
     if isinstance(h, RowSource):

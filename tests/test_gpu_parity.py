@@ -978,6 +978,69 @@ def test_spmm_backward_gather_form_vs_oracle(dev, hiplib, oracle, n_dst, n_src, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_dst,n_src,deg,dim,p", [(6000, 17000, 2, 64, 0.0), (6000, 17000, 2, 64, 0.5), (500, 900, 3, 600, 0.25),
+                                                   (300, 200, 5, 33, 0.0), (300, 200, 5, 602, 0.0), (50, 60, 0, 32, 0.5),
+                                                   (6000, 9000, -2, 64, 0.5), (3000, 500, -3, 600, 0.0), (2000, 300, -2, 33, 0.0)])
+def test_spmm_max_reducer_vs_oracle(dev, hiplib, oracle, n_dst, n_src, deg, dim, p):
+    """a-10's third reducer (graphsage_nssc.py:106-110, fn.max = the 'pool' aggregator): PG_REDUCE_MAX forward is BIT
+    exact against the oracle (zeros for a destination without in-edges); the backward — every in-edge whose message
+    equals the maximum receives the destination's gradient, DGL's `val == accum` — in scatter form (pg_spmm_bwd_max)
+    and in gather form over the source-major copy (pg_spmm_bwd_gather_max, hubs included, bit-identical between runs),
+    with and without the folded dropout. Values come from a small integer set, so ties are everywhere."""
+    from pagraph_amd import ops
+    rng = np.random.default_rng(n_dst + 5 * dim + int(p * 10))
+    hubs = deg < 0
+    deg = abs(deg)
+    cnt = rng.integers(0, deg + 1, n_dst) if deg else np.zeros(n_dst, np.int64)
+    indptr = np.zeros(n_dst + 1, np.int32); indptr[1:] = np.cumsum(cnt)
+    src = rng.integers(0, n_src, int(indptr[-1])).astype(np.int32)
+    if hubs:
+        pick = rng.random(src.size) < 0.15
+        src[pick] = rng.choice(np.array([7, n_src - 1, n_src // 2], np.int32), int(pick.sum()))
+    tptr, tdst = _transpose_ref(indptr, src, n_src)
+    h = rng.integers(-2, 3, (n_src, dim)).astype(np.float32)          # five values: ties in most columns
+    h[rng.random((n_src, dim)) < 0.3] += np.float32(0.25)
+    go = rng.standard_normal((n_dst, dim)).astype(np.float32)
+    step = torch.tensor([9], dtype=torch.int64, device=dev)
+    spec = ops.DropoutSpec(p, 77, 5, step) if p else None
+    x, keep, scale = h, None, 1.0
+    if p:
+        keep, scale = oracle.dropout_mask(n_src, dim, spec.threshold, 77, 5, 9)
+        x = np.where(keep, h * scale, np.float32(0)).astype(np.float32)
+    want = oracle.spmm_fwd(indptr, src, x, n_dst, "max")
+    assert np.all(want[cnt == 0] == 0)
+    want_g = oracle.spmm_bwd_max(indptr, src, go, x, want)
+    if p:
+        want_g = want_g * keep * scale
+    tip, tsr = torch.from_numpy(indptr).to(dev), torch.from_numpy(src).to(dev)
+    heavy_rows = np.nonzero(np.diff(tptr) > 32)[0]
+    heavy = np.zeros(1 + max(1, src.size // 32), np.int32)
+    heavy[0] = len(heavy_rows); heavy[1:1 + len(heavy_rows)] = heavy_rows[::-1]
+    tr = (torch.from_numpy(tptr.astype(np.int32)).to(dev), torch.from_numpy(tdst.astype(np.int32)).to(dev),
+          torch.from_numpy(heavy).to(dev))
+    if p and dim % 4:
+        with pytest.raises(Exception):
+            ops.block_aggregate(tip, tsr, torch.from_numpy(h).to(dev), n_dst, "max", dropout=spec)
+        return
+    grads = []
+    for transpose in (tr, tr, None):
+        th = torch.from_numpy(h).to(dev).requires_grad_(True)
+        out = ops.block_aggregate(tip, tsr, th, n_dst, "max", dropout=spec, transpose=transpose)
+        assert np.array_equal(out.detach().cpu().numpy(), want)
+        out.backward(torch.from_numpy(go).to(dev))
+        grads.append(th.grad.cpu().numpy())
+    assert np.array_equal(grads[0], grads[1])                                    # gather form: fixed summation order
+    for g in grads:
+        assert np.allclose(g, want_g, rtol=0, atol=TOL * max(1.0, float(scale)))
+    # raw C-ABI: the sum / mean backward entry points refuse the max reducer (its backward needs h and out)
+    from pagraph_amd import _lib as L
+    gh = torch.zeros((n_src, dim), device=dev)
+    tgo = torch.from_numpy(go).to(dev)
+    assert hiplib.pg_spmm_bwd(L.ptr(tip), L.ptr(tsr), L.ptr(tgo), dim, n_dst, dim, L.PG_REDUCE_MAX, L.ptr(gh), dim,
+                              L.stream_ptr()) == -1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,K1,K2,N,act", [(17000, 600, 600, 16, 2), (6000, 32, 32, 60, 0), (5000, 600, 64, 32, 1),
                                            (2049, 8, 600, 41, 0), (4096, 64, 64, 64, 2)])
 def test_dual_linear_vs_torch(dev, hiplib, n, K1, K2, N, act):
@@ -1449,7 +1512,7 @@ def test_bench_short_window_reports_steady_state(dev, hiplib):
 
 # ---- f-2: gather fused into the layer-0 aggregation (pg_split_rows + pg_spmm_fwd_rows) -------------------------
 @pytest.mark.parametrize("ratio,p_drop,reduce", [(0.3, 0.0, "mean"), (0.3, 0.25, "mean"), (0.0, 0.25, "sum"),
-                                                 (1.0, 0.0, "mean"), (0.6, 0.5, "sum")])
+                                                 (1.0, 0.0, "mean"), (0.6, 0.5, "sum"), (0.3, 0.0, "max"), (0.5, 0.25, "max")])
 def test_fused_gather_aggregate_vs_oracle(dev, hiplib, oracle, ratio, p_drop, reduce):
     """pg_split_rows + pg_spmm_fwd_rows through the raw C-ABI: hits read from the cache, misses from a staged block in
     miss-list order, dropout keep-mask by source position — equal BIT FOR BIT to the oracle's gather -> dropout ->
@@ -1519,7 +1582,7 @@ def _fused_gather_aggregate_case(dev, hiplib, oracle, ratio, p_drop, reduce, Fd)
     drop = L.PgDropout(thr, tag, seed, L.ptr(stepd))
     prof = torch.zeros(3 * 16, dtype=torch.int64, device=dev)
     L.check(hiplib.pg_spmm_fwd_rows(L.ptr(d_indptr), L.ptr(d_src),
-                                    ctypes.byref(rs), n_dst, Fd, 0 if reduce == "mean" else 1, L.ptr(out), Fd,
+                                    ctypes.byref(rs), n_dst, Fd, {"mean": 0, "sum": 1, "max": 2}[reduce], L.ptr(out), Fd,
                                     ctypes.byref(drop), L.ptr(prof), 16, sp))
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), want)
@@ -1602,7 +1665,8 @@ def test_config3_full_size_sampler_and_fetch(dev, hiplib, oracle):
     del g_full, indptr, indices
     torch.cuda.empty_cache()
     Vs = sub2full.numel()
-    assert Vs > 8_000_000 and subtrain.numel() == train.numel() - 1 or subtrain.numel() == train.numel()
+    # utils.py:48-50: the clamp quirk may fold one train vertex away
+    assert Vs > 8_000_000 and subtrain.numel() in (train.numel() - 1, train.numel())
     g = DeviceGraph.from_csc(sub_indptr, sub_indices, Vs)
     table = torch.empty((V, Fd), dtype=torch.float32, pin_memory=True)
     syn.fill_random_features(table, device=dev)
