@@ -32,6 +32,10 @@
 #include <thread>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
 #include <hsa/amd_hsa_signal.h>
@@ -316,6 +320,7 @@ struct pg_missq {
   bool copy_log = getenv("PG_MISSQ_COPYLOG") != nullptr;
   // direct SDMA path (see k_wait_hsa_signal)
   bool hsa_ok = false;
+  bool hsa_inited = false;        // this queue holds a reference on the HSA runtime (hsa_init / hsa_shut_down)
   hsa_agent_t gpu_agent = {}, cpu_agent = {};
   uint32_t engine = 0;            // hsa_amd_sdma_engine_id_t bit
   double engine_GBps[16] = {0};   // calibration at creation: host->device rate of every engine that reported free
@@ -338,10 +343,47 @@ static bool hsa_copy_sync(pg_missq* q, void* dst, const void* src, size_t bytes,
   return true;
 }
 
+// The wait kernels poll amd_signal_t::value of a completion signal directly (ROCr's user-mode signal layout,
+// amd_hsa_signal.h). Checked once instead of assumed: the signal must be a plain user signal and a store through the API
+// must be visible at that address — anything else (an IPC / doorbell signal kind, a different layout) disables the direct
+// path and the runtime's hipMemcpyAsync is used.
+static bool signal_layout_ok(hsa_signal_t sig) {
+  if (!sig.handle) return false;
+  const amd_signal_t* a = reinterpret_cast<const amd_signal_t*>(sig.handle);
+  if (a->kind != AMD_SIGNAL_KIND_USER) return false;
+  hsa_signal_store_screlease(sig, 0x5a17);
+  const bool ok = __atomic_load_n(&a->value, __ATOMIC_ACQUIRE) == 0x5a17 && hsa_signal_load_scacquire(sig) == 0x5a17;
+  hsa_signal_store_screlease(sig, 0);
+  return ok;
+}
+
+// Ranks of one node calibrate one at a time (an advisory lock on a file in /tmp, held for the ~10 ms per engine the timed
+// copies take): eight ranks timing 16 MiB host->device copies at the same moment share the host's memory system, and a
+// mis-read calibration is exactly what put round 2's run on a 29 GB/s engine. PG_MISSQ_CALIB_LOCK=0 turns it off.
+struct CalibLock {
+  int fd = -1;
+  CalibLock() {
+    const char* e = getenv("PG_MISSQ_CALIB_LOCK");
+    if (e && atoi(e) == 0) return;
+    fd = open("/tmp/.pagraph_sdma_calibration.lock", O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    if (fd >= 0 && flock(fd, LOCK_EX) != 0) {
+      close(fd);
+      fd = -1;
+    }
+  }
+  ~CalibLock() {
+    if (fd >= 0) {
+      (void)flock(fd, LOCK_UN);
+      close(fd);
+    }
+  }
+};
+
 static void hsa_copy_init(pg_missq* q) {
   const char* e = getenv("PG_MISSQ_HSA_COPY");
   if (e && atoi(e) == 0) return;
-  if (hsa_init() != HSA_STATUS_SUCCESS) return;   // reference counted; the HIP runtime holds its own
+  if (hsa_init() != HSA_STATUS_SUCCESS) return;   // reference counted; the HIP runtime holds its own; paired in missq_free
+  q->hsa_inited = true;
   pg_missq_slot& s0 = q->slots[0];
   hsa_amd_pointer_info_t pi_d, pi_h;
   memset(&pi_d, 0, sizeof(pi_d)); memset(&pi_h, 0, sizeof(pi_h));
@@ -358,7 +400,11 @@ static void hsa_copy_init(pg_missq* q) {
   for (auto& s : q->slots)
     for (int f = 0; f < q->n_fields; ++f)
       if (hsa_signal_create(0, 0, nullptr, &s.sig[f]) != HSA_STATUS_SUCCESS) return;
+  for (auto& s : q->slots)
+    for (int f = 0; f < q->n_fields; ++f)
+      if (!signal_layout_ok(s.sig[f])) return;
   (void)hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &q->ts_freq);
+  CalibLock calib_lock;
   uint32_t mask = 0;
   if (hsa_amd_memory_copy_engine_status(q->gpu_agent, q->cpu_agent, &mask) != HSA_STATUS_SUCCESS || mask == 0) return;
   // calibrate: the widest field's staging buffer of slot 0, up to 16 MiB, twice per engine (first = warm-up)
@@ -391,8 +437,10 @@ static void hsa_copy_init(pg_missq* q) {
   for (auto& s : q->slots)
     for (int f = 0; f < q->n_fields; ++f) hsa_signal_store_relaxed(s.sig[f], 0);
   q->hsa_ok = true;
-  if (getenv("PG_MISSQ_DEBUG")) {
-    fprintf(stderr, "[missq] direct SDMA copies on engine mask 0x%x; host->device GB/s per engine:", q->engine);
+  if (getenv("PG_MISSQ_DEBUG") || getenv("PG_MISSQ_LOG_ENGINE")) {
+    const char* rk = getenv("LOCAL_RANK");
+    fprintf(stderr, "[missq] local rank %s device %d: direct SDMA copies on engine mask 0x%x; host->device GB/s per engine:",
+            rk ? rk : "-", q->device, q->engine);
     for (int b = 0; b < 16; ++b)
       if (q->engine_GBps[b] > 0) fprintf(stderr, " %d:%.1f", b, q->engine_GBps[b]);
     fprintf(stderr, "\n");
@@ -588,12 +636,13 @@ static void missq_free(pg_missq* q) {
     q->cv_job.notify_all();
     q->worker.join();
   }
-  // direct jobs' copies are in no HIP stream: let the engine finish before the buffers go (bounded: 1 s each)
-  if (q->hsa_ok)
-    for (auto& s : q->slots)
-      for (int f = 0; f < q->n_fields; ++f)
-        if (s.sig[f].handle)
-          (void)hsa_signal_wait_scacquire(s.sig[f], HSA_SIGNAL_CONDITION_LT, 1, 1000000000ull, HSA_WAIT_STATE_BLOCKED);
+  // direct jobs' copies are in no HIP stream: let the engine finish before the buffers go (bounded: 1 s each). Every
+  // signal that was created is waited for, also after a mid-run fall-back to hipMemcpyAsync (hsa_ok false by then):
+  // copies handed to the engine before the fall-back may still be in flight
+  for (auto& s : q->slots)
+    for (int f = 0; f < PG_MAX_FIELDS; ++f)
+      if (s.sig[f].handle)
+        (void)hsa_signal_wait_scacquire(s.sig[f], HSA_SIGNAL_CONDITION_LT, 1, 1000000000ull, HSA_WAIT_STATE_BLOCKED);
   for (auto& s : q->slots) {
     (void)hipHostFree(s.issued_h);
     (void)hipHostFree(s.fullid_h);
@@ -617,6 +666,7 @@ static void missq_free(pg_missq* q) {
   }
   (void)hipFree(q->timeout_d);
   if (q->copy_stream) (void)hipStreamDestroy(q->copy_stream);
+  if (q->hsa_inited) (void)hsa_shut_down();     // drops this queue's reference only (the HIP runtime keeps its own)
   delete q->pool;
   delete q;
 }

@@ -17,20 +17,34 @@ class FusedDropoutMixin:
         self.register_buffer('_drop_step', torch.zeros(1, dtype=torch.int64), persistent=False)
         self._drop_seed = None
         self.fuse_dropout = True
-        # True: somebody else advances _drop_step once per training step (GraphedTrainer lets the optimiser's launch do
-        # it: one kernel less per replayed step). The counter then holds the value the NEXT forward uses.
+        # True only WHILE a caller that advances _drop_step itself runs the forward (GraphedTrainer's deferred step lets the
+        # optimiser's launch do it: one kernel less per replayed step) — see drop_step_external().
         self._drop_step_external = False
+        # True: the counter already holds the value the NEXT forward uses (an external owner bumps it AFTER each step);
+        # False: it holds the value the last forward used (this class's own bump-then-use order).
+        self._drop_step_primed = False
 
     def _bump_drop_step(self):
         if self.training and self._drop_step.is_cuda and not self._drop_step_external:
+            # (after an external owner the counter is one ahead already: bumping again skips one value, which is harmless
+            # — the masks only have to differ from step to step)
             self._drop_step.add_(1)
+            self._drop_step_primed = False
 
     def externalise_drop_step(self):
-        """hand the once-per-step increment over to the caller; the sequence of values the forwards see stays 1, 2, ..."""
-        if not self._drop_step_external:
-            self._drop_step_external = True
+        """make the counter hold the value the next forward uses (one eager increment, only when it does not already)
+        and return it; the caller then advances it once AFTER every step. Does not switch the model's own bump off:
+        wrap the forward in drop_step_external() for that."""
+        if not self._drop_step_primed:
             self._drop_step.add_(1)
+            self._drop_step_primed = True
         return self._drop_step
+
+    def drop_step_external(self):
+        """context manager: inside it the model's forward leaves the counter alone (the caller advances it); outside,
+        every training forward bumps it as before — a model handed from a GraphedTrainer to an eager loop keeps drawing
+        a fresh mask per step (the hand-over used to be permanent and silently froze the mask)."""
+        return _ExternalDropStep(self)
 
     def _drop_spec(self, layer, h):
         """DropoutSpec for aggregating `h` as the input of block `layer`, or None (use nn.Dropout)"""
@@ -56,3 +70,17 @@ class FusedDropoutMixin:
                                     "dim % 4 == 0); fetch the layer densely instead (virtual=None)")
             return h
         return mod(h) if mod is not None else h
+
+
+class _ExternalDropStep:
+    def __init__(self, model):
+        self.model = model
+
+    def __enter__(self):
+        self.prev = self.model._drop_step_external
+        self.model._drop_step_external = True
+        return self.model._drop_step
+
+    def __exit__(self, *exc):
+        self.model._drop_step_external = self.prev
+        return False

@@ -251,6 +251,18 @@ class DeferredPartials:
         self.second = {}       # parameter data_ptr -> the same for a parameter's SECOND contribution of the step
         self.extra = []        # reduce-only outputs: (destination tensor, partials, chunks, row length, offset)
         self.conflict = False
+        self.plain = set()     # parameters that ALSO went through a non-deferring path this step (library nn.Linear)
+
+    def saw_plain(self, *params):
+        """a dense step that does not defer (the library fall-back of ops.linear / linear2) used these parameters: autograd
+        accumulates their gradient into p.grad, which the deferred optimiser launch would overwrite"""
+        for p in params:
+            if p is not None:
+                self.plain.add(p.data_ptr())
+
+    def mixed(self):
+        """True when some parameter has both kinds of use in one step (its deferred sum would drop the other part)"""
+        return any(k in self.plain for k in self.by_param)
 
     def add(self, param, part, chunks, rowlen, off):
         """register one contribution; returns True for a parameter's first contribution of the step — the caller hands
@@ -434,6 +446,8 @@ def linear2(x1, mod1, x2, mod2, act=ACT_NONE):
     skinny envelope, else through the modules"""
     if x1.size(0) == x2.size(0) and mod1.weight.size(0) == mod2.weight.size(0) and _skinny_ok(x1, mod1.weight) \
             and _skinny_ok(x2, mod2.weight):
+        if _DEFER is not None and (mod1.bias is None or mod2.bias is None):
+            _DEFER.saw_plain(mod1.weight, mod1.bias, mod2.weight, mod2.bias)     # _bwd_w does not defer without a bias
         return _DualLinear.apply(x1, mod1.weight, mod1.bias, x2, mod2.weight, mod2.bias, act)
     return _apply_act(linear(x1, mod1) + linear(x2, mod2), act)
 
@@ -444,10 +458,14 @@ def linear(x, module, act=ACT_NONE):
     w, b = module.weight, module.bias
     if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and w.size(0) <= 64 and _rows_ok(x)
             and x.stride(1) == 1):
+        if _DEFER is not None and b is None:
+            _DEFER.saw_plain(w)                # _SkinnyLinear defers only with a bias
         y = _SkinnyLinear.apply(x, w, b, act)
         if act == ACT_CONCAT:
             y._pg_concat_n = w.size(0)         # lets the consumer's backward produce this layer's dZ (see _DZ_STASH)
         return y
+    if _DEFER is not None:
+        _DEFER.saw_plain(w, b)
     return _apply_act(module(x), act)
 
 

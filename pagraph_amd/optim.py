@@ -29,6 +29,9 @@ class Adam(torch.optim.Optimizer):
     def step(self, closure=None, deferred=None, bump=None):
         """deferred: an ops.DeferredPartials registry — gradients whose per-chunk partial rows were left un-summed by
         the weight-gradient kernels are added up (pg_sum_partials' order) inside this step's single launch"""
+        if deferred is not None and deferred.mixed():
+            raise L.PgError("deferred partial sums: a parameter was used by a deferring dense step AND by a library "
+                            "nn.Linear in the same step; its gradient would be incomplete (run without fuse_partials)")
         if deferred is not None and not deferred.conflict and (deferred.by_param or deferred.extra):
             return self._step_deferred(deferred, bump)
         if bump is not None:

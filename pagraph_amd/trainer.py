@@ -47,6 +47,10 @@ class MinibatchTrainer:
         self._nprep = 0
         # with `need`: layers the model only aggregates stay un-materialised (model.virtual_inputs)
         self.fuse_gather = True
+        # per miss-queue slot: recorded on the compute stream after the step that read the slot's staged block in place
+        # (ops.RowSource). The next fetch into that slot waits for it — the worker's copy of batch k + slots would
+        # otherwise overwrite rows batch k's aggregation has not read yet when the GPU runs behind the host
+        self._consumed = {}
 
     def _virtual(self, nf):
         m = getattr(self.model, 'module', self.model)
@@ -60,6 +64,13 @@ class MinibatchTrainer:
         p.nf = nf
         p.slot = self._nprep % self.cacher.missq_slots     # async miss path: one slot per in-flight batch
         self._nprep += 1
+        ev = self._consumed.pop(p.slot, None)
+        fetch_stream = self.load_stream if self.load_stream is not None else torch.cuda.current_stream(self.device)
+        if ev is not None:
+            # (the copy of the slot's previous job must be in its queue before a wait for something behind that job's
+            # consumer goes into any stream: pg_missq_wait_idle, DESIGN "Miss path")
+            self.cacher.wait_worker(p.slot)
+            fetch_stream.wait_event(ev)
         if self.load_stream is None:
             with torch.autograd.profiler.record_function('gpu-load'):
                 self.cacher.fetch_data(nf, need=self.need, slot=p.slot, virtual=self._virtual(nf))
@@ -88,6 +99,10 @@ class MinibatchTrainer:
             self.optimizer.zero_grad()
             loss.backward()
             self.optimizer.step()
+        if getattr(p.nf, '_fetch_plan', None) is not None and self.cacher.miss_mode == "async":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._consumed[p.slot] = ev
         return loss
 
     def _next(self, it):
@@ -244,7 +259,10 @@ class GraphedTrainer:
         # True: run_steps(it, n) keeps `lookahead` batches prepared when it returns (as long as `it` has more), so
         # the next run_steps call starts on a primed pipeline instead of paying sample -> gather -> miss-path
         # latency for its first batches again. False: every call drains what it prepared.
-        self.keep_primed = True
+        # Off by default: a primed pipeline has consumed `lookahead` batches of `it` that the call did not
+        # train on — right for a caller that passes the SAME iterator again (bench.py's timed windows), wrong for one that
+        # makes a fresh iterator per epoch.
+        self.keep_primed = False
         self.keep_gc = False             # True: leave the interpreter's cyclic garbage collector on inside run_steps
 
     class _Slot:
@@ -270,6 +288,7 @@ class GraphedTrainer:
         s.loss = None
         s.plan = None
         s.slot_index = None
+        s.ext_drop = None      # the model whose dropout counter this slot's (deferred) step body expects to be primed
         return s
 
     def prepare(self, nf):
@@ -368,15 +387,27 @@ class GraphedTrainer:
         return (self.fuse_partials and self.world == 1 and isinstance(self.optimizer, Adam)
                 and getattr(m, "deferrable_parameters", False) and len(self.optimizer.param_groups) == 1)
 
+    def _prime_drop_step(self):
+        """before a deferred step body (eager or captured): the optimiser's launch will advance the model's dropout
+        counter AFTER the step, so the counter must hold the value this step uses"""
+        import os as _os
+        m = self._bare_model()
+        if (self._can_defer_partials() and m.training and hasattr(m, "externalise_drop_step")
+                and not _os.environ.get("PG_KEEP_BUMP_KERNEL")):
+            m.externalise_drop_step()
+
     def _step_body_deferred(self, s):
         """_step_body for one GPU with the partial sums (and the dropout step counter's increment) folded into the
         optimiser's launch"""
         m = self._bare_model()
+        import contextlib
         import os as _os
-        bump = None
+        bump, scope = None, contextlib.nullcontext()
         if m.training and hasattr(m, "externalise_drop_step") and not _os.environ.get("PG_KEEP_BUMP_KERNEL"):
-            bump = m.externalise_drop_step()
-        with ops.defer_partials() as reg:
+            # the counter was primed by compute() (outside any capture); only this forward skips the model's own bump
+            bump, scope = m._drop_step, m.drop_step_external()
+            s.ext_drop = m
+        with scope, ops.defer_partials() as reg:
             rs = s.plan.row_sources if s.plan else {}
             for i in range(s.nf.num_layers):
                 o0, o1 = s.nf._layer_offsets[i], s.nf._layer_offsets[i + 1]
@@ -472,6 +503,11 @@ class GraphedTrainer:
             # the captured step reads the cache / the slot array / the staged block of the fetch plan it was captured
             # over: a new plan (the cache changed, the miss queue was rebuilt) needs a new capture
             s.graph = None
+        if s.ext_drop is not None and not s.ext_drop._drop_step_primed:
+            # this slot's (captured) step expects the dropout counter to hold the NEXT value; somebody ran the model the
+            # other way since (an eager forward bumps first, then uses): one eager increment puts it back
+            with torch.cuda.stream(main):
+                s.ext_drop.externalise_drop_step()
         if s.graph is not None and (self.world == 1 or s.graph_synced) and self._on_main:
             s.graph.replay()                                  # steady state: one launch
             loss = s.loss.clone() if self.keep_losses else s.loss
@@ -485,6 +521,7 @@ class GraphedTrainer:
                 elif warm:
                     if self.world == 1:
                         self.optimizer.zero_grad(set_to_none=True)
+                    self._prime_drop_step()
                     s.loss = (self._step_body_deferred(s) if self._can_defer_partials() else self._step_body(s)).detach()
                 else:
                     if self.world > 1 and self.allreduce_in_graph is None:
@@ -492,6 +529,7 @@ class GraphedTrainer:
                     g = torch.cuda.CUDAGraph()
                     if self.world == 1:
                         self.optimizer.zero_grad(set_to_none=True)
+                    self._prime_drop_step()                      # an eager increment: must stay outside the capture
                     # thread_local: RCCL's watchdog thread may touch the runtime while this thread captures
                     with torch.cuda.graph(g, stream=main, capture_error_mode="thread_local"):
                         s.loss = (self._step_body_deferred(s) if self._can_defer_partials() else self._step_body(s)).detach()
@@ -519,6 +557,7 @@ class GraphedTrainer:
         queue's worker to enqueue its outstanding copies, then for the device"""
         self.cacher.drain_misses()
         self.compute_stream.synchronize()
+        self.cacher.check_misses()       # a device-side wait that gave up means a step trained on rows that never landed
 
     def run_steps(self, it, steps=None):
         # the compute stream is made current for the whole loop (a graph replays on the current stream;
