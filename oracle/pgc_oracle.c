@@ -86,7 +86,9 @@ static int sample_vertex(const int64_t* indptr, const int32_t* indices, int64_t 
     for (int64_t j = 0; j < deg; ++j) out[j] = indices[beg + j];
     return (int)deg;
   }
-  uint64_t sel[64];
+  uint64_t sel_small[64];
+  uint64_t* sel = k <= 64 ? sel_small : (uint64_t*)malloc(sizeof(uint64_t) * (size_t)k);   /* any fan-out (pa_gcn.py:146-147) */
+  if (!sel) return -1;
   const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
   uint32_t w[4] = {0, 0, 0, 0};
   for (int j = 0; j < k; ++j) {
@@ -102,6 +104,7 @@ static int sample_vertex(const int64_t* indptr, const int32_t* indices, int64_t 
     sel[j] = t;
     out[j] = indices[beg + (int64_t)t];
   }
+  if (sel != sel_small) free(sel);
   return k;
 }
 
@@ -123,12 +126,12 @@ static int64_t lower_bound_i64(const int64_t* a, int64_t n, int64_t key) {
  * worst case): node_mapping[sum caps] layer 0 first; layer_offsets[hops+2];
  * per block b: blk_indptr + indptr_off[b] (|layer b+1|+1 entries),
  * blk_src + src_off[b].  edges_out[b] = edges of block b.  Returns 0, or -1 on
- * allocation failure / k > 64.                                                 */
+ * allocation failure.                                                          */
 int pgc_sample_nodeflow(const int64_t* indptr, const int32_t* indices, const int64_t* seeds, int32_t n_seeds,
                         int32_t k, int32_t hops, uint64_t seed, uint32_t epoch, uint32_t batch,
                         int64_t* node_mapping, int32_t* layer_offsets, int32_t* blk_indptr,
                         const int64_t* indptr_off, int32_t* blk_src, const int64_t* src_off, int32_t* edges_out) {
-  if (k > 64 || hops < 1 || hops > 7) return -1;
+  if (k < 1 || hops < 1 || hops > 7) return -1;
   int64_t* layer[8] = {0};
   int64_t lsize[8] = {0};
   layer[hops] = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n_seeds > 0 ? n_seeds : 1));

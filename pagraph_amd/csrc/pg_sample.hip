@@ -37,6 +37,7 @@
 namespace pg {
 
 constexpr int kScanThreads = 1024;
+constexpr int kMaxFanout = 4096;      // k_sample_wide: 4 waves x 4 * fanout bytes of LDS per block (64 KB)
 constexpr int kWordsPerBlock = 1024;  // bitmap words handled by one 256-thread block (4 per thread)
 
 // ---- block-wide exclusive scan of one int per thread (blockDim <= 1024) ----
@@ -132,6 +133,58 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
       }
       if (lane == 0) a.cnt[p] = k;
     }
+  }
+}
+
+// Fan-out above one wave (the reference accepts any --num-neighbors, pa_gcn.py:146-147): the same spec — Floyd's
+// k-subset, draw j = word pair (j & 1) of Philox call j >> 1 — with a vertex's k tentative picks in LDS (one k-entry
+// strip per wave) instead of one per lane. Draws are generated 64 at a time; the "already taken?" test of pick j scans
+// the j resolved picks before it with the whole wave (ceil(j / 64) LDS reads per lane). O(k^2 / 64) per vertex, which
+// a wide fan-out pays once per destination; the k <= 64 kernel above is unchanged.
+__global__ __launch_bounds__(256) void k_sample_wide(const SampleArgs a) {
+  extern __shared__ uint32_t sel_lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int k = a.k;
+  volatile uint32_t* sel = sel_lds + (size_t)(threadIdx.x / kWave) * k;
+  const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
+  const int n = *a.n_dst;
+  for (int64_t p = wave0; p < n; p += nwaves) {
+    const int64_t v = a.dst_ids[p];
+    const int64_t beg = a.indptr[v];
+    const int64_t deg = a.indptr[v + 1] - beg;
+    int32_t* out = a.nbr + p * k;
+    if (deg <= k) {
+      for (int j = lane; j < deg; j += kWave) {
+        const int32_t u = a.indices[beg + j];
+        out[j] = u;
+        atomicOr(&a.bitmap[u >> 6], 1ull << (u & 63));
+      }
+      if (lane == 0) a.cnt[p] = (int32_t)deg;
+      continue;
+    }
+    for (int j = lane; j < k; j += kWave) {
+      uint32_t r[4];
+      Philox::gen((uint32_t)v, a.prm->epoch, a.prm->batch, (a.layer << 24) | (uint32_t)(j >> 1), a.prm->seed_lo,
+                  a.prm->seed_hi, r);
+      const uint64_t r64 = (j & 1) ? ((uint64_t)r[3] << 32 | r[2]) : ((uint64_t)r[1] << 32 | r[0]);
+      sel[j] = (uint32_t)bounded(r64, (uint64_t)(deg - k + j) + 1);      // deg <= V < 2^31
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int j = 1; j < k; ++j) {
+      const uint32_t tj = sel[j];
+      bool dup = false;
+      for (int i = lane; i < j; i += kWave) dup |= sel[i] == tj;
+      if (__ballot(dup) != 0ull && lane == 0) sel[j] = (uint32_t)(deg - k + j);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    for (int j = lane; j < k; j += kWave) {
+      const int32_t u = a.indices[beg + (int64_t)sel[j]];
+      out[j] = u;
+      atomicOr(&a.bitmap[u >> 6], 1ull << (u & 63));
+    }
+    if (lane == 0) a.cnt[p] = k;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the strip is rewritten for the wave's next vertex
   }
 }
 
@@ -621,7 +674,9 @@ int pg_sampler_create(int64_t V, const int64_t* indptr, const int32_t* indices, 
   if (!out || V <= 0 || V > INT32_MAX || !indptr || !indices || max_seeds <= 0 || fanout <= 0 ||
       num_hops <= 0 || num_hops + 1 > PG_MAX_LAYERS)
     return PG_ERR_INVALID;
-  if (fanout > kWave) return PG_ERR_UNSUPPORTED;  // one wave resolves one vertex's k picks
+  // fan-out <= 64: one lane per pick (k_sample); above: the picks of a vertex live in an LDS strip (k_sample_wide),
+  // four strips of 4 * fanout bytes per block
+  if (fanout > kMaxFanout) return PG_ERR_UNSUPPORTED;
   pg_sampler* s = new (std::nothrow) pg_sampler;
   if (!s) return PG_ERR_NOMEM;
   s->V = V; s->indptr = indptr; s->indices = indices;
@@ -636,6 +691,12 @@ int pg_sampler_create(int64_t V, const int64_t* indptr, const int32_t* indices, 
   s->n_bm_blocks = (int)ceil_div<int64_t>(s->n_words, kWordsPerBlock);
   int64_t max_dst = 0;
   for (int l = 1; l <= L; ++l) max_dst = s->cap[l] > max_dst ? s->cap[l] : max_dst;
+  // a NodeFlow block is per-minibatch data with 32-bit edge offsets (blk_indptr / blk_tptr); the graph's own CSC offsets
+  // are 64-bit everywhere. Refuse a (batch, fan-out) whose worst-case block would not fit instead of overflowing.
+  if (max_dst * fanout >= INT32_MAX) {
+    delete s;
+    return PG_ERR_OVERFLOW;
+  }
   bool ok = true;
   ok &= hipMalloc(&s->bitmap, s->n_words * 8) == hipSuccess;
   ok &= hipMalloc(&s->bitmap_b, s->n_words * 8) == hipSuccess;
@@ -756,7 +817,10 @@ static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t
     a.dst_ids = s->layer_ids[b + 1]; a.n_dst = lcnt + b + 1;
     a.nbr = s->nbr; a.cnt = s->cnt; a.bitmap = bm; a.k = s->k;
     a.prm = s->prm_d; a.layer = (uint32_t)b;
-    hipLaunchKernelGGL(k_sample, dim3(grid_for(cap_dst, 4)), dim3(256), 0, st, a);
+    if (s->k <= kWave)
+      hipLaunchKernelGGL(k_sample, dim3(grid_for(cap_dst, 4)), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL(k_sample_wide, dim3(grid_for(cap_dst, 4)), dim3(256), (size_t)4 * s->k * sizeof(uint32_t), st, a);
     PG_LAUNCH_CHECK();
     int32_t* indptr_b = o->blk_indptr + o->blk_indptr_off[b];
     int32_t* src_b = o->blk_src + o->blk_src_off[b];

@@ -2,6 +2,8 @@
 store, built in-process: `features` (feat.npy or U[0,1) fallback) and, for GCN,
 `norm = 1/in_degree` (pa_server.py:43, inf for isolated vertices exactly as there) plus the
 optional one-hop preprocessing X' = norm * (A^T X) (pa_server.py:45-52)."""
+import ctypes
+
 import numpy as np
 import scipy.sparse as spsp
 import torch
@@ -19,20 +21,29 @@ def preprocess_features(csc, features, norm, chunk_rows=1 << 20):
     lib = L.load()
     dev = torch.device("cuda", torch.cuda.current_device())
     V, Fdim = features.shape
-    if csc.nnz >= 2 ** 31:
-        raise L.PgError("preprocess_features: more than 2^31 edges needs the 64-bit-indptr kernel")
     x = features.to(dev).contiguous()
-    indptr = torch.from_numpy(np.ascontiguousarray(csc.indptr, dtype=np.int32)).to(dev)
-    indices = torch.from_numpy(np.ascontiguousarray(csc.indices, dtype=np.int32)).to(dev)
+    # the graph's offsets are 64-bit (scipy gives int64 indptr beyond 2^31 entries); a CHUNK of destinations is a
+    # NodeFlow block with 32-bit offsets relative to its first edge: the chunk's indptr is rebased and the kernel gets
+    # `indices` advanced to that edge, so nothing limits the graph's total edge count
+    indptr = torch.as_tensor(np.ascontiguousarray(csc.indptr, dtype=np.int64)).to(dev)
+    indices = csc.indices if isinstance(csc.indices, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(csc.indices, dtype=np.int32))
+    indices = indices.to(dev, torch.int32)
     nrm = torch.as_tensor(norm, dtype=torch.float32).to(dev)
     out = torch.empty((V, Fdim), dtype=torch.float32)
-    for lo in range(0, V, chunk_rows):
+    lo = 0
+    while lo < V:
         hi = min(V, lo + chunk_rows)
-        # chunk-relative indptr: the kernel indexes src[] with the absolute edge offsets of the chunk
+        e0 = int(indptr[lo])
+        while int(indptr[hi]) - e0 >= 2 ** 31 - 1:       # (a chunk of hub destinations: shrink until its edges fit)
+            if hi - lo == 1:
+                raise L.PgError("preprocess_features: one vertex with >= 2^31 in-edges")
+            hi = lo + max(1, (hi - lo) // 2)
+        rel = (indptr[lo:hi + 1] - e0).to(torch.int32)
         agg = torch.empty((hi - lo, Fdim), dtype=torch.float32, device=dev)
-        L.check(lib.pg_spmm_fwd(L.ptr(indptr[lo:hi + 1]), L.ptr(indices), L.ptr(x), x.stride(0), hi - lo, Fdim,
+        L.check(lib.pg_spmm_fwd(L.ptr(rel), ctypes.c_void_p(indices.data_ptr() + 4 * e0), L.ptr(x), x.stride(0), hi - lo, Fdim,
                                 L.PG_REDUCE_SUM, L.ptr(agg), agg.stride(0), L.stream_ptr()), "pg_spmm_fwd")
         out[lo:hi] = (agg * nrm[lo:hi]).cpu()
+        lo = hi
     return out
 
 

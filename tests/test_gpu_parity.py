@@ -160,7 +160,9 @@ def _rand_csc(rng, V, E, powerlaw=True):
 
 
 @pytest.mark.parametrize("V,E,B,k,hops", [(2000, 12000, 256, 2, 2), (5000, 60000, 1000, 2, 2), (800, 9000, 100, 5, 3),
-                                           (3000, 20000, 333, 1, 1), (4000, 50000, 512, 64, 1), (100000, 900000, 6000, 2, 2)])
+                                           (3000, 20000, 333, 1, 1), (4000, 50000, 512, 64, 1), (100000, 900000, 6000, 2, 2),
+                                           # fan-out above one wave (k_sample_wide; the reference takes any --num-neighbors)
+                                           (3000, 400000, 128, 65, 1), (3000, 500000, 64, 100, 2), (2500, 900000, 50, 300, 1)])
 def test_sampler_vs_oracle_bit_exact(dev, hiplib, oracle, V, E, B, k, hops):
     """NodeFlow node-id sets, layer offsets and block CSRs equal the CPU restatement under a fixed seed"""
     from pagraph_amd.sampling import DeviceGraph, NeighborSampler
@@ -186,6 +188,63 @@ def test_sampler_vs_oracle_bit_exact(dev, hiplib, oracle, V, E, B, k, hops):
                 assert np.array_equal(nf.blk_src[i].cpu().numpy(), ref["blocks"][i][1])
             nb += 1
         assert nb >= 1 and b == len(smp) - 1
+
+
+@pytest.mark.timeout(600)
+def test_graph_offsets_beyond_2_to_31(dev, hiplib, oracle):
+    """the partition's CSC has 64-bit offsets on every path that walks it (scipy's own int64 CSR/CSC,
+    PaGraph/partition/utils.py:36-45): a graph whose in-lists start past entry 2^31 samples, expands and preprocesses
+    exactly like the same lists at the front of the array. Vertex 0 owns a 2^31-entry dummy in-list that nothing ever
+    visits (no vertex lists it as a neighbour, it is not a seed), so the oracle can run on the compact graph."""
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    free, _ = torch.cuda.mem_get_info()
+    if free < 24 << 30:
+        pytest.skip("needs ~10 GB of device memory")
+    rng = np.random.default_rng(31)
+    V, E, B, k, hops = 3000, 40000, 200, 3, 2
+    adj = _rand_csc(rng, V, E).tolil()
+    adj[0, :] = 0; adj[:, 0] = 0                    # vertex 0: isolated in the real graph
+    csc = spsp.csc_matrix(adj.tocsr()); csc.eliminate_zeros(); csc.sort_indices()
+    big = (1 << 31) + 12345
+    indptr = torch.from_numpy(csc.indptr.astype(np.int64))
+    indptr[1:] += big                               # vertex 0's "in-list" = the first `big` entries
+    indices = torch.empty(big + csc.nnz, dtype=torch.int32, device=dev)
+    indices[:4096].fill_(1)
+    indices[big:] = torch.from_numpy(csc.indices.astype(np.int32)).to(dev)
+    g = DeviceGraph.from_csc(indptr.to(dev), indices, V)
+    assert int(g.indptr[-1]) > 2 ** 31
+    train = np.sort(rng.choice(np.arange(1, V), 1500, replace=False)).astype(np.int64)
+    smp = NeighborSampler(g, B, k, neighbor_type='in', shuffle=False, num_hops=hops, seed_nodes=train, seed=7)
+    for b, nf in enumerate(smp):
+        ref = oracle.sample_nodeflow(csc.indptr, csc.indices, train[b * B:(b + 1) * B], k, hops, 7, 0, b)
+        assert np.array_equal(nf._node_mapping.tousertensor().cpu().numpy(), ref["node_mapping"])
+        for i in range(hops):
+            assert np.array_equal(nf.blk_indptr[i].cpu().numpy(), ref["blocks"][i][0])
+            assert np.array_equal(nf.blk_src[i].cpu().numpy(), ref["blocks"][i][1])
+        if b >= 2:
+            break
+    # the L-hop closure's frontier expansion over the same arrays
+    from pagraph_amd import _lib as L
+    bm = torch.zeros((V + 63) // 64, dtype=torch.int64, device=dev)
+    fr = torch.from_numpy(train[:300]).to(dev)
+    L.check(hiplib.pg_frontier_mark_neighbors(L.ptr(g.indptr), L.ptr(g.indices), L.ptr(fr), fr.numel(), L.ptr(bm), 0,
+                                              L.stream_ptr()))
+    got = np.unpackbits(bm.cpu().numpy().view(np.uint8), bitorder="little")[:V].nonzero()[0]
+    want = np.unique(np.concatenate([csc.indices[csc.indptr[v]:csc.indptr[v + 1]] for v in train[:300]]))
+    assert np.array_equal(got, want)
+    # pa_server.py:45-52's one-hop preprocessing on the same offsets
+    from pagraph_amd.server import preprocess_features
+
+    class _BigCSC:                                   # the attributes preprocess_features reads
+        nnz = big + csc.nnz
+        shape = (V, V)
+    bc = _BigCSC()
+    bc.indptr, bc.indices = csc.indptr.astype(np.int64) + big, indices      # every list past 2^31; vertex 0's is empty here
+    feats = torch.from_numpy(rng.random((V, 24), dtype=np.float32))
+    norm = torch.ones((V, 1))
+    got = preprocess_features(bc, feats, norm, chunk_rows=1000).numpy()
+    want = (csc.T @ feats.numpy().astype(np.float64)).astype(np.float32)
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("n_dst,n_src,deg,dim,reduce", [(500, 900, 2, 600, "mean"), (6000, 12000, 2, 64, "mean"),

@@ -42,6 +42,40 @@ def test_nodeflow_invariants(V, k, hops, seed, epoch):
         assert used.all()                                                  # layer = exactly the union of picks
 
 
+def test_wide_fanout_invariants():
+    """fan-out above 64 (the reference accepts any --num-neighbors, pa_gcn.py:146-147): the same rules on a dense graph
+    where most vertices have more than k in-neighbours, and a uniformity check of Floyd's subset at k = 70 of 90"""
+    from oracle import oracle
+    rng = np.random.default_rng(5)
+    V = 400
+    indptr, indices = _graph(rng, V, V * 150)
+    seeds = rng.permutation(V)[:60].astype(np.int64)
+    for k in (65, 100, 130):
+        nf = oracle.sample_nodeflow(indptr, indices, seeds, k, 1, 99, 0, 1)
+        offs, nm = nf["layer_offsets"], nf["node_mapping"]
+        lay = nm[offs[0]:offs[1]]
+        ip, src = nf["blocks"][0]
+        some_sampled = False
+        for p, v in enumerate(seeds):
+            nb = indices[indptr[v]:indptr[v + 1]]
+            picked = lay[src[ip[p]:ip[p + 1]]]
+            assert len(picked) == min(k, len(nb)) and len(set(picked.tolist())) == len(picked)
+            assert set(picked.tolist()) <= set(nb.tolist())
+            some_sampled |= len(nb) > k
+        assert some_sampled
+    deg, k, trials = 90, 70, 1500
+    indptr1 = np.array([0, deg] + [deg] * deg, dtype=np.int64)
+    indices1 = np.arange(1, deg + 1, dtype=np.int32)
+    counts = np.zeros(deg + 1)
+    for t in range(trials):
+        nf = oracle.sample_nodeflow(indptr1, indices1, np.array([0]), k, 1, 4321, t, 0)
+        counts[nf["node_mapping"][:nf["layer_offsets"][1]]] += 1
+    exp = trials * k / deg
+    var = trials * (k / deg) * (1 - k / deg)
+    chi2 = ((counts[1:] - exp) ** 2 / var).sum() * (deg - 1) / deg
+    assert chi2 < 140.0, chi2           # chi2(89 dof) 0.999 quantile ~ 135
+
+
 def test_uniform_selection_chi2():
     """one vertex with 10 in-neighbours, k = 3: each neighbour picked with p = 0.3"""
     from oracle import oracle
