@@ -258,6 +258,9 @@ int pg_missq_stats(pg_missq_t* q, double out[8]);
  * own choice through hipMemcpyAsync) and the host->device GB/s every engine reached in the calibration at creation
  * (0 = engine not offered). The worker submits its copies to the fastest one directly (see pg_missq.hip).   */
 int pg_missq_copy_engine(pg_missq_t* q, uint32_t* engine_mask, double GBps[16]);
+/* chunks (32 rows) of the CPU row gather that the worker re-executed because the pool thread that had claimed them was
+ * overdue (lost its CPU with the chunk in hand): each one is a multi-millisecond stall of the step that did not happen */
+int pg_missq_rescued_chunks(pg_missq_t* q, int64_t* out);
 /* diagnosis (env PG_MISSQ_COPYLOG=1 at creation): the last `cap` host->device copies of the worker's wide field as
  * (bytes, milliseconds on the copy stream), oldest first; *n_out = entries written                        */
 int pg_missq_copy_log(pg_missq_t* q, int64_t* bytes, float* ms, int64_t cap, int64_t* n_out);

@@ -170,17 +170,48 @@ static inline void copy_row_stream(float* dst, const float* src, size_t bytes) {
 }
 
 // Persistent thread pool for the miss path's row gather: parallel_for over [0, n) in chunks of kChunk rows
-// that the threads CLAIM from an atomic counter. A job arrives every ~0.25 ms and is ~50-100 us of work, so
+// that the threads CLAIM from an atomic counter. A job arrives every ~0.15 ms and is ~50-100 us of work, so
 // how fast the threads start matters as much as how fast they copy: after a job they spin on the generation
 // counter for PG_MISSQ_SPIN_US microseconds (default 100) before they sleep on a condition variable. Keep the
 // thread count well under the CPU quota of the process (the GPU boxes give 16 CPUs: 31 spinning threads
 // starved the launch thread and the step got 2x slower; 8 are fine).
+//
+// Stragglers (round 3). A pool thread that has claimed a chunk and then loses its CPU used to hold the whole job —
+// and with it the training step that needs the rows — until the scheduler ran it again: 2-7 ms stalls of the launch
+// loop, once or twice per epoch on a busy host (DESIGN "Where a host stall sits"). A chunk is an idempotent copy, so
+// the caller now RE-EXECUTES chunks that are claimed but not finished kOverdueUs after it ran out of chunks to claim
+// itself; whoever finishes a chunk first counts it. What makes that safe:
+//  * a job lives in a descriptor of its own (a small ring inside the pool), not on the caller's stack: a straggler
+//    that wakes up after parallel_for has returned still finds its function object, bounds and counters intact;
+//  * every thread brackets its time inside a job with the descriptor's `active` count; a descriptor is recycled only
+//    when that count is zero, and parallel_for returns a ticket with which the caller asks "is anybody still
+//    writing on behalf of that job?" (quiesced) before IT recycles what the job wrote to — the miss queue's
+//    worker does so before it reuses a slot's staging buffer, ring-size jobs later.
 class Pool {
  public:
   static constexpr int64_t kChunk = 32;
+  static constexpr int kRing = 16;            // job descriptors (>= miss-queue slots + in-flight stragglers)
+  static constexpr int64_t kMaxChunks = 1 << 16;
+  struct Job {
+    std::function<void(int64_t, int64_t)> fn;
+    int64_t total = 0, chunks = 0;
+    std::atomic<int64_t> left{0}, done{0};
+    std::atomic<int> active{0};               // threads currently inside work(job)
+    std::atomic<uint64_t> ticket{0};          // generation this descriptor currently serves
+    std::unique_ptr<std::atomic<uint8_t>[]> state;   // per chunk: 0 unclaimed, 1 claimed, 2 done
+    int64_t state_cap = 0;
+  };
   explicit Pool(int n) : n_(n < 1 ? 1 : n) {
     const char* e = getenv("PG_MISSQ_SPIN_US");
     spin_us_ = e ? atoi(e) : 100;
+    const char* o = getenv("PG_MISSQ_OVERDUE_US");
+    overdue_us_ = o ? atoi(o) : 40;
+    // test hook: PG_MISSQ_TEST_STALL=<every>,<us> — a pool thread (never the caller) that claims every <every>-th
+    // chunk sleeps <us> microseconds before it executes it, like a thread that lost its CPU with a chunk in hand
+    if (const char* t = getenv("PG_MISSQ_TEST_STALL")) {
+      stall_every_ = atoi(t);
+      if (const char* c = strchr(t, ',')) stall_us_ = atoi(c + 1);
+    }
     for (int i = 1; i < n_; ++i) th_.emplace_back([this] { loop(); });
   }
   ~Pool() {
@@ -192,18 +223,32 @@ class Pool {
     cv_.notify_all();
     for (auto& t : th_) t.join();
   }
-  void parallel_for(int64_t n, const std::function<void(int64_t, int64_t)>& f) {
-    if (n <= 0) return;
+  // runs f over [0, n) in chunks; returns a ticket for quiesced(). One caller at a time.
+  uint64_t parallel_for(int64_t n, std::function<void(int64_t, int64_t)> f) {
+    if (n <= 0) return 0;
     const int64_t chunks = (n + kChunk - 1) / kChunk;
-    if (chunks <= 1 || n_ == 1) {
+    if (chunks <= 1 || n_ == 1 || chunks > kMaxChunks) {
       f(0, n);
-      return;
+      return 0;
     }
-    // publish order: job description, then the counters, then the generation (workers acquire on left_)
-    fn_ = &f;
-    total_ = n;
-    done_.store(0, std::memory_order_relaxed);
-    left_.store(chunks, std::memory_order_release);
+    const uint64_t ticket = ++tickets_;
+    Job& j = ring_[ticket % kRing];
+    // the descriptor's previous job (kRing jobs ago) may still have a straggler inside: it must leave first
+    while (j.active.load(std::memory_order_acquire) != 0) cpu_relax();
+    if (j.state_cap < chunks) {
+      j.state.reset(new std::atomic<uint8_t>[(size_t)chunks]);
+      j.state_cap = chunks;
+    }
+    for (int64_t c = 0; c < chunks; ++c) j.state[c].store(0, std::memory_order_relaxed);
+    j.fn = std::move(f);
+    j.total = n;
+    j.chunks = chunks;
+    j.done.store(0, std::memory_order_relaxed);
+    j.ticket.store(ticket, std::memory_order_relaxed);
+    // publish order: descriptor, then its claim counter, then the pool's current job, then the generation (workers
+    // acquire on left: a claim that succeeds sees the whole descriptor)
+    j.left.store(chunks, std::memory_order_release);
+    cur_.store(&j, std::memory_order_release);
     gen_.fetch_add(1, std::memory_order_release);
     if (sleepers_.load(std::memory_order_acquire) > 0) {
       {
@@ -211,22 +256,59 @@ class Pool {
       }
       cv_.notify_all();
     }
-    work();
-    while (done_.load(std::memory_order_acquire) < chunks) cpu_relax();
-    // every chunk has been executed. The claim counter counts DOWN, so a straggler's claim is valid or not
-    // by its sign alone — it never compares against a chunk count that the next job may have replaced.
+    work(j, true);
+    // nothing left to claim. Chunks still open are in the hands of other threads: normally a few microseconds from
+    // done; a thread that lost its CPU in the middle of one can be away for a scheduler time slice
+    const auto t0 = std::chrono::steady_clock::now();
+    int polls = 0;
+    while (j.done.load(std::memory_order_acquire) < chunks) {
+      cpu_relax();
+      if ((++polls & 31) == 0 &&
+          std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= overdue_us_) {
+        for (int64_t c = 0; c < chunks; ++c) {
+          if (j.state[c].load(std::memory_order_acquire) == 2) continue;
+          const int64_t lo = c * kChunk, hi = std::min<int64_t>(n, lo + kChunk);
+          j.fn(lo, hi);
+          if (j.state[c].exchange(2, std::memory_order_acq_rel) != 2) {
+            j.done.fetch_add(1, std::memory_order_acq_rel);
+            rescued_.fetch_add(1, std::memory_order_relaxed);
+          }
+        }
+        break;
+      }
+    }
+    while (j.done.load(std::memory_order_acquire) < chunks) cpu_relax();   // (every chunk is counted exactly once)
+    return ticket;
   }
+  // true when no thread is still executing on behalf of the job with this ticket (a re-executed chunk's original
+  // owner may still be copying the same bytes): what the job wrote to may be reused
+  bool quiesced(uint64_t ticket) const {
+    if (ticket == 0) return true;
+    const Job& j = ring_[ticket % kRing];
+    if (j.ticket.load(std::memory_order_acquire) != ticket) return true;   // recycled since: it had drained then
+    return j.active.load(std::memory_order_acquire) == 0;
+  }
+  void wait_quiesced(uint64_t ticket) const {
+    while (!quiesced(ticket)) cpu_relax();
+  }
+  int64_t rescued() const { return rescued_.load(std::memory_order_relaxed); }
 
  private:
   static inline void cpu_relax() { __builtin_ia32_pause(); }
-  void work() {
+  void work(Job& j, bool caller = false) {
+    j.active.fetch_add(1, std::memory_order_acq_rel);
     for (;;) {
-      const int64_t c = left_.fetch_sub(1, std::memory_order_acq_rel) - 1;
-      if (c < 0) return;
-      const int64_t lo = c * kChunk, hi = std::min<int64_t>(total_, lo + kChunk);
-      (*fn_)(lo, hi);
-      done_.fetch_add(1, std::memory_order_acq_rel);
+      const int64_t c = j.left.fetch_sub(1, std::memory_order_acq_rel) - 1;
+      if (c < 0) break;       // (the counter counts DOWN: a late claim is invalid by its sign alone)
+      uint8_t expect = 0;
+      if (!j.state[c].compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) continue;   // rescued already
+      if (stall_every_ > 0 && !caller && stall_count_.fetch_add(1, std::memory_order_relaxed) % stall_every_ == 0)
+        std::this_thread::sleep_for(std::chrono::microseconds(stall_us_));
+      const int64_t lo = c * kChunk, hi = std::min<int64_t>(j.total, lo + kChunk);
+      j.fn(lo, hi);
+      if (j.state[c].exchange(2, std::memory_order_acq_rel) != 2) j.done.fetch_add(1, std::memory_order_acq_rel);
     }
+    j.active.fetch_sub(1, std::memory_order_acq_rel);
   }
   void loop() {
     uint64_t seen = gen_.load(std::memory_order_acquire);
@@ -247,17 +329,21 @@ class Pool {
       }
       seen = g;
       if (stop_.load(std::memory_order_acquire)) return;
-      work();
+      Job* j = cur_.load(std::memory_order_acquire);
+      if (j) work(*j, false);
     }
   }
   int n_;
-  int spin_us_ = 100;
+  int spin_us_ = 100, overdue_us_ = 40;
+  int stall_every_ = 0, stall_us_ = 0;
+  std::atomic<int64_t> stall_count_{1};
   std::vector<std::thread> th_;
   std::mutex m_;
   std::condition_variable cv_;
-  const std::function<void(int64_t, int64_t)>* fn_ = nullptr;
-  int64_t total_ = 0;
-  std::atomic<int64_t> left_{0}, done_{0};
+  Job ring_[kRing];
+  std::atomic<Job*> cur_{nullptr};
+  uint64_t tickets_ = 0;
+  std::atomic<int64_t> rescued_{0};
   std::atomic<uint64_t> gen_{0};
   std::atomic<int> sleepers_{0};
   std::atomic<bool> stop_{false};
@@ -287,6 +373,7 @@ struct pg_missq_slot {
   hsa_signal_t sig[PG_MAX_FIELDS] = {};      // direct SDMA path: completion signal of field f's copy
   int cp_field = -1;
   int64_t cp_bytes = 0;
+  uint64_t gather_ticket[PG_MAX_FIELDS] = {0};   // Pool ticket of the last CPU gather into staging_h[f]
   uint32_t submitted = 0;  // last sequence number handed to the worker (trainer thread)
   uint32_t done = 0;       // last sequence number whose copy has been enqueued (worker, under mutex)
   int32_t last_count = 0;
@@ -526,13 +613,20 @@ static void missq_worker(pg_missq* q) {
                                          ? (size_t)atol(strchr(getenv("PG_MISSQ_PREFETCH"), ',') + 1) : 256;
         const size_t pf_bytes = std::min(pf_cfg, row_bytes);
         const auto ta = now();
-        q->pool->parallel_for(m, [&](int64_t lo, int64_t hi) {   // storage.py:128 table[nids]
+        // a straggler of this slot's PREVIOUS job (a re-executed chunk's original owner) may still be copying into
+        // this staging buffer: it must have left before the buffer is rewritten (a formality: n_slots jobs ago)
+        q->pool->wait_quiesced(s.gather_ticket[f]);
+        // everything captured BY VALUE: a straggler may run this after the call has returned
+        const float* table = fd.table;
+        const int64_t tstride = fd.table_stride;
+        const int pfd = pf_dist;
+        s.gather_ticket[f] = q->pool->parallel_for(m, [=](int64_t lo, int64_t hi) {   // storage.py:128 table[nids]
           for (int64_t j = lo; j < hi; ++j) {
-            if (j + pf_dist < hi) {   // rows are random DRAM pages: start a later one while this one streams
-              const char* nx = reinterpret_cast<const char*>(fd.table + ids[j + pf_dist] * fd.table_stride);
+            if (j + pfd < hi) {   // rows are random DRAM pages: start a later one while this one streams
+              const char* nx = reinterpret_cast<const char*>(table + ids[j + pfd] * tstride);
               for (size_t b = 0; b < pf_bytes; b += 64) __builtin_prefetch(nx + b, 0, 0);
             }
-            copy_row_stream(stg + j * srow, fd.table + ids[j] * fd.table_stride, row_bytes);
+            copy_row_stream(stg + j * srow, table + ids[j] * tstride, row_bytes);
           }
           __builtin_ia32_sfence();   // the streaming stores must be globally visible before the chunk counts as done
         });
@@ -636,6 +730,8 @@ static void missq_free(pg_missq* q) {
     q->cv_job.notify_all();
     q->worker.join();
   }
+  delete q->pool;        // joins the gather threads: nobody writes to the staging buffers any more
+  q->pool = nullptr;
   // direct jobs' copies are in no HIP stream: let the engine finish before the buffers go (bounded: 1 s each). Every
   // signal that was created is waited for, also after a mid-run fall-back to hipMemcpyAsync (hsa_ok false by then):
   // copies handed to the engine before the fall-back may still be in flight
@@ -667,7 +763,6 @@ static void missq_free(pg_missq* q) {
   (void)hipFree(q->timeout_d);
   if (q->copy_stream) (void)hipStreamDestroy(q->copy_stream);
   if (q->hsa_inited) (void)hsa_shut_down();     // drops this queue's reference only (the HIP runtime keeps its own)
-  delete q->pool;
   delete q;
 }
 
@@ -994,6 +1089,12 @@ int pg_missq_stats(pg_missq_t* q, double out[8]) {
   out[0] = (double)q->n_jobs; out[1] = (double)q->n_rows;
   out[2] = (double)q->n_wait_event; out[3] = (double)q->n_wait_spin;
   out[4] = q->t_sub2flag / n; out[5] = q->t_gather / n; out[6] = q->t_enqueue / n; out[7] = q->t_total / n;
+  return PG_OK;
+}
+
+int pg_missq_rescued_chunks(pg_missq_t* q, int64_t* out) {
+  if (!q || !out) return PG_ERR_INVALID;
+  *out = q->pool ? q->pool->rescued() : 0;
   return PG_OK;
 }
 

@@ -858,7 +858,10 @@ class GraphCacheServer:
         eng = L.c_u32(0)
         rate = (ctypes.c_double * 16)()
         L.check(self.lib.pg_missq_copy_engine(self._missq, ctypes.byref(eng), rate), "pg_missq_copy_engine")
+        resc = L.c_i64(0)
+        L.check(self.lib.pg_missq_rescued_chunks(self._missq, ctypes.byref(resc)), "pg_missq_rescued_chunks")
         return {"jobs": int(v[0]), "rows_per_job": v[1] / max(1.0, v[0]), "waits_by_event": int(v[2]),
+                "rescued_chunks": int(resc.value),       # overdue 32-row chunks of the CPU gather re-executed by the worker
                 "waits_by_spin_kernel": int(v[3]), "us_submit_to_published": v[4], "us_cpu_gather": v[5],
                 "us_enqueue": v[6], "us_submit_to_done": v[7],
                 "sdma_engine_mask": int(eng.value),      # 0 = hipMemcpyAsync (the runtime picks the engine)
