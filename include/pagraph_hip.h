@@ -257,6 +257,12 @@ int pg_missq_stats(pg_missq_t* q, double out[8]);
 /* which SDMA engine the worker's host->device copies go to (hsa_amd_sdma_engine_id_t bit; 0 = the HIP runtime's
  * own choice through hipMemcpyAsync) and the host->device GB/s every engine reached in the calibration at creation
  * (0 = engine not offered). The worker submits its copies to the fastest one directly (see pg_missq.hip).   */
+/* cpu_share < 1 (pg_missq_set_cpu_share): the tail of the slot's latest miss list, [count * share / 256, count), read
+ * from the pinned host table by the device on `stream` — call on the fetching stream right after pg_missq_submit*.
+ * The rows land in the slot's staged block in miss-list order (where an in-place consumer, or the consumer-side
+ * scatter of a direct job, finds them); a field whose rows the WORKER scatters (no direct SDMA path) is scattered to
+ * its frame here instead. No-op at share 1. The host table must be page-locked / registered.                       */
+int pg_missq_device_tail(pg_missq_t* q, int slot, pg_stream_t stream);
 int pg_missq_copy_engine(pg_missq_t* q, uint32_t* engine_mask, double GBps[16]);
 /* chunks (32 rows) of the CPU row gather that the worker re-executed because the pool thread that had claimed them was
  * overdue (lost its CPU with the chunk in hand): each one is a multi-millisecond stall of the step that did not happen */

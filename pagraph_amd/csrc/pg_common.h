@@ -17,6 +17,12 @@ extern "C" int pg_sum_partials(const float* partials, int32_t chunks, int64_t nk
 
 namespace pg {
 
+// internal (pg_gather.hip): rows [n * start_num / 256, n) of a miss list read from the pinned host table by the device;
+// pos == NULL writes row j of the list to row j of `out`, else to row pos[j] - pos_lo (rows below pos_lo skipped)
+int scatter_host_tail(const float* table, int64_t table_stride, const int32_t* pos, int32_t pos_lo, const int64_t* fullid,
+                      int64_t n_max, const int32_t* n_dev, int32_t start_num, int32_t dim, float* out, int32_t out_stride,
+                      pg_stream_t stream);
+
 constexpr int kWave = 64;
 
 extern thread_local int g_last_hip_error;

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void k_scatter_host(const float* __restrict__ 
                                                       const int64_t* __restrict__ fullid, int64_t n,
                                                       const int32_t* __restrict__ n_dev, int32_t dim,
                                                       float* __restrict__ out, int32_t out_stride,
-                                                      int32_t start_num) {
+                                                      int32_t start_num, int32_t pos_lo) {
   using V = typename VecT<VEC>::type;
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t nn = n_dev ? (int64_t)*n_dev : n;
@@ -292,15 +292,21 @@ __global__ __launch_bounds__(256) void k_scatter_host(const float* __restrict__ 
   for (int64_t j = j0 + (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; j < nn; j += 2 * waves) {
     const int64_t j2 = j + waves;
     const bool two = j2 < nn;
+    // pos == NULL: row j of the miss list goes to row j of `out` (a staged block in miss-list order); else to row
+    // pos[j] - pos_lo, rows below pos_lo skipped (their consumer reads the staged block)
+    const int64_t p0 = pos ? (int64_t)pos[j] - pos_lo : j;
+    const int64_t p1 = pos ? (int64_t)pos[two ? j2 : j] - pos_lo : (two ? j2 : j);
+    const bool w0 = p0 >= 0, w1 = two && p1 >= 0;
     const V* src0 = reinterpret_cast<const V*>(table + fullid[j] * table_stride);
     const V* src1 = reinterpret_cast<const V*>(table + fullid[two ? j2 : j] * table_stride);
-    V* dst0 = reinterpret_cast<V*>(out + (int64_t)pos[j] * out_stride);
-    V* dst1 = reinterpret_cast<V*>(out + (int64_t)pos[two ? j2 : j] * out_stride);
+    V* dst0 = reinterpret_cast<V*>(out + (w0 ? p0 : 0) * out_stride);
+    V* dst1 = reinterpret_cast<V*>(out + (w1 ? p1 : 0) * out_stride);
+    if (!w0 && !w1) continue;
     for (int c = lane; c < pieces; c += kWave) {
       const V a = src0[c];
       const V b = src1[c];
-      dst0[c] = a;
-      if (two) dst1[c] = b;
+      if (w0) dst0[c] = a;
+      if (w1) dst1[c] = b;
     }
   }
 }
@@ -599,10 +605,21 @@ int pg_scatter_rows_from_host(const float* table, int64_t table_stride, const in
 int pg_scatter_rows_from_host_tail(const float* table, int64_t table_stride, const int32_t* pos,
                                    const int64_t* fullid, int64_t n_max, const int32_t* n_dev, int32_t start_num,
                                    int32_t dim, float* out, int32_t out_stride, pg_stream_t stream) {
-  if (n_max < 0 || dim <= 0 || out_stride < dim || table_stride < dim || start_num < 0 || start_num > 256)
+  if (!pos) return PG_ERR_INVALID;
+  return pg::scatter_host_tail(table, table_stride, pos, 0, fullid, n_max, n_dev, start_num, dim, out, out_stride, stream);
+}
+
+}  // extern "C"
+
+// pos may be NULL (identity: a staged block in miss-list order); pos_lo as pg_scatter_rows_strided. Internal: the miss
+// queue's device tail (pg_missq_device_tail).
+int pg::scatter_host_tail(const float* table, int64_t table_stride, const int32_t* pos, int32_t pos_lo,
+                          const int64_t* fullid, int64_t n_max, const int32_t* n_dev, int32_t start_num, int32_t dim,
+                          float* out, int32_t out_stride, pg_stream_t stream) {
+  if (n_max < 0 || dim <= 0 || out_stride < dim || table_stride < dim || start_num < 0 || start_num > 256 || pos_lo < 0)
     return PG_ERR_INVALID;
   if (n_max == 0) return PG_OK;
-  if (!table || !pos || !fullid || !out) return PG_ERR_INVALID;
+  if (!table || !fullid || !out) return PG_ERR_INVALID;
   hipStream_t st = as_stream(stream);
   static const int kHostBlocks = [] {
     const char* e = getenv("PG_SCATTER_HOST_BLOCKS");
@@ -612,15 +629,13 @@ int pg_scatter_rows_from_host_tail(const float* table, int64_t table_stride, con
   const int grid = grid_1d(n_max, 8, kHostBlocks);
   if (dim % 4 == 0 && out_stride % 4 == 0 && table_stride % 4 == 0 && aligned(table, 16) && aligned(out, 16))
     hipLaunchKernelGGL(k_scatter_host<4>, dim3(grid), dim3(256), 0, st, table, table_stride, pos, fullid, n_max,
-                       n_dev, dim, out, out_stride, start_num);
+                       n_dev, dim, out, out_stride, start_num, pos_lo);
   else if (dim % 2 == 0 && out_stride % 2 == 0 && table_stride % 2 == 0 && aligned(table, 8) && aligned(out, 8))
     hipLaunchKernelGGL(k_scatter_host<2>, dim3(grid), dim3(256), 0, st, table, table_stride, pos, fullid, n_max,
-                       n_dev, dim, out, out_stride, start_num);
+                       n_dev, dim, out, out_stride, start_num, pos_lo);
   else
     hipLaunchKernelGGL(k_scatter_host<1>, dim3(grid), dim3(256), 0, st, table, table_stride, pos, fullid, n_max,
-                       n_dev, dim, out, out_stride, start_num);
+                       n_dev, dim, out, out_stride, start_num, pos_lo);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
-
-}  // extern "C"

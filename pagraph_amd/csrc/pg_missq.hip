@@ -373,6 +373,7 @@ struct pg_missq_slot {
   hsa_signal_t sig[PG_MAX_FIELDS] = {};      // direct SDMA path: completion signal of field f's copy
   int cp_field = -1;
   int64_t cp_bytes = 0;
+  int share = 256;         // cpu_share the latest submission was made under
   uint64_t gather_ticket[PG_MAX_FIELDS] = {0};   // Pool ticket of the last CPU gather into staging_h[f]
   uint32_t submitted = 0;  // last sequence number handed to the worker (trainer thread)
   uint32_t done = 0;       // last sequence number whose copy has been enqueued (worker, under mutex)
@@ -593,7 +594,7 @@ static void missq_worker(pg_missq* q) {
     }
     const int64_t m_all = *s.count_h;
     // rows [0, m) are this worker's; the tail is read by the device itself (pg_scatter_rows_from_host_tail)
-    const int64_t m = m_all * q->cpu_share.load(std::memory_order_relaxed) / 256;
+    const int64_t m = m_all * s.share / 256;   // the share this SUBMISSION was made under (its device tail used the same)
     const auto t2 = now();
     q->t_sub2flag += us(s.t_submit, t2);
     q->t_sub2pop += us(s.t_submit, t0);
@@ -926,6 +927,7 @@ int pg_missq_submit_dedup(pg_missq_t* q, int slot, float* const* out_ptrs, const
       s.pos_lo[f] = pos_lo ? pos_lo[f] : 0;
     }
     s.dedup = slots_dev != nullptr;
+    s.share = q->cpu_share.load(std::memory_order_relaxed);
     // every wanted field is read in place from the staged block and the copies go straight to an SDMA engine:
     // the job never touches the copy stream (see k_wait_direct)
     static const bool no_direct = getenv("PG_MISSQ_NO_DIRECT") != nullptr && atoi(getenv("PG_MISSQ_NO_DIRECT")) != 2;
@@ -942,8 +944,9 @@ int pg_missq_submit_dedup(pg_missq_t* q, int slot, float* const* out_ptrs, const
     // the all-layer leg read 0.52-0.58 instead of 0.36-0.38 ms/step whenever the runtime's queue assignment fell
     // that way. PG_MISSQ_NO_DIRECT=1: everything through the copy stream; =2: only staged-only jobs are direct.
     static const int no_direct_mode = getenv("PG_MISSQ_NO_DIRECT") ? atoi(getenv("PG_MISSQ_NO_DIRECT")) : 0;
-    const bool whole_list = q->cpu_share.load(std::memory_order_relaxed) == 256;   // the device count is the worker's count
-    s.direct = any && (all_staged || (no_direct_mode != 2 && whole_list)) && q->hsa_ok && !no_direct && !q->wait_value;
+    // (with cpu_share < 1 the tail of the list is written into the staged block by the device — pg_missq_device_tail —
+    // so the consumer's scatter still covers the whole list)
+    s.direct = any && (all_staged || no_direct_mode != 2) && q->hsa_ok && !no_direct && !q->wait_value;
   }
   if (slots_dev)
     hipLaunchKernelGGL(k_publish_dedup, dim3(1), dim3(256), 0, as_stream(stream), s.count_d, s.count_h, s.flag_h, seq,
@@ -1036,6 +1039,31 @@ int pg_missq_wait_device(pg_missq_t* q, int slot, pg_stream_t stream) {
   }
   hipLaunchKernelGGL(k_wait_landed, dim3(1), dim3(1), 0, as_stream(stream), s.landed_d, seq, q->timeout_d);
   PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+/* cpu_share < 1: the rows of the slot's latest submission that the worker leaves alone — [count * share / 256, count) of
+ * its miss list — are read from the pinned host table by the device itself, on `stream` (the fetching stream, right after
+ * the submit). They land in the slot's staged block in miss-list order, next to the rows the worker copies; fields with
+ * an output frame whose job is NOT scattered by its consumer (no direct SDMA path) are also scattered from the host
+ * table to the frame here. A no-op at share 1.                                                                  */
+int pg_missq_device_tail(pg_missq_t* q, int slot, pg_stream_t stream) {
+  if (!q || slot < 0 || slot >= q->n_slots) return PG_ERR_INVALID;
+  pg_missq_slot& s = q->slots[slot];
+  const int share = s.share;             // of the slot's latest submission (this thread made it)
+  if (share >= 256) return PG_OK;
+  for (int f = 0; f < q->n_fields; ++f) {
+    if (!s.out[f] && s.out_stride[f] != -1) continue;
+    const pg_missq_field_t& fd = q->fields[f];
+    int rc = PG_OK;
+    if (s.direct || !s.out[f])
+      rc = pg::scatter_host_tail(fd.table, fd.table_stride, nullptr, 0, s.fullid_h, q->max_rows, s.count_d, share, fd.dim,
+                                 s.staged_d[f], q->sstride[f], stream);
+    else
+      rc = pg::scatter_host_tail(fd.table, fd.table_stride, s.pos_d, s.pos_lo[f], s.fullid_h, q->max_rows, s.count_d, share,
+                                 fd.dim, s.out[f], s.out_stride[f], stream);
+    if (rc != PG_OK) return rc;
+  }
   return PG_OK;
 }
 

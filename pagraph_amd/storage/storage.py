@@ -495,7 +495,7 @@ class GraphCacheServer:
                                                        L.ptr(self._slots) if dd is not None else None, sp), "pg_missq_submit")
                 self._missq_pending.add(slot)
                 if self._missq_share < 256:
-                    self._device_tail(names, out, miss_pos, miss_fullid, miss_count, R, sp)
+                    L.check(self.lib.pg_missq_device_tail(self._missq, slot, sp), "pg_missq_device_tail")
             elif self.miss_mode == "zerocopy":
                 for name in names:
                     tab = _table(self.graph, name)
@@ -683,7 +683,7 @@ class GraphCacheServer:
                                                    L.ptr(self._slots) if dd is not None else None, sp), "pg_missq_submit")
             self._missq_pending.add(slot)
             if self._missq_share < 256:
-                self._device_tail(plan.names, plan.out, miss_pos, miss_fullid, miss_count, R, sp)
+                L.check(self.lib.pg_missq_device_tail(self._missq, slot, sp), "pg_missq_device_tail")
         else:
             for name in plan.names:
                 tab = _table(self.graph, name)
@@ -724,21 +724,14 @@ class GraphCacheServer:
                                                    L.ptr(plan.slots) if dd is not None else None, sp),
                     "pg_missq_submit_range")
             self._missq_pending.add(slot)
+            if self._missq_share < 256:      # the device reads the tail of the list into the staged block itself
+                L.check(self.lib.pg_missq_device_tail(self._missq, slot, sp), "pg_missq_device_tail")
 
     def _plan_dedup(self, plan, slot):
         """the plan's pg_dedup_t (built at its first fetch: the slot's queue buffers exist by then), or None"""
         if plan.dedup is False:
             plan.dedup = self._dedup_for(slot, plan.layer_lo, plan.first_layer, plan.num_layers, plan.same_fields)
         return plan.dedup
-
-    def _device_tail(self, names, out, miss_pos, miss_fullid, miss_count, R, sp):
-        """the share of the miss list the worker leaves alone: read over PCIe by the device, on the fetching stream"""
-        for name in names:
-            tab = _table(self.graph, name)
-            o = out[name]
-            L.check(self.lib.pg_scatter_rows_from_host_tail(L.ptr(tab), tab.stride(0), miss_pos, miss_fullid, R, miss_count,
-                                                            self._missq_share, self.dims[name], L.ptr(o), o.stride(0), sp),
-                    "pg_scatter_rows_from_host_tail")
 
     def _missq_buffers(self, slot, rows):
         hit = self._missq_bufs.get(slot)
@@ -781,6 +774,52 @@ class GraphCacheServer:
                                                ctypes.byref(cnt)), "pg_missq_slot_buffers")
         self._missq_bufs[slot] = (pos, full, cnt)
         return pos, full, cnt
+
+    def adapt_cpu_share(self, min_jobs=8, floor_GBps=None, quiet=False):
+        """Set `cpu_share` from what this rank's host can really do (VERDICT r02 #1a). The async queue moves a miss list
+        in two legs that overlap across minibatches: the CPU row gather (latency bound, scales with the threads the
+        process may use) and the copy over PCIe. On a host with few free cores (eight ranks sharing a CPU quota, a busy
+        neighbour) the gather, not PCIe, bounds the step. The worker's counters give the gather rate of the last jobs;
+        the rows it cannot gather within the list's PCIe time are handed to the device, which reads them from the
+        pinned table itself (pg_missq_device_tail) — down to share 0, the pure zero-copy path. Shares >= 0.9 round up
+        to 1 (a device-side PCIe read slows the concurrent compute kernels: not worth a 10 % shorter gather).
+        Returns the dict it logged, or None when there is nothing to go by yet (no queue / fewer than `min_jobs` jobs
+        since the last call / pageable tables)."""
+        st = self.miss_queue_stats()
+        if st is None:
+            return None
+        prev = getattr(self, "_adapt_prev", None)
+        jobs = st["jobs"] - (prev["jobs"] if prev else 0)
+        if jobs < min_jobs:
+            return None
+        rows = st["rows_per_job"] * st["jobs"] - (prev["rows_per_job"] * prev["jobs"] if prev else 0.0)
+        gather_us = st["us_cpu_gather"] * st["jobs"] - (prev["us_cpu_gather"] * prev["jobs"] if prev else 0.0)
+        self._adapt_prev = st
+        pinned = getattr(self.graph, "pinned", None)
+        if rows <= 0 or gather_us <= 0 or (pinned is not None and not all(pinned.get(n, False) for n in self.dims)):
+            return None
+        row_bytes = 4 * sum(self.dims.values())
+        rate = floor_GBps
+        if rate is None:
+            eng = [v for b, v in st["sdma_engine_h2d_GBps"].items() if st["sdma_engine_mask"] >> b & 1]
+            rate = eng[0] if eng else 50.0
+        us_per_row_cpu = gather_us / rows                  # what the gather pool achieves, all its threads together
+        us_per_row_pcie = row_bytes / (rate * 1e3)
+        want = min(1.0, us_per_row_pcie / us_per_row_cpu)  # share of a list the CPU finishes within the list's PCIe time
+        old = self.cpu_share
+        # the measured rate belongs to the OLD share's list length; per-row time is roughly length-independent
+        new = 1.0 if want >= 0.9 else (0.0 if want < 0.1 else round(want * 16) / 16)
+        rec = {"us_per_row_cpu_gather": us_per_row_cpu, "us_per_row_pcie": us_per_row_pcie, "cpu_share_before": old,
+               "cpu_share": new, "jobs_measured": int(jobs), "host_threads": self.host_threads}
+        if new != old:
+            self.cpu_share = new
+            # (takes effect at the next _missq_buffers call; dedup plans are rebuilt because their validity depends on it)
+            self._missq_bufs = {}
+            self._cache_epoch += 1
+        if not quiet:
+            print("GraphCacheServer: CPU gather {:.3f} us/row vs PCIe {:.3f} us/row -> cpu_share {} (was {})".format(
+                us_per_row_cpu, us_per_row_pcie, new, old))
+        return rec
 
     def _dedup_for(self, slot, offsets_rel, first_layer, num_layers, same_fields=True):
         """pg_dedup_t over the slot's dup buffers for a launch whose rows are the NodeFlow layers first_layer.. laid out at

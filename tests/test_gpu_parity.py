@@ -1682,7 +1682,7 @@ def _fused_gather_aggregate_case(dev, hiplib, oracle, ratio, p_drop, reduce, Fd)
 
 
 @pytest.mark.parametrize("arch", ["gcn", "sage"])
-@pytest.mark.parametrize("mode", ["async", "full"])
+@pytest.mark.parametrize("mode", ["async", "full", "async-split", "async-device-only"])
 def test_virtual_layer0_matches_materialised(dev, hiplib, arch, mode):
     """fetch_data(virtual=model.virtual_inputs()): logits and gradients equal the materialised path bit for bit,
     with dropout on (same Philox counters), for a partial cache over the async miss queue and for a full cache"""
@@ -1699,6 +1699,9 @@ def test_virtual_layer0_matches_materialised(dev, hiplib, arch, mode):
     store = HostFeatureStore({"features": torch.from_numpy(feats)})
     c = GraphCacheServer(store, V, torch.arange(V), 0, miss_mode="async")
     c.init_field(["features"])
+    # async-split / async-device-only: the worker moves the head of every miss list, the device reads the tail from the
+    # host table straight into the staged block (pg_missq_device_tail) — what adapt_cpu_share picks on a starved host
+    c.cpu_share = {"async-split": 0.4, "async-device-only": 0.0}.get(mode, 1.0)
     c.auto_cache(g, ["features"], cache_ratio=1.0 if mode == "full" else 0.3)
     assert c.full_cached == (mode == "full")
     torch.manual_seed(5)
@@ -1727,6 +1730,30 @@ def test_virtual_layer0_matches_materialised(dev, hiplib, arch, mode):
         assert torch.equal(outs[0][0], outs[1][0])
         for a, b in zip(outs[0][1], outs[1][1]):
             assert torch.equal(a, b)
+    if mode == "async":
+        # adapt_cpu_share: derived from the worker's own counters; a pretended slow gather shifts rows to the device
+        assert c.adapt_cpu_share(min_jobs=10 ** 6) is None            # not enough jobs to go by
+        rec = c.adapt_cpu_share(min_jobs=1, quiet=True)
+        assert rec is not None and 0.0 <= rec["cpu_share"] <= 1.0 and rec["us_per_row_cpu_gather"] > 0
+        c._adapt_prev = None
+        rec = c.adapt_cpu_share(min_jobs=1, floor_GBps=1e6, quiet=True)   # an "infinitely fast" PCIe: the CPU can never keep up
+        assert rec["cpu_share"] == 0.0 and c.cpu_share == 0.0
+        nf = next(it)
+        c.fetch_data(nf, need=need, slot=0, virtual=virt)
+        c.wait_misses(0)
+        torch.cuda.synchronize()
+        ids0 = nf.layer_parent_nid(0).cpu().numpy()
+        out = ops_aggregate_identity(nf._node_frames[0]["features"], dev)
+        assert np.array_equal(out, feats[ids0])
+
+
+def ops_aggregate_identity(rows, dev):
+    """materialise a RowSource through the fused kernel: identity block, sum, no dropout"""
+    from pagraph_amd import ops
+    n = rows.shape[0]
+    ip = torch.arange(n + 1, dtype=torch.int32, device=dev)
+    sr = torch.arange(n, dtype=torch.int32, device=dev)
+    return ops.aggregate_rows(ip, sr, rows, n, "sum").cpu().numpy()
 
 
 # ---- config 3 at full size: RMAT 10 M vertices / 100 M undirected edges, feat 600, GraphSAGE, 30 % cache -----------
