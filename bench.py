@@ -128,8 +128,9 @@ def parse():
     p.add_argument("--timeline", action="store_true", help="print a per-stream event timeline of a few steps (stderr)")
     p.add_argument("--no-transpose", action="store_true", help="sampler does not emit source-major blocks "
                    "(backward aggregation falls back to the atomic scatter form)")
-    p.add_argument("--cpu-share", type=float, default=1.0, help="async miss path: share of every miss list that goes "
-                   "through the worker thread; the rest is read by the device over PCIe (1.0 = all)")
+    p.add_argument("--cpu-share", type=float, default=None, help="async miss path: share of every miss list that goes "
+                   "through the worker thread; the rest is read by the device over PCIe (1.0 = all). Given: fixed. "
+                   "Default: start at 1.0 and adapt after the set-up steps")
     p.add_argument("--inline-transpose", action="store_true", help="build the source-major blocks inside the sampler's "
                    "chain instead of on the trainer's load stream")
     p.add_argument("--probe-miss-mode", action="store_true", help="time a few steps with the zero-copy and with the async "
@@ -138,6 +139,10 @@ def parse():
                    "(default 2 with the async miss queue, else 1); the sampler ring needs lookahead + 2 slots")
     p.add_argument("--profile-host", action="store_true", help="cProfile the timed region (stderr)")
     p.add_argument("--dist-backend", default="nccl", help="gloo lets two ranks share one GPU (testing only)")
+    p.add_argument("--no-epoch-leg", action="store_true", help="with --steps < one epoch: do not time a whole epoch for "
+                   "`value`, scale the --steps window instead (the old behaviour)")
+    p.add_argument("--no-adapt-cpu-share", action="store_true", help="keep --cpu-share as given; default: after the set-up "
+                   "steps every rank sets it from its own CPU-gather rate vs PCIe (GraphCacheServer.adapt_cpu_share)")
     return p.parse_args()
 
 
@@ -164,13 +169,31 @@ def make_host_table(V, Fdim, rank, local_rank, world, dev, tag):
             tab = torch.from_file(path, shared=True, size=V * Fdim, dtype=torch.float32).view(V, Fdim)
             syn.fill_random_features(tab, device=dev)
         except Exception as e:
-            log(f"[bench] rank {rank}: /dev/shm table failed ({e}); every rank keeps a private copy")
-            ok.zero_()
+            # /dev/shm too small (a container's default is 64 MB) or absent: a file-backed shared mapping in the temp
+            # directory is the same single copy in the page cache — never one private copy per rank by accident
+            log(f"[bench] rank {rank}: /dev/shm table failed ({e}); trying a file-backed shared mapping")
+            try:
+                import tempfile
+                path = os.path.join(tempfile.gettempdir(), os.path.basename(path))
+                tab = torch.from_file(path, shared=True, size=V * Fdim, dtype=torch.float32).view(V, Fdim)
+                syn.fill_random_features(tab, device=dev)
+            except Exception as e2:
+                log(f"[bench] rank {rank}: file-backed table failed too ({e2})")
+                ok.zero_()
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     shared = bool(ok.item())
+    paths = [path]
+    dist.broadcast_object_list(paths, src=0)       # (one node: local rank 0 is rank 0)
+    path = paths[0]
     if shared and local_rank != 0:
         tab = torch.from_file(path, shared=True, size=V * Fdim, dtype=torch.float32).view(V, Fdim)
     if not shared:
+        private_gb = V * Fdim * 4 * world / 2 ** 30
+        budget_gb = float(os.environ.get("PG_BENCH_PRIVATE_TABLE_GB", 64))
+        if private_gb > budget_gb:
+            raise SystemExit(f"bench.py: no shared mapping for the host feature table and {world} private copies would take "
+                             f"{private_gb:.0f} GB (> PG_BENCH_PRIVATE_TABLE_GB = {budget_gb:.0f}): refusing")
+        log(f"[bench] rank {rank}: every rank keeps a private copy of the table ({private_gb:.1f} GB in total)")
         tab = torch.empty((V, Fdim), dtype=torch.float32)
         syn.fill_random_features(tab, device=dev)
         path = None
@@ -356,18 +379,31 @@ def reference_equivalent_leg(args, model, loss_fcn, optimizer, cacher, g, subtra
     tr = GraphedTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, need=None, world_size=world,
                         keep_losses=False)
     S = 3 + 2 * len(sampler.slots)
-    it = cycle_batches(sampler, S + steps + 8)
+    WARM = 20
+    it = cycle_batches(sampler, S + WARM + steps + 16)
+    tr.keep_primed = True
     tr.run_steps(it, S)
+    tr.run_steps(it, WARM)                  # steady state before the clock starts, like the main loop's --warmup
     tr.synchronize()
     torch.cuda.synchronize()
     cacher._stats.zero_()
     cacher.profile = []
     mq0_ = cacher.miss_queue_stats()
+    wev = [torch.cuda.Event(enable_timing=True)]
+    def on_step(done_, loss_):
+        if done_ % 20 == 0 or done_ == steps:
+            e_ = torch.cuda.Event(enable_timing=True)
+            e_.record(tr.compute_stream)
+            wev.append(e_)
+    tr.on_step = on_step
+    wev[0].record(tr.compute_stream)
     t0 = time.time()
     tr.run_steps(it, steps)
     cacher.drain_misses()
     torch.cuda.synchronize()
     dt = time.time() - t0
+    tr.on_step = None
+    wins = [round(wev[i - 1].elapsed_time(wev[i]) / (min(i * 20, steps) - (i - 1) * 20), 5) for i in range(1, len(wev))]
     prof, cacher.profile = cacher.profile, None
     if cacher.misses_timed_out():
         raise SystemExit("bench.py: reference-equivalent leg: a device-side wait for miss rows timed out")
@@ -379,7 +415,15 @@ def reference_equivalent_leg(args, model, loss_fcn, optimizer, cacher, g, subtra
     torch.cuda.synchronize()
     mq1 = cacher.miss_queue_stats()
     moved = (mq1["rows_per_job"] * mq1["jobs"] - mq0_["rows_per_job"] * mq0_["jobs"]) / steps if mq1 and mq0_ else None
-    return {"fetch": "every layer and field (storage.py:173-204)", "steps": steps, "ms_per_step": dt / steps * 1e3,
+    gather_us = ((mq1["us_cpu_gather"] * mq1["jobs"] - mq0_["us_cpu_gather"] * mq0_["jobs"]) / max(1, mq1["jobs"] - mq0_["jobs"])
+                 if mq1 and mq0_ else None)
+    pcie_ms = moved * 4 * D / 53e6 if moved else None      # the leg's PCIe floor at the 53 GB/s the copies reach
+    return {"fetch": "every layer and field (storage.py:173-204)", "steps": steps, "warmup": WARM, "ms_per_step": dt / steps * 1e3,
+            "ms_per_step_windows": wins, "ms_per_step_median_window": float(np.median(wins)) if wins else None,
+            # which leg of the miss path bounds this step on this host: the worker's CPU row gather per job vs the
+            # list's time on PCIe (r02's driver line read 0.468 ms with a 0.6 ms gather on a busy host, the builder's
+            # 0.354-0.383 on quiet ones)
+            "us_cpu_gather_per_job": gather_us, "pcie_floor_ms_per_step": pcie_ms, "cpu_share": cacher.cpu_share,
             "rows_per_launch": R, "miss_rows_per_launch": m,
             "miss_rows_over_pcie_per_launch_after_index_dedup": moved,
             "cache_hit_pct": 100.0 * (1.0 - miss_rate),
@@ -499,7 +543,8 @@ def run():
                               host_threads=args.host_threads or default_host_threads(world))
     cacher.init_field(embed_names)
     cacher.log = True
-    cacher.cpu_share = args.cpu_share
+    adapt_share = args.cpu_share is None and not args.no_adapt_cpu_share
+    cacher.cpu_share = 1.0 if args.cpu_share is None else args.cpu_share
     D = cacher.total_dim
     PROF_RING = 1 << 14
     fuse_gather = not args.no_graph and not args.fetch_all and not args.no_fuse_gather
@@ -545,7 +590,7 @@ def run():
     trainer.after_first_step = lambda: cacher.auto_cache(g, embed_names, cache_ratio=args.cache_ratio)  # pa_gcn.py:99-100
     model.train()
     PROBE = 40
-    it = cycle_batches(sampler, 2 * S + W + K + 8 + (4 * PROBE + 64 if probe_modes else 0))
+    it = cycle_batches(sampler, 4 * S + W + K + steps_per_epoch + 64 + (4 * PROBE + 64 if probe_modes else 0))
 
     # ---- set-up (untimed, one-off: the cache is filled after its first step, as in the reference; graph capture) ----
     t0 = time.time()
@@ -569,6 +614,19 @@ def run():
         cacher.shutdown_miss_queue()
         cacher.host_wait = True
         trainer.run_steps(it, S)
+        torch.cuda.synchronize()
+    # ---- every rank sizes its CPU leg of the miss path from what its host can really do (VERDICT r02 #1a) ----
+    share_rec = None
+    if adapt_share and use_graph and cacher.miss_mode == "async" and not cacher.full_cached and table_device_visible:
+        trainer.run_steps(it, 12)                          # a dozen steady-state jobs for the worker's counters
+        trainer.synchronize()
+        share_rec = cacher.adapt_cpu_share(min_jobs=8)
+        if share_rec and share_rec["cpu_share"] != share_rec["cpu_share_before"]:
+            trainer.run_steps(it, S)                       # new fetch plans -> one re-capture per ring slot
+            trainer.synchronize()
+            again = cacher.adapt_cpu_share(min_jobs=8, quiet=True, apply=False)   # what the new split measures; not chased
+            share_rec["after"] = {"us_per_row_cpu_gather": again["us_per_row_cpu_gather"],
+                                  "cpu_share_it_would_pick_now": again["cpu_share"]} if again else None
         torch.cuda.synchronize()
     # ---- warm-up: W steady-state steps, untimed ----
     if W > 0:
@@ -600,137 +658,166 @@ def run():
             cacher.shutdown_miss_queue()                       # no worker / gather threads left behind
         args.miss_mode = cacher.miss_mode
         log(f"[bench] rank {rank}: miss path probe zerocopy {t_zero:.3f} ms/step, async {t_async:.3f} ms/step -> {args.miss_mode}")
-    cacher._stats.zero_()                                      # reset the try/miss counters
 
-    # ---- timed region ------------------------------------------------------------------------
-    cacher.profile = []
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    tl = None
-    if args.timeline and use_graph:
-        tl = []
-        _prep, _comp = trainer.prepare, trainer.compute
-        def prep(nf):
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(trainer.load_stream); s_ = _prep(nf); e1.record(trainer.load_stream)
-            tl.append(("load", e0, e1)); return s_
-        def comp(s_):
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            trainer.compute_stream.wait_event(s_.ready)
-            e0.record(trainer.compute_stream); r_ = _comp(s_); e1.record(trainer.compute_stream)
-            tl.append(("comp", e0, e1)); return r_
-        trainer.debug_events = []
-        trainer.prepare, trainer.compute = prep, comp
-        hostlog = []
-        def wrap(obj, name, tag):
-            f = getattr(obj, name)
-            def g_(*a, **k):
-                t0_ = time.perf_counter(); r_ = f(*a, **k); hostlog.append((tag, t0_, time.perf_counter())); return r_
-            setattr(obj, name, g_)
-        samp_ev = []
-        _enq = sampler._enqueue
-        def enq(b_, e_):
-            a0 = torch.cuda.Event(enable_timing=True); a1 = torch.cuda.Event(enable_timing=True); a2 = torch.cuda.Event(enable_timing=True)
-            a0.record(sampler.stream)
-            sl = sampler.slots[sampler._ring_pos % len(sampler.slots)]
-            if sl.free_recorded:
-                sampler.stream.wait_event(sl.free)
-            a1.record(sampler.stream)
-            r_ = _enq(b_, e_); a2.record(sampler.stream); samp_ev.append((a0, a1, a2)); return r_
-        sampler._enqueue = enq
-        wrap(cacher, "wait_misses", "wait_misses"); wrap(cacher, "fetch_data", "fetch_data"); wrap(sampler, "_enqueue", "sampler_enqueue")
-        wrap(sampler, "release", "release")
-    prof_host = None
-    if args.profile_host:
-        import cProfile
-        prof_host = cProfile.Profile()
-        prof_host.enable()
-    # per-window step times: one event on the compute stream every `window` steps (first one = start of the region)
-    win = max(1, min(args.window, K))
-    cstream = trainer.compute_stream if use_graph else torch.cuda.current_stream(dev)
-    wev = [torch.cuda.Event(enable_timing=True)]
-    host_t = []
-    def on_step(done_, loss_):
-        host_t.append(time.perf_counter())
-        if done_ % win == 0 or done_ == K:
-            e_ = torch.cuda.Event(enable_timing=True)
-            e_.record(cstream)
-            wev.append(e_)
-    trainer.on_step = on_step
-    mq0 = cacher.miss_queue_stats()
-    cg0 = cgroup_cpu_stat()
-    drop_step0 = int(model._drop_step.item()) if hasattr(model, "_drop_step") else 0
-    wev[0].record(cstream)
-    t0 = time.time()
-    done = trainer.run_steps(it, K)
-    t_issued = time.time() - t0          # launch thread done; ~= elapsed when the host is the bottleneck
-    if not os.environ.get("PG_BENCH_NO_DRAIN"):
-        cacher.drain_misses()            # worker's outstanding copies enqueued (host-side wait, no HIP call) ...
-    torch.cuda.synchronize()             # ... then the device
-    if world > 1:
-        dist.barrier()
-    elapsed = time.time() - t0
-    trainer.on_step = None
-    cg1 = cgroup_cpu_stat()
-    cpu_quota = None
-    if cg0 and cg1:      # was the process throttled by its CPU quota inside the timed region? how many CPUs did it use?
-        cpu_quota = {"nr_throttled": cg1[0] - cg0[0], "throttled_ms": (cg1[1] - cg0[1]) / 1e3,
-                     "cpus_used": (cg1[2] - cg0[2]) / 1e6 / max(1e-9, elapsed)}
-    windows = []
-    for i_ in range(1, len(wev)):
-        n_ = min(i_ * win, K) - (i_ - 1) * win
-        windows.append(round(wev[i_ - 1].elapsed_time(wev[i_]) / max(1, n_), 5))
-    # the launch thread's three longest iterations (ms, step index): a stall of the host shows here, one of the GPU /
-    # miss path only in ms_per_step_windows
-    hd = np.diff(np.asarray(host_t)) * 1e3 if len(host_t) > 1 else np.zeros(0)
-    host_longest = [[round(float(hd[i_]), 3), int(i_) + 1] for i_ in np.argsort(-hd)[:3]] if len(hd) else []
-    launch_split = None
-    if getattr(trainer, "launch_trace", None):
-        # PG_TRACE_LAUNCH=1: [sample + prepare, compute, release] ms of the trainer's three longest iterations
-        lt = np.asarray(trainer.launch_trace)
-        launch_split = [[int(i_)] + [round(float(x), 3) for x in lt[i_]] for i_ in np.argsort(-lt.sum(1))[:3]]
-    timed_out = bool(cacher.misses_timed_out())
-    copy_windows = None
-    if os.environ.get("PG_MISSQ_COPYLOG"):
-        cl = cacher.miss_copy_log()[-K:]
-        if os.environ.get("PG_MISSQ_COPYLOG") == "2":
-            log("[copylog] " + " ".join(f"{b / max(1e-9, m) / 1e6:.0f}" for b, m in cl))
-        copy_windows = [round(sum(b for b, _ in cl[i:i + win]) / max(1e-9, sum(m for _, m in cl[i:i + win])) / 1e6, 2)
-                        for i in range(0, len(cl), win)]       # GB/s of the H2D copies per window
-    mq_stats = cacher.miss_queue_stats()
-    if mq_stats and mq0:
-        mq_stats["timed_region"] = {k_: mq_stats[k_] - mq0[k_] for k_ in ("jobs", "waits_by_event", "waits_by_spin_kernel")}
-        # rows the worker really moved over PCIe (after the miss list's index dedup) per step of the timed region
-        mq_stats["timed_region"]["rows_over_pcie_per_step"] = (mq_stats["rows_per_job"] * mq_stats["jobs"]
-                                                               - mq0["rows_per_job"] * mq0["jobs"]) / max(1, K)
-    if timed_out:
-        raise SystemExit("bench.py: the async miss queue's device-side wait timed out (worker thread dead?) — "
-                         "the timed steps trained on rows that never landed; no number is reported")
-    if tl and getattr(trainer, "debug_events", None):
-        for ev in trainer.debug_events[30:42]:
-            log(f"[load-stream] wait(sampler ready) {ev[0].elapsed_time(ev[1])*1e3:8.1f} us | wait(slot done) {ev[1].elapsed_time(ev[2])*1e3:8.1f} us | work {ev[2].elapsed_time(ev[3])*1e3:8.1f} us")
-    if tl:
-        for a0, a1, a2 in samp_ev[30:40]:
-            log(f"[sampler-stream] wait(slot free) {a0.elapsed_time(a1)*1e3:8.1f} us | sampling kernels {a1.elapsed_time(a2)*1e3:8.1f} us")
-    if tl:
-        hb = hostlog[len(hostlog) // 2][1]
-        for tag, a_, b_ in hostlog[len(hostlog) // 2: len(hostlog) // 2 + 40]:
-            log(f"[host] {tag:16s} +{(a_-hb)*1e6:9.1f} us  took {(b_-a_)*1e6:8.1f} us")
-        base = tl[20][1]
-        for name, e0, e1 in tl[20:60]:
-            log(f"[timeline] {name} start {base.elapsed_time(e0)*1e3:9.1f} us  dur {e0.elapsed_time(e1)*1e3:8.1f} us")
-    if prof_host is not None:
-        import pstats
-        prof_host.disable()
-        pstats.Stats(prof_host, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
-    assert done == K, (done, K)
-    elapsed = parallel.max_over_ranks(elapsed, device=dev)
-    prof, cacher.profile = cacher.profile, None
-    tries_total, miss_total = cacher._stats.tolist()          # accumulated on the device by k_split
-    miss_rate = cacher.get_miss_rate()
-    ms_per_step = elapsed * 1e3 / K
-    epoch_s = ms_per_step * steps_per_epoch / 1e3
+    # ---- timed regions ------------------------------------------------------------------------
+    tl_state = {"armed": bool(args.timeline and use_graph)}
+
+    def timed_region(K_, tag):
+        """exactly K_ steps between (barrier +) device-wide syncs; everything the line reports about a region"""
+        cacher._stats.zero_()                                    # the reference's try / miss counters, per region
+        cacher.profile = []
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tl = None
+        if tl_state["armed"]:
+            tl_state["armed"] = False
+            tl = []
+            _prep, _comp = trainer.prepare, trainer.compute
+            def prep(nf):
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(trainer.load_stream); s_ = _prep(nf); e1.record(trainer.load_stream)
+                tl.append(("load", e0, e1)); return s_
+            def comp(s_):
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                trainer.compute_stream.wait_event(s_.ready)
+                e0.record(trainer.compute_stream); r_ = _comp(s_); e1.record(trainer.compute_stream)
+                tl.append(("comp", e0, e1)); return r_
+            trainer.debug_events = []
+            trainer.prepare, trainer.compute = prep, comp
+            hostlog = []
+            def wrap(obj, name, tag_):
+                f = getattr(obj, name)
+                def g_(*a, **k):
+                    t0_ = time.perf_counter(); r_ = f(*a, **k); hostlog.append((tag_, t0_, time.perf_counter())); return r_
+                setattr(obj, name, g_)
+            samp_ev = []
+            _enq = sampler._enqueue
+            def enq(b_, e_):
+                a0 = torch.cuda.Event(enable_timing=True); a1 = torch.cuda.Event(enable_timing=True); a2 = torch.cuda.Event(enable_timing=True)
+                a0.record(sampler.stream)
+                sl = sampler.slots[sampler._ring_pos % len(sampler.slots)]
+                if sl.free_recorded:
+                    sampler.stream.wait_event(sl.free)
+                a1.record(sampler.stream)
+                r_ = _enq(b_, e_); a2.record(sampler.stream); samp_ev.append((a0, a1, a2)); return r_
+            sampler._enqueue = enq
+            wrap(cacher, "wait_misses", "wait_misses"); wrap(cacher, "fetch_data", "fetch_data"); wrap(sampler, "_enqueue", "sampler_enqueue")
+            wrap(sampler, "release", "release")
+        prof_host = None
+        if args.profile_host and tag == "window":
+            import cProfile
+            prof_host = cProfile.Profile()
+            prof_host.enable()
+        # per-window step times: one event on the compute stream every `window` steps (first one = start of the region)
+        win = max(1, min(args.window, K_))
+        cstream = trainer.compute_stream if use_graph else torch.cuda.current_stream(dev)
+        wev = [torch.cuda.Event(enable_timing=True)]
+        host_t = []
+        def on_step(done_, loss_):
+            host_t.append(time.perf_counter())
+            if done_ % win == 0 or done_ == K_:
+                e_ = torch.cuda.Event(enable_timing=True)
+                e_.record(cstream)
+                wev.append(e_)
+        trainer.on_step = on_step
+        if getattr(trainer, "launch_trace", None) is not None:
+            trainer.launch_trace = []
+        mq0 = cacher.miss_queue_stats()
+        cg0 = cgroup_cpu_stat()
+        drop_step0 = int(model._drop_step.item()) if hasattr(model, "_drop_step") else 0
+        wev[0].record(cstream)
+        t0 = time.time()
+        done = trainer.run_steps(it, K_)
+        t_issued = time.time() - t0          # launch thread done; ~= elapsed when the host is the bottleneck
+        if not os.environ.get("PG_BENCH_NO_DRAIN"):
+            cacher.drain_misses()            # worker's outstanding copies enqueued (host-side wait, no HIP call) ...
+        torch.cuda.synchronize()             # ... then the device
+        if world > 1:
+            dist.barrier()
+        elapsed = time.time() - t0
+        trainer.on_step = None
+        assert done == K_, (done, K_)
+        cg1 = cgroup_cpu_stat()
+        cpu_quota = None
+        if cg0 and cg1:      # was the process throttled by its CPU quota inside the region? how many CPUs did it use?
+            cpu_quota = {"nr_throttled": cg1[0] - cg0[0], "throttled_ms": (cg1[1] - cg0[1]) / 1e3,
+                         "cpus_used": (cg1[2] - cg0[2]) / 1e6 / max(1e-9, elapsed)}
+        windows = []
+        for i_ in range(1, len(wev)):
+            n_ = min(i_ * win, K_) - (i_ - 1) * win
+            windows.append(round(wev[i_ - 1].elapsed_time(wev[i_]) / max(1, n_), 5))
+        # the launch thread's three longest iterations (ms, step index): a stall of the host shows here, one of the GPU /
+        # miss path only in the windows
+        hd = np.diff(np.asarray(host_t)) * 1e3 if len(host_t) > 1 else np.zeros(0)
+        host_longest = [[round(float(hd[i_]), 3), int(i_) + 1] for i_ in np.argsort(-hd)[:3]] if len(hd) else []
+        launch_split = None
+        if getattr(trainer, "launch_trace", None):
+            # PG_TRACE_LAUNCH=1: [sample + prepare, compute, release] ms of the trainer's three longest iterations
+            lt = np.asarray(trainer.launch_trace)
+            launch_split = [[int(i_)] + [round(float(x), 3) for x in lt[i_]] for i_ in np.argsort(-lt.sum(1))[:3]]
+        timed_out = bool(cacher.misses_timed_out())
+        copy_windows = None
+        if os.environ.get("PG_MISSQ_COPYLOG"):
+            cl = cacher.miss_copy_log()[-K_:]
+            if os.environ.get("PG_MISSQ_COPYLOG") == "2":
+                log("[copylog] " + " ".join(f"{b / max(1e-9, m) / 1e6:.0f}" for b, m in cl))
+            copy_windows = [round(sum(b for b, _ in cl[i:i + win]) / max(1e-9, sum(m for _, m in cl[i:i + win])) / 1e6, 2)
+                            for i in range(0, len(cl), win)]       # GB/s of the H2D copies per window
+        mq_stats = cacher.miss_queue_stats()
+        if mq_stats and mq0:
+            tr_ = {k_: mq_stats[k_] - mq0[k_] for k_ in ("jobs", "waits_by_event", "waits_by_spin_kernel", "rescued_chunks")}
+            # rows the worker really moved over PCIe (after the miss list's index dedup) per step of the region
+            tr_["rows_over_pcie_per_step"] = (mq_stats["rows_per_job"] * mq_stats["jobs"] - mq0["rows_per_job"] * mq0["jobs"]) / max(1, K_)
+            tr_["us_cpu_gather"] = ((mq_stats["us_cpu_gather"] * mq_stats["jobs"] - mq0["us_cpu_gather"] * mq0["jobs"])
+                                    / max(1, tr_["jobs"]))
+            mq_stats["timed_region"] = tr_
+        if timed_out:
+            raise SystemExit("bench.py: the async miss queue's device-side wait timed out (worker thread dead?) — "
+                             "the timed steps trained on rows that never landed; no number is reported")
+        if tl and getattr(trainer, "debug_events", None):
+            for ev in trainer.debug_events[30:42]:
+                log(f"[load-stream] wait(sampler ready) {ev[0].elapsed_time(ev[1])*1e3:8.1f} us | wait(slot done) {ev[1].elapsed_time(ev[2])*1e3:8.1f} us | work {ev[2].elapsed_time(ev[3])*1e3:8.1f} us")
+        if tl:
+            for a0, a1, a2 in samp_ev[30:40]:
+                log(f"[sampler-stream] wait(slot free) {a0.elapsed_time(a1)*1e3:8.1f} us | sampling kernels {a1.elapsed_time(a2)*1e3:8.1f} us")
+            hb = hostlog[len(hostlog) // 2][1]
+            for tag_, a_, b_ in hostlog[len(hostlog) // 2: len(hostlog) // 2 + 40]:
+                log(f"[host] {tag_:16s} +{(a_-hb)*1e6:9.1f} us  took {(b_-a_)*1e6:8.1f} us")
+            base = tl[20][1]
+            for name, e0, e1 in tl[20:60]:
+                log(f"[timeline] {name} start {base.elapsed_time(e0)*1e3:9.1f} us  dur {e0.elapsed_time(e1)*1e3:8.1f} us")
+        if prof_host is not None:
+            import pstats
+            prof_host.disable()
+            pstats.Stats(prof_host, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
+        elapsed = parallel.max_over_ranks(elapsed, device=dev)
+        prof, cacher.profile = cacher.profile, None
+        tries_total, miss_total = cacher._stats.tolist()          # accumulated on the device by k_split
+        miss_rate = cacher.get_miss_rate() if tries_total else 0.0
+        drop_step1 = int(model._drop_step.item()) if hasattr(model, "_drop_step") else 0
+        return {"tag": tag, "steps": K_, "elapsed": elapsed, "ms_per_step": elapsed * 1e3 / K_, "t_issued": t_issued,
+                "windows": windows, "win": win, "host_longest": host_longest, "launch_split": launch_split,
+                "cpu_quota": cpu_quota, "mq_stats": mq_stats, "copy_windows": copy_windows, "prof": prof,
+                "tries_total": tries_total, "miss_total": miss_total, "miss_rate": miss_rate,
+                "drop_steps": (drop_step0, drop_step1), "timed_out": timed_out}
+
+    # (1) the driver's window: exactly K steps after W warm-up steps — `ms_per_step`
+    reg_win = timed_region(K, "window")
+    # (2) one whole epoch of this rank's (equalised) seeds, measured, for `value` — unless the window already was one.
+    #     0.16 s at N = 1: there is no reason to extrapolate an epoch from 20 steps (VERDICT r02).
+    reg_epoch = reg_win
+    if K < steps_per_epoch and not args.no_epoch_leg:
+        reg_epoch = timed_region(steps_per_epoch, "epoch")
+    big = reg_epoch if reg_epoch["steps"] >= reg_win["steps"] else reg_win     # the region with more launches behind its statistics
+    elapsed, ms_per_step = reg_win["elapsed"], reg_win["ms_per_step"]
+    epoch_s = reg_epoch["elapsed"] * steps_per_epoch / reg_epoch["steps"]
+    windows, win, host_longest, launch_split = big["windows"], big["win"], big["host_longest"], big["launch_split"]
+    cpu_quota, mq_stats, copy_windows, timed_out = big["cpu_quota"], big["mq_stats"], big["copy_windows"], False
+    prof, tries_total, miss_total, miss_rate = big["prof"], big["tries_total"], big["miss_total"], big["miss_rate"]
+    t_issued = big["t_issued"]
+    drop_step0, drop_step1 = big["drop_steps"]
+    K_big = big["steps"]
 
     # ---- in-loop time of the dominant HBM-bound kernel --------------------------------------------------
     avg_ms, rows_per_launch, miss_per_launch, bytes_per_launch = gather_launch_stats_from(tries_total, miss_total, prof, D)
@@ -739,15 +826,15 @@ def run():
                   "rows_per_launch": rows_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
                   "timing": "HIP events attached to each dispatch on the load stream"} if prof else None
     fused_rec = None
-    drop_step1 = int(model._drop_step.item()) if hasattr(model, "_drop_step") else 0
     if fuse_gather and cacher.rows_prof is not None and drop_step1 > drop_step0:
         # pg_spmm_fwd_rows (gather fused into the layer-0 aggregation) runs inside the replayed hipGraph, where HIP
         # events cannot be attached to one kernel: it stamps the device wall clock (100 MHz) at its start and end
         # into ring entry (dropout step % ring); entries [drop_step0+1, drop_step1] are the timed steps
         ring = cacher.rows_prof[0].view(-1, 3)
         # (when the optimiser's launch advances the counter it holds the value the NEXT forward uses: shift by one)
-        shift = 0 if getattr(model, "_drop_step_external", False) else 1
-        idx = torch.arange(drop_step0 + shift, drop_step1 + shift, device=dev) % PROF_RING
+        shift = 0 if getattr(model, "_drop_step_primed", False) else 1
+        first = max(drop_step0, drop_step1 - PROF_RING + 1)          # the ring keeps the last PROF_RING launches
+        idx = torch.arange(first + shift, drop_step1 + shift, device=dev) % PROF_RING
         st = ring[idx].cpu().numpy().astype(np.int64)
         st = st[(st[:, 1] > st[:, 0]) & (st[:, 0] > 0)]
         if len(st):
@@ -825,9 +912,25 @@ def run():
             cpu["all_cores"] = "same as the 16-thread leg: the process may use exactly 16 CPUs (cgroup quota)"
 
     seeds_total = parallel.sum_over_ranks(K * B, device=dev)
+    # ---- what every rank saw (VERDICT r02 #1d): the line used to carry rank 0's host / miss-queue blocks only ----
+    mine = {"rank": rank, "gpu": gpu, "partition_vertices": Vs, "train_vertices": int(subtrain.numel()),
+            "cached_rows": int(cacher.cached_num), "ms_per_step_window_local": reg_win["ms_per_step"],
+            "epoch_s_local": reg_epoch["elapsed"] * steps_per_epoch / reg_epoch["steps"],
+            "cache_hit_pct_rows_fetched": 100.0 * (1.0 - miss_rate), "cpu_share": cacher.cpu_share, "cpu_share_adapt": share_rec,
+            "miss_mode": cacher.miss_mode, "miss_wait": "host" if cacher.host_wait else "device",
+            "allreduce_in_graph": getattr(trainer, "allreduce_in_graph", None) if world > 1 else None,
+            "miss_mode_probe": mode_probe, "host": dict(host_info(cacher), timed_region_cgroup=cpu_quota),
+            "miss_queue": mq_stats, "host_longest_iterations_ms": host_longest,
+            "slowest_window_ms_per_step": max(windows) if windows else None}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     out = None
     if rank == 0:
         out = {
+            # value: ONE WHOLE EPOCH, measured (config.epoch_steps_timed steps between device-wide syncs, max over ranks);
+            # ms_per_step: the --steps window the driver asked for, timed the same way right before it
             "metric": "epoch_time_s", "value": epoch_s, "unit": "s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -835,7 +938,11 @@ def run():
                                    f"2-layer {'GCN' if args.model == 'gcn' else 'GraphSAGE-mean'} hidden {hidden}, "
                                    f"batch {B}, fan-out {k}, {int(args.cache_ratio*100)}% hot-degree cache, "
                                    f"{('dg(hops=%d)' % args.dg_hops) if world > 1 else '1naive'} partition x{world}, closure hops {num_hops}",
-                       "steps_per_epoch": steps_per_epoch, "epoch_time_extrapolated_from_steps": K,
+                       "steps_per_epoch": steps_per_epoch, "epoch_steps_timed": reg_epoch["steps"],
+                       "epoch_ms_per_step": reg_epoch["ms_per_step"], "window_ms_per_step": reg_win["ms_per_step"],
+                       "window_ms_per_step_windows": reg_win["windows"],
+                       "statistics_from": big["tag"],     # which region the windows / roofline / miss-queue blocks describe
+                       "cpu_share": cacher.cpu_share, "cpu_share_adapt": share_rec,
                        "setup_steps": S, "pipeline": "cold (drained before the timed region)" if args.cold_start else "primed",
                        "miss_mode": args.miss_mode, "miss_wait": "host" if cacher.host_wait else "device",
                        "miss_mode_probe": mode_probe, "overlap": not args.no_overlap,
@@ -847,18 +954,19 @@ def run():
             # reference-equivalent leg when the timed loop itself fetches only what the model reads
             "cache_hit_pct": (ref_eq["cache_hit_pct"] if isinstance(ref_eq, dict) else 100.0 * (1.0 - miss_rate)),
             "cache_hit_pct_rows_fetched_by_timed_loop": 100.0 * (1.0 - miss_rate),
-            "miss_rows_per_step_reference_counting": miss_total / max(1, K),
+            "miss_rows_per_step_reference_counting": miss_total / max(1, K_big),
             "miss_list_index_dedup": bool(cacher.dedup_misses and cacher.miss_mode == "async"),
             "reference_equivalent": ref_eq,
             "cache_hit_oracle_upper_bound_pct": opt_hit, "cache_hit_degree_policy_on_trace_pct": deg_hit,
             "feat_gather_GBps": (micro[1 << 20]["GBps"] if micro else achieved),
             "seeds_per_s": seeds_total / elapsed,
-            "host_issue_ms_per_step": t_issued / K * 1e3,     # launch thread's share; == ms_per_step when it is the bottleneck
+            "host_issue_ms_per_step": t_issued / K_big * 1e3,     # launch thread's share; == ms_per_step when it is the bottleneck
             "ms_per_step_windows": windows, "window_steps": win, "host_longest_iterations_ms": host_longest, "launch_thread_longest_split_ms": launch_split,
             "warmup_requested": args.warmup, "misses_timed_out": timed_out,
             "host": dict(host_info(cacher), timed_region_cgroup=cpu_quota), "miss_queue": mq_stats, "miss_copy_GBps_windows": copy_windows,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "ranks": per_rank,
         }
     if world > 1:
         dist.barrier()

@@ -263,6 +263,9 @@ int pg_missq_stats(pg_missq_t* q, double out[8]);
  * scatter of a direct job, finds them); a field whose rows the WORKER scatters (no direct SDMA path) is scattered to
  * its frame here instead. No-op at share 1. The host table must be page-locked / registered.                       */
 int pg_missq_device_tail(pg_missq_t* q, int slot, pg_stream_t stream);
+/* call on the fetching stream BEFORE the split of the slot's next submission when cpu_share < 1: the previous
+ * submission's device tail (which runs on the queue's own stream) still reads the slot's miss list              */
+int pg_missq_order_after_tail(pg_missq_t* q, int slot, pg_stream_t stream);
 int pg_missq_copy_engine(pg_missq_t* q, uint32_t* engine_mask, double GBps[16]);
 /* chunks (32 rows) of the CPU row gather that the worker re-executed because the pool thread that had claimed them was
  * overdue (lost its CPU with the chunk in hand): each one is a multi-millisecond stall of the step that did not happen */

@@ -107,6 +107,7 @@ _SIGS = {
     "pg_missq_stats": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double)]),
     "pg_missq_copy_engine": (ctypes.c_int, [vp, ctypes.POINTER(c_u32), ctypes.POINTER(ctypes.c_double)]),
     "pg_missq_device_tail": (ctypes.c_int, [vp, ctypes.c_int, vp]),
+    "pg_missq_order_after_tail": (ctypes.c_int, [vp, ctypes.c_int, vp]),
     "pg_missq_rescued_chunks": (ctypes.c_int, [vp, ctypes.POINTER(c_i64)]),
     "pg_missq_copy_log": (ctypes.c_int, [vp, vp, vp, c_i64, ctypes.POINTER(c_i64)]),
     "pg_sampler_create": (ctypes.c_int, [c_i64, vp, vp, c_i32, c_i32, c_i32, ctypes.POINTER(vp)]),

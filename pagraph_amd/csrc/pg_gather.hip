@@ -310,6 +310,59 @@ __global__ __launch_bounds__(256) void k_scatter_host(const float* __restrict__ 
     }
   }
 }
+// k_scatter_host_wide: the same job with few waves that each keep MANY reads in flight. In the training loop the zero-copy
+// reads share the chip with the HBM-bound kernels of the other streams, and what those pay for is the NUMBER of waves
+// parked on PCIe reads, not the bytes in flight (round 3, share 0 of every miss list through this kernel: 24 blocks
+// 0.219 ms/step, 48 -> 0.250, 96 -> 0.279, 192 -> 0.288 with the fused gather+aggregate kernel at 86 us instead of 19).
+// Each wave therefore takes kRowsWide rows at a time and issues every piece of all of them (rows of <= 4 * 64 pieces)
+// before the first store: 12 KB in flight per wave at F = 600.
+constexpr int kRowsWide = 4;
+template <int VEC, int P>
+__global__ __launch_bounds__(256) void k_scatter_host_wide(const float* __restrict__ table, int64_t table_stride,
+                                                           const int32_t* __restrict__ pos,
+                                                           const int64_t* __restrict__ fullid, int64_t n,
+                                                           const int32_t* __restrict__ n_dev, int32_t dim,
+                                                           float* __restrict__ out, int32_t out_stride,
+                                                           int32_t start_num, int32_t pos_lo) {
+  using V = typename VecT<VEC>::type;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t nn = n_dev ? (int64_t)*n_dev : n;
+  const int64_t j0 = nn * start_num / 256;
+  const int64_t waves = (int64_t)gridDim.x * (blockDim.x / kWave);
+  const int pieces = dim / VEC;
+  for (int64_t jb = j0 + ((int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) * kRowsWide; jb < nn;
+       jb += waves * kRowsWide) {
+    V x[kRowsWide][P];
+    int64_t p[kRowsWide];
+#pragma unroll
+    for (int r = 0; r < kRowsWide; ++r) {
+      const int64_t j = jb + r;
+      p[r] = -1;
+      if (j < nn) {
+        p[r] = pos ? (int64_t)pos[j] - pos_lo : j;
+        if (p[r] >= 0) {
+          const V* src = reinterpret_cast<const V*>(table + fullid[j] * table_stride);
+#pragma unroll
+          for (int u = 0; u < P; ++u) {
+            const int c = lane + u * kWave;
+            if (c < pieces) x[r][u] = src[c];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kRowsWide; ++r) {
+      if (p[r] < 0) continue;
+      V* dst = reinterpret_cast<V*>(out + p[r] * out_stride);
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        const int c = lane + u * kWave;
+        if (c < pieces) dst[c] = x[r][u];
+      }
+    }
+  }
+}
+
 
 __global__ void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -621,12 +674,32 @@ int pg::scatter_host_tail(const float* table, int64_t table_stride, const int32_
   if (n_max == 0) return PG_OK;
   if (!table || !fullid || !out) return PG_ERR_INVALID;
   hipStream_t st = as_stream(stream);
-  static const int kHostBlocks = [] {
+  // (round 3, measured inside the training loop with every miss row through this kernel — profiles/r03/zero_copy_grid.txt:
+  // two-rows-per-wave kernel 8 / 16 / 24 / 48 / 96 / 192 blocks -> 0.372 / 0.231 / 0.217 / 0.250 / 0.279 / 0.288 ms/step;
+  // wide kernel 4 / 8 / 12 / 16 / 24 / 48 -> 0.484 / 0.289 / 0.221 / 0.208 / 0.222 / 0.252)
+  static const int kEnvBlocks = [] {
     const char* e = getenv("PG_SCATTER_HOST_BLOCKS");
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 48;
+    return e ? atoi(e) : 0;
   }();
+  const int kHostBlocks = kEnvBlocks > 0 ? kEnvBlocks : 24;
+  const int kWideBlocks = kEnvBlocks > 0 ? kEnvBlocks : 16;
   const int grid = grid_1d(n_max, 8, kHostBlocks);
+  static const bool narrow = getenv("PG_SCATTER_HOST_NARROW") != nullptr;     // A/B: the two-rows-per-wave kernel
+  if (!narrow && dim % 4 == 0 && dim >= 256 && dim <= 1024 && out_stride % 4 == 0 && table_stride % 4 == 0 &&
+      aligned(table, 16) && aligned(out, 16)) {
+    const int gw = grid_1d(n_max, 4 * kRowsWide, kWideBlocks);
+#define PG_WIDE(P)                                                                                                   \
+  hipLaunchKernelGGL((k_scatter_host_wide<4, P>), dim3(gw), dim3(256), 0, st, table, table_stride, pos, fullid, n_max, \
+                     n_dev, dim, out, out_stride, start_num, pos_lo)
+    const int pieces = dim / 4;
+    if (pieces <= 64) PG_WIDE(1);
+    else if (pieces <= 128) PG_WIDE(2);
+    else if (pieces <= 192) PG_WIDE(3);
+    else PG_WIDE(4);
+#undef PG_WIDE
+    PG_LAUNCH_CHECK();
+    return PG_OK;
+  }
   if (dim % 4 == 0 && out_stride % 4 == 0 && table_stride % 4 == 0 && aligned(table, 16) && aligned(out, 16))
     hipLaunchKernelGGL(k_scatter_host<4>, dim3(grid), dim3(256), 0, st, table, table_stride, pos, fullid, n_max,
                        n_dev, dim, out, out_stride, start_num, pos_lo);

@@ -237,6 +237,7 @@ class GraphCacheServer:
         # bench.py: (device int64 [3 * ring], ring) — the fused gather+aggregate kernel stamps its own start / end
         self.rows_prof = None
         self._missq_share = None
+        self._missq_tails = False
         self._cache_epoch = 0            # bumped whenever the cache contents / layout change (invalidates fetch plans)
         self.missq_slots = 4
         # miss_mode 'async': the leading share of every miss list goes through the worker thread (CPU gather + copy
@@ -461,6 +462,7 @@ class GraphCacheServer:
                 if slot is None:
                     raise L.PgError("miss_mode='async' needs fetch_data(..., slot=k)")
                 miss_pos, miss_fullid, miss_count = self._missq_buffers(slot, R)
+                self._order_after_tail(slot, sp)
         with torch.autograd.profiler.record_function('cache-gpu'):
             fields, nf = L.make_fields(
                 (self.gpu_fix_cache.get(name), out[name], self.dims[name],
@@ -495,7 +497,7 @@ class GraphCacheServer:
                                                        L.ptr(self._slots) if dd is not None else None, sp), "pg_missq_submit")
                 self._missq_pending.add(slot)
                 if self._missq_share < 256:
-                    L.check(self.lib.pg_missq_device_tail(self._missq, slot, sp), "pg_missq_device_tail")
+                    self._device_tail(slot, sp)
             elif self.miss_mode == "zerocopy":
                 for name in names:
                     tab = _table(self.graph, name)
@@ -663,6 +665,7 @@ class GraphCacheServer:
             if slot is None:
                 raise L.PgError("miss_mode='async' needs fetch_planned(..., slot=k)")
             miss_pos, miss_fullid, miss_count = self._missq_buffers(slot, R)
+            self._order_after_tail(slot, sp)
         else:
             miss_pos, miss_fullid, miss_count = L.ptr(self._miss_pos), L.ptr(self._miss_fullid), L.ptr(self._miss_count)
         timer = None
@@ -683,7 +686,7 @@ class GraphCacheServer:
                                                    L.ptr(self._slots) if dd is not None else None, sp), "pg_missq_submit")
             self._missq_pending.add(slot)
             if self._missq_share < 256:
-                L.check(self.lib.pg_missq_device_tail(self._missq, slot, sp), "pg_missq_device_tail")
+                self._device_tail(slot, sp)
         else:
             for name in plan.names:
                 tab = _table(self.graph, name)
@@ -701,6 +704,7 @@ class GraphCacheServer:
             if slot is None:
                 raise L.PgError("miss_mode='async' needs fetch_planned(..., slot=k)")
             miss_pos, miss_fullid, miss_count = self._missq_buffers(slot, R)
+            self._order_after_tail(slot, sp)
         else:
             self._ensure_capacity(R)
             miss_pos, miss_fullid, miss_count = L.ptr(self._miss_pos), L.ptr(self._miss_fullid), L.ptr(self._miss_count)
@@ -725,13 +729,23 @@ class GraphCacheServer:
                     "pg_missq_submit_range")
             self._missq_pending.add(slot)
             if self._missq_share < 256:      # the device reads the tail of the list into the staged block itself
-                L.check(self.lib.pg_missq_device_tail(self._missq, slot, sp), "pg_missq_device_tail")
+                self._device_tail(slot, sp)
 
     def _plan_dedup(self, plan, slot):
         """the plan's pg_dedup_t (built at its first fetch: the slot's queue buffers exist by then), or None"""
         if plan.dedup is False:
             plan.dedup = self._dedup_for(slot, plan.layer_lo, plan.first_layer, plan.num_layers, plan.same_fields)
         return plan.dedup
+
+    def _device_tail(self, slot, sp):
+        self._missq_tails = True
+        L.check(self.lib.pg_missq_device_tail(self._missq, slot, sp), "pg_missq_device_tail")
+
+    def _order_after_tail(self, slot, sp):
+        """cpu_share < 1: the split about to run rewrites the slot's miss list, which the previous submission's device
+        tail may still be reading on the queue's stream"""
+        if self._missq_tails:           # a device tail has been enqueued on this queue at some point
+            L.check(self.lib.pg_missq_order_after_tail(self._missq, slot, sp), "pg_missq_order_after_tail")
 
     def _missq_buffers(self, slot, rows):
         hit = self._missq_bufs.get(slot)
@@ -775,7 +789,7 @@ class GraphCacheServer:
         self._missq_bufs[slot] = (pos, full, cnt)
         return pos, full, cnt
 
-    def adapt_cpu_share(self, min_jobs=8, floor_GBps=None, quiet=False):
+    def adapt_cpu_share(self, min_jobs=8, floor_GBps=None, quiet=False, apply=True):
         """Set `cpu_share` from what this rank's host can really do (VERDICT r02 #1a). The async queue moves a miss list
         in two legs that overlap across minibatches: the CPU row gather (latency bound, scales with the threads the
         process may use) and the copy over PCIe. On a host with few free cores (eight ranks sharing a CPU quota, a busy
@@ -783,7 +797,7 @@ class GraphCacheServer:
         the rows it cannot gather within the list's PCIe time are handed to the device, which reads them from the
         pinned table itself (pg_missq_device_tail) — down to share 0, the pure zero-copy path. Shares >= 0.9 round up
         to 1 (a device-side PCIe read slows the concurrent compute kernels: not worth a 10 % shorter gather).
-        Returns the dict it logged, or None when there is nothing to go by yet (no queue / fewer than `min_jobs` jobs
+        apply=False only reports. Returns the dict it logged, or None when there is nothing to go by yet (no queue / fewer than `min_jobs` jobs
         since the last call / pageable tables)."""
         st = self.miss_queue_stats()
         if st is None:
@@ -811,7 +825,7 @@ class GraphCacheServer:
         new = 1.0 if want >= 0.9 else (0.0 if want < 0.1 else round(want * 16) / 16)
         rec = {"us_per_row_cpu_gather": us_per_row_cpu, "us_per_row_pcie": us_per_row_pcie, "cpu_share_before": old,
                "cpu_share": new, "jobs_measured": int(jobs), "host_threads": self.host_threads}
-        if new != old:
+        if new != old and apply:
             self.cpu_share = new
             # (takes effect at the next _missq_buffers call; dedup plans are rebuilt because their validity depends on it)
             self._missq_bufs = {}
