@@ -140,6 +140,9 @@ class NeighborSampler:
         self.slots = [_Slot(self.lib, self.handle, self.num_hops, self.device, padded=self.static,
                             transpose_mask=self.transpose_mask, defer_transpose=self.defer_transpose)
                       for _ in range(ring if ring else (5 if self.static else 3))]
+        # the slots' buffers were zero-filled on the CURRENT stream; the sampling chain writes them on self.stream, which
+        # does not synchronise with it: a late fill would wipe the first samples
+        torch.cuda.current_stream(self.device).synchronize()
 
     def __del__(self):
         try:

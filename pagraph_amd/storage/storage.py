@@ -247,6 +247,8 @@ class GraphCacheServer:
         # once and is copied on the device for the other layers. Async queue only. PG_DEDUP_MISSES=0 turns it off.
         self.dedup_misses = os.environ.get("PG_DEDUP_MISSES", "1") != "0"
         self._missq_dup = {}
+        # state tensors were filled on the current stream; the fetching stream of a trainer does not synchronise with it
+        torch.cuda.current_stream(self.device).synchronize()
 
     # -- reference-shaped views of the fused slot map --------------------------
     def _export(self):

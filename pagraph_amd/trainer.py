@@ -271,12 +271,19 @@ class GraphedTrainer:
     def _make_slot(self, nf):
         s = GraphedTrainer._Slot()
         R = nf._node_mapping.tousertensor().numel()
-        # wide rows whose width is not a multiple of 8 floats (Reddit's 602) get padded rows — zeros in the padding — so that
-        # the MFMA dense kernel reads them in whole octets; the views handed to the model are [R, d]
-        s.out = {n: torch.zeros((R, (d + 7) & ~7 if d >= 64 else d), dtype=torch.float32, device=self.device)[:, :d]
-                 for n, d in self.cacher.dims.items()}
-        s.label = torch.full((nf.layer_size(-1),), -100, dtype=torch.int64, device=self.device)
-        s.n_valid = torch.zeros(1, dtype=torch.int32, device=self.device)   # labels the loss will count
+        # The initial fills run ON THE LOAD STREAM, the stream that writes these buffers first (gather, label lookup).
+        # They used to run on whatever stream was current — the compute stream inside run_steps — where they queue behind
+        # up to `lookahead` steps of work while the load stream runs ahead: the slot's first pg_gather_labels could land
+        # BEFORE the fill that then wiped labels and count (every label ignored: a NaN loss and a zero gradient for that
+        # step — the flaky test_zerocopy_refused_... of round 2, ~5 % of runs on a busy host), and a late zero fill of a
+        # frame would silently wipe gathered rows.
+        with torch.cuda.stream(self.load_stream):
+            # wide rows whose width is not a multiple of 8 floats (Reddit's 602) get padded rows — zeros in the padding — so
+            # that the MFMA dense kernel reads them in whole octets; the views handed to the model are [R, d]
+            s.out = {n: torch.zeros((R, (d + 7) & ~7 if d >= 64 else d), dtype=torch.float32, device=self.device)[:, :d]
+                     for n, d in self.cacher.dims.items()}
+            s.label = torch.full((nf.layer_size(-1),), -100, dtype=torch.int64, device=self.device)
+            s.n_valid = torch.zeros(1, dtype=torch.int32, device=self.device)   # labels the loss will count
         s.ready = torch.cuda.Event()
         s.done = torch.cuda.Event()
         s.done_recorded = False
