@@ -379,6 +379,7 @@ struct pg_missq_slot {
   uint64_t gather_ticket[PG_MAX_FIELDS] = {0};   // Pool ticket of the last CPU gather into staging_h[f]
   uint32_t submitted = 0;  // last sequence number handed to the worker (trainer thread)
   uint32_t done = 0;       // last sequence number whose copy has been enqueued (worker, under mutex)
+  uint32_t done_pub = 0;   // the same, published with release order for lock-free polling (pg_missq_wait_idle)
   int32_t last_count = 0;
   float* out[PG_MAX_FIELDS] = {nullptr};
   int32_t out_stride[PG_MAX_FIELDS] = {0};   // -1 with out == NULL: copy to the staging block only
@@ -706,6 +707,7 @@ static void missq_worker(pg_missq* q) {
     {
       std::lock_guard<std::mutex> l(q->m);
       s.done = job.second;
+      __atomic_store_n(&s.done_pub, job.second, __ATOMIC_RELEASE);
       s.last_count = (int32_t)m;
       q->t_sync += us(t0, t1); q->t_flag += us(t1, t2); q->t_gather += tg; q->t_enqueue += te;
       q->n_jobs += 1; q->n_rows += m;
@@ -921,6 +923,10 @@ int pg_missq_submit_dedup(pg_missq_t* q, int slot, float* const* out_ptrs, const
   pg_missq_slot& s = q->slots[slot];
   uint32_t seq;
   {
+    for (int i = 0; i < 20000; ++i) {        // (as pg_missq_wait_idle: poll before sleeping)
+      if (__atomic_load_n(&s.done_pub, __ATOMIC_ACQUIRE) == s.submitted) break;
+      __builtin_ia32_pause();
+    }
     std::unique_lock<std::mutex> l(q->m);
     // the slot's previous submission must have left the worker (its buffers are about to be reused)
     q->cv_done.wait(l, [&] { return s.done == s.submitted || q->error != PG_OK; });
@@ -996,6 +1002,12 @@ int pg_missq_wait(pg_missq_t* q, int slot, pg_stream_t stream, int32_t* miss_cou
 int pg_missq_wait_idle(pg_missq_t* q, int slot) {
   if (!q || slot < 0 || slot >= q->n_slots) return PG_ERR_INVALID;
   pg_missq_slot& s = q->slots[slot];
+  // the caller is the launch thread: spin briefly before sleeping on the condition variable (a futex wake-up costs
+  // ~50 us on an idle host and milliseconds on a loaded one; the worker is normally within a few microseconds of done)
+  for (int i = 0; i < 20000; ++i) {
+    if (__atomic_load_n(&s.done_pub, __ATOMIC_ACQUIRE) == s.submitted) break;
+    __builtin_ia32_pause();
+  }
   std::unique_lock<std::mutex> l(q->m);
   q->cv_done.wait(l, [&] { return s.done == s.submitted || q->error != PG_OK; });
   return q->error;

@@ -895,7 +895,21 @@ int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, ui
   // the feet of the previous sample into the same slot (seen as a wrong loss trajectory once the host got
   // 4 calls ahead). So: wait until the previous launch into this slot has finished on the device — one
   // ring revolution ago, normally long done; otherwise this is the back-pressure that bounds the run-ahead.
-  if (ss->calls > 0) PG_HIP(hipEventSynchronize(ss->done));
+  // (polled, not hipEventSynchronize: a blocking wait puts the launch thread to sleep on an interrupt, and on a shared host
+  // the wake-up can take milliseconds — the whole pipeline hangs on this thread. The event is normally long complete.)
+  if (ss->calls > 0) {
+    hipError_t e;
+    int polls = 0;
+    while ((e = hipEventQuery(ss->done)) == hipErrorNotReady) {
+      if (++polls < 4096) __builtin_ia32_pause();
+      else {
+        PG_HIP(hipEventSynchronize(ss->done));     // something is badly late: stop burning the CPU
+        e = hipSuccess;
+        break;
+      }
+    }
+    if (e != hipSuccess) return pg::hip_fail(e);
+  }
   SampleParams* prm = ss->prm_h;
   prm->seeds = seeds; prm->n_seeds = n_seeds;
   prm->seed_lo = (uint32_t)seed; prm->seed_hi = (uint32_t)(seed >> 32);
