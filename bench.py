@@ -606,8 +606,10 @@ def run():
     if world > 1:
         stuck = parallel.max_over_ranks(stuck, device=dev)
     if stuck:
-        log(f"[bench] rank {rank}: a device-side wait for miss rows timed out during set-up -> host-side waits")
-        trainer.synchronize()
+        log(f"[bench] rank {rank}: a device-side wait for miss rows timed out during set-up -> host-side waits "
+            f"(miss queue: {cacher.miss_queue_stats() if cacher.miss_mode == 'async' else None})")
+        # (not trainer.synchronize(): it ends with check_misses(), which raises on the very flag this branch handles)
+        cacher.drain_misses()
         torch.cuda.synchronize()
         while trainer._prepared:
             sampler.release(trainer._prepared.pop(0).nf_cur)

@@ -27,6 +27,7 @@
 #include <new>
 #include <vector>
 
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/block/block_radix_sort.hpp>
@@ -247,23 +248,18 @@ __global__ __launch_bounds__(kScanThreads) void k_scan2(const int32_t* __restric
 }
 
 // ---- bitmap -> ascending ids ------------------------------------------------
-// (+ optionally: the words of ANOTHER bitmap that hold `clr_ids` back to zero — the previous layer's picks, whose
-// block has been relabelled by now; saves the separate k_clear_words launch of every layer)
+// (+ optionally: ANOTHER bitmap of the same size back to zero — the one the next layer's picks are marked in)
 __global__ __launch_bounds__(256) void k_bm_count(const unsigned long long* __restrict__ bm, int64_t n_words,
-                                                  int32_t* __restrict__ partial, unsigned long long* __restrict__ clr_bm,
-                                                  const int64_t* __restrict__ clr_ids,
-                                                  const int32_t* __restrict__ clr_n) {
+                                                  int32_t* __restrict__ partial, unsigned long long* __restrict__ clr_bm) {
   __shared__ int lds[16];
-  if (clr_bm) {
-    const int n = *clr_n;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-      clr_bm[clr_ids[i] >> 6] = 0ull;
-  }
   const int64_t w0 = (int64_t)blockIdx.x * kWordsPerBlock + threadIdx.x * 4;
   int c = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    if (w0 + i < n_words) c += __popcll(bm[w0 + i]);
+    if (w0 + i < n_words) {
+      c += __popcll(bm[w0 + i]);
+      if (clr_bm) clr_bm[w0 + i] = 0ull;
+    }
   int tot;
   (void)block_excl_scan(c, lds, &tot);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
@@ -352,7 +348,6 @@ struct PackArgs {
   int32_t num_layers;
   int32_t padded;                     // 1: layer l starts at pad_off[l], unused entries = -1
   int32_t pad_off[PG_MAX_LAYERS + 1];
-  unsigned long long* clr_bm;         // the input layer's pick bitmap: its touched words are cleared here
 };
 
 __global__ __launch_bounds__(256) void k_pack(const PackArgs a) {
@@ -376,11 +371,6 @@ __global__ __launch_bounds__(256) void k_pack(const PackArgs a) {
       if (l < a.num_layers && i >= off[l] && i < off[l] + cnt[l]) v = a.layer_ids[l][i - off[l]];
     a.node_mapping[i] = v;
   }
-  if (a.clr_bm) {   // layer 0's ids name the words its picks touched (k_relabel has run)
-    const int n0 = cnt[0];
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n0; i += (int64_t)gridDim.x * blockDim.x)
-      a.clr_bm[a.layer_ids[0][i] >> 6] = 0ull;
-  }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
 #pragma unroll
     for (int l = 0; l < PG_MAX_LAYERS; ++l) {
@@ -393,6 +383,283 @@ __global__ __launch_bounds__(256) void k_pack(const PackArgs a) {
       }
     }
     __threadfence_system();
+  }
+}
+
+// ===========================================================================================================
+// Round 3: the chain above as FIVE launches for fan-outs of at most one wave (was twelve), all plain launches with the
+// call's scalars as kernel arguments (no pinned parameter block, no hipGraph, nothing for the host to wait for):
+//   K1  S(top)            sample the seeds' in-neighbours            K2  R   bitmap -> ascending ids + word ranks
+//   K3  S(next) + X(top)  sample layer L-1 + relabel block L-1       K4  R
+//   K5  X(0) + sizes      relabel block 0, padding, sizes
+// What made twelve: two single-block scans per layer (k_scan2, k_bm_scan) and two passes over the bitmap (count, emit).
+// Both scans are now decoupled look-backs inside the kernel that produces the numbers: a block publishes its aggregate as
+// one 8-byte {value, tag} granule (one sc1 store; tag = a per-launch number, so nothing is ever reset) and sums the granules
+// of ALL its predecessors (at most 1024: one wave, a few loads per lane) — no serial chain, one hand-off deep. Blocks only
+// ever wait for blocks dispatched before them.
+//   S: a group of G = 2^ceil(log2 k) lanes per destination (k = 2: 32 destinations per wave; k_sample gives a vertex a
+//      whole wave and idles 62 lanes) -> pick counts -> block scan + look-back -> the block's CSR offsets are known
+//      while the picks are still in flight, so picks land in CSR position straight away (as vertex ids; no ELL buffer,
+//      no cnt array, no k_scan_cnt).
+//   R: popcount of the block's words -> look-back -> emit ids (straight into node_mapping for the fixed-shape layout)
+//      and the per-word rank table; zeroes the OTHER bitmap, the one the next S marks into.
+//   X: blk_src[e] = rank of the id it holds, in place; rides in the launch of the next layer's S (independent work).
+// The spec (DESIGN "Sampler spec") and therefore every output bit is unchanged: tests compare with oracle/pgc_oracle.c.
+constexpr int kMaxLookback = 1024;     // blocks per S / R launch (every block reads all its predecessors' granules)
+
+// sum of the values of granules [0, b) once each carries `tag`; wave 0 of the block calls it, result in every lane
+__device__ __forceinline__ int lookback_sum(const unsigned long long* agg, int b, uint32_t tag, int lane) {
+  int sum = 0;
+  for (int j = lane; j < b; j += kWave) {
+    unsigned long long g;
+    int spins = 0;
+    while (true) {
+      g = __hip_atomic_load(agg + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((uint32_t)(g >> 32) == tag || ++spins > (1 << 22)) break;   // bounded: a lost predecessor must not hang the GPU
+      __builtin_amdgcn_s_sleep(1);
+    }
+    sum += (int)(uint32_t)g;
+  }
+#pragma unroll
+  for (int d = kWave / 2; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+  return sum;
+}
+
+struct SampleGArgs {
+  const int64_t* indptr;
+  const int32_t* indices;
+  const int64_t* dst_ids;      // ids of layer b+1 (the top layer: the caller's seeds)
+  const int32_t* n_dev;        // device count of layer b+1, or NULL -> n_imm
+  int32_t n_imm;
+  int32_t cap_rows;            // the block's indptr is padded with empty rows up to cap_rows
+  int32_t k, g_shift, iters;   // group of 1 << g_shift lanes per destination, `iters` destinations per group
+  uint32_t layer, epoch, batch, seed_lo, seed_hi;
+  unsigned long long* bitmap;
+  int32_t* blk_indptr;
+  int32_t* blk_src;            // picks in CSR position, as vertex ids until X relabels them
+  int32_t* ecnt;               // edges of the block
+  unsigned long long* agg;
+  uint32_t tag;
+  // top layer only
+  int64_t* top_ids;            // the sampler's copy of the seeds' layer (NULL below the top)
+  int32_t* top_cnt;
+  int64_t* nm_top;             // fixed-shape layout: node_mapping at the top layer's offset (ids, then -1 up to nm_cap)
+  int32_t nm_cap;
+};
+
+__device__ __forceinline__ void sample_body(const SampleGArgs& a, const int blk, int* lds) {
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int G = 1 << a.g_shift, gl = tid & (G - 1), grp = tid >> a.g_shift;   // lane inside the group, group inside the block
+  const int vpi = 256 >> a.g_shift, vpb = vpi * a.iters;
+  const int n = a.n_dev ? *a.n_dev : a.n_imm;
+  const int k = a.k;
+  const int64_t p_base = (int64_t)blk * vpb + grp;
+  // pass 1: pick counts -> the block's aggregate
+  int64_t beg0 = 0, deg0 = 0, v0 = -1;
+  int mine = 0;
+  for (int it = 0; it < a.iters; ++it) {
+    const int64_t p = p_base + (int64_t)it * vpi;
+    int64_t beg = 0, deg = 0, v = -1;
+    if (p < n) {
+      v = a.dst_ids[p];
+      beg = a.indptr[v];
+      deg = a.indptr[v + 1] - beg;
+    }
+    if (it == 0) { beg0 = beg; deg0 = deg; v0 = v; }
+    if (gl == 0) mine += (int)(deg < k ? deg : k);
+  }
+  int tot;
+  (void)block_excl_scan(mine, lds, &tot);
+  if (tid == 0)
+    __hip_atomic_store(a.agg + blk, ((unsigned long long)a.tag << 32) | (uint32_t)tot, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  // pass 2: picks (their loads are in flight while wave 0 collects the predecessors' aggregates)
+  int carry = -1;
+  for (int it = 0; it < a.iters; ++it) {
+    const int64_t p = p_base + (int64_t)it * vpi;
+    int64_t beg = beg0, deg = deg0, v = v0;
+    if (it > 0) {
+      beg = deg = 0; v = -1;
+      if (p < n) {
+        v = a.dst_ids[p];
+        beg = a.indptr[v];
+        deg = a.indptr[v + 1] - beg;
+      }
+    }
+    const int c = (int)(deg < k ? deg : k);
+    // Floyd's k-subset inside the group (spec rule 3): draw j = word pair (j & 1) of Philox call j >> 1
+    const bool floyd = deg > k;
+    uint64_t t = 0;
+    if (floyd && gl < k) {
+      uint32_t r[4];
+      Philox::gen((uint32_t)v, a.epoch, a.batch, (a.layer << 24) | (uint32_t)(gl >> 1), a.seed_lo, a.seed_hi, r);
+      const uint64_t r64 = (gl & 1) ? ((uint64_t)r[3] << 32 | r[2]) : ((uint64_t)r[1] << 32 | r[0]);
+      t = bounded(r64, (uint64_t)(deg - k + gl) + 1);
+    }
+    uint64_t sel = floyd ? t : (uint64_t)gl;
+    const int gbase = lane & ~(G - 1);
+    const unsigned long long gmask = G == 64 ? ~0ull : (((1ull << G) - 1ull) << gbase);
+    for (int j = 1; j < k; ++j) {
+      const uint64_t tj = __shfl(t, gbase + j);
+      const unsigned long long hit = __ballot(floyd && gl < j && sel == tj) & gmask;
+      if (floyd && gl == j && hit != 0ull) sel = (uint64_t)(deg - k + j);
+    }
+    int32_t u = -1;
+    if (gl < c) u = a.indices[beg + (int64_t)sel];
+    if (carry < 0) {
+      // first iteration: the exclusive prefix of this block (block 0 has none)
+      if (tid < kWave) {
+        const int s = blk > 0 ? lookback_sum(a.agg, blk, a.tag, lane) : 0;
+        if (tid == 0) lds[16] = s;
+      }
+      __syncthreads();
+      carry = lds[16];
+    }
+    int itot;
+    const int ex = block_excl_scan(gl == 0 ? c : 0, lds, &itot);
+    const int pos = __shfl(carry + ex, gbase);
+    if (gl == 0 && p <= a.cap_rows) a.blk_indptr[p] = pos;        // rows past n are empty: pos = the block total
+    if (gl == 0 && p == a.cap_rows) *a.ecnt = pos;
+    if (u >= 0) {
+      a.blk_src[pos + gl] = u;
+      atomicOr(&a.bitmap[u >> 6], 1ull << (u & 63));
+    }
+    if (a.top_ids && gl == 0) {
+      if (p < n) a.top_ids[p] = v;
+      if (a.nm_top && p < a.nm_cap) a.nm_top[p] = p < n ? v : -1;
+    }
+    carry += itot;
+  }
+  if (a.top_cnt && blk == 0 && tid == 0) *a.top_cnt = n;
+}
+
+struct RelabelXArgs {
+  int32_t* blk_src;
+  const int32_t* ecnt;
+  const unsigned long long* bm;
+  const uint32_t* word_rank;
+  int64_t* nm_tail;            // fixed-shape layout: node_mapping at layer b's offset; [count, cap) := -1
+  const int32_t* lcnt_b;
+  int32_t cap_b;
+  // the chain's last launch also publishes the sizes (fixed-shape layout; the DGL layout runs k_pack)
+  int32_t final_sizes;
+  int32_t num_layers;
+  const int32_t* lcnt;         // [num_layers]
+  const int32_t* ecnt_all;     // [num_layers - 1]
+  int32_t* layer_offsets;
+  int32_t* sizes_pinned;
+  int32_t* sizes_dev;
+  int32_t pad_off[PG_MAX_LAYERS + 1];
+};
+
+__device__ __forceinline__ void relabel_body(const RelabelXArgs& a, const int blk, const int nblk) {
+  const int64_t tid = (int64_t)blk * blockDim.x + threadIdx.x, nth = (int64_t)nblk * blockDim.x;
+  const int nnz = *a.ecnt;
+  for (int64_t e = tid; e < nnz; e += nth) {
+    const int32_t u = a.blk_src[e];
+    const int64_t w = u >> 6;
+    const unsigned long long below = a.bm[w] & ((1ull << (u & 63)) - 1ull);
+    a.blk_src[e] = (int32_t)(a.word_rank[w] + __popcll(below));
+  }
+  if (a.nm_tail) {
+    const int c = *a.lcnt_b;
+    for (int64_t i = c + tid; i < a.cap_b; i += nth) a.nm_tail[i] = -1;
+  }
+  if (a.final_sizes && blk == 0 && threadIdx.x == 0) {
+#pragma unroll
+    for (int l = 0; l < PG_MAX_LAYERS; ++l) {
+      if (l <= a.num_layers) a.layer_offsets[l] = a.pad_off[l];
+      if (l < a.num_layers) {
+        const int c = a.lcnt[l];
+        a.sizes_pinned[l] = c;
+        if (a.sizes_dev) a.sizes_dev[l] = c;
+      }
+      if (l + 1 < a.num_layers) {
+        const int e = a.ecnt_all[l];
+        a.sizes_pinned[PG_MAX_LAYERS + l] = e;
+        if (a.sizes_dev) a.sizes_dev[PG_MAX_LAYERS + l] = e;
+      }
+    }
+    __threadfence_system();
+  }
+}
+
+// blocks [0, s_blocks): S of one layer; the rest: X of the layer above it (either side may be empty)
+__global__ __launch_bounds__(256) void k_sx(const SampleGArgs s, const RelabelXArgs x, const int s_blocks) {
+  __shared__ int lds[20];
+  if ((int)blockIdx.x < s_blocks) sample_body(s, (int)blockIdx.x, lds);
+  else relabel_body(x, (int)blockIdx.x - s_blocks, (int)gridDim.x - s_blocks);
+}
+
+struct RankArgs {
+  const unsigned long long* bm;
+  unsigned long long* other_bm;   // zeroed here: the next S marks into it
+  int64_t n_words;
+  int32_t m;                      // the block covers 1024 * m words, 4 per thread and round
+  unsigned long long* agg;
+  uint32_t tag;
+  int64_t* out_ids;
+  int64_t cap;
+  uint32_t* word_rank;
+  int32_t* count_out;
+  int64_t* nm_out;                // fixed-shape layout: node_mapping at this layer's offset (NULL otherwise)
+};
+
+__global__ __launch_bounds__(256) void k_bm_rank(const RankArgs a) {
+  __shared__ int lds[20];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), blk = blockIdx.x;
+  const int64_t wblk = (int64_t)blk * kWordsPerBlock * a.m;
+  unsigned long long w[4] = {0ull, 0ull, 0ull, 0ull};
+  int mine = 0;
+  for (int r = 0; r < a.m; ++r) {
+    const int64_t w0 = wblk + (int64_t)r * kWordsPerBlock + tid * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      w[i] = (w0 + i < a.n_words) ? a.bm[w0 + i] : 0ull;
+      mine += __popcll(w[i]);
+      if (w0 + i < a.n_words) a.other_bm[w0 + i] = 0ull;
+    }
+  }
+  int tot;
+  (void)block_excl_scan(mine, lds, &tot);
+  if (tid == 0)
+    __hip_atomic_store(a.agg + blk, ((unsigned long long)a.tag << 32) | (uint32_t)tot, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < kWave) {
+    const int s = blk > 0 ? lookback_sum(a.agg, blk, a.tag, lane) : 0;
+    if (tid == 0) lds[16] = s;
+  }
+  __syncthreads();
+  int carry = lds[16];
+  if (blk == (int)gridDim.x - 1 && tid == 0) *a.count_out = carry + tot;
+  for (int r = 0; r < a.m; ++r) {
+    const int64_t w0 = wblk + (int64_t)r * kWordsPerBlock + tid * 4;
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (a.m > 1) w[i] = (w0 + i < a.n_words) ? a.bm[w0 + i] : 0ull;   // one round: still in registers
+      c += __popcll(w[i]);
+    }
+    int rtot;
+    int pos = carry + block_excl_scan(c, lds, &rtot);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (w0 + i < a.n_words) {
+        a.word_rank[w0 + i] = (uint32_t)pos;
+        unsigned long long x = w[i];
+        const int64_t vbase = (w0 + i) << 6;
+        while (x) {
+          const int b = __ffsll((long long)x) - 1;
+          x &= x - 1;
+          if (pos < a.cap) {
+            a.out_ids[pos] = vbase + b;
+            if (a.nm_out) a.nm_out[pos] = vbase + b;
+          }
+          ++pos;
+        }
+      }
+    }
+    carry += rtot;
   }
 }
 
@@ -559,9 +826,8 @@ __global__ __launch_bounds__(1024) void k_t_block(const int32_t* __restrict__ in
 }
 
 // copy seeds into the top layer buffer + set its count; publishes the call's parameters on the device
-__global__ void k_seed_layer(const SampleParams* __restrict__ prm_host, SampleParams* __restrict__ prm_dev,
-                             int64_t* layer_ids, int32_t* layer_cnt) {
-  const SampleParams p = *prm_host;   // pinned host memory: one PCIe read per thread, 64 blocks at most
+__global__ void k_seed_layer(const SampleParams p, SampleParams* __restrict__ prm_dev, int64_t* layer_ids,
+                             int32_t* layer_cnt) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p.n_seeds; i += gridDim.x * blockDim.x)
     layer_ids[i] = p.seeds[i];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -603,16 +869,18 @@ struct pg_sampler {
     const void* key = nullptr;
     hipStream_t stream = nullptr;
     pg_nodeflow_desc_t desc{};
-    SampleParams* prm_h = nullptr;   // pinned host
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     int64_t calls = 0;
     bool graph_failed = false;
-    hipEvent_t done = nullptr;       // recorded after every launch into this slot
   };
-  std::vector<SlotState*> slot_states;
-  std::vector<SlotState*> tslot_states;   // pg_sampler_transpose's per-(slot, stream) graphs
-  SampleParams* prm_d = nullptr;     // device copy of the running call's parameters
+  std::vector<SlotState*> tslot_states;   // pg_sampler_transpose's per-(slot, stream) graphs (multi-launch device sort only)
+  SampleParams* prm_d = nullptr;     // device copy of the running call's parameters (wide fan-out chain)
+  unsigned long long* agg = nullptr; // look-back granules {value, tag} of the running S / R launch
+  uint32_t tag = 0;                  // last tag handed to a launch (never 0)
+  uint64_t rank_launches = 0;        // picks of launch i are marked in bitmap (i & 1); its R zeroes the other one
+  int max_lookback = kMaxLookback;   // blocks per S / R launch
+  int rank_m = 1, rank_blocks = 1;   // k_bm_rank: rounds per block, blocks (<= max_lookback)
   int64_t V = 0;
   const int64_t* indptr = nullptr;
   const int32_t* indices = nullptr;
@@ -657,13 +925,7 @@ static void sampler_free(pg_sampler* s) {
     if (c->graph) (void)hipGraphDestroy(c->graph);
     delete c;
   }
-  for (auto* c : s->slot_states) {
-    if (c->exec) (void)hipGraphExecDestroy(c->exec);
-    if (c->graph) (void)hipGraphDestroy(c->graph);
-    if (c->prm_h) (void)hipHostFree(c->prm_h);
-    if (c->done) (void)hipEventDestroy(c->done);
-    delete c;
-  }
+  (void)hipFree(s->agg);
   delete s;
 }
 
@@ -704,8 +966,20 @@ int pg_sampler_create(int64_t V, const int64_t* indptr, const int32_t* indices, 
   ok &= hipMalloc(&s->partial, (size_t)s->n_bm_blocks * 4 + 4) == hipSuccess;
   for (int l = 0; l <= L; ++l) ok &= hipMalloc(&s->layer_ids[l], s->cap[l] * 8) == hipSuccess;
   ok &= hipMalloc(&s->counters, 2 * PG_MAX_LAYERS * 4) == hipSuccess;
-  ok &= hipMalloc(&s->nbr, max_dst * fanout * 4) == hipSuccess;
-  ok &= hipMalloc(&s->cnt, max_dst * 4) == hipSuccess;
+  if (fanout > kWave) {   // ELL picks + counts: the wide chain only
+    ok &= hipMalloc(&s->nbr, max_dst * fanout * 4) == hipSuccess;
+    ok &= hipMalloc(&s->cnt, max_dst * 4) == hipSuccess;
+  }
+  // (test hook: PG_SAMPLER_LOOKBACK=<n> shrinks the block limit so that small graphs take the multi-round paths)
+  if (const char* e = getenv("PG_SAMPLER_LOOKBACK")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= kMaxLookback) s->max_lookback = v;
+  }
+  s->rank_m = (int)ceil_div<int64_t>(s->n_words, (int64_t)kWordsPerBlock * s->max_lookback);
+  if (s->rank_m < 1) s->rank_m = 1;
+  s->rank_blocks = (int)ceil_div<int64_t>(s->n_words, (int64_t)kWordsPerBlock * s->rank_m);
+  ok &= hipMalloc(&s->agg, (size_t)kMaxLookback * 8) == hipSuccess;
+  if (ok) ok &= hipMemset(s->agg, 0, (size_t)kMaxLookback * 8) == hipSuccess;
   ok &= hipMalloc(&s->prm_d, sizeof(SampleParams)) == hipSuccess;
   ok &= hipMalloc(&s->tcnt, (s->cap[0] + 1) * 4) == hipSuccess;
   ok &= hipMalloc(&s->tdummy, 4) == hipSuccess;
@@ -744,6 +1018,18 @@ int pg_sampler_capacity(const pg_sampler_t* s, int64_t* cap_nodes, int64_t* cap_
     if (cap_blk_edges) cap_blk_edges[b] = s->cap[b + 1] * s->k;
   }
   return PG_OK;
+}
+
+// does block b take the one-workgroup transpose (k_t_block)?
+static bool transpose_one_workgroup(const pg_sampler* s, int b) {
+  static const bool device_sort = getenv("PG_T_DEVICE_SORT") != nullptr;
+  const int64_t cap_edges = s->cap[b + 1] * s->k;
+  const int64_t larger = cap_edges > s->cap[b] + 1 ? cap_edges : s->cap[b] + 1;
+  if (device_sort || larger > 1024 * 12) return false;
+  int vb = 1, kb = 1;
+  while ((1ll << vb) < s->cap[b + 1]) ++vb;
+  while ((1ll << kb) <= s->cap[b]) ++kb;
+  return vb + kb <= 32;
 }
 
 // source-major copy of block b of the slot `o`. n_dst / n_src / nnz: DEVICE counters of that NodeFlow (the
@@ -796,37 +1082,32 @@ static int transpose_block(pg_sampler* s, const pg_nodeflow_desc_t* o, int b, co
   return PG_OK;
 }
 
-// the whole launch sequence of one sample() into the slot described by `o`; nothing in it depends on the
-// call's scalar arguments (those travel through ss->prm_h), so it can be captured into a hipGraph
-static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t st, pg_sampler::SlotState* ss) {
-  int64_t need = 0;
-  for (int l = 0; l <= s->hops; ++l) need += s->cap[l];
+// fan-out above one wave: the round-1 chain (k_sample_wide -> count -> scans -> emit -> relabel per layer, k_pack), plain
+// launches; the call's scalars reach the kernels through a device copy that k_seed_layer makes of its BY-VALUE argument
+static int enqueue_chain_wide(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t st, const SampleParams& prm) {
   const int L = s->hops;
   int32_t* lcnt = s->counters;
   int32_t* ecnt = s->counters + PG_MAX_LAYERS;
 
-  hipLaunchKernelGGL(k_seed_layer, dim3(grid_for(s->B, 256, 64)), dim3(256), 0, st, ss->prm_h, s->prm_d,
-                     s->layer_ids[L], lcnt + L);
+  hipLaunchKernelGGL(k_seed_layer, dim3(grid_for(s->B, 256, 64)), dim3(256), 0, st, prm, s->prm_d, s->layer_ids[L],
+                     lcnt + L);
   PG_LAUNCH_CHECK();
-  unsigned long long* prev_bm = nullptr;
   for (int b = L - 1; b >= 0; --b) {
     const int64_t cap_dst = s->cap[b + 1];
-    unsigned long long* bm = ((L - 1 - b) & 1) ? s->bitmap_b : s->bitmap;
+    unsigned long long* bm = (s->rank_launches & 1) ? s->bitmap_b : s->bitmap;
+    unsigned long long* other = (s->rank_launches & 1) ? s->bitmap : s->bitmap_b;
+    ++s->rank_launches;
     SampleArgs a{};
     a.indptr = s->indptr; a.indices = s->indices;
     a.dst_ids = s->layer_ids[b + 1]; a.n_dst = lcnt + b + 1;
     a.nbr = s->nbr; a.cnt = s->cnt; a.bitmap = bm; a.k = s->k;
     a.prm = s->prm_d; a.layer = (uint32_t)b;
-    if (s->k <= kWave)
-      hipLaunchKernelGGL(k_sample, dim3(grid_for(cap_dst, 4)), dim3(256), 0, st, a);
-    else
-      hipLaunchKernelGGL(k_sample_wide, dim3(grid_for(cap_dst, 4)), dim3(256), (size_t)4 * s->k * sizeof(uint32_t), st, a);
+    hipLaunchKernelGGL(k_sample_wide, dim3(grid_for(cap_dst, 4)), dim3(256), (size_t)4 * s->k * sizeof(uint32_t), st, a);
     PG_LAUNCH_CHECK();
     int32_t* indptr_b = o->blk_indptr + o->blk_indptr_off[b];
     int32_t* src_b = o->blk_src + o->blk_src_off[b];
-    // (+ the previous layer's bitmap back to zero: its block was relabelled by the launch before this layer's k_sample)
-    hipLaunchKernelGGL(k_bm_count, dim3(s->n_bm_blocks), dim3(256), 0, st, bm, s->n_words, s->partial, prev_bm,
-                       prev_bm ? s->layer_ids[b + 1] : nullptr, prev_bm ? lcnt + b + 1 : nullptr);
+    // (+ the other bitmap back to zero: the next layer — or the next call — marks into it)
+    hipLaunchKernelGGL(k_bm_count, dim3(s->n_bm_blocks), dim3(256), 0, st, bm, s->n_words, s->partial, other);
     PG_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kScanThreads), 0, st, s->cnt, lcnt + b + 1, indptr_b, ecnt + b,
                        (int32_t)cap_dst, s->partial, s->n_bm_blocks, lcnt + b);
@@ -837,7 +1118,6 @@ static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t
     hipLaunchKernelGGL(k_relabel, dim3(grid_for(cap_dst * s->k, 256)), dim3(256), 0, st, s->nbr, s->cnt,
                        lcnt + b + 1, s->k, indptr_b, bm, s->word_rank, src_b);
     PG_LAUNCH_CHECK();
-    prev_bm = bm;      // cleared by the next layer's k_bm_count, or by k_pack after the last layer
     // source-major copy of this block (gather-form backward aggregation) in line, unless the caller asked to
     // run it later on a stream of its own choice (pg_sampler_transpose)
     if (!o->defer_transpose && o->blk_tptr && o->blk_tdst && ((o->transpose_mask >> b) & 1u)) {
@@ -845,21 +1125,107 @@ static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t
       if (rc != PG_OK) return rc;
     }
   }
+  return PG_OK;
+}
+
+// node_mapping / layer_offsets / sizes from the sampler's per-layer id arrays (the DGL layout, where a layer's offset is the
+// sum of the real sizes below it; and the fixed-shape layout of the wide chain)
+static int enqueue_pack(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t st) {
+  const int L = s->hops;
+  int64_t need = 0;
+  for (int l = 0; l <= L; ++l) need += s->cap[l];
   PackArgs p{};
   for (int l = 0; l <= L; ++l) {
     p.layer_ids[l] = s->layer_ids[l];
-    p.layer_cnt[l] = lcnt + l;
+    p.layer_cnt[l] = s->counters + l;
   }
-  for (int b = 0; b < L; ++b) p.blk_edges[b] = ecnt + b;
+  for (int b = 0; b < L; ++b) p.blk_edges[b] = s->counters + PG_MAX_LAYERS + b;
   p.node_mapping = o->node_mapping; p.layer_offsets = o->layer_offsets; p.sizes_pinned = o->sizes_pinned;
   p.sizes_dev = o->sizes_dev;
   p.cap_nodes = o->cap_nodes; p.num_layers = L + 1;
   p.padded = o->padded ? 1 : 0;
   p.pad_off[0] = 0;
   for (int l = 0; l <= L; ++l) p.pad_off[l + 1] = p.pad_off[l] + (int32_t)s->cap[l];
-  p.clr_bm = prev_bm;
   hipLaunchKernelGGL(k_pack, dim3(grid_for(need, 256, 1024)), dim3(256), 0, st, p);
   PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+// the five-launch chain (fan-out <= 64)
+static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t st, const SampleParams& prm) {
+  const int L = s->hops;
+  int32_t* lcnt = s->counters;
+  int32_t* ecnt = s->counters + PG_MAX_LAYERS;
+  int g_shift = 0;
+  while ((1 << g_shift) < s->k) ++g_shift;
+  const int vpi = 256 >> g_shift;
+  int32_t pad_off[PG_MAX_LAYERS + 1];
+  pad_off[0] = 0;
+  for (int l = 0; l <= L; ++l) pad_off[l + 1] = pad_off[l] + (int32_t)s->cap[l];
+  const bool padded = o->padded != 0;
+
+  RelabelXArgs x{};
+  int x_blocks = 0;
+  for (int b = L - 1; b >= -1; --b) {
+    SampleGArgs a{};
+    int s_blocks = 0;
+    unsigned long long* bm = (s->rank_launches & 1) ? s->bitmap_b : s->bitmap;
+    unsigned long long* other = (s->rank_launches & 1) ? s->bitmap : s->bitmap_b;
+    if (b >= 0) {
+      const int64_t cap_dst = s->cap[b + 1];
+      a.indptr = s->indptr; a.indices = s->indices;
+      a.cap_rows = (int32_t)cap_dst;
+      a.k = s->k; a.g_shift = g_shift;
+      a.iters = (int)ceil_div<int64_t>(cap_dst + 1, (int64_t)vpi * s->max_lookback);
+      if (a.iters < 1) a.iters = 1;
+      s_blocks = (int)ceil_div<int64_t>(cap_dst + 1, (int64_t)vpi * a.iters);
+      a.layer = (uint32_t)b; a.epoch = prm.epoch; a.batch = prm.batch; a.seed_lo = prm.seed_lo; a.seed_hi = prm.seed_hi;
+      a.bitmap = bm;
+      a.blk_indptr = o->blk_indptr + o->blk_indptr_off[b];
+      a.blk_src = o->blk_src + o->blk_src_off[b];
+      a.ecnt = ecnt + b;
+      a.agg = s->agg; a.tag = ++s->tag ? s->tag : ++s->tag;
+      if (b == L - 1) {
+        a.dst_ids = prm.seeds; a.n_dev = nullptr; a.n_imm = prm.n_seeds;
+        a.top_ids = s->layer_ids[L]; a.top_cnt = lcnt + L;
+        a.nm_top = padded ? o->node_mapping + pad_off[L] : nullptr;
+        a.nm_cap = (int32_t)s->cap[L];
+      } else {
+        a.dst_ids = s->layer_ids[b + 1]; a.n_dev = lcnt + b + 1;
+      }
+    }
+    hipLaunchKernelGGL(k_sx, dim3(s_blocks + x_blocks), dim3(256), 0, st, a, x, s_blocks);
+    PG_LAUNCH_CHECK();
+    if (b + 1 < L && !o->defer_transpose && o->blk_tptr && o->blk_tdst && ((o->transpose_mask >> (b + 1)) & 1u)) {
+      // block b+1 is final (its relabel rode in the launch above): its source-major copy, in line
+      const int rc = transpose_block(s, o, b + 1, lcnt + b + 2, lcnt + b + 1, ecnt + b + 1,
+                                     s->counters + 2 * PG_MAX_LAYERS - 1, st);
+      if (rc != PG_OK) return rc;
+    }
+    if (b < 0) break;
+    RankArgs r{};
+    r.bm = bm; r.other_bm = other; r.n_words = s->n_words;
+    r.m = s->rank_m;
+    r.agg = s->agg; r.tag = ++s->tag ? s->tag : ++s->tag;
+    r.out_ids = s->layer_ids[b]; r.cap = s->cap[b]; r.word_rank = s->word_rank; r.count_out = lcnt + b;
+    r.nm_out = padded ? o->node_mapping + pad_off[b] : nullptr;
+    hipLaunchKernelGGL(k_bm_rank, dim3(s->rank_blocks), dim3(256), 0, st, r);
+    PG_LAUNCH_CHECK();
+    ++s->rank_launches;
+    // the relabel of this block rides in the next launch
+    x = RelabelXArgs{};
+    x.blk_src = o->blk_src + o->blk_src_off[b];
+    x.ecnt = ecnt + b;
+    x.bm = bm; x.word_rank = s->word_rank;
+    x.nm_tail = padded ? o->node_mapping + pad_off[b] : nullptr;
+    x.lcnt_b = lcnt + b; x.cap_b = (int32_t)s->cap[b];
+    x_blocks = grid_for(s->cap[b + 1] * s->k, 256, 256);
+    if (b == 0 && padded) {
+      x.final_sizes = 1; x.num_layers = L + 1; x.lcnt = lcnt; x.ecnt_all = ecnt;
+      x.layer_offsets = o->layer_offsets; x.sizes_pinned = o->sizes_pinned; x.sizes_dev = o->sizes_dev;
+      for (int l = 0; l <= L + 1; ++l) x.pad_off[l] = pad_off[l];
+    }
+  }
   return PG_OK;
 }
 
@@ -872,88 +1238,20 @@ int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, ui
   for (int l = 0; l <= s->hops; ++l) need += s->cap[l];
   if (o->cap_nodes < need) return PG_ERR_OVERFLOW;
   hipStream_t st = as_stream(stream);
-  // per-slot state, keyed by the slot's output buffers and the stream
-  pg_sampler::SlotState* ss = nullptr;
-  for (auto* c : s->slot_states)
-    if (c->key == o->node_mapping && c->stream == st && memcmp(&c->desc, o, sizeof(*o)) == 0) ss = c;
-  if (!ss) {
-    ss = new (std::nothrow) pg_sampler::SlotState;
-    if (!ss) return PG_ERR_NOMEM;
-    if (hipHostMalloc(&ss->prm_h, sizeof(SampleParams), hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&ss->done, hipEventDisableTiming) != hipSuccess) {
-      if (ss->prm_h) (void)hipHostFree(ss->prm_h);
-      delete ss;
-      return PG_ERR_NOMEM;
-    }
-    ss->key = o->node_mapping;
-    ss->stream = st;
-    ss->desc = *o;
-    s->slot_states.push_back(ss);
+  SampleParams prm{};
+  prm.seeds = seeds; prm.n_seeds = n_seeds;
+  prm.seed_lo = (uint32_t)seed; prm.seed_hi = (uint32_t)(seed >> 32);
+  prm.epoch = epoch; prm.batch = batch;
+  // Every launch takes the call's scalars as kernel arguments: nothing of this call lives in memory that a later call
+  // rewrites, so the host never waits for the device here. One chain at a time per handle (shared scratch: bitmaps, rank
+  // table, look-back granules) — calls on one stream, or on streams the caller orders.
+  if (s->k > kWave) {
+    const int rc = enqueue_chain_wide(s, o, st, prm);
+    return rc != PG_OK ? rc : enqueue_pack(s, o, st);
   }
-  // The parameter block is read by the device when k_seed_layer RUNS, which can be long after this call
-  // returned: a launch thread that runs several minibatches ahead of the GPU would overwrite it under
-  // the feet of the previous sample into the same slot (seen as a wrong loss trajectory once the host got
-  // 4 calls ahead). So: wait until the previous launch into this slot has finished on the device — one
-  // ring revolution ago, normally long done; otherwise this is the back-pressure that bounds the run-ahead.
-  // (polled, not hipEventSynchronize: a blocking wait puts the launch thread to sleep on an interrupt, and on a shared host
-  // the wake-up can take milliseconds — the whole pipeline hangs on this thread. The event is normally long complete.)
-  if (ss->calls > 0) {
-    hipError_t e;
-    int polls = 0;
-    while ((e = hipEventQuery(ss->done)) == hipErrorNotReady) {
-      if (++polls < 4096) __builtin_ia32_pause();
-      else {
-        PG_HIP(hipEventSynchronize(ss->done));     // something is badly late: stop burning the CPU
-        e = hipSuccess;
-        break;
-      }
-    }
-    if (e != hipSuccess) return pg::hip_fail(e);
-  }
-  SampleParams* prm = ss->prm_h;
-  prm->seeds = seeds; prm->n_seeds = n_seeds;
-  prm->seed_lo = (uint32_t)seed; prm->seed_hi = (uint32_t)(seed >> 32);
-  prm->epoch = epoch; prm->batch = batch;
-  ++ss->calls;
-  static const bool no_graph = getenv("PG_SAMPLER_NO_GRAPH") != nullptr;
-  int rc = PG_OK;
-  bool launched = false;
-  if (ss->exec) {
-    PG_HIP(hipGraphLaunch(ss->exec, st));
-    launched = true;
-  } else if (no_graph || ss->graph_failed || ss->calls < 2) {
-    rc = enqueue_chain(s, o, st, ss);
-    launched = true;
-  }
-  if (launched) {
-    if (rc == PG_OK) PG_HIP(hipEventRecord(ss->done, st));
-    return rc;
-  }
-  // second call into this slot: capture the chain (~25-35 launches) once, then replay it with one launch
-  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-    (void)hipGetLastError();
-    ss->graph_failed = true;
-    rc = enqueue_chain(s, o, st, ss);
-    if (rc == PG_OK) PG_HIP(hipEventRecord(ss->done, st));
-    return rc;
-  }
-  rc = enqueue_chain(s, o, st, ss);
-  hipGraph_t graph = nullptr;
-  const hipError_t e_end = hipStreamEndCapture(st, &graph);
-  if (rc == PG_OK && e_end == hipSuccess && graph &&
-      hipGraphInstantiate(&ss->exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-    ss->graph = graph;
-    PG_HIP(hipGraphLaunch(ss->exec, st));
-    PG_HIP(hipEventRecord(ss->done, st));
-    return PG_OK;
-  }
-  (void)hipGetLastError();
-  if (graph) (void)hipGraphDestroy(graph);
-  ss->exec = nullptr;
-  ss->graph_failed = true;
-  rc = enqueue_chain(s, o, st, ss);   // nothing ran during the failed capture
-  if (rc == PG_OK) PG_HIP(hipEventRecord(ss->done, st));
-  return rc;
+  const int rc = enqueue_chain(s, o, st, prm);
+  if (rc != PG_OK || o->padded) return rc;
+  return enqueue_pack(s, o, st);
 }
 
 static int enqueue_transposes(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t st) {
@@ -971,9 +1269,15 @@ int pg_sampler_transpose(pg_sampler_t* s, const pg_nodeflow_desc_t* o, pg_stream
   if (!o->transpose_mask) return PG_OK;
   if (!o->blk_tptr || !o->blk_tdst || !o->sizes_dev) return PG_ERR_INVALID;
   hipStream_t st = as_stream(stream);
-  // like the sampling chain, the launch sequence into a given slot from a given stream is fixed (all sizes are read
-  // from the slot's device counters): from the second call it is one hipGraph launch instead of ~8 kernel launches
-  // on the trainer's launch thread. The key differs from the sampling chain's by the stream.
+  // one-workgroup transposes (k_t_block) are one plain launch per block: cheaper for the launch thread than replaying a
+  // one-node graph (3-4 us against 10-13)
+  bool single = true;
+  for (int b = 0; b < s->hops; ++b)
+    if ((o->transpose_mask >> b) & 1u) single = single && transpose_one_workgroup(s, b);
+  if (single) return enqueue_transposes(s, o, st);
+  // the multi-launch device sort of a large block: the launch sequence into a given slot from a given stream is fixed (all
+  // sizes are read from the slot's device counters), so from the second call it is one hipGraph launch instead of ~8
+  // kernel launches on the trainer's launch thread.
   static const bool no_graph = getenv("PG_SAMPLER_NO_GRAPH") != nullptr;
   pg_sampler::SlotState* ss = nullptr;
   for (auto* c : s->tslot_states)
@@ -1036,8 +1340,7 @@ int pg_bitmap_to_ids(const uint64_t* bitmap, int64_t n_words, int64_t* out_ids, 
   // scratch holds the per-block partials: caller provides >= 4*(nb+1) bytes
   int32_t* partial = reinterpret_cast<int32_t*>(scratch);
   const unsigned long long* bm = reinterpret_cast<const unsigned long long*>(bitmap);
-  hipLaunchKernelGGL(k_bm_count, dim3(nb), dim3(256), 0, st, bm, n_words, partial, (unsigned long long*)nullptr,
-                     (const int64_t*)nullptr, (const int32_t*)nullptr);
+  hipLaunchKernelGGL(k_bm_count, dim3(nb), dim3(256), 0, st, bm, n_words, partial, (unsigned long long*)nullptr);
   PG_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_bm_scan, dim3(1), dim3(kScanThreads), 0, st, partial, nb, (int32_t*)nullptr, count_dev);
   PG_LAUNCH_CHECK();

@@ -80,6 +80,15 @@ class _Slot:
         self.desc = d
 
 
+def _poll(event):
+    polls = 0
+    while not event.query():
+        polls += 1
+        if polls > 400000:            # something is badly late: stop burning the CPU
+            event.synchronize()
+            return
+
+
 class NeighborSampler:
     def __init__(self, g, batch_size, expand_factor, num_hops=1, neighbor_type='in', seed_nodes=None,
                  shuffle=False, num_workers=1, prefetch=False, seed=0, copy_out=True, static=False, ring=None,
@@ -125,6 +134,9 @@ class NeighborSampler:
         # "free" event (GraphedTrainer: GraphCacheServer.wait_worker — the barrier must not overtake the miss copy the
         # slot's consumer is waiting for)
         self.before_slot_reuse = None
+        # True: a ring slot's "free" event is polled by the thread that enqueues the next sample into it instead of being
+        # waited for by the sampler's stream (GraphedTrainer sets it; needs a ring deep enough for the run-ahead)
+        self.host_gated = False
         # transpose: blocks that also come out source-major (NodeFlow.blk_tptr / blk_tdst) so that the backward
         # aggregation is a gather. 'auto' = every block whose input can carry a gradient (all but block 0,
         # whose input is the raw feature frame); or an iterable of block indices; None = none.
@@ -139,7 +151,7 @@ class NeighborSampler:
             raise L.PgError("defer_transpose needs static=True (fixed-shape NodeFlows)")
         self.slots = [_Slot(self.lib, self.handle, self.num_hops, self.device, padded=self.static,
                             transpose_mask=self.transpose_mask, defer_transpose=self.defer_transpose)
-                      for _ in range(ring if ring else (5 if self.static else 3))]
+                      for _ in range(ring if ring else (8 if self.static else 3))]
         # the slots' buffers were zero-filled on the CURRENT stream; the sampling chain writes them on self.stream, which
         # does not synchronise with it: a late fill would wipe the first samples
         torch.cuda.current_stream(self.device).synchronize()
@@ -186,7 +198,20 @@ class NeighborSampler:
         slot.held = True
         lo = b * self.batch_size
         n = min(self.batch_size, self.seeds.numel() - lo)
-        if slot.free_recorded:
+        if slot.free_recorded and self.host_gated:
+            # the consumer of the batch that used this slot is done — checked HERE, on the launch thread, instead of with a
+            # wait on the sampler's stream: an event that another stream waits for costs the stream that records it ~13 us
+            # (tools/exp_graph_gap.py: 4.7 us for a record nobody waits for in-stream), and that stream is the compute
+            # stream, the one that bounds the step once the features are cached. Polled, not synchronize(): a blocking
+            # wait sleeps on an interrupt and, on a shared host, can wake up milliseconds late. The ring is deep enough
+            # for the launch thread to stay ahead of the GPU (see GraphedTrainer).
+            _poll(slot.free)
+        elif getattr(slot, "n_seeds", None) is not None:
+            # back-pressure: the previous sample into this ring slot (one revolution ago) has run. Nothing in the chain
+            # needs it any more (the call's scalars are kernel arguments since round 3), but it bounds how far the launch
+            # thread runs ahead of the GPU.
+            _poll(slot.ready)
+        if slot.free_recorded and not self.host_gated:
             if self.before_slot_reuse is not None:
                 self.before_slot_reuse((self._ring_pos - 1) % len(self.slots))
             self.stream.wait_event(slot.free)  # the consumer of the batch that used this slot is done

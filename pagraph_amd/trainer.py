@@ -236,6 +236,13 @@ class GraphedTrainer:
         self.compute_stream = torch.cuda.Stream(device=device, priority=int(_os.environ.get("PG_PRIO_COMPUTE", 0)))
         sampler.consumer_stream = self.compute_stream   # ring slots are recycled after the graph that read them
         sampler.manual_release = True
+        # the sampler's own "slot free" event (recorded on the compute stream by sampler.release right after the step)
+        # already orders every later use of the slot's buffers after that step: see prepare()
+        self._free_orders_slot = not _os.environ.get("PG_KEEP_DONE_EVENT")
+        # ... and that event is polled by the launch thread before it samples into the slot again, not waited for by the
+        # sampler's stream (sampler.host_gated): the compute stream records an event no stream waits for. With the default
+        # ring of 8 slots the launch thread may be 8 - (lookahead + 2) = 4 steps ahead of the GPU before it has to wait.
+        sampler.host_gated = not _os.environ.get("PG_STREAM_GATED")
         cacher.missq_slots = len(sampler.slots)
         # ring slot i of the sampler carries the batch whose miss job sits in queue slot i: before the sampler waits for
         # "slot free" (recorded after that batch's consumer) the job's copy must be in its queue — see prepare()
@@ -311,10 +318,16 @@ class GraphedTrainer:
         ls.wait_event(nf._slot.ready)            # the sampler wrote this NodeFlow on its own stream
         if dbg is not None:
             ev[1].record(ls)
+        # "The graph that read this slot's buffers has finished" needs no wait of its own: the sampler stream waited for the
+        # ring slot's `free` event — recorded on the compute stream right after that graph (sampler.release) — before it
+        # sampled into the slot, and this stream has just waited for that sample. (Until round 3 a second event, `done`, was
+        # recorded beside `free` and waited for here: one more marker between two replays on the compute stream, one more
+        # barrier on this one, ~10 us of launch-thread time per step.) A sampler that does not recycle its slots that way
+        # (no manual_release / another consumer stream) still gets the explicit wait.
         if s.done_recorded:
-            # s.done was recorded AFTER the consumer of this slot's previous miss job (possibly a spin kernel waiting for
-            # that job's copy): the worker must have enqueued that copy before this barrier goes into a queue the copy
-            # stream may share (pg_missq_wait_idle). The submit below would block for the same condition anyway.
+            # recorded AFTER the consumer of this slot's previous miss job (possibly a spin kernel waiting for that job's
+            # copy): the worker must have enqueued that copy before this barrier goes into a queue the copy stream may
+            # share (pg_missq_wait_idle). The submit below would block for the same condition anyway.
             self.cacher.wait_worker(s.slot_index)
             ls.wait_event(s.done)                # the graph that read these buffers has finished
         if dbg is not None:
@@ -549,8 +562,9 @@ class GraphedTrainer:
                     self._sync_and_step(capture_ok=not warm)
                 # the slot's static loss tensor is overwritten when its graph is replayed again
                 loss = s.loss.clone() if self.keep_losses else s.loss
-        s.done.record(main)
-        s.done_recorded = True
+        if not self._free_orders_slot:
+            s.done.record(main)
+            s.done_recorded = True
         # NOTE: the returned loss lives on the compute stream. No wait is queued on the caller's (default)
         # stream on purpose — a pending wait there delayed the sampler / load streams of LATER batches until
         # this step had finished (measured: the sampler started only when the current graph ended). Call

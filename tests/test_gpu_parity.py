@@ -193,6 +193,8 @@ def _rand_csc(rng, V, E, powerlaw=True):
 
 @pytest.mark.parametrize("V,E,B,k,hops", [(2000, 12000, 256, 2, 2), (5000, 60000, 1000, 2, 2), (800, 9000, 100, 5, 3),
                                            (3000, 20000, 333, 1, 1), (4000, 50000, 512, 64, 1), (100000, 900000, 6000, 2, 2),
+                                           # 64 lanes per destination and more than 1024 * 4 of them: two destinations per group
+                                           (9000, 700000, 5000, 40, 1),
                                            # fan-out above one wave (k_sample_wide; the reference takes any --num-neighbors)
                                            (3000, 400000, 128, 65, 1), (3000, 500000, 64, 100, 2), (2500, 900000, 50, 300, 1)])
 def test_sampler_vs_oracle_bit_exact(dev, hiplib, oracle, V, E, B, k, hops):
@@ -220,6 +222,45 @@ def test_sampler_vs_oracle_bit_exact(dev, hiplib, oracle, V, E, B, k, hops):
                 assert np.array_equal(nf.blk_src[i].cpu().numpy(), ref["blocks"][i][1])
             nb += 1
         assert nb >= 1 and b == len(smp) - 1
+
+
+@pytest.mark.parametrize("V,E,B,k,hops,lookback", [(70000, 400000, 700, 2, 2, 3), (70000, 400000, 300, 3, 3, 2),
+                                                    (5000, 60000, 900, 33, 1, 7), (140000, 300000, 2000, 2, 2, 1)])
+def test_sampler_multi_round_lookback_paths(dev, hiplib, oracle, monkeypatch, V, E, B, k, hops, lookback):
+    """the five-launch chain's decoupled look-backs with the per-launch block limit shrunk (PG_SAMPLER_LOOKBACK, read at
+    sampler creation): a group samples several destinations (iters > 1) and a rank block makes several rounds over its
+    bitmap words (m > 1) — the shapes a 2^31-vertex graph or a 64-wide fan-out over a large batch takes with the real
+    limit of 1024 blocks. Static (fixed-shape, -1 padding) and DGL layouts, bit-exact vs the oracle."""
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    monkeypatch.setenv("PG_SAMPLER_LOOKBACK", str(lookback))
+    rng = np.random.default_rng(V + k + lookback)
+    adj = _rand_csc(rng, V, E)
+    g = DeviceGraph(adj)
+    train = np.sort(rng.choice(V, int(V * 0.3), replace=False)).astype(np.int64)
+    csc = spsp.csc_matrix(adj); csc.sort_indices()
+    for static in (False, True):
+        smp = NeighborSampler(g, B, k, neighbor_type='in', shuffle=False, num_hops=hops, seed_nodes=train, seed=9,
+                              static=static)
+        for b, nf in enumerate(smp):
+            if b > 2 and b < len(smp) - 1:
+                continue
+            ref = oracle.sample_nodeflow(csc.indptr, csc.indices, train[b * B:(b + 1) * B], k, hops, 9, 0, b)
+            torch.cuda.synchronize()
+            nm = nf._node_mapping.tousertensor().cpu().numpy()
+            if not static:
+                assert nf._layer_offsets == [int(x) for x in ref["layer_offsets"][:hops + 2]]
+                assert np.array_equal(nm, ref["node_mapping"])
+            offs = ref["layer_offsets"]
+            for l in range(hops + 1):
+                want = ref["node_mapping"][offs[l]:offs[l + 1]]
+                o0, o1 = nf._layer_offsets[l], nf._layer_offsets[l + 1]
+                assert np.array_equal(nm[o0:o0 + len(want)], want)
+                assert (nm[o0 + len(want):o1] == -1).all()
+            for i in range(hops):
+                ip, sr = ref["blocks"][i]
+                got_ip = nf.blk_indptr[i].cpu().numpy()
+                assert np.array_equal(got_ip[:len(ip)], ip) and (got_ip[len(ip):] == ip[-1]).all()
+                assert np.array_equal(nf.blk_src[i].cpu().numpy()[:len(sr)], sr)
 
 
 @pytest.mark.timeout(600)

@@ -23,3 +23,17 @@ for pos in range(L):
     print(f"{d:7.1f} us  {n[:110]}")
 span = sum(int(s[-1]["End_Timestamp"]) - int(s[0]["Start_Timestamp"]) for s in steps) / len(steps) / 1e3
 print(f"sum {tot:.1f} us, first-start..last-end {span:.1f} us, over {len(steps)} steps of {L} kernels")
+# step-to-step: period (first kernel start to the next step's first kernel start) and the gap between a step's last kernel
+# and the next step's first one — what the stream spends between two graph replays (event records, waits, launch)
+per, gap = [], []
+for a, b in zip(idx[5:-2], idx[6:-1]):
+    s0, s1 = q[a + 1:b + 1], q[b + 1:]
+    if len(s0) != L or not s1:
+        continue
+    per.append(int(s1[0]["Start_Timestamp"]) - int(s0[0]["Start_Timestamp"]))
+    gap.append(int(s1[0]["Start_Timestamp"]) - int(s0[-1]["End_Timestamp"]))
+if per:
+    per.sort(); gap.sort()
+    m = len(per) // 2
+    print(f"step period median {per[m] / 1e3:.1f} us (p10 {per[len(per) // 10] / 1e3:.1f}, p90 {per[9 * len(per) // 10] / 1e3:.1f}); "
+          f"gap between steps median {gap[m] / 1e3:.1f} us (p10 {gap[len(gap) // 10] / 1e3:.1f}, p90 {gap[9 * len(gap) // 10] / 1e3:.1f})")
