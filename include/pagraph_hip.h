@@ -218,7 +218,9 @@ int pg_missq_submit_range(pg_missq_t* q, int slot, float* const* out_ptrs, const
 /* pg_missq_submit_range for a launch that was split with a pg_dedup_t over the slot's dup buffers
  * (pg_missq_slot_dup_buffers): `slots_dev` = the slot array that split wrote (still intact at this point of
  * `stream`). The publish step turns every dup entry's "earlier row" into that row's staged index; after the primary
- * rows' scatter the worker fills the repeats on the device (pg_scatter_rows_dups) — they never cross PCIe. */
+ * rows' scatter the worker fills the repeats on the device (pg_scatter_rows_dups) — they never cross PCIe. The publish
+ * step also rewrites the repeats' OWN entries of `slots_dev` to their primary's value, -(staged row + 3), so that a
+ * consumer reading rows in place through that array (pg_spmm_fwd_rows, pg_linear2_fwd_rows) finds them.        */
 int pg_missq_submit_dedup(pg_missq_t* q, int slot, float* const* out_ptrs, const int32_t* out_strides,
                           const int32_t* pos_lo, const int32_t* slots_dev, pg_stream_t stream);
 int pg_missq_slot_dup_buffers(pg_missq_t* q, int slot, int32_t** dup_pos_dev, int32_t** dup_src_dev,
@@ -520,6 +522,19 @@ int pg_gcn_head_ex(const int32_t* indptr, const int32_t* src, const float* h, in
 int pg_linear_bwd_w_ex(const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n, int32_t K,
                        int32_t N, float* dW, float* db, const float* Yout, int32_t yo_stride, int32_t act,
                        float* dz_scratch, float* partials, int32_t sum_partials, pg_stream_t stream);
+
+/* NodeUpdate's dense step with its FIRST operand read in place from a row source (round 3; graphsage_nssc.py:21-30 —
+ * fc_self(h) of a layer whose 'features' were never gathered into a frame: h = the cache / the miss queue's staged block
+ * through pg_row_source_t, exactly as pg_spmm_fwd_rows reads them). Same arithmetic on the same bytes as
+ * pg_gather_rows + pg_linear2_fwd / pg_linear_bwd_w_ex: bit-identical results. Rows with slot -1 / -2 (padding of a
+ * fixed-shape layer) count as zero rows. K2 = 0 (X2, W2, bias2 NULL): the one-operand step. Needs 16-byte aligned
+ * rows in both homes (strides % 4 == 0, >= K rounded up to 4), N <= 64 for the forward.                         */
+int pg_linear2_fwd_rows(const pg_row_source_t* X, int32_t K, const float* W, const float* bias, const float* X2,
+                        int32_t x2_stride, const float* W2, const float* bias2, int32_t K2, float* Y, int32_t y_stride,
+                        int64_t n, int32_t N, int32_t act, pg_stream_t stream);
+int pg_linear_bwd_w_rows(const float* dY, int32_t dy_stride, const pg_row_source_t* X, int64_t n, int32_t K, int32_t N,
+                         float* dW, float* db, const float* Yout, int32_t yo_stride, int32_t act, float* dz_scratch,
+                         float* partials, int32_t sum_partials, pg_stream_t stream);
 int pg_gcn_head(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
                 const float* W, const float* bias, int32_t C, const int64_t* labels, int64_t ignore_index,
                 const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,

@@ -55,7 +55,25 @@ typedef float df2 __attribute__((ext_vector_type(2)));
 // (2.1 TB/s of X); the two-operand 12 000 x (600 + 600) x 16: 28.4 -> 21.1 us.
 constexpr int kXsStride = 36;
 
-template <int WV, int NW, bool LDSX>
+// ROWS (round 3): the first operand's rows are never materialised — row r lives at X + slots[r] * x_stride (the fused
+// feature cache) when slots[r] >= 0, at staged - (slots[r] + 3) * staged_stride (the miss queue's staged block) when
+// slots[r] <= -3, and is all zeros for -2 / -1 (the padding of a fixed-shape layer): pg_row_source_t, the same
+// addressing k_spmm_fwd_rows uses. A lane resolves the (at most four) rows it ever fetches once, before the K loop; the
+// bytes multiplied are the ones a gather would have copied, so the result is bit-identical to gather + k_linear_fwd.
+struct RowsArg {
+  const int32_t* slots;
+  const float* staged;
+  int32_t staged_stride;
+};
+
+__device__ __forceinline__ const float* row_of(const float* cache, int32_t cstride, const RowsArg& ra, int64_t r) {
+  const int32_t sl = ra.slots[r];
+  if (sl >= 0) return cache + (int64_t)sl * cstride;
+  if (sl <= -3) return ra.staged + (int64_t)(-(sl + 3)) * ra.staged_stride;
+  return nullptr;
+}
+
+template <int WV, int NW, bool LDSX, bool ROWS = false>
 __global__ __launch_bounds__(NW * 64) void k_linear_fwd(const float* __restrict__ X, int32_t x_stride,
                                                     const float* __restrict__ W /* [N][K] */,
                                                     const float* __restrict__ bias /* [N] or null */,
@@ -63,7 +81,7 @@ __global__ __launch_bounds__(NW * 64) void k_linear_fwd(const float* __restrict_
                                                     const float* __restrict__ W2 /* [N][K2] */,
                                                     const float* __restrict__ bias2, int32_t K2,
                                                     float* __restrict__ Y, int32_t y_stride, int64_t n, int32_t K,
-                                                    int32_t N, int32_t act) {
+                                                    int32_t N, int32_t act, const RowsArg ra = RowsArg{}) {
   // one LDS buffer: during the K loop wave w's X slab, afterwards wave w's partial output tile (same region, same wave)
   // (+ with WV == 4 a second slab per wave for its share of W)
   __shared__ __attribute__((aligned(16))) float smem[NW * kTile * kXsStride * ((LDSX && WV == 4) ? 2 : 1)];
@@ -79,6 +97,21 @@ __global__ __launch_bounds__(NW * 64) void k_linear_fwd(const float* __restrict_
   const int col = n0 + (lane & 31);
   const bool col_ok = col < N;
   const float* xr = X + (row_ok ? row : 0) * x_stride + 4 * half;
+  bool x1_ok = true;                                  // ROWS: this lane's own row exists (not padding)
+  if constexpr (ROWS) {
+    const float* rp = row_ok ? row_of(X, x_stride, ra, row) : nullptr;
+    x1_ok = rp != nullptr;
+    xr = (x1_ok ? rp : X) + 4 * half;
+  }
+  // ROWS: the four rows this lane fetches for the wave's slab (row (lane >> 3) + 8 i of the tile), resolved once
+  const float* slab_row[4] = {nullptr, nullptr, nullptr, nullptr};
+  if constexpr (ROWS && LDSX) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t r = r0 + (lane >> 3) + 8 * i;
+      slab_row[i] = r < n ? row_of(X, x_stride, ra, r) : nullptr;
+    }
+  }
   // B operand: lane (col, half) needs W[col][kk + 4*half + j], j = 0..3 -> one 16-byte load per octet
   const float* wr = W + (int64_t)(col_ok ? col : 0) * K + 4 * half;
   const float* xr2 = X2 ? X2 + (row_ok ? row : 0) * x2_stride + 4 * half : nullptr;
@@ -112,8 +145,12 @@ __global__ __launch_bounds__(NW * 64) void k_linear_fwd(const float* __restrict_
     }
   };
   auto load = [&](int o, df4& a, df4& b) {
-    if (o < oct1) load1(xr, wr, o, K, a, b);
-    else load1(xr2, wr2, o - oct1, K2, a, b);
+    if (o < oct1) {
+      load1(xr, wr, o, K, a, b);
+      if (ROWS && !x1_ok) a = df4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      load1(xr2, wr2, o - oct1, K2, a, b);
+    }
     if (!row_ok) a = df4{0.f, 0.f, 0.f, 0.f};
     if (!col_ok) b = df4{0.f, 0.f, 0.f, 0.f};
   };
@@ -141,8 +178,9 @@ __global__ __launch_bounds__(NW * 64) void k_linear_fwd(const float* __restrict_
       for (int i = 0; i < 4; ++i) {
         const int c = lane + 64 * i, r = c >> 3, kc = kbase + (c & 7) * 4;
         v[i] = df4{0.f, 0.f, 0.f, 0.f};
-        if (r0 + r < n && kc < Kx) {
-          v[i] = *reinterpret_cast<const df4*>(xb + (r0 + r) * xst + kc);   // rows are padded to 4 floats
+        const float* rowp = (ROWS && first) ? slab_row[i] : xb + (r0 + r) * xst;
+        if (r0 + r < n && kc < Kx && rowp) {
+          v[i] = *reinterpret_cast<const df4*>(rowp + kc);   // rows are padded to 4 floats
           const int left = Kx - kc;
           if (left < 4) {
             if (left < 2) v[i].y = 0.f;
@@ -284,10 +322,13 @@ __global__ __launch_bounds__(256) void k_dz(const float* __restrict__ G, int32_t
 // block = 4 waves on ONE (32-feature, 32-column) tile of dW, each wave reducing its own `rpw` rows
 // (16 rows = 8 MFMA steps with all 16 loads in flight per iteration); the four partial tiles are summed
 // through LDS and leave as one set of atomics per block.
+// ROWS: X's rows through a pg_row_source_t (see k_linear_fwd): lane l of a wave looks up the slot of the wave's l-th row
+// once (rpw <= 64), a row's base address then comes from that lane by shuffle.
+template <bool ROWS>
 __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ dY, int32_t dy_stride,
                                                       const float* __restrict__ X, int32_t x_stride, int64_t n,
                                                       int32_t K, int32_t N, float* __restrict__ part, int32_t with_bias,
-                                                      int32_t rpw, int32_t items, int32_t chunks) {
+                                                      int32_t rpw, int32_t items, int32_t chunks, const RowsArg ra) {
   __shared__ float red[4][kTile][kTile + 1];
   __shared__ float bred[4][kWave];
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
@@ -309,18 +350,39 @@ __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ 
   const bool a_ok = i < N, b_ok = c0 + (lane & 31) < K;
   const bool do_bias = with_bias && c0 == 0;
   const float* ap = dY + (a_ok ? i : 0);
-  const float* bp = X + c0 + (b_ok ? (lane & 31) : 0);
+  const int bcol = c0 + (b_ok ? (lane & 31) : 0);
+  const float* bp = X + bcol;
+  // ROWS: lane l holds the slot of the wave's l-th row; a row pair's slots come back by v_readlane (the pair is
+  // wave-uniform: lane half h works on row base + h)
+  int32_t my_slot = -2;
+  if constexpr (ROWS) {
+    const int64_t r = rb + lane;
+    if (lane < rpw && r < re) my_slot = ra.slots[r];
+  }
+  auto xload = [&](int rel /* wave-uniform: even row of the pair, relative to rb */, int64_t r) -> float {
+    if constexpr (ROWS) {
+      const int32_t s_e = __builtin_amdgcn_readlane(my_slot, rel);
+      const int32_t s_o = __builtin_amdgcn_readlane(my_slot, rel + 1 < kWave ? rel + 1 : kWave - 1);
+      const int32_t sl = half ? s_o : s_e;
+      if (sl >= 0) return X[(int64_t)sl * x_stride + bcol];
+      if (sl <= -3) return ra.staged[(int64_t)(-(sl + 3)) * ra.staged_stride + bcol];
+      return 0.f;
+    } else {
+      return bp[r * x_stride];
+    }
+  };
   f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   float bsum = 0.f;
   // `base` is wave-uniform (MFMA needs the whole wave); lane half h works on row base + h
   int64_t base = rb;
   for (; base + 15 < re; base += 16) {
     const int64_t r = base + half;
+    const int ub = __builtin_amdgcn_readfirstlane((int)(base - rb));
     float a[8], b[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       a[u] = ap[(r + 2 * u) * dy_stride];
-      b[u] = bp[(r + 2 * u) * x_stride];
+      b[u] = xload(ub + 2 * u, r + 2 * u);
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -332,8 +394,10 @@ __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ 
   for (; base < re; base += 2) {  // tail: the odd half may fall off the end
     const int64_t r = base + half;
     const bool ok = r < re;
+    const int ub = __builtin_amdgcn_readfirstlane((int)(base - rb));
     const float a = (ok && a_ok) ? ap[r * dy_stride] : 0.f;
-    const float b = (ok && b_ok) ? bp[r * x_stride] : 0.f;
+    const float bx = (ROWS || ok) ? xload(ub, ok ? r : rb) : 0.f;     // (ROWS: a row past the end has slot -2 -> 0)
+    const float b = (ok && b_ok) ? bx : 0.f;
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     bsum += a;
   }
@@ -403,9 +467,27 @@ using namespace pg;
 
 extern "C" {
 
+// a row source's envelope for the dense kernels: 16-byte aligned rows in both homes
+static int rows_arg(const pg_row_source_t* X, int32_t K, const float** base, int32_t* stride, RowsArg* ra) {
+  if (!X || !X->slots) return PG_ERR_INVALID;
+  if (!X->cache && !X->staged) return PG_ERR_INVALID;
+  const int32_t k4 = (K + 3) & ~3;
+  if (X->cache && (X->cache_stride < k4 || (X->cache_stride & 3) || (reinterpret_cast<uintptr_t>(X->cache) & 15)))
+    return PG_ERR_UNSUPPORTED;
+  if (X->staged && (X->staged_stride < k4 || (X->staged_stride & 3) || (reinterpret_cast<uintptr_t>(X->staged) & 15)))
+    return PG_ERR_UNSUPPORTED;
+  // a home that does not exist is never addressed (no slot points into it); its base only has to be a valid pointer
+  *base = X->cache ? X->cache : X->staged;
+  *stride = X->cache ? X->cache_stride : X->staged_stride;
+  ra->slots = X->slots;
+  ra->staged = X->staged ? X->staged : X->cache;
+  ra->staged_stride = X->staged ? X->staged_stride : X->cache_stride;
+  return PG_OK;
+}
+
 static int linear_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, const float* X2,
                       int32_t x2_stride, const float* W2, const float* bias2, int32_t K2, float* Y, int32_t y_stride,
-                      int64_t n, int32_t K, int32_t N, int32_t act, pg_stream_t stream) {
+                      int64_t n, int32_t K, int32_t N, int32_t act, pg_stream_t stream, const RowsArg* rows = nullptr) {
   if (n < 0 || K <= 0 || N <= 0 || K2 < 0 || x_stride < K || act < 0 || act > 2 || y_stride < (act == 2 ? 2 * N : N))
     return PG_ERR_INVALID;
   if (K2 > 0 && (!X2 || !W2 || x2_stride < K2)) return PG_ERR_INVALID;
@@ -436,7 +518,10 @@ static int linear_fwd(const float* X, int32_t x_stride, const float* W, const fl
   static const bool no_lds = getenv("PG_LINEAR_NO_LDS") != nullptr;
 #define PG_LIN_FWD(WV, NW)                                                                                          \
   do {                                                                                                              \
-    if (no_lds)                                                                                                     \
+    if (rows)                                                                                                       \
+      hipLaunchKernelGGL((k_linear_fwd<WV, NW, true, true>), grid, dim3(NW * 64), 0, as_stream(stream), X, x_stride, \
+                         W, bias, X2, x2_stride, W2, bias2, K2, Y, y_stride, n, K, N, act, *rows);                  \
+    else if (no_lds)                                                                                                \
       hipLaunchKernelGGL((k_linear_fwd<WV, NW, false>), grid, dim3(NW * 64), 0, as_stream(stream), X, x_stride, W,  \
                          bias, X2, x2_stride, W2, bias2, K2, Y, y_stride, n, K, N, act);                            \
     else                                                                                                            \
@@ -459,6 +544,18 @@ static int linear_fwd(const float* X, int32_t x_stride, const float* W, const fl
 int pg_linear_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, float* Y, int32_t y_stride,
                   int64_t n, int32_t K, int32_t N, int32_t act, pg_stream_t stream) {
   return linear_fwd(X, x_stride, W, bias, nullptr, 0, nullptr, nullptr, 0, Y, y_stride, n, K, N, act, stream);
+}
+
+int pg_linear2_fwd_rows(const pg_row_source_t* X, int32_t K, const float* W, const float* bias, const float* X2,
+                        int32_t x2_stride, const float* W2, const float* bias2, int32_t K2, float* Y, int32_t y_stride,
+                        int64_t n, int32_t N, int32_t act, pg_stream_t stream) {
+  const float* base = nullptr;
+  int32_t stride = 0;
+  RowsArg ra{};
+  const int rc = rows_arg(X, K, &base, &stride, &ra);
+  if (rc != PG_OK) return rc;
+  return linear_fwd(base, stride, W, bias, X2, x2_stride, W2, bias2, K2 > 0 ? K2 : 0, Y, y_stride, n, K, N, act, stream,
+                    &ra);
 }
 
 int pg_linear2_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, int32_t K, const float* X2,
@@ -490,9 +587,32 @@ int pg_linear_bwd_w(const float* dY, int32_t dy_stride, const float* X, int32_t 
                             stream);
 }
 
+static int linear_bwd_w(const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n, int32_t K,
+                        int32_t N, float* dW, float* db, const float* Yout, int32_t yo_stride, int32_t act,
+                        float* dz_scratch, float* partials, int32_t sum_partials, const RowsArg* rows, pg_stream_t stream);
+
 int pg_linear_bwd_w_ex(const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n, int32_t K,
                        int32_t N, float* dW, float* db, const float* Yout, int32_t yo_stride, int32_t act,
                        float* dz_scratch, float* partials, int32_t sum_partials, pg_stream_t stream) {
+  return linear_bwd_w(dY, dy_stride, X, x_stride, n, K, N, dW, db, Yout, yo_stride, act, dz_scratch, partials, sum_partials,
+                      nullptr, stream);
+}
+
+int pg_linear_bwd_w_rows(const float* dY, int32_t dy_stride, const pg_row_source_t* X, int64_t n, int32_t K, int32_t N,
+                         float* dW, float* db, const float* Yout, int32_t yo_stride, int32_t act, float* dz_scratch,
+                         float* partials, int32_t sum_partials, pg_stream_t stream) {
+  const float* base = nullptr;
+  int32_t stride = 0;
+  RowsArg ra{};
+  const int rc = rows_arg(X, K, &base, &stride, &ra);
+  if (rc != PG_OK) return rc;
+  return linear_bwd_w(dY, dy_stride, base, stride, n, K, N, dW, db, Yout, yo_stride, act, dz_scratch, partials,
+                      sum_partials, &ra, stream);
+}
+
+static int linear_bwd_w(const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n, int32_t K,
+                        int32_t N, float* dW, float* db, const float* Yout, int32_t yo_stride, int32_t act,
+                        float* dz_scratch, float* partials, int32_t sum_partials, const RowsArg* rows, pg_stream_t stream) {
   if (n < 0 || K <= 0 || N <= 0 || x_stride < K || act < 0 || act > 2 || dy_stride < (act == 2 ? 2 * N : N))
     return PG_ERR_INVALID;
   if (act != 0 && (!Yout || yo_stride < N || !dz_scratch)) return PG_ERR_INVALID;
@@ -511,8 +631,12 @@ int pg_linear_bwd_w_ex(const float* dY, int32_t dy_stride, const float* X, int32
     dY = dz_scratch;
     dy_stride = N;
   }
-  hipLaunchKernelGGL(k_linear_bwd_w, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), dY, dy_stride, X, x_stride,
-                     n, K, N, partials, db ? 1 : 0, rpw, (int32_t)items, (int32_t)chunks);
+  if (rows)
+    hipLaunchKernelGGL(k_linear_bwd_w<true>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), dY, dy_stride, X,
+                       x_stride, n, K, N, partials, db ? 1 : 0, rpw, (int32_t)items, (int32_t)chunks, *rows);
+  else
+    hipLaunchKernelGGL(k_linear_bwd_w<false>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), dY, dy_stride, X,
+                       x_stride, n, K, N, partials, db ? 1 : 0, rpw, (int32_t)items, (int32_t)chunks, RowsArg{});
   PG_LAUNCH_CHECK();
   if (!sum_partials) return PG_OK;   // the consumer (pg_adam_step_partials) adds the chunks up itself
   const int64_t nk = (int64_t)N * K;

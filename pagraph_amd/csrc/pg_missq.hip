@@ -53,14 +53,19 @@ __global__ void k_publish(const int32_t* __restrict__ count_dev, int32_t* count_
 
 // k_publish for a launch whose split ran with index dedup: every dup entry's "earlier row" becomes that row's
 // staged index (the split wrote -(j + 3) into the primary's slot), then the count is published as above
+// (round 3) ... and the repeat's OWN slot entry takes the primary's value: a consumer that reads rows in place through
+// the slot array (pg_spmm_fwd_rows, pg_linear2_fwd_rows: no frame the repeat could be copied into) then finds the
+// primary's staged row. A repeat is never a primary, so the entries read and the entries written are disjoint.
 __global__ __launch_bounds__(256) void k_publish_dedup(const int32_t* __restrict__ count_dev, int32_t* count_host,
-                                                       uint32_t* flag_host, uint32_t seq,
-                                                       const int32_t* __restrict__ slots, int32_t* __restrict__ dup_src,
+                                                       uint32_t* flag_host, uint32_t seq, int32_t* slots,
+                                                       int32_t* __restrict__ dup_src,
+                                                       const int32_t* __restrict__ dup_pos,
                                                        const int32_t* __restrict__ dup_count) {
   const int32_t nd = *dup_count;
   for (int32_t k = threadIdx.x; k < nd; k += blockDim.x) {
     const int32_t s = slots[dup_src[k]];
     dup_src[k] = s <= -3 ? -s - 3 : -1;
+    if (s <= -3) slots[dup_pos[k]] = s;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -962,7 +967,7 @@ int pg_missq_submit_dedup(pg_missq_t* q, int slot, float* const* out_ptrs, const
   }
   if (slots_dev)
     hipLaunchKernelGGL(k_publish_dedup, dim3(1), dim3(256), 0, as_stream(stream), s.count_d, s.count_h, s.flag_h, seq,
-                       slots_dev, s.dup_src_d, s.dup_count_d);
+                       const_cast<int32_t*>(slots_dev), s.dup_src_d, s.dup_pos_d, s.dup_count_d);
   else
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, as_stream(stream), s.count_d, s.count_h, s.flag_h, seq);
   PG_LAUNCH_CHECK();

@@ -85,10 +85,18 @@ class GraphSageSampling(FusedDropoutMixin, nn.Module):
         return {l: list(f) for l in range(num_layers)}
 
     def virtual_inputs(self, num_layers):
-        """layer 0 is only ever a source of block 0's aggregation (its self term belongs to no NodeUpdate,
-        graphsage_nssc.py:92-111): its 'features' may stay un-materialised (ops.RowSource). Not under preprocess
-        (every layer goes through fc_self / fc_neigh first, :76-87)."""
-        return {} if self.preprocess else {0: ['features']}
+        """Every layer's raw 'features' may stay un-materialised (ops.RowSource): they are read by model layer 0 only —
+        as the source rows of a block's aggregation (graphsage_nssc.py:92-111: pg_spmm_fwd_rows) and as the self term
+        fc_self(h) of the block's destinations (:24: pg_linear2_fwd_rows / pg_linear_bwd_w_rows, which need at most 64
+        hidden units); from model layer 1 on a layer's 'h' is the previous activation. With a wider hidden layer only
+        layer 0 (a source of block 0 and nothing else) stays virtual. Not under preprocess (every layer goes through
+        fc_self / fc_neigh first, :76-87). PG_SAGE_VIRTUAL_L0=1: layer 0 only (rounds 1-2), for A/B runs."""
+        import os
+        if self.preprocess:
+            return {}
+        if self.layers[0].fc_self.out_features > 64 or os.environ.get("PG_SAGE_VIRTUAL_L0"):
+            return {0: ['features']}
+        return {l: ['features'] for l in range(num_layers)}
 
     def forward(self, nf):
         L = nf.num_layers

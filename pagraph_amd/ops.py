@@ -381,9 +381,15 @@ def _bwd_w(lib, g, x, K, N, y, act, want_bias, weight=None, bias=None):
     dz = torch.empty((x.size(0), N), dtype=torch.float32, device=x.device) if act != ACT_NONE else None
     defer = _DEFER is not None and weight is not None and want_bias and bias is not None
     with torch.cuda.device(x.device):
-        L.check(lib.pg_linear_bwd_w_ex(L.ptr(g), g.stride(0), L.ptr(x), x.stride(0), x.size(0), K, N, L.ptr(gw), L.ptr(gb),
-                                       L.ptr(y), y.stride(0) if y is not None else 0, act, L.ptr(dz), L.ptr(part),
-                                       0 if defer else 1, L.stream_ptr()), "pg_linear_bwd_w")
+        if isinstance(x, RowSource):     # the rows were never gathered: read them where they live
+            rs = x.struct()
+            L.check(lib.pg_linear_bwd_w_rows(L.ptr(g), g.stride(0), ctypes.byref(rs), x.size(0), K, N, L.ptr(gw), L.ptr(gb),
+                                             L.ptr(y), y.stride(0) if y is not None else 0, act, L.ptr(dz), L.ptr(part),
+                                             0 if defer else 1, L.stream_ptr()), "pg_linear_bwd_w_rows")
+        else:
+            L.check(lib.pg_linear_bwd_w_ex(L.ptr(g), g.stride(0), L.ptr(x), x.stride(0), x.size(0), K, N, L.ptr(gw),
+                                           L.ptr(gb), L.ptr(y), y.stride(0) if y is not None else 0, act, L.ptr(dz),
+                                           L.ptr(part), 0 if defer else 1, L.stream_ptr()), "pg_linear_bwd_w")
     if defer:
         rowlen = N * K + N
         if not _DEFER.add(weight, part, part.numel() // rowlen, rowlen, 0):
@@ -405,11 +411,21 @@ class _DualLinear(torch.autograd.Function):
         K2 = x2.size(1)
         N = w1.size(0)
         y = torch.empty((n, 2 * N if act == ACT_CONCAT else N), dtype=torch.float32, device=x1.device)
+        rows = x1 if isinstance(x1, RowSource) else None
         with torch.cuda.device(x1.device):
-            L.check(lib.pg_linear2_fwd(L.ptr(x1), x1.stride(0), L.ptr(w1), L.ptr(b1), K1, L.ptr(x2), x2.stride(0),
-                                       L.ptr(w2), L.ptr(b2), K2, L.ptr(y), y.stride(0), n, N, act, L.stream_ptr()),
-                    "pg_linear2_fwd")
-        ctx.save_for_backward(x1, w1, x2, w2, y if act != ACT_NONE else None)
+            if rows is not None:
+                # fc_self(h) of a layer whose features stayed in the cache / the staged miss block (graphsage_nssc.py:24):
+                # the gather is the dense kernel's own LDS fill
+                rs = rows.struct()
+                L.check(lib.pg_linear2_fwd_rows(ctypes.byref(rs), K1, L.ptr(w1), L.ptr(b1), L.ptr(x2), x2.stride(0),
+                                                L.ptr(w2), L.ptr(b2), K2, L.ptr(y), y.stride(0), n, N, act,
+                                                L.stream_ptr()), "pg_linear2_fwd_rows")
+            else:
+                L.check(lib.pg_linear2_fwd(L.ptr(x1), x1.stride(0), L.ptr(w1), L.ptr(b1), K1, L.ptr(x2), x2.stride(0),
+                                           L.ptr(w2), L.ptr(b2), K2, L.ptr(y), y.stride(0), n, N, act, L.stream_ptr()),
+                        "pg_linear2_fwd")
+        ctx.rows = rows
+        ctx.save_for_backward(x1 if rows is None else None, w1, x2, w2, y if act != ACT_NONE else None)
         ctx.bias = (b1 is not None, b2 is not None)
         ctx.bias_refs = (b1, b2)
         ctx.act = act
@@ -418,6 +434,8 @@ class _DualLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x1, w1, x2, w2, y = ctx.saved_tensors
+        if ctx.rows is not None:
+            x1 = ctx.rows
         lib = L.load()
         gy = gy.contiguous()
         N = w1.size(0)
@@ -436,19 +454,25 @@ def _rows_ok(x):
     return x.size(0) >= 1024 or _DEFER is not None
 
 
-def _skinny_ok(x, w):
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and w.size(0) <= 64 and _rows_ok(x)
+def _skinny_ok(x, w, any_rows=False):
+    if isinstance(x, RowSource):
+        return x.aligned() and w.size(0) <= 64 and w.is_contiguous() and w.size(1) == x.dim
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and w.size(0) <= 64 and (any_rows or _rows_ok(x))
             and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and w.is_contiguous())
 
 
 def linear2(x1, mod1, x2, mod2, act=ACT_NONE):
     """act(mod1(x1) + mod2(x2)) — GraphSAGE's NodeUpdate — on one MFMA pass when both operands fit the
     skinny envelope, else through the modules"""
+    virt = isinstance(x1, RowSource)      # rows that exist nowhere as a tensor: the kernel is the only way, however few
     if x1.size(0) == x2.size(0) and mod1.weight.size(0) == mod2.weight.size(0) and _skinny_ok(x1, mod1.weight) \
-            and _skinny_ok(x2, mod2.weight):
+            and _skinny_ok(x2, mod2.weight, any_rows=virt):
         if _DEFER is not None and (mod1.bias is None or mod2.bias is None):
             _DEFER.saw_plain(mod1.weight, mod1.bias, mod2.weight, mod2.bias)     # _bwd_w does not defer without a bias
         return _DualLinear.apply(x1, mod1.weight, mod1.bias, x2, mod2.weight, mod2.bias, act)
+    if isinstance(x1, RowSource) or isinstance(x2, RowSource):
+        raise L.PgError("linear2: an un-materialised operand (ops.RowSource) needs the skinny dense kernels: first operand "
+                        "only, 16-byte aligned rows, at most 64 outputs (a model's virtual_inputs() promised that)")
     return _apply_act(linear(x1, mod1) + linear(x2, mod2), act)
 
 

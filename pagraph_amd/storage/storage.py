@@ -645,7 +645,10 @@ class GraphCacheServer:
                 for name in (need[l] if need is not None else names):
                     plan.row_sources[(l, name)] = RowSource(plan.slots[a:b], self.gpu_fix_cache.get(name), staged.get(name, 0),
                                                             sstride.get(name, self.dims[name]), self.dims[name],
-                                                            keep=(self, plan), prof=self.rows_prof)
+                                                            keep=(self, plan),
+                                                            # (the self-timing ring is indexed by the step: ONE launch per
+                                                            # step may stamp it — the first layer's, the dominant one)
+                                                            prof=self.rows_prof if l == vlayers[0] else None)
         plan.cache_epoch = self._cache_epoch
         return plan
 

@@ -1733,7 +1733,9 @@ def test_virtual_layer0_matches_materialised(dev, hiplib, arch, mode):
     from pagraph_amd.sampling import DeviceGraph, NeighborSampler
     from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
     rng = np.random.default_rng(12)
-    V, Fd, C, B, k = 5000, 600, 11, 300, 2
+    # (>= 1024 rows in every layer: below that ops.linear / linear2 hand a DENSE operand to the library GEMM, whose rounding
+    # differs from the MFMA kernel an un-materialised operand always takes)
+    V, Fd, C, B, k = 5000, 600, 11, 1250, 2
     adj = _rand_csc(rng, V, 40000)
     g = DeviceGraph(adj)
     feats = rng.random((V, Fd), dtype=np.float32)
@@ -1750,11 +1752,13 @@ def test_virtual_layer0_matches_materialised(dev, hiplib, arch, mode):
     model = model.to(dev).train()
     need = model.required_inputs(3)
     virt = model.virtual_inputs(3)
-    assert virt == {0: ['features']}
-    smp = NeighborSampler(g, B, k, neighbor_type='in', shuffle=False, num_hops=2, seed_nodes=np.arange(0, V, 2), seed=1)
+    # GCN reads layer 0 only; GraphSAGE's self terms read layers 1 and 2 in place as well (pg_linear2_fwd_rows, round 3)
+    assert virt == ({0: ['features']} if arch == "gcn" else {0: ['features'], 1: ['features'], 2: ['features']})
+    smp = NeighborSampler(g, B, k, neighbor_type='in', shuffle=False, num_hops=2, seed_nodes=np.arange(V), seed=1)
     it = iter(smp)
     for rep in range(2):
         nf = next(it)
+        assert min(nf.layer_size(i) for i in range(3)) >= 1024
         outs = []
         for v in (None, virt):
             model._drop_step.fill_(7 + rep)                  # both runs draw the same dropout masks
@@ -1763,7 +1767,7 @@ def test_virtual_layer0_matches_materialised(dev, hiplib, arch, mode):
             c.wait_misses(rep)
             assert isinstance(nf._node_frames[0]["features"], RowSource) == (v is not None)
             if arch == "sage":
-                assert all(torch.is_tensor(nf._node_frames[i]["features"]) for i in (1, 2))
+                assert all(isinstance(nf._node_frames[i]["features"], RowSource) == (v is not None) for i in (1, 2))
             y = model(nf)
             y.square().sum().backward()
             torch.cuda.synchronize()
@@ -1786,6 +1790,68 @@ def test_virtual_layer0_matches_materialised(dev, hiplib, arch, mode):
         ids0 = nf.layer_parent_nid(0).cpu().numpy()
         out = ops_aggregate_identity(nf._node_frames[0]["features"], dev)
         assert np.array_equal(out, feats[ids0])
+
+
+@pytest.mark.parametrize("n,K,N,K2,act", [(12000, 600, 16, 600, 2), (6000, 600, 16, 600, 1), (4133, 600, 32, 64, 2),
+                                          (1000, 602, 16, 602, 0), (777, 256, 64, 0, 1), (50, 600, 16, 600, 2)])
+def test_dense_step_from_row_source_is_bit_identical(dev, hiplib, n, K, N, K2, act):
+    """pg_linear2_fwd_rows / pg_linear_bwd_w_rows read the first operand's rows where they live (cache slot, staged miss
+    row, zero for padding) and give exactly what pg_linear2_fwd / pg_linear_bwd_w_ex give on the gathered copy"""
+    from pagraph_amd import _lib as L
+    rng = np.random.default_rng(n + K)
+    cs = (K + 7) & ~7                      # fused cache rows are padded
+    ss = (K + 3) & ~3                      # staged rows: whole 16-byte pieces
+    n_cache, n_staged = 3000, 700
+    cache = torch.from_numpy(rng.standard_normal((n_cache, cs), dtype=np.float32)).to(dev)
+    staged = torch.from_numpy(rng.standard_normal((n_staged, ss), dtype=np.float32)).to(dev)
+    kind = rng.random(n)
+    slots = np.where(kind < 0.7, rng.integers(0, n_cache, n), np.where(kind < 0.95, -(rng.integers(0, n_staged, n) + 3), -2))
+    slots = slots.astype(np.int32)
+    X = np.zeros((n, cs), np.float32)      # what a gather would have produced (padding rows: zeros)
+    hit, miss = slots >= 0, slots <= -3
+    X[hit, :K] = cache.cpu().numpy()[slots[hit], :K]
+    X[miss, :K] = staged.cpu().numpy()[-(slots[miss] + 3), :K]
+    Xd = torch.from_numpy(X).to(dev)
+    sl = torch.from_numpy(slots).to(dev)
+    W = torch.from_numpy(rng.standard_normal((N, K), dtype=np.float32) * 0.05).to(dev)
+    b = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(dev)
+    X2 = W2 = b2 = None
+    if K2:
+        X2 = torch.from_numpy(rng.standard_normal((n, (K2 + 3) & ~3), dtype=np.float32)).to(dev)
+        W2 = torch.from_numpy(rng.standard_normal((N, K2), dtype=np.float32) * 0.05).to(dev)
+        b2 = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(dev)
+    rs = L.PgRowSource(sl.data_ptr(), cache.data_ptr(), staged.data_ptr(), cs, ss)
+    yc = 2 * N if act == 2 else N
+    Ya = torch.empty((n, yc), device=dev); Yb = torch.empty((n, yc), device=dev)
+    x2p, x2s = (L.ptr(X2), X2.stride(0)) if K2 else (None, 0)
+    L.check(hiplib.pg_linear2_fwd(L.ptr(Xd), cs, L.ptr(W), L.ptr(b), K, x2p, x2s, L.ptr(W2), L.ptr(b2), K2, L.ptr(Ya), yc,
+                                  n, N, act, None) if K2 else
+            hiplib.pg_linear_fwd(L.ptr(Xd), cs, L.ptr(W), L.ptr(b), L.ptr(Ya), yc, n, K, N, act, None), "dense fwd")
+    L.check(hiplib.pg_linear2_fwd_rows(ctypes.byref(rs), K, L.ptr(W), L.ptr(b), x2p, x2s, L.ptr(W2), L.ptr(b2), K2,
+                                       L.ptr(Yb), yc, n, N, act, None), "pg_linear2_fwd_rows")
+    torch.cuda.synchronize()
+    assert torch.equal(Ya, Yb)
+    # weight gradient of the first operand
+    G = torch.from_numpy(rng.standard_normal((n, yc), dtype=np.float32)).to(dev)
+    scratch = hiplib.pg_linear_bwd_w_scratch(n, K, N)
+    res = []
+    for rows in (False, True):
+        part = torch.zeros(scratch, device=dev)
+        dW = torch.empty((N, K), device=dev); db = torch.empty(N, device=dev)
+        dz = torch.empty((n, N), device=dev)
+        if rows:
+            L.check(hiplib.pg_linear_bwd_w_rows(L.ptr(G), yc, ctypes.byref(rs), n, K, N, L.ptr(dW), L.ptr(db), L.ptr(Ya), yc,
+                                                act, L.ptr(dz), L.ptr(part), 1, None), "pg_linear_bwd_w_rows")
+        else:
+            L.check(hiplib.pg_linear_bwd_w_ex(L.ptr(G), yc, L.ptr(Xd), cs, n, K, N, L.ptr(dW), L.ptr(db), L.ptr(Ya), yc,
+                                              act, L.ptr(dz), L.ptr(part), 1, None), "pg_linear_bwd_w_ex")
+        torch.cuda.synchronize()
+        res.append((dW.clone(), db.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    ref = (G[:, :N] if act == 0 else None)
+    if act == 0:      # sanity against torch in float64
+        want = ref.double().t() @ Xd[:, :K].double()
+        assert (res[1][0].double() - want).abs().max() < 1e-3 * max(1.0, float(want.abs().max()))
 
 
 def ops_aggregate_identity(rows, dev):
@@ -1885,9 +1951,9 @@ def test_config3_full_size_sampler_and_fetch(dev, hiplib, oracle):
             for l in range(hops + 1):
                 fr = nf._node_frames[l]["features"]
                 if isinstance(fr, RowSource):
-                    assert l == 0 and v is not None
+                    assert v is not None          # (GraphSAGE: every layer's rows stay where they live, round 3)
                     # read the un-materialised rows the way the kernel does: an identity block, reduce = sum
-                    n0 = o[1] - o[0]
+                    n0 = o[l + 1] - o[l]
                     from pagraph_amd import ops
                     ident_ip = torch.arange(n0 + 1, dtype=torch.int32, device=dev)
                     ident_src = torch.arange(n0, dtype=torch.int32, device=dev)
