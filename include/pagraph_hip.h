@@ -506,6 +506,9 @@ int pg_xent_bwd(const float* dlogits, int32_t d_stride, int64_t n, int32_t C, co
  *   scalar = d(objective)/d(loss), NULL = 1), #counted read from *n_valid_dev (pg_gather_labels); labels outside [0, C) other than ignore_index are
  *   not counted. partials: pg_gcn_head_scratch(n_dst, K, C) floats. drop may be NULL. Deterministic.          */
 int64_t pg_gcn_head_scratch(int64_t n_dst, int32_t K, int32_t C);
+/* floats between two blocks' rows of that scratch: [C * K] dW | [C] db | [1] loss, padded to a multiple of 4 — the
+ * `part_len` a caller hands pg_adam_step_partials when it lets the optimiser add the rows up (sum_partials = 0)   */
+int32_t pg_gcn_head_row_len(int32_t K, int32_t C);
 /* pg_gcn_head_ex / pg_linear_bwd_w_ex: the same with `sum_partials` = 0 leaving the per-block / per-chunk partial rows
  * un-summed in `partials` ([rows][C*K + C + 1] resp. [rows][N*K + N], rows = scratch size / row length) for
  * pg_adam_step_partials; dW / db(_loss) are then not written.                                            */

@@ -427,12 +427,12 @@ __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ 
 // chunk groups, 8 independent loads in flight per thread (a one-thread-per-output loop over ~70 chunks is
 // a chain of dependent-latency loads: 12 us for 5 MB).
 __global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ part, int32_t chunks, int64_t nk,
-                                                      int32_t N, float* __restrict__ dW, float* __restrict__ db) {
+                                                      int32_t N, float* __restrict__ dW, float* __restrict__ db,
+                                                      int64_t len /* floats between two partial rows, >= nk + N */) {
   __shared__ float red[4][64];
   const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int64_t j = (int64_t)blockIdx.x * 64 + tx;
-  const int64_t len = nk + N;
-  const bool ok = j < (db ? len : nk);
+  const bool ok = j < (db ? nk + N : nk);
   const int per = (chunks + 3) / 4;
   const int cb = g * per, ce = (cb + per < chunks) ? cb + per : chunks;
   float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -568,9 +568,14 @@ int pg_linear2_fwd(const float* X, int32_t x_stride, const float* W, const float
 /* out[j] = sum over chunks of part[c][j] (chunk order), j < nk -> dW[j], nk <= j < nk + N -> db[j - nk] */
 int pg_sum_partials(const float* partials, int32_t chunks, int64_t nk, int32_t N, float* dW, float* db,
                     pg_stream_t stream) {
-  if (!partials || chunks <= 0 || nk <= 0 || N < 0 || !dW) return PG_ERR_INVALID;
+  return pg_sum_partials_strided(partials, chunks, nk, N, nk + N, dW, db, stream);
+}
+
+int pg_sum_partials_strided(const float* partials, int32_t chunks, int64_t nk, int32_t N, int64_t row_len, float* dW,
+                            float* db, pg_stream_t stream) {
+  if (!partials || chunks <= 0 || nk <= 0 || N < 0 || !dW || row_len < nk + N) return PG_ERR_INVALID;
   hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)ceil_div<int64_t>(nk + N, 64)), dim3(256), 0, as_stream(stream),
-                     partials, chunks, nk, N, dW, db);
+                     partials, chunks, nk, N, dW, db, row_len);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
@@ -641,7 +646,7 @@ static int linear_bwd_w(const float* dY, int32_t dy_stride, const float* X, int3
   if (!sum_partials) return PG_OK;   // the consumer (pg_adam_step_partials) adds the chunks up itself
   const int64_t nk = (int64_t)N * K;
   hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)ceil_div<int64_t>(nk + N, 64)), dim3(256), 0, as_stream(stream),
-                     partials, (int32_t)chunks, nk, N, dW, db);
+                     partials, (int32_t)chunks, nk, N, dW, db, nk + N);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }

@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
                                                   int64_t ignore_index, const int32_t* __restrict__ n_valid_dev,
                                                   const float* __restrict__ grad_scale_dev, HeadDrop d, int reduce,
                                                   int64_t n_dst, float* __restrict__ logits,
-                                                  float* __restrict__ dagg, float* __restrict__ part, int dagg_per_edge) {
+                                                  float* __restrict__ dagg, float* __restrict__ part, int dagg_per_edge,
+                                                  int row_len) {
   __shared__ __attribute__((aligned(16))) float s_rows[4][kHeadRows][kHeadMax];   // the waves' aggregated rows
   __shared__ int s_lab[4][kHeadRows];
   __shared__ float s_deg[4][kHeadRows];      // what dAgg is divided by when it leaves per edge (dagg_per_edge)
@@ -53,20 +54,29 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
   // W staged with coalesced loads, zero padded to 64 x 64, row stride 65 (conflict-free row AND column reads);
   // the block's partial sums laid out [k][class] so that the 64 lanes of a wave hit 64 banks
   __shared__ float s_w[kHeadMax * (kHeadMax + 1)];
-  __shared__ float s_big[kHeadMax * kHeadMax + 2 * kHeadMax];
+  __shared__ __attribute__((aligned(16))) float s_big[2 * kHeadMax * kHeadMax + 2 * kHeadMax + 4];
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
   const int64_t wave_g = (int64_t)blockIdx.x * 4 + w;
   const bool is_c = lane < C, is_k = lane < K;
-  for (int t = threadIdx.x; t < kHeadMax * (kHeadMax + 1); t += 256) s_w[t] = 0.f;
-  __syncthreads();
-  for (int t = threadIdx.x; t < C * K; t += 256) s_w[(t / K) * (kHeadMax + 1) + (t % K)] = W[t];
-  __syncthreads();
-  // W row of class `lane` and W column of input `lane`, zero padded to 64
-  // (the column stays in LDS: three 64-register arrays per lane would leave one wave per SIMD)
+  // W row of class `lane` straight from global memory into registers (one round of 16-byte loads; 15 KB that every block
+  // finds in L2), zero padded to 64 x 64; wave 0 parks its copy in LDS for the column reads of dAgg (the column stays in
+  // LDS: three 64-register arrays per lane would leave one wave per SIMD). Round 3: this replaced zero-fill -> barrier ->
+  // strided copy with a div/mod per element -> barrier -> 64 LDS reads per lane.
   float wrow[kHeadMax], accw[kHeadMax];
+  if ((K & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0) {
+#pragma unroll
+    for (int k = 0; k < kHeadMax; k += 4) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (is_c && k < K) v = *reinterpret_cast<const float4*>(W + (int64_t)lane * K + k);
+      wrow[k] = v.x; wrow[k + 1] = v.y; wrow[k + 2] = v.z; wrow[k + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kHeadMax; ++k) wrow[k] = (is_c && k < K) ? W[(int64_t)lane * K + k] : 0.f;
+  }
 #pragma unroll
   for (int k = 0; k < kHeadMax; ++k) {
-    wrow[k] = s_w[lane * (kHeadMax + 1) + k];
+    if (w == 0) s_w[lane * (kHeadMax + 1) + k] = wrow[k];      // read after the barrier that closes phase 1
     accw[k] = 0.f;
   }
   const float bz = (is_c && bias) ? bias[lane] : 0.f;
@@ -174,26 +184,57 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
     accb += dl;
     __syncthreads();   // s_dl is rewritten by the next row
   }
-  // block partial: the four waves add into s_big[k][class] one after the other (fixed order)
-  float* s_b = s_big + kHeadMax * kHeadMax;            // [class] bias sums, then the loss
-  for (int wv = 0; wv < 4; ++wv) {
-    if (w == wv) {
+  // block partial = (wave 0 + wave 2) + (wave 1 + wave 3), a fixed tree (deterministic): two LDS hand-offs instead of four
+  // read-modify-write passes, and wave 0 stores the block's row of the partial layout straight from its registers —
+  // lane = class owns W's row `lane`, K contiguous floats — instead of a transposing copy with a div/mod per element
+  float* regA = s_big;                                   // [k][class]: the 64 lanes of a wave hit 64 banks
+  float* regB = s_big + kHeadMax * kHeadMax;
+  float* s_b = s_big + 2 * kHeadMax * kHeadMax;          // [2][class] bias sums, then [2] loss
+  // no counted row at all: the mean over zero rows is nan, as torch's CrossEntropyLoss returns
+  float lpart = nv > 0 ? lsum * inv : NAN;               // (lane 0's value is the wave's)
+  if (w >= 2) {
+    float* r = w == 2 ? regA : regB;
 #pragma unroll
-      for (int k = 0; k < kHeadMax; ++k) s_big[k * kHeadMax + lane] = (wv ? s_big[k * kHeadMax + lane] : 0.f) + accw[k];
-      s_b[lane] = (wv ? s_b[lane] : 0.f) + accb;
-      // no counted row at all: the mean over zero rows is nan, as torch's CrossEntropyLoss returns
-      if (lane == 0) s_b[kHeadMax] = (wv ? s_b[kHeadMax] : 0.f) + (nv > 0 ? lsum * inv : NAN);
-    }
-    __syncthreads();
+    for (int k = 0; k < kHeadMax; ++k) r[k * kHeadMax + lane] = accw[k];
+    s_b[(w - 2) * kHeadMax + lane] = accb;
+    if (lane == 0) s_b[2 * kHeadMax + (w - 2)] = lpart;
   }
-  const int len = C * K + C + 1;
-  float* mine = part + (int64_t)blockIdx.x * len;
-  for (int t = threadIdx.x; t < len; t += 256) {
-    float val;
-    if (t < C * K) val = s_big[(t % K) * kHeadMax + (t / K)];
-    else if (t < C * K + C) val = s_b[t - C * K];
-    else val = s_b[kHeadMax];
-    mine[t] = val;
+  __syncthreads();
+  if (w < 2) {
+    const float* r = w == 0 ? regA : regB;
+#pragma unroll
+    for (int k = 0; k < kHeadMax; ++k) accw[k] += r[k * kHeadMax + lane];
+    accb += s_b[w * kHeadMax + lane];
+    lpart += s_b[2 * kHeadMax + w];
+  }
+  __syncthreads();
+  if (w == 1) {
+#pragma unroll
+    for (int k = 0; k < kHeadMax; ++k) regA[k * kHeadMax + lane] = accw[k];
+    s_b[lane] = accb;
+    if (lane == 0) s_b[2 * kHeadMax] = lpart;
+  }
+  __syncthreads();
+  if (w == 0) {
+    float* mine = part + (int64_t)blockIdx.x * row_len;      // row_len % 4 == 0 (pg_gcn_head_row_len)
+#pragma unroll
+    for (int k = 0; k < kHeadMax; ++k) accw[k] += regA[k * kHeadMax + lane];
+    accb += s_b[lane];
+    lpart += s_b[2 * kHeadMax];
+    if (is_c) {
+      float* row = mine + (int64_t)lane * K;
+      if ((K & 3) == 0 && (row_len & 3) == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0) {
+#pragma unroll
+        for (int k = 0; k < kHeadMax; k += 4)
+          if (k < K) *reinterpret_cast<float4*>(row + k) = make_float4(accw[k], accw[k + 1], accw[k + 2], accw[k + 3]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < kHeadMax; ++k)
+          if (k < K) row[k] = accw[k];
+      }
+      mine[C * K + lane] = accb;
+    }
+    if (lane == 0) mine[C * K + C] = lpart;
   }
 }
 
@@ -208,9 +249,16 @@ static int head_rows(int64_t n_dst) {
 
 extern "C" {
 
+/* floats per block of the partial layout: [C * K] dW, [C] db, [1] loss, padded to whole 16-byte pieces (the rows leave the
+ * kernel as float4 stores) */
+int32_t pg_gcn_head_row_len(int32_t K, int32_t C) {
+  if (K <= 0 || C <= 0) return 0;
+  return (C * K + C + 1 + 3) & ~3;
+}
+
 int64_t pg_gcn_head_scratch(int64_t n_dst, int32_t K, int32_t C) {
   if (n_dst <= 0 || K <= 0 || C <= 0) return 0;
-  return ceil_div<int64_t>(n_dst, 4 * head_rows(n_dst)) * ((int64_t)C * K + C + 1);
+  return ceil_div<int64_t>(n_dst, 4 * head_rows(n_dst)) * (int64_t)pg_gcn_head_row_len(K, C);
 }
 
 int pg_gcn_head(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
@@ -247,7 +295,7 @@ int pg_gcn_head_ex(const int32_t* indptr, const int32_t* src, const float* h, in
 #define PG_HEAD(R)                                                                                                   \
   hipLaunchKernelGGL(k_gcn_head<R>, dim3((unsigned)blocks), dim3(256), 0, st, indptr, src, h, h_stride, K, W, bias, C, \
                      labels, ignore_index, n_valid_dev, grad_scale_dev, d, reduce, n_dst, logits, dagg, partials,          \
-                     (flags & PG_HEAD_DAGG_PER_EDGE) ? 1 : 0)
+                     (flags & PG_HEAD_DAGG_PER_EDGE) ? 1 : 0, (int)pg_gcn_head_row_len(K, C))
   if (rpw == 1) PG_HEAD(1);
   else if (rpw == 2) PG_HEAD(2);
   else if (rpw == 4) PG_HEAD(4);
@@ -256,7 +304,8 @@ int pg_gcn_head_ex(const int32_t* indptr, const int32_t* src, const float* h, in
   PG_LAUNCH_CHECK();
   if (!sum_partials) return PG_OK;   // pg_adam_step_partials adds the blocks' partials up
   // dW [C*K], then db [C] and the loss (db_loss[C]) contiguous behind it in the partial layout
-  return pg_sum_partials(partials, (int32_t)blocks, (int64_t)C * K, C + 1, dW, db_loss, stream);
+  return pg_sum_partials_strided(partials, (int32_t)blocks, (int64_t)C * K, C + 1, pg_gcn_head_row_len(K, C), dW, db_loss,
+                                 stream);
 }
 
 }  // extern "C"

@@ -97,10 +97,13 @@ struct AdamPartArgs {
 __global__ __launch_bounds__(256) void k_adam_partials(const AdamPartArgs a) {
   __shared__ float red[4][64];
   const int64_t total = a.end[a.n_tensors - 1];
-  const double t = (double)(*a.step + 1);
-  const float bc1 = (float)(1.0 - pow((double)a.beta1, t));
-  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, t));
-  const float step_size = a.lr / bc1;
+  // the bias corrections (two double-precision pow) once per block, while the partial rows are on their way
+  __shared__ float s_bc[2];
+  if (threadIdx.x == 255) {
+    const double t = (double)(*a.step + 1);
+    s_bc[0] = (float)(1.0 - pow((double)a.beta1, t));
+    s_bc[1] = (float)sqrt(1.0 - pow((double)a.beta2, t));
+  }
   const int tx = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + tx;
   const bool ok = i < total;
@@ -130,6 +133,16 @@ __global__ __launch_bounds__(256) void k_adam_partials(const AdamPartArgs a) {
       const int cb = grp * per, ce = (cb + per < nch) ? cb + per : nch;
       const float* col = pt + of + o;
       int c = cb;
+      // 32 loads in flight per round (the head's partials are one row per block of pg_gcn_head: ~94 rows per chunk
+      // group, twelve dependent rounds of 8 — the critical path of this launch); the additions keep k_sum_partials'
+      // order: accumulator u & 7 takes rows c + u in ascending order
+      for (; c + 31 < ce; c += 32) {
+        float x[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) x[u] = col[(int64_t)(c + u) * rl];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc[u & 7] += x[u];
+      }
       for (; c + 7 < ce; c += 8) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc[u] += col[(int64_t)(c + u) * rl];
@@ -154,6 +167,8 @@ __global__ __launch_bounds__(256) void k_adam_partials(const AdamPartArgs a) {
       g = gp[o];
     }
     if (is_adam) {
+      const float bc1 = s_bc[0], bc2_sqrt = s_bc[1];      // (ordered_sum's barriers lie between the write and this read)
+      const float step_size = a.lr / bc1;
       const float p = pp[o];
       if (a.weight_decay != 0.f) g += a.weight_decay * p;
       const float m = a.beta1 * mp[o] + (1.f - a.beta1) * g;

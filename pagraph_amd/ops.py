@@ -583,7 +583,7 @@ class _GCNHead(torch.autograd.Function):
                                        (0 if defer else L.PG_HEAD_SUM_PARTIALS) | L.PG_HEAD_DAGG_PER_EDGE, L.stream_ptr()),
                     "pg_gcn_head")
         if defer:
-            rowlen = C * K + C + 1
+            rowlen = lib.pg_gcn_head_row_len(K, C)      # C * K + C + 1 padded to whole 16-byte pieces
             chunks = part.numel() // rowlen
             _DEFER.add(weight, part, chunks, rowlen, 0)
             _DEFER.add(bias, part, chunks, rowlen, C * K)
