@@ -143,11 +143,18 @@ def main(arch, description, n_hidden, lr):
     # additions of this build
     parser.add_argument("--cache-ratio", type=float, default=None,
                         help="cap the cache at this fraction of the partition (storage.py:85-86 overrides)")
-    parser.add_argument("--miss-mode", default="zerocopy", choices=["staged", "zerocopy", "async"])
+    # The defaults are the path bench.py measures (hipGraph-replayed step, only what the model reads is fetched — read in
+    # place where it can be —, async miss queue). --eager --fetch-all --miss-mode zerocopy is the reference-shaped loop
+    # (pa_gcn.py:82-103 step by step: every layer and field fetched into frames, DDP, torch's Adam).
+    parser.add_argument("--miss-mode", default="async", choices=["staged", "zerocopy", "async"])
     parser.add_argument("--no-overlap", action="store_true")
-    parser.add_argument("--graph", action="store_true", help="replay the training step as a hipGraph")
-    parser.add_argument("--fetch-needed", action="store_true",
-                        help="fetch only the layers/fields the model reads instead of everything (SURVEY 8f-2)")
+    parser.add_argument("--graph", dest="graph", action="store_true", default=True,
+                        help="replay the training step as a hipGraph (default)")
+    parser.add_argument("--eager", dest="graph", action="store_false", help="the reference's eager loop, step by step")
+    parser.add_argument("--fetch-needed", dest="fetch_needed", action="store_true", default=True,
+                        help="fetch only the layers/fields the model reads instead of everything (SURVEY 8f-2; default)")
+    parser.add_argument("--fetch-all", dest="fetch_needed", action="store_false",
+                        help="fetch every layer and field into frames, as storage.py:157-204 does")
     parser.add_argument("--log-miss-rate", action="store_true")
     parser.add_argument("--ckpt", type=str, default=None, help="directory for one checkpoint per epoch (examples/eval.py)")
     args = parser.parse_args()
@@ -155,6 +162,9 @@ def main(arch, description, n_hidden, lr):
         print('--remote-sample: sampling already runs on the GPU; flag ignored')
     if args.gpu == 'cpu':
         raise SystemExit('pagraph_amd has no CPU path: pass --gpu 0[,1,...]')
+    print('pagraph_amd: {} step, {}, miss path {}'.format(
+        'hipGraph-replayed' if args.graph else 'eager', 'fetching what the model reads' if args.fetch_needed
+        else 'fetching every layer and field', args.miss_mode))
     os.environ['HIP_VISIBLE_DEVICES'] = args.gpu
     gpu_num = len(args.gpu.split(','))
     mp.spawn(trainer, args=(gpu_num, args, arch), nprocs=gpu_num, join=True)

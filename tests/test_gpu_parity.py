@@ -558,9 +558,12 @@ def test_cli_pipeline_end_to_end(dev, hiplib, tmp_path):
     r = run("-m", "pagraph_amd.partition.hash", "--dataset", str(ds), "--partition", "1", "--num-hops", "2")
     assert r.returncode == 0, r.stderr[-2000:]
     assert (ds / "1naive" / "subadj_0.npz").exists()
-    for script, extra in (("pa_gcn.py", []), ("pa_gs.py", ["--miss-mode", "staged"]), ("pa_gcn.py", ["--graph", "--fetch-needed", "--miss-mode", "async"]),
+    ref_loop = ["--eager", "--fetch-all", "--miss-mode", "zerocopy"]          # the reference-shaped loop; the defaults are bench.py's path
+    for script, extra in (("pa_gcn.py", []), ("pa_gs.py", []), ("pa_gcn.py", ref_loop), ("pa_gs.py", ["--eager", "--fetch-all", "--miss-mode", "staged"]),
+                          ("pa_gcn.py", ["--graph", "--fetch-needed", "--miss-mode", "async"]),
                           ("pa_gs.py", ["--graph", "--fetch-needed", "--miss-mode", "zerocopy"]),
-                          ("pa_gcn.py", ["--miss-mode", "async", "--preprocess"])):
+                          ("pa_gcn.py", ["--eager", "--fetch-all", "--miss-mode", "async", "--preprocess"]),
+                          ("pa_gcn.py", ["--preprocess"])):
         r = run(os.path.join("examples", "profile", script), "--dataset", str(ds), "--gpu", "0", "--feat-size", "64",
                 "--n-classes", "7", "--n-epochs", "3", "--batch-size", "1000", "--cache-ratio", "0.3", "--log-miss-rate", *extra)
         assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
