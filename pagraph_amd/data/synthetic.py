@@ -48,7 +48,8 @@ def select_unique_undirected(src, dst, V, E):
     if first_idx.numel() < E:
         return None
     if first_idx.numel() > E:
-        thr = torch.kthvalue(first_idx, E).values
+        # (the E-th smallest candidate index; a device sort takes tens of ms where torch.kthvalue took 2.5 s at 10^8 entries)
+        thr = torch.sort(first_idx).values[E - 1]
         keep = first_idx <= thr
         keys = skey[first][keep]
     else:
