@@ -831,14 +831,18 @@ class GraphCacheServer:
         rec = {"us_per_row_cpu_gather": us_per_row_cpu, "us_per_row_pcie": us_per_row_pcie, "cpu_share_before": old,
                "cpu_share": new, "jobs_measured": int(jobs), "host_threads": self.host_threads}
         if new != old and apply:
-            self.cpu_share = new
-            # (takes effect at the next _missq_buffers call; dedup plans are rebuilt because their validity depends on it)
-            self._missq_bufs = {}
-            self._cache_epoch += 1
+            self.apply_cpu_share(new)
         if not quiet:
             print("GraphCacheServer: CPU gather {:.3f} us/row vs PCIe {:.3f} us/row -> cpu_share {} (was {})".format(
                 us_per_row_cpu, us_per_row_pcie, new, old))
         return rec
+
+    def apply_cpu_share(self, share):
+        """set cpu_share between minibatches (takes effect at the next _missq_buffers call; fetch plans are rebuilt because
+        the validity of their dedup depends on it)"""
+        self.cpu_share = float(share)
+        self._missq_bufs = {}
+        self._cache_epoch += 1
 
     def _dedup_for(self, slot, offsets_rel, first_layer, num_layers, same_fields=True):
         """pg_dedup_t over the slot's dup buffers for a launch whose rows are the NodeFlow layers first_layer.. laid out at

@@ -18,6 +18,14 @@ timeout 600 python bench.py --cache-ratio 1.0 --skip-opt-hit --skip-cpu-baseline
 timeout 600 python bench.py --model graphsage --cache-ratio 1.0 --skip-opt-hit --skip-cpu-baseline > "$OUT/bench_graphsage_full_cache.json" 2>/dev/null
 ( timeout 300 python tools/exp_fused_rows.py; PG_FWD_ROWS_GENERIC=1 timeout 300 python tools/exp_fused_rows.py ) 2>&1 | grep -v amdgpu.ids > "$OUT/fused_rows_alone.txt"
 timeout 600 python tools/exp_dup_census.py > "$OUT/dup_census.json" 2>/dev/null
+timeout 300 python tools/exp_sampler_rate.py 2>&1 | grep -v amdgpu.ids > "$OUT/sampler_alone.txt"
+timeout 300 python tools/exp_graph_gap.py 6 2>&1 | grep -v amdgpu.ids > "$OUT/graph_replay_gap.txt"
+# the driver's N = 2 launch line, both ranks on the one GPU of the box over gloo (a path check, not a scaling number)
+if [ "${SKIP_TWO_RANKS:-0}" != "1" ]; then
+HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+        --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 5 --dist-backend gloo --skip-cpu-baseline --skip-opt-hit \
+        > "$OUT/bench_two_ranks_one_gpu_gloo.json" 2> "$OUT/bench_two_ranks_one_gpu_gloo.err"
+fi
 
 # 2. per-kernel time of the same command + the kernel sequence of one replayed step
 ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o b -- \
@@ -28,6 +36,10 @@ python tools/trace_seq.py /tmp/prof_stats/b_kernel_trace.csv > "$OUT/step_sequen
       python "$R/bench.py" --model graphsage --skip-cpu-baseline --skip-opt-hit --skip-reference-equivalent --skip-microbench > /tmp/prof_gs.log 2>&1 )
 cp /tmp/prof_gs/*kernel_stats.csv "$OUT/bench_graphsage_kernel_stats.csv"
 python tools/trace_seq.py /tmp/prof_gs/b_kernel_trace.csv > "$OUT/step_sequence_graphsage.txt"
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_fc -o b -- \
+      python "$R/bench.py" --cache-ratio 1.0 --skip-cpu-baseline --skip-opt-hit --skip-reference-equivalent --skip-microbench > /tmp/prof_fc.log 2>&1 )
+cp /tmp/prof_fc/*kernel_stats.csv "$OUT/bench_full_cache_kernel_stats.csv"
+python tools/trace_seq.py /tmp/prof_fc/b_kernel_trace.csv > "$OUT/step_sequence_full_cache.txt"
 
 # 3. HBM bytes per kernel (FETCH_SIZE x2, WRITE_SIZE, KiB): eager loop (rocprofv3 --pmc serialises all kernels), async
 #    miss queue with the consumer waiting for the worker on the host (a spin-wait kernel parked on the compute stream
