@@ -330,12 +330,13 @@ int pg_sampler_destroy(pg_sampler_t* s);
 int pg_sampler_capacity(const pg_sampler_t* s, int64_t* cap_nodes, int64_t* cap_blk_rows /*[num_hops]*/,
                         int64_t* cap_blk_edges /*[num_hops]*/);
 /* one minibatch: seeds (device int64[n_seeds]) -> NodeFlow. RNG key (seed, epoch, batch).
- * `out` names an output slot (a set of caller-owned buffers). The launch sequence for a slot is fixed, so from
- * the second call into the same slot on the same stream it is replayed as ONE hipGraph launch (the call's
- * scalars travel through a pinned parameter block; PG_SAMPLER_NO_GRAPH=1 keeps the ~30 individual launches).
- * The call blocks the host until the previous sample into the SAME slot has completed on the device (its
- * parameter block is about to be rewritten): with a ring of slots, as pagraph_amd.sampling.NeighborSampler
- * uses, that is one ring revolution ago and bounds how far the launch thread can run ahead of the GPU.   */
+ * `out` names an output slot (a set of caller-owned buffers). Fully asynchronous: the call enqueues five plain launches
+ * (fan-out <= 64; the wide chain and the DGL layout a few more) that take the call's scalars as kernel arguments — nothing
+ * of the call lives in memory a later call rewrites, so the host never waits for the device here (rounds 1-2 replayed a
+ * hipGraph over a pinned parameter block and blocked until the previous sample into the same slot had run). `seeds` must
+ * stay valid until the launches have run. One chain at a time per handle (shared scratch: bitmaps, rank table, look-back
+ * granules): calls on one stream, or on streams the caller orders. Not capturable into a caller's graph (per-launch
+ * look-back tags and the bitmap parity are host state).                                                   */
 int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, uint64_t seed,
                       uint32_t epoch, uint32_t batch, const pg_nodeflow_desc_t* out, pg_stream_t stream);
 /* The source-major block copies of a sampled slot (transpose_mask, blk_tptr / blk_tdst / blk_theavy) on `stream`,
