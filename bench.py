@@ -741,6 +741,7 @@ def run():
         if getattr(trainer, "launch_trace", None) is not None:
             trainer.launch_trace = []
         mq0 = cacher.miss_queue_stats()
+        cacher.miss_queue_longest(reset=True)
         cg0 = cgroup_cpu_stat()
         drop_step0 = int(model._drop_step.item()) if hasattr(model, "_drop_step") else 0
         wev[0].record(cstream)
@@ -783,11 +784,12 @@ def run():
                             for i in range(0, len(cl), win)]       # GB/s of the H2D copies per window
         mq_stats = cacher.miss_queue_stats()
         if mq_stats and mq0:
-            tr_ = {k_: mq_stats[k_] - mq0[k_] for k_ in ("jobs", "waits_by_event", "waits_by_spin_kernel", "rescued_chunks")}
+            tr_ = {k_: mq_stats[k_] - mq0[k_] for k_ in ("jobs", "waits_by_event", "waits_by_spin_kernel", "rescued_chunks", "spared_jobs")}
             # rows the worker really moved over PCIe (after the miss list's index dedup) per step of the region
             tr_["rows_over_pcie_per_step"] = (mq_stats["rows_per_job"] * mq_stats["jobs"] - mq0["rows_per_job"] * mq0["jobs"]) / max(1, K_)
             tr_["us_cpu_gather"] = ((mq_stats["us_cpu_gather"] * mq_stats["jobs"] - mq0["us_cpu_gather"] * mq0["jobs"])
                                     / max(1, tr_["jobs"]))
+            tr_["longest_us"] = cacher.miss_queue_longest()      # where a stall of the miss path sat (one job's worst phase)
             mq_stats["timed_region"] = tr_
         if timed_out:
             raise SystemExit("bench.py: the async miss queue's device-side wait timed out (worker thread dead?) — "

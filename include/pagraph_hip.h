@@ -269,9 +269,17 @@ int pg_missq_device_tail(pg_missq_t* q, int slot, pg_stream_t stream);
  * submission's device tail (which runs on the queue's own stream) still reads the slot's miss list              */
 int pg_missq_order_after_tail(pg_missq_t* q, int slot, pg_stream_t stream);
 int pg_missq_copy_engine(pg_missq_t* q, uint32_t* engine_mask, double GBps[16]);
+/* the LONGEST single occurrence, in microseconds, of the worker's phases since the last call with reset != 0: [0] wait
+ * for the published miss list (the device side: split + publish on the caller's stream), [1] CPU row gather, [2] enqueue
+ * (copy submission + scatter launches), [3] submit -> done. A stall of the miss path shows in exactly one of them.     */
+int pg_missq_stats_max(pg_missq_t* q, double out[4], int reset);
 /* chunks (32 rows) of the CPU row gather that the worker re-executed because the pool thread that had claimed them was
  * overdue (lost its CPU with the chunk in hand): each one is a multi-millisecond stall of the step that did not happen */
 int pg_missq_rescued_chunks(pg_missq_t* q, int64_t* out);
+/* jobs that gathered into a spare staging buffer because the pool thread whose chunk was re-executed had not come back
+ * yet and still held their slot's buffer (it may write into it when it does): each one is a stall of that length — 8-9 ms
+ * on the shared boxes — that did not happen                                                                */
+int pg_missq_spared_jobs(pg_missq_t* q, int64_t* out);
 /* diagnosis (env PG_MISSQ_COPYLOG=1 at creation): the last `cap` host->device copies of the worker's wide field as
  * (bytes, milliseconds on the copy stream), oldest first; *n_out = entries written                        */
 int pg_missq_copy_log(pg_missq_t* q, int64_t* bytes, float* ms, int64_t cap, int64_t* n_out);
@@ -339,6 +347,10 @@ int pg_sampler_capacity(const pg_sampler_t* s, int64_t* cap_nodes, int64_t* cap_
  * look-back tags and the bitmap parity are host state).                                                   */
 int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, uint64_t seed,
                       uint32_t epoch, uint32_t batch, const pg_nodeflow_desc_t* out, pg_stream_t stream);
+/* Health of the chain's in-kernel look-backs: *lookback_timeouts = how many polls for a predecessor block's aggregate gave
+ * up (bounded at a few seconds so that nothing can hang the GPU). Non-zero means at least one NodeFlow was garbage: a
+ * caller checks it where it checks for lost miss rows (GraphedTrainer.synchronize). Synchronises with the device.    */
+int pg_sampler_status(pg_sampler_t* s, int32_t* lookback_timeouts);
 /* The source-major block copies of a sampled slot (transpose_mask, blk_tptr / blk_tdst / blk_theavy) on `stream`,
  * which must already be ordered after the sample (defer_transpose = 1, sizes_dev set). The 8 latency-bound launches
  * then leave the sampler's chain — the stage that bounds the pipeline once the features are cached — for a stream

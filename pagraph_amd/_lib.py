@@ -108,11 +108,14 @@ _SIGS = {
     "pg_missq_copy_engine": (ctypes.c_int, [vp, ctypes.POINTER(c_u32), ctypes.POINTER(ctypes.c_double)]),
     "pg_missq_device_tail": (ctypes.c_int, [vp, ctypes.c_int, vp]),
     "pg_missq_order_after_tail": (ctypes.c_int, [vp, ctypes.c_int, vp]),
+    "pg_missq_spared_jobs": (ctypes.c_int, [vp, ctypes.POINTER(c_i64)]),
+    "pg_missq_stats_max": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
     "pg_missq_rescued_chunks": (ctypes.c_int, [vp, ctypes.POINTER(c_i64)]),
     "pg_missq_copy_log": (ctypes.c_int, [vp, vp, vp, c_i64, ctypes.POINTER(c_i64)]),
     "pg_sampler_create": (ctypes.c_int, [c_i64, vp, vp, c_i32, c_i32, c_i32, ctypes.POINTER(vp)]),
     "pg_sampler_destroy": (ctypes.c_int, [vp]),
     "pg_sampler_capacity": (ctypes.c_int, [vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    "pg_sampler_status": (ctypes.c_int, [vp, ctypes.POINTER(c_i32)]),
     "pg_sampler_sample": (ctypes.c_int, [vp, vp, c_i32, c_u64, c_u32, c_u32, ctypes.POINTER(PgNodeflowDesc), vp]),
     "pg_sampler_transpose": (ctypes.c_int, [vp, ctypes.POINTER(PgNodeflowDesc), vp]),
     "pg_frontier_mark_neighbors": (ctypes.c_int, [vp, vp, vp, c_i64, vp, ctypes.c_int, vp]),

@@ -195,7 +195,9 @@ static inline void copy_row_stream(float* dst, const float* src, size_t bytes) {
 class Pool {
  public:
   static constexpr int64_t kChunk = 32;
-  static constexpr int kRing = 16;            // job descriptors (>= miss-queue slots + in-flight stragglers)
+  static constexpr int kRing = 256;           // job descriptors: one is reused 256 jobs (tens of ms) after its job — a thread
+                                              // that lost its CPU with a chunk in hand (8-9 ms at a time on the shared boxes)
+                                              // has long left by then; with 16 the caller waited for it 2.4 ms later
   static constexpr int64_t kMaxChunks = 1 << 16;
   struct Job {
     std::function<void(int64_t, int64_t)> fn;
@@ -401,6 +403,10 @@ struct pg_missq {
   hipStream_t copy_stream = nullptr;
   uint32_t* timeout_d = nullptr;
   Pool* pool = nullptr;
+  // staging buffers out of rotation: spares, and buffers a straggler of the gather pool may still write into (with the
+  // ticket of that gather). Worker thread only.
+  std::vector<std::pair<float*, uint64_t>> parked[PG_MAX_FIELDS];
+  int64_t n_spared = 0;              // jobs that took a spare because a straggler still held their slot's buffer
   std::thread worker;
   std::mutex m;
   std::condition_variable cv_job, cv_done;
@@ -412,6 +418,8 @@ struct pg_missq {
   std::atomic<int> cpu_share{256};   // of 256: the leading share of every miss list that the CPU path moves
   // PG_MISSQ_DEBUG=1: accumulated worker phase times (us) printed at destroy
   double t_sync = 0, t_flag = 0, t_gather = 0, t_enqueue = 0, t_copy = 0, t_sub2flag = 0, t_sub2pop = 0;
+  // the longest single occurrence of each phase since the last pg_missq_stats_max(reset): where a stall of the miss path sat
+  double mx_flag = 0, mx_gather = 0, mx_enqueue = 0, mx_total = 0;
   double t_total = 0;
   bool copy_log = getenv("PG_MISSQ_COPYLOG") != nullptr;
   // direct SDMA path (see k_wait_hsa_signal)
@@ -623,8 +631,26 @@ static void missq_worker(pg_missq* q) {
         const size_t pf_bytes = std::min(pf_cfg, row_bytes);
         const auto ta = now();
         // a straggler of this slot's PREVIOUS job (a re-executed chunk's original owner) may still be copying into
-        // this staging buffer: it must have left before the buffer is rewritten (a formality: n_slots jobs ago)
-        q->pool->wait_quiesced(s.gather_ticket[f]);
+        // this staging buffer: it must have left before the buffer is rewritten. Normally a formality (n_slots jobs ago);
+        // a thread that lost its CPU stays away for 8-9 ms on the shared boxes — sixty jobs — and the job that waited
+        // for it here WAS the stall (round 3: `longest_us.cpu_gather` 9 ms in 3 of 6 epochs). So the buffer is left to
+        // the straggler and the job takes a spare one; the old buffer comes back once the straggler has gone.
+        if (!q->pool->quiesced(s.gather_ticket[f])) {
+          float* spare = nullptr;
+          for (auto& pk : q->parked[f])
+            if (pk.first && q->pool->quiesced(pk.second)) {
+              spare = pk.first;
+              pk = {s.staging_h[f], s.gather_ticket[f]};
+              break;
+            }
+          if (spare) {
+            s.staging_h[f] = stg = spare;
+            s.gather_ticket[f] = 0;
+            ++q->n_spared;
+          } else {
+            q->pool->wait_quiesced(s.gather_ticket[f]);     // every spare is held by a straggler too
+          }
+        }
         // everything captured BY VALUE: a straggler may run this after the call has returned
         const float* table = fd.table;
         const int64_t tstride = fd.table_stride;
@@ -716,7 +742,10 @@ static void missq_worker(pg_missq* q) {
       s.last_count = (int32_t)m;
       q->t_sync += us(t0, t1); q->t_flag += us(t1, t2); q->t_gather += tg; q->t_enqueue += te;
       q->n_jobs += 1; q->n_rows += m;
-      q->t_total += us(s.t_submit, now());
+      const double tt = us(s.t_submit, now());
+      q->t_total += tt;
+      q->mx_flag = std::max(q->mx_flag, us(t1, t2)); q->mx_gather = std::max(q->mx_gather, tg);
+      q->mx_enqueue = std::max(q->mx_enqueue, te); q->mx_total = std::max(q->mx_total, tt);
       if (rc != PG_OK) q->error = rc;
     }
     q->cv_done.notify_all();
@@ -742,6 +771,10 @@ static void missq_free(pg_missq* q) {
   }
   delete q->pool;        // joins the gather threads: nobody writes to the staging buffers any more
   q->pool = nullptr;
+  for (auto& v : q->parked) {
+    for (auto& pk : v) (void)hipHostFree(pk.first);
+    v.clear();
+  }
   // direct jobs' copies are in no HIP stream: let the engine finish before the buffers go (bounded: 1 s each). Every
   // signal that was created is waited for, also after a mid-run fall-back to hipMemcpyAsync (hsa_ok false by then):
   // copies handed to the engine before the fall-back may still be in flight
@@ -867,6 +900,20 @@ int pg_missq_create(int device, int n_slots, int64_t max_rows, const pg_missq_fi
   if (!q->pool) {
     missq_free(q);
     return PG_ERR_NOMEM;
+  }
+  // two spare staging buffers per field (see the worker: a job whose slot's buffer is still held by a straggler of the
+  // gather pool takes one instead of waiting for it); PG_MISSQ_SPARES=<n> (0: wait, as rounds 1-2 did)
+  {
+    const int spares = getenv("PG_MISSQ_SPARES") ? atoi(getenv("PG_MISSQ_SPARES")) : 2;
+    for (int f = 0; f < n_fields; ++f)
+      for (int i = 0; i < spares; ++i) {
+        float* b = nullptr;
+        if (hipHostMalloc((void**)&b, (size_t)max_rows * q->sstride[f] * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+          (void)hipGetLastError();      // no spare: the job waits for the straggler instead
+          break;
+        }
+        q->parked[f].push_back({b, 0});
+      }
   }
   hsa_copy_init(q);
   q->worker = std::thread(missq_worker, q);
@@ -1166,6 +1213,21 @@ int pg_missq_stats(pg_missq_t* q, double out[8]) {
   out[0] = (double)q->n_jobs; out[1] = (double)q->n_rows;
   out[2] = (double)q->n_wait_event; out[3] = (double)q->n_wait_spin;
   out[4] = q->t_sub2flag / n; out[5] = q->t_gather / n; out[6] = q->t_enqueue / n; out[7] = q->t_total / n;
+  return PG_OK;
+}
+
+int pg_missq_stats_max(pg_missq_t* q, double out[4], int reset) {
+  if (!q || !out) return PG_ERR_INVALID;
+  std::lock_guard<std::mutex> l(q->m);
+  out[0] = q->mx_flag; out[1] = q->mx_gather; out[2] = q->mx_enqueue; out[3] = q->mx_total;
+  if (reset) q->mx_flag = q->mx_gather = q->mx_enqueue = q->mx_total = 0;
+  return PG_OK;
+}
+
+int pg_missq_spared_jobs(pg_missq_t* q, int64_t* out) {
+  if (!q || !out) return PG_ERR_INVALID;
+  std::lock_guard<std::mutex> l(q->m);
+  *out = q->n_spared;
   return PG_OK;
 }
 

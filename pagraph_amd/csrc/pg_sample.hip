@@ -408,14 +408,18 @@ __global__ __launch_bounds__(256) void k_pack(const PackArgs a) {
 constexpr int kMaxLookback = 1024;     // blocks per S / R launch (every block reads all its predecessors' granules)
 
 // sum of the values of granules [0, b) once each carries `tag`; wave 0 of the block calls it, result in every lane
-__device__ __forceinline__ int lookback_sum(const unsigned long long* agg, int b, uint32_t tag, int lane) {
+__device__ __forceinline__ int lookback_sum(const unsigned long long* agg, int b, uint32_t tag, int lane, int32_t* err) {
   int sum = 0;
   for (int j = lane; j < b; j += kWave) {
     unsigned long long g;
     int spins = 0;
     while (true) {
       g = __hip_atomic_load(agg + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((uint32_t)(g >> 32) == tag || ++spins > (1 << 22)) break;   // bounded: a lost predecessor must not hang the GPU
+      if ((uint32_t)(g >> 32) == tag) break;
+      if (++spins > (1 << 22)) {      // bounded (seconds): a lost predecessor must not hang the GPU — and must not go unseen
+        atomicAdd(err, 1);            // pg_sampler_status reports it; the sample it belongs to is garbage
+        break;
+      }
       __builtin_amdgcn_s_sleep(1);
     }
     sum += (int)(uint32_t)g;
@@ -440,6 +444,7 @@ struct SampleGArgs {
   int32_t* ecnt;               // edges of the block
   unsigned long long* agg;
   uint32_t tag;
+  int32_t* err;                // look-back time-outs (device counter)
   // top layer only
   int64_t* top_ids;            // the sampler's copy of the seeds' layer (NULL below the top)
   int32_t* top_cnt;
@@ -509,7 +514,7 @@ __device__ __forceinline__ void sample_body(const SampleGArgs& a, const int blk,
     if (carry < 0) {
       // first iteration: the exclusive prefix of this block (block 0 has none)
       if (tid < kWave) {
-        const int s = blk > 0 ? lookback_sum(a.agg, blk, a.tag, lane) : 0;
+        const int s = blk > 0 ? lookback_sum(a.agg, blk, a.tag, lane, a.err) : 0;
         if (tid == 0) lds[16] = s;
       }
       __syncthreads();
@@ -598,6 +603,7 @@ struct RankArgs {
   int32_t m;                      // the block covers 1024 * m words, 4 per thread and round
   unsigned long long* agg;
   uint32_t tag;
+  int32_t* err;
   int64_t* out_ids;
   int64_t cap;
   uint32_t* word_rank;
@@ -626,7 +632,7 @@ __global__ __launch_bounds__(256) void k_bm_rank(const RankArgs a) {
     __hip_atomic_store(a.agg + blk, ((unsigned long long)a.tag << 32) | (uint32_t)tot, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
   if (tid < kWave) {
-    const int s = blk > 0 ? lookback_sum(a.agg, blk, a.tag, lane) : 0;
+    const int s = blk > 0 ? lookback_sum(a.agg, blk, a.tag, lane, a.err) : 0;
     if (tid == 0) lds[16] = s;
   }
   __syncthreads();
@@ -877,6 +883,7 @@ struct pg_sampler {
   std::vector<SlotState*> tslot_states;   // pg_sampler_transpose's per-(slot, stream) graphs (multi-launch device sort only)
   SampleParams* prm_d = nullptr;     // device copy of the running call's parameters (wide fan-out chain)
   unsigned long long* agg = nullptr; // look-back granules {value, tag} of the running S / R launch
+  int32_t* err = nullptr;            // device: look-back polls that gave up (pg_sampler_status)
   uint32_t tag = 0;                  // last tag handed to a launch (never 0)
   uint64_t rank_launches = 0;        // picks of launch i are marked in bitmap (i & 1); its R zeroes the other one
   int max_lookback = kMaxLookback;   // blocks per S / R launch
@@ -926,6 +933,7 @@ static void sampler_free(pg_sampler* s) {
     delete c;
   }
   (void)hipFree(s->agg);
+  (void)hipFree(s->err);
   delete s;
 }
 
@@ -980,6 +988,8 @@ int pg_sampler_create(int64_t V, const int64_t* indptr, const int32_t* indices, 
   s->rank_blocks = (int)ceil_div<int64_t>(s->n_words, (int64_t)kWordsPerBlock * s->rank_m);
   ok &= hipMalloc(&s->agg, (size_t)kMaxLookback * 8) == hipSuccess;
   if (ok) ok &= hipMemset(s->agg, 0, (size_t)kMaxLookback * 8) == hipSuccess;
+  ok &= hipMalloc(&s->err, 4) == hipSuccess;
+  if (ok) ok &= hipMemset(s->err, 0, 4) == hipSuccess;
   ok &= hipMalloc(&s->prm_d, sizeof(SampleParams)) == hipSuccess;
   ok &= hipMalloc(&s->tcnt, (s->cap[0] + 1) * 4) == hipSuccess;
   ok &= hipMalloc(&s->tdummy, 4) == hipSuccess;
@@ -1184,7 +1194,7 @@ static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t
       a.blk_indptr = o->blk_indptr + o->blk_indptr_off[b];
       a.blk_src = o->blk_src + o->blk_src_off[b];
       a.ecnt = ecnt + b;
-      a.agg = s->agg; a.tag = ++s->tag ? s->tag : ++s->tag;
+      a.agg = s->agg; a.tag = ++s->tag ? s->tag : ++s->tag; a.err = s->err;
       if (b == L - 1) {
         a.dst_ids = prm.seeds; a.n_dev = nullptr; a.n_imm = prm.n_seeds;
         a.top_ids = s->layer_ids[L]; a.top_cnt = lcnt + L;
@@ -1206,7 +1216,7 @@ static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t
     RankArgs r{};
     r.bm = bm; r.other_bm = other; r.n_words = s->n_words;
     r.m = s->rank_m;
-    r.agg = s->agg; r.tag = ++s->tag ? s->tag : ++s->tag;
+    r.agg = s->agg; r.tag = ++s->tag ? s->tag : ++s->tag; r.err = s->err;
     r.out_ids = s->layer_ids[b]; r.cap = s->cap[b]; r.word_rank = s->word_rank; r.count_out = lcnt + b;
     r.nm_out = padded ? o->node_mapping + pad_off[b] : nullptr;
     hipLaunchKernelGGL(k_bm_rank, dim3(s->rank_blocks), dim3(256), 0, st, r);
@@ -1252,6 +1262,12 @@ int pg_sampler_sample(pg_sampler_t* s, const int64_t* seeds, int32_t n_seeds, ui
   const int rc = enqueue_chain(s, o, st, prm);
   if (rc != PG_OK || o->padded) return rc;
   return enqueue_pack(s, o, st);
+}
+
+int pg_sampler_status(pg_sampler_t* s, int32_t* lookback_timeouts) {
+  if (!s || !lookback_timeouts) return PG_ERR_INVALID;
+  PG_HIP(hipMemcpy(lookback_timeouts, s->err, 4, hipMemcpyDeviceToHost));     // synchronises: call it off the hot loop
+  return PG_OK;
 }
 
 static int enqueue_transposes(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t st) {

@@ -167,6 +167,16 @@ class NeighborSampler:
     def __len__(self):
         return self.num_batches
 
+    def check(self):
+        """raise if a look-back poll inside the sampling chain ever gave up (a NodeFlow since then was garbage).
+        Synchronises with the device: the trainers call it where they check for lost miss rows, once per epoch."""
+        v = L.c_i32(0)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.pg_sampler_status(self.handle, ctypes.byref(v)), "pg_sampler_status")
+        if v.value:
+            raise L.PgError(f"NeighborSampler: {v.value} look-back poll(s) inside the sampling chain timed out; at least one "
+                            "NodeFlow was not sampled correctly")
+
     def transpose_blocks(self, nf, stream):
         """build the deferred source-major block copies of `nf` (a NodeFlow of this sampler) on `stream`, which the
         caller has ordered after the sample (stream.wait_event(nf._slot.ready))"""

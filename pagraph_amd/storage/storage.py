@@ -922,12 +922,26 @@ class GraphCacheServer:
         L.check(self.lib.pg_missq_copy_engine(self._missq, ctypes.byref(eng), rate), "pg_missq_copy_engine")
         resc = L.c_i64(0)
         L.check(self.lib.pg_missq_rescued_chunks(self._missq, ctypes.byref(resc)), "pg_missq_rescued_chunks")
+        spared = L.c_i64(0)
+        L.check(self.lib.pg_missq_spared_jobs(self._missq, ctypes.byref(spared)), "pg_missq_spared_jobs")
         return {"jobs": int(v[0]), "rows_per_job": v[1] / max(1.0, v[0]), "waits_by_event": int(v[2]),
                 "rescued_chunks": int(resc.value),       # overdue 32-row chunks of the CPU gather re-executed by the worker
+                "spared_jobs": int(spared.value),        # jobs that took a spare staging buffer instead of waiting for a straggler
                 "waits_by_spin_kernel": int(v[3]), "us_submit_to_published": v[4], "us_cpu_gather": v[5],
                 "us_enqueue": v[6], "us_submit_to_done": v[7],
                 "sdma_engine_mask": int(eng.value),      # 0 = hipMemcpyAsync (the runtime picks the engine)
                 "sdma_engine_h2d_GBps": {b: round(rate[b], 1) for b in range(16) if rate[b] > 0}}
+
+    def miss_queue_longest(self, reset=False):
+        """the longest single occurrence (us) of each of the worker's phases since the last reset — a stall of the miss
+        path sits in exactly one of them: waiting for the device to publish the miss list, the CPU row gather, the copy
+        submission, or the whole submit -> done span"""
+        if self._missq is None:
+            return None
+        v = (ctypes.c_double * 4)()
+        L.check(self.lib.pg_missq_stats_max(self._missq, v, 1 if reset else 0), "pg_missq_stats_max")
+        return {"wait_published": round(v[0], 1), "cpu_gather": round(v[1], 1), "enqueue": round(v[2], 1),
+                "submit_to_done": round(v[3], 1)}
 
     def miss_copy_log(self, cap=1 << 16):
         """(bytes, ms) of the worker's last host->device copies (needs PG_MISSQ_COPYLOG=1 in the environment)"""

@@ -579,6 +579,7 @@ class GraphedTrainer:
         self.cacher.drain_misses()
         self.compute_stream.synchronize()
         self.cacher.check_misses()       # a device-side wait that gave up means a step trained on rows that never landed
+        self.sampler.check()             # ... a look-back poll of the sampling chain that gave up, on a garbage NodeFlow
 
     def run_steps(self, it, steps=None):
         # the compute stream is made current for the whole loop (a graph replays on the current stream;

@@ -261,6 +261,7 @@ def test_sampler_multi_round_lookback_paths(dev, hiplib, oracle, monkeypatch, V,
                 got_ip = nf.blk_indptr[i].cpu().numpy()
                 assert np.array_equal(got_ip[:len(ip)], ip) and (got_ip[len(ip):] == ip[-1]).all()
                 assert np.array_equal(nf.blk_src[i].cpu().numpy()[:len(sr)], sr)
+        smp.check()                                       # no look-back poll gave up (pg_sampler_status)
 
 
 @pytest.mark.timeout(600)
