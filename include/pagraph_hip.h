@@ -567,6 +567,13 @@ int pg_gcn_head(const int32_t* indptr, const int32_t* src, const float* h, int32
 int pg_adam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                  float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int64_t* step_dev, uint32_t* ticket_dev, pg_stream_t stream);
+/* Mirror a step counter to the host: from now on every pg_adam_step* launch given `step_dev` also writes the new step
+ * count to *mirror_host (pinned host memory mapped into the device; NULL = stop), from its last block, after the device
+ * counter. A launch thread that recycles per-step buffers can then POLL "step n has run" in its own memory instead of
+ * recording an event on the compute stream (an event costs the stream that records it ~5 us, ~13 when another stream
+ * waits for it). The kernels are the last launches of a training step, so "the optimiser of step n has started its last
+ * block" implies every earlier kernel of that step has finished. Up to 16 registered counters per process.          */
+int pg_adam_step_mirror(int64_t* step_dev, int64_t* mirror_host);
 /* The same step with the ordered partial sums of pg_linear_bwd_w_ex / pg_gcn_head_ex (sum_partials = 0) folded in:
  * tensor i's gradient element o = grads[i][o] when partials[i] == NULL, else the sum over part_chunks[i] rows of
  * partials[i][c * part_len[i] + part_off[i] + o], added in exactly pg_sum_partials' order (bit-identical result) and

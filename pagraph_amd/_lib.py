@@ -143,6 +143,7 @@ _SIGS = {
     "pg_gcn_head_row_len": (c_i32, [c_i32, c_i32]),
     "pg_gcn_head": (ctypes.c_int, [vp, vp, vp, c_i32, c_i32, vp, vp, c_i32, vp, c_i64, vp, vp, vp, ctypes.c_int,
                                    c_i64, vp, vp, vp, vp, vp, vp]),
+    "pg_adam_step_mirror": (ctypes.c_int, [vp, vp]),
     "pg_adam_step": (ctypes.c_int, [c_i32, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                     ctypes.c_float, ctypes.c_float, vp, vp, vp]),
     "pg_adam_step_partials": (ctypes.c_int, [c_i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float,

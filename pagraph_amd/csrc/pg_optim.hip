@@ -5,6 +5,8 @@
 // block: 4 blocks for these models, 15 us); here one launch spreads the elements over ~100 blocks and keeps
 // ONE step counter on the device, bumped by the last block to finish (so that a replayed hipGraph
 // advances it without the host).
+#include <mutex>
+
 #include "pg_common.h"
 
 namespace pg {
@@ -19,6 +21,7 @@ struct AdamArgs {
   float lr, beta1, beta2, eps, weight_decay;
   int64_t* step;                      // device: completed steps
   uint32_t* ticket;                   // device, zero between launches
+  int64_t* mirror;                    // optional, pinned host memory: the new step count, written by the last block
 };
 
 __global__ __launch_bounds__(256) void k_adam(const AdamArgs a) {
@@ -57,8 +60,10 @@ __global__ __launch_bounds__(256) void k_adam(const AdamArgs a) {
   if (threadIdx.x == 0) {
     const uint32_t done = atomicAdd(a.ticket, 1u) + 1;
     if (done == gridDim.x) {
-      *a.step += 1;
+      const int64_t ns = *a.step + 1;
+      *a.step = ns;
       *a.ticket = 0;
+      if (a.mirror) __hip_atomic_store(a.mirror, ns, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -92,6 +97,7 @@ struct AdamPartArgs {
   int64_t* step;
   uint32_t* ticket;
   int64_t* bump;                        // optional: one more device counter advanced with the step (the model's dropout step)
+  int64_t* mirror;                      // optional, pinned host memory: the new step count, written by the last block
 };
 
 __global__ __launch_bounds__(256) void k_adam_partials(const AdamPartArgs a) {
@@ -183,9 +189,11 @@ __global__ __launch_bounds__(256) void k_adam_partials(const AdamPartArgs a) {
   if (threadIdx.x == 0) {
     const uint32_t done = atomicAdd(a.ticket, 1u) + 1;
     if (done == gridDim.x) {
-      *a.step += 1;
+      const int64_t ns = *a.step + 1;
+      *a.step = ns;
       *a.ticket = 0;
       if (a.bump) *a.bump += 1;
+      if (a.mirror) __hip_atomic_store(a.mirror, ns, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -193,6 +201,40 @@ __global__ __launch_bounds__(256) void k_adam_partials(const AdamPartArgs a) {
 }  // namespace pg
 
 using namespace pg;
+
+// step counter -> host mirror (pg_adam_step_mirror): consulted at launch time, so the entry points keep their signatures
+namespace {
+struct MirrorReg {
+  std::mutex m;
+  int64_t* key[16] = {nullptr};
+  int64_t* val[16] = {nullptr};
+} g_mirror;
+int64_t* mirror_of(int64_t* step_dev) {
+  std::lock_guard<std::mutex> l(g_mirror.m);
+  for (int i = 0; i < 16; ++i)
+    if (g_mirror.key[i] == step_dev) return g_mirror.val[i];
+  return nullptr;
+}
+}  // namespace
+
+extern "C" int pg_adam_step_mirror(int64_t* step_dev, int64_t* mirror_host) {
+  if (!step_dev) return PG_ERR_INVALID;
+  std::lock_guard<std::mutex> l(g_mirror.m);
+  int free_i = -1;
+  for (int i = 0; i < 16; ++i) {
+    if (g_mirror.key[i] == step_dev) {
+      g_mirror.val[i] = mirror_host;
+      if (!mirror_host) g_mirror.key[i] = nullptr;
+      return PG_OK;
+    }
+    if (!g_mirror.key[i] && free_i < 0) free_i = i;
+  }
+  if (!mirror_host) return PG_OK;
+  if (free_i < 0) return PG_ERR_NOMEM;
+  g_mirror.key[free_i] = step_dev;
+  g_mirror.val[free_i] = mirror_host;
+  return PG_OK;
+}
 
 extern "C" int pg_adam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                             float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2,
@@ -211,7 +253,7 @@ extern "C" int pg_adam_step(int32_t n_tensors, float* const* params, const float
   }
   a.n_tensors = n_tensors;
   a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
-  a.step = step_dev; a.ticket = ticket_dev;
+  a.step = step_dev; a.ticket = ticket_dev; a.mirror = mirror_of(step_dev);
   int64_t g = ceil_div<int64_t>(tot, 256);
   hipLaunchKernelGGL(k_adam, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, as_stream(stream), a);
   PG_LAUNCH_CHECK();
@@ -261,7 +303,7 @@ extern "C" int pg_adam_step_partials2(int32_t n_tensors, float* const* params, f
   }
   a.n_tensors = n_tensors;
   a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
-  a.step = step_dev; a.ticket = ticket_dev; a.bump = bump_dev;
+  a.step = step_dev; a.ticket = ticket_dev; a.bump = bump_dev; a.mirror = mirror_of(step_dev);
   hipLaunchKernelGGL(k_adam_partials, dim3((unsigned)ceil_div<int64_t>(tot, 64)), dim3(256), 0, as_stream(stream), a);
   PG_LAUNCH_CHECK();
   return PG_OK;

@@ -18,6 +18,34 @@ class Adam(torch.optim.Optimizer):
         self._lib = L.load()
         self._dev_state = {}      # per group: (step int64[1], ticket int32[1]) on the group's device
 
+    def enable_step_mirror(self, device):
+        """Mirror the (single) parameter group's device step counter into pinned host memory: every later step's launch
+        writes the new count there from its last block (pg_adam_step_mirror). Returns a ctypes.c_int64 living IN that
+        memory — `.value` is "steps whose optimiser launch has run", readable by a launch thread without touching the HIP
+        runtime — or None (several groups: no single counter). The optimiser's launch is the last of a training step, so
+        a trainer can recycle a step's buffers once the count has reached that step (GraphedTrainer does, instead of
+        recording an event on its compute stream)."""
+        if getattr(self, "_mirror", None) is None:
+            if len(self.param_groups) != 1:
+                return None
+            step_dev, _ = self._group_state(0, device)
+            m = torch.zeros(1, dtype=torch.int64).pin_memory()
+            m[0] = int(step_dev.item())                    # (synchronises once)
+            L.check(self._lib.pg_adam_step_mirror(L.ptr(step_dev), ctypes.c_void_p(m.data_ptr())), "pg_adam_step_mirror")
+            self._mirror = m
+            self._mirror_cell = ctypes.c_int64.from_address(m.data_ptr())
+        return self._mirror_cell
+
+    def __del__(self):
+        try:
+            if getattr(self, "_mirror", None) is not None:
+                st = self._dev_state.get(0)
+                if st is not None:
+                    self._lib.pg_adam_step_mirror(L.ptr(st[0]), None)
+                self._mirror = None
+        except Exception:
+            pass
+
     def _group_state(self, gi, device):
         st = self._dev_state.get(gi)
         if st is None:

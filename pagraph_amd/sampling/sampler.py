@@ -137,6 +137,8 @@ class NeighborSampler:
         # True: a ring slot's "free" event is polled by the thread that enqueues the next sample into it instead of being
         # waited for by the sampler's stream (GraphedTrainer sets it; needs a ring deep enough for the run-ahead)
         self.host_gated = False
+        # callable(token) -> bool for slots released with a token instead of an event (see release)
+        self.free_reached = None
         # transpose: blocks that also come out source-major (NodeFlow.blk_tptr / blk_tdst) so that the backward
         # aggregation is a gather. 'auto' = every block whose input can carry a gradient (all but block 0,
         # whose input is the raw feature frame); or an iterable of block indices; None = none.
@@ -187,14 +189,22 @@ class NeighborSampler:
 
     def _release_slot(self, slot):
         slot.free.record(self.consumer_stream or torch.cuda.current_stream(self.device))
+        slot.free_token = None
         slot.free_recorded = True
         slot.held = False
 
-    def release(self, nf):
+    def release(self, nf, token=None):
         """manual_release mode: the ring slot behind `nf` may be re-sampled once the work enqueued so far
-        on the consumer stream has finished"""
+        on the consumer stream has finished. `token` (host-gated consumers with `free_reached` set): no event is recorded;
+        the slot is free once free_reached(token) is true."""
         slot = getattr(nf, "_slot", None)
-        if slot is not None:
+        if slot is None:
+            return
+        if token is not None and self.host_gated and self.free_reached is not None:
+            slot.free_token = token
+            slot.free_recorded = True
+            slot.held = False
+        else:
             self._release_slot(slot)
 
     def _enqueue(self, b, epoch):
@@ -208,7 +218,16 @@ class NeighborSampler:
         slot.held = True
         lo = b * self.batch_size
         n = min(self.batch_size, self.seeds.numel() - lo)
-        if slot.free_recorded and self.host_gated:
+        if slot.free_recorded and self.host_gated and getattr(slot, "free_token", None) is not None:
+            # (the consumer handed back a token instead of an event: "done" = its step counter has reached the token —
+            # a word of pinned memory its last kernel writes, GraphedTrainer / optim.Adam.enable_step_mirror)
+            polls = 0
+            while not self.free_reached(slot.free_token):
+                polls += 1
+                if polls > 50_000_000:
+                    raise L.PgError("NeighborSampler: the consumer's step counter never reached the token of a released "
+                                    "ring slot (did the step that owned it run its optimiser?)")
+        elif slot.free_recorded and self.host_gated:
             # the consumer of the batch that used this slot is done — checked HERE, on the launch thread, instead of with a
             # wait on the sampler's stream: an event that another stream waits for costs the stream that records it ~13 us
             # (tools/exp_graph_gap.py: 4.7 us for a record nobody waits for in-stream), and that stream is the compute

@@ -243,6 +243,18 @@ class GraphedTrainer:
         # sampler's stream (sampler.host_gated): the compute stream records an event no stream waits for. With the default
         # ring of 8 slots the launch thread may be 8 - (lookahead + 2) = 4 steps ahead of the GPU before it has to wait.
         sampler.host_gated = not _os.environ.get("PG_STREAM_GATED")
+        # ... and when the optimiser can mirror its step counter into pinned memory (pagraph_amd.optim.Adam: written by the
+        # last block of the step's last launch) there is no event at all: a slot is free once the counter has reached the
+        # step that read it. tools/exp_graph_gap.py: an event record nobody waits for in-stream still costs the compute
+        # stream 4.7 us per step. PG_NO_STEP_MIRROR=1 keeps the event.
+        self._step_cell = None
+        self._steps_issued = 0
+        if sampler.host_gated and hasattr(optimizer, "enable_step_mirror") and not _os.environ.get("PG_NO_STEP_MIRROR"):
+            self._step_cell = optimizer.enable_step_mirror(device)
+            if self._step_cell is not None:
+                self._steps_issued = int(self._step_cell.value)
+                cell = self._step_cell
+                sampler.free_reached = lambda token: cell.value >= token
         cacher.missq_slots = len(sampler.slots)
         # ring slot i of the sampler carries the batch whose miss job sits in queue slot i: before the sampler waits for
         # "slot free" (recorded after that batch's consumer) the job's copy must be in its queue — see prepare()
@@ -570,6 +582,7 @@ class GraphedTrainer:
         # this step had finished (measured: the sampler started only when the current graph ended). Call
         # synchronize() (or compute_stream.synchronize()) before reading it.
         self.steps_done += 1
+        self._steps_issued += 1          # one optimiser launch per compute(): the token of this step's buffers
         self.last_loss = loss
         return loss
 
@@ -603,6 +616,11 @@ class GraphedTrainer:
 
     def _run_steps(self, it, steps=None):
         done = 0
+        if self._step_cell is not None and not self._prepared:
+            # nothing of this trainer is in flight: line the token count up with the optimiser's real step count (somebody
+            # may have stepped it outside this loop since the last call)
+            self.compute_stream.synchronize()
+            self._steps_issued = int(self._step_cell.value)
 
         def prepare_one():
             nf = next(it, None)
@@ -628,7 +646,7 @@ class GraphedTrainer:
             cur = self._prepared.pop(0)
             loss = self.compute(cur)
             t_2 = time.perf_counter() if trace is not None else 0.0
-            self.sampler.release(cur.nf_cur)
+            self.sampler.release(cur.nf_cur, token=self._steps_issued if self._step_cell is not None else None)
             if trace is not None:
                 trace.append(((t_1 - t_0) * 1e3, (t_2 - t_1) * 1e3, (time.perf_counter() - t_2) * 1e3))
             done += 1
