@@ -24,6 +24,12 @@ struct HeadDrop {
   float scale;
 };
 
+// value of lane R of this lane's quad (DPP quad_perm broadcast)
+template <int R>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, R * 0x55, 0xF, 0xF, true);
+}
+
 __device__ __forceinline__ float hw_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
@@ -119,12 +125,45 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
     const uint32_t u = (j4 & 1) ? (wd >> 16) : (wd & 0xffffu);
     return u >= d.thr ? x * d.scale : 0.f;
   };
+  // The mask of the rows' first two sources, one Philox call per FOUR source rows (round 3). Lane = column, so the four lanes
+  // of a 16-byte piece all need the same call (counter = (source row, piece, tag, step)) and use 16 bits of it each: done per
+  // lane, as `dropped` does, the wave runs 2 * kHeadRows identical-per-quad calls — ~640 cycles each, 4 us of every SIMD's
+  // time in this kernel. Instead lane j of a quad draws for source j of a batch of four and the two words a piece needs
+  // travel inside the quad (DPP quad_perm broadcasts, full rate). Same counters, same bits.
+  bool keep0[kHeadRows], keep1[kHeadRows];
+#pragma unroll
+  for (int it = 0; it < kHeadRows; ++it) keep0[it] = keep1[it] = true;
+  if (d.thr) {
+    constexpr int NS = 2 * kHeadRows;
+    auto source = [&](int i) { return i < NS ? ((i & 1) ? s1[i >> 1] : s0[i >> 1]) : -1; };
+    auto decide = [&](uint32_t b0, uint32_t b1) {
+      const uint32_t wd = (j4 >> 1) ? b1 : b0;
+      const uint32_t u = (j4 & 1) ? (wd >> 16) : (wd & 0xffffu);
+      return u >= d.thr;
+    };
+#pragma unroll
+    for (int b = 0; b < NS; b += 4) {
+      const int32_t c0 = source(b), c1 = source(b + 1), c2 = source(b + 2), c3 = source(b + 3);
+      const int32_t mine = j4 == 0 ? c0 : (j4 == 1 ? c1 : (j4 == 2 ? c2 : c3));
+      uint32_t o[4];
+      Philox::gen((uint32_t)mine, q, d.tag, step, d.k0, d.k1, o);
+      const uint32_t w0 = half ? o[2] : o[0], w1 = half ? o[3] : o[1];
+      const bool k0 = decide(quad_bcast<0>(w0), quad_bcast<0>(w1));
+      const bool k1 = decide(quad_bcast<1>(w0), quad_bcast<1>(w1));
+      const bool k2 = decide(quad_bcast<2>(w0), quad_bcast<2>(w1));
+      const bool k3 = decide(quad_bcast<3>(w0), quad_bcast<3>(w1));
+      if (b < NS) keep0[b >> 1] = k0;
+      if (b + 1 < NS) keep1[b >> 1] = k1;
+      if (b + 2 < NS) keep0[(b + 2) >> 1] = k2;
+      if (b + 3 < NS) keep1[(b + 2) >> 1] = k3;
+    }
+  }
 #pragma unroll
   for (int it = 0; it < kHeadRows; ++it) {
     float a = 0.f;
     if (is_k) {
-      if (s0[it] >= 0) a += dropped(s0[it], x0[it]);
-      if (s1[it] >= 0) a += dropped(s1[it], x1[it]);
+      if (s0[it] >= 0) a += d.thr ? (keep0[it] ? x0[it] * d.scale : 0.f) : x0[it];
+      if (s1[it] >= 0) a += d.thr ? (keep1[it] ? x1[it] * d.scale : 0.f) : x1[it];
       for (int32_t e = beg[it] + 2; e < end[it]; ++e) {     // fan-out > 2: the rest of the row, one by one
         const int32_t sr = src[e];
         a += dropped(sr, h[(int64_t)sr * h_stride + lane]);
