@@ -7,23 +7,20 @@
 // are the build-defined spec of DESIGN.md ("Sampler spec"), restated
 // independently in oracle/pgc_oracle.c.
 //
-// Per block b (layer b+1 = destinations, layer b = sources), stream-ordered:
-//   k_sample      wave per destination vertex: deg <= k takes the whole
-//                 adjacency list (coalesced), else Floyd's k-subset with
-//                 Philox4x32-10 draws keyed (seed; v, epoch, batch, layer, j);
-//                 picks go to an ELL buffer and are marked in a V-bit bitmap
-//                 (atomicOr) — the per-layer dedup.
-//   k_scan_cnt    exclusive scan of per-destination pick counts -> block indptr
-//   k_bm_count / k_bm_scan / k_bm_emit
-//                 popcount prefix over the bitmap words: emits the layer's
-//                 vertex ids ASCENDING (the spec's canonical order) and the
-//                 per-word rank table; LDS holds the per-wave partials.
-//   k_relabel     edge source id -> position in the layer = word_rank[w] +
-//                 popcount(bits below) — no hash table, no sort.
-//   k_clear       zero the bitmap words the layer touched.
-// k_pack finally concatenates the layers (layer 0 first) into node_mapping and
-// writes the sizes straight into pinned host memory.
-// All sizes stay on the device; launches are sized by worst-case capacities.
+// Fan-out <= 64 (round 3): five launches per minibatch — k_sx (sample + relabel), k_bm_rank (bitmap -> ascending ids and
+// word ranks), scans as decoupled look-backs inside them; see the block comment above k_sx. Wider fan-outs keep the
+// round-1 chain, per block b (layer b+1 = destinations, layer b = sources), stream-ordered:
+//   k_sample_wide wave per destination vertex: deg <= k takes the whole adjacency list (coalesced), else Floyd's
+//                 k-subset with Philox4x32-10 draws keyed (seed; v, epoch, batch, layer, j), a vertex's tentative
+//                 picks in an LDS strip; picks go to an ELL buffer and are marked in a V-bit bitmap (atomicOr) — the
+//                 per-layer dedup.
+//   k_scan2       exclusive scan of per-destination pick counts -> block indptr (+ the per-block popcounts' scan)
+//   k_bm_count / k_bm_emit
+//                 popcount prefix over the bitmap words: emits the layer's vertex ids ASCENDING (the spec's canonical
+//                 order) and the per-word rank table; LDS holds the per-wave partials.
+//   k_relabel     edge source id -> position in the layer = word_rank[w] + popcount(bits below) — no hash table, no sort.
+// k_pack finally concatenates the layers (layer 0 first) into node_mapping and writes the sizes straight into pinned
+// host memory. All sizes stay on the device; launches are sized by worst-case capacities.
 #include <new>
 #include <vector>
 
@@ -90,52 +87,6 @@ struct SampleArgs {
   int32_t k;
   uint32_t layer;
 };
-
-__global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
-  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
-  const int n = *a.n_dst;
-  const int k = a.k;
-  for (int64_t p = wave0; p < n; p += nwaves) {
-    const int64_t v = a.dst_ids[p];
-    const int64_t beg = a.indptr[v];
-    const int64_t deg = a.indptr[v + 1] - beg;
-    int32_t* out = a.nbr + p * k;
-    if (deg <= k) {
-      // take the whole in-neighbour list, adjacency order
-      if (lane < deg) {
-        const int32_t u = a.indices[beg + lane];
-        out[lane] = u;
-        atomicOr(&a.bitmap[u >> 6], 1ull << (u & 63));
-      }
-      if (lane == 0) a.cnt[p] = (int32_t)deg;
-    } else {
-      // Floyd's algorithm for a uniform k-subset of {0..deg-1}: for j = 0..k-1,
-      // m = deg-k+j, t ~ U{0..m}; pick t unless already picked, then pick m.
-      uint64_t t = 0;
-      if (lane < k) {
-        uint32_t r[4];
-        Philox::gen((uint32_t)v, a.prm->epoch, a.prm->batch, (a.layer << 24) | (uint32_t)(lane >> 1),
-                    a.prm->seed_lo, a.prm->seed_hi, r);
-        const uint64_t r64 = (lane & 1) ? ((uint64_t)r[3] << 32 | r[2]) : ((uint64_t)r[1] << 32 | r[0]);
-        t = bounded(r64, (uint64_t)(deg - k + lane) + 1);
-      }
-      uint64_t sel = t;
-      for (int j = 1; j < k; ++j) {
-        const uint64_t tj = __shfl(t, j);
-        const bool dup = __ballot(lane < j && sel == tj) != 0ull;
-        if (lane == j && dup) sel = (uint64_t)(deg - k + j);
-      }
-      if (lane < k) {
-        const int32_t u = a.indices[beg + (int64_t)sel];
-        out[lane] = u;
-        atomicOr(&a.bitmap[u >> 6], 1ull << (u & 63));
-      }
-      if (lane == 0) a.cnt[p] = k;
-    }
-  }
-}
 
 // Fan-out above one wave (the reference accepts any --num-neighbors, pa_gcn.py:146-147): the same spec — Floyd's
 // k-subset, draw j = word pair (j & 1) of Philox call j >> 1 — with a vertex's k tentative picks in LDS (one k-entry
@@ -397,7 +348,7 @@ __global__ __launch_bounds__(256) void k_pack(const PackArgs a) {
 // one 8-byte {value, tag} granule (one sc1 store; tag = a per-launch number, so nothing is ever reset) and sums the granules
 // of ALL its predecessors (at most 1024: one wave, a few loads per lane) — no serial chain, one hand-off deep. Blocks only
 // ever wait for blocks dispatched before them.
-//   S: a group of G = 2^ceil(log2 k) lanes per destination (k = 2: 32 destinations per wave; k_sample gives a vertex a
+//   S: a group of G = 2^ceil(log2 k) lanes per destination (k = 2: 32 destinations per wave; rounds 1-2 gave a vertex a
 //      whole wave and idles 62 lanes) -> pick counts -> block scan + look-back -> the block's CSR offsets are known
 //      while the picks are still in flight, so picks land in CSR position straight away (as vertex ids; no ELL buffer,
 //      no cnt array, no k_scan_cnt).
@@ -944,7 +895,7 @@ int pg_sampler_create(int64_t V, const int64_t* indptr, const int32_t* indices, 
   if (!out || V <= 0 || V > INT32_MAX || !indptr || !indices || max_seeds <= 0 || fanout <= 0 ||
       num_hops <= 0 || num_hops + 1 > PG_MAX_LAYERS)
     return PG_ERR_INVALID;
-  // fan-out <= 64: one lane per pick (k_sample); above: the picks of a vertex live in an LDS strip (k_sample_wide),
+  // fan-out <= 64: lane groups (k_sx); above: the picks of a vertex live in an LDS strip (k_sample_wide),
   // four strips of 4 * fanout bytes per block
   if (fanout > kMaxFanout) return PG_ERR_UNSUPPORTED;
   pg_sampler* s = new (std::nothrow) pg_sampler;
