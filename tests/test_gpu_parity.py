@@ -195,6 +195,8 @@ def _rand_csc(rng, V, E, powerlaw=True):
                                            (3000, 20000, 333, 1, 1), (4000, 50000, 512, 64, 1), (100000, 900000, 6000, 2, 2),
                                            # 64 lanes per destination and more than 1024 * 4 of them: two destinations per group
                                            (9000, 700000, 5000, 40, 1),
+                                           # a two-word bitmap, five seeds per batch, three hops: every launch is one block
+                                           (70, 300, 5, 2, 3),
                                            # fan-out above one wave (k_sample_wide; the reference takes any --num-neighbors)
                                            (3000, 400000, 128, 65, 1), (3000, 500000, 64, 100, 2), (2500, 900000, 50, 300, 1)])
 def test_sampler_vs_oracle_bit_exact(dev, hiplib, oracle, V, E, B, k, hops):
