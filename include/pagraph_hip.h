@@ -250,7 +250,8 @@ int pg_missq_timed_out(pg_missq_t* q, int* out);
 /* blocks the HOST until every submitted job has left the worker (its copy is enqueued); makes no HIP call, so
  * it is safe to call right before a device-wide synchronise (a worker that still has to enqueue a copy while
  * the trainer thread sits in hipDeviceSynchronize with a spin-wait kernel parked behind it was measured to
- * cost 15 ms).                                                                                         */
+ * cost 15 ms). Round 3: it also waits (ROCr signals, no HIP call) until the copies handed straight to an SDMA
+ * engine have landed — they sit in no HIP stream, so the synchronise that follows would not wait for them.   */
 int pg_missq_drain(pg_missq_t* q);
 /* counters since creation: out[0] jobs, out[1] rows moved, out[2] consumer waits ordered by event (copy already
  * enqueued), out[3] consumer waits by the spin kernel, out[4..7] mean per-job microseconds: submit->miss list

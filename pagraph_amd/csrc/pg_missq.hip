@@ -1190,6 +1190,14 @@ int pg_missq_drain(pg_missq_t* q) {
       if (s.done != s.submitted) return false;
     return true;
   });
+  // ... and the copies the worker handed straight to an SDMA engine have landed: they sit in no HIP stream, so a device-wide
+  // synchronise does not wait for them — a timed region that ends with drain + synchronise would otherwise leave the copies
+  // of its last prepared batches outside (bounded: 1 s per signal; nothing is outstanding on a queue that never went direct)
+  if (q->error == PG_OK)
+    for (auto& s : q->slots)
+      for (int f = 0; f < PG_MAX_FIELDS; ++f)
+        if (s.sig[f].handle)
+          (void)hsa_signal_wait_scacquire(s.sig[f], HSA_SIGNAL_CONDITION_LT, 1, 1000000000ull, HSA_WAIT_STATE_ACTIVE);
   return q->error;
 }
 
