@@ -543,6 +543,13 @@ def run():
                               host_threads=args.host_threads or default_host_threads(world))
     cacher.init_field(embed_names)
     cacher.log = True
+    if world > torch.cuda.device_count():
+        # several ranks on ONE GPU (the gloo path check of the tests / profiles): their device-side waits — a one-wave kernel
+        # spinning for up to 3 s — share the device's hardware queues and scheduler time slices with the other rank's streams.
+        # Twice this round such a run saw a wait give up although worker and copy were healthy (never on a GPU of its own, in
+        # several hundred runs). Ranks that share a device order their consumers after the miss rows on the host instead.
+        cacher.host_wait = True
+        log(f"[bench] rank {rank}: {world} ranks on {torch.cuda.device_count()} GPU(s) -> host-side waits for miss rows")
     adapt_share = args.cpu_share is None and not args.no_adapt_cpu_share
     cacher.cpu_share = 1.0 if args.cpu_share is None else args.cpu_share
     D = cacher.total_dim
