@@ -1196,8 +1196,12 @@ int pg_missq_drain(pg_missq_t* q) {
   if (q->error == PG_OK)
     for (auto& s : q->slots)
       for (int f = 0; f < PG_MAX_FIELDS; ++f)
-        if (s.sig[f].handle)
-          (void)hsa_signal_wait_scacquire(s.sig[f], HSA_SIGNAL_CONDITION_LT, 1, 1000000000ull, HSA_WAIT_STATE_ACTIVE);
+        if (s.sig[f].handle &&
+            hsa_signal_wait_scacquire(s.sig[f], HSA_SIGNAL_CONDITION_LT, 1, 1000000000ull, HSA_WAIT_STATE_ACTIVE) > 0) {
+          static bool said = false;
+          if (!said) fprintf(stderr, "[missq] pg_missq_drain: a direct copy's completion signal did not arrive within 1 s\n");
+          said = true;
+        }
   return q->error;
 }
 

@@ -180,6 +180,14 @@ def test_miss_gather_stragglers_are_rescued(dev, hiplib, monkeypatch):
     c.shutdown_miss_queue()
 
 
+def _free_port():
+    """a TCP port nobody listens on right now (a fixed rendezvous port can sit in TIME_WAIT after the previous run)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _rand_csc(rng, V, E, powerlaw=True):
     if powerlaw:
         w = 1.0 / np.arange(1, V + 1) ** 0.9; w /= w.sum()
@@ -551,8 +559,10 @@ def test_cli_pipeline_end_to_end(dev, hiplib, tmp_path):
     import subprocess, sys
     ds = tmp_path / "tiny"
     ds.mkdir()
-    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_PORT="29653")
-    run = lambda *a: subprocess.run([sys.executable, *a], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    # (a fresh rendezvous port per script: seven process groups in a row on one fixed port can wait on TIME_WAIT)
+    run = lambda *a: subprocess.run([sys.executable, *a], cwd=ROOT, env=dict(env, MASTER_PORT=str(_free_port())),
+                                    capture_output=True, text=True, timeout=600)
     r = run("-m", "pagraph_amd.data.preprocess", "--dataset", str(ds), "--gen-rmat", "20000", "120000", "--gen-feature",
             "--feat-size", "64", "--gen-label", "--class-num", "7", "--gen-set")
     assert r.returncode == 0, r.stderr[-2000:]
@@ -2011,7 +2021,7 @@ def test_eval_and_count_vnum_scripts(dev, hiplib, oracle, tmp_path):
     from pagraph_amd import data
     ds = tmp_path / "tiny"
     ds.mkdir()
-    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_PORT="29671")
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_PORT=str(_free_port()))
     run = lambda *a: subprocess.run([sys.executable, *a], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     r = run("-m", "pagraph_amd.data.preprocess", "--dataset", str(ds), "--gen-rmat", "6000", "30000", "--gen-feature",
             "--feat-size", "32", "--gen-label", "--class-num", "5", "--gen-set")
