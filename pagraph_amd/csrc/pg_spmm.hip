@@ -590,7 +590,7 @@ __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, in
                                            const int32_t* __restrict__ indptr, const float* __restrict__ go,
                                            int32_t go_stride, int32_t dim, int reduce, float* __restrict__ gh,
                                            int32_t gh_stride, int lpr_log2, DropArgs d, int first, int stride, DzOut z,
-                                           MaxIn mi);
+                                           MaxIn mi, int parts);
 
 constexpr int kBwdBatch = 4;
 
@@ -603,12 +603,14 @@ __global__ __launch_bounds__(256) void k_spmm_bwd_gather(const int32_t* __restri
                                                          int64_t n_src, int32_t dim, int reduce,
                                                          float* __restrict__ gh, int32_t gh_stride, int lpr_log2,
                                                          int skip_heavy, DropArgs d, const int32_t* __restrict__ heavy,
-                                                         int32_t heavy_cap, int32_t n_row_blocks, DzOut z, MaxIn mi) {
+                                                         int32_t heavy_cap, int32_t n_row_blocks, DzOut z, MaxIn mi,
+                                                         int hub_parts) {
   using S = SV<VEC>;
   using V = typename S::type;
   if ((int)blockIdx.x >= n_row_blocks) {
     heavy_rows<VEC, DROP, 256, MAXR>(heavy, heavy_cap, tptr, tdst, indptr, go, go_stride, dim, reduce, gh, gh_stride,
-                                     lpr_log2, d, (int)blockIdx.x - n_row_blocks, (int)gridDim.x - n_row_blocks, z, mi);
+                                     lpr_log2, d, (int)blockIdx.x - n_row_blocks, (int)gridDim.x - n_row_blocks, z, mi,
+                                     hub_parts);
     return;
   }
   const int lpr = 1 << lpr_log2;
@@ -624,6 +626,12 @@ __global__ __launch_bounds__(256) void k_spmm_bwd_gather(const int32_t* __restri
   if (skip_heavy && end - beg > PG_HEAVY_ROW) return;   // a hub: k_spmm_bwd_heavy gives it a whole block
   V* grow = reinterpret_cast<V*>(gh + sr * gh_stride);
   V last = S::zero();       // this lane's piece of the row (the dZ epilogue needs it; pieces <= lpr there)
+  // the dZ epilogue's own operand (the layer's saved output) depends on nothing but the row: its load is issued here, ahead
+  // of the tptr -> tdst -> gradient-rows chain, instead of as one more dependent round trip behind it
+  float4 yv_early = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (VEC == 4) {
+    if (z.dz && gl < z.N / 4) yv_early = reinterpret_cast<const float4*>(z.y + sr * z.y_stride)[gl];
+  }
   for (int c = gl; c < pieces; c += lpr) {
     V acc = S::zero();
     V xd = S::zero();          // MAXR: this source's message as the forward saw it
@@ -678,10 +686,7 @@ __global__ __launch_bounds__(256) void k_spmm_bwd_gather(const int32_t* __restri
       hi.y = __shfl_down(last.y, hp, lpr);
       hi.z = __shfl_down(last.z, hp, lpr);
       hi.w = __shfl_down(last.w, hp, lpr);
-      if (gl < hp) {
-        const float4 yv = reinterpret_cast<const float4*>(z.y + sr * z.y_stride)[gl];
-        reinterpret_cast<float4*>(z.dz + sr * z.N)[gl] = dz_piece(last, hi, yv);
-      }
+      if (gl < hp) reinterpret_cast<float4*>(z.dz + sr * z.N)[gl] = dz_piece(last, hi, yv_early);
     }
   }
 }
@@ -697,7 +702,7 @@ __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, in
                                            const int32_t* __restrict__ indptr, const float* __restrict__ go,
                                            int32_t go_stride, int32_t dim, int reduce, float* __restrict__ gh,
                                            int32_t gh_stride, int lpr_log2, DropArgs d, int first, int stride, DzOut z,
-                                           MaxIn mi) {
+                                           MaxIn mi, int parts) {
   constexpr int kHeavyThreads = T;
 
   using S = SV<VEC>;
@@ -707,19 +712,33 @@ __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, in
   __shared__ float s_w[kStage];
   __shared__ V red[kHeavyThreads];
   __shared__ float4 zrow[64];               // the finished row, for the dZ epilogue
+  // Round 3: a hub's COLUMNS are split over `parts` blocks (extra block id = hub slot * parts + part). One block per hub
+  // had 256 / lpr edge lanes with 16 loads in flight each: a hub of ~870 edges (the vertex every isolated seed aliases to)
+  // took four dependent rounds of loads, and the two hub blocks set the duration of the whole launch (13-16 us; the
+  // ~9.5 K regular rows need about half). With the row's pieces dealt to `parts` blocks each block has parts times the
+  // edge lanes — one round for up to 1024 edges — and nothing has to be combined across blocks. Part p takes pieces
+  // [p q, (p + 1) q) and their partners hp + the same, q = hp / parts, hp = pieces / 2, so that the skip-concat's dZ
+  // (which pairs piece c with c + hp) stays inside a block. The mapping does not depend on whether dZ is asked for.
+  const int part = first % parts;
+  first /= parts;
+  stride /= parts;
   int n_heavy = heavy[0];
-  int32_t sr_next = heavy[1 + first];        // (first < heavy_cap) fetched with the count, not after it
+  int32_t sr_next = first < heavy_cap ? heavy[1 + first] : 0;        // fetched with the count, not after it
   if (n_heavy > heavy_cap) n_heavy = heavy_cap;
-  const int lpr = 1 << lpr_log2;                  // lanes across the row's pieces
-  const int el = threadIdx.x >> lpr_log2, n_el = kHeavyThreads >> lpr_log2, gl = threadIdx.x & (lpr - 1);
+  int lp_log2 = lpr_log2;                         // log2 of the lanes across THIS block's pieces
+  for (int p = parts; p > 1; p >>= 1) --lp_log2;
+  const int lpr = 1 << lp_log2;
+  const int el = threadIdx.x >> lp_log2, n_el = kHeavyThreads >> lp_log2, gl = threadIdx.x & (lpr - 1);
   const int pieces = dim / VEC;
+  const int hp = pieces / 2, qn = parts > 1 ? hp / parts : 0;
   const uint32_t step = (DROP && d.step) ? (uint32_t)*d.step : 0u;
   for (int hi = first; hi < n_heavy; hi += stride) {
     const int sr = sr_next;
     if (hi + stride < n_heavy) sr_next = heavy[1 + hi + stride];
     const int32_t beg = tptr[sr], end = tptr[sr + 1];
-    for (int c0 = 0; c0 < pieces; c0 += lpr) {
-      const int c = c0 + gl;
+    for (int c0 = 0; c0 < (parts > 1 ? 1 : pieces); c0 += lpr) {
+      // (parts > 1: one pass, this lane's piece comes from the part's two runs of qn pieces)
+      const int c = parts > 1 ? (gl < qn ? part * qn + gl : hp + part * qn + (gl - qn)) : c0 + gl;
       V acc = S::zero();
       V xd = S::zero();          // MAXR: this source's message as the forward saw it
       if constexpr (MAXR) {
@@ -768,21 +787,21 @@ __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, in
       __syncthreads();
       if (el == 0 && c < pieces) {
         V tot = S::zero();
-        for (int k = 0; k < n_el; ++k) S::add(tot, red[(k << lpr_log2) + gl]);
+        for (int k = 0; k < n_el; ++k) S::add(tot, red[(k << lp_log2) + gl]);
         if constexpr (DROP) tot = drop_piece<VEC>(tot, (uint32_t)sr, c, d, step);
         reinterpret_cast<V*>(gh + (int64_t)sr * gh_stride)[c] = tot;
         if constexpr (VEC == 4) {
-          if (z.dz) zrow[gl] = tot;
+          if (z.dz) zrow[c] = tot;
         }
       }
       if constexpr (VEC == 4) {
-        if (z.dz) {        // pieces <= lpr (one c0 pass): piece c pairs with piece c + N/4
+        if (z.dz) {        // one c0 pass: piece c pairs with piece c + N/4, both in this block
           __syncthreads();
-          const int hp = z.N / 4;
-          if (el == 0 && gl < hp) {
-            const float4 lo = zrow[gl], hi = zrow[gl + hp];
-            const float4 yv = reinterpret_cast<const float4*>(z.y + (int64_t)sr * z.y_stride)[gl];
-            reinterpret_cast<float4*>(z.dz + (int64_t)sr * z.N)[gl] = dz_piece(lo, hi, yv);
+          const int zh = z.N / 4;
+          if (el == 0 && c < zh) {
+            const float4 lo = zrow[c], hi2 = zrow[c + zh];
+            const float4 yv = reinterpret_cast<const float4*>(z.y + (int64_t)sr * z.y_stride)[c];
+            reinterpret_cast<float4*>(z.dz + (int64_t)sr * z.N)[c] = dz_piece(lo, hi2, yv);
           }
         }
       }
@@ -1026,12 +1045,20 @@ static int bwd_gather_impl(const int32_t* tptr, const int32_t* tdst, const int32
   const int64_t row_blocks = ceil_div<int64_t>(n_src, rows_per_block);
   const bool hubs = heavy && heavy_cap > 0;
   // hub rows: up to 16 extra blocks of the same launch (hub i goes to extra block i % 16)
-  const int hub_blocks = hubs ? (heavy_cap < 16 ? heavy_cap : 16) : 0;
+  // ... each hub's columns dealt to `hub_parts` blocks when the row is one pass of an even number of 16-byte pieces
+  // (dim 64: 16 pieces, 4 parts of 2 + 2) — see heavy_rows; PG_HUB_PARTS=1 keeps one block per hub
+  static const int parts_cfg = getenv("PG_HUB_PARTS") ? atoi(getenv("PG_HUB_PARTS")) : 4;
+  int hub_parts = 1;
+  if (hubs && v4 && pieces <= (1 << l2) && pieces == (1 << l2))
+    for (int p = parts_cfg; p > 1; p >>= 1)
+      if ((p & (p - 1)) == 0 && pieces % (2 * p) == 0 && (pieces / p) >= 2) { hub_parts = p; break; }
+  const int hub_blocks = hubs ? (heavy_cap < 16 ? heavy_cap : 16) * hub_parts : 0;
   const dim3 grid((unsigned)(row_blocks + hub_blocks));
   hipStream_t st = as_stream(stream);
 #define PG_BWD_GATHER(VEC, DROP, MAXR)                                                                                 \
   hipLaunchKernelGGL((k_spmm_bwd_gather<VEC, DROP, MAXR>), grid, dim3(256), 0, st, tptr, tdst, indptr, grad_out, go_stride, \
-                     n_src, dim, reduce, grad_h, gh_stride, l2, hubs ? 1 : 0, d, heavy, heavy_cap, (int32_t)row_blocks, z, mi)
+                     n_src, dim, reduce, grad_h, gh_stride, l2, hubs ? 1 : 0, d, heavy, heavy_cap, (int32_t)row_blocks, z, mi, \
+                     hub_parts)
   if (mx) {
     if (v4 && dr) PG_BWD_GATHER(4, true, true);
     else if (v4) PG_BWD_GATHER(4, false, true);
