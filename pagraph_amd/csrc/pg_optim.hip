@@ -131,6 +131,14 @@ __global__ __launch_bounds__(256) void k_adam_partials(const AdamPartArgs a) {
     }
   }
   const int64_t o = i - base;
+  // the parameter and its two moments depend on nothing but the element: their loads are issued here, ahead of the partial
+  // rows' rounds and the two barriers of the ordered sum, instead of as one more round trip behind them
+  float p_early = 0.f, m_early = 0.f, v_early = 0.f;
+  if (grp == 0 && ok && is_adam) {
+    p_early = pp[o];
+    m_early = mp[o];
+    v_early = vp[o];
+  }
   // one ordered sum per set of partial rows (4 chunk groups x 8 rotating accumulators, pairwise combine)
   auto ordered_sum = [&](const float* pt, int nch, int rl, int of) -> float {
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -175,10 +183,10 @@ __global__ __launch_bounds__(256) void k_adam_partials(const AdamPartArgs a) {
     if (is_adam) {
       const float bc1 = s_bc[0], bc2_sqrt = s_bc[1];      // (ordered_sum's barriers lie between the write and this read)
       const float step_size = a.lr / bc1;
-      const float p = pp[o];
+      const float p = p_early;
       if (a.weight_decay != 0.f) g += a.weight_decay * p;
-      const float m = a.beta1 * mp[o] + (1.f - a.beta1) * g;
-      const float v = a.beta2 * vp[o] + (1.f - a.beta2) * g * g;
+      const float m = a.beta1 * m_early + (1.f - a.beta1) * g;
+      const float v = a.beta2 * v_early + (1.f - a.beta2) * g * g;
       mp[o] = m;
       vp[o] = v;
       const float denom = sqrtf(v) / bc2_sqrt + a.eps;
