@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
   __shared__ __attribute__((aligned(16))) float s_rows[4][kHeadRows][kHeadMax];   // the waves' aggregated rows
   __shared__ int s_lab[4][kHeadRows];
   __shared__ float s_deg[4][kHeadRows];      // what dAgg is divided by when it leaves per edge (dagg_per_edge)
-  __shared__ __attribute__((aligned(16))) float s_dl[4][kHeadMax];
+  __shared__ __attribute__((aligned(16))) float s_dl[4][kHeadRows][kHeadMax];   // dZ of the wave's rows (lane = class)
   // W staged with coalesced loads, zero padded to 64 x 64, row stride 65 (conflict-free row AND column reads);
   // the block's partial sums laid out [k][class] so that the 64 lanes of a wave hit 64 banks
   __shared__ float s_w[kHeadMax * (kHeadMax + 1)];
@@ -179,8 +179,12 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
   }
   __syncthreads();
   float accb = 0.f, lsum = 0.f;
-#pragma unroll 1      // not unrolled: keeps the kernel at ~100 VGPRs (4 waves per SIMD) instead of 256 (one)
-  for (int it = 0; it < kHeadRows; ++it) {              // same trip count for every wave: barriers inside
+  // Two passes over the wave's rows with ONE barrier between them (round 3; rounds 1-2 ran both halves per row with two
+  // workgroup barriers each — eight per block): pass A (lane = class) computes z, the log-sum-exp, the loss and dZ and
+  // parks dZ in LDS; pass B (lane = input column) reads it back for dAgg and accumulates the dW row. Neither pass rewrites
+  // anything the other reads, so the rows inside a pass are independent and the compiler may overlap them.
+#pragma unroll 2
+  for (int it = 0; it < kHeadRows; ++it) {
     const int64_t v = wave_g * kHeadRows + it;
     const bool live = v < n_dst;
     const float* arow = s_rows[w][it];
@@ -201,13 +205,25 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
     float dl = 0.f;
     if (counted && is_c) dl = (expf(z - lse) - (lane == lb ? 1.f : 0.f)) * (inv * grad_scale);
     if (counted && lane == 0) lsum += lse - zl;
-    s_dl[w][lane] = dl;
-    __syncthreads();
-    // dAgg[input = lane] and the dW row of class `lane`
+    s_dl[w][it][lane] = dl;
+    // the dW row of class `lane` (dl is this lane's own value: no LDS round trip)
+#pragma unroll
+    for (int k = 0; k < kHeadMax; k += 4) {
+      const float4 g = *reinterpret_cast<const float4*>(arow + k);
+      accw[k] += dl * g.x; accw[k + 1] += dl * g.y; accw[k + 2] += dl * g.z; accw[k + 3] += dl * g.w;
+    }
+    accb += dl;
+  }
+  __syncthreads();
+#pragma unroll 2
+  for (int it = 0; it < kHeadRows; ++it) {
+    const int64_t v = wave_g * kHeadRows + it;
+    const bool live = v < n_dst;
+    // dAgg[input = lane]
     float gk = 0.f;
 #pragma unroll
     for (int c = 0; c < kHeadMax; c += 4) {
-      const float4 g = *reinterpret_cast<const float4*>(&s_dl[w][c]);
+      const float4 g = *reinterpret_cast<const float4*>(&s_dl[w][it][c]);
       const float* wc = s_w + c * (kHeadMax + 1) + lane;          // W[c .. c+3][lane]: consecutive banks
       gk += wc[0] * g.x + wc[kHeadMax + 1] * g.y + wc[2 * (kHeadMax + 1)] * g.z + wc[3 * (kHeadMax + 1)] * g.w;
     }
@@ -215,14 +231,8 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
     // sum and never loads the destinations' degrees (same division, same operands: bit-identical gradients)
     const float dg = s_deg[w][it];
     if (live && is_k) dagg[v * K + lane] = dg > 0.f ? gk / dg : gk;
-#pragma unroll
-    for (int k = 0; k < kHeadMax; k += 4) {
-      const float4 g = *reinterpret_cast<const float4*>(arow + k);
-      accw[k] += dl * g.x; accw[k + 1] += dl * g.y; accw[k + 2] += dl * g.z; accw[k + 3] += dl * g.w;
-    }
-    accb += dl;
-    __syncthreads();   // s_dl is rewritten by the next row
   }
+  __syncthreads();        // (the partial sums below reuse nothing of the above, but s_big aliases nothing: kept for clarity of phases)
   // block partial = (wave 0 + wave 2) + (wave 1 + wave 3), a fixed tree (deterministic): two LDS hand-offs instead of four
   // read-modify-write passes, and wave 0 stores the block's row of the partial layout straight from its registers —
   // lane = class owns W's row `lane`, K contiguous floats — instead of a transposing copy with a div/mod per element
