@@ -31,7 +31,8 @@ class Adam(torch.optim.Optimizer):
             step_dev, _ = self._group_state(0, device)
             m = torch.zeros(1, dtype=torch.int64).pin_memory()
             m[0] = int(step_dev.item())                    # (synchronises once)
-            L.check(self._lib.pg_adam_step_mirror(L.ptr(step_dev), ctypes.c_void_p(m.data_ptr())), "pg_adam_step_mirror")
+            if self._lib.pg_adam_step_mirror(L.ptr(step_dev), ctypes.c_void_p(m.data_ptr())) != 0:
+                return None        # the library's table of mirrored counters is full (16 per process): the caller keeps its events
             self._mirror = m
             self._mirror_cell = ctypes.c_int64.from_address(m.data_ptr())
         return self._mirror_cell
