@@ -214,6 +214,15 @@ class GraphedTrainer:
         # PG_GRAPH_ALLREDUCE=0 forces the eager collective.
         import os as _os
         self.allreduce_in_graph = False if _os.environ.get("PG_GRAPH_ALLREDUCE") == "0" else None
+        # world > 1: EVERY eager collective of this trainer runs on a communication stream of its own, ordered with the compute
+        # stream by wait_stream, never on the compute stream itself. ProcessGroupNCCL's watchdog thread polls the end event of
+        # each eager collective until it has completed; on ROCm an event query fails with hipErrorCapturedEvent as soon as the
+        # stream the event was last recorded on is CAPTURING — also for an event recorded long before the capture began — and
+        # the watchdog turns that into std::terminate. The trainer captures a step graph on the compute stream microseconds
+        # after the previous step's eager all-reduce: with the collective on that stream every rank of the first real N > 1 run
+        # would have died at its first capture (tools/exp_rccl_capture.py: `nosleep` aborts, `other` / `flow` run). Collectives
+        # captured INSIDE a graph are fine (the process group does not hand them to the watchdog).
+        self.comm_stream = torch.cuda.Stream(device=device) if self.world > 1 else None
         if self.world > 1:
             import torch.distributed as dist
             params = [p for p in model.parameters() if p.requires_grad]
@@ -405,8 +414,11 @@ class GraphedTrainer:
             self.flat.zero_()
             loss.backward(self._gseed)          # loss / world: the SUM all-reduce then yields DDP's mean gradient
             if self.allreduce_in_graph:         # the collective and the optimizer belong to the same captured step
-                import torch.distributed as dist
-                dist.all_reduce(self.flat, group=self.pg)
+                if torch.cuda.is_current_stream_capturing():
+                    import torch.distributed as dist
+                    dist.all_reduce(self.flat, group=self.pg)
+                else:                           # the same body run eagerly: never an eager collective on this stream
+                    self._eager_all_reduce(self.flat)
                 self.optimizer.step()
         else:
             loss.backward(self._gseed)
@@ -472,8 +484,7 @@ class GraphedTrainer:
         g = torch.cuda.CUDAGraph()
         probe_stream = torch.cuda.Stream(device=self.device)     # a failed capture must not wedge the compute stream
         try:
-            with torch.cuda.stream(self.compute_stream):
-                dist.all_reduce(t.clone(), group=self.pg)          # communicator set-up happens outside the capture
+            self._eager_all_reduce(t.clone())                     # communicator set-up happens outside the capture
             self.compute_stream.synchronize()
             with torch.cuda.stream(probe_stream):
                 g.capture_begin(capture_error_mode="thread_local")
@@ -488,9 +499,9 @@ class GraphedTrainer:
                         ok = 0
         except Exception:
             ok = 0
-        flag.fill_(ok)
         with torch.cuda.stream(self.compute_stream):
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+            flag.fill_(ok)
+        self._eager_all_reduce(flag, op=dist.ReduceOp.MIN)
         self.compute_stream.synchronize()
         if int(flag.item()) == 0:
             return False
@@ -506,16 +517,33 @@ class GraphedTrainer:
                     good = 0
         except Exception:
             good = 0
-        flag.fill_(good)
         with torch.cuda.stream(self.compute_stream):
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+            flag.fill_(good)
+        self._eager_all_reduce(flag, op=dist.ReduceOp.MIN)
         self.compute_stream.synchronize()
         return int(flag.item()) == 1
 
+    def _eager_all_reduce(self, tensor, op=None):
+        """an all-reduce of `tensor` ordered after and before the compute stream's work, issued on the communication stream
+        (see __init__: an eager collective must never sit on a stream that is captured later)"""
+        import torch.distributed as dist
+        import os as _os
+        if _os.environ.get("PG_COLLECTIVES_ON_COMPUTE_STREAM"):      # rounds 1-2 (reproduces the abort under RCCL)
+            with torch.cuda.stream(self.compute_stream):
+                dist.all_reduce(tensor, group=self.pg) if op is None else dist.all_reduce(tensor, op=op, group=self.pg)
+            return
+        cs = self.comm_stream
+        cs.wait_stream(self.compute_stream)
+        with torch.cuda.stream(cs):
+            if op is None:
+                dist.all_reduce(tensor, group=self.pg)
+            else:
+                dist.all_reduce(tensor, op=op, group=self.pg)
+        self.compute_stream.wait_stream(cs)
+
     def _sync_and_step(self, capture_ok):
         """world > 1: all-reduce the flat gradient (eager), then the optimizer step (graph B)"""
-        import torch.distributed as dist
-        dist.all_reduce(self.flat, group=self.pg)
+        self._eager_all_reduce(self.flat)
         if self.graph_b is not None:
             self.graph_b.replay()
         elif not capture_ok:

@@ -701,6 +701,70 @@ def _two_rank_graph_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _rccl_one_rank_worker(rank, port, out_dir):
+    """GraphedTrainer's world > 1 code over a REAL RCCL process group — of one rank, all a one-GPU box can host: the trainer
+    is told world_size = 2 (loss / 2, flat gradient buffer, all-reduce per step), the group sums over its single member."""
+    import torch.distributed as dist
+    import torch.nn.functional as Fn
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from pagraph_amd.model import GCNSampling
+    from pagraph_amd.optim import Adam
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    from pagraph_amd.trainer import GraphedTrainer, cycle_batches
+    rng = np.random.default_rng(5)
+    V, Fdim, C, B = 4000, 32, 4, 250
+    adj = _rand_csc(rng, V, 24000)
+    g = DeviceGraph(adj)
+    feats = rng.standard_normal((V, Fdim)).astype(np.float32)
+    labels = torch.from_numpy(rng.integers(0, C, V)).to(dev)
+    train = np.arange(0, V, 2, dtype=np.int64)
+    res = {}
+    for mode in ("eager", "ingraph"):
+        store = HostFeatureStore({"features": torch.from_numpy(feats)})
+        c = GraphCacheServer(store, V, torch.arange(V), 0, miss_mode="async")
+        c.init_field(["features"])
+        c.auto_cache(g, ["features"], cache_ratio=0.5)
+        torch.manual_seed(1)
+        model = GCNSampling(Fdim, 8, C, 1, Fn.relu, 0.0).to(dev)
+        need = model.required_inputs(3)
+        opt = Adam(model.parameters(), lr=1e-2)
+        smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=True, num_hops=2, seed_nodes=train, prefetch=True, seed=3,
+                              static=True, defer_transpose=True)
+        tr = GraphedTrainer(model, torch.nn.CrossEntropyLoss(), opt, c, smp, labels, dev, need=need, world_size=2)
+        # eager: graph A -> all-reduce on the communication stream -> graph B; ingraph: the collective captured in the step
+        tr.allreduce_in_graph = (mode == "ingraph")
+        out = []
+        tr.on_step = lambda step, loss: out.append(loss.detach().clone())
+        tr.run_steps(cycle_batches(smp, 30), 30)      # 3 eager steps, 8 captures (each microseconds behind an eager collective), replays
+        tr.synchronize()
+        torch.cuda.synchronize()
+        res[mode] = (torch.stack(out).cpu(), [p.detach().cpu().clone() for p in model.parameters()], bool(tr.allreduce_in_graph))
+        c.shutdown_miss_queue()
+    torch.save(res, os.path.join(out_dir, "r0.pt"))
+    dist.destroy_process_group()
+
+
+def test_graphed_trainer_over_an_rccl_group_survives_its_captures(dev, hiplib, tmp_path):
+    """ProcessGroupNCCL's watchdog polls the end event of every eager collective; on ROCm that query throws once the stream
+    the event was recorded on is capturing, and the watchdog takes the process down (tools/exp_rccl_capture.py). The trainer
+    therefore keeps its eager collectives on a communication stream of its own. Both world > 1 step shapes — eager
+    all-reduce between two graphs, and the all-reduce captured inside the step — run over a one-rank RCCL group, survive
+    their captures, and give the same trajectory."""
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_one_rank_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(tmp_path / "r0.pt")
+    assert r["eager"][2] is False and r["ingraph"][2] is True
+    assert torch.isfinite(r["eager"][0]).all() and len(r["eager"][0]) == 30
+    assert float(r["eager"][0][-5:].mean()) < float(r["eager"][0][:5].mean())        # it trains
+    assert torch.allclose(r["eager"][0], r["ingraph"][0], rtol=1e-5, atol=1e-6)
+    for a, b in zip(r["eager"][1], r["ingraph"][1]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
 def test_two_rank_graphed_allreduce_matches_ddp(dev, hiplib, tmp_path):
     import socket
     import torch.multiprocessing as mp
