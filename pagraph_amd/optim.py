@@ -10,6 +10,12 @@ import torch
 from . import _lib as L
 
 
+# Pinned words the optimiser kernels write their step count to (enable_step_mirror). Never released: a replayed graph that
+# outlives its optimiser object for a few microseconds (a trainer dropped without a device sync) must not write into a block
+# the pinned-memory allocator has handed to somebody else. Eight bytes per optimiser that asked for a mirror.
+_MIRROR_KEEPALIVE = []
+
+
 class Adam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
@@ -34,6 +40,7 @@ class Adam(torch.optim.Optimizer):
             if self._lib.pg_adam_step_mirror(L.ptr(step_dev), ctypes.c_void_p(m.data_ptr())) != 0:
                 return None        # the library's table of mirrored counters is full (16 per process): the caller keeps its events
             self._mirror = m
+            _MIRROR_KEEPALIVE.append(m)
             self._mirror_cell = ctypes.c_int64.from_address(m.data_ptr())
         return self._mirror_cell
 
