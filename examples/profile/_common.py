@@ -95,28 +95,35 @@ def trainer(rank, world_size, args, arch, backend='nccl'):
 
     epoch_dur = []
     tic = time.time()
-    for epoch in range(args.n_epochs):
-        state['epoch'] = epoch
-        model.train()
-        torch.cuda.synchronize(dev)
-        epoch_start_time = time.time()
-        loop.run_steps(cycle_batches(sampler, steps), steps)
-        cacher.drain_misses()         # the miss queue's worker has enqueued its outstanding copies ...
-        torch.cuda.synchronize(dev)   # ... (the reference does not sync here; without it the time is meaningless)
-        cacher.check_misses()         # raises if any step consumed rows that never landed
-        if rank == 0:
-            epoch_dur.append(time.time() - epoch_start_time)
-            print('Epoch average time: {:.4f}'.format(np.mean(np.array(epoch_dur[2:]))))
-        if cacher.log:
-            miss_rate = cacher.get_miss_rate()
-            print('Epoch average miss rate: {:.4f}'.format(miss_rate))
-        if args.ckpt and rank == 0:
-            # what examples/eval.py loads: <ckpt>/<arch>_<epoch> (eval.py:30-32); parameters in module order
-            os.makedirs(args.ckpt, exist_ok=True)
-            bare = getattr(model, 'module', model)
-            torch.save({k_: v_.detach().cpu() for k_, v_ in bare.named_parameters()},
-                       os.path.join(args.ckpt, ('gcn-nssc' if arch == 'gcn' else 'gs-nssc') + '_' + str(epoch)))
-    toc = time.time()
+    # pa_gcn.py:81,112 profiles the WHOLE run on rank 0, unconditionally, and prints the table; here it is opt-in (--profile):
+    # the profiler's per-launch bookkeeping costs the launch thread more than a replayed step takes
+    loop.profile_ranges = bool(args.profile)      # 'gpu-load' / 'gpu-compute' ranges around prepare / compute (pa_gcn.py:87,92)
+    with torch.autograd.profiler.profile(enabled=(rank == 0 and args.profile), use_cuda=True) as prof:
+        for epoch in range(args.n_epochs):
+            state['epoch'] = epoch
+            model.train()
+            torch.cuda.synchronize(dev)
+            epoch_start_time = time.time()
+            loop.run_steps(cycle_batches(sampler, steps), steps)
+            cacher.drain_misses()         # the miss queue's worker has enqueued its outstanding copies ...
+            torch.cuda.synchronize(dev)   # ... (the reference does not sync here; without it the time is meaningless)
+            cacher.check_misses()         # raises if any step consumed rows that never landed
+            sampler.check()               # ... or trained on a NodeFlow whose sampling chain gave up on a look-back poll
+            if rank == 0:
+                epoch_dur.append(time.time() - epoch_start_time)
+                print('Epoch average time: {:.4f}'.format(np.mean(np.array(epoch_dur[2:]))))
+            if cacher.log:
+                miss_rate = cacher.get_miss_rate()
+                print('Epoch average miss rate: {:.4f}'.format(miss_rate))
+            if args.ckpt and rank == 0:
+                # what examples/eval.py loads: <ckpt>/<arch>_<epoch> (eval.py:30-32); parameters in module order
+                os.makedirs(args.ckpt, exist_ok=True)
+                bare = getattr(model, 'module', model)
+                torch.save({k_: v_.detach().cpu() for k_, v_ in bare.named_parameters()},
+                           os.path.join(args.ckpt, ('gcn-nssc' if arch == 'gcn' else 'gs-nssc') + '_' + str(epoch)))
+        toc = time.time()
+    if rank == 0 and args.profile:
+        print(prof.key_averages().table(sort_by='cuda_time_total'))
     print('Total Time: {:.4f}s'.format(toc - tic))
     dist.destroy_process_group()
 
@@ -156,6 +163,9 @@ def main(arch, description, n_hidden, lr):
     parser.add_argument("--fetch-all", dest="fetch_needed", action="store_false",
                         help="fetch every layer and field into frames, as storage.py:157-204 does")
     parser.add_argument("--log-miss-rate", action="store_true")
+    parser.add_argument("--profile", action="store_true",
+                        help="wrap the run in torch.autograd.profiler.profile on rank 0 and print key_averages().table "
+                             "(pa_gcn.py:81,112 does this unconditionally)")
     parser.add_argument("--ckpt", type=str, default=None, help="directory for one checkpoint per epoch (examples/eval.py)")
     args = parser.parse_args()
     if args.remote_sample:

@@ -414,10 +414,19 @@ int pg_spmm_fwd_drop(const int32_t* indptr, const int32_t* src, const float* h, 
  * Needs dim >= 256 and 16-byte aligned rows whose strides (cache, staged, out) are multiples of 4 floats >= dim
  * rounded up to 4 (else PG_ERR_UNSUPPORTED): dim % 4 != 0 (602) is read and written in whole 16-byte pieces, the
  * columns past dim are masked on the way in and written as zeros. drop may be NULL.
- * prof (device uint64[3 * prof_ring], may be NULL): entry i = (*drop->step, or 0) % prof_ring receives the
- * device wall clock (100 MHz ticks) at [3i] kernel start and [3i+1] kernel end, and [3i+2] the number of edges
- * aggregated — the kernel usually runs inside a replayed hipGraph, where HIP events cannot be attached to it;
- * zero [3i+1] before reuse.                                                                             */
+ * prof (device uint64[PG_PROF_WORDS * prof_ring], zero-initialised, may be NULL): the kernel usually runs inside a
+ * replayed hipGraph, where HIP events cannot be attached to it, so it times itself with the device wall clock (100 MHz
+ * ticks). Entry i = (*drop->step, or 0) % prof_ring, words: [0] start of the first wave; [1] start of the first wave of
+ * the next dependent dense / head launch issued by the same host thread (pg_linear_fwd, pg_linear2_fwd[_rows],
+ * pg_gcn_head[_ex]) — [1] - [0] is the time this kernel occupies its stream: body, drain, end-of-kernel release and the
+ * successor's launch latency, the figure rocprofv3's End - Start of the dispatch agrees with; [2] edges aggregated;
+ * [PG_PROF_END0 + PG_PROF_SHARD_STRIDE * s], s < PG_PROF_SHARDS: latest end-of-block stamp of the blocks b with
+ * b % PG_PROF_SHARDS == s (the kernel body ends at their maximum; one 128-byte line per shard — sixteen shards on ONE
+ * line serialised 3000 atomics at a single L2 channel and took the kernel from 14 to 25 us). The launch clears entry i + 1. */
+#define PG_PROF_END0 16
+#define PG_PROF_SHARDS 16
+#define PG_PROF_SHARD_STRIDE 16
+#define PG_PROF_WORDS (PG_PROF_END0 + PG_PROF_SHARDS * PG_PROF_SHARD_STRIDE)
 typedef struct pg_row_source {
   const int32_t* slots;   /* device int32 [rows of the source layer] */
   const float* cache;     /* device; may be NULL when nothing is cached */
@@ -434,6 +443,10 @@ int pg_compose_edge_slots(const int32_t* src, int64_t n_edges, const int32_t* sl
 int pg_spmm_fwd_rows(const int32_t* indptr, const int32_t* src, const pg_row_source_t* rows, int64_t n_dst,
                      int32_t dim, int reduce, float* out, int32_t out_stride, const pg_dropout_t* drop,
                      uint64_t* prof, int32_t prof_ring, pg_stream_t stream);
+/* Profiling aid: one-thread marker kernel, ring[(*step or 0) % ring_len] = device wall clock (100 MHz ticks). Launched
+ * right behind a kernel inside a captured step it gives that kernel's TRUE end as the stream sees it (the write-back of
+ * what the kernel left dirty in L2 included): a dispatch cannot start before its predecessor has completed.          */
+int pg_prof_stamp(uint64_t* ring, int32_t ring_len, const uint64_t* step, pg_stream_t stream);
 /* grad_h[src[e],:] += grad_out[v,:] * (mean ? 1/deg(v) : 1) * mask(src[e],:) * scale; grad_h zeroed by caller */
 int pg_spmm_bwd_drop(const int32_t* indptr, const int32_t* src, const float* grad_out, int32_t go_stride,
                      int64_t n_dst, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,
@@ -603,7 +616,11 @@ int pg_adam_step_partials2(int32_t n_tensors, float* const* params, float* const
  * 4. Offline partitioning (host)  —  PaGraph/partition/dg.py:59-103
  * ------------------------------------------------------------------------
  * CSC of the full graph on the host. belongs_out[V] (int8, -1 = unassigned). Returns r_vnum/p_vnum.
- * r_mask_out: P*V bytes (r_belongs, dg.py:64) or NULL.                                            */
+ * r_mask_out: P*V bytes (r_belongs, dg.py:64) or NULL. 2 <= P <= 127 (belongs is int8, dg.py:63; argsort[-2:]).
+ * The arg-max of dg.py:30-35 takes the last two of np.argsort(score) with numpy's DEFAULT kind, whose tie order is part
+ * of the result (every first assignment ties): stable up to 16 partitions, numpy's scalar introsort above
+ * (pg_np_argsort_f64). numpy on AVX2 / AVX-512 hosts dispatches that call to x86-simd-sort, which orders ties
+ * differently — the reference's own output is machine-dependent; this is its portable scalar behaviour.       */
 int pg_dg_partition(int64_t V, const int64_t* indptr, const int32_t* indices, const int64_t* train_nids,
                     int64_t n_train, int32_t P, int32_t hops, int8_t* belongs_out, uint8_t* r_mask_out,
                     int64_t* p_vnum_out, int64_t* r_vnum_out);
@@ -613,6 +630,9 @@ int pg_dg_partition(int64_t V, const int64_t* indptr, const int32_t* indices, co
 int pg_dg_partition_mt(int64_t V, const int64_t* indptr, const int32_t* indices, const int64_t* train_nids,
                        int64_t n_train, int32_t P, int32_t hops, int8_t* belongs_out, uint8_t* r_mask_out,
                        int64_t* p_vnum_out, int64_t* r_vnum_out, int32_t n_threads);
+/* order[0..n) = np.argsort(v) (default kind) of n <= 127 float64 on numpy 2.2's scalar path (npysort/quicksort.cpp,
+ * heapsort.cpp restated): what dg's arg-max sorts its scores with. Exported so the tests can pin it against numpy.  */
+int pg_np_argsort_f64(const double* v, int32_t n, int32_t* order);
 
 /* ------------------------------------------------------------------------
  * 5. Synthetic inputs  —  PaGraph/data/preprocess.py:50-114 + PaRMAT (README.md:36-41)

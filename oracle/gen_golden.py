@@ -254,6 +254,20 @@ def gen_dg(dgmod):
     # a tie-heavy case: ring graph, every score ties at the start
     cases.append(("ring", 48, None, 4, 1))
     cases.append(("ring", 48, None, 3, 2))
+    # round 4 (appended: the files above keep their numbers): hops >= 3 — the `neighs = nids[-1]` quirk of dg.py:22-27, only
+    # the LAST appended adjacency list is expanded from depth 2 on — and partition counts at and beyond numpy's stable
+    # range: P = 16 (insertion sort), 17 (the first size its introsort partitions), 24, 40, and a ring with P = 20 where
+    # every score ties
+    cases.append((200, 900, True, 4, 3))
+    cases.append((400, 1500, True, 8, 3))
+    cases.append((150, 500, False, 3, 4))
+    cases.append((400, 1500, True, 16, 1))
+    cases.append((400, 1500, True, 16, 2))
+    cases.append((400, 1500, True, 17, 1))
+    cases.append((500, 2500, True, 24, 2))
+    cases.append((600, 2400, False, 40, 1))
+    cases.append(("ring", 120, None, 20, 1))
+    cases.append((300, 1200, True, 17, 3))
     for idx, (V, E, pl, P, hops) in enumerate(cases):
         if V == "ring":
             V = E

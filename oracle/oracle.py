@@ -463,6 +463,84 @@ def optimal_cache_hit(freq, cached):
 # --------------------------------------------------------------------------
 # partitioning (PaGraph/partition/dg.py, utils.py) — small-case Python restatements
 # --------------------------------------------------------------------------
+def _less(a, b):
+    return a < b or (b != b and a == a)
+
+def _aheapsort(v, t, lo, n):
+    # t[lo .. lo+n-1], 1-based view a[i] = t[lo + i - 1]
+    a = lambda i: t[lo + i - 1]
+    def seta(i, x): t[lo + i - 1] = x
+    l = n >> 1
+    while l > 0:
+        tmp = a(l); i = l; j = l << 1
+        while j <= n:
+            if j < n and _less(v[a(j)], v[a(j + 1)]): j += 1
+            if _less(v[tmp], v[a(j)]):
+                seta(i, a(j)); i = j; j += j
+            else: break
+        seta(i, tmp); l -= 1
+    while n > 1:
+        tmp = a(n); seta(n, a(1)); n -= 1
+        i = 1; j = 2
+        while j <= n:
+            if j < n and _less(v[a(j)], v[a(j + 1)]): j += 1
+            if _less(v[tmp], v[a(j)]):
+                seta(i, a(j)); i = j; j += j
+            else: break
+        seta(i, tmp)
+
+def numpy_scalar_argsort(v):
+    """np.argsort(v) with the default, UNSTABLE kind as dg.py:31 calls it, on numpy's portable scalar path (numpy 2.2,
+    numpy/_core/src/npysort/quicksort.cpp aquicksort_ / heapsort.cpp aheapsort_, restated from the algorithm): introsort —
+    median-of-3 Hoare partitions while a range spans more than 16 elements (pr - pl > 15), insertion sort below (so up to
+    16 partitions the sort is stable), heapsort when the depth budget 2 * floor(log2(n)) runs out. The tie order is part of
+    dg's result (every first assignment ties). Pinned against numpy itself with its SIMD dispatch disabled
+    (tests/test_oracle_golden.py) and, through dg(), by the G4 fixtures with P > 16."""
+    v = [float(x) for x in v]
+    num = len(v)
+    t = list(range(num))
+    if num < 2: return np.asarray(t, dtype=np.int64)
+    pl, pr = 0, num - 1
+    stack, depth = [], []
+    cdepth = (num.bit_length() - 1) * 2
+    while True:
+        if cdepth < 0:
+            _aheapsort(v, t, pl, pr - pl + 1)
+        else:
+            while pr - pl > 15:
+                pm = pl + ((pr - pl) >> 1)
+                if _less(v[t[pm]], v[t[pl]]): t[pm], t[pl] = t[pl], t[pm]
+                if _less(v[t[pr]], v[t[pm]]): t[pr], t[pm] = t[pm], t[pr]
+                if _less(v[t[pm]], v[t[pl]]): t[pm], t[pl] = t[pl], t[pm]
+                vp = v[t[pm]]
+                pi, pj = pl, pr - 1
+                t[pm], t[pj] = t[pj], t[pm]
+                while True:
+                    pi += 1
+                    while _less(v[t[pi]], vp): pi += 1
+                    pj -= 1
+                    while _less(vp, v[t[pj]]): pj -= 1
+                    if pi >= pj: break
+                    t[pi], t[pj] = t[pj], t[pi]
+                pk = pr - 1
+                t[pi], t[pk] = t[pk], t[pi]
+                if pi - pl < pr - pi:
+                    stack.append((pi + 1, pr)); pr = pi - 1
+                else:
+                    stack.append((pl, pi - 1)); pl = pi + 1
+                cdepth -= 1
+                depth.append(cdepth)
+            for pi in range(pl + 1, pr + 1):
+                vi = t[pi]; vp = v[vi]; pj = pi
+                while pj > pl and _less(vp, v[t[pj - 1]]):
+                    t[pj] = t[pj - 1]; pj -= 1
+                t[pj] = vi
+        if not stack: break
+        pl, pr = stack.pop()
+        cdepth = depth.pop()
+    return np.asarray(t, dtype=np.int64)
+
+
 def dg_partition(P, indptr, indices, V, train_nids, hops):
     """dg.py:59-103 restated with explicit loops (slow; small graphs only)."""
     def in_nb(n):
@@ -491,7 +569,7 @@ def dg_partition(P, indptr, indices, V, train_nids, hops):
         com[pid] += freq
         avg = V * 0.65 / P                                        # :54
         score = com * (-p_vnum + avg) / (r_vnum + 1)              # :55
-        ids = np.argsort(score, kind="stable")[-2:]               # :31 (insertion sort for P<=16 == stable)
+        ids = numpy_scalar_argsort(score)[-2:]                    # :31 (default kind: stable only up to P = 16)
         if score[ids[0]] != score[ids[1]]:
             ind = ids[1]
         else:

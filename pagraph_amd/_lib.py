@@ -21,6 +21,8 @@ PG_HEAD_SUM_PARTIALS, PG_HEAD_DAGG_PER_EDGE = 1, 2
 PG_REDUCE_MEAN = 0
 PG_REDUCE_SUM = 1
 PG_REDUCE_MAX = 2
+PG_PROF_END0, PG_PROF_SHARDS, PG_PROF_SHARD_STRIDE = 16, 16, 16      # pg_spmm_fwd_rows' self-timing ring (include/pagraph_hip.h)
+PG_PROF_WORDS = PG_PROF_END0 + PG_PROF_SHARDS * PG_PROF_SHARD_STRIDE
 
 c_i32, c_i64, c_u32, c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 vp = ctypes.c_void_p
@@ -125,6 +127,7 @@ _SIGS = {
     "pg_spmm_fwd_drop": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, vp]),
     "pg_spmm_fwd_rows": (ctypes.c_int, [vp, vp, ctypes.POINTER(PgRowSource), c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, vp,
                                         c_i32, vp]),
+    "pg_prof_stamp": (ctypes.c_int, [vp, c_i32, vp, vp]),
     "pg_compose_edge_slots": (ctypes.c_int, [vp, c_i64, vp, c_i64, vp, vp]),
     "pg_spmm_bwd_drop": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, vp]),
     "pg_spmm_bwd_gather": (ctypes.c_int, [vp, vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, c_i32, vp, vp]),
@@ -158,6 +161,7 @@ _SIGS = {
     "pg_linear_bwd_w_rows": (ctypes.c_int, [vp, c_i32, vp, c_i64, c_i32, c_i32, vp, vp, vp, c_i32, c_i32, vp, vp, c_i32, vp]),
     "pg_dg_partition": (ctypes.c_int, [c_i64, vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp]),
     "pg_dg_partition_mt": (ctypes.c_int, [c_i64, vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp, c_i32]),
+    "pg_np_argsort_f64": (ctypes.c_int, [vp, c_i32, vp]),
     "pg_rmat_edges": (ctypes.c_int, [c_u64, c_i32, c_u32, c_u32, c_u32, c_i64, c_i64, vp, vp, vp]),
     "pg_random_features": (ctypes.c_int, [c_u64, c_i64, c_i64, c_i32, vp, c_i64, vp]),
     "pg_timer_create": (ctypes.c_int, [ctypes.POINTER(vp)]),

@@ -9,6 +9,7 @@
 
 namespace pg {
 thread_local int g_last_hip_error = 0;
+thread_local ProfSucc g_prof_succ;
 }
 
 

@@ -30,6 +30,56 @@ constexpr int kWave = 64;
 
 extern thread_local int g_last_hip_error;
 
+// ---- self-timing of a kernel inside a replayed hipGraph (HIP events cannot bracket one kernel there) ----------------
+// One ring entry = PG_PROF_WORDS uint64 (include/pagraph_hip.h): [0] first wave's start, [1] the SUCCESSOR's first wave's
+// start, [2] a count the kernel reports (edges), [PG_PROF_END0 + PG_PROF_SHARD_STRIDE * s] the latest end-of-block stamp
+// of shard s (block b stamps shard b % PG_PROF_SHARDS, so "kernel body end" = the maximum over the shards: EVERY block
+// takes part — round 3 stamped only the last 256 block indices, which in a fixed-shape launch are padding blocks that
+// retire before the last real ones; every shard has a 128-byte line of its own). 100 MHz device wall clock.
+// The successor's stamp: a launcher that profiles arms this thread-local record; the next dependent launch of one of the
+// dense / head kernels on the same host thread takes it (once) and its block 0 writes entry word [1]. "Start of this kernel's
+// first wave -> start of its successor's first wave" is the time the kernel occupies its stream: body + drain + the
+// end-of-kernel release + the next dispatch's launch latency — what rocprofv3's End - Start of the same dispatch shows.
+struct ProfSucc {
+  unsigned long long* ring = nullptr;
+  int32_t ring_len = 0;
+  const uint64_t* step = nullptr;
+};
+extern thread_local ProfSucc g_prof_succ;
+inline ProfSucc take_prof_succ() {
+  ProfSucc p = g_prof_succ;
+  g_prof_succ = ProfSucc{};
+  return p;
+}
+__device__ __forceinline__ void prof_succ_stamp(const ProfSucc& p) {
+  if (p.ring && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    p.ring[(size_t)((uint32_t)(p.step ? *p.step : 0) % (uint32_t)p.ring_len) * PG_PROF_WORDS + 1] = wall_clock64();
+}
+// first thing in a profiled kernel (every thread calls it): returns this launch's ring entry or null
+__device__ __forceinline__ unsigned long long* prof_begin(unsigned long long* prof, int ring_len, uint32_t step,
+                                                          unsigned long long count) {
+  if (!prof) return nullptr;
+  unsigned long long* e = prof + (size_t)(step % (uint32_t)ring_len) * PG_PROF_WORDS;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) {
+      e[0] = wall_clock64();
+      e[2] = count;
+    }
+    // the NEXT launch's entry is cleared here: nobody writes it before this launch has completed
+    if (ring_len > 1)
+      for (int i = threadIdx.x; i < PG_PROF_WORDS; i += blockDim.x)
+        prof[(size_t)((step + 1u) % (uint32_t)ring_len) * PG_PROF_WORDS + i] = 0ull;
+  }
+  return e;
+}
+// last thing in a profiled kernel (every thread of every block calls it; contains a block barrier)
+__device__ __forceinline__ void prof_end(unsigned long long* e) {
+  if (!e) return;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(e + PG_PROF_END0 + PG_PROF_SHARD_STRIDE * (blockIdx.x % PG_PROF_SHARDS), wall_clock64());
+}
+
 inline int hip_fail(hipError_t e) {
   g_last_hip_error = (int)e;
   return PG_ERR_HIP;

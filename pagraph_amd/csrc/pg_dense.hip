@@ -81,7 +81,9 @@ __global__ __launch_bounds__(NW * 64) void k_linear_fwd(const float* __restrict_
                                                     const float* __restrict__ W2 /* [N][K2] */,
                                                     const float* __restrict__ bias2, int32_t K2,
                                                     float* __restrict__ Y, int32_t y_stride, int64_t n, int32_t K,
-                                                    int32_t N, int32_t act, const RowsArg ra = RowsArg{}) {
+                                                    int32_t N, int32_t act, const RowsArg ra = RowsArg{},
+                                                    const ProfSucc succ = ProfSucc{}) {
+  prof_succ_stamp(succ);
   // one LDS buffer: during the K loop wave w's X slab, afterwards wave w's partial output tile (same region, same wave)
   // (+ with WV == 4 a second slab per wave for its share of W)
   __shared__ __attribute__((aligned(16))) float smem[NW * kTile * kXsStride * ((LDSX && WV == 4) ? 2 : 1)];
@@ -516,17 +518,18 @@ static int linear_fwd(const float* X, int32_t x_stride, const float* W, const fl
   int nw = octets >= 32 ? 8 : 4;
   if (nw_force == 4 || nw_force == 8 || nw_force == 16) nw = nw_force;
   static const bool no_lds = getenv("PG_LINEAR_NO_LDS") != nullptr;
+  const ProfSucc succ = take_prof_succ();      // a profiled predecessor's "my successor started" stamp (pg_common.h)
 #define PG_LIN_FWD(WV, NW)                                                                                          \
   do {                                                                                                              \
     if (rows)                                                                                                       \
       hipLaunchKernelGGL((k_linear_fwd<WV, NW, true, true>), grid, dim3(NW * 64), 0, as_stream(stream), X, x_stride, \
-                         W, bias, X2, x2_stride, W2, bias2, K2, Y, y_stride, n, K, N, act, *rows);                  \
+                         W, bias, X2, x2_stride, W2, bias2, K2, Y, y_stride, n, K, N, act, *rows, succ);            \
     else if (no_lds)                                                                                                \
       hipLaunchKernelGGL((k_linear_fwd<WV, NW, false>), grid, dim3(NW * 64), 0, as_stream(stream), X, x_stride, W,  \
-                         bias, X2, x2_stride, W2, bias2, K2, Y, y_stride, n, K, N, act);                            \
+                         bias, X2, x2_stride, W2, bias2, K2, Y, y_stride, n, K, N, act, RowsArg{}, succ);           \
     else                                                                                                            \
       hipLaunchKernelGGL((k_linear_fwd<WV, NW, true>), grid, dim3(NW * 64), 0, as_stream(stream), X, x_stride, W,   \
-                         bias, X2, x2_stride, W2, bias2, K2, Y, y_stride, n, K, N, act);                            \
+                         bias, X2, x2_stride, W2, bias2, K2, Y, y_stride, n, K, N, act, RowsArg{}, succ);           \
   } while (0)
 #define PG_LIN_FWD_NW(WV)        \
   if (nw == 16) PG_LIN_FWD(WV, 16); \

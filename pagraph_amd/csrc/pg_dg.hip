@@ -11,8 +11,9 @@
 //   * score          = dg.py:47-55: com[p] = 1 + |{u in N : belongs[u]==p}|,
 //     score[p] = com[p] * (avg - p_vnum[p]) / (r_vnum[p] + 1) in float64 with
 //     avg = V*0.65/P evaluated left to right;
-//   * arg-max        = dg.py:30-35 on np.argsort(score)[-2:]; numpy's default
-//     sort is an insertion sort (stable) for n <= 16, which fixes the tie order;
+//   * arg-max        = dg.py:30-35 on np.argsort(score)[-2:] with numpy's default, unstable kind: its scalar
+//     introsort restated below (np_argsort_f64) — an insertion sort (stable) up to 16 partitions, median-of-3
+//     partitions above, which fixes the tie order for every P <= 127 (belongs is int8);
 //   * bookkeeping    = dg.py:76-83.
 #include <algorithm>
 #include <atomic>
@@ -38,6 +39,85 @@
 // operation). Same set arithmetic as the sequential code: bit-identical partitions (tests/golden/g4_*, and the
 // sequential / threaded comparison in tests/test_host_logic.py).
 namespace {
+
+// np.argsort(v) (default kind) of n float64 on numpy's portable scalar path — numpy 2.2 npysort/quicksort.cpp aquicksort_,
+// heapsort.cpp aheapsort_, restated from the algorithm: median-of-3 Hoare partitions while a range spans more than 16
+// elements, insertion sort below, heapsort once the depth budget 2 * floor(log2 n) is spent. NaNs sort last. (On AVX2 /
+// AVX-512 hosts numpy dispatches to x86-simd-sort, whose tie order differs: the reference's partition is machine-dependent;
+// this is the order the fixtures pin — oracle/gen_golden.py runs the reference with the dispatch disabled.)
+inline bool np_less(double a, double b) { return a < b || (b != b && a == a); }
+
+void np_aheapsort(const double* v, int32_t* tosort, int n) {
+  int32_t* a = tosort - 1;                       // 1-based
+  for (int l = n >> 1; l > 0; --l) {
+    const int32_t tmp = a[l];
+    int i = l, j = l << 1;
+    while (j <= n) {
+      if (j < n && np_less(v[a[j]], v[a[j + 1]])) ++j;
+      if (np_less(v[tmp], v[a[j]])) { a[i] = a[j]; i = j; j += j; }
+      else break;
+    }
+    a[i] = tmp;
+  }
+  while (n > 1) {
+    const int32_t tmp = a[n];
+    a[n] = a[1];
+    --n;
+    int i = 1, j = 2;
+    while (j <= n) {
+      if (j < n && np_less(v[a[j]], v[a[j + 1]])) ++j;
+      if (np_less(v[tmp], v[a[j]])) { a[i] = a[j]; i = j; j += j; }
+      else break;
+    }
+    a[i] = tmp;
+  }
+}
+
+void np_argsort_f64(const double* v, int n, int32_t* t) {
+  for (int i = 0; i < n; ++i) t[i] = i;
+  if (n < 2) return;
+  int pl = 0, pr = n - 1;
+  int stack[128], depth[64], sp = 0, dp = 0;
+  int cdepth = 0;
+  for (unsigned u = (unsigned)n; u >>= 1;) ++cdepth;
+  cdepth *= 2;
+  for (;;) {
+    if (cdepth < 0) {
+      np_aheapsort(v, t + pl, pr - pl + 1);
+    } else {
+      while (pr - pl > 15) {
+        const int pm = pl + ((pr - pl) >> 1);
+        if (np_less(v[t[pm]], v[t[pl]])) std::swap(t[pm], t[pl]);
+        if (np_less(v[t[pr]], v[t[pm]])) std::swap(t[pr], t[pm]);
+        if (np_less(v[t[pm]], v[t[pl]])) std::swap(t[pm], t[pl]);
+        const double vp = v[t[pm]];
+        int pi = pl, pj = pr - 1;
+        std::swap(t[pm], t[pj]);
+        for (;;) {
+          do ++pi; while (np_less(v[t[pi]], vp));
+          do --pj; while (np_less(vp, v[t[pj]]));
+          if (pi >= pj) break;
+          std::swap(t[pi], t[pj]);
+        }
+        std::swap(t[pi], t[pr - 1]);
+        if (pi - pl < pr - pi) { stack[sp++] = pi + 1; stack[sp++] = pr; pr = pi - 1; }   // the larger part waits
+        else { stack[sp++] = pl; stack[sp++] = pi - 1; pl = pi + 1; }
+        depth[dp++] = --cdepth;
+      }
+      for (int pi = pl + 1; pi <= pr; ++pi) {
+        const int32_t vi = t[pi];
+        const double vp = v[vi];
+        int pj = pi;
+        while (pj > pl && np_less(vp, v[t[pj - 1]])) { t[pj] = t[pj - 1]; --pj; }
+        t[pj] = vi;
+      }
+    }
+    if (sp == 0) break;
+    pr = stack[--sp];
+    pl = stack[--sp];
+    cdepth = depth[--dp];
+  }
+}
 
 struct Dg2Slot {
   std::vector<int32_t> word;
@@ -119,6 +199,13 @@ void dg2_builder(Dg2Shared* sh) {
 
 }  // namespace
 
+// np.argsort(v) as dg.py:31 gets it on numpy's scalar path (exported for the tests: pinned against numpy itself)
+extern "C" int pg_np_argsort_f64(const double* v, int32_t n, int32_t* order) {
+  if (!v || !order || n < 0 || n > 127) return PG_ERR_INVALID;
+  np_argsort_f64(v, n, order);
+  return PG_OK;
+}
+
 extern "C" int pg_dg_partition(int64_t V, const int64_t* indptr, const int32_t* indices,
                                const int64_t* train_nids, int64_t n_train, int32_t P, int32_t hops,
                                int8_t* belongs_out, uint8_t* r_mask_out, int64_t* p_vnum_out,
@@ -134,7 +221,6 @@ extern "C" int pg_dg_partition_mt(int64_t V, const int64_t* indptr, const int32_
                                   int64_t* r_vnum_out, int32_t n_threads) {
   if (V <= 0 || !indptr || !indices || n_train < 0 || (n_train > 0 && !train_nids) || !belongs_out) return PG_ERR_INVALID;
   if (P < 2 || P > 127 || hops < 1) return PG_ERR_INVALID;  // belongs is int8 (dg.py:63); argsort[-2:] needs P>=2
-  if (P > 16) return PG_ERR_UNSUPPORTED;                     // numpy's argsort stops being stable beyond 16
   if (hops == 2 && n_threads > 1 && n_train > 0) {
     for (int64_t i = 0; i < n_train; ++i)
       if (train_nids[i] < 0 || train_nids[i] >= V) return PG_ERR_INVALID;
@@ -175,16 +261,7 @@ extern "C" int pg_dg_partition_mt(int64_t V, const int64_t* indptr, const int32_
       }
       for (int p = 0; p < P; ++p)                                       // dg.py:51-55
         score[p] = (double)com[p] * (-(double)p_vnum[p] + avg) / (double)(r_vnum[p] + 1);
-      for (int p = 0; p < P; ++p) order[p] = p;                         // dg.py:30-35, stable insertion sort
-      for (int a = 1; a < P; ++a) {
-        const int32_t x = order[a];
-        int j = a - 1;
-        while (j >= 0 && score[x] < score[order[j]]) {
-          order[j + 1] = order[j];
-          --j;
-        }
-        order[j + 1] = x;
-      }
+      np_argsort_f64(score.data(), P, order.data());                    // dg.py:30-35 np.argsort(score)[-2:]
       const int32_t i0 = order[P - 2], i1 = order[P - 1];
       const int32_t ind = (score[i0] != score[i1]) ? i1 : ((p_vnum[i0] < p_vnum[i1]) ? i0 : i1);
       if (belongs_out[nid] == -1) {                                     // dg.py:76-83
@@ -274,17 +351,8 @@ extern "C" int pg_dg_partition_mt(int64_t V, const int64_t* indptr, const int32_
     }
     for (int p = 0; p < P; ++p)
       score[p] = (double)com[p] * (-(double)p_vnum[p] + avg) / (double)(r_vnum[p] + 1);
-    // dg.py:30-35 — stable ascending argsort, then the top two
-    for (int p = 0; p < P; ++p) order[p] = p;
-    for (int i = 1; i < P; ++i) {  // insertion sort, as numpy does for n <= 16
-      const int32_t x = order[i];
-      int j = i - 1;
-      while (j >= 0 && score[x] < score[order[j]]) {
-        order[j + 1] = order[j];
-        --j;
-      }
-      order[j + 1] = x;
-    }
+    // dg.py:30-35 — np.argsort(score) (numpy's scalar introsort: stable up to 16 partitions), then the top two
+    np_argsort_f64(score.data(), P, order.data());
     const int32_t i0 = order[P - 2], i1 = order[P - 1];
     int32_t ind;
     if (score[i0] != score[i1]) ind = i1;

@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
                                                   const float* __restrict__ grad_scale_dev, HeadDrop d, int reduce,
                                                   int64_t n_dst, float* __restrict__ logits,
                                                   float* __restrict__ dagg, float* __restrict__ part, int dagg_per_edge,
-                                                  int row_len) {
+                                                  int row_len, const ProfSucc succ) {
+  prof_succ_stamp(succ);     // a profiled predecessor's "my successor started" stamp (pg_common.h)
   __shared__ __attribute__((aligned(16))) float s_rows[4][kHeadRows][kHeadMax];   // the waves' aggregated rows
   __shared__ int s_lab[4][kHeadRows];
   __shared__ float s_deg[4][kHeadRows];      // what dAgg is divided by when it leaves per edge (dagg_per_edge)
@@ -344,7 +345,8 @@ int pg_gcn_head_ex(const int32_t* indptr, const int32_t* src, const float* h, in
 #define PG_HEAD(R)                                                                                                   \
   hipLaunchKernelGGL(k_gcn_head<R>, dim3((unsigned)blocks), dim3(256), 0, st, indptr, src, h, h_stride, K, W, bias, C, \
                      labels, ignore_index, n_valid_dev, grad_scale_dev, d, reduce, n_dst, logits, dagg, partials,          \
-                     (flags & PG_HEAD_DAGG_PER_EDGE) ? 1 : 0, (int)pg_gcn_head_row_len(K, C))
+                     (flags & PG_HEAD_DAGG_PER_EDGE) ? 1 : 0, (int)pg_gcn_head_row_len(K, C), succ)
+  const ProfSucc succ = take_prof_succ();
   if (rpw == 1) PG_HEAD(1);
   else if (rpw == 2) PG_HEAD(2);
   else if (rpw == 4) PG_HEAD(4);

@@ -34,6 +34,8 @@
 
 #include <fcntl.h>
 #include <sys/file.h>
+#include <sys/stat.h>
+#include <cerrno>
 #include <unistd.h>
 
 #include <hsa/hsa.h>
@@ -469,10 +471,33 @@ struct CalibLock {
   CalibLock() {
     const char* e = getenv("PG_MISSQ_CALIB_LOCK");
     if (e && atoi(e) == 0) return;
-    fd = open("/tmp/.pagraph_sdma_calibration.lock", O_CREAT | O_RDWR | O_CLOEXEC, 0666);
-    if (fd >= 0 && flock(fd, LOCK_EX) != 0) {
-      close(fd);
-      fd = -1;
+    // a per-user lock file (another user's ranks calibrate another job's GPUs; their file would not be ours to open),
+    // never followed through a symlink, mode independent of the umask
+    char path[96];
+    snprintf(path, sizeof(path), "/tmp/.pagraph_sdma_calibration.%u.lock", (unsigned)geteuid());
+    fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
+    if (fd < 0) {
+      fprintf(stderr, "[pg_missq] calibration lock %s: %s — calibrating without it\n", path, strerror(errno));
+      return;
+    }
+    (void)fchmod(fd, 0600);
+    // bounded: a stopped or hung rank that holds the lock must not block every other rank's queue creation for ever. A
+    // calibration takes ~10 ms per engine; after PG_MISSQ_CALIB_LOCK_MS (default 5000) this rank goes ahead without it.
+    const char* ms_e = getenv("PG_MISSQ_CALIB_LOCK_MS");
+    const long budget_ms = ms_e ? atol(ms_e) : 5000;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      if (flock(fd, LOCK_EX | LOCK_NB) == 0) return;
+      const bool busy = errno == EWOULDBLOCK || errno == EINTR;
+      const long waited = (long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+      if (!busy || waited >= budget_ms) {
+        fprintf(stderr, "[pg_missq] calibration lock %s not acquired after %ld ms (%s) — calibrating without it\n", path,
+                waited, busy ? "held by another process" : strerror(errno));
+        close(fd);
+        fd = -1;
+        return;
+      }
+      std::this_thread::sleep_for(std::chrono::milliseconds(2));
     }
   }
   ~CalibLock() {

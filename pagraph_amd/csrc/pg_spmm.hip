@@ -13,6 +13,7 @@
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include <cstdlib>
+#include <cstring>
 
 #include "pg_common.h"
 
@@ -241,9 +242,8 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_drop(const int32_t* __restrict
 // write and one read of the [|L0|, dim] frame (2 x 45 MB per step at the benchmark's shape).
 // One wave per destination (dim >= 256): lane e of the wave looks up edge e's position and slot, the two
 // dependent index loads of ALL of the destination's edges are in flight together, then the rows are streamed.
-// prof (optional): [3 * i], [3 * i + 1] = device wall-clock (100 MHz) when block 0 started / the last blocks
-// finished, [3 * i + 2] = edges aggregated, i = (*drop.step or 0) % prof_ring — a kernel inside a replayed
-// hipGraph cannot carry HIP events.
+// prof (optional): the kernel's own ring of time stamps, entry (*drop.step or 0) % prof_ring (layout: pg_common.h,
+// include/pagraph_hip.h) — a kernel inside a replayed hipGraph cannot carry HIP events.
 constexpr int kRowsBatch = 4;   // source rows whose loads are in flight together per wave
 
 // TAIL: dim % 4 != 0 (Reddit's 602). The rows are still read and written as 16-byte pieces — every row of the fused
@@ -262,11 +262,7 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict
                                                        unsigned long long* __restrict__ prof, int prof_ring) {
   using S = SV<4>;
   const uint32_t step = d.step ? (uint32_t)*d.step : 0u;
-  unsigned long long* pslot = prof ? prof + 3 * (size_t)(step % (uint32_t)prof_ring) : nullptr;
-  if (pslot && blockIdx.x == 0 && threadIdx.x == 0) {
-    pslot[0] = wall_clock64();
-    pslot[2] = (unsigned long long)indptr[n_dst];   // edges of this launch
-  }
+  unsigned long long* pslot = prof_begin(prof, prof_ring, step, prof ? (unsigned long long)indptr[n_dst] : 0ull);
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t v = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
   if (v < n_dst) {
@@ -353,10 +349,7 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict
       }
     }
   }
-  if (pslot && blockIdx.x + 256 >= gridDim.x) {   // the tail of the grid: kernel end = the latest of these
-    __syncthreads();
-    if (threadIdx.x == 0) atomicMax(pslot + 1, wall_clock64());
-  }
+  prof_end(pslot);
 }
 
 // k_spmm_fwd_rows_w<DROP, TAIL, M>: the same arithmetic (edge order, dropout counters: bit-identical) for rows of at
@@ -370,6 +363,29 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict
 //  * a row's Philox draws are issued between the loads and their first use.
 constexpr int kRowsPair = 2;
 
+// How the aggregated row leaves the CU (store_mode is wave-uniform: a scalar branch around three stores).
+//   PG_STORE_PLAIN: write-back — the 23 MB of `out` a launch produces sit dirty in the XCDs' L2s until the kernel's closing
+//                   release writes them back, AFTER the last wave has retired: time the kernel's own stamps do not see but
+//                   the dispatch (rocprofv3's End, and the successor's start) pays (profiles/r04).
+//   PG_STORE_NT:    non-temporal hint (still write-back).
+//   PG_STORE_WT:    `sc0 sc1` write-through: every piece goes to memory while the row loads of other waves stream, nothing is
+//                   left dirty for the kernel's end; the consumer (another launch, usually on another XCD) reads from
+//                   memory / MALL either way.
+enum { PG_STORE_PLAIN = 0, PG_STORE_NT = 1, PG_STORE_WT = 2 };
+typedef float pg_f4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void store_row_piece(float4* p, const float4& v, int mode) {
+  if (mode == PG_STORE_WT) {
+    pg_f4v t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(t) : "memory");
+  } else if (mode == PG_STORE_NT) {
+    pg_f4v t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<pg_f4v*>(p));
+  } else {
+    *p = v;
+  }
+}
+
 template <bool DROP, bool TAIL, int M, bool MAXR>
 __global__ __launch_bounds__(256) void k_spmm_fwd_rows_w(const int32_t* __restrict__ indptr,
                                                          const int32_t* __restrict__ src,
@@ -379,14 +395,11 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows_w(const int32_t* __restri
                                                          const float* __restrict__ staged, int32_t staged_stride,
                                                          int64_t n_dst, int32_t dim, int reduce,
                                                          float* __restrict__ out, int32_t out_stride, DropArgs d,
-                                                         unsigned long long* __restrict__ prof, int prof_ring) {
+                                                         unsigned long long* __restrict__ prof, int prof_ring,
+                                                         int store_mode) {
   using S = SV<4>;
   const uint32_t step = d.step ? (uint32_t)*d.step : 0u;
-  unsigned long long* pslot = prof ? prof + 3 * (size_t)(step % (uint32_t)prof_ring) : nullptr;
-  if (pslot && blockIdx.x == 0 && threadIdx.x == 0) {
-    pslot[0] = wall_clock64();
-    pslot[2] = (unsigned long long)indptr[n_dst];   // edges of this launch
-  }
+  unsigned long long* pslot = prof_begin(prof, prof_ring, step, prof ? (unsigned long long)indptr[n_dst] : 0ull);
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t v = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
   if (v < n_dst) {
@@ -480,14 +493,11 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows_w(const int32_t* __restri
       if (c < pieces) {
         if (!MAXR && reduce == PG_REDUCE_MEAN && end > beg) S::div(acc[m], dg);
         if (MAXR && !any) acc[m] = S::zero();
-        orow[c] = acc[m];
+        store_row_piece(orow + c, acc[m], store_mode);
       }
     }
   }
-  if (pslot && blockIdx.x + 256 >= gridDim.x) {   // the tail of the grid: kernel end = the latest of these
-    __syncthreads();
-    if (threadIdx.x == 0) atomicMax(pslot + 1, wall_clock64());
-  }
+  prof_end(pslot);
 }
 
 // edge_slots[e] = slots[src[e]] for the block's edges (entries whose source position is out of range: -2)
@@ -917,6 +927,37 @@ int pg_spmm_fwd_drop(const int32_t* indptr, const int32_t* src, const float* h, 
   return PG_OK;
 }
 
+// PG_FWD_ROWS_STORE = plain | nt | wt: how k_spmm_fwd_rows_w writes `out` (see store_row_piece). Default wt (round 4):
+// dispatch End - Start in the training loop 20.5 (plain) / 19.2 (wt) / 21.5 (nt) us, alone on cold rows 16.1 / 15.2 / 15.0,
+// profiles/r04/fused_store_modes.txt.
+static int fwd_rows_store_mode() {
+  const char* e = getenv("PG_FWD_ROWS_STORE");
+  if (!e) return PG_STORE_WT;
+  if (!strcmp(e, "wt")) return PG_STORE_WT;
+  if (!strcmp(e, "nt")) return PG_STORE_NT;
+  return PG_STORE_PLAIN;
+}
+
+// One-thread marker kernel: word [3] of the profiling ring's entry (*step) % ring_len = device wall clock (100 MHz). Launched
+// right behind a profiled kernel it cannot start before that dispatch has completed, whatever runs next (profiling aid for
+// tools/join_stamps_trace.py: a one-thread kernel's stamp is taken within a fraction of a microsecond of its dispatch start,
+// which ties the stamps' clock to rocprofv3's; bench.py PG_BENCH_STAMP_SUCCESSOR=1). It also takes the armed successor
+// stamp, like any other dependent launch would.
+__global__ void k_prof_stamp(unsigned long long* __restrict__ ring, int ring_len, const uint64_t* __restrict__ step,
+                             ProfSucc succ) {
+  prof_succ_stamp(succ);
+  if (threadIdx.x == 0)
+    ring[(size_t)((uint32_t)(step ? *step : 0) % (uint32_t)ring_len) * PG_PROF_WORDS + 3] = wall_clock64();
+}
+
+int pg_prof_stamp(uint64_t* ring, int32_t ring_len, const uint64_t* step, pg_stream_t stream) {
+  if (!ring || ring_len <= 0) return PG_ERR_INVALID;
+  hipLaunchKernelGGL(k_prof_stamp, dim3(1), dim3(64), 0, as_stream(stream), reinterpret_cast<unsigned long long*>(ring),
+                     (int)ring_len, step, take_prof_succ());
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
 int pg_spmm_fwd_rows(const int32_t* indptr, const int32_t* src, const pg_row_source_t* rows, int64_t n_dst,
                      int32_t dim, int reduce, float* out, int32_t out_stride, const pg_dropout_t* drop,
                      uint64_t* prof, int32_t prof_ring, pg_stream_t stream) {
@@ -944,7 +985,7 @@ int pg_spmm_fwd_rows(const int32_t* indptr, const int32_t* src, const pg_row_sou
 #define PG_FWD_ROWS_W(DROP, TAIL, M, MAXR)                                                                              \
   hipLaunchKernelGGL((k_spmm_fwd_rows_w<DROP, TAIL, M, MAXR>), dim3(grid), dim3(256), 0, as_stream(stream), indptr, src, \
                      rows->slots, rows->edge_slots, rows->cache, rows->cache_stride, rows->staged, rows->staged_stride, \
-                     n_dst, dim, reduce, out, out_stride, d, pr, (int)prof_ring)
+                     n_dst, dim, reduce, out, out_stride, d, pr, (int)prof_ring, store_mode)
 #define PG_FWD_ROWS_R(DROP, TAIL, MAXR)                               \
   do {                                                                \
     if (generic || dim4 > 1024) PG_FWD_ROWS(DROP, TAIL, MAXR);        \
@@ -959,6 +1000,7 @@ int pg_spmm_fwd_rows(const int32_t* indptr, const int32_t* src, const pg_row_sou
   } while (0)
   // rows of up to 1024 floats take the wave-uniform kernel (PG_FWD_ROWS_GENERIC=1: the generic one, for A/B runs)
   static const bool generic = getenv("PG_FWD_ROWS_GENERIC") != nullptr;
+  static const int store_mode = fwd_rows_store_mode();
   if (dim % 4 == 0) {
     if (has_drop) PG_FWD_ROWS_ANY(true, false);
     else PG_FWD_ROWS_ANY(false, false);
@@ -971,6 +1013,11 @@ int pg_spmm_fwd_rows(const int32_t* indptr, const int32_t* src, const pg_row_sou
 #undef PG_FWD_ROWS_W
 #undef PG_FWD_ROWS
   PG_LAUNCH_CHECK();
+  if (pr) {                     // the next dense / head launch of this thread stamps this entry's word [1]
+    g_prof_succ.ring = pr;
+    g_prof_succ.ring_len = prof_ring;
+    g_prof_succ.step = d.step;
+  }
   return PG_OK;
 }
 

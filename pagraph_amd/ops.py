@@ -43,7 +43,7 @@ class RowSource:
         self.staged_stride = int(staged_stride)
         self.dim = int(dim)
         self.keep = keep                      # whatever owns the staged block
-        self.prof = prof                      # (device uint64 [3 * ring], ring) or None: kernel self-timing
+        self.prof = prof                      # (device uint64 [PG_PROF_WORDS * ring], ring[, marker kernel?]) or None: self-timing
         self.is_cuda, self.dtype, self.device = True, torch.float32, slots.device
         self.requires_grad = False
 
@@ -83,11 +83,14 @@ def aggregate_rows(indptr, src, rows, n_dst, reduce="mean", dropout=None):
     out = torch.empty((int(n_dst), pad), dtype=torch.float32, device=rows.device)[:, :rows.dim]
     rs = rows.struct()
     d = dropout.struct() if dropout is not None else None
-    prof, ring = rows.prof if rows.prof is not None else (None, 0)
+    prof, ring, marker = (tuple(rows.prof) + (None,))[:3] if rows.prof is not None else (None, 0, None)
     with torch.cuda.device(rows.device):
         L.check(lib.pg_spmm_fwd_rows(L.ptr(indptr), L.ptr(src), ctypes.byref(rs), int(n_dst), rows.dim, _REDUCE[reduce],
                                      L.ptr(out), out.stride(0), ctypes.byref(d) if d is not None else None,
                                      L.ptr(prof), ring, L.stream_ptr()), "pg_spmm_fwd_rows")
+        if marker:                   # profiling runs only: a one-thread marker kernel right behind it (tools/join_stamps_trace.py)
+            L.check(lib.pg_prof_stamp(L.ptr(prof), ring, L.ptr(dropout.step) if dropout is not None else None,
+                                      L.stream_ptr()), "pg_prof_stamp")
     return out
 
 

@@ -23,6 +23,11 @@ class Adam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._lib = L.load()
         self._dev_state = {}      # per group: (step int64[1], ticket int32[1]) on the group's device
+        # Host-side count of the step launches ENQUEUED so far for the (single) parameter group: every eager step() bumps it,
+        # and whoever replays a captured graph that contains a step reports the replay (note_replayed_steps). It belongs to
+        # the optimiser, not to a trainer: two trainers that share one optimiser (bench.py's reference-equivalent leg) then
+        # hand out tokens from the same sequence the mirrored device counter advances through.
+        self._issued = 0
 
     def enable_step_mirror(self, device):
         """Mirror the (single) parameter group's device step counter into pinned host memory: every later step's launch
@@ -42,7 +47,26 @@ class Adam(torch.optim.Optimizer):
             self._mirror = m
             _MIRROR_KEEPALIVE.append(m)
             self._mirror_cell = ctypes.c_int64.from_address(m.data_ptr())
+            self._issued = int(m[0])
         return self._mirror_cell
+
+    def steps_issued(self):
+        """step launches enqueued so far (eager steps + reported graph replays): the value the mirrored device counter
+        (enable_step_mirror) reaches once all of them have run"""
+        return self._issued
+
+    def note_replayed_steps(self, n=1):
+        """a captured graph holding `n` of this optimiser's step launches was replayed (a capture itself launches nothing
+        and is not counted)"""
+        self._issued += int(n)
+
+    def resync_steps_issued(self, device):
+        """with NOTHING of this optimiser in flight: line the host count up with the device counter (somebody replayed a
+        graph with a step in it without reporting it). Synchronises. Returns the count."""
+        st = self._dev_state.get(0)
+        if st is not None:
+            self._issued = int(st[0].item())
+        return self._issued
 
     def __del__(self):
         try:
@@ -110,6 +134,8 @@ class Adam(torch.optim.Optimizer):
                                                    float(group['lr']), float(b1), float(b2), float(group['eps']),
                                                    float(group['weight_decay']), L.ptr(sd), L.ptr(ticket),
                                                    L.stream_ptr()), "pg_adam_step")
+                if last and gi == 0 and not torch.cuda.is_current_stream_capturing():
+                    self._issued += 1
         return loss
 
     @torch.no_grad()
@@ -163,4 +189,6 @@ class Adam(torch.optim.Optimizer):
                                                      off2, adam, float(group['lr']), float(b1), float(b2),
                                                      float(group['eps']), float(group['weight_decay']), L.ptr(step_dev),
                                                      L.ptr(ticket), L.ptr(bump), L.stream_ptr()), "pg_adam_step_partials")
+        if gi == 0 and not torch.cuda.is_current_stream_capturing():
+            self._issued += 1
         return None

@@ -8,6 +8,7 @@ One `for nf in sampler` pass = one epoch; batch b+1 is sampled on a side stream
 while the caller works on batch b (the role of DGL's prefetch=True thread).
 """
 import ctypes
+import time
 
 import torch
 
@@ -80,13 +81,36 @@ class _Slot:
         self.desc = d
 
 
+_SPIN_POLLS = 4000          # ~ a few hundred microseconds of back-to-back polling before the thread starts yielding
+
+
 def _poll(event):
+    """wait for `event` on the launch thread without sleeping on an interrupt (a blocking wait can wake up milliseconds
+    late on a shared host) — but not at any price: past _SPIN_POLLS polls the thread yields its CPU between polls (the
+    gather pool and the miss queue's worker, whose progress it is usually waiting for, run on the same quota-limited cores:
+    ADVICE r03), and a wait that is badly late ends in a blocking synchronize()."""
     polls = 0
     while not event.query():
         polls += 1
-        if polls > 400000:            # something is badly late: stop burning the CPU
-            event.synchronize()
-            return
+        if polls > _SPIN_POLLS:
+            time.sleep(0)
+            if polls > 400000:        # something is badly late: stop burning the CPU
+                event.synchronize()
+                return
+
+
+def _poll_until(pred, what, seconds=60.0):
+    """the same for a host-side predicate (a word of pinned memory a kernel writes); raises after `seconds`"""
+    polls = 0
+    deadline = None
+    while not pred():
+        polls += 1
+        if polls > _SPIN_POLLS:
+            time.sleep(0)
+            if deadline is None:
+                deadline = time.monotonic() + seconds
+            elif (polls & 1023) == 0 and time.monotonic() > deadline:
+                raise L.PgError(what)
 
 
 class NeighborSampler:
@@ -221,12 +245,10 @@ class NeighborSampler:
         if slot.free_recorded and self.host_gated and getattr(slot, "free_token", None) is not None:
             # (the consumer handed back a token instead of an event: "done" = its step counter has reached the token —
             # a word of pinned memory its last kernel writes, GraphedTrainer / optim.Adam.enable_step_mirror)
-            polls = 0
-            while not self.free_reached(slot.free_token):
-                polls += 1
-                if polls > 50_000_000:
-                    raise L.PgError("NeighborSampler: the consumer's step counter never reached the token of a released "
-                                    "ring slot (did the step that owned it run its optimiser?)")
+            token = slot.free_token
+            _poll_until(lambda: self.free_reached(token),
+                        "NeighborSampler: the consumer's step counter never reached the token of a released ring slot "
+                        "(did the step that owned it run its optimiser?)")
         elif slot.free_recorded and self.host_gated:
             # the consumer of the batch that used this slot is done — checked HERE, on the launch thread, instead of with a
             # wait on the sampler's stream: an event that another stream waits for costs the stream that records it ~13 us

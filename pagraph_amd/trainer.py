@@ -146,7 +146,18 @@ class MinibatchTrainer:
         torch.cuda.synchronize(self.device)
         dt = time.time() - t0
         self.cacher.check_misses()
+        if hasattr(self.sampler, "check"):
+            self.sampler.check()         # a look-back poll of the sampling chain that gave up = a garbage NodeFlow was trained on
         return n, dt
+
+    def synchronize(self):
+        """wait for everything enqueued so far, then raise if the miss path or the sampling chain gave up on something
+        (callers of run_steps that only synchronise a stream never see those flags: ADVICE r03)"""
+        self.cacher.drain_misses()
+        torch.cuda.synchronize(self.device)
+        self.cacher.check_misses()
+        if hasattr(self.sampler, "check"):
+            self.sampler.check()
 
 
 def cycle_batches(sampler, steps):
@@ -256,12 +267,14 @@ class GraphedTrainer:
         # last block of the step's last launch) there is no event at all: a slot is free once the counter has reached the
         # step that read it. tools/exp_graph_gap.py: an event record nobody waits for in-stream still costs the compute
         # stream 4.7 us per step. PG_NO_STEP_MIRROR=1 keeps the event.
+        # The token of a step is the OPTIMISER's count of step launches enqueued once that step's launch is in
+        # (optim.Adam.steps_issued: eager steps count themselves, replays are reported below) — one sequence per optimiser,
+        # so a second trainer on the same optimiser, or steps somebody runs between two run_steps calls, cannot make this
+        # trainer's tokens lag the counter they are compared with (every released slot then read as free at once).
         self._step_cell = None
-        self._steps_issued = 0
         if sampler.host_gated and hasattr(optimizer, "enable_step_mirror") and not _os.environ.get("PG_NO_STEP_MIRROR"):
             self._step_cell = optimizer.enable_step_mirror(device)
             if self._step_cell is not None:
-                self._steps_issued = int(self._step_cell.value)
                 cell = self._step_cell
                 sampler.free_reached = lambda token: cell.value >= token
         cacher.missq_slots = len(sampler.slots)
@@ -292,6 +305,9 @@ class GraphedTrainer:
         # makes a fresh iterator per epoch.
         self.keep_primed = False
         self.keep_gc = False             # True: leave the interpreter's cyclic garbage collector on inside run_steps
+        # True: prepare / compute run inside the reference's profiler ranges 'gpu-load' / 'gpu-compute' (pa_gcn.py:87,92);
+        # off by default — a record_function costs the launch thread a few microseconds per step
+        self.profile_ranges = False
 
     class _Slot:
         pass
@@ -547,13 +563,16 @@ class GraphedTrainer:
         if self.graph_b is not None:
             self.graph_b.replay()
         elif not capture_ok:
-            self.optimizer.step()
+            self.optimizer.step()                 # (an eager step counts itself)
+            return
         else:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=self.compute_stream, capture_error_mode="thread_local"):
                 self.optimizer.step()
             self.graph_b = g
             g.replay()
+        if self._step_cell is not None:
+            self.optimizer.note_replayed_steps(1)
 
     def compute(self, s):
         main = self.compute_stream
@@ -568,8 +587,12 @@ class GraphedTrainer:
             # other way since (an eager forward bumps first, then uses): one eager increment puts it back
             with torch.cuda.stream(main):
                 s.ext_drop.externalise_drop_step()
+        counted = self._step_cell is not None
+        issued0 = self.optimizer.steps_issued() if counted else 0
         if s.graph is not None and (self.world == 1 or s.graph_synced) and self._on_main:
             s.graph.replay()                                  # steady state: one launch
+            if counted:
+                self.optimizer.note_replayed_steps(1)
             loss = s.loss.clone() if self.keep_losses else s.loss
         else:
             with torch.cuda.stream(main):
@@ -578,6 +601,8 @@ class GraphedTrainer:
                 if s.graph is not None:
                     s.graph.replay()
                     synced = s.graph_synced
+                    if counted and (self.world == 1 or synced):
+                        self.optimizer.note_replayed_steps(1)
                 elif warm:
                     if self.world == 1:
                         self.optimizer.zero_grad(set_to_none=True)
@@ -598,6 +623,8 @@ class GraphedTrainer:
                     s.graph_plan = s.plan
                     s.graph_synced = synced = bool(self.allreduce_in_graph)
                     g.replay()                                   # capture does not execute
+                    if counted and (self.world == 1 or synced):
+                        self.optimizer.note_replayed_steps(1)
                 if self.world > 1 and not synced:
                     self._sync_and_step(capture_ok=not warm)
                 # the slot's static loss tensor is overwritten when its graph is replayed again
@@ -610,7 +637,14 @@ class GraphedTrainer:
         # this step had finished (measured: the sampler started only when the current graph ended). Call
         # synchronize() (or compute_stream.synchronize()) before reading it.
         self.steps_done += 1
-        self._steps_issued += 1          # one optimiser launch per compute(): the token of this step's buffers
+        # the token of this step's buffers: the optimiser's launch count with this step's launch in. A step that enqueued
+        # no optimiser launch at all (every gradient None) has no "last launch" to stand for it: None = release by event.
+        self._last_token = None
+        if counted:
+            issued1 = self.optimizer.steps_issued()
+            if issued1 != issued0 + 1 and issued1 != issued0:
+                raise L.PgError(f"GraphedTrainer: one step advanced the optimiser's launch count by {issued1 - issued0}")
+            self._last_token = issued1 if issued1 == issued0 + 1 else None
         self.last_loss = loss
         return loss
 
@@ -645,16 +679,25 @@ class GraphedTrainer:
     def _run_steps(self, it, steps=None):
         done = 0
         if self._step_cell is not None and not self._prepared:
-            # nothing of this trainer is in flight: line the token count up with the optimiser's real step count (somebody
-            # may have stepped it outside this loop since the last call)
+            # nothing of this trainer is in flight: the optimiser's host count and its device counter must agree once the
+            # device is idle — unless somebody replayed a step of this optimiser without reporting it (their own captured
+            # graph): then the device is right
             self.compute_stream.synchronize()
-            self._steps_issued = int(self._step_cell.value)
+            if int(self._step_cell.value) != self.optimizer.steps_issued():
+                torch.cuda.synchronize(self.device)
+                self.optimizer.resync_steps_issued(self.device)
+
+        ranges = self.profile_ranges
 
         def prepare_one():
             nf = next(it, None)
             if nf is None:
                 return False
-            self._prepared.append(self.prepare(nf))
+            if ranges:
+                with torch.autograd.profiler.record_function('gpu-load'):
+                    self._prepared.append(self.prepare(nf))
+            else:
+                self._prepared.append(self.prepare(nf))
             return True
 
         while len(self._prepared) < self.lookahead and prepare_one():
@@ -672,9 +715,13 @@ class GraphedTrainer:
                 prepare_one()
             t_1 = time.perf_counter() if trace is not None else 0.0
             cur = self._prepared.pop(0)
-            loss = self.compute(cur)
+            if ranges:
+                with torch.autograd.profiler.record_function('gpu-compute'):
+                    loss = self.compute(cur)
+            else:
+                loss = self.compute(cur)
             t_2 = time.perf_counter() if trace is not None else 0.0
-            self.sampler.release(cur.nf_cur, token=self._steps_issued if self._step_cell is not None else None)
+            self.sampler.release(cur.nf_cur, token=self._last_token)
             if trace is not None:
                 trace.append(((t_1 - t_0) * 1e3, (t_2 - t_1) * 1e3, (time.perf_counter() - t_2) * 1e3))
             done += 1

@@ -1792,14 +1792,27 @@ def _fused_gather_aggregate_case(dev, hiplib, oracle, ratio, p_drop, reduce, Fd)
     out = torch.empty((n_dst, Fd), dtype=torch.float32, device=dev)
     stepd = torch.tensor([step], dtype=torch.int64, device=dev)
     drop = L.PgDropout(thr, tag, seed, L.ptr(stepd))
-    prof = torch.zeros(3 * 16, dtype=torch.int64, device=dev)
+    prof = torch.zeros(L.PG_PROF_WORDS * 16, dtype=torch.int64, device=dev)
     L.check(hiplib.pg_spmm_fwd_rows(L.ptr(d_indptr), L.ptr(d_src),
                                     ctypes.byref(rs), n_dst, Fd, {"mean": 0, "sum": 1, "max": 2}[reduce], L.ptr(out), Fd,
                                     ctypes.byref(drop), L.ptr(prof), 16, sp))
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), want)
-    t0, t1, ne = prof[3 * (step % 16):3 * (step % 16) + 3].tolist()
-    assert 0 < t1 - t0 < 100_000_000 and ne == int(indptr[-1])   # the kernel stamped its own start / end (100 MHz ticks)
+    # the kernel stamped its own start / end (100 MHz ticks; every block stamps a shard of the end) and cleared the next entry
+    e = prof.view(16, L.PG_PROF_WORDS)[step % 16].tolist()
+    ends = e[L.PG_PROF_END0::L.PG_PROF_SHARD_STRIDE]
+    t0, ne, t1 = e[0], e[2], max(ends)
+    assert 0 < t1 - t0 < 100_000_000 and ne == int(indptr[-1])
+    assert len(ends) == L.PG_PROF_SHARDS and (min(ends) > 0 or n_dst < 4 * L.PG_PROF_SHARDS)
+    assert prof.view(16, L.PG_PROF_WORDS)[(step + 1) % 16].abs().sum().item() == 0
+    # ... and armed the successor stamp: the next dense launch of this thread writes word [1] of the same entry
+    if Fd % 4 == 0:
+        w8, y8 = torch.rand((8, Fd), device=dev), torch.empty((64, 8), device=dev)
+        L.check(hiplib.pg_linear_fwd(L.ptr(out), out.stride(0), L.ptr(w8), None, L.ptr(y8), 8, 64, Fd, 8, 0, sp))
+        torch.cuda.synchronize()
+        t_succ = prof.view(16, L.PG_PROF_WORDS)[step % 16, 1].item()
+        assert t_succ >= t1 and t_succ - t0 < 100_000_000
+        assert torch.allclose(y8, out[:64] @ w8.t(), rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize("arch", ["gcn", "sage"])

@@ -86,7 +86,8 @@ def test_dg_product_vs_reference_golden(hiplib, path):
         assert p_vnum[p] == len(z[f"sub_trainv_{p}"]) and r_vnum[p] == len(z[f"sub_v_{p}"])
 
 
-@pytest.mark.parametrize("V,E,P,hops", [(3000, 20000, 4, 1), (3000, 12000, 8, 2), (1500, 6000, 3, 3), (2000, 9000, 16, 2)])
+@pytest.mark.parametrize("V,E,P,hops", [(3000, 20000, 4, 1), (3000, 12000, 8, 2), (1500, 6000, 3, 3), (2000, 9000, 16, 2),
+                                        (2500, 12000, 24, 1), (1800, 7000, 40, 2), (1200, 5000, 17, 3)])
 def test_dg_product_vs_oracle_medium(hiplib, oracle, V, E, P, hops):
     """larger than the fixtures, incl. the hops>=3 quirk of dg.py:22-27 and isolated vertices"""
     from pagraph_amd.partition.dg import dg
@@ -111,9 +112,54 @@ def test_dg_argument_limits(hiplib):
     with pytest.raises(_lib.PgError):
         dg_raw(1, ip, ix, 10, tr, 1)          # the reference's argsort[-2:] needs P >= 2 (dg.py:31-32)
     with pytest.raises(_lib.PgError):
-        dg_raw(17, ip, ix, 10, tr, 1)         # beyond numpy's stable small-sort range: refused, not guessed
+        dg_raw(128, ip, ix, 10, tr, 1)        # belongs is int8 (dg.py:63)
+    b17 = dg_raw(17, ip, ix, 10, tr, 1)[0]    # beyond numpy's stable small-sort range: its introsort, restated (round 4)
+    assert set(np.unique(b17)) <= set(range(-1, 17))
     b, r, pv, rv = dg_raw(2, ip, ix, 10, tr, 2)   # edgeless graph: every score ties
     assert pv.sum() == 5 and set(np.unique(b)) <= {-1, 0, 1}
+
+
+_NP_ARGSORT_PROBE = r"""
+import json, sys
+import numpy as np
+rng = np.random.default_rng(int(sys.argv[1]))
+out = []
+for trial in range(int(sys.argv[2])):
+    n = int(rng.integers(2, 128))
+    kind = trial % 5
+    if kind == 0: a = rng.integers(0, 3, n).astype(np.float64)
+    elif kind == 1: a = rng.random(n)
+    elif kind == 2: a = np.round(rng.random(n) * 5) / 5
+    elif kind == 3: a = np.sort(rng.integers(0, 4, n).astype(np.float64))[::(-1 if trial % 2 else 1)].copy()
+    else: a = np.zeros(n)
+    out.append([a.tolist(), np.argsort(a).tolist()])
+print(json.dumps(out))
+"""
+
+
+def test_numpy_default_argsort_restated_in_library_and_oracle(hiplib, oracle):
+    """dg.py:31 `np.argsort(score)[-2:]` uses numpy's default, UNSTABLE kind; its tie order decides dg's partition (every
+    first assignment ties). The library (pg_np_argsort_f64) and the oracle (numpy_scalar_argsort) restate numpy's scalar
+    introsort; both must reproduce numpy itself — run in a child process with numpy's SIMD dispatch disabled (on AVX2 /
+    AVX-512 hosts numpy otherwise routes the call to x86-simd-sort, whose tie order differs) — on tie-heavy inputs of
+    every length up to 127 partitions."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, NPY_DISABLE_CPU_FEATURES="AVX2 AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL")
+    r = subprocess.run([sys.executable, "-c", _NP_ARGSORT_PROBE, "11", "1500"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cases = json.loads(r.stdout)
+    assert len(cases) == 1500
+    unstable = 0
+    for vals, want in cases:
+        a = np.asarray(vals, np.float64)
+        order = np.empty(len(a), np.int32)
+        assert hiplib.pg_np_argsort_f64(a.ctypes.data, len(a), order.ctypes.data) == 0
+        assert order.tolist() == want, (len(a), vals)
+        assert oracle.numpy_scalar_argsort(a).tolist() == want
+        unstable += int(want != np.argsort(a, kind="stable").tolist())
+    assert unstable > 100           # the probe really left the stable regime (n > 16 with ties)
 
 
 def test_partition_file_roundtrip(tmp_path):
