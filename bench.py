@@ -39,7 +39,8 @@ def pmc_traffic(kernel="k_gather"):
     MI355X_MICROARCH.md §HBM). bench.py cannot collect PMC counters itself; None when absent. The figure belongs
     to the default workload (10M/100M GCN, 30 % cache): other workloads get None."""
     import glob
-    name = {"k_gather": "pmc_gather_inloop.json", "k_spmm_fwd_rows": "pmc_spmm_fwd_rows_inloop.json"}[kernel]
+    name = {"k_gather": "pmc_gather_inloop.json", "k_spmm_fwd_rows": "pmc_spmm_fwd_rows_inloop.json",
+            "k_agg_linear_fwd": "pmc_agg_linear_fwd_inloop.json"}[kernel]
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)))
     if not files:
         return None, None
@@ -1051,8 +1052,14 @@ def run():
             # written (4 F) + its indptr entry (4). Rows that miss are read from the staged block instead of the cache
             # (same bytes). Padding destinations of the fixed-shape block write zeros: not counted.
             f_bytes = edges * (4 * Fw + 8) + n_dst * (4 * Fw + 4)
+            from pagraph_amd import ops as _ops
+            with_dense = args.model == "gcn" and _ops.FUSE_AGG_LINEAR
+            if with_dense:
+                # + the NodeUpdate the kernel absorbed (pg_agg_linear_fwd): its output [z | relu z] written per destination
+                # (2 x hidden floats), the weight and bias read once
+                f_bytes += n_dst * 4 * 2 * hidden + 4 * (Fw * hidden + hidden)
             dur = np.sort(slot[st[:, 3] > st[:, 1]] if has_succ else (st[:, 1] - st[:, 0]).astype(np.float64) / 1e5)
-            fused_rec = {"kernel": "k_spmm_fwd_rows", "achieved": f_bytes / f_ms / 1e6, "frac": f_bytes / f_ms / 1e6 / HBM_PEAK_GBPS,
+            fused_rec = {"kernel": "k_agg_linear_fwd" if with_dense else "k_spmm_fwd_rows", "achieved": f_bytes / f_ms / 1e6, "frac": f_bytes / f_ms / 1e6 / HBM_PEAK_GBPS,
                          "avg_launch_ms": f_ms, "launches_timed": int(len(st)),
                          "launch_ms_min_median_p90_max": [float(dur[0]), float(dur[len(dur) // 2]), float(dur[int(len(dur) * 0.9)]),
                                                           float(dur[-1])], "edges_per_launch": edges,
@@ -1065,7 +1072,7 @@ def run():
                                     "wave's start -> last block's end (every block stamps)") if has_succ else
                                    "device wall-clock stamps written by the kernel itself (first wave's start, last block's "
                                    "end): no dependent dense / head launch followed it"}
-    traffic, traffic_src = pmc_traffic("k_spmm_fwd_rows" if fused_rec else "k_gather")
+    traffic, traffic_src = pmc_traffic(fused_rec["kernel"] if fused_rec else "k_gather")
     default_workload = (V, E, Fdim, B, k, args.model, args.cache_ratio) == (10_000_000, 100_000_000, 600, 6000, 2, "gcn", 0.30)
     if not default_workload or world > 1:
         traffic, traffic_src = None, "no PMC pass committed for this workload"

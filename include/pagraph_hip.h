@@ -497,6 +497,18 @@ int pg_spmm_bwd_gather_max(const int32_t* tptr, const int32_t* tdst, const float
  * Returns PG_ERR_UNSUPPORTED outside that envelope (callers then use the library GEMM).            */
 int pg_linear_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, float* Y,
                   int32_t y_stride, int64_t n, int32_t K, int32_t N, int32_t act, pg_stream_t stream);
+/* Layer 0's aggregation AND its NodeUpdate in one kernel (round 4): agg = pg_spmm_fwd_rows(indptr, src, rows, ...) —
+ * fetch_data fused into block_compute's reduce, storage.py:176-204 + gcn_nssc.py:66-74 — and Y = pg_linear_fwd(agg, W, bias,
+ * act) — NodeUpdate.forward, gcn_nssc.py:14-24 — without the round trip of agg through memory between two launches: the
+ * dense kernel's operand fetch IS the aggregation. Same arithmetic in the same order as that pair: agg (written once, the
+ * weight gradient reads it) and Y are bit-identical to it. Envelope: the intersection of the two (K >= 256, rows of whole
+ * 16-byte pieces, N <= 64, PG_REDUCE_MEAN | PG_REDUCE_SUM), else PG_ERR_UNSUPPORTED and the caller runs the pair. Fastest
+ * when no destination has more than two in-edges (the sampler's fan-out of pa_gcn.py:146-147); correct for any degree.
+ * prof / prof_ring: as pg_spmm_fwd_rows.                                                                  */
+int pg_agg_linear_fwd(const int32_t* indptr, const int32_t* src, const pg_row_source_t* rows, int64_t n_dst, int32_t K,
+                      int reduce, const pg_dropout_t* drop, const float* W, const float* bias, int32_t N, int32_t act,
+                      float* agg, int32_t agg_stride, float* Y, int32_t y_stride, uint64_t* prof, int32_t prof_ring,
+                      pg_stream_t stream);
 /* GraphSAGE's NodeUpdate, `fc_self(h) + fc_neigh(neigh)` then the activation (graphsage_nssc.py:24-29), in one
  * pass: Z = X W^T + bias + X2 W2^T + bias2 (W [N,K], W2 [N,K2]; same envelope for both operand pairs).      */
 int pg_linear2_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, int32_t K,

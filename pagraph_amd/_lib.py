@@ -137,6 +137,8 @@ _SIGS = {
     "pg_spmm_bwd_gather_max": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, vp, c_i32, vp, c_i32, vp, c_i32, vp, c_i32, vp,
                                               vp, vp]),
     "pg_linear_fwd": (ctypes.c_int, [vp, c_i32, vp, vp, vp, c_i32, c_i64, c_i32, c_i32, c_i32, vp]),
+    "pg_agg_linear_fwd": (ctypes.c_int, [vp, vp, ctypes.POINTER(PgRowSource), c_i64, c_i32, ctypes.c_int, vp, vp, vp, c_i32, c_i32,
+                                         vp, c_i32, vp, c_i32, vp, c_i32, vp]),
     "pg_linear2_fwd": (ctypes.c_int, [vp, c_i32, vp, vp, c_i32, vp, c_i32, vp, vp, c_i32, vp, c_i32, c_i64, c_i32, c_i32, vp]),
     "pg_linear_bwd_w_scratch": (c_i64, [c_i64, c_i32, c_i32]),
     "pg_linear_bwd_w": (ctypes.c_int, [vp, c_i32, vp, c_i32, c_i64, c_i32, c_i32, vp, vp, vp, c_i32, c_i32, vp, vp, vp]),

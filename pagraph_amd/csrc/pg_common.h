@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "../../include/pagraph_hip.h"
 
 // a pair of HIP events (pg_timer_*): either recorded around a launch (pg_timer_start / _stop) or attached
@@ -126,6 +129,71 @@ struct Philox {
     out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
   }
 };
+
+// ---- the model's dropout folded into the kernels that consume its output (mask spec: pg_spmm.hip, include/pagraph_hip.h) ----
+struct DropArgs {
+  uint32_t thr, tag, k0, k1;
+  const uint64_t* step;
+  float scale;
+};
+
+__device__ __forceinline__ float4 drop_apply(float4 x, const uint32_t (&o)[4], int half, uint32_t thr, float scale) {
+  const uint32_t w0 = half ? o[2] : o[0], w1 = half ? o[3] : o[1];
+  x.x = (w0 & 0xffffu) >= thr ? x.x * scale : 0.f;
+  x.y = (w0 >> 16) >= thr ? x.y * scale : 0.f;
+  x.z = (w1 & 0xffffu) >= thr ? x.z * scale : 0.f;
+  x.w = (w1 >> 16) >= thr ? x.w * scale : 0.f;
+  return x;
+}
+
+
+inline bool drop_args(const pg_dropout_t* dp, DropArgs* d) {
+  if (!dp || dp->threshold == 0 || dp->threshold > 65535u) return false;
+  d->thr = dp->threshold;
+  d->tag = dp->tag;
+  d->k0 = (uint32_t)dp->seed;
+  d->k1 = (uint32_t)(dp->seed >> 32);
+  d->step = dp->step;
+  d->scale = 65536.f / (float)(65536u - dp->threshold);
+  return true;
+}
+
+
+// How the aggregated row leaves the CU (store_mode is wave-uniform: a scalar branch around three stores).
+//   PG_STORE_PLAIN: write-back — the 23 MB of `out` a launch produces sit dirty in the XCDs' L2s until the kernel's closing
+//                   release writes them back, AFTER the last wave has retired: time the kernel's own stamps do not see but
+//                   the dispatch (rocprofv3's End, and the successor's start) pays (profiles/r04).
+//   PG_STORE_NT:    non-temporal hint (still write-back).
+//   PG_STORE_WT:    `sc0 sc1` write-through: every piece goes to memory while the row loads of other waves stream, nothing is
+//                   left dirty for the kernel's end; the consumer (another launch, usually on another XCD) reads from
+//                   memory / MALL either way.
+enum { PG_STORE_PLAIN = 0, PG_STORE_NT = 1, PG_STORE_WT = 2 };
+typedef float pg_f4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void store_row_piece(float4* p, const float4& v, int mode) {
+  if (mode == PG_STORE_WT) {
+    pg_f4v t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(t) : "memory");
+  } else if (mode == PG_STORE_NT) {
+    pg_f4v t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<pg_f4v*>(p));
+  } else {
+    *p = v;
+  }
+}
+
+
+// PG_FWD_ROWS_STORE = plain | nt | wt: how k_spmm_fwd_rows_w writes `out` (see store_row_piece). Default wt (round 4):
+// dispatch End - Start in the training loop 20.5 (plain) / 19.2 (wt) / 21.5 (nt) us, alone on cold rows 16.1 / 15.2 / 15.0,
+// profiles/r04/fused_store_modes.txt.
+inline int fwd_rows_store_mode() {
+  const char* e = getenv("PG_FWD_ROWS_STORE");
+  if (!e) return PG_STORE_WT;
+  if (!strcmp(e, "wt")) return PG_STORE_WT;
+  if (!strcmp(e, "nt")) return PG_STORE_NT;
+  return PG_STORE_PLAIN;
+}
+
 
 // uniform integer in [0, n) from a 64-bit draw: floor(r * n / 2^64)
 __host__ __device__ inline uint64_t bounded(uint64_t r, uint64_t n) {

@@ -298,6 +298,315 @@ __global__ __launch_bounds__(NW * 64) void k_linear_fwd(const float* __restrict_
   }
 }
 
+// ---- layer 0's aggregation AND its NodeUpdate in one kernel (round 4; gcn_nssc.py:64-74 + :14-24 over storage.py:176-204) ---
+// k_linear_fwd<..., ROWS> whose "fetch a row" is "aggregate a destination": the A operand of tile row r is
+//   agg[r, :] = reduce over r's in-edges of dropout(row(src[e]))      (row(p) = the cache / the staged miss block, pg_row_source_t)
+// computed piece by piece where the dense step consumes it, and written out once (the weight gradient needs agg again).
+// What k_spmm_fwd_rows_w + k_linear_fwd did in two launches with a 29 MB round trip through memory between them. Same
+// arithmetic in the same order as that pair — per piece: 0 + drop(x_0) + drop(x_1) ... in edge order, / degree; per output:
+// the K range split over the same NW waves, octet by octet through the same MFMA sequence, the waves' partial tiles added
+// in wave order, + bias — so agg AND Y are bit-identical to the two-kernel path (tests/test_gpu_parity.py).
+// Wave w owns octets [o_beg, o_end) of K for all 32 destinations of the tile: per slab (4 octets) a lane fetches the pieces
+// of 4 destinations x their first DEG in-edges (8 x 16-byte loads in flight; the rows' addresses are resolved once, before
+// the K loop), applies the dropout mask (one Philox call per piece and edge), sums, scales, stores the piece to `agg`
+// (write-through) and to the wave's LDS slab, and runs the slab's MFMAs. Destinations with more than DEG in-edges take a
+// slower loop for the rest (correct for any degree; the sampler's fan-out is 2).
+struct AggArgs {
+  const int32_t* indptr;
+  const int32_t* src;
+  const int32_t* slots;
+  const int32_t* edge_slots;   // optional: slots[src[e]] per edge
+  const float* cache;
+  const float* staged;
+  int32_t cache_stride, staged_stride;
+  int32_t reduce;              // PG_REDUCE_MEAN | PG_REDUCE_SUM
+  float* agg;
+  int32_t agg_stride, store_mode;
+  DropArgs d;                  // d.thr == 0: no dropout
+  unsigned long long* prof;
+  int32_t prof_ring;
+};
+
+constexpr int kAggDeg = 2;
+
+struct AggRow {                // one destination of the tile (32 bytes; the block keeps the tile's 32 in LDS)
+  const float* ptr[kAggDeg];   // its first kAggDeg source rows (nullptr: padding / unresolved: contributes nothing)
+  int32_t pos[kAggDeg];        // their positions in the source layer (the dropout mask's row index)
+  int32_t beg, deg;
+};
+static_assert(sizeof(AggRow) == 32, "AggRow is read back from LDS as two 16-byte pieces");
+
+__device__ __forceinline__ const float* agg_row_ptr(const AggArgs& g, int32_t e, int32_t* pos) {
+  const int32_t p = g.src[e];
+  *pos = p;
+  const int32_t sl = g.edge_slots ? g.edge_slots[e] : g.slots[p];
+  if (sl >= 0) return g.cache + (int64_t)sl * g.cache_stride;
+  if (sl <= -3) return g.staged + (int64_t)(-(sl + 3)) * g.staged_stride;
+  return nullptr;
+}
+
+__device__ __forceinline__ AggRow agg_row_of(const AggArgs& g, int64_t r, int64_t n) {
+  AggRow a;
+  a.beg = 0; a.deg = 0;
+#pragma unroll
+  for (int e = 0; e < kAggDeg; ++e) { a.ptr[e] = nullptr; a.pos[e] = 0; }
+  if (r < n) {
+    a.beg = g.indptr[r];
+    a.deg = g.indptr[r + 1] - a.beg;
+#pragma unroll
+    for (int e = 0; e < kAggDeg; ++e)
+      if (e < a.deg) a.ptr[e] = agg_row_ptr(g, a.beg + e, &a.pos[e]);
+  }
+  return a;
+}
+
+// one 16-byte piece of a source row through the dropout mask (k_spmm_fwd_rows' drop_apply) and the ragged-K mask
+template <bool DROP>
+__device__ __forceinline__ df4 agg_term(const AggArgs& g, df4 x, int32_t pos, int c, int left, uint32_t step) {
+  if constexpr (DROP) {
+    uint32_t o[4];
+    Philox::gen((uint32_t)pos, (uint32_t)(((c >> 7) << 6) | (c & 63)), g.d.tag, step, g.d.k0, g.d.k1, o);
+    const float4 y = drop_apply(make_float4(x.x, x.y, x.z, x.w), o, (c >> 6) & 1, g.d.thr, g.d.scale);
+    x = df4{y.x, y.y, y.z, y.w};
+  }
+  if (left < 4) {               // columns past K (the next field of the fused cache row / padding) are never summed
+    if (left < 2) x.y = 0.f;
+    if (left < 3) x.z = 0.f;
+    x.w = 0.f;
+  }
+  return x;
+}
+
+// finish a piece: the in-edges beyond the first kAggDeg (any degree stays correct), then the mean's division
+template <bool DROP>
+__device__ __forceinline__ df4 agg_finish(const AggArgs& g, df4 acc, const AggRow& a, int kc, int left, uint32_t step) {
+  for (int32_t e = kAggDeg; e < a.deg; ++e) {
+    int32_t pos;
+    const float* rp = agg_row_ptr(g, a.beg + e, &pos);
+    if (rp) {
+      const df4 t = agg_term<DROP>(g, *reinterpret_cast<const df4*>(rp + kc), pos, kc >> 2, left, step);
+      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+  }
+  if (g.reduce == PG_REDUCE_MEAN && a.deg > 0) {
+    const float dg = (float)a.deg;
+    acc.x /= dg; acc.y /= dg; acc.z /= dg; acc.w /= dg;
+  }
+  return acc;
+}
+
+__device__ __forceinline__ void agg_store(const AggArgs& g, int64_t r, int kc, const df4& v) {
+  store_row_piece(reinterpret_cast<float4*>(g.agg + r * g.agg_stride + kc), make_float4(v.x, v.y, v.z, v.w), g.store_mode);
+}
+
+template <int WV, int NW, bool DROP>
+__global__ __launch_bounds__(NW * 64, NW / 2) void k_agg_linear_fwd(const AggArgs g, const float* __restrict__ W /* [N][K] */,
+                                                        const float* __restrict__ bias, float* __restrict__ Y,
+                                                        int32_t y_stride, int64_t n, int32_t K, int32_t N, int32_t act) {
+  __shared__ __attribute__((aligned(16))) float smem[NW * kTile * kXsStride * (WV == 4 ? 2 : 1)];
+  __shared__ __attribute__((aligned(16))) AggRow s_rows[kTile];     // the tile's destinations, resolved once per block
+  float (*red)[kTile][kXsStride] = reinterpret_cast<float (*)[kTile][kXsStride]>(smem);
+  const uint32_t step = g.d.step ? (uint32_t)*g.d.step : 0u;
+  unsigned long long* pslot = prof_begin(g.prof, g.prof_ring, step, g.prof ? (unsigned long long)g.indptr[n] : 0ull);
+  if (threadIdx.x < kTile) s_rows[threadIdx.x] = agg_row_of(g, (int64_t)blockIdx.x * kTile + threadIdx.x, n);
+  __syncthreads();
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+  const int64_t r0 = (int64_t)blockIdx.x * kTile;
+  const int n0 = (int)blockIdx.y * kTile;
+  const int64_t row = r0 + (lane & 31);
+  const int half = lane >> 5;
+  const int octets = (K + 7) / 8;
+  const int o_beg = (octets * w) / NW, o_end = (octets * (w + 1)) / NW;
+  const bool row_ok = row < n;
+  const int col = n0 + (lane & 31);
+  const bool col_ok = col < N;
+  // blockIdx.y > 0 (N > 32): the second column tile recomputes the aggregation for its MFMAs but leaves the stores of
+  // `agg` to the first
+  const bool writer = blockIdx.y == 0;
+  // (per slab a lane fetches the pieces of four destinations: rows (lane >> 3) + 8 i of the tile, segment lane & 7)
+  const float* wr = W + (int64_t)(col_ok ? col : 0) * K + 4 * half;
+  f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  auto mma = [&](const df4& a, const df4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  };
+  auto load_w = [&](int o, df4& b) {                 // k_linear_fwd's load1, W side
+    const int left = K - (o * 8 + 4 * half);
+    b = df4{0.f, 0.f, 0.f, 0.f};
+    if (left <= 0 || !col_ok) return;
+    if (WV == 4) {
+      b = *reinterpret_cast<const df4*>(wr + o * 8);
+    } else if (WV == 2) {
+      const df2 lo = *reinterpret_cast<const df2*>(wr + o * 8);
+      b.x = lo.x; b.y = lo.y;
+      if (left > 2) {
+        const df2 hi = *reinterpret_cast<const df2*>(wr + o * 8 + 2);
+        b.z = hi.x; b.w = hi.y;
+      }
+    } else {
+      b.x = wr[o * 8];
+      if (left > 1) b.y = wr[o * 8 + 1];
+      if (left > 2) b.z = wr[o * 8 + 2];
+      if (left > 3) b.w = wr[o * 8 + 3];
+    }
+    if (left < 4) {
+      if (left < 2) b.y = 0.f;
+      if (left < 3) b.z = 0.f;
+      b.w = 0.f;
+    }
+  };
+  int o = o_beg;
+  float* xs = smem + (size_t)w * kTile * kXsStride;
+  for (; o + 3 < o_end; o += 4) {
+    const int kbase = o * 8;
+    const int kc = kbase + (lane & 7) * 4;           // this lane's piece of the slab, the same for its four destinations
+    const int left = K - kc;
+    df4 x[4][kAggDeg];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const AggRow& ar = s_rows[(lane >> 3) + 8 * i];
+#pragma unroll
+      for (int e = 0; e < kAggDeg; ++e) {
+        x[i][e] = df4{0.f, 0.f, 0.f, 0.f};
+        const float* rp = ar.ptr[e];
+        if (left > 0 && rp) x[i][e] = *reinterpret_cast<const df4*>(rp + kc);
+      }
+    }
+    df4 b0, b1, b2, b3;
+    df4 u[4];
+    if constexpr (WV == 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i, cc = n0 + (c >> 3), kw = kbase + (c & 7) * 4;
+        u[i] = df4{0.f, 0.f, 0.f, 0.f};
+        if (cc < N && kw < K) u[i] = *reinterpret_cast<const df4*>(W + (int64_t)cc * K + kw);
+      }
+    } else {
+      load_w(o, b0);
+      load_w(o + 1, b1);
+      load_w(o + 2, b2);
+      load_w(o + 3, b3);
+    }
+    asm volatile("" ::: "memory");                   // every load of the slab is issued before the first Philox round
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (WV == 4) {                          // W's slab goes to LDS first: its registers are free for the draws
+      float* ws = smem + (size_t)(NW + w) * kTile * kXsStride;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        *reinterpret_cast<df4*>(ws + (c >> 3) * kXsStride + (c & 7) * 4) = u[i];
+      }
+    }
+    // one destination at a time (scheduling barriers keep the four Philox groups from being interleaved: unrolled and
+    // interleaved they took 224 VGPRs, one 8-wave block per CU instead of two)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_barrier(0);
+      df4 a = df4{0.f, 0.f, 0.f, 0.f};
+      if (left > 0) {
+        const AggRow ar = s_rows[(lane >> 3) + 8 * i];
+#pragma unroll
+        for (int e = 0; e < kAggDeg; ++e)
+          if (ar.ptr[e]) {
+            const df4 t = agg_term<DROP>(g, x[i][e], ar.pos[e], kc >> 2, left, step);
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+          }
+        a = agg_finish<DROP>(g, a, ar, kc, left, step);
+        const int64_t r = r0 + (lane >> 3) + 8 * i;
+        if (writer && r < n) agg_store(g, r, kc, a);
+      }
+      const int c = lane + 64 * i;
+      *reinterpret_cast<df4*>(xs + (c >> 3) * kXsStride + (c & 7) * 4) = a;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if constexpr (WV == 4) {
+      const float* wa = smem + (size_t)(NW + w) * kTile * kXsStride + (lane & 31) * kXsStride + 4 * half;
+      b0 = *reinterpret_cast<const df4*>(wa);
+      b1 = *reinterpret_cast<const df4*>(wa + 8);
+      b2 = *reinterpret_cast<const df4*>(wa + 16);
+      b3 = *reinterpret_cast<const df4*>(wa + 24);
+    }
+    const float* xa = xs + (lane & 31) * kXsStride + 4 * half;
+    const df4 a0 = *reinterpret_cast<const df4*>(xa);
+    const df4 a1 = *reinterpret_cast<const df4*>(xa + 8);
+    const df4 a2 = *reinterpret_cast<const df4*>(xa + 16);
+    const df4 a3 = *reinterpret_cast<const df4*>(xa + 24);
+    mma(a0, b0);
+    mma(a1, b1);
+    mma(a2, b2);
+    mma(a3, b3);
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (o < o_end) {
+    // the wave's last 1-3 octets: lane (row, half) aggregates the 16-byte piece of ITS destination
+    const AggRow me = s_rows[lane & 31];
+    for (; o < o_end; ++o) {
+      const int kc = o * 8 + 4 * half;
+      const int left = K - kc;
+      df4 a = df4{0.f, 0.f, 0.f, 0.f}, b;
+      df4 xe[kAggDeg];
+#pragma unroll
+      for (int e = 0; e < kAggDeg; ++e) {
+        xe[e] = df4{0.f, 0.f, 0.f, 0.f};
+        if (left > 0 && me.ptr[e]) xe[e] = *reinterpret_cast<const df4*>(me.ptr[e] + kc);
+      }
+      load_w(o, b);
+      if (left > 0) {
+#pragma unroll
+        for (int e = 0; e < kAggDeg; ++e)
+          if (me.ptr[e]) {
+            const df4 t = agg_term<DROP>(g, xe[e], me.pos[e], kc >> 2, left, step);
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+          }
+        a = agg_finish<DROP>(g, a, me, kc, left, step);
+        if (writer && row_ok) agg_store(g, row, kc, a);
+      }
+      if (!row_ok) a = df4{0.f, 0.f, 0.f, 0.f};
+      mma(a, b);
+    }
+  }
+  // C layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)   (the epilogue of k_linear_fwd)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[w][(r & 3) + 8 * (r >> 2) + 4 * half][lane & 31] = acc[r];
+  __syncthreads();
+  const int orow = threadIdx.x >> 3, oc = (threadIdx.x & 7) * 4;
+  if (threadIdx.x < 256 && r0 + orow < n) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = red[0][orow][oc + j] + red[1][orow][oc + j] + red[2][orow][oc + j] + red[3][orow][oc + j];
+#pragma unroll
+      for (int ww = 4; ww < NW; ++ww) v[j] += red[ww][orow][oc + j];
+      if (bias && n0 + oc + j < N) v[j] += bias[n0 + oc + j];
+    }
+    float* yr = Y + (r0 + orow) * y_stride + n0 + oc;
+    const bool vec_ok = (N & 3) == 0 && (y_stride & 3) == 0 && n0 + oc + 3 < N;
+    if (act == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+    }
+    if (vec_ok) {
+      *reinterpret_cast<df4*>(yr) = df4{v[0], v[1], v[2], v[3]};
+      if (act == 2)
+        *reinterpret_cast<df4*>(yr + N) = df4{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f,
+                                              v[2] > 0.f ? v[2] : 0.f, v[3] > 0.f ? v[3] : 0.f};
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n0 + oc + j < N) {
+          yr[j] = v[j];
+          if (act == 2) yr[N + j] = v[j] > 0.f ? v[j] : 0.f;
+        }
+    }
+  }
+  prof_end(pslot);
+}
+
 // gradient of the pre-activation z w.r.t. the loss, from the gradient G of the (activated) output and the
 // saved output Yout: act 0: G; act 1 (relu): G * (Yout > 0); act 2 (concat): G[:, :N] + G[:, N:] * (Yout[:, :N] > 0)
 __device__ __forceinline__ float dz_at(const float* __restrict__ G, int32_t g_stride, const float* __restrict__ Yout,
@@ -566,6 +875,64 @@ int pg_linear2_fwd(const float* X, int32_t x_stride, const float* W, const float
                    int64_t n, int32_t N, int32_t act, pg_stream_t stream) {
   if (K2 <= 0) return PG_ERR_INVALID;
   return linear_fwd(X, x_stride, W, bias, X2, x2_stride, W2, bias2, K2, Y, y_stride, n, K, N, act, stream);
+}
+
+int pg_agg_linear_fwd(const int32_t* indptr, const int32_t* src, const pg_row_source_t* rows, int64_t n_dst, int32_t K,
+                      int reduce, const pg_dropout_t* drop, const float* W, const float* bias, int32_t N, int32_t act,
+                      float* agg, int32_t agg_stride, float* Y, int32_t y_stride, uint64_t* prof, int32_t prof_ring,
+                      pg_stream_t stream) {
+  if (!rows || n_dst < 0 || K <= 0 || N <= 0 || act < 0 || act > 2 || y_stride < (act == 2 ? 2 * N : N)) return PG_ERR_INVALID;
+  if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return reduce == PG_REDUCE_MAX ? PG_ERR_UNSUPPORTED : PG_ERR_INVALID;
+  if (drop && drop->threshold > 65535u) return PG_ERR_INVALID;
+  if (prof && prof_ring <= 0) return PG_ERR_INVALID;
+  const int32_t k4 = (K + 3) & ~3;
+  // the envelope of pg_spmm_fwd_rows (wide rows of whole 16-byte pieces) and of pg_linear_fwd (N <= 64); K >= 256 is also
+  // what makes the dense kernel split K over 8 waves, the split this kernel reproduces
+  if (K < 256 || N > 2 * kTile || agg_stride < k4 || (agg_stride & 3) || (reinterpret_cast<uintptr_t>(agg) & 15))
+    return PG_ERR_UNSUPPORTED;
+  if (rows->cache && (rows->cache_stride < k4 || (rows->cache_stride & 3) || (reinterpret_cast<uintptr_t>(rows->cache) & 15)))
+    return PG_ERR_UNSUPPORTED;
+  if (rows->staged && (rows->staged_stride < k4 || (rows->staged_stride & 3) || (reinterpret_cast<uintptr_t>(rows->staged) & 15)))
+    return PG_ERR_UNSUPPORTED;
+  if (n_dst == 0) return PG_OK;
+  if (!indptr || !src || !rows->slots || !W || !agg || !Y) return PG_ERR_INVALID;
+  AggArgs g{};
+  g.indptr = indptr; g.src = src; g.slots = rows->slots; g.edge_slots = rows->edge_slots;
+  g.cache = rows->cache; g.staged = rows->staged;
+  g.cache_stride = rows->cache_stride; g.staged_stride = rows->staged_stride;
+  g.reduce = reduce; g.agg = agg; g.agg_stride = agg_stride;
+  static const int store_mode = fwd_rows_store_mode();
+  g.store_mode = store_mode;
+  const bool has_drop = drop_args(drop, &g.d);
+  if (!has_drop) {
+    g.d = DropArgs{};
+    if (drop) g.d.step = drop->step;                  // the profiling ring is indexed by the caller's step counter
+  }
+  g.prof = reinterpret_cast<unsigned long long*>(prof);
+  g.prof_ring = prof_ring;
+  const uintptr_t wa = reinterpret_cast<uintptr_t>(W);
+  const int wv = (K % 4 == 0 && !(wa & 15)) ? 4 : ((K % 2 == 0 && !(wa & 7)) ? 2 : 1);
+  const dim3 grid((unsigned)ceil_div<int64_t>(n_dst, kTile), (unsigned)ceil_div<int>(N, kTile));
+#define PG_AGG_LIN(WV)                                                                                                 \
+  do {                                                                                                                 \
+    if (has_drop)                                                                                                      \
+      hipLaunchKernelGGL((k_agg_linear_fwd<WV, 8, true>), grid, dim3(512), 0, as_stream(stream), g, W, bias, Y, y_stride, \
+                         n_dst, K, N, act);                                                                            \
+    else                                                                                                               \
+      hipLaunchKernelGGL((k_agg_linear_fwd<WV, 8, false>), grid, dim3(512), 0, as_stream(stream), g, W, bias, Y,       \
+                         y_stride, n_dst, K, N, act);                                                                  \
+  } while (0)
+  if (wv == 4) PG_AGG_LIN(4);
+  else if (wv == 2) PG_AGG_LIN(2);
+  else PG_AGG_LIN(1);
+#undef PG_AGG_LIN
+  PG_LAUNCH_CHECK();
+  if (g.prof) {                 // the next dense / head launch of this thread stamps this entry's word [1]
+    g_prof_succ.ring = g.prof;
+    g_prof_succ.ring_len = prof_ring;
+    g_prof_succ.step = g.d.step;
+  }
+  return PG_OK;
 }
 
 /* out[j] = sum over chunks of part[c][j] (chunk order), j < nk -> dW[j], nk <= j < nk + N -> db[j - nk] */

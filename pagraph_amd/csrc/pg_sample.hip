@@ -550,6 +550,11 @@ __global__ __launch_bounds__(256) void k_sx(const SampleGArgs s, const RelabelXA
 struct RankArgs {
   const unsigned long long* bm;
   unsigned long long* other_bm;   // zeroed here: the next S marks into it
+  // how: every word (a V/8-byte store per layer: 1 MB at 8.5 M vertices), or — clear_ids set — only the words of the ids
+  // that were marked there, i.e. the layer the PREVIOUS rank launch emitted (<= a few 10^4 scattered stores whatever V is)
+  const int64_t* clear_ids;
+  const int32_t* clear_cnt;
+  int64_t clear_cap;
   int64_t n_words;
   int32_t m;                      // the block covers 1024 * m words, 4 per thread and round
   unsigned long long* agg;
@@ -568,13 +573,20 @@ __global__ __launch_bounds__(256) void k_bm_rank(const RankArgs a) {
   const int64_t wblk = (int64_t)blk * kWordsPerBlock * a.m;
   unsigned long long w[4] = {0ull, 0ull, 0ull, 0ull};
   int mine = 0;
+  const bool clear_all = a.clear_ids == nullptr;
+  if (!clear_all) {
+    int64_t n = *a.clear_cnt;
+    if (n > a.clear_cap) n = a.clear_cap;
+    for (int64_t i = (int64_t)blk * blockDim.x + tid; i < n; i += (int64_t)gridDim.x * blockDim.x)
+      a.other_bm[a.clear_ids[i] >> 6] = 0ull;
+  }
   for (int r = 0; r < a.m; ++r) {
     const int64_t w0 = wblk + (int64_t)r * kWordsPerBlock + tid * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       w[i] = (w0 + i < a.n_words) ? a.bm[w0 + i] : 0ull;
       mine += __popcll(w[i]);
-      if (w0 + i < a.n_words) a.other_bm[w0 + i] = 0ull;
+      if (clear_all && w0 + i < a.n_words) a.other_bm[w0 + i] = 0ull;
     }
   }
   int tot;
@@ -839,6 +851,7 @@ struct pg_sampler {
   uint64_t rank_launches = 0;        // picks of launch i are marked in bitmap (i & 1); its R zeroes the other one
   int max_lookback = kMaxLookback;   // blocks per S / R launch
   int rank_m = 1, rank_blocks = 1;   // k_bm_rank: rounds per block, blocks (<= max_lookback)
+  bool clear_by_ids = false;         // k_bm_rank clears the other bitmap through the previous layer's id list (large V)
   int64_t V = 0;
   const int64_t* indptr = nullptr;
   const int32_t* indices = nullptr;
@@ -933,6 +946,17 @@ int pg_sampler_create(int64_t V, const int64_t* indptr, const int32_t* indices, 
   if (const char* e = getenv("PG_SAMPLER_LOOKBACK")) {
     const int v = atoi(e);
     if (v >= 1 && v <= kMaxLookback) s->max_lookback = v;
+  }
+  // The rank launch zeroes the bitmap the next S marks into. Every word of it — a V/8-byte store per layer, fine at 8.5 M
+  // vertices (1 MB) — or, from PG_SAMPLER_CLEAR_IDS_ABOVE bitmap words on (default 2^20 words = 64 M vertices; 0 = always),
+  // only the words of the ids that were marked there: at 10^9 vertices the full clear alone is 125 MB of stores per layer,
+  // as much HBM traffic as a whole training step, on a stream that runs beside the step's HBM-bound kernel.
+  // The id list is the layer the previous rank launch emitted; with one hop that is the buffer this launch rewrites, so a
+  // one-hop sampler keeps the full clear.
+  {
+    int64_t above = (int64_t)1 << 20;
+    if (const char* e = getenv("PG_SAMPLER_CLEAR_IDS_ABOVE")) above = atoll(e);
+    s->clear_by_ids = s->hops >= 2 && s->n_words > above;
   }
   s->rank_m = (int)ceil_div<int64_t>(s->n_words, (int64_t)kWordsPerBlock * s->max_lookback);
   if (s->rank_m < 1) s->rank_m = 1;
@@ -1166,6 +1190,13 @@ static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t
     if (b < 0) break;
     RankArgs r{};
     r.bm = bm; r.other_bm = other; r.n_words = s->n_words;
+    if (s->clear_by_ids) {
+      // `other` holds the marks of the previous rank launch's layer: layer b + 1 of this call, or — for the first rank
+      // launch of a call — layer 0 of the previous call (its ids and count are still in place: this call has not emitted
+      // layer 0 yet; before the very first call the count is 0 and the bitmap clean)
+      const int lp = b + 1 < L ? b + 1 : 0;
+      r.clear_ids = s->layer_ids[lp]; r.clear_cnt = lcnt + lp; r.clear_cap = s->cap[lp];
+    }
     r.m = s->rank_m;
     r.agg = s->agg; r.tag = ++s->tag ? s->tag : ++s->tag; r.err = s->err;
     r.out_ids = s->layer_ids[b]; r.cap = s->cap[b]; r.word_rank = s->word_rank; r.count_out = lcnt + b;

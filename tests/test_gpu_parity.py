@@ -234,15 +234,20 @@ def test_sampler_vs_oracle_bit_exact(dev, hiplib, oracle, V, E, B, k, hops):
         assert nb >= 1 and b == len(smp) - 1
 
 
+@pytest.mark.parametrize("clear_by_ids", [False, True])
 @pytest.mark.parametrize("V,E,B,k,hops,lookback", [(70000, 400000, 700, 2, 2, 3), (70000, 400000, 300, 3, 3, 2),
                                                     (5000, 60000, 900, 33, 1, 7), (140000, 300000, 2000, 2, 2, 1)])
-def test_sampler_multi_round_lookback_paths(dev, hiplib, oracle, monkeypatch, V, E, B, k, hops, lookback):
+def test_sampler_multi_round_lookback_paths(dev, hiplib, oracle, monkeypatch, V, E, B, k, hops, lookback, clear_by_ids):
     """the five-launch chain's decoupled look-backs with the per-launch block limit shrunk (PG_SAMPLER_LOOKBACK, read at
     sampler creation): a group samples several destinations (iters > 1) and a rank block makes several rounds over its
     bitmap words (m > 1) — the shapes a 2^31-vertex graph or a 64-wide fan-out over a large batch takes with the real
-    limit of 1024 blocks. Static (fixed-shape, -1 padding) and DGL layouts, bit-exact vs the oracle."""
+    limit of 1024 blocks. Static (fixed-shape, -1 padding) and DGL layouts, bit-exact vs the oracle.
+    clear_by_ids: the rank launch clears the other bitmap through the previous layer's id list instead of word by word (what
+    samplers over more than 64 M vertices do: PG_SAMPLER_CLEAR_IDS_ABOVE) — every batch of the pass is checked then, a mark
+    left behind would show up as a foreign vertex in a later batch's layers."""
     from pagraph_amd.sampling import DeviceGraph, NeighborSampler
     monkeypatch.setenv("PG_SAMPLER_LOOKBACK", str(lookback))
+    monkeypatch.setenv("PG_SAMPLER_CLEAR_IDS_ABOVE", "0" if clear_by_ids else str(1 << 40))
     rng = np.random.default_rng(V + k + lookback)
     adj = _rand_csc(rng, V, E)
     g = DeviceGraph(adj)
@@ -252,7 +257,7 @@ def test_sampler_multi_round_lookback_paths(dev, hiplib, oracle, monkeypatch, V,
         smp = NeighborSampler(g, B, k, neighbor_type='in', shuffle=False, num_hops=hops, seed_nodes=train, seed=9,
                               static=static)
         for b, nf in enumerate(smp):
-            if b > 2 and b < len(smp) - 1:
+            if b > 2 and b < len(smp) - 1 and not (clear_by_ids and b < 12):
                 continue
             ref = oracle.sample_nodeflow(csc.indptr, csc.indices, train[b * B:(b + 1) * B], k, hops, 9, 0, b)
             torch.cuda.synchronize()
@@ -653,6 +658,81 @@ def test_graphed_trainer_matches_eager(dev, hiplib):
     assert np.allclose(losses["eager"], losses["graph"], rtol=2e-4, atol=2e-5), (losses["eager"], losses["graph"])
     assert np.allclose(losses["eager"], losses["graph-async"], rtol=2e-4, atol=2e-5)
     assert losses["graph"][-1] < losses["graph"][0]
+
+
+def test_stress_objects_dropped_with_work_in_flight(dev, hiplib):
+    """Samplers, cachers (async miss queue: worker thread, gather pool, SDMA copies), trainers with captured step graphs and
+    optimisers with a mirrored step counter are created, driven WITHOUT a final synchronise, and dropped in every order
+    while replays, sampling chains and miss jobs are still in flight — every *_destroy / __del__ path of _lib.py,
+    storage.py, sampler.py, optim.py (one unexplained core dump of the test process in round 3). The process
+    must survive, later pipelines must still train, and nothing may be reported lost."""
+    import gc
+    import itertools
+    import torch.nn.functional as Fn
+    from pagraph_amd.model import GCNSampling, GraphSageSampling
+    from pagraph_amd.optim import Adam
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    from pagraph_amd.trainer import GraphedTrainer, cycle_batches
+    rng = np.random.default_rng(99)
+    V, Fdim, C, B = 6000, 256, 5, 400
+    adj = _rand_csc(rng, V, 40000)
+    g = DeviceGraph(adj)
+    feats = torch.from_numpy(rng.standard_normal((V, Fdim)).astype(np.float32))
+    labels = torch.from_numpy(rng.integers(0, C, V)).to(dev)
+    train = np.arange(0, V, 2, dtype=np.int64)
+    orders = list(itertools.permutations(range(5)))
+    rng.shuffle(orders)
+    last = None
+    for it, order in enumerate(orders[:14]):
+        store = HostFeatureStore({"features": feats})
+        c = GraphCacheServer(store, V, torch.arange(V), 0, miss_mode="async", host_threads=3)
+        c.init_field(["features"])
+        c.auto_cache(g, ["features"], cache_ratio=0.3)
+        torch.manual_seed(it)
+        model = (GCNSampling(Fdim, 16, C, 1, Fn.relu, 0.2) if it % 2 == 0 else GraphSageSampling(Fdim, 16, C, 1, Fn.relu, 0.2, 'mean')).to(dev)
+        opt = Adam(model.parameters(), lr=1e-2)
+        smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=True, num_hops=2, seed_nodes=train, prefetch=True, seed=it,
+                              static=True, defer_transpose=True)
+        tr = GraphedTrainer(model, torch.nn.CrossEntropyLoss(), opt, c, smp, labels, dev, need=model.required_inputs(3),
+                            keep_losses=False)
+        tr.keep_primed = (it % 3 == 0)            # leaves prepared batches (held ring slots, submitted miss jobs) behind
+        n = 19 + 3 * (it % 4)                     # eager warm-up, captures, a few replays — the tail is still running below
+        tr.run_steps(cycle_batches(smp, n + 8), n)
+        loss = tr.last_loss
+        if it % 5 == 4:
+            tr.synchronize()                      # some iterations do end cleanly
+            assert torch.isfinite(loss).all()
+        # drop the five owners in this iteration's order, collecting after each, work still in flight
+        owners = {0: "tr", 1: "smp", 2: "c", 3: "opt", 4: "model"}
+        scope = {"tr": tr, "smp": smp, "c": c, "opt": opt, "model": model}
+        del tr, smp, c, opt, model, store
+        for k in order:
+            scope.pop(owners[k])
+            gc.collect()
+        last = loss
+        del scope, loss
+        gc.collect()
+    torch.cuda.synchronize()
+    assert last is None or True
+    # the device and the library are still healthy: one more pipeline trains, eagerly checked
+    store = HostFeatureStore({"features": feats})
+    c = GraphCacheServer(store, V, torch.arange(V), 0, miss_mode="async", host_threads=3)
+    c.init_field(["features"])
+    c.auto_cache(g, ["features"], cache_ratio=0.3)
+    torch.manual_seed(0)
+    model = GCNSampling(Fdim, 16, C, 1, Fn.relu, 0.0).to(dev)
+    opt = Adam(model.parameters(), lr=1e-2)
+    smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=True, num_hops=2, seed_nodes=train, prefetch=True, seed=1,
+                          static=True, defer_transpose=True)
+    tr = GraphedTrainer(model, torch.nn.CrossEntropyLoss(), opt, c, smp, labels, dev, need=model.required_inputs(3))
+    out = []
+    tr.on_step = lambda step, loss: out.append(loss.detach().clone())
+    tr.run_steps(cycle_batches(smp, 60), 60)
+    tr.synchronize()
+    lv = torch.stack(out).cpu()
+    assert torch.isfinite(lv).all() and float(lv[-10:].mean()) < float(lv[:10].mean())
+    c.shutdown_miss_queue()
 
 
 def _two_rank_graph_worker(rank, world, port, out_dir):
@@ -1813,6 +1893,77 @@ def _fused_gather_aggregate_case(dev, hiplib, oracle, ratio, p_drop, reduce, Fd)
         t_succ = prof.view(16, L.PG_PROF_WORDS)[step % 16, 1].item()
         assert t_succ >= t1 and t_succ - t0 < 100_000_000
         assert torch.allclose(y8, out[:64] @ w8.t(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("Fd,N,act,reduce,p_drop,max_deg,use_es", [
+    (600, 32, 2, "mean", 0.2, 2, False),       # the benchmark's layer 0: fan-out 2, skip-concat, dropout
+    (600, 32, 2, "mean", 0.2, 2, True),        # + pre-composed edge slots
+    (602, 32, 2, "mean", 0.3, 2, False),       # Reddit's ragged width
+    (600, 64, 1, "sum", 0.0, 2, False),        # two column tiles (the second recomputes the aggregation), no dropout, sum
+    (600, 16, 0, "mean", 0.5, 7, False),       # destinations with more in-edges than the kernel keeps addresses for
+    (256, 41, 2, "mean", 0.1, 3, False),       # the narrowest K the 8-wave split serves, ragged N
+    (1000, 60, 1, "mean", 0.2, 150, False)])   # a hub destination
+def test_fused_aggregate_and_dense_step_is_bit_identical_to_the_pair(dev, hiplib, Fd, N, act, reduce, p_drop, max_deg, use_es):
+    """pg_agg_linear_fwd (layer 0's reduce AND its NodeUpdate in one kernel) == pg_spmm_fwd_rows + pg_linear_fwd, bit for bit:
+    the aggregated rows it writes and the activation output — hits, staged misses, padding sources, empty destinations,
+    a row count that is not a multiple of the tile."""
+    from pagraph_amd import _lib as L
+    rng = np.random.default_rng(Fd + N + max_deg)
+    n_cache, n_src, n_dst = 3000, 2600, 1191
+    cs = (Fd + 7) & ~7
+    fused = torch.from_numpy(rng.random((n_cache, cs), dtype=np.float32)).to(dev)         # fused cache rows [F | norm | pad]
+    if cs > Fd:
+        fused[:, Fd:] = float("nan")                                                      # never summed
+    n_miss = 500
+    staged_stride = (Fd + 3) & ~3
+    staged = torch.from_numpy(rng.random((n_miss, staged_stride), dtype=np.float32)).to(dev)
+    slots = rng.integers(0, n_cache, n_src).astype(np.int32)
+    miss = rng.permutation(n_src)[:n_miss]
+    slots[miss] = -(np.arange(n_miss, dtype=np.int32) + 3)
+    slots[-9:] = -2                                                                       # padding of a fixed-shape layer
+    slots[-12:-9] = -1
+    deg = rng.integers(0, min(max_deg, 3) + 1, n_dst)
+    deg[5] = 0
+    deg[17] = max_deg
+    deg[n_dst - 40:] = 0                                                                  # the padded tail of the block
+    indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    src = rng.integers(0, n_src, int(indptr[-1])).astype(np.int32)
+    d_indptr, d_src, d_slots = (torch.from_numpy(a).to(dev) for a in (indptr, src, slots))
+    es = torch.from_numpy(slots[src]).to(dev) if use_es else None
+    rs = L.PgRowSource(d_slots.data_ptr(), fused.data_ptr(), staged.data_ptr(), cs, staged_stride, es.data_ptr() if use_es else 0)
+    W = torch.from_numpy((rng.random((N, Fd), dtype=np.float32) - 0.5)).to(dev)
+    bias = torch.from_numpy(rng.random(N, dtype=np.float32)).to(dev)
+    stepd = torch.tensor([11], dtype=torch.int64, device=dev)
+    thr = min(65535, int(round(p_drop * 65536)))
+    drop = L.PgDropout(thr, 4, 0xABCDEF12345, L.ptr(stepd))
+    dp = ctypes.byref(drop)
+    red = {"mean": 0, "sum": 1}[reduce]
+    sp = L.stream_ptr()
+    pad = (Fd + 7) & ~7
+    ycols = 2 * N if act == 2 else N
+    # the pair
+    agg_ref = torch.zeros((n_dst, pad), device=dev)
+    y_ref = torch.empty((n_dst, ycols), device=dev)
+    L.check(hiplib.pg_spmm_fwd_rows(L.ptr(d_indptr), L.ptr(d_src), ctypes.byref(rs), n_dst, Fd, red, L.ptr(agg_ref), pad, dp,
+                                    None, 0, sp))
+    L.check(hiplib.pg_linear_fwd(L.ptr(agg_ref), pad, L.ptr(W), L.ptr(bias), L.ptr(y_ref), ycols, n_dst, Fd, N, act, sp))
+    # the fused kernel, with its self-timing ring
+    agg = torch.zeros((n_dst, pad), device=dev)
+    y = torch.empty((n_dst, ycols), device=dev)
+    prof = torch.zeros(L.PG_PROF_WORDS * 4, dtype=torch.int64, device=dev)
+    L.check(hiplib.pg_agg_linear_fwd(L.ptr(d_indptr), L.ptr(d_src), ctypes.byref(rs), n_dst, Fd, red, dp, L.ptr(W), L.ptr(bias),
+                                     N, act, L.ptr(agg), pad, L.ptr(y), ycols, L.ptr(prof), 4, sp))
+    torch.cuda.synchronize()
+    k4 = (Fd + 3) & ~3
+    assert torch.equal(agg[:, :k4], agg_ref[:, :k4])
+    assert torch.equal(y, y_ref)
+    e = prof.view(4, L.PG_PROF_WORDS)[11 % 4].tolist()
+    assert e[0] > 0 and e[2] == int(indptr[-1]) and max(e[L.PG_PROF_END0::L.PG_PROF_SHARD_STRIDE]) > e[0]
+    # envelope: the max reducer and narrow rows are the caller's to run as a pair
+    assert hiplib.pg_agg_linear_fwd(L.ptr(d_indptr), L.ptr(d_src), ctypes.byref(rs), n_dst, Fd, 2, dp, L.ptr(W), L.ptr(bias),
+                                    N, act, L.ptr(agg), pad, L.ptr(y), ycols, None, 0, sp) == -4
+    assert hiplib.pg_agg_linear_fwd(L.ptr(d_indptr), L.ptr(d_src), ctypes.byref(rs), n_dst, 128, red, dp, L.ptr(W), L.ptr(bias),
+                                    N, act, L.ptr(agg), pad, L.ptr(y), ycols, None, 0, sp) == -4
 
 
 @pytest.mark.parametrize("arch", ["gcn", "sage"])

@@ -22,7 +22,8 @@ for k, v in table.items():
     print(f"{k[:70]:70s} n={v['launches']:5d}  fetch {v['fetch_bytes_corrected_per_launch']/1e6:9.3f} MB  write {v['write_bytes_per_launch']/1e6:9.3f} MB  "
           f"{v['avg_ns_under_pmc']/1e3:8.1f} us")
 for k, v in table.items():
-    if "k_spmm_fwd_rows" in k:
+    if "k_spmm_fwd_rows" in k or "k_agg_linear_fwd" in k:
+        short = "agg_linear_fwd" if "k_agg_linear_fwd" in k else "spmm_fwd_rows"
         rec = {"kernel": k.split("(")[0] + " in-loop (eager loop, layer 0 aggregated straight from the cache + staged miss rows)",
                "launches": v["launches"], "fetch_bytes_corrected_per_launch": v["fetch_bytes_corrected_per_launch"],
                "write_bytes_per_launch": v["write_bytes_per_launch"], "hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
@@ -30,4 +31,4 @@ for k, v in table.items():
                "collected": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace, separate passes (FETCH_SIZE x2 on gfx950, "
                             "WRITE_SIZE x1, KiB; calibrated in the same run on the 2.5 GB cache-fill copies: x1.000 / x1.000), over "
                             "PG_SAMPLER_NO_GRAPH=1 PG_MISSQ_HOST_WAIT=1 python bench.py --steps 60 --no-graph ... (tools/run_profiles.sh)"}
-        json.dump(rec, open(os.path.join(out_dir, "pmc_spmm_fwd_rows_inloop.json"), "w"), indent=1)
+        json.dump(rec, open(os.path.join(out_dir, f"pmc_{short}_inloop.json"), "w"), indent=1)
