@@ -101,6 +101,10 @@ def parse():
     p.add_argument("--batch-size", type=int, default=6000)
     p.add_argument("--num-neighbors", type=int, default=2)
     p.add_argument("--cache-ratio", type=float, default=0.30)
+    p.add_argument("--presample-epochs", type=int, default=8, help="epochs the presample policy counts accesses over")
+    p.add_argument("--cache-policy", choices=("degree", "presample"), default="degree",
+                   help="degree = the reference's rule (storage.py:97-104, the headline); presample = opt-in: the vertices "
+                        "a presampled epoch (another sampler seed) looked up most often")
     p.add_argument("--miss-mode", default=None, choices=["staged", "zerocopy", "async"],
                    help="default: async (worker-thread queue) on one GPU. With --gpus > 1 both zerocopy and async are "
                         "timed for 40 steps after the warm-up and every rank keeps the faster one: on a single GPU one "
@@ -747,7 +751,24 @@ def run():
     else:
         trainer = MinibatchTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, overlap=not args.no_overlap,
                                    need=need)
-    trainer.after_first_step = lambda: cacher.auto_cache(g, embed_names, cache_ratio=args.cache_ratio)  # pa_gcn.py:99-100
+    PRESAMPLE_SEED = 7919            # the presampled epoch is NOT the epoch that is trained on and timed (another seed)
+
+    def presampled_freq():
+        from pagraph_amd import analysis
+        t_ = time.time()
+        probe_ = NeighborSampler(g, B, k, neighbor_type='in', shuffle=True, num_hops=num_hops, seed_nodes=subtrain,
+                                 prefetch=True, seed=rank + PRESAMPLE_SEED)
+        f_, _ = analysis.access_frequency(probe_, layers=None if need is None else set(need), epochs=args.presample_epochs)
+        del probe_
+        log(f"[bench] rank {rank}: presampled {args.presample_epochs} epoch(s) for the cache policy in {time.time()-t_:.2f}s")
+        return f_
+
+    def fill_cache():
+        if args.cache_policy == "presample" and args.cache_ratio < 1.0:
+            cacher.auto_cache(g, embed_names, cache_ratio=args.cache_ratio, policy="presample", freq=presampled_freq())
+        else:
+            cacher.auto_cache(g, embed_names, cache_ratio=args.cache_ratio)
+    trainer.after_first_step = fill_cache                 # pa_gcn.py:99-100
     model.train()
     PROBE = 40
     it = cycle_batches(sampler, 4 * S + W + K + steps_per_epoch + 64 + (4 * PROBE + 64 if probe_modes else 0))
@@ -756,7 +777,7 @@ def run():
     t0 = time.time()
     trainer.run_steps(it, S)
     if cacher.cached_num == 0:
-        cacher.auto_cache(g, embed_names, cache_ratio=args.cache_ratio)
+        fill_cache()
     torch.cuda.synchronize()
     log(f"[bench] rank {rank}: set-up {S} steps + cache fill ({cacher.cached_num} rows) in {time.time()-t0:.1f}s")
     # safety net: a device-side wait for miss rows that timed out during set-up means the runtime put the consuming
@@ -1091,7 +1112,7 @@ def run():
         roofline["step_shape_all_hits"] = micro[42000]
         roofline["sizes"] = [micro[k] for k in sorted(micro, key=lambda k: (k[0], 1) if isinstance(k, tuple) else (k, 0))]
 
-    opt_hit = deg_hit = None
+    opt_hit = deg_hit = pre_hit = None
     if rank == 0 and not args.skip_opt_hit:
         # oracle upper bound at the same cache ratio on the same access pattern (opt_cache_hit.py:26-31),
         # over one full epoch of sampling; `layers` = what fetch_data really looks up
@@ -1101,6 +1122,8 @@ def run():
         freq, _ = analysis.access_frequency(probe, layers=None if need is None else set(need))   # one full epoch
         opt_hit = 100.0 * analysis.optimal_cache_hit(freq, args.cache_ratio)
         deg_hit = 100.0 * analysis.degree_cache_hit(freq, g.out_degrees(), args.cache_ratio)
+        # what auto_cache(policy='presample') reaches on this trace when its counts come from ANOTHER epoch
+        pre_hit = 100.0 * analysis.presample_cache_hit(freq, presampled_freq(), g.out_degrees(), args.cache_ratio)
         del probe, freq
 
     ref_eq = None
@@ -1155,7 +1178,8 @@ def run():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"RMAT {V} vertices / {E} undirected edges (nnz {2*E}), feat={Fdim}, "
                                    f"2-layer {'GCN' if args.model == 'gcn' else 'GraphSAGE-mean'} hidden {hidden}, "
-                                   f"batch {B}, fan-out {k}, {int(args.cache_ratio*100)}% hot-degree cache, "
+                                   f"batch {B}, fan-out {k}, {int(args.cache_ratio*100)}% "
+                                   f"{'hot-degree' if args.cache_policy == 'degree' else 'presampled-frequency (opt-in policy)'} cache, "
                                    f"{('dg(hops=%d)' % args.dg_hops) if world > 1 else '1naive'} partition x{world}, closure hops {num_hops}",
                        "steps_per_epoch": steps_per_epoch, "epoch_steps_timed": reg_epoch["steps"],
                        "epoch_ms_per_step": reg_epoch["ms_per_step"], "window_ms_per_step": reg_win["ms_per_step"],
@@ -1177,6 +1201,8 @@ def run():
             "miss_list_index_dedup": bool(cacher.dedup_misses and cacher.miss_mode == "async"),
             "reference_equivalent": ref_eq,
             "cache_hit_oracle_upper_bound_pct": opt_hit, "cache_hit_degree_policy_on_trace_pct": deg_hit,
+            "cache_hit_presample_policy_on_trace_pct": pre_hit, "cache_policy": args.cache_policy,
+            "presample_epochs": args.presample_epochs,
             "feat_gather_GBps": (micro[1 << 20]["GBps"] if micro else achieved),
             "seeds_per_s": seeds_total / elapsed,
             "host_issue_ms_per_step": t_issued / K_big * 1e3,     # launch thread's share; == ms_per_step when it is the bottleneck

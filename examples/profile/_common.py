@@ -83,7 +83,18 @@ def trainer(rank, world_size, args, arch, backend='nccl'):
     else:               # the reference's eager loop
         loop = MinibatchTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, overlap=not args.no_overlap,
                                 need=need)
-    loop.after_first_step = lambda: cacher.auto_cache(g, embed_names, cache_ratio=args.cache_ratio)
+    def fill_cache():                  # pa_gcn.py:99-100
+        if args.cache_policy == 'presample':
+            # opt-in, beyond the reference: cache what a presampled epoch (another sampler seed) looked up most often
+            from pagraph_amd import analysis
+            probe = NeighborSampler(g, args.batch_size, args.num_neighbors, neighbor_type='in', shuffle=True,
+                                    num_hops=num_hops, seed_nodes=train_nid, prefetch=True, seed=rank + 7919)
+            freq, _ = analysis.access_frequency(probe, layers=None if need is None else set(need), epochs=args.presample_epochs)
+            del probe
+            cacher.auto_cache(g, embed_names, cache_ratio=args.cache_ratio, policy='presample', freq=freq)
+        else:
+            cacher.auto_cache(g, embed_names, cache_ratio=args.cache_ratio)
+    loop.after_first_step = fill_cache
     state = {'epoch': 0}
 
     def on_step(step, loss):
@@ -150,6 +161,10 @@ def main(arch, description, n_hidden, lr):
     # additions of this build
     parser.add_argument("--cache-ratio", type=float, default=None,
                         help="cap the cache at this fraction of the partition (storage.py:85-86 overrides)")
+    parser.add_argument("--cache-policy", choices=["degree", "presample"], default="degree",
+                        help="degree: the reference's top-out-degree rule (storage.py:97-104); presample: the vertices a "
+                             "presampled epoch looked up most often (opt-in)")
+    parser.add_argument("--presample-epochs", type=int, default=8, help="epochs the presample policy counts accesses over")
     # The defaults are the path bench.py measures (hipGraph-replayed step, only what the model reads is fetched — read in
     # place where it can be —, async miss queue). --eager --fetch-all --miss-mode zerocopy is the reference-shaped loop
     # (pa_gcn.py:82-103 step by step: every layer and field fetched into frames, DDP, torch's Adam).

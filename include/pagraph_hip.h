@@ -443,6 +443,10 @@ int pg_compose_edge_slots(const int32_t* src, int64_t n_edges, const int32_t* sl
 int pg_spmm_fwd_rows(const int32_t* indptr, const int32_t* src, const pg_row_source_t* rows, int64_t n_dst,
                      int32_t dim, int reduce, float* out, int32_t out_stride, const pg_dropout_t* drop,
                      uint64_t* prof, int32_t prof_ring, pg_stream_t stream);
+/* A stream restricted to the CUs of `mask` (hipExtStreamCreateWithCUMask; bit i of word i / 32 = CU i). No reference
+ * counterpart: the reference's only streams are torch's (pa_gcn.py:86-92 uses the default stream). */
+int pg_stream_create_masked(const uint32_t* mask, int32_t words, pg_stream_t* out);
+int pg_stream_destroy(pg_stream_t stream);
 /* Profiling aid: one-thread marker kernel, ring[(*step or 0) % ring_len] = device wall clock (100 MHz ticks). Launched
  * right behind a kernel inside a captured step it gives that kernel's TRUE end as the stream sees it (the write-back of
  * what the kernel left dirty in L2 included): a dispatch cannot start before its predecessor has completed.          */

@@ -128,6 +128,8 @@ _SIGS = {
     "pg_spmm_fwd_rows": (ctypes.c_int, [vp, vp, ctypes.POINTER(PgRowSource), c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, vp,
                                         c_i32, vp]),
     "pg_prof_stamp": (ctypes.c_int, [vp, c_i32, vp, vp]),
+    "pg_stream_create_masked": (ctypes.c_int, [vp, c_i32, ctypes.POINTER(ctypes.c_void_p)]),
+    "pg_stream_destroy": (ctypes.c_int, [vp]),
     "pg_compose_edge_slots": (ctypes.c_int, [vp, c_i64, vp, c_i64, vp, vp]),
     "pg_spmm_bwd_drop": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, vp]),
     "pg_spmm_bwd_gather": (ctypes.c_int, [vp, vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, c_i32, vp, vp]),
@@ -239,6 +241,33 @@ def stream_ptr(stream=None):
     """hipStream_t of a torch stream (default: current stream of the current device)"""
     s = stream if stream is not None else torch.cuda.current_stream()
     return ctypes.c_void_p(s.cuda_stream)
+
+
+_MASKED = {}     # (device index, role) -> torch ExternalStream over a CU-masked HIP stream (one per process and role)
+
+
+def pipeline_stream(device, role, priority=0):
+    """A stream for one role of the training pipeline: 'side' (sampler chain, load stream: a handful of small latency-bound
+    launches per step) or 'compute' (the replayed step, HBM-bound). Default: a plain torch stream of the given priority.
+    PG_CU_SIDE=<n> (experiment): the side streams may only use n CUs (the low n bits of the CU mask, which
+    ROCr deals round-robin over the XCDs) and the compute stream only the others, so the side launches never take wave
+    slots next to the HBM-bound kernels. CU-masked streams have the default priority."""
+    import os
+    n = int(os.environ.get("PG_CU_SIDE", "0") or 0)
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    cus = torch.cuda.get_device_properties(idx).multi_processor_count
+    if n <= 0 or n >= cus or role not in ("side", "compute"):
+        return torch.cuda.Stream(device=device, priority=priority)
+    if role == "compute" and os.environ.get("PG_CU_COMPUTE_ALL"):
+        return torch.cuda.Stream(device=device, priority=priority)
+    words = (cus + 31) // 32
+    bits = ((1 << n) - 1) if role == "side" else (((1 << cus) - 1) ^ ((1 << n) - 1))
+    arr = (ctypes.c_uint32 * words)(*[(bits >> (32 * i)) & 0xFFFFFFFF for i in range(words)])
+    out = ctypes.c_void_p()
+    with torch.cuda.device(idx):
+        check(load().pg_stream_create_masked(arr, words, ctypes.byref(out)), "pg_stream_create_masked")
+    return torch.cuda.ExternalStream(out.value, device=dev)
 
 
 def ptr(t):

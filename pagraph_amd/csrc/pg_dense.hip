@@ -26,6 +26,7 @@
 #include <cstdlib>
 
 #include "pg_common.h"
+#include "pg_rows_w.h"
 
 namespace pg {
 
@@ -299,140 +300,225 @@ __global__ __launch_bounds__(NW * 64) void k_linear_fwd(const float* __restrict_
 }
 
 // ---- layer 0's aggregation AND its NodeUpdate in one kernel (round 4; gcn_nssc.py:64-74 + :14-24 over storage.py:176-204) ---
-// k_linear_fwd<..., ROWS> whose "fetch a row" is "aggregate a destination": the A operand of tile row r is
-//   agg[r, :] = reduce over r's in-edges of dropout(row(src[e]))      (row(p) = the cache / the staged miss block, pg_row_source_t)
-// computed piece by piece where the dense step consumes it, and written out once (the weight gradient needs agg again).
-// What k_spmm_fwd_rows_w + k_linear_fwd did in two launches with a 29 MB round trip through memory between them. Same
-// arithmetic in the same order as that pair — per piece: 0 + drop(x_0) + drop(x_1) ... in edge order, / degree; per output:
-// the K range split over the same NW waves, octet by octet through the same MFMA sequence, the waves' partial tiles added
-// in wave order, + bias — so agg AND Y are bit-identical to the two-kernel path (tests/test_gpu_parity.py).
-// Wave w owns octets [o_beg, o_end) of K for all 32 destinations of the tile: per slab (4 octets) a lane fetches the pieces
-// of 4 destinations x their first DEG in-edges (8 x 16-byte loads in flight; the rows' addresses are resolved once, before
-// the K loop), applies the dropout mask (one Philox call per piece and edge), sums, scales, stores the piece to `agg`
-// (write-through) and to the wave's LDS slab, and runs the slab's MFMAs. Destinations with more than DEG in-edges take a
-// slower loop for the rest (correct for any degree; the sampler's fan-out is 2).
-struct AggArgs {
-  const int32_t* indptr;
-  const int32_t* src;
-  const int32_t* slots;
-  const int32_t* edge_slots;   // optional: slots[src[e]] per edge
-  const float* cache;
-  const float* staged;
-  int32_t cache_stride, staged_stride;
+// k_spmm_fwd_rows_w + k_linear_fwd without the round trip of the aggregated rows through memory between them and without
+// the second launch: a block of 8 waves owns a tile of 32 destinations.
+//   phase 1  each wave aggregates 4 of the tile's destinations exactly as k_spmm_fwd_rows_w does (rows_w_accumulate: whole
+//            source rows, coalesced, straight from the cache / the staged miss block, dropout mask, edge order, / degree) —
+//            the index loads of all four are issued before the first row load — and writes each finished row twice: to
+//            `agg` in memory (the weight gradient reads it in the backward pass) and to the tile's A operand in LDS
+//            (32 rows x (K + pad) floats: 77 KB at K = 600, two blocks per CU);
+//   phase 2  k_linear_fwd's K loop with the A operand read from LDS: wave w owns octets [o_beg, o_end) of K — the same split
+//            over 8 waves, the same MFMA sequence per octet — and reads its share of W straight from memory, 16 bytes per
+//            lane and octet (four consecutive octets of a weight row share a 128-byte line: the L1 serves three of them);
+//   phase 3  the waves' partial 32 x 32 tiles are added in wave order through LDS (aliased onto the A operand), + bias,
+//            activation / skip-concat, exactly k_linear_fwd's epilogue.
+// Same arithmetic in the same order as the pair, so `agg` AND Y are bit-identical to it (tests/test_gpu_parity.py).
+// (The first version of this round split K over the waves DURING the gather — 128-byte segments of 8 rows per load
+// instruction — and reached 2 TB/s: 45 us against 18 + 15 for the pair.)
+struct AggArgs {               // (the index / row pointers are kernel parameters of their own: __restrict__, so that the
+  int32_t cache_stride, staged_stride;   // wave-uniform index loads become scalar loads that are issued together)
   int32_t reduce;              // PG_REDUCE_MEAN | PG_REDUCE_SUM
   float* agg;
   int32_t agg_stride, store_mode;
-  DropArgs d;                  // d.thr == 0: no dropout
+  DropArgs d;                  // DROP == false: only d.step is read (the profiling ring's index)
   unsigned long long* prof;
   int32_t prof_ring;
+  unsigned long long* dbg;     // experiment: per block 4 stamps (start, after phase 1, after phase 2, end)
 };
 
-constexpr int kAggDeg = 2;
+constexpr int kAggWaves = 8;                     // = k_linear_fwd's NW for K >= 256: the K split this kernel reproduces
+constexpr int kAggDpw = kTile / kAggWaves;       // destinations per wave
+static_assert(kAggDpw == 4, "k_agg_dense_fwd spells out four destinations per wave");
 
-struct AggRow {                // one destination of the tile (32 bytes; the block keeps the tile's 32 in LDS)
-  const float* ptr[kAggDeg];   // its first kAggDeg source rows (nullptr: padding / unresolved: contributes nothing)
-  int32_t pos[kAggDeg];        // their positions in the source layer (the dropout mask's row index)
-  int32_t beg, deg;
-};
-static_assert(sizeof(AggRow) == 32, "AggRow is read back from LDS as two 16-byte pieces");
-
-__device__ __forceinline__ const float* agg_row_ptr(const AggArgs& g, int32_t e, int32_t* pos) {
-  const int32_t p = g.src[e];
-  *pos = p;
-  const int32_t sl = g.edge_slots ? g.edge_slots[e] : g.slots[p];
-  if (sl >= 0) return g.cache + (int64_t)sl * g.cache_stride;
-  if (sl <= -3) return g.staged + (int64_t)(-(sl + 3)) * g.staged_stride;
-  return nullptr;
+// floats per row of the A operand in LDS: >= K rounded up to whole pieces, and an ODD number of 16-byte pieces, so that the
+// 16-byte reads of 8 consecutive rows at one column (a quarter of an MFMA operand fetch) fall into 8 different bank groups
+inline __host__ __device__ int agg_as_stride(int K) {
+  int p = (K + 3) / 4 + 1;
+  if (!(p & 1)) ++p;
+  return 4 * p;
 }
 
-__device__ __forceinline__ AggRow agg_row_of(const AggArgs& g, int64_t r, int64_t n) {
-  AggRow a;
-  a.beg = 0; a.deg = 0;
+template <int WV, bool DROP, bool TAIL, int M, int NT>
+__global__ __launch_bounds__(kAggWaves * 64, 4) void k_agg_dense_fwd(const int32_t* __restrict__ indptr,
+                                                                      const int32_t* __restrict__ src,
+                                                                      const int32_t* __restrict__ slots,
+                                                                      const int32_t* __restrict__ edge_slots,
+                                                                      const float* __restrict__ cache,
+                                                                      const float* __restrict__ staged, const AggArgs g,
+                                                                      const float* __restrict__ W /* [N][K] */,
+                                                                      const float* __restrict__ bias, float* __restrict__ Y,
+                                                                      int32_t y_stride, int64_t n, int32_t K, int32_t N,
+                                                                      int32_t act, int32_t as_stride) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // A operand [32][as_stride]; then the partial tiles
+  const uint32_t step = g.d.step ? (uint32_t)*g.d.step : 0u;
+  unsigned long long* pslot = prof_begin(g.prof, g.prof_ring, step, g.prof ? (unsigned long long)indptr[n] : 0ull);
+  const RowsW rows{src, slots, edge_slots, cache, staged, g.cache_stride, g.staged_stride};
+  const int lane = threadIdx.x & (kWave - 1);
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+  const int64_t r0 = (int64_t)blockIdx.x, G = (int64_t)gridDim.x;   // tile row j = destination r0 + G * j (see the launcher)
+  const int pieces = (K + 3) / 4;
+  const int tail = K & 3;
+  if (g.dbg && threadIdx.x == 0) g.dbg[blockIdx.x * 4 + 0] = wall_clock64();
+  // ---- phase 1: the wave's destinations r0 + w + 8 i ----
+  {
+    int32_t beg[kAggDpw], deg[kAggDpw];
+    bool fast = true;
 #pragma unroll
-  for (int e = 0; e < kAggDeg; ++e) { a.ptr[e] = nullptr; a.pos[e] = 0; }
-  if (r < n) {
-    a.beg = g.indptr[r];
-    a.deg = g.indptr[r + 1] - a.beg;
+    for (int i = 0; i < kAggDpw; ++i) {
+      const int64_t v = r0 + G * (w + kAggWaves * i);
+      const int64_t vc = v < n ? v : n - 1;          // unconditional scalar loads: the four pairs are in flight together
+      const int32_t b0 = indptr[vc], e0 = indptr[vc + 1];
+      beg[i] = b0;
+      deg[i] = v < n ? e0 - b0 : 0;
+      fast = fast && deg[i] <= 2;
+    }
+    // fast path (wave-uniform): every destination of the wave has at most two in-edges — the sampler's fan-out. All EIGHT
+    // source rows are in flight together, one 64-piece column group m at a time (the next group's loads are issued before
+    // this group is consumed): a destination's piece is final as soon as its two rows' pieces have arrived, so nothing
+    // accumulates across groups. Straight-line code: the index loads are two rounds (positions, then slots) of four loads
+    // each, the row loads are unconditional (a row that contributes nothing — padding, an unresolved miss, a missing second
+    // edge — reads the home's first row and is replaced by zeros, which adds +0: the same bits as skipping it).
+    if (fast) {
+      int32_t pp[kAggDpw], ps[kAggDpw];
 #pragma unroll
-    for (int e = 0; e < kAggDeg; ++e)
-      if (e < a.deg) a.ptr[e] = agg_row_ptr(g, a.beg + e, &a.pos[e]);
-  }
-  return a;
-}
-
-// one 16-byte piece of a source row through the dropout mask (k_spmm_fwd_rows' drop_apply) and the ragged-K mask
-template <bool DROP>
-__device__ __forceinline__ df4 agg_term(const AggArgs& g, df4 x, int32_t pos, int c, int left, uint32_t step) {
-  if constexpr (DROP) {
-    uint32_t o[4];
-    Philox::gen((uint32_t)pos, (uint32_t)(((c >> 7) << 6) | (c & 63)), g.d.tag, step, g.d.k0, g.d.k1, o);
-    const float4 y = drop_apply(make_float4(x.x, x.y, x.z, x.w), o, (c >> 6) & 1, g.d.thr, g.d.scale);
-    x = df4{y.x, y.y, y.z, y.w};
-  }
-  if (left < 4) {               // columns past K (the next field of the fused cache row / padding) are never summed
-    if (left < 2) x.y = 0.f;
-    if (left < 3) x.z = 0.f;
-    x.w = 0.f;
-  }
-  return x;
-}
-
-// finish a piece: the in-edges beyond the first kAggDeg (any degree stays correct), then the mean's division
-template <bool DROP>
-__device__ __forceinline__ df4 agg_finish(const AggArgs& g, df4 acc, const AggRow& a, int kc, int left, uint32_t step) {
-  for (int32_t e = kAggDeg; e < a.deg; ++e) {
-    int32_t pos;
-    const float* rp = agg_row_ptr(g, a.beg + e, &pos);
-    if (rp) {
-      const df4 t = agg_term<DROP>(g, *reinterpret_cast<const df4*>(rp + kc), pos, kc >> 2, left, step);
-      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+      for (int i = 0; i < kAggDpw; ++i) {
+        pp[i] = 0;
+        ps[i] = -2;
+      }
+      if (deg[0] | deg[1] | deg[2] | deg[3]) {        // (kAggDpw == 4) an edge exists, so src[0] does: lanes without an
+        int32_t idx[kAggDpw];                         // edge read it, unconditionally — no branch between the loads
+#pragma unroll
+        for (int i = 0; i < kAggDpw; ++i) idx[i] = lane < deg[i] ? beg[i] + lane : 0;
+#pragma unroll
+        for (int i = 0; i < kAggDpw; ++i) pp[i] = src[idx[i]];
+        if (edge_slots) {
+#pragma unroll
+          for (int i = 0; i < kAggDpw; ++i) ps[i] = edge_slots[idx[i]];
+        } else {
+#pragma unroll
+          for (int i = 0; i < kAggDpw; ++i) ps[i] = slots[pp[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < kAggDpw; ++i) ps[i] = lane < deg[i] ? ps[i] : -2;
+      }
+      const float4* const dummy = reinterpret_cast<const float4*>(rows.cache ? rows.cache : rows.staged);
+      const float4* rp[kAggDpw][2];
+      uint32_t pos[kAggDpw][2];
+      bool ok[kAggDpw][2];
+#pragma unroll
+      for (int i = 0; i < kAggDpw; ++i) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int32_t sl = __builtin_amdgcn_readlane(ps[i], e);
+          pos[i][e] = (uint32_t)__builtin_amdgcn_readlane(pp[i], e);
+          ok[i][e] = e < deg[i] && sl != -1 && sl != -2;            // padding / an unresolved miss contributes nothing
+          const float4* real = sl >= 0
+                                   ? reinterpret_cast<const float4*>(rows.cache + (int64_t)sl * rows.cache_stride)
+                                   : reinterpret_cast<const float4*>(rows.staged + (int64_t)(-sl - 3) * rows.staged_stride);
+          rp[i][e] = ok[i][e] ? real : dummy;
+        }
+      }
+      float4 xbuf[2][kAggDpw][2];
+      auto issue = [&](int m, float4 (&x)[kAggDpw][2]) {
+        const int c = m * kWave + lane;
+        if (m < M - 1 || c < pieces) {
+#pragma unroll
+          for (int i = 0; i < kAggDpw; ++i) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) x[i][e] = rp[i][e][c];
+          }
+        }
+      };
+      issue(0, xbuf[0]);
+      asm volatile("" ::: "memory");
+      uint32_t keep[kAggDpw][2];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        if (m + 1 < M) {
+          issue(m + 1, xbuf[(m + 1) & 1]);
+          asm volatile("" ::: "memory");            // the next group's loads are issued HERE, ahead of this group's draws
+        }
+        if constexpr (DROP) {
+          if ((m & 1) == 0) {                        // one draw serves groups m and m + 1 (its two halves)
+#pragma unroll
+            for (int i = 0; i < kAggDpw; ++i) {
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                keep[i][e] = 0;
+                if (ok[i][e] && m * kWave < pieces) {
+                  uint32_t o[4];
+                  Philox::gen(pos[i][e], (uint32_t)((m >> 1) * kWave + lane), g.d.tag, step, g.d.k0, g.d.k1, o);
+                  keep[i][e] = keep_bits(o, g.d.thr);
+                }
+              }
+            }
+          }
+        }
+        const int c = m * kWave + lane;
+        if (m < M - 1 || c < pieces) {
+#pragma unroll
+          for (int i = 0; i < kAggDpw; ++i) {
+            const int64_t v = r0 + G * (w + kAggWaves * i);
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              float4 xv = xbuf[m & 1][i][e];
+              if (!ok[i][e]) xv = make_float4(0.f, 0.f, 0.f, 0.f);
+              if constexpr (DROP) xv = keep_apply(xv, keep[i][e] >> (4 * (m & 1)), g.d.scale);
+              if constexpr (TAIL) {
+                if (c == pieces - 1) {
+                  if (tail < 2) xv.y = 0.f;
+                  if (tail < 3) xv.z = 0.f;
+                  xv.w = 0.f;
+                }
+              }
+              SV<4>::add(a, xv);
+            }
+            if (g.reduce == PG_REDUCE_MEAN && deg[i] > 0) SV<4>::div(a, (float)deg[i]);
+            if (v < n) store_row_piece(reinterpret_cast<float4*>(g.agg + v * g.agg_stride) + c, a, g.store_mode);
+            reinterpret_cast<float4*>(smem + (size_t)(w + kAggWaves * i) * as_stride)[c] = a;
+          }
+        }
+      }
+    } else {
+      // any degree: one destination at a time, k_spmm_fwd_rows_w's own loop (kept rolled: the fast path is the one that runs)
+#pragma unroll 1
+      for (int i = 0; i < kAggDpw; ++i) {
+        const int64_t v = r0 + G * (w + kAggWaves * i);
+        int32_t b0 = 0, e0 = 0;
+        if (v < n) {
+          b0 = indptr[v];
+          e0 = indptr[v + 1];
+        }
+        float4 acc[M];
+        bool any = false;
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rows_w_accumulate<DROP, TAIL, M, false, false>(rows, b0, e0, lane, pieces, tail, step, g.d, 0, 0, acc, any);
+        const float dg = (float)(e0 - b0);
+        float4* orow = reinterpret_cast<float4*>(g.agg + v * g.agg_stride);
+        float4* arow = reinterpret_cast<float4*>(smem + (size_t)(w + kAggWaves * i) * as_stride);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          const int c = m * kWave + lane;
+          if (m < M - 1 || c < pieces) {
+            if (g.reduce == PG_REDUCE_MEAN && e0 > b0) SV<4>::div(acc[m], dg);
+            if (v < n) store_row_piece(orow + c, acc[m], g.store_mode);
+            arow[c] = acc[m];                         // (rows past n: zeros — their outputs are never written)
+          }
+        }
+      }
     }
   }
-  if (g.reduce == PG_REDUCE_MEAN && a.deg > 0) {
-    const float dg = (float)a.deg;
-    acc.x /= dg; acc.y /= dg; acc.z /= dg; acc.w /= dg;
-  }
-  return acc;
-}
-
-__device__ __forceinline__ void agg_store(const AggArgs& g, int64_t r, int kc, const df4& v) {
-  store_row_piece(reinterpret_cast<float4*>(g.agg + r * g.agg_stride + kc), make_float4(v.x, v.y, v.z, v.w), g.store_mode);
-}
-
-template <int WV, int NW, bool DROP>
-__global__ __launch_bounds__(NW * 64, NW / 2) void k_agg_linear_fwd(const AggArgs g, const float* __restrict__ W /* [N][K] */,
-                                                        const float* __restrict__ bias, float* __restrict__ Y,
-                                                        int32_t y_stride, int64_t n, int32_t K, int32_t N, int32_t act) {
-  __shared__ __attribute__((aligned(16))) float smem[NW * kTile * kXsStride * (WV == 4 ? 2 : 1)];
-  __shared__ __attribute__((aligned(16))) AggRow s_rows[kTile];     // the tile's destinations, resolved once per block
-  float (*red)[kTile][kXsStride] = reinterpret_cast<float (*)[kTile][kXsStride]>(smem);
-  const uint32_t step = g.d.step ? (uint32_t)*g.d.step : 0u;
-  unsigned long long* pslot = prof_begin(g.prof, g.prof_ring, step, g.prof ? (unsigned long long)g.indptr[n] : 0ull);
-  if (threadIdx.x < kTile) s_rows[threadIdx.x] = agg_row_of(g, (int64_t)blockIdx.x * kTile + threadIdx.x, n);
-  __syncthreads();
-  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-  const int64_t r0 = (int64_t)blockIdx.x * kTile;
-  const int n0 = (int)blockIdx.y * kTile;
-  const int64_t row = r0 + (lane & 31);
+  // ---- phase 2: k_linear_fwd's K loop, A from LDS ----
   const int half = lane >> 5;
   const int octets = (K + 7) / 8;
-  const int o_beg = (octets * w) / NW, o_end = (octets * (w + 1)) / NW;
-  const bool row_ok = row < n;
-  const int col = n0 + (lane & 31);
-  const bool col_ok = col < N;
-  // blockIdx.y > 0 (N > 32): the second column tile recomputes the aggregation for its MFMAs but leaves the stores of
-  // `agg` to the first
-  const bool writer = blockIdx.y == 0;
-  // (per slab a lane fetches the pieces of four destinations: rows (lane >> 3) + 8 i of the tile, segment lane & 7)
-  const float* wr = W + (int64_t)(col_ok ? col : 0) * K + 4 * half;
-  f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  auto mma = [&](const df4& a, const df4& b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-  };
-  auto load_w = [&](int o, df4& b) {                 // k_linear_fwd's load1, W side
+  const int o_beg = (octets * w) / kAggWaves, o_end = (octets * (w + 1)) / kAggWaves;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const float* xa = smem + (size_t)(lane & 31) * as_stride + 4 * half;
+  auto load_w = [&](const float* wr, bool col_ok, int o, df4& b) {      // k_linear_fwd's load1, W side
     const int left = K - (o * 8 + 4 * half);
     b = df4{0.f, 0.f, 0.f, 0.f};
     if (left <= 0 || !col_ok) return;
@@ -457,153 +543,90 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_agg_linear_fwd(const AggArg
       b.w = 0.f;
     }
   };
-  int o = o_beg;
-  float* xs = smem + (size_t)w * kTile * kXsStride;
-  for (; o + 3 < o_end; o += 4) {
-    const int kbase = o * 8;
-    const int kc = kbase + (lane & 7) * 4;           // this lane's piece of the slab, the same for its four destinations
-    const int left = K - kc;
-    df4 x[4][kAggDeg];
+  // octets whose W fragments are in flight together: all of the wave's share at K = 600 (9-10 octets) with one column tile.
+  // The first batch is requested BEFORE the barrier that closes phase 1 (it does not depend on the aggregation): its
+  // latency passes while the block's slower waves finish their rows.
+  constexpr int OB = NT == 1 ? 10 : 5;
+  df4 b[NT][OB];
+  auto load_batch = [&](int ob) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const AggRow& ar = s_rows[(lane >> 3) + 8 * i];
+    for (int t = 0; t < NT; ++t) {
+      const int col = t * kTile + (lane & 31);
+      const bool col_ok = col < N;
+      const float* wr = W + (int64_t)(col_ok ? col : 0) * K + 4 * half;
 #pragma unroll
-      for (int e = 0; e < kAggDeg; ++e) {
-        x[i][e] = df4{0.f, 0.f, 0.f, 0.f};
-        const float* rp = ar.ptr[e];
-        if (left > 0 && rp) x[i][e] = *reinterpret_cast<const df4*>(rp + kc);
+      for (int i = 0; i < OB; ++i) {
+        b[t][i] = df4{0.f, 0.f, 0.f, 0.f};
+        if (ob + i < o_end) load_w(wr, col_ok, ob + i, b[t][i]);
       }
     }
-    df4 b0, b1, b2, b3;
-    df4 u[4];
-    if constexpr (WV == 4) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c = lane + 64 * i, cc = n0 + (c >> 3), kw = kbase + (c & 7) * 4;
-        u[i] = df4{0.f, 0.f, 0.f, 0.f};
-        if (cc < N && kw < K) u[i] = *reinterpret_cast<const df4*>(W + (int64_t)cc * K + kw);
-      }
-    } else {
-      load_w(o, b0);
-      load_w(o + 1, b1);
-      load_w(o + 2, b2);
-      load_w(o + 3, b3);
-    }
-    asm volatile("" ::: "memory");                   // every load of the slab is issued before the first Philox round
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (WV == 4) {                          // W's slab goes to LDS first: its registers are free for the draws
-      float* ws = smem + (size_t)(NW + w) * kTile * kXsStride;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c = lane + 64 * i;
-        *reinterpret_cast<df4*>(ws + (c >> 3) * kXsStride + (c & 7) * 4) = u[i];
-      }
-    }
-    // one destination at a time (scheduling barriers keep the four Philox groups from being interleaved: unrolled and
-    // interleaved they took 224 VGPRs, one 8-wave block per CU instead of two)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_sched_barrier(0);
-      df4 a = df4{0.f, 0.f, 0.f, 0.f};
-      if (left > 0) {
-        const AggRow ar = s_rows[(lane >> 3) + 8 * i];
-#pragma unroll
-        for (int e = 0; e < kAggDeg; ++e)
-          if (ar.ptr[e]) {
-            const df4 t = agg_term<DROP>(g, x[i][e], ar.pos[e], kc >> 2, left, step);
-            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
-          }
-        a = agg_finish<DROP>(g, a, ar, kc, left, step);
-        const int64_t r = r0 + (lane >> 3) + 8 * i;
-        if (writer && r < n) agg_store(g, r, kc, a);
-      }
-      const int c = lane + 64 * i;
-      *reinterpret_cast<df4*>(xs + (c >> 3) * kXsStride + (c & 7) * 4) = a;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if constexpr (WV == 4) {
-      const float* wa = smem + (size_t)(NW + w) * kTile * kXsStride + (lane & 31) * kXsStride + 4 * half;
-      b0 = *reinterpret_cast<const df4*>(wa);
-      b1 = *reinterpret_cast<const df4*>(wa + 8);
-      b2 = *reinterpret_cast<const df4*>(wa + 16);
-      b3 = *reinterpret_cast<const df4*>(wa + 24);
-    }
-    const float* xa = xs + (lane & 31) * kXsStride + 4 * half;
-    const df4 a0 = *reinterpret_cast<const df4*>(xa);
-    const df4 a1 = *reinterpret_cast<const df4*>(xa + 8);
-    const df4 a2 = *reinterpret_cast<const df4*>(xa + 16);
-    const df4 a3 = *reinterpret_cast<const df4*>(xa + 24);
-    mma(a0, b0);
-    mma(a1, b1);
-    mma(a2, b2);
-    mma(a3, b3);
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (o < o_end) {
-    // the wave's last 1-3 octets: lane (row, half) aggregates the 16-byte piece of ITS destination
-    const AggRow me = s_rows[lane & 31];
-    for (; o < o_end; ++o) {
-      const int kc = o * 8 + 4 * half;
-      const int left = K - kc;
-      df4 a = df4{0.f, 0.f, 0.f, 0.f}, b;
-      df4 xe[kAggDeg];
-#pragma unroll
-      for (int e = 0; e < kAggDeg; ++e) {
-        xe[e] = df4{0.f, 0.f, 0.f, 0.f};
-        if (left > 0 && me.ptr[e]) xe[e] = *reinterpret_cast<const df4*>(me.ptr[e] + kc);
-      }
-      load_w(o, b);
-      if (left > 0) {
-#pragma unroll
-        for (int e = 0; e < kAggDeg; ++e)
-          if (me.ptr[e]) {
-            const df4 t = agg_term<DROP>(g, xe[e], me.pos[e], kc >> 2, left, step);
-            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
-          }
-        a = agg_finish<DROP>(g, a, me, kc, left, step);
-        if (writer && row_ok) agg_store(g, row, kc, a);
-      }
-      if (!row_ok) a = df4{0.f, 0.f, 0.f, 0.f};
-      mma(a, b);
-    }
-  }
-  // C layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)   (the epilogue of k_linear_fwd)
-#pragma unroll
-  for (int r = 0; r < 16; ++r) red[w][(r & 3) + 8 * (r >> 2) + 4 * half][lane & 31] = acc[r];
+  };
+  load_batch(o_beg);
+  asm volatile("" ::: "memory");
   __syncthreads();
-  const int orow = threadIdx.x >> 3, oc = (threadIdx.x & 7) * 4;
-  if (threadIdx.x < 256 && r0 + orow < n) {
-    float v[4];
+  if (g.dbg && threadIdx.x == 0) g.dbg[blockIdx.x * 4 + 1] = wall_clock64();
+  for (int ob = o_beg; ob < o_end; ob += OB) {
+    if (ob != o_beg) load_batch(ob);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      v[j] = red[0][orow][oc + j] + red[1][orow][oc + j] + red[2][orow][oc + j] + red[3][orow][oc + j];
+    for (int i = 0; i < OB; ++i) {
+      if (ob + i < o_end) {                           // wave-uniform
+        // columns in [K, 4 * pieces) of an LDS row are zeros (the TAIL mask of the aggregation); a quad wholly past K is
+        // not read (as_stride >= 4 * pieces only)
+        df4 a = df4{0.f, 0.f, 0.f, 0.f};
+        if (K - ((ob + i) * 8 + 4 * half) > 0) a = *reinterpret_cast<const df4*>(xa + (ob + i) * 8);
 #pragma unroll
-      for (int ww = 4; ww < NW; ++ww) v[j] += red[ww][orow][oc + j];
-      if (bias && n0 + oc + j < N) v[j] += bias[n0 + oc + j];
-    }
-    float* yr = Y + (r0 + orow) * y_stride + n0 + oc;
-    const bool vec_ok = (N & 3) == 0 && (y_stride & 3) == 0 && n0 + oc + 3 < N;
-    if (act == 1) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
-    }
-    if (vec_ok) {
-      *reinterpret_cast<df4*>(yr) = df4{v[0], v[1], v[2], v[3]};
-      if (act == 2)
-        *reinterpret_cast<df4*>(yr + N) = df4{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f,
-                                              v[2] > 0.f ? v[2] : 0.f, v[3] > 0.f ? v[3] : 0.f};
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (n0 + oc + j < N) {
-          yr[j] = v[j];
-          if (act == 2) yr[N + j] = v[j] > 0.f ? v[j] : 0.f;
+        for (int t = 0; t < NT; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t][i].x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t][i].y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t][i].z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t][i].w, acc[t], 0, 0, 0);
         }
+      }
     }
   }
+  if (g.dbg && threadIdx.x == 0) g.dbg[blockIdx.x * 4 + 2] = wall_clock64();
+  // ---- phase 3: k_linear_fwd's epilogue per column tile (the partial tiles reuse the A operand's LDS) ----
+  float (*red)[kTile][kXsStride] = reinterpret_cast<float (*)[kTile][kXsStride]>(smem);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    __syncthreads();                                  // every wave is done with the A operand / the previous tile's partials
+    // C layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[w][(r & 3) + 8 * (r >> 2) + 4 * half][lane & 31] = acc[t][r];
+    __syncthreads();
+    const int n0 = t * kTile;
+    const int orow = threadIdx.x >> 3, oc = (threadIdx.x & 7) * 4;
+    if (threadIdx.x < 256 && r0 + G * orow < n) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = red[0][orow][oc + j] + red[1][orow][oc + j] + red[2][orow][oc + j] + red[3][orow][oc + j];
+#pragma unroll
+        for (int ww = 4; ww < kAggWaves; ++ww) v[j] += red[ww][orow][oc + j];
+        if (bias && n0 + oc + j < N) v[j] += bias[n0 + oc + j];
+      }
+      float* yr = Y + (r0 + G * orow) * y_stride + n0 + oc;
+      const bool vec_ok = (N & 3) == 0 && (y_stride & 3) == 0 && n0 + oc + 3 < N;
+      if (act == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+      }
+      if (vec_ok) {
+        *reinterpret_cast<df4*>(yr) = df4{v[0], v[1], v[2], v[3]};
+        if (act == 2)
+          *reinterpret_cast<df4*>(yr + N) = df4{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f,
+                                                v[2] > 0.f ? v[2] : 0.f, v[3] > 0.f ? v[3] : 0.f};
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n0 + oc + j < N) {
+            yr[j] = v[j];
+            if (act == 2) yr[N + j] = v[j] > 0.f ? v[j] : 0.f;
+          }
+      }
+    }
+  }
+  if (g.dbg && threadIdx.x == 0) g.dbg[blockIdx.x * 4 + 3] = wall_clock64();
   prof_end(pslot);
 }
 
@@ -776,7 +799,14 @@ static inline int bwd_rows_per_wave(int64_t n, int32_t K, int32_t N) {
 
 using namespace pg;
 
+static unsigned long long* g_agg_dbg = nullptr;
+
 extern "C" {
+
+int pg_debug_agg_stamps(uint64_t* p) {   // experiment hook (tools/exp_agg_dense.py): 4 stamps per block of k_agg_dense_fwd
+  g_agg_dbg = reinterpret_cast<unsigned long long*>(p);
+  return PG_OK;
+}
 
 // a row source's envelope for the dense kernels: 16-byte aligned rows in both homes
 static int rows_arg(const pg_row_source_t* X, int32_t K, const float** base, int32_t* stride, RowsArg* ra) {
@@ -888,7 +918,7 @@ int pg_agg_linear_fwd(const int32_t* indptr, const int32_t* src, const pg_row_so
   const int32_t k4 = (K + 3) & ~3;
   // the envelope of pg_spmm_fwd_rows (wide rows of whole 16-byte pieces) and of pg_linear_fwd (N <= 64); K >= 256 is also
   // what makes the dense kernel split K over 8 waves, the split this kernel reproduces
-  if (K < 256 || N > 2 * kTile || agg_stride < k4 || (agg_stride & 3) || (reinterpret_cast<uintptr_t>(agg) & 15))
+  if (K < 256 || k4 > 1024 || N > 2 * kTile || agg_stride < k4 || (agg_stride & 3) || (reinterpret_cast<uintptr_t>(agg) & 15))
     return PG_ERR_UNSUPPORTED;
   if (rows->cache && (rows->cache_stride < k4 || (rows->cache_stride & 3) || (reinterpret_cast<uintptr_t>(rows->cache) & 15)))
     return PG_ERR_UNSUPPORTED;
@@ -897,8 +927,6 @@ int pg_agg_linear_fwd(const int32_t* indptr, const int32_t* src, const pg_row_so
   if (n_dst == 0) return PG_OK;
   if (!indptr || !src || !rows->slots || !W || !agg || !Y) return PG_ERR_INVALID;
   AggArgs g{};
-  g.indptr = indptr; g.src = src; g.slots = rows->slots; g.edge_slots = rows->edge_slots;
-  g.cache = rows->cache; g.staged = rows->staged;
   g.cache_stride = rows->cache_stride; g.staged_stride = rows->staged_stride;
   g.reduce = reduce; g.agg = agg; g.agg_stride = agg_stride;
   static const int store_mode = fwd_rows_store_mode();
@@ -910,22 +938,55 @@ int pg_agg_linear_fwd(const int32_t* indptr, const int32_t* src, const pg_row_so
   }
   g.prof = reinterpret_cast<unsigned long long*>(prof);
   g.prof_ring = prof_ring;
+  g.dbg = g_agg_dbg;
   const uintptr_t wa = reinterpret_cast<uintptr_t>(W);
   const int wv = (K % 4 == 0 && !(wa & 15)) ? 4 : ((K % 2 == 0 && !(wa & 7)) ? 2 : 1);
-  const dim3 grid((unsigned)ceil_div<int64_t>(n_dst, kTile), (unsigned)ceil_div<int>(N, kTile));
-#define PG_AGG_LIN(WV)                                                                                                 \
+  // Tiles are STRIDED: tile t owns destinations t, t + G, t + 2 G, ... (at most 32 of them). With G = 512 — two blocks per CU
+  // on 256 CUs, the residency the LDS tile allows — every CU carries the same number of rows however many the launch has
+  // (9 532 real rows are 298 contiguous tiles: 42 CUs with two of them finish 50 % after the others), and the empty
+  // padding rows at the end of a fixed-shape layer are dealt evenly to all tiles instead of forming blocks of their own.
+  const int64_t g32 = ceil_div<int64_t>(n_dst, kTile);
+  static const int tiles_cfg = getenv("PG_AGG_TILES") ? atoi(getenv("PG_AGG_TILES")) : 512;
+  const int64_t G = (tiles_cfg > 0 && n_dst >= 4096 && g32 < tiles_cfg) ? tiles_cfg : g32;
+  const dim3 grid((unsigned)G);
+  const int32_t as_stride = agg_as_stride(K);
+  size_t lds = (size_t)kTile * as_stride * sizeof(float);
+  const size_t lds_red = (size_t)kAggWaves * kTile * kXsStride * sizeof(float);
+  if (lds < lds_red) lds = lds_red;
+  const bool tail = (K & 3) != 0;
+  const int nt = N > kTile ? 2 : 1;
+  // one instantiation per (W access width, dropout, ragged K, pieces per lane, column tiles); each may use > 64 KB of LDS
+#define PG_AGG_K(WV, DROP, TAIL, M, NT)                                                                                \
   do {                                                                                                                 \
-    if (has_drop)                                                                                                      \
-      hipLaunchKernelGGL((k_agg_linear_fwd<WV, 8, true>), grid, dim3(512), 0, as_stream(stream), g, W, bias, Y, y_stride, \
-                         n_dst, K, N, act);                                                                            \
-    else                                                                                                               \
-      hipLaunchKernelGGL((k_agg_linear_fwd<WV, 8, false>), grid, dim3(512), 0, as_stream(stream), g, W, bias, Y,       \
-                         y_stride, n_dst, K, N, act);                                                                  \
+    auto kfn = k_agg_dense_fwd<WV, DROP, TAIL, M, NT>;                                                                 \
+    static bool attr_set = false;                                                                                      \
+    if (!attr_set) {                                                                                                   \
+      PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                 160 * 1024 - 256));                                                                   \
+      attr_set = true;                                                                                                 \
+    }                                                                                                                  \
+    hipLaunchKernelGGL(kfn, grid, dim3(kAggWaves * 64), lds, as_stream(stream), indptr, src, rows->slots,            \
+                       rows->edge_slots, rows->cache, rows->staged, g, W, bias, Y, y_stride, n_dst, K, N, act,       \
+                       as_stride);                                                                                \
   } while (0)
-  if (wv == 4) PG_AGG_LIN(4);
-  else if (wv == 2) PG_AGG_LIN(2);
-  else PG_AGG_LIN(1);
-#undef PG_AGG_LIN
+#define PG_AGG_NT(WV, DROP, TAIL, M) \
+  do { if (nt == 2) PG_AGG_K(WV, DROP, TAIL, M, 2); else PG_AGG_K(WV, DROP, TAIL, M, 1); } while (0)
+#define PG_AGG_M(WV, DROP, TAIL)                                  \
+  do {                                                            \
+    if (k4 <= 512) PG_AGG_NT(WV, DROP, TAIL, 2);                  \
+    else if (k4 <= 768) PG_AGG_NT(WV, DROP, TAIL, 3);             \
+    else PG_AGG_NT(WV, DROP, TAIL, 4);                            \
+  } while (0)
+#define PG_AGG_D(WV, TAIL) \
+  do { if (has_drop) PG_AGG_M(WV, true, TAIL); else PG_AGG_M(WV, false, TAIL); } while (0)
+  // (a ragged K is never 16-byte aligned per weight row: WV 4 implies !tail)
+  if (wv == 4) PG_AGG_D(4, false);
+  else if (wv == 2) { if (tail) PG_AGG_D(2, true); else PG_AGG_D(2, false); }
+  else { if (tail) PG_AGG_D(1, true); else PG_AGG_D(1, false); }
+#undef PG_AGG_D
+#undef PG_AGG_M
+#undef PG_AGG_NT
+#undef PG_AGG_K
   PG_LAUNCH_CHECK();
   if (g.prof) {                 // the next dense / head launch of this thread stamps this entry's word [1]
     g_prof_succ.ring = g.prof;

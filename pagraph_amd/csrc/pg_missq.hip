@@ -649,10 +649,13 @@ static void missq_worker(pg_missq* q) {
         const size_t copy_bytes = (size_t)m * srow * sizeof(float);    // what crosses PCIe (padding included: < 1 %)
         float* stg = s.staging_h[f];
         const int64_t* ids = s.fullid_h;
-        // PG_MISSQ_PREFETCH=<rows ahead>,<bytes of that row>: default 2 rows ahead, 256 bytes
-        static const int pf_dist = getenv("PG_MISSQ_PREFETCH") ? std::max(1, atoi(getenv("PG_MISSQ_PREFETCH"))) : 2;
+        // PG_MISSQ_PREFETCH=<rows ahead>,<bytes of that row>: default 6 rows ahead, the whole row (up to 4 KB). Round 4: a
+        // thread that only had the head (256 bytes) of the row after next on its way spent its time waiting for DRAM — with
+        // six whole rows in flight per thread the same gather takes 80 us instead of 100-114 on 12 threads, 119-135 on 6
+        // (the step stays on its PCIe floor with half the threads), 280 instead of 508 on 2 (profiles/r04/host_gather_sweep.txt).
+        static const int pf_dist = getenv("PG_MISSQ_PREFETCH") ? std::max(1, atoi(getenv("PG_MISSQ_PREFETCH"))) : 6;
         static const size_t pf_cfg = (getenv("PG_MISSQ_PREFETCH") && strchr(getenv("PG_MISSQ_PREFETCH"), ','))
-                                         ? (size_t)atol(strchr(getenv("PG_MISSQ_PREFETCH"), ',') + 1) : 256;
+                                         ? (size_t)atol(strchr(getenv("PG_MISSQ_PREFETCH"), ',') + 1) : 4096;
         const size_t pf_bytes = std::min(pf_cfg, row_bytes);
         const auto ta = now();
         // a straggler of this slot's PREVIOUS job (a re-executed chunk's original owner) may still be copying into
@@ -681,6 +684,10 @@ static void missq_worker(pg_missq* q) {
         const int64_t tstride = fd.table_stride;
         const int pfd = pf_dist;
         s.gather_ticket[f] = q->pool->parallel_for(m, [=](int64_t lo, int64_t hi) {   // storage.py:128 table[nids]
+          for (int64_t j = lo; j < hi && j < lo + pfd; ++j) {     // the chunk's first rows: all on their way before the first copy
+            const char* nx = reinterpret_cast<const char*>(table + ids[j] * tstride);
+            for (size_t b = 0; b < pf_bytes; b += 64) __builtin_prefetch(nx + b, 0, 0);
+          }
           for (int64_t j = lo; j < hi; ++j) {
             if (j + pfd < hi) {   // rows are random DRAM pages: start a later one while this one streams
               const char* nx = reinterpret_cast<const char*>(table + ids[j + pfd] * tstride);

@@ -16,25 +16,10 @@
 #include <cstring>
 
 #include "pg_common.h"
+#include "pg_rows_w.h"
 
 namespace pg {
 
-template <int VEC>
-struct SV;
-template <>
-struct SV<4> {
-  using type = float4;
-  __device__ static inline float4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-  __device__ static inline void add(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
-  __device__ static inline void div(float4& a, float d) { a.x /= d; a.y /= d; a.z /= d; a.w /= d; }
-  __device__ static inline float4 fill(float f) { return make_float4(f, f, f, f); }
-  __device__ static inline void mx(float4& a, const float4& b) { a.x = fmaxf(a.x, b.x); a.y = fmaxf(a.y, b.y); a.z = fmaxf(a.z, b.z); a.w = fmaxf(a.w, b.w); }
-  // b where x == o (component-wise), else 0: the max reducer's backward routes a destination's gradient to every in-edge
-  // whose message equals the maximum
-  __device__ static inline float4 where_eq(const float4& x, const float4& o, const float4& b) {
-    return make_float4(x.x == o.x ? b.x : 0.f, x.y == o.y ? b.y : 0.f, x.z == o.z ? b.z : 0.f, x.w == o.w ? b.w : 0.f);
-  }
-};
 template <>
 struct SV<2> {
   using type = float2;
@@ -59,7 +44,6 @@ struct SV<1> {
 };
 
 constexpr int kMaxAcc = 4;
-constexpr float kNegInf = -__builtin_huge_valf();
 
 // MAXR (PG_REDUCE_MAX, graphsage_nssc.py:106-110 'pool'): out[v] = element-wise maximum of v's in-edge messages in place of
 // their sum; a destination without in-edges gets zeros like the other reducers.
@@ -144,25 +128,6 @@ __global__ __launch_bounds__(256) void k_spmm_bwd(const int32_t* __restrict__ in
 //   u16     = 16 bits of w[2 * half + j / 2], low half-word for even j, high for odd j
 //   keep iff u16 >= threshold;  kept values are multiplied by scale = 65536 / (65536 - threshold).
 // (pieces p and p + 64 share one Philox call: with 64 lanes on a row, lane l owns pieces l, l + 64, ...)
-// drop_apply in two steps: the 8 keep-bits of a draw (bit i: column i of the first piece, bit 4 + i: of the second) ...
-__device__ __forceinline__ uint32_t keep_bits(const uint32_t (&o)[4], uint32_t thr) {
-  uint32_t k = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    k |= ((o[i] & 0xffffu) >= thr ? 1u : 0u) << (2 * i);
-    k |= ((o[i] >> 16) >= thr ? 1u : 0u) << (2 * i + 1);
-  }
-  return k;
-}
-// ... and their application: the same products and zeros as drop_apply(x, o, half, thr, scale) with bits >> 4 * half
-__device__ __forceinline__ float4 keep_apply(float4 x, uint32_t bits, float scale) {
-  x.x = (bits & 1u) ? x.x * scale : 0.f;
-  x.y = (bits & 2u) ? x.y * scale : 0.f;
-  x.z = (bits & 4u) ? x.z * scale : 0.f;
-  x.w = (bits & 8u) ? x.w * scale : 0.f;
-  return x;
-}
-
 template <bool MAXR>
 __global__ __launch_bounds__(256) void k_spmm_fwd_drop(const int32_t* __restrict__ indptr,
                                                        const int32_t* __restrict__ src,
@@ -346,8 +311,6 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict
 //  * two source rows (the sampler's fan-out) x M pieces in flight per wave and M accumulators — no dead register slots
 //    for pieces the row does not have — which is what lets 8 waves share a SIMD (the generic kernel: 126 VGPRs, 4 waves);
 //  * a row's Philox draws are issued between the loads and their first use.
-constexpr int kRowsPair = 2;
-
 template <bool DROP, bool TAIL, int M, bool MAXR>
 __global__ __launch_bounds__(256) void k_spmm_fwd_rows_w(const int32_t* __restrict__ indptr,
                                                          const int32_t* __restrict__ src,
@@ -372,81 +335,8 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows_w(const int32_t* __restri
     bool any = false;            // MAXR: a row was taken
 #pragma unroll
     for (int m = 0; m < M; ++m) acc[m] = MAXR ? S::fill(kNegInf) : S::zero();
-    for (int32_t eb = beg; eb < end; eb += kWave) {
-      const int ne = end - eb < kWave ? end - eb : kWave;
-      int32_t my_p = 0, my_s = -2;
-      if (lane < ne) {
-        my_p = src[eb + lane];
-        my_s = edge_slots ? edge_slots[eb + lane] : slots[my_p];
-      }
-      for (int e0 = 0; e0 < ne; e0 += kRowsPair) {
-        float4 x[kRowsPair][M];
-        int32_t srp[kRowsPair], sl[kRowsPair];
-        bool ok[kRowsPair];
-        // all of the pair's lane reads first: they wait for the index loads, and must not wait for a row load
-#pragma unroll
-        for (int j = 0; j < kRowsPair; ++j) {
-          const int e = e0 + j < ne ? e0 + j : ne - 1;
-          sl[j] = __builtin_amdgcn_readlane(my_s, e);
-          srp[j] = __builtin_amdgcn_readlane(my_p, e);
-          ok[j] = e0 + j < ne && sl[j] != -1 && sl[j] != -2;   // padding / an unresolved miss contributes nothing
-        }
-#pragma unroll
-        for (int j = 0; j < kRowsPair; ++j) {
-          if (ok[j]) {
-            const float4* hrow = sl[j] >= 0
-                                     ? reinterpret_cast<const float4*>(cache + (int64_t)sl[j] * cache_stride)
-                                     : reinterpret_cast<const float4*>(staged + (int64_t)(-sl[j] - 3) * staged_stride);
-#pragma unroll
-            for (int m = 0; m < M; ++m) {
-              const int c = m * kWave + lane;
-              if (m < M - 1 || c < pieces) x[j][m] = hrow[c];   // the launcher picks M = ceil(pieces / 64)
-            }
-          }
-        }
-        asm volatile("" ::: "memory");   // the row loads are issued HERE, not sunk to their use behind the draws
-        // every draw of both rows happens between the loads' issue and their first use; what is kept of a draw is its
-        // 8 keep-bits (two pieces x 4 columns): pieces lane + 64 mm and lane + 64 (mm + 1) share one draw (its two
-        // halves), q = (c >> 7) << 6 | (c & 63) — the counters of pg_spmm_fwd_drop
-        uint32_t keep[kRowsPair][(M + 1) / 2];
-        if constexpr (DROP) {
-#pragma unroll
-          for (int j = 0; j < kRowsPair; ++j) {
-#pragma unroll
-            for (int mm = 0; mm < M; mm += 2) {
-              keep[j][mm >> 1] = 0;
-              if (ok[j] && mm * kWave < pieces) {
-                uint32_t o[4];
-                Philox::gen((uint32_t)srp[j], (uint32_t)((mm >> 1) * kWave + lane), d.tag, step, d.k0, d.k1, o);
-                keep[j][mm >> 1] = keep_bits(o, d.thr);
-              }
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < kRowsPair; ++j) {
-          if (!ok[j]) continue;
-          if constexpr (MAXR) any = true;
-#pragma unroll
-          for (int m = 0; m < M; ++m) {
-            const int c = m * kWave + lane;
-            if (m < M - 1 || c < pieces) {
-              float4 xv = x[j][m];
-              if constexpr (DROP) xv = keep_apply(xv, keep[j][m >> 1] >> (4 * (m & 1)), d.scale);
-              if constexpr (TAIL) {
-                if (c == pieces - 1) {
-                  if (tail < 2) xv.y = 0.f;
-                  if (tail < 3) xv.z = 0.f;
-                  xv.w = 0.f;
-                }
-              }
-              if constexpr (MAXR) S::mx(acc[m], xv);
-              else S::add(acc[m], xv);
-            }
-          }
-        }
-      }
-    }
+    const RowsW rw{src, slots, edge_slots, cache, staged, cache_stride, staged_stride};
+    rows_w_accumulate<DROP, TAIL, M, MAXR, false>(rw, beg, end, lane, pieces, tail, step, d, 0, 0, acc, any);
     const float dg = (float)(end - beg);
     float4* orow = reinterpret_cast<float4*>(out + v * out_stride);
 #pragma unroll

@@ -147,7 +147,7 @@ class NeighborSampler:
                     "pg_sampler_create")
         self.handle = h
         import os as _os
-        self.stream = torch.cuda.Stream(device=self.device, priority=int(_os.environ.get("PG_PRIO_SAMPLER", -1)))   # ~12 tiny latency-bound launches
+        self.stream = L.pipeline_stream(self.device, "side", int(_os.environ.get("PG_PRIO_SAMPLER", -1)))   # ~12 tiny latency-bound launches
         # stream on which the consumer finishes with a NodeFlow (None = current stream at hand-back);
         # a ring slot is re-sampled only after the event recorded there
         self.consumer_stream = None

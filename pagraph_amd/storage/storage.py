@@ -151,7 +151,9 @@ def default_host_threads(world_size=1):
             cpus = min(cpus, max(1, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
-    return max(2, min(16, (cpus - 4 * max(1, world_size)) // max(1, world_size) if cpus > 8 else cpus // 2))
+    # Round 4: with six whole rows prefetched per thread (pg_missq.hip) 6 threads keep the step on its PCIe floor (0.1506-0.152
+    # ms/step for every prefetch setting tried, 7.8 CPUs busy instead of 13.4 with 12 threads): at most 8.
+    return max(2, min(8, (cpus - 4 * max(1, world_size)) // max(1, world_size) if cpus > 8 else cpus // 2))
 
 
 # How a consumer stream is ordered after the async queue's miss rows. Default: on the DEVICE — an event when the worker has
@@ -280,10 +282,20 @@ class GraphCacheServer:
         print('total dims: {}'.format(self.total_dim))
 
     # -- storage.py:70-104 ----------------------------------------------------
-    def auto_cache(self, dgl_g, embed_names, cache_ratio=None):
+    def auto_cache(self, dgl_g, embed_names, cache_ratio=None, policy="degree", freq=None):
         """Reference rule: capability = (total - peak_alloc - peak_reserved - 1 GiB) / (4*total_dim).
         `cache_ratio` (fraction of node_num) overrides it — the reference keeps such overrides
-        commented out at storage.py:85-86; on a 288 GB MI355X the rule alone caches everything."""
+        commented out at storage.py:85-86; on a 288 GB MI355X the rule alone caches everything.
+        `policy`: 'degree' (default) = the reference's rule, the `capability` highest out-degree vertices
+        (storage.py:97-104). 'presample' (opt-in, beyond the reference): the `capability` vertices a presampled epoch
+        looked up most often — `freq` = analysis.access_frequency(...)[0] over the layers the loop fetches, i.e. the
+        ORDER examples/opt_cache_hit.py:22-31 evaluates as its upper bound, made the policy; ties (the many vertices
+        never seen) fall back to the degree order. On a GPU the sampler does an epoch in tens of milliseconds, which is
+        what makes the oracle's order affordable at start-up."""
+        if policy not in ("degree", "presample"):
+            raise ValueError(f"unknown cache policy {policy!r}")
+        if policy == "presample" and freq is None:
+            raise ValueError("policy='presample' needs freq (analysis.access_frequency over a presampled epoch)")
         peak_allocated_mem = torch.cuda.max_memory_allocated(device=self.device)
         peak_cached_mem = torch.cuda.max_memory_reserved(device=self.device)
         total_mem = torch.cuda.get_device_properties(self.device).total_memory
@@ -311,6 +323,14 @@ class GraphCacheServer:
             out_degrees = torch.as_tensor(dgl_g.out_degrees()).to(self.device)
             # descending by out-degree; ties -> lower id first (the reference's torch.argsort is unstable)
             sort_nid = torch.argsort(out_degrees, descending=True, stable=True)
+            if policy == "presample":
+                f = torch.as_tensor(freq).to(self.device, torch.int64)
+                if f.numel() != self.node_num:
+                    raise ValueError("freq must have one entry per vertex of the partition")
+                # most looked-up first; among equals the degree order (a stable sort of the degree order by frequency)
+                sort_nid = sort_nid[torch.argsort(f[sort_nid], descending=True, stable=True)]
+                print('cache policy: presampled access frequency ({} of {} vertices seen)'.format(
+                    int((f > 0).sum()), self.node_num))
             cache_nid = sort_nid[:self.capability]
             self._fill_cache(cache_nid, embed_names, is_full=False, chunk_rows=chunk_rows)
 

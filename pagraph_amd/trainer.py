@@ -250,10 +250,10 @@ class GraphedTrainer:
         self.device = device
         # high priority: the short HBM-bound gather should not queue behind the compute stream's GEMMs
         import os as _os
-        self.load_stream = torch.cuda.Stream(device=device, priority=int(_os.environ.get("PG_PRIO_LOAD", -1)))
+        self.load_stream = L.pipeline_stream(device, "side", int(_os.environ.get("PG_PRIO_LOAD", -1)))
         # eager warm-up, capture and replay all run on ONE non-default stream, so autograd's
         # AccumulateGrad nodes and the captured graphs agree on the stream
-        self.compute_stream = torch.cuda.Stream(device=device, priority=int(_os.environ.get("PG_PRIO_COMPUTE", 0)))
+        self.compute_stream = L.pipeline_stream(device, "compute", int(_os.environ.get("PG_PRIO_COMPUTE", 0)))
         sampler.consumer_stream = self.compute_stream   # ring slots are recycled after the graph that read them
         sampler.manual_release = True
         # the sampler's own "slot free" event (recorded on the compute stream by sampler.release right after the step)

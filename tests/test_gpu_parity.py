@@ -100,6 +100,47 @@ def test_auto_cache_vs_reference_golden(dev, hiplib, golden_dir, tag, monkeypatc
     assert np.array_equal(c.gpu_fix_cache["norm"].cpu().numpy(), z["cache_norm"])
 
 
+def test_auto_cache_presample_policy(dev, hiplib, golden_dir, monkeypatch):
+    """auto_cache(policy='presample'): the `capability` most looked-up vertices, ties in the reference's degree order; fetches
+    stay bit-exact; the default policy is untouched (the G5 test above); on its own trace it reaches opt_cache_hit.py's bound"""
+    import types
+    from pagraph_amd import analysis
+    z = np.load(os.path.join(golden_dir, "g5_auto_cache_partial.npz"))
+    c = _cacher(z, dev)
+    monkeypatch.setattr(torch.cuda, "max_memory_allocated", lambda device=None: int(z["peak_allocated"]))
+    monkeypatch.setattr(torch.cuda, "max_memory_reserved", lambda device=None: int(z["peak_cached"]))
+    monkeypatch.setattr(torch.cuda, "get_device_properties",
+                        lambda d: types.SimpleNamespace(total_memory=int(z["total_memory"])))
+    deg = z["out_degrees"]
+    V = len(deg)
+    g = types.SimpleNamespace(out_degrees=lambda: torch.from_numpy(deg))
+    rng = np.random.default_rng(5)
+    freq = np.zeros(V, np.int64)
+    seen = rng.choice(V, V // 3, replace=False)
+    freq[seen] = rng.integers(1, 6, len(seen))               # many ties, two thirds never seen
+    with pytest.raises(ValueError):
+        c.auto_cache(g, ["features", "norm"], policy="presample")
+    c.auto_cache(g, ["features", "norm"], policy="presample", freq=torch.from_numpy(freq))
+    cap = int(z["capability"])
+    assert c.cached_num == cap and not c.full_cached
+    by_deg = np.argsort(-deg, kind="stable")
+    want = by_deg[np.argsort(-freq[by_deg], kind="stable")][:cap]
+    l2c = c.localid2cacheid.cpu().numpy()
+    assert np.array_equal(np.flatnonzero(c.gpu_flag.cpu().numpy()), np.sort(want))
+    assert np.array_equal(l2c[want], np.arange(cap))
+    assert np.array_equal(c.gpu_fix_cache["features"].cpu().numpy(), z["features_table"][z["nid_map"][want]])
+    ids = rng.integers(0, V, 500).astype(np.int64)
+    nf = FakeNF([ids], dev)
+    c.fetch_data(nf)
+    torch.cuda.synchronize()
+    assert np.array_equal(nf._node_frames[0]["features"].cpu().numpy(), z["features_table"][z["nid_map"][ids]])
+    f = torch.from_numpy(freq).to(dev)
+    d = torch.from_numpy(deg).to(dev)
+    ratio = cap / V
+    assert abs(analysis.presample_cache_hit(f, f, d, ratio) - analysis.optimal_cache_hit(f, ratio)) < 1e-12
+    assert analysis.presample_cache_hit(f, f, d, ratio) >= analysis.degree_cache_hit(f, d, ratio)
+
+
 @pytest.mark.parametrize("n,F,ratio", [(1, 600, 0.5), (63, 600, 0.0), (64, 602, 1.0), (65, 600, 0.3), (4097, 128, 0.3),
                                         (50000, 600, 0.3), (600000, 64, 0.7), (1000, 7, 0.5), (1000, 33, 0.5)])
 def test_gather_vs_oracle_random(dev, hiplib, oracle, n, F, ratio):
