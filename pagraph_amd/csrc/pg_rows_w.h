@@ -105,16 +105,34 @@ __device__ __forceinline__ void rows_w_accumulate(const RowsW& r, int32_t beg, i
       // halves), q = (c >> 7) << 6 | (c & 63) — the counters of pg_spmm_fwd_drop
       uint32_t keep[kRowsPair][(M + 1) / 2];
       if constexpr (DROP) {
+        // An odd M's last column group is at most half a draw wide; when it is also at most 32 pieces wide (K = 600: pieces
+        // 128..149) only lanes 0..31 hold a piece of it, so ONE draw serves both rows of the pair: lanes 0..31 draw for row 0,
+        // lanes 32..63 — with the counters of lanes 0..31 — for row 1, whose bits then move down 32 lanes. Same counters, same
+        // bits; three draws per pair of rows instead of four (the draws are a quarter-rate multiply chain: the kernel's whole
+        // ALU bill).
+        const bool packed = (M & 1) && kRowsPair == 2 && pieces - (M - 1) * kWave <= 32;
 #pragma unroll
         for (int j = 0; j < kRowsPair; ++j) {
 #pragma unroll
           for (int mm = 0; mm < M; mm += 2) {
             keep[j][mm >> 1] = 0;
+            if (packed && mm == M - 1) continue;
             if (ok[j] && mm * kWave < pieces) {
               uint32_t o[4];
               Philox::gen((uint32_t)srp[j], (uint32_t)((mm >> 1) * kWave + lane), d.tag, step, d.k0, d.k1, o);
               keep[j][mm >> 1] = keep_bits(o, d.thr);
             }
+          }
+        }
+        if constexpr ((M & 1) != 0) {
+          if (packed && (ok[0] || ok[kRowsPair - 1])) {
+            const uint32_t row = lane < 32 ? (uint32_t)srp[0] : (uint32_t)srp[kRowsPair - 1];
+            uint32_t o[4];
+            Philox::gen(row, (uint32_t)(((M - 1) >> 1) * kWave + (lane & 31)), d.tag, step, d.k0, d.k1, o);
+            const uint32_t kb = keep_bits(o, d.thr);
+            const uint32_t kb_hi = (uint32_t)__shfl_down((int)kb, 32, kWave);
+            keep[0][(M - 1) >> 1] = ok[0] ? kb : 0u;
+            keep[kRowsPair - 1][(M - 1) >> 1] = ok[kRowsPair - 1] ? kb_hi : 0u;
           }
         }
       }

@@ -141,6 +141,28 @@ def test_auto_cache_presample_policy(dev, hiplib, golden_dir, monkeypatch):
     assert analysis.presample_cache_hit(f, f, d, ratio) >= analysis.degree_cache_hit(f, d, ratio)
 
 
+@pytest.mark.parametrize("n", [1, 63, 1000, 6000, 16384, 16385, 50000])
+def test_gather_labels_and_valid_count(dev, hiplib, n):
+    """pg_gather_labels == labels[batch_nids] (pa_gcn.py:99-100) with the padding ids of a fixed-shape batch mapped to the
+    loss's ignore_index, + the number of rows the loss counts — written, not accumulated: the count word holds garbage before
+    the call (one workgroup up to 16 K ids, the multi-block kernel behind a zero fill above)"""
+    from pagraph_amd import _lib as L
+    rng = np.random.default_rng(n)
+    V = 5000
+    labels = torch.from_numpy(rng.integers(0, 41, V)).to(dev)
+    ids = rng.integers(0, V, n)
+    ids[rng.random(n) < 0.2] = -1                                 # padding
+    d_ids = torch.from_numpy(ids).to(dev)
+    out = torch.full((n,), 7777, dtype=torch.int64, device=dev)
+    cnt = torch.full((1,), 123456, dtype=torch.int32, device=dev)
+    for _ in range(2):                                            # the second call must not add to the first one's count
+        L.check(hiplib.pg_gather_labels(L.ptr(d_ids), n, L.ptr(labels), V, -100, L.ptr(out), L.ptr(cnt), L.stream_ptr()))
+    torch.cuda.synchronize()
+    want = np.where(ids >= 0, labels.cpu().numpy()[np.maximum(ids, 0)], -100)
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert int(cnt.item()) == int((ids >= 0).sum())
+
+
 @pytest.mark.parametrize("n,F,ratio", [(1, 600, 0.5), (63, 600, 0.0), (64, 602, 1.0), (65, 600, 0.3), (4097, 128, 0.3),
                                         (50000, 600, 0.3), (600000, 64, 0.7), (1000, 7, 0.5), (1000, 33, 0.5)])
 def test_gather_vs_oracle_random(dev, hiplib, oracle, n, F, ratio):

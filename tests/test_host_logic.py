@@ -221,11 +221,13 @@ def test_default_host_threads_respects_the_cpu_quota(monkeypatch, tmp_path):
 
     monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)), raising=False)
     monkeypatch.setattr(builtins, "open", fake("1600000 100000\n"))
-    assert st.default_host_threads() == 12             # 16-CPU quota on a 256-core box
+    assert st.default_host_threads() == 8              # 16-CPU quota on a 256-core box: capped (round 4: 6 threads suffice)
     assert st.default_host_threads(8) == 2             # eight ranks share it
+    monkeypatch.setattr(builtins, "open", fake("800000 100000\n"))
+    assert st.default_host_threads() == 4              # 8-CPU quota: half
     monkeypatch.setattr(builtins, "open", fake("max 100000\n"))
-    assert st.default_host_threads() == 16             # no quota: capped
-    assert st.default_host_threads(8) == 16
+    assert st.default_host_threads() == 8              # no quota: capped
+    assert st.default_host_threads(8) == 8
     monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(8)), raising=False)
     assert st.default_host_threads() == 4
 
