@@ -722,6 +722,8 @@ def run():
     else:
         model = GraphSageSampling(Fdim, hidden, C, n_layers, F.relu, 0.2, 'mean', False)
     model = model.to(dev)
+    if os.environ.get("PG_BENCH_DROP_OFFSET"):               # diagnosis: another stream of dropout masks (same seed, later steps)
+        model._drop_step += int(os.environ["PG_BENCH_DROP_OFFSET"])
     loss_fcn = torch.nn.CrossEntropyLoss()
     use_graph = not args.no_graph
     if use_graph:
@@ -913,10 +915,11 @@ def run():
         wev = [torch.cuda.Event(enable_timing=True)]
         host_t = []
         loss_ev = {}
+        loss_trace = os.environ.get("PG_BENCH_LOSS_TRACE")       # diagnosis: every step's loss (one clone launch per step)
         p_before = torch.cat([p_.detach().reshape(-1) for p_ in model.parameters()]).clone()
         def on_step(done_, loss_):
             host_t.append(time.perf_counter())
-            if done_ == 1 or done_ == K_:      # evidence that the timed steps trained: a private copy of two loss values
+            if done_ == 1 or done_ == K_ or loss_trace:   # evidence that the timed steps trained: a private copy of two loss values
                 loss_ev[done_] = loss_.detach().clone()          # (the slot's static loss tensor is overwritten 8 steps later)
             if done_ % win == 0 or done_ == K_:
                 e_ = torch.cuda.Event(enable_timing=True)
@@ -929,6 +932,7 @@ def run():
         cacher.miss_queue_longest(reset=True)
         cg0 = cgroup_cpu_stat()
         drop_step0 = int(model._drop_step.item()) if hasattr(model, "_drop_step") else 0
+        early0 = getattr(trainer, "early_ordinal", 0)
         wev[0].record(cstream)
         t0 = time.time()
         done = trainer.run_steps(it, K_)
@@ -1000,7 +1004,14 @@ def run():
         tries_total, miss_total = cacher._stats.tolist()          # accumulated on the device by k_split
         miss_rate = cacher.get_miss_rate() if tries_total else 0.0
         drop_step1 = int(model._drop_step.item()) if hasattr(model, "_drop_step") else 0
+        early1 = getattr(trainer, "early_ordinal", 0)
         p_after = torch.cat([p_.detach().reshape(-1) for p_ in model.parameters()])
+        if loss_trace:
+            ls_ = np.array([float(loss_ev[i_].item()) for i_ in sorted(loss_ev)])
+            log(f"[bench] loss trace ({tag}, {len(ls_)} steps): means of 10 equal parts " +
+                " ".join(f"{c_.mean():.3f}" for c_ in np.array_split(ls_, 10)) + f"; max {ls_.max():.3f} nan {int(np.isnan(ls_).sum())}"
+                f"; first > 6: {np.flatnonzero(ls_ > 6)[:8].tolist()} early_ordinal {getattr(trainer, 'early_ordinal', None)}"
+                f" around: {[round(float(x_), 2) for x_ in ls_[max(0, int(np.flatnonzero(ls_ > 6)[0]) - 6):int(np.flatnonzero(ls_ > 6)[0]) + 6]] if (ls_ > 6).any() else None}")
         trained = {"loss_first": float(loss_ev[1].item()) if 1 in loss_ev else None,
                    "loss_last": float(loss_ev[K_].item()) if K_ in loss_ev else None,
                    "params_finite": bool(torch.isfinite(p_after).all().item()),
@@ -1012,7 +1023,7 @@ def run():
                 "windows": windows, "win": win, "host_longest": host_longest, "launch_split": launch_split,
                 "cpu_quota": cpu_quota, "mq_stats": mq_stats, "copy_windows": copy_windows, "prof": prof,
                 "tries_total": tries_total, "miss_total": miss_total, "miss_rate": miss_rate,
-                "drop_steps": (drop_step0, drop_step1), "timed_out": timed_out}
+                "drop_steps": (drop_step0, drop_step1), "early_steps": (early0, early1), "timed_out": timed_out}
 
     # (1) the driver's window: exactly K steps after W warm-up steps — `ms_per_step`
     reg_win = timed_region(K, "window")
@@ -1029,6 +1040,11 @@ def run():
     prof, tries_total, miss_total, miss_rate = big["prof"], big["tries_total"], big["miss_total"], big["miss_rate"]
     t_issued = big["t_issued"]
     drop_step0, drop_step1 = big["drop_steps"]
+    early_agg = big["early_steps"][1] > big["early_steps"][0]
+    if early_agg:
+        # GraphedTrainer.early_aggregate: the fused kernel is launched from prepare() on the load stream with a step value the
+        # trainer counts itself; its ring entries are indexed by that count (the launches issued inside the region)
+        drop_step0, drop_step1 = big["early_steps"]
     K_big = big["steps"]
 
     # ---- in-loop time of the dominant HBM-bound kernel --------------------------------------------------
@@ -1044,7 +1060,7 @@ def run():
         # into ring entry (dropout step % ring); entries [drop_step0+1, drop_step1] are the timed steps
         ring = cacher.rows_prof[0].view(-1, L.PG_PROF_WORDS)
         # (when the optimiser's launch advances the counter it holds the value the NEXT forward uses: shift by one)
-        shift = 0 if getattr(model, "_drop_step_primed", False) else 1
+        shift = 1 if early_agg else (0 if getattr(model, "_drop_step_primed", False) else 1)
         first = max(drop_step0, drop_step1 - PROF_RING + 2)          # the ring keeps the last PROF_RING - 1 launches
         idx = torch.arange(first + shift, drop_step1 + shift, device=dev) % PROF_RING
         raw = ring[idx].cpu().numpy().astype(np.int64)
@@ -1191,6 +1207,9 @@ def run():
                        "miss_mode_probe": mode_probe, "overlap": not args.no_overlap,
                        "partition_vertices": Vs, "dg_hops": args.dg_hops if world > 1 else None,
                        "hip_graph_step": use_graph,
+                       # block 0's aggregation launched ahead of its step on the load stream (GraphedTrainer.early_aggregate:
+                       # 'auto' = when the whole table is cached)
+                       "early_layer0_aggregation": bool(early_agg),
                        "allreduce_in_graph": getattr(trainer, "allreduce_in_graph", None) if world > 1 else None,
                        "fetch": "all layers+fields (reference)" if need is None else "only what the model reads"},
             # headline = the reference's counting (every row of every layer, storage.py:203-204,219-227): from the

@@ -400,7 +400,10 @@ typedef struct pg_dropout {
   uint32_t threshold;
   uint32_t tag;          /* distinguishes call sites (layer index, rank) */
   uint64_t seed;
-  const uint64_t* step;  /* device */
+  const uint64_t* step;  /* device; NULL: step_value is used */
+  uint64_t step_value;   /* the step counter's value as an immediate (step == NULL): for a launch whose caller keeps the
+                          * count on the host — GraphedTrainer's early layer-0 aggregation, which runs on the load stream
+                          * several batches ahead of the counter the optimiser's launch advances */
 } pg_dropout_t;
 int pg_spmm_fwd_drop(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride,
                      int64_t n_dst, int32_t dim, int reduce, float* out, int32_t out_stride,

@@ -57,7 +57,7 @@ class PgDedup(ctypes.Structure):
 
 
 class PgDropout(ctypes.Structure):
-    _fields_ = [("threshold", c_u32), ("tag", c_u32), ("seed", c_u64), ("step", vp)]
+    _fields_ = [("threshold", c_u32), ("tag", c_u32), ("seed", c_u64), ("step", vp), ("step_value", c_u64)]
 
 
 class PgError(RuntimeError):

@@ -135,7 +135,9 @@ struct DropArgs {
   uint32_t thr, tag, k0, k1;
   const uint64_t* step;
   float scale;
+  uint32_t step_imm;     // the step value when step == nullptr (pg_dropout_t.step_value)
 };
+__device__ __forceinline__ uint32_t drop_step_of(const DropArgs& d) { return d.step ? (uint32_t)*d.step : d.step_imm; }
 
 __device__ __forceinline__ float4 drop_apply(float4 x, const uint32_t (&o)[4], int half, uint32_t thr, float scale) {
   const uint32_t w0 = half ? o[2] : o[0], w1 = half ? o[3] : o[1];
@@ -154,6 +156,7 @@ inline bool drop_args(const pg_dropout_t* dp, DropArgs* d) {
   d->k0 = (uint32_t)dp->seed;
   d->k1 = (uint32_t)(dp->seed >> 32);
   d->step = dp->step;
+  d->step_imm = (uint32_t)dp->step_value;
   d->scale = 65536.f / (float)(65536u - dp->threshold);
   return true;
 }

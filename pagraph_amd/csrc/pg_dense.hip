@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kAggWaves * 64, 4) void k_agg_dense_fwd(const int32
                                                                       int32_t y_stride, int64_t n, int32_t K, int32_t N,
                                                                       int32_t act, int32_t as_stride) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // A operand [32][as_stride]; then the partial tiles
-  const uint32_t step = g.d.step ? (uint32_t)*g.d.step : 0u;
+  const uint32_t step = drop_step_of(g.d);
   unsigned long long* pslot = prof_begin(g.prof, g.prof_ring, step, g.prof ? (unsigned long long)indptr[n] : 0ull);
   const RowsW rows{src, slots, edge_slots, cache, staged, g.cache_stride, g.staged_stride};
   const int lane = threadIdx.x & (kWave - 1);

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_drop(const int32_t* __restrict
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
   const int64_t v = wave * rows_per_wave + (lane >> lpr_log2);
   if (v >= n_dst) return;
-  const uint32_t step = d.step ? (uint32_t)*d.step : 0u;
+  const uint32_t step = drop_step_of(d);
   const int pieces = dim / 4;
   const int32_t beg = indptr[v], end = indptr[v + 1];
   float4* orow = reinterpret_cast<float4*>(out + v * out_stride);
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict
                                                        float* __restrict__ out, int32_t out_stride, DropArgs d,
                                                        unsigned long long* __restrict__ prof, int prof_ring) {
   using S = SV<4>;
-  const uint32_t step = d.step ? (uint32_t)*d.step : 0u;
+  const uint32_t step = drop_step_of(d);
   unsigned long long* pslot = prof_begin(prof, prof_ring, step, prof ? (unsigned long long)indptr[n_dst] : 0ull);
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t v = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows_w(const int32_t* __restri
                                                          unsigned long long* __restrict__ prof, int prof_ring,
                                                          int store_mode) {
   using S = SV<4>;
-  const uint32_t step = d.step ? (uint32_t)*d.step : 0u;
+  const uint32_t step = drop_step_of(d);
   unsigned long long* pslot = prof_begin(prof, prof_ring, step, prof ? (unsigned long long)indptr[n_dst] : 0ull);
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t v = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void k_spmm_bwd_drop(const int32_t* __restrict
   if (v >= n_dst) return;
   const int32_t beg = indptr[v], end = indptr[v + 1];
   if (end == beg) return;
-  const uint32_t step = d.step ? (uint32_t)*d.step : 0u;
+  const uint32_t step = drop_step_of(d);
   const float dg = (float)(end - beg);
   const float* grow = go + v * go_stride;
   for (int c = gl; c < dim; c += lpr) {
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void k_spmm_bwd_gather(const int32_t* __restri
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
   const int64_t sr = wave * rows_per_wave + (lane >> lpr_log2);
   if (sr >= n_src) return;
-  const uint32_t step = (DROP && d.step) ? (uint32_t)*d.step : 0u;
+  const uint32_t step = DROP ? drop_step_of(d) : 0u;
   const int pieces = dim / VEC;
   const int32_t beg = tptr[sr], end = tptr[sr + 1];
   if (skip_heavy && end - beg > PG_HEAVY_ROW) return;   // a hub: k_spmm_bwd_heavy gives it a whole block
@@ -593,7 +593,7 @@ __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, in
   const int el = threadIdx.x >> lp_log2, n_el = kHeavyThreads >> lp_log2, gl = threadIdx.x & (lpr - 1);
   const int pieces = dim / VEC;
   const int hp = pieces / 2, qn = parts > 1 ? hp / parts : 0;
-  const uint32_t step = (DROP && d.step) ? (uint32_t)*d.step : 0u;
+  const uint32_t step = DROP ? drop_step_of(d) : 0u;
   for (int hi = first; hi < n_heavy; hi += stride) {
     const int sr = sr_next;
     if (hi + stride < n_heavy) sr_next = heavy[1 + hi + stride];
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256) void k_spmm_bwd_max(const int32_t* __restrict_
   if (v >= n_dst) return;
   const int32_t beg = indptr[v], end = indptr[v + 1];
   if (end == beg) return;
-  const uint32_t step = (DROP && d.step) ? (uint32_t)*d.step : 0u;
+  const uint32_t step = DROP ? drop_step_of(d) : 0u;
   for (int c = gl; c < dim; c += lpr) {
     const float g = go[v * go_stride + c];
     const float o = mi.out[v * mi.out_stride + c];
@@ -805,7 +805,10 @@ int pg_spmm_fwd_rows(const int32_t* indptr, const int32_t* src, const pg_row_sou
   if (!indptr || !src || !out || !rows->slots) return PG_ERR_INVALID;
   DropArgs d{};
   const bool has_drop = drop_args(drop, &d);
-  if (!has_drop && drop) d.step = drop->step;     // the profiling ring is indexed by the caller's step counter
+  if (!has_drop && drop) {                        // the profiling ring is indexed by the caller's step counter
+    d.step = drop->step;
+    d.step_imm = (uint32_t)drop->step_value;
+  }
   const unsigned grid = (unsigned)ceil_div<int64_t>(n_dst, 4);
   unsigned long long* pr = reinterpret_cast<unsigned long long*>(prof);
 #define PG_FWD_ROWS(DROP, TAIL, MAXR)                                                                                   \
@@ -843,8 +846,8 @@ int pg_spmm_fwd_rows(const int32_t* indptr, const int32_t* src, const pg_row_sou
 #undef PG_FWD_ROWS_W
 #undef PG_FWD_ROWS
   PG_LAUNCH_CHECK();
-  if (pr) {                     // the next dense / head launch of this thread stamps this entry's word [1]
-    g_prof_succ.ring = pr;
+  if (pr && d.step) {           // the next dense / head launch of this thread stamps this entry's word [1] (a launch with an
+    g_prof_succ.ring = pr;      // immediate step value has no dependent successor on its own stream: body time only)
     g_prof_succ.ring_len = prof_ring;
     g_prof_succ.step = d.step;
   }

@@ -99,6 +99,26 @@ class _GCNBase(FusedDropoutMixin, nn.Module):
             return {}
         return {0: ['features']}
 
+    def early_aggregate_spec(self, step_value):
+        """(reduce name, DropoutSpec or None) of block 0's aggregation for a caller that runs it ahead of the step
+        (GraphedTrainer.early_aggregate) with a step count of its own, or None when the model's first operation on its
+        input is not that aggregation. (seed, layer tag) are the model's; the step value is the caller's count of what
+        the model's own counter will hold when the batch is computed (then the masks are the in-step path's)."""
+        if self.preprocess or len(self.layers) < 2 or self.uses_norm:
+            return None
+        mod = getattr(self, 'dropout', None)
+        drop = None
+        if self.training and isinstance(mod, nn.Dropout) and mod.p > 0.0:
+            if not (self.fuse_dropout and mod.p < 1.0 and self._drop_step.is_cuda):
+                return None
+            if self._drop_seed is None:
+                self._drop_seed = torch.initial_seed()
+            rank = 0
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                rank = torch.distributed.get_rank()
+            drop = ops.DropoutSpec(mod.p, self._drop_seed, (rank << 8) | 0, None, step_value)
+        return self.reducer(msg='m', out='h').op, drop
+
     def _input_transform(self, nf):
         """gcn_nssc.py:80-90: dense transform of the raw features before any aggregation"""
         h = nf.layers[0].data['features']
@@ -112,7 +132,9 @@ class _GCNBase(FusedDropoutMixin, nn.Module):
     def _propagate(self, nf, h):
         for i, layer in enumerate(self.layers):
             drop = None
-            if getattr(self, 'dropout', None) and not self.preprocess:
+            if isinstance(h, ops.PreAggregated):
+                pass                                     # aggregated ahead of the step, dropout included
+            elif getattr(self, 'dropout', None) and not self.preprocess:
                 drop = self._drop_spec(i, h)             # dropout inside the aggregation kernel ...
                 if drop is None:
                     h = self._dropout_or_raise(h)        # ... or nn.Dropout where that cannot be done
@@ -142,7 +164,9 @@ class _GCNBase(FusedDropoutMixin, nn.Module):
         n = len(self.layers)
         for i, layer in enumerate(self.layers[:-1]):
             drop = None
-            if getattr(self, 'dropout', None) and not self.preprocess:
+            if isinstance(h, ops.PreAggregated):
+                pass
+            elif getattr(self, 'dropout', None) and not self.preprocess:
                 drop = self._drop_spec(i, h)
                 if drop is None:
                     h = self._dropout_or_raise(h)

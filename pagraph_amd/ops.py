@@ -13,14 +13,15 @@ class DropoutSpec:
     """nn.Dropout folded into the aggregation that consumes its output (pg_dropout_t, include/pagraph_hip.h):
     p quantised to threshold / 65536, counter-based mask keyed by (seed, tag, *step) — `step` is a device int64
     tensor the owner bumps once per forward, so a replayed hipGraph draws a fresh mask every step."""
-    __slots__ = ("threshold", "seed", "tag", "step")
+    __slots__ = ("threshold", "seed", "tag", "step", "step_value")
 
-    def __init__(self, p, seed, tag, step):
+    def __init__(self, p, seed, tag, step, step_value=0):
         self.threshold = min(65535, int(round(float(p) * 65536.0)))
         self.seed, self.tag, self.step = int(seed) & 0xFFFFFFFFFFFFFFFF, int(tag) & 0xFFFFFFFF, step
+        self.step_value = int(step_value)      # used when step is None: the caller keeps the count on the host
 
     def struct(self):
-        return L.PgDropout(self.threshold, self.tag, self.seed, L.ptr(self.step))
+        return L.PgDropout(self.threshold, self.tag, self.seed, L.ptr(self.step), self.step_value)
 
     @staticmethod
     def fusable(h):
@@ -92,6 +93,21 @@ def aggregate_rows(indptr, src, rows, n_dst, reduce="mean", dropout=None):
             L.check(lib.pg_prof_stamp(L.ptr(prof), ring, L.ptr(dropout.step) if dropout is not None else None,
                                       L.stream_ptr()), "pg_prof_stamp")
     return out
+
+
+class PreAggregated:
+    """Stands in for a NodeFlow layer's source field whose block aggregation (with the model's dropout) has ALREADY been
+    computed into `agg` [n_dst, dim] — by GraphedTrainer on the load stream, while the previous steps' backward passes ran
+    (the layer-0 aggregation reads raw features: it depends on no parameter). NodeFlow.block_compute and the models take
+    `agg` as the block's reduce result and run only the node UDF."""
+
+    def __init__(self, agg):
+        self.agg = agg
+        self.is_cuda, self.dtype, self.device = True, agg.dtype, agg.device
+        self.requires_grad = False
+
+    def size(self, i=None):
+        return self.agg.size() if i is None else self.agg.size(i)
 
 
 class _BlockAggregate(torch.autograd.Function):

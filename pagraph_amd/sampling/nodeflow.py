@@ -11,7 +11,7 @@ import scipy.sparse as spsp
 import torch
 
 from .. import _lib as L
-from ..ops import RowSource, block_aggregate
+from ..ops import PreAggregated, RowSource, block_aggregate
 
 
 class DeviceGraph:
@@ -145,6 +145,12 @@ class NodeFlow:
         src_field = message_func.src
         assert reduce_func.msg == message_func.out, "reduce must consume the message field"
         h = self.layers[i].data[src_field]
+        if isinstance(h, PreAggregated):          # the reduce ran ahead of the step (GraphedTrainer.early_aggregate)
+            dst = self.layers[i + 1].data
+            dst[reduce_func.out] = h.agg
+            if apply_node_func is not None:
+                dst.update(apply_node_func(_NodeBatch(dst)))
+            return
         fused = getattr(apply_node_func, "aggregate_and_update", None)
         if fused is not None and isinstance(h, RowSource):
             # rows that were never gathered (layer 0 read straight from the feature cache) feeding a NodeUpdate whose first

@@ -304,6 +304,19 @@ class GraphedTrainer:
         # train on — right for a caller that passes the SAME iterator again (bench.py's timed windows), wrong for one that
         # makes a fresh iterator per epoch.
         self.keep_primed = False
+        # Block 0's aggregation (layer-0 features -> the first hidden layer's input, dropout included) depends on no parameter:
+        # it can run AHEAD of its step, on the load stream, while the previous steps' head / backward / optimiser kernels
+        # (small, latency-bound, leaving the memory system idle) run on the compute stream — the replayed step then starts at
+        # the dense kernel. 'auto' (default): when the whole table is cached (no miss rows to wait for: a wait parked on the
+        # load stream would hold up the NEXT batch's miss list, and at a partial cache the step sits on its PCIe time anyway);
+        # '1': always (waits for the miss rows on the load stream); '0': never. PG_EARLY_AGG overrides.
+        self.early_aggregate = _os.environ.get("PG_EARLY_AGG", "auto")
+        # The dropout mask of an early aggregation is keyed by the value the model's step counter WILL hold when the batch is
+        # computed (counted on the host from one read of the counter: pg_dropout_t.step_value), so the early path draws exactly
+        # the masks the in-step path would have drawn — same losses, bit for bit, dropout on (tools/dbg_early.py). If somebody
+        # runs the model in between the values drift apart, which is harmless: a mask only has to differ from step to step.
+        self.early_ordinal = 0           # the dropout step value of the last early aggregation (0: none yet)
+        self._early_next = None
         self.keep_gc = False             # True: leave the interpreter's cyclic garbage collector on inside run_steps
         # True: prepare / compute run inside the reference's profiler ranges 'gpu-load' / 'gpu-compute' (pa_gcn.py:87,92);
         # off by default — a record_function costs the launch thread a few microseconds per step
@@ -340,6 +353,9 @@ class GraphedTrainer:
         s.plan = None
         s.slot_index = None
         s.ext_drop = None      # the model whose dropout counter this slot's (deferred) step body expects to be primed
+        s.early = None         # (field, RowSource) when block 0's aggregation of this slot's plan runs in prepare()
+        s.agg0 = None          # ... and its output [layer-1 capacity, padded dim]
+        s.early_call = None    # ... and the cached arguments of its launch
         return s
 
     def prepare(self, nf):
@@ -383,6 +399,8 @@ class GraphedTrainer:
                 self.cacher.fetch_data(nf, out=s.out, need=self.need, slot=s.slot_index)
         if self.sampler.defer_transpose:
             self.sampler.transpose_blocks(nf, ls)     # after the gather: the miss path starts first
+        if s.early is not None:
+            self._aggregate_early(nf, s, ls)
         o0, o1 = nf._layer_offsets[-2], nf._layer_offsets[-1]
         sp = ctypes.c_void_p(ls.cuda_stream)
         L.check(self._lib.pg_gather_labels(ctypes.c_void_p(ids.data_ptr() + 8 * o0), o1 - o0, L.ptr(self.labels),
@@ -406,17 +424,75 @@ class GraphedTrainer:
         virtual = None
         if self.fuse_gather and self.need is not None and hasattr(self._bare_model(), 'virtual_inputs'):
             virtual = self._bare_model().virtual_inputs(nf.num_layers)
-        return self.cacher.plan_fetch(nf._layer_offsets, s.out, self.need, virtual=virtual, slot=s.slot_index)
+        plan = self.cacher.plan_fetch(nf._layer_offsets, s.out, self.need, virtual=virtual, slot=s.slot_index)
+        s.early = self._early_for(plan, virtual)
+        return plan
 
-    def _bare_model(self):
-        return getattr(self.model, 'module', self.model)
+    def _early_for(self, plan, virtual):
+        """(field, RowSource) if block 0's aggregation of this plan is to run ahead of its step, else None"""
+        mode = str(self.early_aggregate).lower()
+        m = self._bare_model()
+        if mode in ("0", "false", "off") or plan is False or not virtual or not hasattr(m, "early_aggregate_spec"):
+            return None
+        if mode == "auto" and not self.cacher.full_cached:
+            return None
+        fields = virtual.get(0) or []
+        if list(virtual) != [0] or len(fields) != 1 or (0, fields[0]) not in plan.row_sources:
+            return None
+        rows = plan.row_sources[(0, fields[0])]
+        if not rows.aligned() or m.early_aggregate_spec(0) is None:
+            return None
+        return fields[0], rows
 
-    def _step_body(self, s):
+    def _aggregate_early(self, nf, s, ls):
+        field, rows = s.early
+        n_dst = nf.layer_size(1)
+        if s.agg0 is None or s.agg0.size(0) != n_dst:
+            with torch.cuda.stream(ls):
+                s.agg0 = torch.empty((n_dst, (rows.dim + 7) & ~7), dtype=torch.float32, device=self.device)
+            s.early_call = None
+        if not self.cacher.full_cached:
+            self.cacher.wait_misses(s.slot_index, ls)     # forced mode only: the staged miss rows are read in place
+        m = self._bare_model()
+        if self._early_next is None or not self._prepared:
+            # nothing of this trainer is prepared ahead: one read of the device counter (the pipeline is empty anyway)
+            self.compute_stream.synchronize()
+            with torch.cuda.stream(self.compute_stream):
+                v = int(m._drop_step.item())
+            self._early_next = v + (0 if m._drop_step_primed else 1) + len(self._prepared)
+        self.early_ordinal = self._early_next
+        self._early_next += 1
+        call = s.early_call
+        if call is None or call[0] is not rows or call[1] != m.training:
+            # the launch's arguments, built once per (slot, plan): the slot's static NodeFlow and frames never move; only the
+            # step value changes from batch to batch (the launch thread is what bounds the step once the table is cached)
+            red, drop = m.early_aggregate_spec(self.early_ordinal)
+            rs = rows.struct()
+            d = drop.struct() if drop is not None else None
+            prof, ring = (rows.prof[0], rows.prof[1]) if rows.prof is not None else (None, 0)
+            args = (L.ptr(nf.blk_indptr[0]), L.ptr(nf.blk_src[0]), ctypes.byref(rs), int(n_dst), rows.dim, ops._REDUCE[red],
+                    L.ptr(s.agg0), s.agg0.stride(0), ctypes.byref(d) if d is not None else None, L.ptr(prof), ring,
+                    ctypes.c_void_p(ls.cuda_stream))
+            call = s.early_call = (rows, m.training, args, d, (rs, nf.blk_indptr[0], nf.blk_src[0], prof))
+        if call[3] is not None:
+            call[3].step_value = self.early_ordinal
+        L.check(self._lib.pg_spmm_fwd_rows(*call[2]), "pg_spmm_fwd_rows")
+
+    def _frames_for(self, s):
         rs = s.plan.row_sources if s.plan else {}
         for i in range(s.nf.num_layers):
             o0, o1 = s.nf._layer_offsets[i], s.nf._layer_offsets[i + 1]
             s.nf._node_frames[i] = {n: (rs[(i, n)] if (i, n) in rs else t[o0:o1]) for n, t in s.out.items()
                                     if self.need is None or n in self.need.get(i, ())}
+        if s.early is not None and s.agg0 is not None:
+            field, rows = s.early
+            s.nf._node_frames[0][field] = ops.PreAggregated(s.agg0[:, :rows.dim])
+
+    def _bare_model(self):
+        return getattr(self.model, 'module', self.model)
+
+    def _step_body(self, s):
+        self._frames_for(s)
         if self._gseed is None:                 # persistent d loss / d loss: no ones_like fill (nor a divide) per step
             self._gseed = torch.full((), 1.0 / self.world, dtype=torch.float32, device=self.device)
         loss = None
@@ -468,11 +544,7 @@ class GraphedTrainer:
             bump, scope = m._drop_step, m.drop_step_external()
             s.ext_drop = m
         with scope, ops.defer_partials() as reg:
-            rs = s.plan.row_sources if s.plan else {}
-            for i in range(s.nf.num_layers):
-                o0, o1 = s.nf._layer_offsets[i], s.nf._layer_offsets[i + 1]
-                s.nf._node_frames[i] = {n: (rs[(i, n)] if (i, n) in rs else t[o0:o1]) for n, t in s.out.items()
-                                        if self.need is None or n in self.need.get(i, ())}
+            self._frames_for(s)
             if self._gseed is None:
                 self._gseed = torch.full((), 1.0, dtype=torch.float32, device=self.device)
             loss = None

@@ -723,6 +723,61 @@ def test_graphed_trainer_matches_eager(dev, hiplib):
     assert losses["graph"][-1] < losses["graph"][0]
 
 
+@pytest.mark.parametrize("ratio,miss_mode", [(1.0, "async"), (0.4, "async")])
+def test_early_layer0_aggregation_matches_the_in_step_one(dev, hiplib, ratio, miss_mode, monkeypatch):
+    """GraphedTrainer.early_aggregate: block 0's aggregation launched from prepare() on the load stream (ahead of its step)
+    gives the same loss trajectory, bit for bit, as the aggregation inside the replayed step (dropout off: the same kernel on
+    the same rows) — table cached ('auto' switches it on) and partial cache over the async miss queue (forced '1': the miss
+    rows are waited for on the load stream); with dropout on it draws a fresh mask per batch and still trains."""
+    import torch.nn.functional as Fn
+    from pagraph_amd.model import GCNSampling
+    from pagraph_amd.optim import Adam
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    from pagraph_amd.trainer import GraphedTrainer, cycle_batches
+    rng = np.random.default_rng(77)
+    V, Fdim, C, B = 6000, 600, 7, 600
+    adj = _rand_csc(rng, V, 40000)
+    g = DeviceGraph(adj)
+    feats = rng.standard_normal((V, Fdim)).astype(np.float32)
+    labels = torch.from_numpy(rng.integers(0, C, V)).to(dev)
+    train = np.arange(0, V, 2, dtype=np.int64)
+
+    def run(early, p_drop, steps=24):
+        store = HostFeatureStore({"features": torch.from_numpy(feats)})
+        c = GraphCacheServer(store, V, torch.arange(V), 0, miss_mode=miss_mode)
+        c.init_field(["features"])
+        c.auto_cache(g, ["features"], cache_ratio=ratio)
+        torch.manual_seed(0)
+        model = GCNSampling(Fdim, 32, C, 1, Fn.relu, p_drop).to(dev)
+        opt = Adam(model.parameters(), lr=1e-2)
+        smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=True, num_hops=2, seed_nodes=train, prefetch=True,
+                              seed=9, static=True, defer_transpose=True)
+        tr = GraphedTrainer(model, torch.nn.CrossEntropyLoss(), opt, c, smp, labels, dev, need=model.required_inputs(3))
+        tr.early_aggregate = early
+        out = []
+        tr.on_step = lambda step, loss: out.append(loss.detach().clone())
+        tr.run_steps(cycle_batches(smp, steps), steps)
+        tr.synchronize()
+        used = sum(1 for s_ in tr.slots.values() if s_.early is not None)
+        return torch.stack(out).cpu().numpy(), tr.early_ordinal, used
+
+    base, n0, used0 = run("0", 0.0)
+    assert n0 == 0 and used0 == 0
+    for mode in (["auto", "1"] if ratio == 1.0 else ["1"]):
+        got, n1, used1 = run(mode, 0.0)
+        assert n1 >= 24 and used1 > 0, (mode, n1, used1)          # every batch of the run (+ the look-ahead) went early
+        assert np.array_equal(got, base), (mode, got, base)
+    if ratio < 1.0:
+        assert run("auto", 0.0)[1] == 0                            # a partial cache keeps the aggregation in the step
+    # dropout on: the early launch is keyed by the value the model's step counter will hold when the batch is computed —
+    # the masks, and with them every loss, are the in-step path's
+    drop, n2, _ = run("1", 0.3, steps=40)
+    ref, _, _ = run("0", 0.3, steps=40)
+    assert np.isfinite(drop).all() and np.array_equal(drop, ref), (drop, ref)
+    assert not np.array_equal(drop[:24], base)                     # ... and dropout was really on
+
+
 def test_stress_objects_dropped_with_work_in_flight(dev, hiplib):
     """Samplers, cachers (async miss queue: worker thread, gather pool, SDMA copies), trainers with captured step graphs and
     optimisers with a mirrored step counter are created, driven WITHOUT a final synchronise, and dropped in every order
