@@ -60,6 +60,21 @@ class FusedDropoutMixin:
             rank = torch.distributed.get_rank()
         return ops.DropoutSpec(mod.p, self._drop_seed, (rank << 8) | (layer & 0xFF), self._drop_step)
 
+    def _early_drop_spec(self, tag, step_value):
+        """_drop_spec for an aggregation somebody runs ahead of the step with the step value as an immediate
+        (pg_dropout_t.step_value): None = dropout inactive, False = active but not fusable (the caller must not run ahead)"""
+        mod = getattr(self, 'dropout', None)
+        if not (self.training and isinstance(mod, torch.nn.Dropout) and mod.p > 0.0):
+            return None
+        if not (self.fuse_dropout and mod.p < 1.0 and self._drop_step.is_cuda):
+            return False
+        if self._drop_seed is None:
+            self._drop_seed = torch.initial_seed()
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()
+        return ops.DropoutSpec(mod.p, self._drop_seed, (rank << 8) | (tag & 0xFF), None, step_value)
+
     def _dropout_or_raise(self, h):
         """nn.Dropout for an input the aggregation kernel could not take the mask for; rows that were never
         materialised (ops.RowSource) have no tensor to drop from: identity when dropout is inactive, else refuse"""

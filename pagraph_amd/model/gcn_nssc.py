@@ -99,25 +99,18 @@ class _GCNBase(FusedDropoutMixin, nn.Module):
             return {}
         return {0: ['features']}
 
-    def early_aggregate_spec(self, step_value):
-        """(reduce name, DropoutSpec or None) of block 0's aggregation for a caller that runs it ahead of the step
-        (GraphedTrainer.early_aggregate) with a step count of its own, or None when the model's first operation on its
-        input is not that aggregation. (seed, layer tag) are the model's; the step value is the caller's count of what
-        the model's own counter will hold when the batch is computed (then the masks are the in-step path's)."""
+    def early_aggregations(self, num_layers, step_value):
+        """[(block, field, reduce name, DropoutSpec or None)]: the aggregations of RAW feature rows this model starts with —
+        they depend on no parameter, so a trainer may run them ahead of the step (GraphedTrainer.early_aggregate) and hand
+        the results over as nf._pre_agg. (seed, layer tag) of the masks are the model's; the step value is the caller's
+        count of what the model's own counter will hold when the batch is computed (then the masks are the in-step path's).
+        [] when the model's first operation on its input is not such an aggregation."""
         if self.preprocess or len(self.layers) < 2 or self.uses_norm:
-            return None
-        mod = getattr(self, 'dropout', None)
-        drop = None
-        if self.training and isinstance(mod, nn.Dropout) and mod.p > 0.0:
-            if not (self.fuse_dropout and mod.p < 1.0 and self._drop_step.is_cuda):
-                return None
-            if self._drop_seed is None:
-                self._drop_seed = torch.initial_seed()
-            rank = 0
-            if torch.distributed.is_available() and torch.distributed.is_initialized():
-                rank = torch.distributed.get_rank()
-            drop = ops.DropoutSpec(mod.p, self._drop_seed, (rank << 8) | 0, None, step_value)
-        return self.reducer(msg='m', out='h').op, drop
+            return []
+        drop = self._early_drop_spec(0, step_value)
+        if drop is False:
+            return []
+        return [(0, 'features', self.reducer(msg='m', out='h').op, drop)]
 
     def _input_transform(self, nf):
         """gcn_nssc.py:80-90: dense transform of the raw features before any aggregation"""
@@ -131,10 +124,11 @@ class _GCNBase(FusedDropoutMixin, nn.Module):
 
     def _propagate(self, nf, h):
         for i, layer in enumerate(self.layers):
+            if self._apply_pre_aggregated(nf, i, layer):  # aggregated ahead of the step, dropout included
+                h = nf.layers[i + 1].data.pop('activation')
+                continue
             drop = None
-            if isinstance(h, ops.PreAggregated):
-                pass                                     # aggregated ahead of the step, dropout included
-            elif getattr(self, 'dropout', None) and not self.preprocess:
+            if getattr(self, 'dropout', None) and not self.preprocess:
                 drop = self._drop_spec(i, h)             # dropout inside the aggregation kernel ...
                 if drop is None:
                     h = self._dropout_or_raise(h)        # ... or nn.Dropout where that cannot be done
@@ -142,6 +136,13 @@ class _GCNBase(FusedDropoutMixin, nn.Module):
             nf.block_compute(i, fn.copy_src(src='h', out='m'), self.reducer(msg='m', out='h'), layer, dropout=drop)
             h = nf.layers[i + 1].data.pop('activation')
         return h
+
+    def _apply_pre_aggregated(self, nf, i, layer):
+        pre = getattr(nf, '_pre_agg', None)
+        if i != 0 or self.preprocess or not pre or 0 not in pre:
+            return False
+        nf.apply_block(0, pre[0], 'h', layer)
+        return True
 
     def forward(self, nf):
         self._bump_drop_step()
@@ -163,10 +164,11 @@ class _GCNBase(FusedDropoutMixin, nn.Module):
         h = self._input_transform(nf) if self.preprocess else nf.layers[0].data['features']
         n = len(self.layers)
         for i, layer in enumerate(self.layers[:-1]):
+            if self._apply_pre_aggregated(nf, i, layer):
+                h = nf.layers[i + 1].data.pop('activation')
+                continue
             drop = None
-            if isinstance(h, ops.PreAggregated):
-                pass
-            elif getattr(self, 'dropout', None) and not self.preprocess:
+            if getattr(self, 'dropout', None) and not self.preprocess:
                 drop = self._drop_spec(i, h)
                 if drop is None:
                     h = self._dropout_or_raise(h)

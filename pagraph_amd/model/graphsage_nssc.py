@@ -98,6 +98,19 @@ class GraphSageSampling(FusedDropoutMixin, nn.Module):
             return {0: ['features']}
         return {l: ['features'] for l in range(num_layers)}
 
+    def early_aggregations(self, num_layers, step_value):
+        """[(block, field, reduce name, DropoutSpec or None)] (see _GCNBase.early_aggregations): model layer 0 aggregates
+        the raw 'features' of EVERY block's source layer (graphsage_nssc.py:92-111) — none of them depends on a parameter"""
+        if self.preprocess or self.aggregator_type not in _REDUCERS:
+            return []
+        out = []
+        for i in range(num_layers - 1):
+            drop = self._early_drop_spec(i, step_value)          # (tag lid * 16 + i with lid = 0)
+            if drop is False:
+                return []
+            out.append((i, 'features', _REDUCERS[self.aggregator_type]('m', 'neigh').op, drop))
+        return out
+
     def forward(self, nf):
         L = nf.num_layers
         self._bump_drop_step()
@@ -121,8 +134,12 @@ class GraphSageSampling(FusedDropoutMixin, nn.Module):
         red = _REDUCERS[self.aggregator_type]
         # graphsage_nssc.py:92-131: model layer `lid` is applied to every block i >= lid, so the
         # self term of a destination always has the same depth as its neighbour term.
+        pre = getattr(nf, '_pre_agg', None) or {}
         for lid, layer in enumerate(self.layers):
             for i in range(lid, L - 1):
+                if lid == 0 and i in pre:               # block i's aggregation of the raw rows ran ahead of the step
+                    nf.apply_block(i, pre[i], 'neigh', layer)
+                    continue
                 d = nf.layers[i].data
                 # the dropped 'h' is read by this aggregation only (layer i's self term was consumed by block
                 # i - 1 already), so the mask can be applied inside the kernel (tag: one per (lid, i) call site)

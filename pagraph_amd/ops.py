@@ -95,21 +95,6 @@ def aggregate_rows(indptr, src, rows, n_dst, reduce="mean", dropout=None):
     return out
 
 
-class PreAggregated:
-    """Stands in for a NodeFlow layer's source field whose block aggregation (with the model's dropout) has ALREADY been
-    computed into `agg` [n_dst, dim] — by GraphedTrainer on the load stream, while the previous steps' backward passes ran
-    (the layer-0 aggregation reads raw features: it depends on no parameter). NodeFlow.block_compute and the models take
-    `agg` as the block's reduce result and run only the node UDF."""
-
-    def __init__(self, agg):
-        self.agg = agg
-        self.is_cuda, self.dtype, self.device = True, agg.dtype, agg.device
-        self.requires_grad = False
-
-    def size(self, i=None):
-        return self.agg.size() if i is None else self.agg.size(i)
-
-
 class _BlockAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, indptr, src, h, n_dst, reduce, drop, tptr, tdst, heavy, dz_n=0):

@@ -11,7 +11,7 @@ import scipy.sparse as spsp
 import torch
 
 from .. import _lib as L
-from ..ops import PreAggregated, RowSource, block_aggregate
+from ..ops import RowSource, block_aggregate
 
 
 class DeviceGraph:
@@ -113,6 +113,9 @@ class NodeFlow:
         self.blk_tptr = [None] * self.num_blocks
         self.blk_tdst = [None] * self.num_blocks
         self.blk_theavy = [None] * self.num_blocks   # [count, hub sources...] (more than PG_HEAVY_ROW edges)
+        # {block index: aggregated rows} for blocks whose FIRST aggregation (of the raw feature rows) was run ahead of the step
+        # by the trainer (GraphedTrainer.early_aggregate); the models then call apply_block instead of block_compute
+        self._pre_agg = None
         self._node_frames = [None] * self.num_layers
         self.layers = _Layers(self)
         self.padded = False      # True: fixed-shape layout, ids < 0 are padding (sampler static=True)
@@ -136,6 +139,15 @@ class NodeFlow:
     def block_size(self, i):
         return int(self.blk_src[i].numel())
 
+    def apply_block(self, i, agg, out_field, apply_node_func=None):
+        """block_compute(i, ...) whose reduce has ALREADY been computed into `agg` [|L(i+1)|, dim] — by GraphedTrainer, ahead
+        of the step (`_pre_agg`: an aggregation of raw features depends on no parameter): store it as layer i+1's
+        `out_field` and run the node UDF"""
+        dst = self.layers[i + 1].data
+        dst[out_field] = agg
+        if apply_node_func is not None:
+            dst.update(apply_node_func(_NodeBatch(dst)))
+
     def block_compute(self, i, message_func, reduce_func, apply_node_func=None, dropout=None):
         """DGL's nf.block_compute for the builtin pair copy_src + mean|sum
         (gcn_nssc.py:71-74,139-142; graphsage_nssc.py:98-111): aggregate layer i's
@@ -145,12 +157,6 @@ class NodeFlow:
         src_field = message_func.src
         assert reduce_func.msg == message_func.out, "reduce must consume the message field"
         h = self.layers[i].data[src_field]
-        if isinstance(h, PreAggregated):          # the reduce ran ahead of the step (GraphedTrainer.early_aggregate)
-            dst = self.layers[i + 1].data
-            dst[reduce_func.out] = h.agg
-            if apply_node_func is not None:
-                dst.update(apply_node_func(_NodeBatch(dst)))
-            return
         fused = getattr(apply_node_func, "aggregate_and_update", None)
         if fused is not None and isinstance(h, RowSource):
             # rows that were never gathered (layer 0 read straight from the feature cache) feeding a NodeUpdate whose first

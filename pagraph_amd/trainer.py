@@ -353,8 +353,8 @@ class GraphedTrainer:
         s.plan = None
         s.slot_index = None
         s.ext_drop = None      # the model whose dropout counter this slot's (deferred) step body expects to be primed
-        s.early = None         # (field, RowSource) when block 0's aggregation of this slot's plan runs in prepare()
-        s.agg0 = None          # ... and its output [layer-1 capacity, padded dim]
+        s.early = None         # [(block, field, RowSource)]: the aggregations of this slot's plan that run in prepare()
+        s.agg0 = None          # ... and their outputs {block: [destination capacity, padded dim]}
         s.early_call = None    # ... and the cached arguments of its launch
         return s
 
@@ -426,34 +426,34 @@ class GraphedTrainer:
             virtual = self._bare_model().virtual_inputs(nf.num_layers)
         plan = self.cacher.plan_fetch(nf._layer_offsets, s.out, self.need, virtual=virtual, slot=s.slot_index)
         s.early = self._early_for(plan, virtual)
+        s.agg0, s.early_call = None, None
         return plan
 
     def _early_for(self, plan, virtual):
-        """(field, RowSource) if block 0's aggregation of this plan is to run ahead of its step, else None"""
+        """[(block, field, RowSource)] for the aggregations of this plan that are to run ahead of their step, else None"""
         mode = str(self.early_aggregate).lower()
         m = self._bare_model()
-        if mode in ("0", "false", "off") or plan is False or not virtual or not hasattr(m, "early_aggregate_spec"):
+        if mode in ("0", "false", "off") or plan is False or not virtual or not hasattr(m, "early_aggregations"):
             return None
         if mode == "auto" and not self.cacher.full_cached:
             return None
-        fields = virtual.get(0) or []
-        if list(virtual) != [0] or len(fields) != 1 or (0, fields[0]) not in plan.row_sources:
-            return None
-        rows = plan.row_sources[(0, fields[0])]
-        if not rows.aligned() or m.early_aggregate_spec(0) is None:
-            return None
-        return fields[0], rows
+        out = []
+        for blk, field, _red, _drop in m.early_aggregations(plan.num_layers, 0):
+            rows = plan.row_sources.get((blk, field))
+            if rows is None or not rows.aligned():
+                return None            # all of the model's raw-row aggregations or none: the model skips them as a set
+            out.append((blk, field, rows))
+        return out or None
 
     def _aggregate_early(self, nf, s, ls):
-        field, rows = s.early
-        n_dst = nf.layer_size(1)
-        if s.agg0 is None or s.agg0.size(0) != n_dst:
+        m = self._bare_model()
+        if s.agg0 is None:
             with torch.cuda.stream(ls):
-                s.agg0 = torch.empty((n_dst, (rows.dim + 7) & ~7), dtype=torch.float32, device=self.device)
+                s.agg0 = {blk: torch.empty((nf.layer_size(blk + 1), (rows.dim + 7) & ~7), dtype=torch.float32,
+                                           device=self.device) for blk, _f, rows in s.early}
             s.early_call = None
         if not self.cacher.full_cached:
             self.cacher.wait_misses(s.slot_index, ls)     # forced mode only: the staged miss rows are read in place
-        m = self._bare_model()
         if self._early_next is None or not self._prepared:
             # nothing of this trainer is prepared ahead: one read of the device counter (the pipeline is empty anyway)
             self.compute_stream.synchronize()
@@ -463,20 +463,27 @@ class GraphedTrainer:
         self.early_ordinal = self._early_next
         self._early_next += 1
         call = s.early_call
-        if call is None or call[0] is not rows or call[1] != m.training:
-            # the launch's arguments, built once per (slot, plan): the slot's static NodeFlow and frames never move; only the
+        if call is None or call[0] is not s.early or call[1] != m.training:
+            # the launches' arguments, built once per (slot, plan): the slot's static NodeFlow and frames never move; only the
             # step value changes from batch to batch (the launch thread is what bounds the step once the table is cached)
-            red, drop = m.early_aggregate_spec(self.early_ordinal)
-            rs = rows.struct()
-            d = drop.struct() if drop is not None else None
-            prof, ring = (rows.prof[0], rows.prof[1]) if rows.prof is not None else (None, 0)
-            args = (L.ptr(nf.blk_indptr[0]), L.ptr(nf.blk_src[0]), ctypes.byref(rs), int(n_dst), rows.dim, ops._REDUCE[red],
-                    L.ptr(s.agg0), s.agg0.stride(0), ctypes.byref(d) if d is not None else None, L.ptr(prof), ring,
-                    ctypes.c_void_p(ls.cuda_stream))
-            call = s.early_call = (rows, m.training, args, d, (rs, nf.blk_indptr[0], nf.blk_src[0], prof))
-        if call[3] is not None:
-            call[3].step_value = self.early_ordinal
-        L.check(self._lib.pg_spmm_fwd_rows(*call[2]), "pg_spmm_fwd_rows")
+            specs = {blk: (red, drop) for blk, _f, red, drop in m.early_aggregations(nf.num_layers, self.early_ordinal)}
+            launches, keep = [], []
+            for blk, _field, rows in s.early:
+                red, drop = specs[blk]
+                rs = rows.struct()
+                d = drop.struct() if drop is not None else None
+                prof, ring = (rows.prof[0], rows.prof[1]) if rows.prof is not None else (None, 0)
+                out = s.agg0[blk]
+                args = (L.ptr(nf.blk_indptr[blk]), L.ptr(nf.blk_src[blk]), ctypes.byref(rs), int(out.size(0)), rows.dim,
+                        ops._REDUCE[red], L.ptr(out), out.stride(0), ctypes.byref(d) if d is not None else None, L.ptr(prof),
+                        ring, ctypes.c_void_p(ls.cuda_stream))
+                launches.append((args, d))
+                keep.append((rs, nf.blk_indptr[blk], nf.blk_src[blk], prof, rows))
+            call = s.early_call = (s.early, m.training, launches, keep)
+        for args, d in call[2]:
+            if d is not None:
+                d.step_value = self.early_ordinal
+            L.check(self._lib.pg_spmm_fwd_rows(*args), "pg_spmm_fwd_rows")
 
     def _frames_for(self, s):
         rs = s.plan.row_sources if s.plan else {}
@@ -484,9 +491,9 @@ class GraphedTrainer:
             o0, o1 = s.nf._layer_offsets[i], s.nf._layer_offsets[i + 1]
             s.nf._node_frames[i] = {n: (rs[(i, n)] if (i, n) in rs else t[o0:o1]) for n, t in s.out.items()
                                     if self.need is None or n in self.need.get(i, ())}
+        s.nf._pre_agg = None
         if s.early is not None and s.agg0 is not None:
-            field, rows = s.early
-            s.nf._node_frames[0][field] = ops.PreAggregated(s.agg0[:, :rows.dim])
+            s.nf._pre_agg = {blk: s.agg0[blk][:, :rows.dim] for blk, _f, rows in s.early}
 
     def _bare_model(self):
         return getattr(self.model, 'module', self.model)

@@ -723,14 +723,15 @@ def test_graphed_trainer_matches_eager(dev, hiplib):
     assert losses["graph"][-1] < losses["graph"][0]
 
 
+@pytest.mark.parametrize("arch", ["gcn", "sage"])
 @pytest.mark.parametrize("ratio,miss_mode", [(1.0, "async"), (0.4, "async")])
-def test_early_layer0_aggregation_matches_the_in_step_one(dev, hiplib, ratio, miss_mode, monkeypatch):
+def test_early_layer0_aggregation_matches_the_in_step_one(dev, hiplib, ratio, miss_mode, arch, monkeypatch):
     """GraphedTrainer.early_aggregate: block 0's aggregation launched from prepare() on the load stream (ahead of its step)
     gives the same loss trajectory, bit for bit, as the aggregation inside the replayed step (dropout off: the same kernel on
     the same rows) — table cached ('auto' switches it on) and partial cache over the async miss queue (forced '1': the miss
     rows are waited for on the load stream); with dropout on it draws a fresh mask per batch and still trains."""
     import torch.nn.functional as Fn
-    from pagraph_amd.model import GCNSampling
+    from pagraph_amd.model import GCNSampling, GraphSageSampling
     from pagraph_amd.optim import Adam
     from pagraph_amd.sampling import DeviceGraph, NeighborSampler
     from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
@@ -749,7 +750,10 @@ def test_early_layer0_aggregation_matches_the_in_step_one(dev, hiplib, ratio, mi
         c.init_field(["features"])
         c.auto_cache(g, ["features"], cache_ratio=ratio)
         torch.manual_seed(0)
-        model = GCNSampling(Fdim, 32, C, 1, Fn.relu, p_drop).to(dev)
+        if arch == "gcn":
+            model = GCNSampling(Fdim, 32, C, 1, Fn.relu, p_drop).to(dev)
+        else:                     # GraphSAGE: BOTH blocks' aggregations of raw rows run ahead (graphsage_nssc.py:92-111)
+            model = GraphSageSampling(Fdim, 16, C, 1, Fn.relu, p_drop, 'mean').to(dev)
         opt = Adam(model.parameters(), lr=1e-2)
         smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=True, num_hops=2, seed_nodes=train, prefetch=True,
                               seed=9, static=True, defer_transpose=True)
