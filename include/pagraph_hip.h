@@ -584,6 +584,15 @@ int pg_linear2_fwd_rows(const pg_row_source_t* X, int32_t K, const float* W, con
 int pg_linear_bwd_w_rows(const float* dY, int32_t dy_stride, const pg_row_source_t* X, int64_t n, int32_t K, int32_t N,
                          float* dW, float* db, const float* Yout, int32_t yo_stride, int32_t act, float* dz_scratch,
                          float* partials, int32_t sum_partials, pg_stream_t stream);
+/* Both weight gradients of GraphSAGE's NodeUpdate z = fc_self(h) + fc_neigh(neigh) (graphsage_nssc.py:24) in ONE launch
+ * (round 4): dW1 = dZ^T X1, dW2 = dZ^T X2 over the same dZ (derived once from dY / Yout when act != 0, as
+ * pg_linear_bwd_w does). The first operand is dense (X1) or read in place (X1rows) — exactly one of the two is given; the
+ * second is dense. Same blocks, same arithmetic as pg_linear_bwd_w_ex / pg_linear_bwd_w_rows called once per operand:
+ * bit-identical partial rows (partials1 / partials2: pg_linear_bwd_w_scratch(n, K1 | K2, N) floats each) and sums.   */
+int pg_linear2_bwd_w(const float* dY, int32_t dy_stride, const float* X1, int32_t x1_stride, const pg_row_source_t* X1rows,
+                     int32_t K1, const float* X2, int32_t x2_stride, int32_t K2, int64_t n, int32_t N, float* dW1, float* db1,
+                     float* dW2, float* db2, const float* Yout, int32_t yo_stride, int32_t act, float* dz_scratch,
+                     float* partials1, float* partials2, int32_t sum_partials, pg_stream_t stream);
 int pg_gcn_head(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
                 const float* W, const float* bias, int32_t C, const int64_t* labels, int64_t ignore_index,
                 const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,

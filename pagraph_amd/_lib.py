@@ -163,6 +163,8 @@ _SIGS = {
                                           vp]),
     "pg_linear2_fwd_rows": (ctypes.c_int, [vp, c_i32, vp, vp, vp, c_i32, vp, vp, c_i32, vp, c_i32, c_i64, c_i32, c_i32, vp]),
     "pg_linear_bwd_w_rows": (ctypes.c_int, [vp, c_i32, vp, c_i64, c_i32, c_i32, vp, vp, vp, c_i32, c_i32, vp, vp, c_i32, vp]),
+    "pg_linear2_bwd_w": (ctypes.c_int, [vp, c_i32, vp, c_i32, vp, c_i32, vp, c_i32, c_i32, c_i64, c_i32, vp, vp, vp, vp, vp,
+                                         c_i32, c_i32, vp, vp, vp, c_i32, vp]),
     "pg_dg_partition": (ctypes.c_int, [c_i64, vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp]),
     "pg_dg_partition_mt": (ctypes.c_int, [c_i64, vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp, c_i32]),
     "pg_np_argsort_f64": (ctypes.c_int, [vp, c_i32, vp]),

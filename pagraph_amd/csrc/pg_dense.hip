@@ -658,19 +658,31 @@ __global__ __launch_bounds__(256) void k_dz(const float* __restrict__ G, int32_t
 // through LDS and leave as one set of atomics per block.
 // ROWS: X's rows through a pg_row_source_t (see k_linear_fwd): lane l of a wave looks up the slot of the wave's l-th row
 // once (rpw <= 64), a row's base address then comes from that lane by shuffle.
+struct BwdWArgs {              // one weight-gradient launch (k_linear_bwd_w's former parameter list)
+  const float* dY;
+  const float* X;
+  float* part;
+  int64_t n;
+  int32_t dy_stride, x_stride, K, N, with_bias, rpw, items, chunks;
+  RowsArg ra;
+};
+
 template <bool ROWS>
-__global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ dY, int32_t dy_stride,
-                                                      const float* __restrict__ X, int32_t x_stride, int64_t n,
-                                                      int32_t K, int32_t N, float* __restrict__ part, int32_t with_bias,
-                                                      int32_t rpw, int32_t items, int32_t chunks, const RowsArg ra) {
-  __shared__ float red[4][kTile][kTile + 1];
-  __shared__ float bred[4][kWave];
+__device__ __forceinline__ void linear_bwd_w_block(const BwdWArgs& g, unsigned bid, float (&red)[4][kTile][kTile + 1],
+                                                   float (&bred)[4][kWave]) {
+  const float* __restrict__ dY = g.dY;
+  const float* __restrict__ X = g.X;
+  float* __restrict__ part = g.part;
+  const int32_t dy_stride = g.dy_stride, x_stride = g.x_stride, K = g.K, N = g.N, with_bias = g.with_bias, rpw = g.rpw,
+                items = g.items, chunks = g.chunks;
+  const int64_t n = g.n;
+  const RowsArg& ra = g.ra;
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
   const int half = lane >> 5;
   // XCD-aware order: workgroups go round-robin over the 8 XCDs, so workgroup id -> (xcd, q); all `items`
   // tiles of one row chunk run back to back on ONE XCD. Their 128-byte column strips of X straddle cache
   // lines (row stride 2400 B), which that XCD's L2 then fetches once instead of once per neighbour.
-  const int xcd = (int)(blockIdx.x & 7), q = (int)(blockIdx.x >> 3);
+  const int xcd = (int)(bid & 7), q = (int)(bid >> 3);
   const int item = q % items;
   const int chunk = (q / items) * 8 + xcd;
   if (chunk >= chunks) return;
@@ -755,6 +767,25 @@ __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ 
     mine[(int64_t)N * K + f0 + t] = bred[0][t] + bred[0][t + 32] + bred[1][t] + bred[1][t + 32] + bred[2][t] +
                                     bred[2][t + 32] + bred[3][t] + bred[3][t + 32];
   }
+}
+
+template <bool ROWS>
+__global__ __launch_bounds__(256) void k_linear_bwd_w(const BwdWArgs g) {
+  __shared__ float red[4][kTile][kTile + 1];
+  __shared__ float bred[4][kWave];
+  linear_bwd_w_block<ROWS>(g, blockIdx.x, red, bred);
+}
+
+// GraphSAGE's NodeUpdate z = fc_self(h) + fc_neigh(neigh) (graphsage_nssc.py:24) has TWO weight gradients over the same
+// dZ: dW_self = dZ^T h, dW_neigh = dZ^T neigh. One launch: workgroups [0, g1) are the first operand's tiles, the rest the
+// second's — the same blocks doing the same arithmetic as two k_linear_bwd_w launches (bit-identical partial rows), minus
+// one kernel boundary of the replayed step per NodeUpdate use (each of these launches is 5-15 us of mostly latency).
+template <bool ROWS1>
+__global__ __launch_bounds__(256) void k_linear_bwd_w_pair(const BwdWArgs a, const BwdWArgs b, unsigned g1) {
+  __shared__ float red[4][kTile][kTile + 1];
+  __shared__ float bred[4][kWave];
+  if (blockIdx.x < g1) linear_bwd_w_block<ROWS1>(a, blockIdx.x, red, bred);
+  else linear_bwd_w_block<false>(b, blockIdx.x - g1, red, bred);
 }
 
 // dW / db = sum over the row chunks' partials in a fixed order (deterministic). Block = 64 outputs x 4
@@ -1046,6 +1077,22 @@ int pg_linear_bwd_w_rows(const float* dY, int32_t dy_stride, const pg_row_source
                       sum_partials, &ra, stream);
 }
 
+// fills the launch record of one weight gradient; returns its grid (0: nothing to do) or a negative error
+static int64_t bwd_w_args(BwdWArgs* a, const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n,
+                          int32_t K, int32_t N, float* partials, bool with_bias, const RowsArg* rows, int64_t* chunks_out) {
+  const int64_t items = ceil_div<int64_t>(K, kTile) * ceil_div<int64_t>(N, kTile);
+  const int rpw = bwd_rows_per_wave(n, K, N);
+  const int64_t chunks = ceil_div<int64_t>(n, 4 * rpw);
+  const int64_t grid = items * 8 * ceil_div<int64_t>(chunks, 8);
+  if (grid > 0x7fffffff) return PG_ERR_INVALID;
+  a->dY = dY; a->X = X; a->part = partials; a->n = n;
+  a->dy_stride = dy_stride; a->x_stride = x_stride; a->K = K; a->N = N;
+  a->with_bias = with_bias ? 1 : 0; a->rpw = rpw; a->items = (int32_t)items; a->chunks = (int32_t)chunks;
+  a->ra = rows ? *rows : RowsArg{};
+  *chunks_out = chunks;
+  return grid;
+}
+
 static int linear_bwd_w(const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n, int32_t K,
                         int32_t N, float* dW, float* db, const float* Yout, int32_t yo_stride, int32_t act,
                         float* dz_scratch, float* partials, int32_t sum_partials, const RowsArg* rows, pg_stream_t stream) {
@@ -1054,11 +1101,6 @@ static int linear_bwd_w(const float* dY, int32_t dy_stride, const float* X, int3
   if (act != 0 && (!Yout || yo_stride < N || !dz_scratch)) return PG_ERR_INVALID;
   if (n == 0) return PG_OK;
   if (!dY || !X || !dW || !partials) return PG_ERR_INVALID;
-  const int64_t items = ceil_div<int64_t>(K, kTile) * ceil_div<int64_t>(N, kTile);
-  const int rpw = bwd_rows_per_wave(n, K, N);
-  const int64_t chunks = ceil_div<int64_t>(n, 4 * rpw);
-  const int64_t grid = items * 8 * ceil_div<int64_t>(chunks, 8);
-  if (grid > 0x7fffffff) return PG_ERR_INVALID;
   if (act != 0) {
     int64_t g = ceil_div<int64_t>(n * N, 256);
     hipLaunchKernelGGL(k_dz, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, as_stream(stream), dY, dy_stride, Yout,
@@ -1067,17 +1109,64 @@ static int linear_bwd_w(const float* dY, int32_t dy_stride, const float* X, int3
     dY = dz_scratch;
     dy_stride = N;
   }
-  if (rows)
-    hipLaunchKernelGGL(k_linear_bwd_w<true>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), dY, dy_stride, X,
-                       x_stride, n, K, N, partials, db ? 1 : 0, rpw, (int32_t)items, (int32_t)chunks, *rows);
-  else
-    hipLaunchKernelGGL(k_linear_bwd_w<false>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), dY, dy_stride, X,
-                       x_stride, n, K, N, partials, db ? 1 : 0, rpw, (int32_t)items, (int32_t)chunks, RowsArg{});
+  BwdWArgs a{};
+  int64_t chunks = 0;
+  const int64_t grid = bwd_w_args(&a, dY, dy_stride, X, x_stride, n, K, N, partials, db != nullptr, rows, &chunks);
+  if (grid < 0) return (int)grid;
+  if (rows) hipLaunchKernelGGL(k_linear_bwd_w<true>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+  else hipLaunchKernelGGL(k_linear_bwd_w<false>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
   PG_LAUNCH_CHECK();
   if (!sum_partials) return PG_OK;   // the consumer (pg_adam_step_partials) adds the chunks up itself
   const int64_t nk = (int64_t)N * K;
   hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)ceil_div<int64_t>(nk + N, 64)), dim3(256), 0, as_stream(stream),
                      partials, (int32_t)chunks, nk, N, dW, db, nk + N);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+int pg_linear2_bwd_w(const float* dY, int32_t dy_stride, const float* X1, int32_t x1_stride, const pg_row_source_t* X1rows,
+                     int32_t K1, const float* X2, int32_t x2_stride, int32_t K2, int64_t n, int32_t N, float* dW1, float* db1,
+                     float* dW2, float* db2, const float* Yout, int32_t yo_stride, int32_t act, float* dz_scratch,
+                     float* partials1, float* partials2, int32_t sum_partials, pg_stream_t stream) {
+  if (n < 0 || K1 <= 0 || K2 <= 0 || N <= 0 || x2_stride < K2 || act < 0 || act > 2 || dy_stride < (act == 2 ? 2 * N : N))
+    return PG_ERR_INVALID;
+  if (act != 0 && (!Yout || yo_stride < N || !dz_scratch)) return PG_ERR_INVALID;
+  if ((X1 != nullptr) == (X1rows != nullptr)) return PG_ERR_INVALID;          // exactly one form of the first operand
+  const float* base = X1;
+  int32_t stride = x1_stride;
+  RowsArg ra{};
+  if (X1rows) {
+    const int rc = rows_arg(X1rows, K1, &base, &stride, &ra);
+    if (rc != PG_OK) return rc;
+  } else if (x1_stride < K1) {
+    return PG_ERR_INVALID;
+  }
+  if (n == 0) return PG_OK;
+  if (!dY || !X2 || !dW1 || !dW2 || !partials1 || !partials2) return PG_ERR_INVALID;
+  if (act != 0) {
+    int64_t g = ceil_div<int64_t>(n * N, 256);
+    hipLaunchKernelGGL(k_dz, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, as_stream(stream), dY, dy_stride, Yout,
+                       yo_stride, n, N, act, dz_scratch);
+    PG_LAUNCH_CHECK();
+    dY = dz_scratch;
+    dy_stride = N;
+  }
+  BwdWArgs a{}, b{};
+  int64_t ch1 = 0, ch2 = 0;
+  const int64_t g1 = bwd_w_args(&a, dY, dy_stride, base, stride, n, K1, N, partials1, db1 != nullptr, X1rows ? &ra : nullptr, &ch1);
+  const int64_t g2 = bwd_w_args(&b, dY, dy_stride, X2, x2_stride, n, K2, N, partials2, db2 != nullptr, nullptr, &ch2);
+  if (g1 < 0 || g2 < 0 || g1 + g2 > 0x7fffffff) return PG_ERR_INVALID;
+  if (X1rows)
+    hipLaunchKernelGGL(k_linear_bwd_w_pair<true>, dim3((unsigned)(g1 + g2)), dim3(256), 0, as_stream(stream), a, b, (unsigned)g1);
+  else
+    hipLaunchKernelGGL(k_linear_bwd_w_pair<false>, dim3((unsigned)(g1 + g2)), dim3(256), 0, as_stream(stream), a, b, (unsigned)g1);
+  PG_LAUNCH_CHECK();
+  if (!sum_partials) return PG_OK;
+  const int64_t nk1 = (int64_t)N * K1, nk2 = (int64_t)N * K2;
+  hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)ceil_div<int64_t>(nk1 + N, 64)), dim3(256), 0, as_stream(stream),
+                     partials1, (int32_t)ch1, nk1, N, dW1, db1, nk1 + N);
+  hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)ceil_div<int64_t>(nk2 + N, 64)), dim3(256), 0, as_stream(stream),
+                     partials2, (int32_t)ch2, nk2, N, dW2, db2, nk2 + N);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }

@@ -469,6 +469,45 @@ def _bwd_w(lib, g, x, K, N, y, act, want_bias, weight=None, bias=None):
     return gw, gb, (dz if dz is not None else g)
 
 
+PAIR_BWD_W = os.environ.get("PG_PAIR_BWD_W", "1") != "0"      # both weight gradients of a two-operand NodeUpdate in one launch
+
+
+def _bwd_w_pair(lib, g, x1, x2, w1, w2, y, act, has_bias, bias_refs):
+    """_bwd_w for both operands of _DualLinear in ONE launch (pg_linear2_bwd_w): (dW1, db1, dW2, db2, dZ) — the same
+    partial rows, sums and deferral as two _bwd_w calls"""
+    n, N = x1.size(0), w1.size(0)
+    K1, K2 = w1.size(1), w2.size(1)
+    dev = x2.device
+    buf1 = torch.empty(N * K1 + N, dtype=torch.float32, device=dev)
+    buf2 = torch.empty(N * K2 + N, dtype=torch.float32, device=dev)
+    part1 = torch.empty(lib.pg_linear_bwd_w_scratch(n, K1, N), dtype=torch.float32, device=dev)
+    part2 = torch.empty(lib.pg_linear_bwd_w_scratch(n, K2, N), dtype=torch.float32, device=dev)
+    gw1, gb1 = buf1[:N * K1].view(N, K1), (buf1[N * K1:] if has_bias[0] else None)
+    gw2, gb2 = buf2[:N * K2].view(N, K2), (buf2[N * K2:] if has_bias[1] else None)
+    dz = torch.empty((n, N), dtype=torch.float32, device=dev) if act != ACT_NONE else None
+    d1 = _DEFER is not None and has_bias[0] and bias_refs[0] is not None
+    d2 = _DEFER is not None and has_bias[1] and bias_refs[1] is not None
+    defer = d1 and d2
+    rows = x1 if isinstance(x1, RowSource) else None
+    rs = rows.struct() if rows is not None else None
+    with torch.cuda.device(dev):
+        L.check(lib.pg_linear2_bwd_w(L.ptr(g), g.stride(0), None if rows is not None else L.ptr(x1),
+                                     0 if rows is not None else x1.stride(0), ctypes.byref(rs) if rs is not None else None, K1,
+                                     L.ptr(x2), x2.stride(0), K2, n, N, L.ptr(gw1), L.ptr(gb1), L.ptr(gw2), L.ptr(gb2),
+                                     L.ptr(y), y.stride(0) if y is not None else 0, act, L.ptr(dz), L.ptr(part1), L.ptr(part2),
+                                     0 if defer else 1, L.stream_ptr()), "pg_linear2_bwd_w")
+    if defer:
+        for (w, b, part, K) in ((w1, bias_refs[0], part1, K1), (w2, bias_refs[1], part2, K2)):
+            rowlen = N * K + N
+            okw = _DEFER.add(w, part, part.numel() // rowlen, rowlen, 0)
+            okb = _DEFER.add(b, part, part.numel() // rowlen, rowlen, N * K)
+            if w is w1:
+                gw1, gb1 = (gw1 if okw else None), (gb1 if okb else None)
+            else:
+                gw2, gb2 = (gw2 if okw else None), (gb2 if okb else None)
+    return gw1, gb1, gw2, gb2, (dz if dz is not None else g)
+
+
 class _DualLinear(torch.autograd.Function):
     """GraphSAGE's NodeUpdate dense step y = act(x1 @ W1.T + b1 + x2 @ W2.T + b2) (graphsage_nssc.py:24-29) in
     one MFMA pass (pg_linear2_fwd) instead of two GEMMs, an add, and the activation / concat kernels; the
@@ -510,8 +549,14 @@ class _DualLinear(torch.autograd.Function):
         gy = gy.contiguous()
         N = w1.size(0)
         need = ctx.needs_input_grad
-        gw1, gb1, dz = _bwd_w(lib, gy, x1, w1.size(1), N, y, ctx.act, ctx.bias[0], w1, ctx.bias_refs[0])
-        gw2, gb2, _ = _bwd_w(lib, dz, x2, w2.size(1), N, None, ACT_NONE, ctx.bias[1], w2, ctx.bias_refs[1])
+        both_or_none = _DEFER is None or all(ctx.bias[i] and ctx.bias_refs[i] is not None for i in (0, 1)) \
+            or not any(ctx.bias[i] and ctx.bias_refs[i] is not None for i in (0, 1))
+        if (PAIR_BWD_W and both_or_none and x2.stride(1) == 1 and gy.stride(1) == 1
+                and (isinstance(x1, RowSource) or x1.stride(1) == 1)):
+            gw1, gb1, gw2, gb2, dz = _bwd_w_pair(lib, gy, x1, x2, w1, w2, y, ctx.act, ctx.bias, ctx.bias_refs)
+        else:
+            gw1, gb1, dz = _bwd_w(lib, gy, x1, w1.size(1), N, y, ctx.act, ctx.bias[0], w1, ctx.bias_refs[0])
+            gw2, gb2, _ = _bwd_w(lib, dz, x2, w2.size(1), N, None, ACT_NONE, ctx.bias[1], w2, ctx.bias_refs[1])
         gx1 = dz @ w1 if need[0] else None
         gx2 = dz @ w2 if need[3] else None
         return gx1, gw1, gb1, gx2, gw2, gb2, None

@@ -2218,6 +2218,39 @@ def test_dense_step_from_row_source_is_bit_identical(dev, hiplib, n, K, N, K2, a
     if act == 0:      # sanity against torch in float64
         want = ref.double().t() @ Xd[:, :K].double()
         assert (res[1][0].double() - want).abs().max() < 1e-3 * max(1.0, float(want.abs().max()))
+    if K2:
+        # pg_linear2_bwd_w: BOTH operands' weight gradients in one launch == one pg_linear_bwd_w_ex / _rows call per operand,
+        # partial rows and sums bit for bit (summed and left for the optimiser), first operand dense and read in place
+        sc2 = hiplib.pg_linear_bwd_w_scratch(n, K2, N)
+        p2 = torch.zeros(sc2, device=dev); dW2 = torch.empty((N, K2), device=dev); db2 = torch.empty(N, device=dev)
+        dzr = torch.empty((n, N), device=dev)
+        p1 = torch.zeros(scratch, device=dev); dW1 = torch.empty((N, K), device=dev); db1 = torch.empty(N, device=dev)
+        L.check(hiplib.pg_linear_bwd_w_ex(L.ptr(G), yc, L.ptr(Xd), cs, n, K, N, L.ptr(dW1), L.ptr(db1), L.ptr(Ya), yc, act,
+                                          L.ptr(dzr), L.ptr(p1), 1, None))
+        dzin, dzs = (dzr, N) if act else (G, yc)
+        L.check(hiplib.pg_linear_bwd_w_ex(L.ptr(dzin), dzs, L.ptr(X2), X2.stride(0), n, K2, N, L.ptr(dW2), L.ptr(db2), None, 0, 0,
+                                          None, L.ptr(p2), 1, None))
+        for rows in (False, True):
+            for summed in (1, 0):
+                q1 = torch.zeros(scratch, device=dev); q2 = torch.zeros(sc2, device=dev)
+                eW1 = torch.full((N, K), 7.0, device=dev); eb1 = torch.full((N,), 7.0, device=dev)
+                eW2 = torch.full((N, K2), 7.0, device=dev); eb2 = torch.full((N,), 7.0, device=dev)
+                dz2 = torch.empty((n, N), device=dev)
+                L.check(hiplib.pg_linear2_bwd_w(L.ptr(G), yc, None if rows else L.ptr(Xd), 0 if rows else cs,
+                                                ctypes.byref(rs) if rows else None, K, L.ptr(X2), X2.stride(0), K2, n, N, L.ptr(eW1),
+                                                L.ptr(eb1), L.ptr(eW2), L.ptr(eb2), L.ptr(Ya), yc, act, L.ptr(dz2), L.ptr(q1),
+                                                L.ptr(q2), summed, None), "pg_linear2_bwd_w")
+                torch.cuda.synchronize()
+                assert torch.equal(q1, p1) and torch.equal(q2, p2), (rows, summed)
+                if summed:
+                    assert torch.equal(eW1, dW1) and torch.equal(eb1, db1) and torch.equal(eW2, dW2) and torch.equal(eb2, db2)
+                else:
+                    assert float(eW1.min()) == 7.0 and float(eb2.min()) == 7.0          # left to the optimiser's launch
+                if act:
+                    assert torch.equal(dz2, dzr)
+        assert hiplib.pg_linear2_bwd_w(L.ptr(G), yc, L.ptr(Xd), cs, ctypes.byref(rs), K, L.ptr(X2), X2.stride(0), K2, n, N,
+                                       L.ptr(dW1), L.ptr(db1), L.ptr(dW2), L.ptr(db2), L.ptr(Ya), yc, act, L.ptr(dzr), L.ptr(p1),
+                                       L.ptr(p2), 1, None) == -1                          # both forms of the first operand
 
 
 def ops_aggregate_identity(rows, dev):

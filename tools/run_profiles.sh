@@ -27,11 +27,22 @@ HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 900 python -m torch.distributed.run --nnode
         > "$OUT/bench_two_ranks_one_gpu_gloo.json" 2> "$OUT/bench_two_ranks_one_gpu_gloo.err"
 fi
 
-# 2. per-kernel time of the same command + the kernel sequence of one replayed step
-( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o b -- \
-      python "$R/bench.py" --skip-cpu-baseline --skip-opt-hit --skip-reference-equivalent > /tmp/prof_stats.log 2>&1 )
+# 1b. (round 4) the table cached with block 0's aggregation inside the step (PG_EARLY_AGG=0) for the A/B with the default
+PG_EARLY_AGG=0 timeout 600 python bench.py --cache-ratio 1.0 --skip-opt-hit --skip-cpu-baseline > "$OUT/bench_full_cache_agg_in_step.json" 2>/dev/null
+PG_EARLY_AGG=0 timeout 600 python bench.py --vertices 232965 --edges 57300000 --feat-size 602 --n-classes 41 --cache-ratio 1.0 \
+        --steps 260 --skip-opt-hit --skip-cpu-baseline > "$OUT/bench_config2_agg_in_step.json" 2>/dev/null
+timeout 600 python bench.py --cache-policy presample --skip-cpu-baseline --skip-reference-equivalent --skip-microbench > "$OUT/bench_presample_policy.json" 2>/dev/null
+timeout 600 python bench.py --host-threads 2 --skip-opt-hit --skip-cpu-baseline --skip-reference-equivalent --skip-microbench > "$OUT/bench_host_threads_2.json" 2>/dev/null
+timeout 600 python bench.py --host-threads 4 --skip-opt-hit --skip-cpu-baseline --skip-reference-equivalent --skip-microbench > "$OUT/bench_host_threads_4.json" 2>/dev/null
+
+# 2. per-kernel time of the same command + the kernel sequence of one replayed step; the fused kernel's own stamps of the
+#    SAME launches joined with the trace (the line's roofline block must follow from the committed summary)
+( cd /tmp && PG_BENCH_DUMP_STAMPS=/tmp/stamps_final.npy timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o b -- \
+      python "$R/bench.py" --skip-cpu-baseline --skip-opt-hit --skip-reference-equivalent > "$R/$OUT/bench_profiled.json" 2> /tmp/prof_stats.log )
 cp /tmp/prof_stats/*kernel_stats.csv "$OUT/bench_kernel_stats_final.csv"
 python tools/trace_seq.py /tmp/prof_stats/b_kernel_trace.csv > "$OUT/step_sequence_final.txt"
+python tools/join_stamps_trace.py /tmp/stamps_final.npy /tmp/prof_stats/b_kernel_trace.csv "$OUT/fused_stamps_vs_trace.csv" > "$OUT/fused_stamps_vs_trace.txt" 2>&1
+python tools/trace_overlap_cond.py /tmp/prof_stats/b_kernel_trace.csv k_spmm_fwd_rows > "$OUT/fused_overlap_by_neighbour.txt" 2>&1
 ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_gs -o b -- \
       python "$R/bench.py" --model graphsage --skip-cpu-baseline --skip-opt-hit --skip-reference-equivalent --skip-microbench > /tmp/prof_gs.log 2>&1 )
 cp /tmp/prof_gs/*kernel_stats.csv "$OUT/bench_graphsage_kernel_stats.csv"
