@@ -558,6 +558,17 @@ int32_t pg_gcn_head_row_len(int32_t K, int32_t C);
 /* pg_gcn_head_ex / pg_linear_bwd_w_ex: the same with `sum_partials` = 0 leaving the per-block / per-chunk partial rows
  * un-summed in `partials` ([rows][C*K + C + 1] resp. [rows][N*K + N], rows = scratch size / row length) for
  * pg_adam_step_partials; dW / db(_loss) are then not written.                                            */
+/* The same head for GraphSAGE's output NodeUpdate z = fc_neigh(agg) + fc_self(h_self) (graphsage_nssc.py:24, the last layer of
+ * graphsage_nssc.py:55-72; round 4): h_self [n_dst, >= Ks] is the destinations' own input (not aggregated, not dropped), W_self
+ * [C, Ks], bias_self [C] or NULL; K + Ks <= 64. dself [n_dst, Ks] = dZ W_self. Partial rows: pg_gcn_head_scratch(n_dst, K + Ks, C)
+ * floats laid out [C x K] dW | [C x Ks] dW_self | [C] db | loss per block (pg_gcn_head_row_len(K + Ks, C) apart); with
+ * PG_HEAD_SUM_PARTIALS dW_both receives [C x K | C x Ks] contiguous and db_loss [C + 1]; both biases have the gradient db. */
+int pg_sage_head(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
+                 const float* W, const float* bias, const float* h_self, int32_t hs_stride, int32_t Ks,
+                 const float* W_self, const float* bias_self, int32_t C, const int64_t* labels, int64_t ignore_index,
+                 const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
+                 int64_t n_dst, float* logits, float* dagg, float* dself, float* partials, float* dW_both, float* db_loss,
+                 int32_t flags, pg_stream_t stream);
 /* pg_gcn_head_ex's flags: PG_HEAD_SUM_PARTIALS as above; PG_HEAD_DAGG_PER_EDGE: under PG_REDUCE_MEAN dagg[v] leaves
  * already divided by v's in-degree in the block (what each in-edge carries back) — feed it to pg_spmm_bwd_gather /
  * pg_spmm_bwd_drop with PG_REDUCE_SUM: same operations in the same order, without the backward's degree loads.  */

@@ -159,6 +159,8 @@ _SIGS = {
                                               ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]),
     "pg_gcn_head_ex": (ctypes.c_int, [vp, vp, vp, c_i32, c_i32, vp, vp, c_i32, vp, c_i64, vp, vp, vp, ctypes.c_int,
                                       c_i64, vp, vp, vp, vp, vp, c_i32, vp]),
+    "pg_sage_head": (ctypes.c_int, [vp, vp, vp, c_i32, c_i32, vp, vp, vp, c_i32, c_i32, vp, vp, c_i32, vp, c_i64, vp, vp, vp,
+                                    ctypes.c_int, c_i64, vp, vp, vp, vp, vp, vp, c_i32, vp]),
     "pg_linear_bwd_w_ex": (ctypes.c_int, [vp, c_i32, vp, c_i32, c_i64, c_i32, c_i32, vp, vp, vp, c_i32, c_i32, vp, vp, c_i32,
                                           vp]),
     "pg_linear2_fwd_rows": (ctypes.c_int, [vp, c_i32, vp, vp, vp, c_i32, vp, vp, c_i32, vp, c_i32, c_i64, c_i32, c_i32, vp]),

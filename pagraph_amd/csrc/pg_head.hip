@@ -24,6 +24,17 @@ struct HeadDrop {
   float scale;
 };
 
+// GraphSAGE's output NodeUpdate z = fc_neigh(agg) + fc_self(h_self) (graphsage_nssc.py:24; round 4): the destination's OWN row is
+// a second operand that is neither aggregated nor dropped. It rides in the input columns [K, K + Ks) of the same wave —
+// K + Ks <= 64 — with its own weight matrix and bias; its gradient leaves as dself. Ks == 0: the GCN head.
+struct HeadSelf {
+  const float* h;        // [n_dst, >= Ks]: row v = destination v's own input
+  const float* W;        // [C, Ks]
+  const float* bias;     // [C] or null
+  float* dself;          // [n_dst, Ks]
+  int32_t stride, Ks;
+};
+
 // value of lane R of this lane's quad (DPP quad_perm broadcast)
 template <int R>
 __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
@@ -52,8 +63,9 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
                                                   const float* __restrict__ grad_scale_dev, HeadDrop d, int reduce,
                                                   int64_t n_dst, float* __restrict__ logits,
                                                   float* __restrict__ dagg, float* __restrict__ part, int dagg_per_edge,
-                                                  int row_len, const ProfSucc succ) {
+                                                  int row_len, const ProfSucc succ, const HeadSelf self) {
   prof_succ_stamp(succ);     // a profiled predecessor's "my successor started" stamp (pg_common.h)
+  const int Ks = self.Ks, Kt = K + Ks;          // input columns: [0, K) aggregated, [K, Kt) the destination's own row
   __shared__ __attribute__((aligned(16))) float s_rows[4][kHeadRows][kHeadMax];   // the waves' aggregated rows
   __shared__ int s_lab[4][kHeadRows];
   __shared__ float s_deg[4][kHeadRows];      // what dAgg is divided by when it leaves per edge (dagg_per_edge)
@@ -64,29 +76,32 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
   __shared__ __attribute__((aligned(16))) float s_big[2 * kHeadMax * kHeadMax + 2 * kHeadMax + 4];
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
   const int64_t wave_g = (int64_t)blockIdx.x * 4 + w;
-  const bool is_c = lane < C, is_k = lane < K;
+  const bool is_c = lane < C, is_k = lane < K, is_s = lane >= K && lane < Kt;
   // W row of class `lane` straight from global memory into registers (one round of 16-byte loads; 15 KB that every block
   // finds in L2), zero padded to 64 x 64; wave 0 parks its copy in LDS for the column reads of dAgg (the column stays in
   // LDS: three 64-register arrays per lane would leave one wave per SIMD). Round 3: this replaced zero-fill -> barrier ->
   // strided copy with a div/mod per element -> barrier -> 64 LDS reads per lane.
   float wrow[kHeadMax], accw[kHeadMax];
-  if ((K & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0) {
+  if ((K & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0 &&
+      (Ks == 0 || ((Ks & 3) == 0 && (reinterpret_cast<uintptr_t>(self.W) & 15) == 0))) {
 #pragma unroll
     for (int k = 0; k < kHeadMax; k += 4) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (is_c && k < K) v = *reinterpret_cast<const float4*>(W + (int64_t)lane * K + k);
+      else if (is_c && k < Kt) v = *reinterpret_cast<const float4*>(self.W + (int64_t)lane * Ks + (k - K));
       wrow[k] = v.x; wrow[k + 1] = v.y; wrow[k + 2] = v.z; wrow[k + 3] = v.w;
     }
   } else {
 #pragma unroll
-    for (int k = 0; k < kHeadMax; ++k) wrow[k] = (is_c && k < K) ? W[(int64_t)lane * K + k] : 0.f;
+    for (int k = 0; k < kHeadMax; ++k)
+      wrow[k] = (is_c && k < K) ? W[(int64_t)lane * K + k] : ((is_c && k < Kt) ? self.W[(int64_t)lane * Ks + (k - K)] : 0.f);
   }
 #pragma unroll
   for (int k = 0; k < kHeadMax; ++k) {
     if (w == 0) s_w[lane * (kHeadMax + 1) + k] = wrow[k];      // read after the barrier that closes phase 1
     accw[k] = 0.f;
   }
-  const float bz = (is_c && bias) ? bias[lane] : 0.f;
+  const float bz = ((is_c && bias) ? bias[lane] : 0.f) + ((is_c && Ks && self.bias) ? self.bias[lane] : 0.f);
   const int nv = *n_valid_dev;
   const float inv = nv > 0 ? 1.f / (float)nv : 0.f;
   const float grad_scale = grad_scale_dev ? *grad_scale_dev : 1.f;
@@ -170,6 +185,9 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
         a += dropped(sr, h[(int64_t)sr * h_stride + lane]);
       }
       if (reduce == PG_REDUCE_MEAN && end[it] > beg[it]) a /= (float)(end[it] - beg[it]);
+    } else if (is_s) {
+      const int64_t v = wave_g * kHeadRows + it;
+      if (v < n_dst) a = self.h[v * self.stride + (lane - K)];      // the destination's own row: no mask, no reduce
     }
     s_rows[w][it][lane] = a;
     if (lane == 0) {
@@ -232,6 +250,7 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
     // sum and never loads the destinations' degrees (same division, same operands: bit-identical gradients)
     const float dg = s_deg[w][it];
     if (live && is_k) dagg[v * K + lane] = dg > 0.f ? gk / dg : gk;
+    if (live && is_s) self.dself[v * Ks + (lane - K)] = gk;
   }
   __syncthreads();        // (the partial sums below reuse nothing of the above, but s_big aliases nothing: kept for clarity of phases)
   // block partial = (wave 0 + wave 2) + (wave 1 + wave 3), a fixed tree (deterministic): two LDS hand-offs instead of four
@@ -272,19 +291,26 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
     accb += s_b[lane];
     lpart += s_b[2 * kHeadMax];
     if (is_c) {
+      // partial layout of a block: [C x K] dW | [C x Ks] dW_self | [C] db | loss — each weight gradient contiguous, so that
+      // the optimiser's launch can add the blocks' rows up per parameter
       float* row = mine + (int64_t)lane * K;
-      if ((K & 3) == 0 && (row_len & 3) == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0) {
+      float* srow = mine + (int64_t)C * K + (int64_t)lane * Ks;
+      if ((K & 3) == 0 && (Ks & 3) == 0 && (row_len & 3) == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0) {
 #pragma unroll
-        for (int k = 0; k < kHeadMax; k += 4)
+        for (int k = 0; k < kHeadMax; k += 4) {
           if (k < K) *reinterpret_cast<float4*>(row + k) = make_float4(accw[k], accw[k + 1], accw[k + 2], accw[k + 3]);
+          else if (k < Kt) *reinterpret_cast<float4*>(srow + (k - K)) = make_float4(accw[k], accw[k + 1], accw[k + 2], accw[k + 3]);
+        }
       } else {
 #pragma unroll
-        for (int k = 0; k < kHeadMax; ++k)
+        for (int k = 0; k < kHeadMax; ++k) {
           if (k < K) row[k] = accw[k];
+          else if (k < Kt) srow[k - K] = accw[k];
+        }
       }
-      mine[C * K + lane] = accb;
+      mine[C * Kt + lane] = accb;
     }
-    if (lane == 0) mine[C * K + C] = lpart;
+    if (lane == 0) mine[C * Kt + C] = lpart;
   }
 }
 
@@ -320,15 +346,17 @@ int pg_gcn_head(const int32_t* indptr, const int32_t* src, const float* h, int32
                         reduce, n_dst, logits, dagg, partials, dW, db_loss, 1, stream);
 }
 
-int pg_gcn_head_ex(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
-                   const float* W, const float* bias, int32_t C, const int64_t* labels, int64_t ignore_index,
-                   const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
-                   int64_t n_dst, float* logits, float* dagg, float* partials, float* dW, float* db_loss,
-                   int32_t flags, pg_stream_t stream) {
+static int head_impl(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
+                     const float* W, const float* bias, int32_t C, const int64_t* labels, int64_t ignore_index,
+                     const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
+                     int64_t n_dst, float* logits, float* dagg, float* partials, float* dW, float* db_loss,
+                     int32_t flags, const HeadSelf& self, pg_stream_t stream) {
   const int32_t sum_partials = flags & PG_HEAD_SUM_PARTIALS;
+  const int32_t Kt = K + self.Ks;
   if (flags & ~(PG_HEAD_SUM_PARTIALS | PG_HEAD_DAGG_PER_EDGE)) return PG_ERR_INVALID;
-  if (n_dst <= 0 || K <= 0 || C <= 0 || h_stride < K) return PG_ERR_INVALID;
-  if (K > kHeadMax || C > kHeadMax) return PG_ERR_UNSUPPORTED;
+  if (n_dst <= 0 || K <= 0 || C <= 0 || h_stride < K || self.Ks < 0) return PG_ERR_INVALID;
+  if (self.Ks > 0 && (!self.h || !self.W || !self.dself || self.stride < self.Ks)) return PG_ERR_INVALID;
+  if (Kt > kHeadMax || C > kHeadMax) return PG_ERR_UNSUPPORTED;
   if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return PG_ERR_INVALID;
   if (!indptr || !h || !W || !labels || !n_valid_dev || !dagg || !partials || !dW || !db_loss) return PG_ERR_INVALID;
   if (drop && drop->threshold > 65535u) return PG_ERR_INVALID;
@@ -345,7 +373,7 @@ int pg_gcn_head_ex(const int32_t* indptr, const int32_t* src, const float* h, in
 #define PG_HEAD(R)                                                                                                   \
   hipLaunchKernelGGL(k_gcn_head<R>, dim3((unsigned)blocks), dim3(256), 0, st, indptr, src, h, h_stride, K, W, bias, C, \
                      labels, ignore_index, n_valid_dev, grad_scale_dev, d, reduce, n_dst, logits, dagg, partials,          \
-                     (flags & PG_HEAD_DAGG_PER_EDGE) ? 1 : 0, (int)pg_gcn_head_row_len(K, C), succ)
+                     (flags & PG_HEAD_DAGG_PER_EDGE) ? 1 : 0, (int)pg_gcn_head_row_len(Kt, C), succ, self)
   const ProfSucc succ = take_prof_succ();
   if (rpw == 1) PG_HEAD(1);
   else if (rpw == 2) PG_HEAD(2);
@@ -354,9 +382,31 @@ int pg_gcn_head_ex(const int32_t* indptr, const int32_t* src, const float* h, in
 #undef PG_HEAD
   PG_LAUNCH_CHECK();
   if (!sum_partials) return PG_OK;   // pg_adam_step_partials adds the blocks' partials up
-  // dW [C*K], then db [C] and the loss (db_loss[C]) contiguous behind it in the partial layout
-  return pg_sum_partials_strided(partials, (int32_t)blocks, (int64_t)C * K, C + 1, pg_gcn_head_row_len(K, C), dW, db_loss,
+  // dW [C*K] (then dW_self [C*Ks]: the caller's dW buffer holds both, contiguous), then db [C] and the loss (db_loss[C])
+  // contiguous behind them in the partial layout
+  return pg_sum_partials_strided(partials, (int32_t)blocks, (int64_t)C * Kt, C + 1, pg_gcn_head_row_len(Kt, C), dW, db_loss,
                                  stream);
+}
+
+int pg_gcn_head_ex(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
+                   const float* W, const float* bias, int32_t C, const int64_t* labels, int64_t ignore_index,
+                   const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
+                   int64_t n_dst, float* logits, float* dagg, float* partials, float* dW, float* db_loss,
+                   int32_t flags, pg_stream_t stream) {
+  return head_impl(indptr, src, h, h_stride, K, W, bias, C, labels, ignore_index, n_valid_dev, grad_scale_dev, drop, reduce,
+                   n_dst, logits, dagg, partials, dW, db_loss, flags, HeadSelf{}, stream);
+}
+
+int pg_sage_head(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
+                 const float* W, const float* bias, const float* h_self, int32_t hs_stride, int32_t Ks,
+                 const float* W_self, const float* bias_self, int32_t C, const int64_t* labels, int64_t ignore_index,
+                 const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
+                 int64_t n_dst, float* logits, float* dagg, float* dself, float* partials, float* dW_both, float* db_loss,
+                 int32_t flags, pg_stream_t stream) {
+  if (Ks <= 0) return PG_ERR_INVALID;
+  HeadSelf self{h_self, W_self, bias_self, dself, hs_stride, Ks};
+  return head_impl(indptr, src, h, h_stride, K, W, bias, C, labels, ignore_index, n_valid_dev, grad_scale_dev, drop, reduce,
+                   n_dst, logits, dagg, partials, dW_both, db_loss, flags, self, stream);
 }
 
 }  // extern "C"

@@ -111,7 +111,37 @@ class GraphSageSampling(FusedDropoutMixin, nn.Module):
             out.append((i, 'features', _REDUCERS[self.aggregator_type]('m', 'neigh').op, drop))
         return out
 
+    def forward_loss(self, nf, labels, n_valid, grad_seed=None, ignore_index=-100, want_logits=False):
+        """CrossEntropyLoss(self(nf), labels) with the LAST model layer — the output NodeUpdate fc_neigh(neigh) + fc_self(h),
+        applied to the seeds' block only (graphsage_nssc.py:92-131 with lid = n_layers) — its aggregation (+ dropout), the
+        loss and all their gradients in ONE kernel (ops.sage_head; round 4): nine launches of the replayed step become one.
+        Returns the loss, or None where the fused kernel does not apply (preprocess variant, 'pool' / 'lstm', more than 64
+        input columns or classes, logits wanted) — the caller then runs forward() and its loss function."""
+        last = self.layers[-1]
+        if (self.preprocess or want_logits or self.aggregator_type not in ('mean', 'gcn') or last.concat
+                or last.activation is not None or not labels.is_cuda or len(self.layers) < 2):
+            return None
+        L = nf.num_layers
+        h = self._forward_layers(nf, upto=len(self.layers) - 1)
+        if h is None:
+            return None
+        lid, i = len(self.layers) - 1, L - 2
+        src_h, self_h = nf.layers[i].data['h'], nf.layers[i + 1].data['h']
+        if not (torch.is_tensor(src_h) and torch.is_tensor(self_h)):
+            return None
+        drop = self._drop_spec(lid * 16 + i, src_h) if self.training else None
+        if drop is None and self.training and self.dropout.p > 0:
+            src_h = self._dropout_or_raise(src_h)
+        red = _REDUCERS[self.aggregator_type]('m', 'neigh').op
+        return ops.sage_head(nf.blk_indptr[i], nf.blk_src[i], src_h, last.fc_neigh, self_h, last.fc_self, labels, n_valid,
+                             grad_seed, ignore_index, red, drop, (nf.blk_tptr[i], nf.blk_tdst[i], nf.blk_theavy[i]))
+
     def forward(self, nf):
+        h = self._forward_layers(nf, upto=len(self.layers))
+        return h
+
+    def _forward_layers(self, nf, upto):
+        """model layers [0, upto) of forward(); upto == len(self.layers): the whole model, returns the seeds' output"""
         L = nf.num_layers
         self._bump_drop_step()
         if self.preprocess:
@@ -136,6 +166,8 @@ class GraphSageSampling(FusedDropoutMixin, nn.Module):
         # self term of a destination always has the same depth as its neighbour term.
         pre = getattr(nf, '_pre_agg', None) or {}
         for lid, layer in enumerate(self.layers):
+            if lid >= upto:
+                return True                             # (forward_loss takes over: the last layer runs inside the loss head)
             for i in range(lid, L - 1):
                 if lid == 0 and i in pre:               # block i's aggregation of the raw rows ran ahead of the step
                     nf.apply_block(i, pre[i], 'neigh', layer)

@@ -750,6 +750,109 @@ class _GCNHead(torch.autograd.Function):
         return (None, None, gh, gw, gbl[:C] if ctx.has_bias else None) + (None,) * 11
 
 
+class _SageHead(torch.autograd.Function):
+    """_GCNHead for GraphSAGE's output NodeUpdate z = fc_neigh(aggregate(dropout(h))) + fc_self(h_self)
+    (graphsage_nssc.py:24, pg_sage_head): loss and every gradient — dAgg (scattered back over the block in backward),
+    dSelf, both weight matrices, both biases — in one pass, already multiplied by `grad_seed`."""
+
+    @staticmethod
+    def forward(ctx, indptr, src, h, w_n, b_n, h_self, w_s, b_s, labels, n_valid, grad_seed, ignore_index, reduce, drop,
+                tptr, tdst, heavy):
+        lib = L.load()
+        h = h.contiguous()
+        n_dst = labels.numel()
+        C, K = w_n.shape
+        Ks = w_s.size(1)
+        Kt = K + Ks
+        buf = torch.empty(C * Kt + C + 1, dtype=torch.float32, device=h.device)
+        gwn, gws, gbl = buf[:C * K].view(C, K), buf[C * K:C * Kt].view(C, Ks), buf[C * Kt:]
+        dagg = torch.empty((n_dst, K), dtype=torch.float32, device=h.device)
+        dself = torch.empty((n_dst, Ks), dtype=torch.float32, device=h.device)
+        part = torch.empty(lib.pg_gcn_head_scratch(n_dst, Kt, C), dtype=torch.float32, device=h.device)
+        d = drop.struct() if drop is not None and drop.threshold else None
+        defer = _DEFER is not None and b_n is not None and b_s is not None and grad_seed is not None
+        with torch.cuda.device(h.device):
+            L.check(lib.pg_sage_head(L.ptr(indptr), L.ptr(src), L.ptr(h), h.stride(0), K, L.ptr(w_n), L.ptr(b_n),
+                                     L.ptr(h_self), h_self.stride(0), Ks, L.ptr(w_s), L.ptr(b_s), C, L.ptr(labels),
+                                     int(ignore_index), L.ptr(n_valid), L.ptr(grad_seed),
+                                     ctypes.byref(d) if d is not None else None, _REDUCE[reduce], n_dst, None, L.ptr(dagg),
+                                     L.ptr(dself), L.ptr(part), L.ptr(buf), L.ptr(gbl),
+                                     (0 if defer else L.PG_HEAD_SUM_PARTIALS) | L.PG_HEAD_DAGG_PER_EDGE, L.stream_ptr()),
+                    "pg_sage_head")
+        ok = [True] * 4
+        if defer:
+            rowlen = lib.pg_gcn_head_row_len(Kt, C)
+            chunks = part.numel() // rowlen
+            ok[0] = _DEFER.add(w_n, part, chunks, rowlen, 0)
+            ok[1] = _DEFER.add(w_s, part, chunks, rowlen, C * K)
+            ok[2] = _DEFER.add(b_n, part, chunks, rowlen, C * Kt)
+            ok[3] = _DEFER.add(b_s, part, chunks, rowlen, C * Kt)
+            _DEFER.extra.append((gbl[C:C + 1], part, chunks, rowlen, C * Kt + C))     # the loss value
+        use_t = tptr is not None and tptr.numel() == h.size(0) + 1
+        ctx.save_for_backward(indptr, src, dagg, dself, gwn, gws, gbl, grad_seed, *((tptr, tdst, heavy) if use_t else ()))
+        ctx.use_t, ctx.n_src, ctx.reduce, ctx.drop = use_t, h.size(0), reduce, (drop if d is not None else None)
+        ctx.has_bias = (b_n is not None, b_s is not None)
+        ctx.deferred_ok = ok
+        # both biases have the gradient db. Handing autograd the SAME tensor for two parameters makes AccumulateGrad copy it
+        # (one more launch per replayed step); when the optimiser adds the partial rows up itself the tensors autograd sees
+        # are placeholders anyway: the second bias gets one of its own
+        # (made in backward: a tensor this context also held could not be stolen by AccumulateGrad either)
+        ctx.gb_self_placeholder = bool(defer)
+        return gbl[C]
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        indptr, src, dagg, dself, gwn, gws, gbl, seed = saved[:8]
+        if seed is None or g.data_ptr() != seed.data_ptr():
+            k = g if seed is None else g / seed
+            dagg, dself, gwn, gws, gbl = dagg * k, dself * k, gwn * k, gws * k, gbl * k
+        lib = L.load()
+        gh = None
+        if ctx.needs_input_grad[2]:
+            K = dagg.size(1)
+            d = ctx.drop.struct() if ctx.drop is not None else None
+            dp = ctypes.byref(d) if d is not None else None
+            with torch.cuda.device(dagg.device):
+                if ctx.use_t:
+                    tptr, tdst, heavy = saved[8:11]
+                    gh = torch.empty((ctx.n_src, K), dtype=torch.float32, device=dagg.device)
+                    L.check(lib.pg_spmm_bwd_gather(L.ptr(tptr), L.ptr(tdst), L.ptr(indptr), L.ptr(dagg), K, ctx.n_src, K,
+                                                   L.PG_REDUCE_SUM, L.ptr(gh), K, L.ptr(heavy),
+                                                   heavy.numel() - 1 if heavy is not None else 0, dp, L.stream_ptr()),
+                            "pg_spmm_bwd_gather")
+                else:
+                    gh = torch.zeros((ctx.n_src, K), dtype=torch.float32, device=dagg.device)
+                    L.check(lib.pg_spmm_bwd_drop(L.ptr(indptr), L.ptr(src), L.ptr(dagg), K, dagg.size(0), K,
+                                                 L.PG_REDUCE_SUM, L.ptr(gh), K, dp, L.stream_ptr()), "pg_spmm_bwd_drop")
+        C = gwn.size(0)
+        ok = ctx.deferred_ok
+        gb = gbl[:C]
+        gbs = torch.empty_like(gb) if ctx.gb_self_placeholder else gb
+        return (None, None, gh, gwn if ok[0] else None, (gb if ok[2] else None) if ctx.has_bias[0] else None,
+                dself if ctx.needs_input_grad[5] else None, gws if ok[1] else None,
+                (gbs if ok[3] else None) if ctx.has_bias[1] else None) + (None,) * 9
+
+
+def sage_head(indptr, src, h, fc_neigh, h_self, fc_self, labels, n_valid, grad_seed=None, ignore_index=-100, reduce="mean",
+              dropout=None, transpose=None):
+    """loss of GraphSAGE's output layer over the last NodeFlow block: CrossEntropyLoss(fc_neigh(aggregate(dropout(h))) +
+    fc_self(h_self)) with every gradient produced in the same pass (pg_sage_head). None when the shapes are outside the
+    kernel's envelope (the caller then runs the unfused path)."""
+    wn, bn, ws, bs = fc_neigh.weight, fc_neigh.bias, fc_self.weight, fc_self.bias
+    ok = lambda t: torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1
+    if not (ok(h) and ok(h_self) and wn.size(1) == h.size(1) and ws.size(1) == h_self.size(1) and ws.size(0) == wn.size(0)
+            and wn.size(1) + ws.size(1) <= 64 and wn.size(0) <= 64 and wn.is_contiguous() and ws.is_contiguous()
+            and labels.dtype == torch.int64 and labels.numel() > 0 and h_self.size(0) == labels.numel()
+            and reduce in ("mean", "sum")):
+        return None
+    if dropout is not None and dropout.threshold and h.size(1) % 4:
+        return None
+    tptr, tdst, heavy = (tuple(transpose) + (None,))[:3] if transpose is not None else (None, None, None)
+    return _SageHead.apply(indptr, src, h, wn, bn, h_self, ws, bs, labels.contiguous(), n_valid, grad_seed, ignore_index,
+                           reduce, dropout, tptr, tdst, heavy)
+
+
 def gcn_head(indptr, src, h, linear, labels, n_valid, grad_seed=None, ignore_index=-100, reduce="mean", dropout=None,
              transpose=None, want_logits=False):
     """loss (and optionally logits) of the sampled GCN's output layer over the last NodeFlow block:

@@ -1741,6 +1741,55 @@ def test_gcn_forward_loss_matches_forward_plus_loss(dev, hiplib):
     assert model.forward_loss(nf, labels.cpu(), n_valid) is None
 
 
+@pytest.mark.parametrize("agg", ["mean", "gcn"])
+def test_sage_forward_loss_matches_forward_plus_loss(dev, hiplib, agg):
+    """GraphSageSampling.forward_loss (the output NodeUpdate fc_neigh(neigh) + fc_self(h), its aggregation, the loss and all
+    their gradients in one kernel: pg_sage_head) == CrossEntropyLoss(model(nf)) in value and in every parameter gradient,
+    with dropout (same step counter) and without; 'pool' and CPU labels decline (None)."""
+    from pagraph_amd import ops
+    from pagraph_amd.data import synthetic as syn
+    from pagraph_amd.model import GraphSageSampling
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    V, E, B, Fd, C = 30000, 300000, 1500, 64, 11
+    ip, ix = syn.rmat_graph(V, E, seed=8, device=dev)
+    g = DeviceGraph.from_csc(ip, ix, V)
+    smp = NeighborSampler(g, B, 2, neighbor_type='in', num_hops=2, seed_nodes=torch.arange(2 * B, device=dev), seed=1)
+    nf = next(iter(smp))
+    feats = syn.random_features_device(V, Fd, seed=2, device=dev)
+    labels = torch.randint(0, C, (nf.layer_size(-1),), device=dev)
+    labels[::7] = -100
+    n_valid = (labels != -100).sum().to(torch.int32).reshape(1)
+
+    def load():
+        for i in range(nf.num_layers):
+            nf.layers[i].data.clear()
+            nf.layers[i].data['features'] = feats[nf.layer_parent_nid(i)]
+
+    for pdrop in (0.0, 0.5):
+        torch.manual_seed(3)
+        model = GraphSageSampling(Fd, 16, C, 1, torch.relu, pdrop, agg).to(dev).train()
+        load()
+        model._drop_step.fill_(10)
+        ref = ops.cross_entropy(model(nf), labels)
+        ref.backward()
+        gref = [p.grad.clone() for p in model.parameters()]
+        model.zero_grad()
+        load()
+        model._drop_step.fill_(10)
+        loss = model.forward_loss(nf, labels, n_valid, None, -100)
+        assert loss is not None
+        loss.backward()
+        assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+        for (name, p), gr in zip(model.named_parameters(), gref):
+            assert p.grad is not None, name
+            assert float((p.grad - gr).abs().max()) < TOL * max(1e-3, float(gr.abs().max())), name
+    load()
+    assert model.forward_loss(nf, labels.cpu(), n_valid) is None
+    pool = GraphSageSampling(Fd, 16, C, 1, torch.relu, 0.0, 'pool').to(dev)
+    load()
+    assert pool.forward_loss(nf, labels, n_valid) is None
+
+
 @pytest.mark.gpu
 def test_bench_default_path_end_to_end_small(dev, hiplib):
     """`python bench.py` with every default phase on (timed loop, gather micro-benchmark, cache-policy analysis,
