@@ -135,6 +135,11 @@ int pg_gather_rows_dedup(const int64_t* ids, int64_t n, const int32_t* slot_map,
 int pg_split_rows_dedup(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
                         int32_t* miss_pos, int64_t* miss_fullid, int32_t* miss_count, int32_t* slots_out,
                         uint64_t* stats, const pg_dedup_t* dedup, pg_stream_t stream);
+/* slots_out[i] = slot_map[ids[i]] (ids[i] < 0, the padding of a fixed-shape layer: -2) for a launch over a FULLY cached table
+ * (storage.py:207-216): what pg_split_rows writes when nothing can miss, without the miss list and its counter's zero fill.
+ * stats (may be NULL): stats[0] += rows looked up.                                                                    */
+int pg_slots_full(const int64_t* ids, int64_t n, const int32_t* slot_map, int32_t* slots_out, uint64_t* stats,
+                  pg_stream_t stream);
 /* the general form behind pg_scatter_rows / _range / _dups: out[pos[j] - pos_lo, :dim] = staged[(src_row ? src_row[j] : j)
  * * staged_stride, :dim] for j < (n_dev ? *n_dev : n); rows below pos_lo or with a negative source are skipped.
  * staged_stride >= dim lets the staged block keep padded rows (the miss queue pads wide rows to whole 16-byte pieces so
@@ -160,6 +165,11 @@ int pg_gather_rows_full(const int64_t* ids, int64_t n, const pg_field_t* fields,
  * ignore_index = fill will count (pg_gcn_head reads it).                                             */
 int pg_gather_labels(const int64_t* ids, int64_t n, const int64_t* labels, int64_t n_labels, int64_t fill,
                      int64_t* out, int32_t* n_valid_out, pg_stream_t stream);
+/* The same with a self-cleaning count: scratch2 = two device int32 words, zero before the FIRST call and owned by this call
+ * sequence afterwards (one stream at a time); the last block to finish writes *n_valid_out and zeroes them again, so no
+ * zero fill precedes the launch. n > 0. */
+int pg_gather_labels_sc(const int64_t* ids, int64_t n, const int64_t* labels, int64_t n_labels, int64_t fill,
+                        int64_t* out, int32_t* n_valid_out, int32_t* scratch2, pg_stream_t stream);
 
 /* storage.py:199-200 — out[pos[j], :] = staged[j, :] for j < n (n from host, or *n_dev when n_dev != NULL
  * in which case `n` is the launch upper bound). `staged` is device memory, row stride = dim.        */

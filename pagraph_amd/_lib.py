@@ -81,6 +81,7 @@ _SIGS = {
     "pg_gather_rows_presplit": (ctypes.c_int, [vp, c_i64, ctypes.POINTER(PgField), ctypes.c_int, vp, vp]),
     "pg_gather_rows_full": (ctypes.c_int, [vp, c_i64, ctypes.POINTER(PgField), ctypes.c_int, vp]),
     "pg_gather_labels": (ctypes.c_int, [vp, c_i64, vp, c_i64, c_i64, vp, vp, vp]),
+    "pg_gather_labels_sc": (ctypes.c_int, [vp, c_i64, vp, c_i64, c_i64, vp, vp, vp, vp]),
     "pg_scatter_rows": (ctypes.c_int, [vp, vp, c_i64, vp, c_i32, vp, c_i32, vp]),
     "pg_scatter_rows_range": (ctypes.c_int, [vp, vp, c_i64, vp, c_i32, vp, c_i32, c_i32, vp]),
     "pg_host_gather_rows": (ctypes.c_int, [vp, c_i64, c_i32, vp, c_i64, vp, ctypes.c_int]),
@@ -128,6 +129,7 @@ _SIGS = {
     "pg_spmm_fwd_rows": (ctypes.c_int, [vp, vp, ctypes.POINTER(PgRowSource), c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, vp,
                                         c_i32, vp]),
     "pg_prof_stamp": (ctypes.c_int, [vp, c_i32, vp, vp]),
+    "pg_slots_full": (ctypes.c_int, [vp, c_i64, vp, vp, vp, vp]),
     "pg_stream_create_masked": (ctypes.c_int, [vp, c_i32, ctypes.POINTER(ctypes.c_void_p)]),
     "pg_stream_destroy": (ctypes.c_int, [vp]),
     "pg_compose_edge_slots": (ctypes.c_int, [vp, c_i64, vp, c_i64, vp, vp]),

@@ -459,6 +459,39 @@ __global__ __launch_bounds__(256) void k_gather_labels(const int64_t* __restrict
   }
 }
 
+// the same with a self-cleaning count (round 4): the waves add to scratch[0], a block that finishes takes a ticket from
+// scratch[1], and the LAST block publishes *n_valid = scratch[0] and zeroes both words for the next launch — no zero fill in
+// front of the launch (a launch of its own on the load stream and ~4 us of the launch thread per batch). A batch is ~24 blocks.
+__global__ __launch_bounds__(256) void k_gather_labels_sc(const int64_t* __restrict__ ids, int64_t n,
+                                                          const int64_t* __restrict__ labels, int64_t n_labels,
+                                                          int64_t fill, int64_t* __restrict__ out,
+                                                          int32_t* __restrict__ n_valid, int32_t* __restrict__ scratch) {
+  int mine = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = ids[i];
+    const int64_t l = (v >= 0 && v < n_labels) ? labels[v] : fill;
+    out[i] = l;
+    mine += (l != fill && l >= 0) ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, kWave);
+  __shared__ int s_cnt[4];
+  if ((threadIdx.x & (kWave - 1)) == 0) s_cnt[threadIdx.x / kWave] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (t) atomicAdd(&scratch[0], t);
+    __threadfence();                                   // this block's sum is visible before its ticket is
+    const int ticket = atomicAdd(&scratch[1], 1);
+    if (ticket == (int)gridDim.x - 1) {                // every other block's sum is in: publish and clean up
+      __threadfence();
+      const int total = atomicExch(&scratch[0], 0);
+      *n_valid = total;
+      atomicExch(&scratch[1], 0);
+    }
+  }
+}
+
 static int launch_split(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map, int32_t* miss_pos,
                         int64_t* miss_fullid, int32_t* miss_count, int32_t* slots_out, uint64_t* stats,
                         const pg_dedup_t* dedup, hipStream_t st) {
@@ -572,6 +605,42 @@ int pg_split_rows_dedup(const int64_t* ids, int64_t n, const int32_t* slot_map, 
   return launch_split(ids, n, slot_map, nid_map, miss_pos, miss_fullid, miss_count, slots_out, stats, dedup, st);
 }
 
+// slots of a launch over a FULLY cached table (storage.py:207-216's fetch_from_cache, for rows that are read in place): no
+// miss list, so no counter to zero first — one launch instead of a 4-byte fill + the split (the launch thread bounds the
+// step once the table is cached). Padding ids (< 0) -> -2; stats[0] += rows looked up (storage.py:203's try counter).
+__global__ __launch_bounds__(256) void k_slots_full(const int64_t* __restrict__ ids, int64_t n,
+                                                    const int32_t* __restrict__ slot_map, int32_t* __restrict__ slots_out,
+                                                    unsigned long long* __restrict__ stats) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int valid = 0;
+  if (i < n) {
+    const int64_t v = ids[i];
+    valid = v >= 0;
+    slots_out[i] = valid ? slot_map[v] : -2;
+  }
+  if (stats) {
+    const unsigned long long b = __ballot(valid);
+    __shared__ int s_cnt[4];
+    if ((threadIdx.x & (kWave - 1)) == 0) s_cnt[threadIdx.x / kWave] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int t = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+      if (t) atomicAdd(&stats[0], (unsigned long long)t);
+    }
+  }
+}
+
+int pg_slots_full(const int64_t* ids, int64_t n, const int32_t* slot_map, int32_t* slots_out, uint64_t* stats,
+                  pg_stream_t stream) {
+  if (n < 0 || n > INT32_MAX) return PG_ERR_INVALID;
+  if (n == 0) return PG_OK;
+  if (!ids || !slot_map || !slots_out) return PG_ERR_INVALID;
+  hipLaunchKernelGGL(k_slots_full, dim3((unsigned)ceil_div<int64_t>(n, 256)), dim3(256), 0, as_stream(stream), ids, n, slot_map,
+                     slots_out, reinterpret_cast<unsigned long long*>(stats));
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
 int pg_scatter_rows_dups(const float* staged, const int32_t* dup_pos, const int32_t* dup_staged_row, int64_t cap,
                          const int32_t* dup_count_dev, int32_t dim, float* out, int32_t out_stride, int32_t pos_lo,
                          pg_stream_t stream) {
@@ -637,6 +706,17 @@ int pg_gather_labels(const int64_t* ids, int64_t n, const int64_t* labels, int64
   int64_t g = ceil_div<int64_t>(n, 256);
   hipLaunchKernelGGL(k_gather_labels, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, as_stream(stream), ids, n,
                      labels, n_labels, fill, out, n_valid_out);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+int pg_gather_labels_sc(const int64_t* ids, int64_t n, const int64_t* labels, int64_t n_labels, int64_t fill,
+                        int64_t* out, int32_t* n_valid_out, int32_t* scratch2, pg_stream_t stream) {
+  if (n <= 0 || n_labels < 0 || !n_valid_out || !scratch2) return PG_ERR_INVALID;
+  if (!ids || !out || (!labels && n_labels > 0)) return PG_ERR_INVALID;
+  int64_t g = ceil_div<int64_t>(n, 256);
+  hipLaunchKernelGGL(k_gather_labels_sc, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, as_stream(stream), ids, n,
+                     labels, n_labels, fill, out, n_valid_out, scratch2);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }

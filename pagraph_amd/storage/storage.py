@@ -734,10 +734,15 @@ class GraphCacheServer:
             self._ensure_capacity(R)
             miss_pos, miss_fullid, miss_count = L.ptr(self._miss_pos), L.ptr(self._miss_fullid), L.ptr(self._miss_count)
         dd = self._plan_dedup(plan, slot) if use_q else None
-        L.check(self.lib.pg_split_rows_dedup(ids, R, L.ptr(self.slot_map), L.ptr(self.nid_map), miss_pos, miss_fullid,
-                                             miss_count, L.ptr(plan.slots), L.ptr(self._stats) if self.log else None,
-                                             ctypes.byref(dd) if dd is not None else None, sp),
-                "pg_split_rows")
+        if self.full_cached and not use_q:
+            # nothing can miss: the slots alone, one launch (no miss counter to zero first)
+            L.check(self.lib.pg_slots_full(ids, R, L.ptr(self.slot_map), L.ptr(plan.slots),
+                                           L.ptr(self._stats) if self.log else None, sp), "pg_slots_full")
+        else:
+            L.check(self.lib.pg_split_rows_dedup(ids, R, L.ptr(self.slot_map), L.ptr(self.nid_map), miss_pos, miss_fullid,
+                                                 miss_count, L.ptr(plan.slots), L.ptr(self._stats) if self.log else None,
+                                                 ctypes.byref(dd) if dd is not None else None, sp),
+                    "pg_split_rows")
         if plan.dense_rows > 0:
             timer = None
             if self.profile is not None:

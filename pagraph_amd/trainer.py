@@ -176,6 +176,10 @@ def cycle_batches(sampler, steps):
             return
 
 
+import os as _os_mod
+_LABELS_MEMSET = bool(_os_mod.environ.get("PG_LABELS_MEMSET"))     # A/B: the label lookup behind a zero fill (rounds 1-3)
+
+
 class GraphedTrainer:
     """The same loop with the whole compute step (forward, loss, backward, Adam) replayed as a
     hipGraph.  Everything between "seed ids" and "logits" has a fixed shape: the sampler emits
@@ -340,7 +344,9 @@ class GraphedTrainer:
             s.out = {n: torch.zeros((R, (d + 7) & ~7 if d >= 64 else d), dtype=torch.float32, device=self.device)[:, :d]
                      for n, d in self.cacher.dims.items()}
             s.label = torch.full((nf.layer_size(-1),), -100, dtype=torch.int64, device=self.device)
-            s.n_valid = torch.zeros(1, dtype=torch.int32, device=self.device)   # labels the loss will count
+            # labels the loss will count (+ the label lookup's two self-cleaning scratch words, pg_gather_labels_sc)
+            s.n_valid3 = torch.zeros(4, dtype=torch.int32, device=self.device)
+            s.n_valid = s.n_valid3[:1]
         s.ready = torch.cuda.Event()
         s.done = torch.cuda.Event()
         s.done_recorded = False
@@ -403,9 +409,14 @@ class GraphedTrainer:
             self._aggregate_early(nf, s, ls)
         o0, o1 = nf._layer_offsets[-2], nf._layer_offsets[-1]
         sp = ctypes.c_void_p(ls.cuda_stream)
-        L.check(self._lib.pg_gather_labels(ctypes.c_void_p(ids.data_ptr() + 8 * o0), o1 - o0, L.ptr(self.labels),
-                                           self.labels.numel(), -100, L.ptr(s.label), L.ptr(s.n_valid), sp),
-                "pg_gather_labels")
+        if o1 > o0 and not _LABELS_MEMSET:
+            L.check(self._lib.pg_gather_labels_sc(ctypes.c_void_p(ids.data_ptr() + 8 * o0), o1 - o0, L.ptr(self.labels),
+                                                  self.labels.numel(), -100, L.ptr(s.label), L.ptr(s.n_valid),
+                                                  ctypes.c_void_p(s.n_valid3.data_ptr() + 4), sp), "pg_gather_labels_sc")
+        else:
+            L.check(self._lib.pg_gather_labels(ctypes.c_void_p(ids.data_ptr() + 8 * o0), o1 - o0, L.ptr(self.labels),
+                                               self.labels.numel(), -100, L.ptr(s.label), L.ptr(s.n_valid), sp),
+                    "pg_gather_labels")
         s.ready.record(ls)
         if dbg is not None:
             ev[3].record(ls)

@@ -161,6 +161,16 @@ def test_gather_labels_and_valid_count(dev, hiplib, n):
     want = np.where(ids >= 0, labels.cpu().numpy()[np.maximum(ids, 0)], -100)
     assert np.array_equal(out.cpu().numpy(), want)
     assert int(cnt.item()) == int((ids >= 0).sum())
+    # the self-cleaning variant (no zero fill in front): same outputs, call after call, its two scratch words back at zero
+    out2 = torch.full((n,), 7777, dtype=torch.int64, device=dev)
+    cnt2 = torch.full((1,), 123456, dtype=torch.int32, device=dev)
+    scr = torch.zeros(2, dtype=torch.int32, device=dev)
+    for _ in range(3):
+        L.check(hiplib.pg_gather_labels_sc(L.ptr(d_ids), n, L.ptr(labels), V, -100, L.ptr(out2), L.ptr(cnt2), L.ptr(scr),
+                                           L.stream_ptr()))
+        torch.cuda.synchronize()
+        assert int(cnt2.item()) == int((ids >= 0).sum()) and scr.tolist() == [0, 0]
+    assert np.array_equal(out2.cpu().numpy(), want)
 
 
 @pytest.mark.parametrize("n,F,ratio", [(1, 600, 0.5), (63, 600, 0.0), (64, 602, 1.0), (65, 600, 0.3), (4097, 128, 0.3),
