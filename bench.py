@@ -810,31 +810,43 @@ def run():
         torch.cuda.synchronize()
     # ---- every rank sizes its CPU leg of the miss path from what its host can really do (VERDICT r02 #1a) ----
     share_rec = None
-    if adapt_share and use_graph and cacher.miss_mode == "async" and not cacher.full_cached and table_device_visible:
+    adapt_here = bool(adapt_share and use_graph and cacher.miss_mode == "async" and not cacher.full_cached and table_device_visible)
+    if (bool(parallel.max_over_ranks(1.0 if adapt_here else 0.0, device=dev)) if world > 1 else adapt_here):
         trainer.run_steps(it, 12)                          # a dozen steady-state jobs for the worker's counters
         trainer.synchronize()
-        share_rec = cacher.adapt_cpu_share(min_jobs=8, apply=False)
-        if share_rec and share_rec["cpu_share"] != share_rec["cpu_share_before"]:
+        share_rec = cacher.adapt_cpu_share(min_jobs=8, apply=False) if adapt_here else None
+        # EVERY step contains a gradient all-reduce when world > 1: the ranks must run the same NUMBER of steps whatever each
+        # of them decides about its own split. Until round 4 the second window and the re-capture steps below ran only on the
+        # ranks whose own measurement asked for them — a rank that disagreed with its peers left them waiting in an all-reduce
+        # for ever (the "two ranks on one GPU" time-outs of rounds 3 and 4: 1 run in 5 once the faster CPU gather made the
+        # ranks' measurements straddle the threshold; `tools/hunt_two_ranks.sh`). The decisions are now agreed (max over ranks).
+        def anywhere(flag):
+            return bool(parallel.max_over_ranks(1.0 if flag else 0.0, device=dev)) if world > 1 else bool(flag)
+        wants = bool(share_rec and share_rec["cpu_share"] != share_rec["cpu_share_before"])
+        if anywhere(wants):
             # A busy moment of a shared host reads like a starved one (profiles/r03: one collection measured 0.075 us per
             # row in this window, 0.041 right after, and ran the whole epoch 9 % slower with 44 % of the rows read by
             # the device). Leaving the all-CPU path takes two windows in a row that say so; the milder of the two wins.
             trainer.run_steps(it, 24)
             trainer.synchronize()
             second = cacher.adapt_cpu_share(min_jobs=8, quiet=True, apply=False)
-            share_rec["first_window"] = {k_: share_rec[k_] for k_ in ("us_per_row_cpu_gather", "cpu_share")}
-            if second:
-                share_rec["us_per_row_cpu_gather"] = second["us_per_row_cpu_gather"]
-                share_rec["cpu_share"] = max(share_rec["cpu_share"], second["cpu_share"])
-            if share_rec["cpu_share"] != share_rec["cpu_share_before"]:
-                cacher.apply_cpu_share(share_rec["cpu_share"])
-            log(f"[bench] rank {rank}: cpu_share {share_rec['cpu_share_before']} -> {share_rec['cpu_share']} "
-                f"(windows: {share_rec['first_window']['cpu_share']}, {second['cpu_share'] if second else None})")
-        if share_rec and share_rec["cpu_share"] != share_rec["cpu_share_before"]:
-            trainer.run_steps(it, S)                       # new fetch plans -> one re-capture per ring slot
+            if wants:
+                share_rec["first_window"] = {k_: share_rec[k_] for k_ in ("us_per_row_cpu_gather", "cpu_share")}
+                if second:
+                    share_rec["us_per_row_cpu_gather"] = second["us_per_row_cpu_gather"]
+                    share_rec["cpu_share"] = max(share_rec["cpu_share"], second["cpu_share"])
+                if share_rec["cpu_share"] != share_rec["cpu_share_before"]:
+                    cacher.apply_cpu_share(share_rec["cpu_share"])
+                log(f"[bench] rank {rank}: cpu_share {share_rec['cpu_share_before']} -> {share_rec['cpu_share']} "
+                    f"(windows: {share_rec['first_window']['cpu_share']}, {second['cpu_share'] if second else None})")
+        changed = bool(share_rec and share_rec["cpu_share"] != share_rec["cpu_share_before"])
+        if anywhere(changed):
+            trainer.run_steps(it, S)                       # new fetch plans -> one re-capture per ring slot (where it changed)
             trainer.synchronize()
-            again = cacher.adapt_cpu_share(min_jobs=8, quiet=True, apply=False)   # what the new split measures; not chased
-            share_rec["after"] = {"us_per_row_cpu_gather": again["us_per_row_cpu_gather"],
-                                  "cpu_share_it_would_pick_now": again["cpu_share"]} if again else None
+            if changed:
+                again = cacher.adapt_cpu_share(min_jobs=8, quiet=True, apply=False)   # what the new split measures; not chased
+                share_rec["after"] = {"us_per_row_cpu_gather": again["us_per_row_cpu_gather"],
+                                      "cpu_share_it_would_pick_now": again["cpu_share"]} if again else None
         torch.cuda.synchronize()
     # ---- warm-up: W steady-state steps, untimed ----
     if W > 0:

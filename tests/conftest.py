@@ -105,3 +105,32 @@ def dev():
         pytest.skip("no GPU")
     torch.cuda.set_device(0)
     return torch.device("cuda", 0)
+
+
+def run_group(cmd, timeout, **kw):
+    """subprocess.run(cmd, capture_output=True, text=True, timeout=...) for commands that spawn GPU processes of their own
+    (torch.distributed.run, the trainer scripts): the command gets a process GROUP, and on a time-out the whole group is
+    killed before the test fails with what the command had printed. subprocess.run kills only its direct child: the ranks of
+    a hung torchrun then stayed alive ON THE GPU, and minutes later the test process itself met a sticky
+    hipErrorIllegalAddress and dumped core while pytest rendered that failure (round 4: both sightings of "the core dump"
+    came right behind a timed-out two-rank bench; profiles/r04/core_dump_*.txt)."""
+    import signal
+    import subprocess
+    import types
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True, **kw)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        out, err = p.communicate()
+        pytest.fail(f"timed out after {timeout} s (process group killed): {' '.join(map(str, cmd))[-300:]}\n"
+                    f"--- stdout tail\n{out[-1500:]}\n--- stderr tail\n{err[-6000:]}", pytrace=False)
+    finally:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)        # stragglers of a command that returned (a rank that outlived its agent)
+        except (ProcessLookupError, PermissionError):
+            pass
+    return types.SimpleNamespace(returncode=p.returncode, stdout=out, stderr=err)

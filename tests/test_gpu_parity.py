@@ -639,8 +639,8 @@ def test_cli_pipeline_end_to_end(dev, hiplib, tmp_path):
     ds.mkdir()
     env = dict(os.environ, PYTHONPATH=ROOT)
     # (a fresh rendezvous port per script: seven process groups in a row on one fixed port can wait on TIME_WAIT)
-    run = lambda *a: subprocess.run([sys.executable, *a], cwd=ROOT, env=dict(env, MASTER_PORT=str(_free_port())),
-                                    capture_output=True, text=True, timeout=600)
+    from conftest import run_group              # (the trainer scripts spawn a process per GPU: kill the GROUP on a time-out)
+    run = lambda *a: run_group([sys.executable, *a], 600, cwd=ROOT, env=dict(env, MASTER_PORT=str(_free_port())))
     r = run("-m", "pagraph_amd.data.preprocess", "--dataset", str(ds), "--gen-rmat", "20000", "120000", "--gen-feature",
             "--feat-size", "64", "--gen-label", "--class-num", "7", "--gen-set")
     assert r.returncode == 0, r.stderr[-2000:]
@@ -1840,11 +1840,11 @@ def test_bench_two_ranks_as_the_driver_launches_it(dev, hiplib):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--steps", "20", "--warmup", "5", "--dist-backend", "gloo",
-                        "--vertices", "300000", "--edges", "3000000"], cwd=ROOT, capture_output=True, text=True,
-                       timeout=900, env=env)
+    from conftest import run_group
+    r = run_group([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                   "--gpus", "2", "--steps", "20", "--warmup", "5", "--dist-backend", "gloo",
+                   "--vertices", "300000", "--edges", "3000000"], 420, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -2464,7 +2464,8 @@ def test_eval_and_count_vnum_scripts(dev, hiplib, oracle, tmp_path):
     ds = tmp_path / "tiny"
     ds.mkdir()
     env = dict(os.environ, PYTHONPATH=ROOT, MASTER_PORT=str(_free_port()))
-    run = lambda *a: subprocess.run([sys.executable, *a], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    from conftest import run_group
+    run = lambda *a: run_group([sys.executable, *a], 600, cwd=ROOT, env=env)
     r = run("-m", "pagraph_amd.data.preprocess", "--dataset", str(ds), "--gen-rmat", "6000", "30000", "--gen-feature",
             "--feat-size", "32", "--gen-label", "--class-num", "5", "--gen-set")
     assert r.returncode == 0, r.stderr[-2000:]
