@@ -9,6 +9,8 @@
 #include <signal.h>
 #include <unistd.h>
 
+#include <fcntl.h>
+
 #include "pg_common.h"
 
 namespace pg {
@@ -21,12 +23,17 @@ thread_local ProfSucc g_prof_succ;
 // top of this one and hands the signal down). For the one core dump of round 3 that left nothing but a banner.
 namespace {
 struct sigaction g_prev_sa[NSIG];
+int g_bt_fd = -1;      // PG_NATIVE_BACKTRACE_FILE: a second copy that survives a test runner's capture of stderr
 void fault_handler(int sig, siginfo_t* info, void* ctx) {
   static const char head[] = "\n[libpagraph_hip] fatal signal, native back-trace of the faulting thread:\n";
   (void)!write(2, head, sizeof(head) - 1);
   void* frames[64];
   const int n = backtrace(frames, 64);
   backtrace_symbols_fd(frames, n, 2);
+  if (g_bt_fd >= 0) {
+    (void)!write(g_bt_fd, head, sizeof(head) - 1);
+    backtrace_symbols_fd(frames, n, g_bt_fd);
+  }
   const struct sigaction& prev = g_prev_sa[sig];
   if (prev.sa_flags & SA_SIGINFO) {
     if (prev.sa_sigaction) { prev.sa_sigaction(sig, info, ctx); return; }
@@ -43,6 +50,7 @@ struct FaultInit {
     if (!e || !atoi(e)) return;
     void* warm[2];
     (void)backtrace(warm, 2);                       // loads libgcc now, not inside the handler
+    if (const char* f = getenv("PG_NATIVE_BACKTRACE_FILE")) g_bt_fd = open(f, O_WRONLY | O_CREAT | O_APPEND, 0644);
     struct sigaction sa;
     memset(&sa, 0, sizeof(sa));
     sa.sa_sigaction = fault_handler;

@@ -15,6 +15,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # and (ii) keeps Python's faulthandler output of every thread in a file that survives the run (gpurun_out/ travels back from
 # the GPU box), besides pytest's own copy on stderr.
 os.environ.setdefault("PG_NATIVE_BACKTRACE", "1")
+_out = os.path.join(ROOT, "gpurun_out")
+if os.path.isdir(_out) and os.access(_out, os.W_OK):
+    # a copy of that back-trace outside pytest's capture of stderr (which dies with the process). Written only on a fatal signal.
+    os.environ.setdefault("PG_NATIVE_BACKTRACE_FILE", os.path.join(_out, f"native_backtrace_{os.getpid()}.txt"))
 os.environ.setdefault("PYTHONFAULTHANDLER", "1")        # child processes (mp.spawn workers, subprocess CLIs) too
 _FAULT_LOG = None
 
@@ -39,6 +43,12 @@ def pytest_sessionstart(session):
 
 def pytest_sessionfinish(session, exitstatus):
     global _FAULT_LOG
+    bt = os.environ.get("PG_NATIVE_BACKTRACE_FILE")
+    try:
+        if bt and os.path.exists(bt) and os.path.getsize(bt) == 0:
+            os.unlink(bt)                     # opened when the library loaded, written only on a fatal signal
+    except OSError:
+        pass
     if _FAULT_LOG is not None:
         import faulthandler
         faulthandler.disable()
