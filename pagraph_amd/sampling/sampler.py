@@ -183,6 +183,17 @@ class NeighborSampler:
         torch.cuda.current_stream(self.device).synchronize()
 
     def __del__(self):
+        # A sampling chain may still be in flight (the iterator samples one batch ahead and nobody waits for the last one):
+        # its kernels WRITE the ring slots' buffers, which are torch tensors — freed without a wait they are handed to the
+        # next allocation while the chain still scribbles into them (a later pipeline then reads a corrupted slot array or
+        # index list: the rare hipErrorIllegalAddress of round 4's whole-suite runs, always in tests that build several
+        # pipelines back to back). Wait for the stream before anything is released.
+        try:
+            st = getattr(self, "stream", None)
+            if st is not None:
+                st.synchronize()
+        except Exception:
+            pass
         try:
             if getattr(self, "handle", None):
                 self.lib.pg_sampler_destroy(self.handle)

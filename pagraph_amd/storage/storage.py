@@ -996,6 +996,13 @@ class GraphCacheServer:
 
     def __del__(self):
         try:
+            # kernels of a pipeline that is being dropped may still write this object's index buffers (torch tensors: freed
+            # without a wait they are recycled under the kernels' feet — see NeighborSampler.__del__)
+            if torch.cuda.is_available() and getattr(self, "device", None) is not None:
+                torch.cuda.synchronize(self.device)
+        except Exception:
+            pass
+        try:
             if getattr(self, "_missq", None):
                 self.lib.pg_missq_destroy(self._missq)
                 self._missq = None

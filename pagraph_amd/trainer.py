@@ -34,6 +34,14 @@ class Prepared:
 
 
 class MinibatchTrainer:
+    def __del__(self):
+        try:                             # the load stream may still be writing this trainer's frames (see NeighborSampler.__del__)
+            st = getattr(self, "load_stream", None)
+            if st is not None:
+                st.synchronize()
+        except Exception:
+            pass
+
     def __init__(self, model, loss_fcn, optimizer, cacher, sampler, labels, device, overlap=True, need=None):
         self.need = need             # fetch_data(need=...): None = every layer and field, like the reference
         self.model, self.loss_fcn, self.optimizer = model, ops.fused_loss(loss_fcn), optimizer
@@ -328,6 +336,17 @@ class GraphedTrainer:
 
     class _Slot:
         pass
+
+    def __del__(self):
+        # the load / compute streams may still be writing this trainer's per-slot buffers (frames, slot arrays, labels,
+        # early-aggregated rows): wait before they are released (see NeighborSampler.__del__)
+        for name in ("load_stream", "compute_stream", "comm_stream"):
+            try:
+                st = getattr(self, name, None)
+                if st is not None:
+                    st.synchronize()
+            except Exception:
+                pass
 
     def _make_slot(self, nf):
         s = GraphedTrainer._Slot()
