@@ -738,8 +738,8 @@ def test_graphed_trainer_matches_eager(dev, hiplib):
 def test_early_layer0_aggregation_matches_the_in_step_one(dev, hiplib, ratio, miss_mode, arch, monkeypatch):
     """GraphedTrainer.early_aggregate: block 0's aggregation launched from prepare() on the load stream (ahead of its step)
     gives the same loss trajectory, bit for bit, as the aggregation inside the replayed step (dropout off: the same kernel on
-    the same rows) — table cached ('auto' switches it on) and partial cache over the async miss queue (forced '1': the miss
-    rows are waited for on the load stream); with dropout on it draws a fresh mask per batch and still trains."""
+    the same rows) with the table cached; a partial cache keeps the aggregation in the step whatever the mode; with dropout on
+    the early launch draws the very masks the in-step path draws."""
     import torch.nn.functional as Fn
     from pagraph_amd.model import GCNSampling, GraphSageSampling
     from pagraph_amd.optim import Adam
@@ -778,12 +778,15 @@ def test_early_layer0_aggregation_matches_the_in_step_one(dev, hiplib, ratio, mi
 
     base, n0, used0 = run("0", 0.0)
     assert n0 == 0 and used0 == 0
-    for mode in (["auto", "1"] if ratio == 1.0 else ["1"]):
+    if ratio < 1.0:
+        for mode in ("auto", "1"):                                 # a partial cache keeps the aggregation in the step
+            got, n1, used1 = run(mode, 0.0)
+            assert n1 == 0 and used1 == 0 and np.array_equal(got, base)
+        return
+    for mode in ("auto", "1"):
         got, n1, used1 = run(mode, 0.0)
         assert n1 >= 24 and used1 > 0, (mode, n1, used1)          # every batch of the run (+ the look-ahead) went early
         assert np.array_equal(got, base), (mode, got, base)
-    if ratio < 1.0:
-        assert run("auto", 0.0)[1] == 0                            # a partial cache keeps the aggregation in the step
     # dropout on: the early launch is keyed by the value the model's step counter will hold when the batch is computed —
     # the masks, and with them every loss, are the in-step path's
     drop, n2, _ = run("1", 0.3, steps=40)
