@@ -285,3 +285,28 @@ def test_dg_hops2_threaded_equals_sequential(hiplib, P, threads):
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
     assert a[2].sum() == len(np.unique(train))
+
+
+def test_run_group_kills_the_whole_process_group_on_a_timeout(tmp_path):
+    """conftest.run_group: a command that spawned children of its own (torchrun's ranks) and hangs is killed WITH them — a
+    surviving rank of a timed-out two-rank bench is what stood behind round 4's core dumps"""
+    import subprocess
+    import sys
+    import time
+    from conftest import run_group
+    pidfile = tmp_path / "child.pid"
+    script = ("import subprocess, sys, time\n"
+              f"p = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(300)'])\n"
+              f"open({str(pidfile)!r}, 'w').write(str(p.pid))\n"
+              "time.sleep(300)\n")
+    with pytest.raises(pytest.fail.Exception, match="timed out"):
+        run_group([sys.executable, "-c", script], 3)
+    child = int(pidfile.read_text())
+    for _ in range(50):                       # the grandchild is gone too (reaped by init: /proc entry disappears)
+        if not os.path.exists(f"/proc/{child}") or open(f"/proc/{child}/stat").read().split()[2] == "Z":
+            break
+        time.sleep(0.1)
+    else:
+        raise AssertionError("the grandchild survived the group kill")
+    r = run_group([sys.executable, "-c", "print('fine')"], 30)
+    assert r.returncode == 0 and r.stdout.strip() == "fine"
