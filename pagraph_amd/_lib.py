@@ -249,10 +249,85 @@ def stream_ptr(stream=None):
     return ctypes.c_void_p(s.cuda_stream)
 
 
-_MASKED = {}     # (device index, role) -> torch ExternalStream over a CU-masked HIP stream (one per process and role)
+def del_waits_enabled():
+    """PG_NO_DEL_WAIT=1 switches the finalizers' stream waits off (diagnosis: with them off, only the allocator-side
+    lifetime rule below protects a pipeline that is dropped with work in flight — DESIGN section 3 'Lifetimes')"""
+    return not os.environ.get("PG_NO_DEL_WAIT")
 
 
-def pipeline_stream(device, role, priority=0):
+def safe_stream_wait(stream):
+    """a finalizer's best-effort wait: never inside a capture of this thread (a synchronize there is illegal and
+    invalidates the capture), never raises"""
+    try:
+        if stream is None or not del_waits_enabled() or torch.cuda.is_current_stream_capturing():
+            return
+        stream.synchronize()
+    except Exception:
+        pass
+
+
+def record_streams(root, streams, _seen=None, _depth=0):
+    """tensor.record_stream(s) for every CUDA tensor reachable from `root` and every stream in `streams`.
+
+    torch's caching allocator hands a freed block back to the stream it was ALLOCATED on at once: a buffer allocated on the
+    default stream and written by kernels on a sampler / load / compute stream is recycled under those kernels' feet when its
+    owner is dropped with work in flight (round 4's rare hipErrorIllegalAddress in whole-suite runs). record_stream is the
+    allocator's own cure: at free time it records an event on every recorded stream and defers the block's reuse until those
+    events have completed — whatever drops the owner (refcount, cyclic GC, interpreter exit) and whether or not a
+    finalizer ran. Called ONCE per buffer, where the buffer is created (the cost is paid at free time only).
+    Walks tensors, lists / tuples / dicts / sets, nn.Modules (parameters + buffers), optimizers (state) and plain
+    pagraph_amd objects; PG_NO_RECORD_STREAM=1 switches it off (diagnosis)."""
+    if os.environ.get("PG_NO_RECORD_STREAM") or root is None:
+        return
+    streams = [s for s in streams if s is not None]
+    if not streams:
+        return
+    if _seen is None:
+        _seen = set()
+    if id(root) in _seen or _depth > 6:
+        return
+    _seen.add(id(root))
+    if torch.is_tensor(root):
+        if root.is_cuda:
+            for st in streams:
+                try:
+                    root.record_stream(st)
+                except RuntimeError:
+                    pass              # memory the caching allocator does not own (an external / mapped allocation)
+        return
+    if isinstance(root, (str, bytes, int, float, bool, ctypes.Structure, ctypes.Array, torch.cuda.Stream, torch.cuda.Event)):
+        return
+    if isinstance(root, dict):
+        for v in root.values():
+            record_streams(v, streams, _seen, _depth + 1)
+        return
+    if isinstance(root, (list, tuple, set, frozenset)):
+        for v in root:
+            record_streams(v, streams, _seen, _depth + 1)
+        return
+    if isinstance(root, torch.nn.Module):
+        for t in list(root.parameters()) + list(root.buffers()):
+            record_streams(t, streams, _seen, _depth + 1)
+            if t.grad is not None:
+                record_streams(t.grad, streams, _seen, _depth + 1)
+        return
+    if isinstance(root, torch.optim.Optimizer):
+        record_streams(dict(root.state), streams, _seen, _depth + 1)
+    if type(root).__module__.startswith("pagraph_amd"):
+        d = getattr(root, "__dict__", None)
+        if d is not None:
+            for k, v in list(d.items()):
+                if k in ("model", "optimizer", "cacher", "sampler", "g", "store", "lib", "_lib"):
+                    continue          # other owners: their creators / the trainer record them explicitly
+                record_streams(v, streams, _seen, _depth + 1)
+        for k in getattr(type(root), "__slots__", ()):
+            record_streams(getattr(root, k, None), streams, _seen, _depth + 1)
+
+
+_MASKED = {}     # (device index, role, user name) -> torch ExternalStream over a CU-masked HIP stream (one per process and role)
+
+
+def pipeline_stream(device, role, priority=0, name=None):
     """A stream for one role of the training pipeline: 'side' (sampler chain, load stream: a handful of small latency-bound
     launches per step) or 'compute' (the replayed step, HBM-bound). Default: a plain torch stream of the given priority.
     PG_CU_SIDE=<n> (experiment): the side streams may only use n CUs (the low n bits of the CU mask, which
@@ -267,13 +342,18 @@ def pipeline_stream(device, role, priority=0):
         return torch.cuda.Stream(device=device, priority=priority)
     if role == "compute" and os.environ.get("PG_CU_COMPUTE_ALL"):
         return torch.cuda.Stream(device=device, priority=priority)
+    if (idx, role, name) in _MASKED:
+        # ONE masked stream per (device, role, user name) and process: pg_stream_create_masked's stream is never destroyed by its users
+        # (every sampler / trainer leaked one); the requested priority does not apply to CU-masked streams
+        return _MASKED[(idx, role, name)]
     words = (cus + 31) // 32
     bits = ((1 << n) - 1) if role == "side" else (((1 << cus) - 1) ^ ((1 << n) - 1))
     arr = (ctypes.c_uint32 * words)(*[(bits >> (32 * i)) & 0xFFFFFFFF for i in range(words)])
     out = ctypes.c_void_p()
     with torch.cuda.device(idx):
         check(load().pg_stream_create_masked(arr, words, ctypes.byref(out)), "pg_stream_create_masked")
-    return torch.cuda.ExternalStream(out.value, device=dev)
+    _MASKED[(idx, role, name)] = torch.cuda.ExternalStream(out.value, device=dev)
+    return _MASKED[(idx, role, name)]
 
 
 def ptr(t):

@@ -160,6 +160,12 @@ class _GCNBase(FusedDropoutMixin, nn.Module):
         last = self.layers[-1]
         if self.uses_norm or last.test or last.concat or last.activation is not None or not labels.is_cuda:
             return None
+        # the head's static envelope BEFORE the layers below it run (a head that declines afterwards made the caller's
+        # fall-back forward(nf) run those layers a second time — inside a captured step, every step)
+        drop_active = bool(self.training and getattr(self, 'dropout', None) and not self.preprocess and self.dropout.p > 0)
+        if (labels.dtype != torch.int64 or labels.numel() == 0
+                or not ops.head_fits(last.linear.in_features, 0, last.linear.out_features, (last.linear.weight,), drop_active)):
+            return None
         self._bump_drop_step()
         h = self._input_transform(nf) if self.preprocess else nf.layers[0].data['features']
         n = len(self.layers)
@@ -181,9 +187,20 @@ class _GCNBase(FusedDropoutMixin, nn.Module):
             drop = self._drop_spec(i, h)
             if drop is None:
                 h = self.dropout(h)
-        return ops.gcn_head(nf.blk_indptr[i], nf.blk_src[i], h, last.linear, labels, n_valid, grad_seed, ignore_index,
-                            self.reducer(msg='m', out='h').op, drop,
-                            (nf.blk_tptr[i], nf.blk_tdst[i], nf.blk_theavy[i]), want_logits)
+        out = None
+        if torch.is_tensor(h):
+            out = ops.gcn_head(nf.blk_indptr[i], nf.blk_src[i], h, last.linear, labels, n_valid, grad_seed, ignore_index,
+                               self.reducer(msg='m', out='h').op, drop,
+                               (nf.blk_tptr[i], nf.blk_tdst[i], nf.blk_theavy[i]), want_logits)
+        if out is None:
+            # only the run-time tensor could say no (strides): the output layer finishes unfused from the state the layers
+            # below left, instead of handing the caller a None it answers with a second run of the whole model
+            nf.layers[i].data['h'] = h
+            nf.block_compute(i, fn.copy_src(src='h', out='m'), self.reducer(msg='m', out='h'), last, dropout=drop)
+            logits = nf.layers[i + 1].data.pop('activation')
+            loss = ops.cross_entropy(logits, labels, ignore_index)
+            out = (loss, logits) if want_logits else loss
+        return out
 
 
 class GCNSampling(_GCNBase):

@@ -121,20 +121,36 @@ class GraphSageSampling(FusedDropoutMixin, nn.Module):
         if (self.preprocess or want_logits or self.aggregator_type not in ('mean', 'gcn') or last.concat
                 or last.activation is not None or not labels.is_cuda or len(self.layers) < 2):
             return None
-        L = nf.num_layers
-        h = self._forward_layers(nf, upto=len(self.layers) - 1)
-        if h is None:
+        # the head's envelope is checked BEFORE the layers below it run: they pop every frame's 'features', so a head that
+        # declined afterwards left the caller's fall-back forward(nf) a consumed NodeFlow (--n-hidden 32)
+        drop_active = bool(self.training and 0.0 < self.dropout.p)
+        if (labels.dtype != torch.int64 or labels.numel() == 0
+                or not ops.head_fits(last.fc_neigh.in_features, last.fc_self.in_features, last.fc_neigh.out_features,
+                                     (last.fc_neigh.weight, last.fc_self.weight), drop_active)):
             return None
+        L = nf.num_layers
+        self._forward_layers(nf, upto=len(self.layers) - 1)
         lid, i = len(self.layers) - 1, L - 2
         src_h, self_h = nf.layers[i].data['h'], nf.layers[i + 1].data['h']
-        if not (torch.is_tensor(src_h) and torch.is_tensor(self_h)):
-            return None
+        red = _REDUCERS[self.aggregator_type]
+        loss = None
         drop = self._drop_spec(lid * 16 + i, src_h) if self.training else None
-        if drop is None and self.training and self.dropout.p > 0:
-            src_h = self._dropout_or_raise(src_h)
-        red = _REDUCERS[self.aggregator_type]('m', 'neigh').op
-        return ops.sage_head(nf.blk_indptr[i], nf.blk_src[i], src_h, last.fc_neigh, self_h, last.fc_self, labels, n_valid,
-                             grad_seed, ignore_index, red, drop, (nf.blk_tptr[i], nf.blk_tdst[i], nf.blk_theavy[i]))
+        if torch.is_tensor(src_h) and torch.is_tensor(self_h):
+            h_in = src_h
+            if drop is None and drop_active:
+                h_in = self._dropout_or_raise(src_h)
+            loss = ops.sage_head(nf.blk_indptr[i], nf.blk_src[i], h_in, last.fc_neigh, self_h, last.fc_self, labels, n_valid,
+                                 grad_seed, ignore_index, red('m', 'neigh').op, drop,
+                                 (nf.blk_tptr[i], nf.blk_tdst[i], nf.blk_theavy[i]))
+        if loss is None:
+            # what only the run-time tensors can say (strides, a row source instead of a tensor): the last layer finishes
+            # UNFUSED from the state the layers below left — never `return None` with the frames consumed
+            d = nf.layers[i].data
+            if drop is None:
+                d['h'] = self._dropout_or_raise(d.pop('h'))
+            nf.block_compute(i, fn.copy_src(src='h', out='m'), red('m', 'neigh'), last, dropout=drop)
+            loss = ops.cross_entropy(nf.layers[L - 1].data.pop('activation'), labels, ignore_index)
+        return loss
 
     def forward(self, nf):
         h = self._forward_layers(nf, upto=len(self.layers))

@@ -834,6 +834,17 @@ class _SageHead(torch.autograd.Function):
                 (gbs if ok[3] else None) if ctx.has_bias[1] else None) + (None,) * 9
 
 
+def head_fits(n_agg_cols, n_self_cols, n_classes, weights, dropout_active):
+    """the STATIC part of pg_gcn_head / pg_sage_head's envelope, from the module alone: a model asks BEFORE it runs (and
+    consumes) the layers below the head — a head that declines afterwards leaves a NodeFlow whose frames were popped
+    (`pa_gs.py --n-hidden 32` raised KeyError('features') in the fall-back forward)."""
+    if n_agg_cols + n_self_cols > 64 or n_classes > 64:
+        return False
+    if dropout_active and n_agg_cols % 4:
+        return False
+    return all(w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() for w in weights)
+
+
 def sage_head(indptr, src, h, fc_neigh, h_self, fc_self, labels, n_valid, grad_seed=None, ignore_index=-100, reduce="mean",
               dropout=None, transpose=None):
     """loss of GraphSAGE's output layer over the last NodeFlow block: CrossEntropyLoss(fc_neigh(aggregate(dropout(h))) +

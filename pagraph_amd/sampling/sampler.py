@@ -147,7 +147,7 @@ class NeighborSampler:
                     "pg_sampler_create")
         self.handle = h
         import os as _os
-        self.stream = L.pipeline_stream(self.device, "side", int(_os.environ.get("PG_PRIO_SAMPLER", -1)))   # ~12 tiny latency-bound launches
+        self.stream = L.pipeline_stream(self.device, "side", int(_os.environ.get("PG_PRIO_SAMPLER", -1)), name="sampler")   # ~12 tiny latency-bound launches
         # stream on which the consumer finishes with a NodeFlow (None = current stream at hand-back);
         # a ring slot is re-sampled only after the event recorded there
         self.consumer_stream = None
@@ -181,25 +181,33 @@ class NeighborSampler:
         # the slots' buffers were zero-filled on the CURRENT stream; the sampling chain writes them on self.stream, which
         # does not synchronise with it: a late fill would wipe the first samples
         torch.cuda.current_stream(self.device).synchronize()
+        # Lifetimes: the ring slots, the seed list and the graph's arrays are allocated on the current stream and WRITTEN /
+        # read by the sampling chain on self.stream. The allocator is told so (L.record_streams): dropped with a chain in
+        # flight, their memory is not reused before the chain has finished — whatever drops them.
+        L.record_streams([self.slots, self.seeds, g.indptr, g.indices], [self.stream])
 
-    def __del__(self):
-        # A sampling chain may still be in flight (the iterator samples one batch ahead and nobody waits for the last one):
-        # its kernels WRITE the ring slots' buffers, which are torch tensors — freed without a wait they are handed to the
-        # next allocation while the chain still scribbles into them (a later pipeline then reads a corrupted slot array or
-        # index list: the rare hipErrorIllegalAddress of round 4's whole-suite runs, always in tests that build several
-        # pipelines back to back). Wait for the stream before anything is released.
-        try:
-            st = getattr(self, "stream", None)
-            if st is not None:
-                st.synchronize()
-        except Exception:
-            pass
+    def close(self):
+        """deterministic teardown: wait for the sampling chain, then release the library's handle (its own scratch is
+        hipMalloc'ed: pg_sampler_destroy frees it behind a device-wide wait). Idempotent; also the context manager's exit."""
+        L.safe_stream_wait(getattr(self, "stream", None))
         try:
             if getattr(self, "handle", None):
                 self.lib.pg_sampler_destroy(self.handle)
                 self.handle = None
         except Exception:
             pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        # best-effort backstop only (close() is the deterministic path; the buffers' lifetimes are the allocator's business,
+        # see __init__): a chain still in flight when the sampler is dropped must not outlive the handle's scratch
+        self.close()
 
     def __len__(self):
         return self.num_batches

@@ -994,11 +994,12 @@ class GraphCacheServer:
             raise L.PgError("async miss queue: a device-side wait for miss rows timed out (worker thread dead or "
                             "stalled); feature rows of at least one minibatch never landed")
 
-    def __del__(self):
+    def close(self):
+        """deterministic teardown: wait for the device (kernels of the pipeline may still read the cache, the slot map and the
+        miss queue's staged blocks), then stop the miss queue's threads and free its buffers. Idempotent."""
         try:
-            # kernels of a pipeline that is being dropped may still write this object's index buffers (torch tensors: freed
-            # without a wait they are recycled under the kernels' feet — see NeighborSampler.__del__)
-            if torch.cuda.is_available() and getattr(self, "device", None) is not None:
+            if (L.del_waits_enabled() and torch.cuda.is_available() and getattr(self, "device", None) is not None
+                    and not torch.cuda.is_current_stream_capturing()):
                 torch.cuda.synchronize(self.device)
         except Exception:
             pass
@@ -1008,6 +1009,19 @@ class GraphCacheServer:
                 self._missq = None
         except Exception:
             pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        # best-effort backstop (close() is the deterministic path). The torch buffers of this object that other streams touch
+        # are recorded on those streams by the trainers (L.record_streams): their memory outlives kernels in flight whatever
+        # drops the object; the miss queue's own blocks are freed by the library behind hipFree's device-wide wait
+        self.close()
 
     # -- storage.py:207-216 ---------------------------------------------------
     def fetch_from_cache(self, nodeflow, out=None):

@@ -34,13 +34,19 @@ class Prepared:
 
 
 class MinibatchTrainer:
+    def close(self):
+        """deterministic teardown: wait for the load stream (it may still be writing this trainer's frames)"""
+        L.safe_stream_wait(getattr(self, "load_stream", None))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def __del__(self):
-        try:                             # the load stream may still be writing this trainer's frames (see NeighborSampler.__del__)
-            st = getattr(self, "load_stream", None)
-            if st is not None:
-                st.synchronize()
-        except Exception:
-            pass
+        self.close()                     # best-effort backstop; the buffers' lifetimes are the allocator's (L.record_streams)
 
     def __init__(self, model, loss_fcn, optimizer, cacher, sampler, labels, device, overlap=True, need=None):
         self.need = need             # fetch_data(need=...): None = every layer and field, like the reference
@@ -59,6 +65,8 @@ class MinibatchTrainer:
         # (ops.RowSource). The next fetch into that slot waits for it — the worker's copy of batch k + slots would
         # otherwise overwrite rows batch k's aggregation has not read yet when the GPU runs behind the host
         self._consumed = {}
+        # Lifetimes (L.record_streams): what the load stream touches of objects allocated on other streams
+        L.record_streams([cacher, self.labels, getattr(sampler, "slots", None)], [self.load_stream])
 
     def _virtual(self, nf):
         m = getattr(self.model, 'module', self.model)
@@ -333,20 +341,38 @@ class GraphedTrainer:
         # True: prepare / compute run inside the reference's profiler ranges 'gpu-load' / 'gpu-compute' (pa_gcn.py:87,92);
         # off by default — a record_function costs the launch thread a few microseconds per step
         self.profile_ranges = False
+        # Lifetimes: everything the load / compute (/ communication) streams read or write of objects that were allocated on
+        # other streams — the sampler's ring, the cacher's cache / slot map / staging, the labels, the model and the optimiser
+        # state — is recorded on those streams once, here (L.record_streams): dropped with steps in flight, their memory is
+        # not reused before those steps have finished, with or without a finalizer.
+        L.record_streams([sampler.slots, sampler.seeds, cacher, self.labels, model, optimizer, self.flat],
+                         [self.load_stream, self.compute_stream, self.comm_stream])
 
     class _Slot:
         pass
 
-    def __del__(self):
-        # the load / compute streams may still be writing this trainer's per-slot buffers (frames, slot arrays, labels,
-        # early-aggregated rows): wait before they are released (see NeighborSampler.__del__)
+    def close(self):
+        """deterministic teardown: wait for the load / compute / communication streams, then drop the captured step graphs
+        (a graph's private pool is released with it: never under a replay still in flight). Idempotent."""
         for name in ("load_stream", "compute_stream", "comm_stream"):
-            try:
-                st = getattr(self, name, None)
-                if st is not None:
-                    st.synchronize()
-            except Exception:
-                pass
+            L.safe_stream_wait(getattr(self, name, None))
+        if L.del_waits_enabled():
+            for s_ in list(getattr(self, "slots", {}).values()):
+                s_.graph = None
+            self.graph_b = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        # best-effort backstop (never inside a capture: L.safe_stream_wait). What keeps a dropped trainer's buffers from being
+        # recycled under kernels still in flight is the allocator itself: every buffer another stream touches is recorded on
+        # that stream where it is created (L.record_streams in __init__ / _make_slot / _aggregate_early)
+        self.close()
 
     def _make_slot(self, nf):
         s = GraphedTrainer._Slot()
@@ -381,6 +407,10 @@ class GraphedTrainer:
         s.early = None         # [(block, field, RowSource)]: the aggregations of this slot's plan that run in prepare()
         s.agg0 = None          # ... and their outputs {block: [destination capacity, padded dim]}
         s.early_call = None    # ... and the cached arguments of its launch
+        s.early_training = None  # ... and the model's mode (train / eval) they were aggregated in
+        # allocated on the load stream, read by the captured step on the compute stream (and by the sampler's chain when it
+        # clears through the previous ids): see L.record_streams
+        L.record_streams([s.out, s.label, s.n_valid3], [self.compute_stream, self.load_stream, self.sampler.stream])
         return s
 
     def prepare(self, nf):
@@ -484,6 +514,7 @@ class GraphedTrainer:
             with torch.cuda.stream(ls):
                 s.agg0 = {blk: torch.empty((nf.layer_size(blk + 1), (rows.dim + 7) & ~7), dtype=torch.float32,
                                            device=self.device) for blk, _f, rows in s.early}
+            L.record_streams(s.agg0, [self.compute_stream])
             s.early_call = None
         if self._early_next is None or not self._prepared:
             # nothing of this trainer is prepared ahead: one read of the device counter (the pipeline is empty anyway)
@@ -515,6 +546,7 @@ class GraphedTrainer:
             if d is not None:
                 d.step_value = self.early_ordinal
             L.check(self._lib.pg_spmm_fwd_rows(*args), "pg_spmm_fwd_rows")
+        s.early_training = m.training
 
     def _frames_for(self, s):
         rs = s.plan.row_sources if s.plan else {}
@@ -523,7 +555,9 @@ class GraphedTrainer:
             s.nf._node_frames[i] = {n: (rs[(i, n)] if (i, n) in rs else t[o0:o1]) for n, t in s.out.items()
                                     if self.need is None or n in self.need.get(i, ())}
         s.nf._pre_agg = None
-        if s.early is not None and s.agg0 is not None:
+        # rows aggregated ahead of the step carry the model's mode of THAT moment (dropout on / off): a model toggled between
+        # prepare() and compute() (a validation callback) must not consume them — the step then aggregates in place
+        if s.early is not None and s.agg0 is not None and s.early_training == self._bare_model().training:
             s.nf._pre_agg = {blk: s.agg0[blk][:, :rows.dim] for blk, _f, rows in s.early}
 
     def _bare_model(self):
@@ -553,6 +587,7 @@ class GraphedTrainer:
         else:
             loss.backward(self._gseed)
             self.optimizer.step()
+        s.nf._pre_agg = None                    # consumed: an eager forward on this NodeFlow later aggregates for itself
         return loss
 
     def _can_defer_partials(self):
@@ -593,6 +628,7 @@ class GraphedTrainer:
                 loss = self.loss_fcn(pred, s.label)
             loss.backward(self._gseed)
         self.optimizer.step(deferred=reg, bump=bump)
+        s.nf._pre_agg = None
         return loss
 
     def _probe_graph_allreduce(self):

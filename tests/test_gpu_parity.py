@@ -10,8 +10,9 @@ import pytest
 import scipy.sparse as spsp
 import torch
 
+from _helpers import ROOT, free_port as _free_port, rand_csc as _rand_csc  # noqa: F401
+
 pytestmark = pytest.mark.gpu
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 1e-4
 
 
@@ -251,25 +252,6 @@ def test_miss_gather_stragglers_are_rescued(dev, hiplib, monkeypatch):
     # tens of milliseconds without the rescue
     assert np.median(took) < 0.012, took
     c.shutdown_miss_queue()
-
-
-def _free_port():
-    """a TCP port nobody listens on right now (a fixed rendezvous port can sit in TIME_WAIT after the previous run)"""
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        return sk.getsockname()[1]
-
-
-def _rand_csc(rng, V, E, powerlaw=True):
-    if powerlaw:
-        w = 1.0 / np.arange(1, V + 1) ** 0.9; w /= w.sum()
-        s = rng.choice(V, E, p=w); d = rng.choice(V, E, p=w)
-    else:
-        s = rng.integers(0, V, E); d = rng.integers(0, V, E)
-    a = spsp.coo_matrix((np.ones(2 * E, np.int8), (np.concatenate([s, d]), np.concatenate([d, s]))), shape=(V, V)).tocsr()
-    a.data[:] = 1
-    return a
 
 
 @pytest.mark.parametrize("V,E,B,k,hops", [(2000, 12000, 256, 2, 2), (5000, 60000, 1000, 2, 2), (800, 9000, 100, 5, 3),
@@ -631,41 +613,6 @@ def test_trainer_loop_runs_and_learns(dev, hiplib):
     assert 0.0 < mr < 1.0
 
 
-def test_cli_pipeline_end_to_end(dev, hiplib, tmp_path):
-    """preprocess -> hash partition -> pa_gcn.py / pa_gs.py on a small dataset folder
-    (the reference's README.md:36-110 workflow, same file layout, same prints)"""
-    import subprocess, sys
-    ds = tmp_path / "tiny"
-    ds.mkdir()
-    env = dict(os.environ, PYTHONPATH=ROOT)
-    # (a fresh rendezvous port per script: seven process groups in a row on one fixed port can wait on TIME_WAIT)
-    from conftest import run_group              # (the trainer scripts spawn a process per GPU: kill the GROUP on a time-out)
-    run = lambda *a: run_group([sys.executable, *a], 600, cwd=ROOT, env=dict(env, MASTER_PORT=str(_free_port())))
-    r = run("-m", "pagraph_amd.data.preprocess", "--dataset", str(ds), "--gen-rmat", "20000", "120000", "--gen-feature",
-            "--feat-size", "64", "--gen-label", "--class-num", "7", "--gen-set")
-    assert r.returncode == 0, r.stderr[-2000:]
-    for f in ("adj.npz", "feat.npy", "labels.npy", "train.npy", "val.npy", "test.npy"):
-        assert (ds / f).exists()
-    r = run("-m", "pagraph_amd.partition.hash", "--dataset", str(ds), "--partition", "1", "--num-hops", "2")
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert (ds / "1naive" / "subadj_0.npz").exists()
-    ref_loop = ["--eager", "--fetch-all", "--miss-mode", "zerocopy"]          # the reference-shaped loop; the defaults are bench.py's path
-    for script, extra in (("pa_gcn.py", []), ("pa_gs.py", []), ("pa_gcn.py", ref_loop), ("pa_gs.py", ["--eager", "--fetch-all", "--miss-mode", "staged"]),
-                          ("pa_gcn.py", ["--graph", "--fetch-needed", "--miss-mode", "async"]),
-                          ("pa_gs.py", ["--graph", "--fetch-needed", "--miss-mode", "zerocopy"]),
-                          ("pa_gcn.py", ["--eager", "--fetch-all", "--miss-mode", "async", "--preprocess"]),
-                          ("pa_gcn.py", ["--preprocess"])):
-        r = run(os.path.join("examples", "profile", script), "--dataset", str(ds), "--gpu", "0", "--feat-size", "64",
-                "--n-classes", "7", "--n-epochs", "3", "--batch-size", "1000", "--cache-ratio", "0.3", "--log-miss-rate", *extra)
-        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-        assert "Epoch average time" in r.stdout and "Total Time" in r.stdout and "total dims" in r.stdout
-        assert "Epoch average miss rate" in r.stdout
-    r = run(os.path.join("examples", "opt_cache_hit.py"), "--dataset", str(ds), "--n-epochs", "1", "--batch-size", "1000")
-    assert r.returncode == 0, r.stderr[-2000:]
-    vals = [float(l.split(":")[1]) for l in r.stdout.splitlines() if "hit rate" in l]
-    assert len(vals) == 2 and 0.2 < vals[1] <= vals[0] <= 1.0      # degree policy <= oracle
-
-
 @pytest.mark.parametrize("mode", ["staged", "zerocopy", "async"])
 def test_fetch_only_what_the_model_reads(dev, hiplib, golden_dir, mode):
     """fetch_data(need=...) returns, for the requested layers/fields, exactly the rows
@@ -731,6 +678,50 @@ def test_graphed_trainer_matches_eager(dev, hiplib):
     assert np.allclose(losses["eager"], losses["graph"], rtol=2e-4, atol=2e-5), (losses["eager"], losses["graph"])
     assert np.allclose(losses["eager"], losses["graph-async"], rtol=2e-4, atol=2e-5)
     assert losses["graph"][-1] < losses["graph"][0]
+
+
+@pytest.mark.parametrize("arch,hidden,C,p_drop", [("sage", 32, 5, 0.0), ("sage", 16, 70, 0.0), ("sage", 32, 70, 0.25),
+                                                  ("gcn", 64, 5, 0.0), ("gcn", 16, 70, 0.25), ("sage", 8, 5, 0.0)])
+def test_graphed_trainer_outside_the_fused_head_envelope(dev, hiplib, arch, hidden, C, p_drop):
+    """`pa_gs.py --n-hidden 32`, a dataset with more than 64 classes: the fused output head declines, and it
+    must decline BEFORE the layers below it consume the NodeFlow's frames — GraphedTrainer's fall-back `model(nf)` then
+    trains as the eager reference-style loop does (same losses, dropout off; finite and falling with dropout on).
+    The last case is inside the envelope: the control."""
+    import torch.nn.functional as Fn
+    from pagraph_amd.model import GCNSampling, GraphSageSampling
+    from pagraph_amd.optim import Adam
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    from pagraph_amd.trainer import GraphedTrainer, MinibatchTrainer, cycle_batches
+    rng = np.random.default_rng(11)
+    V, Fdim, B = 5000, 64, 500
+    g = DeviceGraph(_rand_csc(rng, V, 30000))
+    feats = rng.standard_normal((V, Fdim)).astype(np.float32)
+    labels = torch.from_numpy(rng.integers(0, C, V)).to(dev)
+    train = np.arange(0, V, 2, dtype=np.int64)
+    losses = {}
+    for mode in ("eager", "graph"):
+        c = GraphCacheServer(HostFeatureStore({"features": torch.from_numpy(feats)}), V, torch.arange(V), 0, miss_mode="async")
+        c.init_field(["features"])
+        c.auto_cache(g, ["features"], cache_ratio=0.4)
+        torch.manual_seed(0)
+        model = (GraphSageSampling(Fdim, hidden, C, 1, Fn.relu, p_drop, 'mean') if arch == "sage"
+                 else GCNSampling(Fdim, hidden, C, 1, Fn.relu, p_drop)).to(dev)
+        opt = Adam(model.parameters(), lr=1e-2)
+        smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=True, num_hops=2, seed_nodes=train, prefetch=True,
+                              seed=9, static=(mode != "eager"))
+        cls = GraphedTrainer if mode != "eager" else MinibatchTrainer
+        tr = cls(model, torch.nn.CrossEntropyLoss(), opt, c, smp, labels, dev, need=model.required_inputs(3))
+        out = []
+        tr.on_step = lambda step, loss: out.append(loss.detach().clone())
+        tr.run_steps(cycle_batches(smp, 20), 20)
+        torch.cuda.synchronize()
+        losses[mode] = torch.stack(out).cpu().numpy()
+        c.shutdown_miss_queue()
+    for v in losses.values():
+        assert np.isfinite(v).all() and v[-5:].mean() < v[:5].mean(), v
+    if p_drop == 0.0:
+        assert np.allclose(losses["eager"], losses["graph"], rtol=3e-4, atol=3e-5), (losses["eager"], losses["graph"])
 
 
 @pytest.mark.parametrize("arch", ["gcn", "sage"])
@@ -868,131 +859,6 @@ def test_stress_objects_dropped_with_work_in_flight(dev, hiplib):
     lv = torch.stack(out).cpu()
     assert torch.isfinite(lv).all() and float(lv[-10:].mean()) < float(lv[:10].mean())
     c.shutdown_miss_queue()
-
-
-def _two_rank_graph_worker(rank, world, port, out_dir):
-    """two ranks share GPU 0 over gloo: GraphedTrainer's flat-gradient all-reduce path vs DDP eager"""
-    import torch.distributed as dist
-    import torch.nn.functional as Fn
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
-    from pagraph_amd.model import GCNSampling
-    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
-    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
-    from pagraph_amd.trainer import GraphedTrainer, MinibatchTrainer, cycle_batches
-    rng = np.random.default_rng(5)
-    V, Fdim, C, B = 4000, 32, 4, 250
-    adj = _rand_csc(rng, V, 24000)
-    g = DeviceGraph(adj)
-    feats = rng.standard_normal((V, Fdim)).astype(np.float32)
-    labels = torch.from_numpy(rng.integers(0, C, V)).to(dev)
-    train = np.arange(rank, V, 4, dtype=np.int64)              # disjoint seeds per rank, 1000 each
-    res = {}
-    for mode in ("ddp", "graph"):
-        store = HostFeatureStore({"features": torch.from_numpy(feats)})
-        c = GraphCacheServer(store, V, torch.arange(V), 0, miss_mode="zerocopy")
-        c.init_field(["features"])
-        c.auto_cache(g, ["features"], cache_ratio=0.5)
-        torch.manual_seed(rank)                                 # different init per rank: broadcast must fix it
-        model = GCNSampling(Fdim, 8, C, 1, Fn.relu, 0.0).to(dev)
-        need = model.required_inputs(3)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=(mode == "graph"))
-        smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=True, num_hops=2, seed_nodes=train, prefetch=True,
-                              seed=3 + rank, static=(mode == "graph"))
-        if mode == "ddp":
-            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
-            tr = MinibatchTrainer(net, torch.nn.CrossEntropyLoss(), opt, c, smp, labels, dev, need=need)
-        else:
-            tr = GraphedTrainer(model, torch.nn.CrossEntropyLoss(), opt, c, smp, labels, dev, need=need, world_size=world)
-        out = []
-        tr.on_step = lambda step, loss: out.append(loss.detach())
-        tr.run_steps(cycle_batches(smp, 12), 12)
-        torch.cuda.synchronize()
-        res[mode] = (torch.stack(out).cpu(), [p.detach().cpu().clone() for p in model.parameters()])
-    torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def _rccl_one_rank_worker(rank, port, out_dir):
-    """GraphedTrainer's world > 1 code over a REAL RCCL process group — of one rank, all a one-GPU box can host: the trainer
-    is told world_size = 2 (loss / 2, flat gradient buffer, all-reduce per step), the group sums over its single member."""
-    import torch.distributed as dist
-    import torch.nn.functional as Fn
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
-    dist.init_process_group("nccl", rank=0, world_size=1)
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
-    from pagraph_amd.model import GCNSampling
-    from pagraph_amd.optim import Adam
-    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
-    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
-    from pagraph_amd.trainer import GraphedTrainer, cycle_batches
-    rng = np.random.default_rng(5)
-    V, Fdim, C, B = 4000, 32, 4, 250
-    adj = _rand_csc(rng, V, 24000)
-    g = DeviceGraph(adj)
-    feats = rng.standard_normal((V, Fdim)).astype(np.float32)
-    labels = torch.from_numpy(rng.integers(0, C, V)).to(dev)
-    train = np.arange(0, V, 2, dtype=np.int64)
-    res = {}
-    for mode in ("eager", "ingraph"):
-        store = HostFeatureStore({"features": torch.from_numpy(feats)})
-        c = GraphCacheServer(store, V, torch.arange(V), 0, miss_mode="async")
-        c.init_field(["features"])
-        c.auto_cache(g, ["features"], cache_ratio=0.5)
-        torch.manual_seed(1)
-        model = GCNSampling(Fdim, 8, C, 1, Fn.relu, 0.0).to(dev)
-        need = model.required_inputs(3)
-        opt = Adam(model.parameters(), lr=1e-2)
-        smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=True, num_hops=2, seed_nodes=train, prefetch=True, seed=3,
-                              static=True, defer_transpose=True)
-        tr = GraphedTrainer(model, torch.nn.CrossEntropyLoss(), opt, c, smp, labels, dev, need=need, world_size=2)
-        # eager: graph A -> all-reduce on the communication stream -> graph B; ingraph: the collective captured in the step
-        tr.allreduce_in_graph = (mode == "ingraph")
-        out = []
-        tr.on_step = lambda step, loss: out.append(loss.detach().clone())
-        tr.run_steps(cycle_batches(smp, 30), 30)      # 3 eager steps, 8 captures (each microseconds behind an eager collective), replays
-        tr.synchronize()
-        torch.cuda.synchronize()
-        res[mode] = (torch.stack(out).cpu(), [p.detach().cpu().clone() for p in model.parameters()], bool(tr.allreduce_in_graph))
-        c.shutdown_miss_queue()
-    torch.save(res, os.path.join(out_dir, "r0.pt"))
-    dist.destroy_process_group()
-
-
-def test_graphed_trainer_over_an_rccl_group_survives_its_captures(dev, hiplib, tmp_path):
-    """ProcessGroupNCCL's watchdog polls the end event of every eager collective; on ROCm that query throws once the stream
-    the event was recorded on is capturing, and the watchdog takes the process down (tools/exp_rccl_capture.py). The trainer
-    therefore keeps its eager collectives on a communication stream of its own. Both world > 1 step shapes — eager
-    all-reduce between two graphs, and the all-reduce captured inside the step — run over a one-rank RCCL group, survive
-    their captures, and give the same trajectory."""
-    import torch.multiprocessing as mp
-    mp.spawn(_rccl_one_rank_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
-    r = torch.load(tmp_path / "r0.pt")
-    assert r["eager"][2] is False and r["ingraph"][2] is True
-    assert torch.isfinite(r["eager"][0]).all() and len(r["eager"][0]) == 30
-    assert float(r["eager"][0][-5:].mean()) < float(r["eager"][0][:5].mean())        # it trains
-    assert torch.allclose(r["eager"][0], r["ingraph"][0], rtol=1e-5, atol=1e-6)
-    for a, b in zip(r["eager"][1], r["ingraph"][1]):
-        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
-
-
-def test_two_rank_graphed_allreduce_matches_ddp(dev, hiplib, tmp_path):
-    import socket
-    import torch.multiprocessing as mp
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_two_rank_graph_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r = [torch.load(tmp_path / f"r{i}.pt") for i in range(2)]
-    for mode in ("ddp", "graph"):                                # replicas stay identical
-        for a, b in zip(r[0][mode][1], r[1][mode][1]):
-            assert torch.allclose(a, b, rtol=0, atol=1e-6), mode
-    for i in range(2):                                           # same trajectory as DDP
-        assert torch.allclose(r[i]["ddp"][0], r[i]["graph"][0], rtol=3e-4, atol=3e-5), (r[i]["ddp"][0], r[i]["graph"][0])
-        for a, b in zip(r[i]["ddp"][1], r[i]["graph"][1]):
-            assert torch.allclose(a, b, rtol=1e-3, atol=1e-4)
 
 
 @pytest.mark.parametrize("n,K,N,bias", [(12000, 600, 32, True), (11999, 600, 16, True), (1025, 600, 32, True), (1033, 128, 7, False),
@@ -1803,61 +1669,6 @@ def test_sage_forward_loss_matches_forward_plus_loss(dev, hiplib, agg):
     assert pool.forward_loss(nf, labels, n_valid) is None
 
 
-@pytest.mark.gpu
-def test_bench_default_path_end_to_end_small(dev, hiplib):
-    """`python bench.py` with every default phase on (timed loop, gather micro-benchmark, cache-policy analysis,
-    CPU baseline) at a small size: exactly one JSON line on stdout carrying the contract's keys"""
-    import json
-    import subprocess
-    import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--vertices", "300000", "--edges", "3000000",
-                        "--steps", "30", "--cpu-baseline-seconds", "2"], cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 30 and d["higher_is_better"] is False and d["vs_baseline"] is None
-    assert "workload" in d["config"] and d["config"]["miss_mode"] == "async"
-    rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and 0 < rf["frac"] < 1 and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
-    cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
-    assert 0 < d["cache_hit_pct"] <= 100
-
-
-@pytest.mark.gpu
-def test_bench_two_ranks_as_the_driver_launches_it(dev, hiplib):
-    """`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`: the N > 1 path of the bench (rank 0 runs
-    dg, every rank builds the closure of its own partition, shared host table, equalised step counts, gradient all-reduce,
-    max-over-ranks timing) end to end; two ranks share the one GPU of the test box over gloo (RCCL refuses two ranks on one
-    device) — the launch line is the driver's otherwise"""
-    import json
-    import socket
-    import subprocess
-    import sys
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    from conftest import run_group
-    r = run_group([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                   "--gpus", "2", "--steps", "20", "--warmup", "5", "--dist-backend", "gloo",
-                   "--vertices", "300000", "--edges", "3000000"], 420, cwd=ROOT, env=env)
-    assert r.returncode == 0, r.stderr[-4000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["metric"] == "epoch_time_s"
-    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["higher_is_better"] is False and not d["misses_timed_out"]
-    assert d["config"]["dg_hops"] == 2 and "dg(hops=2)" in d["config"]["workload"]
-    assert "roofline" in d and 0 < d["roofline"]["frac"] < 1
-
-
 # ---- G7 / G8: the HIP models against the reference's own model classes -----------------------------------------
 def _nf_from_fixture(z, dev):
     from pagraph_amd.sampling.nodeflow import NodeFlow
@@ -1957,33 +1768,6 @@ def test_auto_cache_never_outgrows_free_memory(dev, hiplib, monkeypatch):
     assert torch.equal(torch.nonzero(c.gpu_flag.cpu()).squeeze(1), torch.sort(want).values)
     got = c.gpu_fix_cache["features"][c.localid2cacheid[want.to(dev)]].cpu().numpy()
     assert np.array_equal(got, feats[want.numpy()])
-
-
-@pytest.mark.timeout(600)
-def test_bench_short_window_reports_steady_state(dev, hiplib):
-    """the driver's invocation (`--steps 20 --warmup 5`) must report the same per-step time as a long run
-    (r01: 0.996 vs 0.197 ms/step — the copy stream had been moved to a slow SDMA engine): within 1.3x of a 400-step line"""
-    import json
-    import subprocess
-    import sys
-    flags = ["--skip-microbench", "--skip-cpu-baseline", "--skip-opt-hit", "--skip-reference-equivalent"]
-    def run(steps):
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(steps),
-                            "--warmup", "5"] + flags, capture_output=True, text=True, timeout=280)
-        assert r.returncode == 0, r.stderr[-2000:]
-        return json.loads(r.stdout.strip().splitlines()[-1])
-    short, long_ = run(20), run(400)
-    if short["ms_per_step"] > 1.3 * long_["ms_per_step"]:
-        # 20 steps are 3.2 ms: one host hiccup of a millisecond (this process still owns the worker threads of every
-        # earlier test's miss queue) moves the line by a third. One retry; a systematic slow start fails both.
-        short = run(20)
-    assert short["warmup"] == 5 and short["steps"] == 20 and not short["misses_timed_out"]
-    assert short["ms_per_step"] <= 1.3 * long_["ms_per_step"], (short["ms_per_step"], long_["ms_per_step"])
-    # no slow MODE inside the long run: the median 20-step window stays near the best one (single windows may carry a
-    # host hiccup on a shared box: seen at 0.33-0.38 against 0.157 with identical code an hour apart)
-    w = sorted(long_["ms_per_step_windows"])
-    assert w[len(w) // 2] <= 1.3 * w[0], long_["ms_per_step_windows"]
-    assert short["miss_queue"]["sdma_engine_mask"] != 0          # the direct-SDMA copy path is the one that ran
 
 
 # ---- f-2: gather fused into the layer-0 aggregation (pg_split_rows + pg_spmm_fwd_rows) -------------------------
@@ -2457,59 +2241,6 @@ def test_cache_analysis_vs_reference_golden(dev, hiplib, golden_dir):
     cv = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(cv)
     assert sum(cv.count_nf_vnum(nf) for nf in nfs) == int(z["vnum"])
-
-
-def test_eval_and_count_vnum_scripts(dev, hiplib, oracle, tmp_path):
-    """examples/profile/pa_gcn.py --ckpt -> examples/eval.py (eval.py:13-46): the accuracy it prints equals the one
-    computed from the oracle's GCNInfer restatement on a numpy full-neighbour NodeFlow; examples/count_vnum.py runs"""
-    import subprocess, sys
-    from pagraph_amd import data
-    ds = tmp_path / "tiny"
-    ds.mkdir()
-    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_PORT=str(_free_port()))
-    from conftest import run_group
-    run = lambda *a: run_group([sys.executable, *a], 600, cwd=ROOT, env=env)
-    r = run("-m", "pagraph_amd.data.preprocess", "--dataset", str(ds), "--gen-rmat", "6000", "30000", "--gen-feature",
-            "--feat-size", "32", "--gen-label", "--class-num", "5", "--gen-set")
-    assert r.returncode == 0, r.stderr[-2000:]
-    r = run("-m", "pagraph_amd.partition.hash", "--dataset", str(ds), "--partition", "1", "--num-hops", "2")
-    assert r.returncode == 0, r.stderr[-2000:]
-    ck = tmp_path / "ck"
-    r = run(os.path.join("examples", "profile", "pa_gcn.py"), "--dataset", str(ds), "--gpu", "0", "--feat-size", "32",
-            "--n-classes", "5", "--n-epochs", "2", "--batch-size", "500", "--cache-ratio", "0.3", "--miss-mode", "async",
-            "--ckpt", str(ck))
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    assert (ck / "gcn-nssc_0").exists() and (ck / "gcn-nssc_1").exists()
-    r = run(os.path.join("examples", "eval.py"), "--dataset", str(ds), "--gpu", "0", "--feat-size", "32", "--ckpt", str(ck),
-            "--start", "0", "--end", "2", "--interval", "1")
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    accs = {int(l.split("]")[0][1:]): float(l.split()[-1]) for l in r.stdout.splitlines() if "Test Accuracy" in l}
-    assert set(accs) == {0, 1}
-    # the same number from the oracle: numpy full-neighbour NodeFlow + gcn_model_forward(infer=True)
-    adj = data.get_struct(str(ds))
-    csc = spsp.csc_matrix(adj); csc.sum_duplicates(); csc.sort_indices()
-    feat = np.load(ds / "feat.npy").astype(np.float32)
-    labels = data.get_labels(str(ds))
-    test_nid = np.nonzero(data.get_masks(str(ds))[2])[0].astype(np.int64)
-    with np.errstate(divide="ignore"):
-        norm = (1.0 / np.diff(csc.indptr).astype(np.float32)).reshape(-1, 1)       # pa_server.py:43 (inf when isolated)
-    layers, blocks = [test_nid], []
-    for _ in range(2):
-        dst = layers[0]
-        below = np.unique(np.concatenate([csc.indices[csc.indptr[v]:csc.indptr[v + 1]] for v in dst] + [np.zeros(0, np.int32)]))
-        ip = np.concatenate([[0], np.cumsum([csc.indptr[v + 1] - csc.indptr[v] for v in dst])]).astype(np.int32)
-        sr = np.searchsorted(below, np.concatenate([csc.indices[csc.indptr[v]:csc.indptr[v + 1]] for v in dst] + [np.zeros(0, np.int32)])).astype(np.int32)
-        layers.insert(0, below.astype(np.int64)); blocks.insert(0, (ip, sr))
-    frames = [{"features": feat[l], "norm": norm[l]} for l in layers]
-    for ep in (0, 1):
-        state = {f"{k}": v.numpy() for k, v in torch.load(ck / f"gcn-nssc_{ep}").items()}
-        logits, _ = oracle.gcn_model_forward(blocks, [len(l) for l in layers], frames, state, 1, False, infer=True)
-        ok = np.isfinite(logits).all(axis=1)
-        want = float((logits.argmax(1) == labels[test_nid]).sum()) / len(test_nid)
-        assert abs(accs[ep] - want) <= 2.0 / len(test_nid) + 1e-4, (ep, accs[ep], want)    # argmax ties / nan rows
-    r = run(os.path.join("examples", "count_vnum.py"), "--dataset", str(ds), "--n-epochs", "1", "--batch-size", "500")
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert int(r.stdout.split("Epoch loaded vertex#:")[1].split()[0]) > len(np.nonzero(data.get_masks(str(ds))[0])[0])
 
 
 def test_adam_with_deferred_partial_sums_is_bit_identical(dev, hiplib):

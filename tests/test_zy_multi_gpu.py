@@ -2,7 +2,7 @@
 diagnosis. Real RCCL, one rank per GPU:
   * GraphedTrainer's flat-gradient all-reduce — both shapes: eager collective between two graphs, collective captured in the
     step — against DDP's trajectory on the same seeds; replicas bit-identical after 30 steps
-    (the asserts of test_gpu_parity.py::test_two_rank_graphed_allreduce_matches_ddp, which runs over gloo on one GPU);
+    (the asserts of test_zz_bench_lines.py::test_two_rank_graphed_allreduce_matches_ddp, which runs over gloo on one GPU);
   * bench.py --gpus 2 over nccl exactly as the driver launches it, at 300 K vertices: preflight, dg, closures, shared host
     table, equalised steps, all-reduce, per-rank blocks, loss evidence.
 reference: /root/reference/examples/profile/pa_gcn.py:18-24 (init_process), :65 (DDP), :154-157 (mp.spawn per GPU)."""
