@@ -39,8 +39,7 @@ def pmc_traffic(kernel="k_gather"):
     MI355X_MICROARCH.md §HBM). bench.py cannot collect PMC counters itself; None when absent. The figure belongs
     to the default workload (10M/100M GCN, 30 % cache): other workloads get None."""
     import glob
-    name = {"k_gather": "pmc_gather_inloop.json", "k_spmm_fwd_rows": "pmc_spmm_fwd_rows_inloop.json",
-            "k_agg_linear_fwd": "pmc_agg_linear_fwd_inloop.json"}[kernel]
+    name = {"k_gather": "pmc_gather_inloop.json", "k_spmm_fwd_rows": "pmc_spmm_fwd_rows_inloop.json"}[kernel]
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)))
     if not files:
         return None, None
@@ -148,6 +147,8 @@ def parse():
                    "`value`, scale the --steps window instead (the old behaviour)")
     p.add_argument("--skip-preflight", action="store_true", help="--gpus > 1: skip the ~10 s small-graph run through the whole "
                    "N-rank path (collectives, dg, closures, miss queues, captures, replica check) before the big set-up")
+    p.add_argument("--no-configs", action="store_true", help="do not append the `configs` block (BASELINE configs 2 and 3, each "
+                   "timed by a child run of this script) to the headline line")
     p.add_argument("--no-adapt-cpu-share", action="store_true", help="keep --cpu-share as given; default: after the set-up "
                    "steps every rank sets it from its own CPU-gather rate vs PCIe (GraphCacheServer.adapt_cpu_share)")
     return p.parse_args()
@@ -573,6 +574,60 @@ def device_identity(gpu):
     return rec
 
 
+# BASELINE.json's other single-GPU configurations, timed inside the driver's own `bench.py --gpus 1` run (they
+# used to exist only as builder-run files under profiles/): each is a CHILD run of this script — its own process, its own graph,
+# cacher and captured steps, so nothing of the headline run's state leaks into it — whose line is condensed into one entry.
+CONFIG_LEGS = (
+    # config 2: Reddit's shape (232 965 vertices, mean degree 492, feat 602, 41 classes), table resident in HBM, 2-layer GCN —
+    # 26 steps per epoch, ten epochs (examples/profile/pa_gcn.py:144-150 defaults; SURVEY 8d "Config 2")
+    ("config2_reddit_shape_full_cache_gcn",
+     ["--vertices", "232965", "--edges", "57300000", "--feat-size", "602", "--n-classes", "41", "--cache-ratio", "1.0",
+      "--model", "gcn", "--steps", "260"]),
+    # config 3: the headline graph with config 3's own model — GraphSAGE-mean, hidden 16, lr 1e-2 (pa_gs.py:134,141) — and the
+    # 30 % hot-degree cache: one whole epoch (1 084 steps)
+    ("config3_rmat_10M_graphsage_30pct_cache", ["--model", "graphsage", "--cache-ratio", "0.30"]),
+)
+
+
+def config_legs(args, budget_s=150.0):
+    import subprocess
+    out = {}
+    t_all = time.time()
+    for name, flags in CONFIG_LEGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--warmup", "10", "--no-configs", "--skip-microbench",
+               "--skip-cpu-baseline", "--skip-opt-hit", "--skip-reference-equivalent"] + flags
+        if args.host_threads:
+            cmd += ["--host-threads", str(args.host_threads)]
+        t0 = time.time()
+        left = budget_s - (t0 - t_all)
+        if left < 20:
+            out[name] = {"error": "skipped: the configs block's time budget was spent"}
+            continue
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=left)
+            if r.returncode != 0:
+                raise RuntimeError(f"rc {r.returncode}: {r.stderr[-600:]}")
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            rf = d["roofline"]
+            out[name] = {
+                "workload": d["config"]["workload"], "command": " ".join(["bench.py"] + cmd[2:]),
+                "ms_per_step": d["config"]["epoch_ms_per_step"], "steps_timed": d["config"]["epoch_steps_timed"],
+                "steps_per_epoch": d["config"]["steps_per_epoch"], "epoch_time_s": d["value"],
+                "ms_per_step_window_quantiles": d["ms_per_step_window_quantiles"],
+                "cache_hit_pct": d["cache_hit_pct"], "miss_mode": d["config"]["miss_mode"],
+                "early_layer0_aggregation": d["config"]["early_layer0_aggregation"],
+                "trained": d["trained"], "misses_timed_out": d["misses_timed_out"],
+                "host_issue_ms_per_step": d["host_issue_ms_per_step"],
+                "cpus_used": (d["host"]["timed_region_cgroup"] or {}).get("cpus_used"),
+                "roofline": {k_: rf.get(k_) for k_ in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms",
+                                                       "launches_timed", "algorithmic_bytes_per_launch", "kernel_body_ms")},
+                "leg_wall_s": time.time() - t0}
+        except Exception as e:                      # a leg that fails must not take the headline line with it
+            out[name] = {"error": f"{type(e).__name__}: {str(e)[-800:]}", "leg_wall_s": time.time() - t0}
+        log(f"[bench] configs block: {name} -> {json.dumps(out[name])[:300]}")
+    return out
+
+
 def main():
     # the JSON line is the ONLY thing on stdout: the library's reference-style prints
     # ('total dims', 'Cache Memory', ...) go to stderr
@@ -580,6 +635,12 @@ def main():
     sys.stdout = sys.stderr
     try:
         out = run()
+        if out is not None and out.pop("_wants_configs", False):
+            # the headline run's device memory, pinned table and worker threads are gone with run()'s frame
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["configs"] = config_legs(parse())
     finally:
         sys.stdout = real_stdout
     if out is not None:
@@ -951,6 +1012,7 @@ def run():
         mq0 = cacher.miss_queue_stats()
         cacher.miss_queue_longest(reset=True)
         cg0 = cgroup_cpu_stat()
+        pt0 = time.process_time()            # CPU time of THIS process, all its threads (the cgroup's figure covers every rank)
         drop_step0 = int(model._drop_step.item()) if hasattr(model, "_drop_step") else 0
         early0 = getattr(trainer, "early_ordinal", 0)
         wev[0].record(cstream)
@@ -970,6 +1032,9 @@ def run():
         if cg0 and cg1:      # was the process throttled by its CPU quota inside the region? how many CPUs did it use?
             cpu_quota = {"nr_throttled": cg1[0] - cg0[0], "throttled_ms": (cg1[1] - cg0[1]) / 1e3,
                          "cpus_used": (cg1[2] - cg0[2]) / 1e6 / max(1e-9, elapsed)}
+        if cpu_quota is None:
+            cpu_quota = {}
+        cpu_quota["process_cpus_used"] = (time.process_time() - pt0) / max(1e-9, elapsed)     # this rank alone
         # FULL windows only: a region's last, shorter window (4 steps of a 1 084-step epoch) is reported apart. It is the
         # pipeline running dry, not a steady state: the miss rows of the look-ahead batches have landed before their steps
         # start, so those steps run at the table-cached time (r04's unexplained 0.098 ms/step 'window' beside 0.150-0.165).
@@ -1116,14 +1181,8 @@ def run():
             # written (4 F) + its indptr entry (4). Rows that miss are read from the staged block instead of the cache
             # (same bytes). Padding destinations of the fixed-shape block write zeros: not counted.
             f_bytes = edges * (4 * Fw + 8) + n_dst * (4 * Fw + 4)
-            from pagraph_amd import ops as _ops
-            with_dense = args.model == "gcn" and _ops.FUSE_AGG_LINEAR
-            if with_dense:
-                # + the NodeUpdate the kernel absorbed (pg_agg_linear_fwd): its output [z | relu z] written per destination
-                # (2 x hidden floats), the weight and bias read once
-                f_bytes += n_dst * 4 * 2 * hidden + 4 * (Fw * hidden + hidden)
             dur = np.sort(slot[st[:, 3] > st[:, 1]] if has_succ else (st[:, 1] - st[:, 0]).astype(np.float64) / 1e5)
-            fused_rec = {"kernel": "k_agg_linear_fwd" if with_dense else "k_spmm_fwd_rows", "achieved": f_bytes / f_ms / 1e6, "frac": f_bytes / f_ms / 1e6 / HBM_PEAK_GBPS,
+            fused_rec = {"kernel": "k_spmm_fwd_rows", "achieved": f_bytes / f_ms / 1e6, "frac": f_bytes / f_ms / 1e6 / HBM_PEAK_GBPS,
                          "avg_launch_ms": f_ms, "launches_timed": int(len(st)),
                          "launch_ms_min_median_p90_max": [float(dur[0]), float(dur[len(dur) // 2]), float(dur[int(len(dur) * 0.9)]),
                                                           float(dur[-1])], "edges_per_launch": edges,
@@ -1264,6 +1323,9 @@ def run():
             "trained": reg_epoch["trained"], "trained_window": reg_win["trained"],
             "dist": dist_rec,
             "ranks": per_rank,
+            # (main() replaces this by the `configs` block: BASELINE configs 2 and 3 as child runs, for the headline workload
+            # on one GPU only — the small-graph runs of the tests and the N > 1 lines do not spawn full-size children)
+            "_wants_configs": bool(default_workload and world == 1 and not args.no_configs and use_graph and not args.fetch_all),
         }
     if world > 1:
         dist.barrier()

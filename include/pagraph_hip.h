@@ -46,6 +46,22 @@ typedef void* pg_stream_t; /* hipStream_t */
 int pg_version(void);
 const char* pg_strerror(int code);
 int pg_last_hip_error(void);
+
+/* Debug build that bounds-checks ids (`make -C pagraph_amd/csrc bounds` -> libpagraph_hip_bounds.so, loaded by
+ * pagraph_amd/_lib.py under PG_BOUNDS=1). The reference has one assert (storage.py:149) and no bounds checks on ids: an id
+ * out of range is an illegal address somewhere behind the kernel that followed it. In the debug build every index a kernel
+ * reads from a buffer and then follows (vertex ids, block edges, cache slots, staged-row numbers) is checked; the first
+ * offender of the process is recorded and the access redirected to element 0, so the launch completes.
+ * pg_bounds_enabled: 1 in the debug build, 0 in the product build.
+ * pg_bounds_region:  (debug build; no-op otherwise) `bytes` bytes at device / pinned address `base` are one buffer; kernels'
+ *                    bounds that the ABI does not carry (rows of a slot array, of the cache, of a staged block) are derived
+ *                    from the registered buffer a pointer argument lies in. bytes <= 0 forgets the buffer.
+ * pg_bounds_report:  (debug build; PG_ERR_UNSUPPORTED otherwise) synchronises the device; rec[8] = {hit, kernel (PG_K_* of
+ *                    csrc/pg_common.h), site, value, bound, block, total offenders, 0}; unit = the .hip file of the kernel;
+ *                    reset != 0 clears the record.                                                                        */
+int pg_bounds_enabled(void);
+int pg_bounds_region(const void* base, int64_t bytes);
+int pg_bounds_report(uint64_t* rec, char* unit, int32_t unit_len, int32_t reset);
 /* number of CUs of the current device, or <0 when no HIP device is visible */
 int pg_device_cu_count(void);
 
@@ -514,18 +530,6 @@ int pg_spmm_bwd_gather_max(const int32_t* tptr, const int32_t* tdst, const float
  * Returns PG_ERR_UNSUPPORTED outside that envelope (callers then use the library GEMM).            */
 int pg_linear_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, float* Y,
                   int32_t y_stride, int64_t n, int32_t K, int32_t N, int32_t act, pg_stream_t stream);
-/* Layer 0's aggregation AND its NodeUpdate in one kernel (round 4): agg = pg_spmm_fwd_rows(indptr, src, rows, ...) —
- * fetch_data fused into block_compute's reduce, storage.py:176-204 + gcn_nssc.py:66-74 — and Y = pg_linear_fwd(agg, W, bias,
- * act) — NodeUpdate.forward, gcn_nssc.py:14-24 — without the round trip of agg through memory between two launches: the
- * dense kernel's operand fetch IS the aggregation. Same arithmetic in the same order as that pair: agg (written once, the
- * weight gradient reads it) and Y are bit-identical to it. Envelope: the intersection of the two (K >= 256, rows of whole
- * 16-byte pieces, N <= 64, PG_REDUCE_MEAN | PG_REDUCE_SUM), else PG_ERR_UNSUPPORTED and the caller runs the pair. Fastest
- * when no destination has more than two in-edges (the sampler's fan-out of pa_gcn.py:146-147); correct for any degree.
- * prof / prof_ring: as pg_spmm_fwd_rows.                                                                  */
-int pg_agg_linear_fwd(const int32_t* indptr, const int32_t* src, const pg_row_source_t* rows, int64_t n_dst, int32_t K,
-                      int reduce, const pg_dropout_t* drop, const float* W, const float* bias, int32_t N, int32_t act,
-                      float* agg, int32_t agg_stride, float* Y, int32_t y_stride, uint64_t* prof, int32_t prof_ring,
-                      pg_stream_t stream);
 /* GraphSAGE's NodeUpdate, `fc_self(h) + fc_neigh(neigh)` then the activation (graphsage_nssc.py:24-29), in one
  * pass: Z = X W^T + bias + X2 W2^T + bias2 (W [N,K], W2 [N,K2]; same envelope for both operand pairs).      */
 int pg_linear2_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, int32_t K,
@@ -579,6 +583,16 @@ int pg_sage_head(const int32_t* indptr, const int32_t* src, const float* h, int3
                  const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
                  int64_t n_dst, float* logits, float* dagg, float* dself, float* partials, float* dW_both, float* db_loss,
                  int32_t flags, pg_stream_t stream);
+
+/* Phase signal (round 5; scheduling hint of the training pipeline, see csrc/pg_common.h PhaseSig). pg_phase_arm: the NEXT
+ * pg_gcn_head[_ex] / pg_sage_head launch of the calling thread adds 1 to *word (device uint64) when its kernel starts, i.e.
+ * when the dense forward before it in stream order has drained; word == NULL disarms; *was_pending (may be NULL) = an earlier
+ * arm had not been taken yet. pg_wait_phase: a one-wave kernel on `stream` returns once *word >= target or after
+ * timeout_us — later work of that stream (an HBM-bound aggregation of a later batch) then runs beside the compute stream's
+ * latency-bound tail instead of beside its dense forward. Never a correctness condition. */
+int pg_phase_arm(uint64_t* word, int32_t* was_pending);
+int pg_wait_phase(const uint64_t* word, uint64_t target, uint32_t timeout_us, pg_stream_t stream);
+
 /* pg_gcn_head_ex's flags: PG_HEAD_SUM_PARTIALS as above; PG_HEAD_DAGG_PER_EDGE: under PG_REDUCE_MEAN dagg[v] leaves
  * already divided by v's in-degree in the block (what each in-edge carries back) — feed it to pg_spmm_bwd_gather /
  * pg_spmm_bwd_drop with PG_REDUCE_SUM: same operations in the same order, without the backward's degree loads.  */

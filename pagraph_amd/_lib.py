@@ -12,6 +12,11 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpagraph_hip.so")
+# PG_BOUNDS=1: the debug build that bounds-checks ids (`make -C pagraph_amd/csrc bounds`; include/pagraph_hip.h
+# pg_bounds_*): every tensor handed to the library has its extent registered (ptr / note below), kernels check the indices
+# they follow against those extents, bounds_report() says which kernel met which bad index
+BOUNDS_LIB_PATH = os.path.join(_HERE, "libpagraph_hip_bounds.so")
+BOUNDS = False
 
 PG_MAX_FIELDS = 4
 PG_MAX_LAYERS = 8
@@ -68,6 +73,9 @@ _SIGS = {
     "pg_version": (ctypes.c_int, []),
     "pg_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "pg_last_hip_error": (ctypes.c_int, []),
+    "pg_bounds_enabled": (ctypes.c_int, []),
+    "pg_bounds_region": (ctypes.c_int, [vp, c_i64]),
+    "pg_bounds_report": (ctypes.c_int, [ctypes.POINTER(c_u64), ctypes.c_char_p, c_i32, c_i32]),
     "pg_device_cu_count": (ctypes.c_int, []),
     "pg_slot_map_reset": (ctypes.c_int, [vp, c_i64, vp]),
     "pg_slot_map_assign": (ctypes.c_int, [vp, vp, c_i64, vp]),
@@ -141,8 +149,6 @@ _SIGS = {
     "pg_spmm_bwd_gather_max": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, vp, c_i32, vp, c_i32, vp, c_i32, vp, c_i32, vp,
                                               vp, vp]),
     "pg_linear_fwd": (ctypes.c_int, [vp, c_i32, vp, vp, vp, c_i32, c_i64, c_i32, c_i32, c_i32, vp]),
-    "pg_agg_linear_fwd": (ctypes.c_int, [vp, vp, ctypes.POINTER(PgRowSource), c_i64, c_i32, ctypes.c_int, vp, vp, vp, c_i32, c_i32,
-                                         vp, c_i32, vp, c_i32, vp, c_i32, vp]),
     "pg_linear2_fwd": (ctypes.c_int, [vp, c_i32, vp, vp, c_i32, vp, c_i32, vp, vp, c_i32, vp, c_i32, c_i64, c_i32, c_i32, vp]),
     "pg_linear_bwd_w_scratch": (c_i64, [c_i64, c_i32, c_i32]),
     "pg_linear_bwd_w": (ctypes.c_int, [vp, c_i32, vp, c_i32, c_i64, c_i32, c_i32, vp, vp, vp, c_i32, c_i32, vp, vp, vp]),
@@ -163,6 +169,8 @@ _SIGS = {
                                       c_i64, vp, vp, vp, vp, vp, c_i32, vp]),
     "pg_sage_head": (ctypes.c_int, [vp, vp, vp, c_i32, c_i32, vp, vp, vp, c_i32, c_i32, vp, vp, c_i32, vp, c_i64, vp, vp, vp,
                                     ctypes.c_int, c_i64, vp, vp, vp, vp, vp, vp, c_i32, vp]),
+    "pg_phase_arm": (ctypes.c_int, [vp, ctypes.POINTER(c_i32)]),
+    "pg_wait_phase": (ctypes.c_int, [vp, c_u64, c_u32, vp]),
     "pg_linear_bwd_w_ex": (ctypes.c_int, [vp, c_i32, vp, c_i32, c_i64, c_i32, c_i32, vp, vp, vp, c_i32, c_i32, vp, vp, c_i32,
                                           vp]),
     "pg_linear2_fwd_rows": (ctypes.c_int, [vp, c_i32, vp, vp, vp, c_i32, vp, vp, c_i32, vp, c_i32, c_i64, c_i32, c_i32, vp]),
@@ -187,21 +195,57 @@ _lib = None
 
 def load():
     """dlopen the HIP library; raises PgError (never falls back) when it is missing."""
-    global _lib
+    global _lib, BOUNDS
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = LIB_PATH
+        if os.environ.get("PG_BOUNDS") not in (None, "", "0"):
+            path = BOUNDS_LIB_PATH
+            if not os.path.exists(path):
+                raise PgError(f"PG_BOUNDS is set but {path} is not built: `make -C pagraph_amd/csrc bounds`")
+        if not os.path.exists(path):
             raise PgError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C pagraph_amd/csrc`. pagraph_amd has no CPU fallback.")
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(path)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)  # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
+        BOUNDS = bool(L.pg_bounds_enabled())
         if os.environ.get("PG_HOST_TIMING"):
             L = _TimedLib(L)
         _lib = L
     return _lib
+
+
+_K_NAMES = ("?", "k_spmm_fwd_rows(_w)", "k_compose_edge_slots", "k_sx (sample)", "k_sx (relabel)", "k_bm_rank", "k_t_keys",
+            "k_t_block", "k_split / k_slots_full", "k_gather", "k_gather_labels", "k_linear_fwd<ROWS>", "k_linear_bwd_w<ROWS>",
+            "k_gcn_head", "k_spmm_bwd_gather", "k_spmm_fwd(_drop)", "k_spmm_bwd", "k_scatter")
+
+
+def note(t):
+    """debug build: register the extent of the allocation behind tensor `t` (bounds of the indices kernels follow into it)"""
+    if BOUNDS and t is not None and torch.is_tensor(t) and t.numel():
+        st = t.untyped_storage()
+        _lib.pg_bounds_region(ctypes.c_void_p(st.data_ptr()), st.nbytes())
+    return t
+
+
+def bounds_report(reset=True):
+    """debug build: None when no kernel met an out-of-range index since the last reset, else a dict naming the first one
+    (synchronises the device). Product build: None."""
+    if not BOUNDS:
+        return None
+    rec = (c_u64 * 8)()
+    unit = ctypes.create_string_buffer(256)
+    check(_lib.pg_bounds_report(rec, unit, 256, 1 if reset else 0), "pg_bounds_report")
+    if not rec[0]:
+        return None
+    k = int(rec[1])
+    v = int(rec[3])
+    return {"kernel": _K_NAMES[k] if 0 <= k < len(_K_NAMES) else str(k), "site": int(rec[2]),
+            "value": v - (1 << 64) if v >= 1 << 63 else v, "bound": int(rec[4]), "block": int(rec[5]),
+            "offenders": int(rec[6]), "unit": os.path.basename(unit.value.decode() or "?")}
 
 
 class _TimedLib:
@@ -360,6 +404,8 @@ def ptr(t):
     """raw pointer of a tensor (None -> NULL)"""
     if t is None:
         return ctypes.c_void_p(0)
+    if BOUNDS:
+        note(t)
     return ctypes.c_void_p(t.data_ptr())
 
 
@@ -370,6 +416,8 @@ def make_fields(items):
         raise PgError(f"at most {PG_MAX_FIELDS} fields per gather")
     arr = (PgField * max(1, len(items)))()
     for i, (cache, out, dim, cs, os_) in enumerate(items):
+        if BOUNDS:
+            note(cache), note(out)
         arr[i].cache = cache.data_ptr() if cache is not None else 0
         arr[i].out = out.data_ptr()
         arr[i].dim = dim

@@ -13,9 +13,43 @@
 
 #include "pg_common.h"
 
+#include <map>
+#include <mutex>
+
 namespace pg {
 thread_local int g_last_hip_error = 0;
 thread_local ProfSucc g_prof_succ;
+thread_local PhaseSig g_phase_sig;
+
+#ifdef PG_BOUNDS
+namespace {
+struct BoundsState {
+  std::mutex m;
+  std::vector<std::pair<bounds_collect_fn, const char*>> units;
+  std::map<uintptr_t, size_t> regions;      // base -> bytes
+};
+BoundsState& bounds_state() {
+  static BoundsState* s = new BoundsState;   // never destroyed: units register from static initialisers of other objects
+  return *s;
+}
+}  // namespace
+void bounds_register(bounds_collect_fn fn, const char* unit) {
+  BoundsState& b = bounds_state();
+  std::lock_guard<std::mutex> l(b.m);
+  b.units.emplace_back(fn, unit);
+}
+long long bounds_elems(const void* p, size_t elem_size) {
+  if (!p || !elem_size) return kBndUnknown;
+  BoundsState& b = bounds_state();
+  std::lock_guard<std::mutex> l(b.m);
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  auto it = b.regions.upper_bound(a);
+  if (it == b.regions.begin()) return kBndUnknown;
+  --it;
+  if (a >= it->first + it->second) return kBndUnknown;
+  return (long long)((it->first + it->second - a) / elem_size);
+}
+#endif
 }
 
 // PG_NATIVE_BACKTRACE=1: a native back-trace of the faulting thread on SIGSEGV / SIGBUS / SIGABRT / SIGFPE, written straight
@@ -79,6 +113,66 @@ const char* pg_strerror(int code) {
 }
 
 int pg_last_hip_error(void) { return pg::g_last_hip_error; }
+
+int pg_bounds_enabled(void) {
+#ifdef PG_BOUNDS
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+int pg_bounds_region(const void* base, int64_t bytes) {
+#ifdef PG_BOUNDS
+  if (!base) return PG_OK;
+  auto& b = pg::bounds_state();
+  std::lock_guard<std::mutex> l(b.m);
+  const uintptr_t a = reinterpret_cast<uintptr_t>(base);
+  if (bytes <= 0) {
+    b.regions.erase(a);
+    return PG_OK;
+  }
+  // a new registration replaces every older one it overlaps (the allocator handed the memory to somebody else since)
+  auto it = b.regions.lower_bound(a);
+  if (it != b.regions.begin()) {
+    auto prev = std::prev(it);
+    if (prev->first + prev->second > a) b.regions.erase(prev);
+  }
+  while (it != b.regions.end() && it->first < a + (uintptr_t)bytes) it = b.regions.erase(it);
+  b.regions[a] = (size_t)bytes;
+  return PG_OK;
+#else
+  (void)base; (void)bytes;
+  return PG_OK;
+#endif
+}
+
+int pg_bounds_report(uint64_t* rec, char* unit, int32_t unit_len, int32_t reset) {
+#ifdef PG_BOUNDS
+  if (!rec) return PG_ERR_INVALID;
+  for (int i = 0; i < 8; ++i) rec[i] = 0;
+  if (unit && unit_len > 0) unit[0] = 0;
+  PG_HIP(hipDeviceSynchronize());
+  auto& b = pg::bounds_state();
+  std::lock_guard<std::mutex> l(b.m);
+  for (auto& u : b.units) {
+    pg::BoundsRec r{};
+    if (u.first(&r, reset) != 0) return PG_ERR_HIP;
+    rec[6] += r.count;
+    if (r.hit && !rec[0]) {
+      rec[0] = 1; rec[1] = r.kernel; rec[2] = r.site; rec[3] = r.value; rec[4] = r.bound; rec[5] = r.block;
+      if (unit && unit_len > 0) {
+        strncpy(unit, u.second ? u.second : "?", (size_t)unit_len - 1);
+        unit[unit_len - 1] = 0;
+      }
+    }
+  }
+  return PG_OK;
+#else
+  (void)rec; (void)unit; (void)unit_len; (void)reset;
+  return PG_ERR_UNSUPPORTED;
+#endif
+}
 
 int pg_device_cu_count(void) {
   int dev = 0;

@@ -5,6 +5,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/pagraph_hip.h"
 
@@ -54,6 +55,28 @@ inline ProfSucc take_prof_succ() {
   g_prof_succ = ProfSucc{};
   return p;
 }
+// ---- phase signal (round 5): "the dense forward of this step has finished" --------------------------------------------------
+// A trainer arms this thread-local record before it issues a step's body (pg_phase_arm); the step's head launch
+// (pg_gcn_head / pg_sage_head) takes it, and the kernel's first thread adds 1 to the word when it STARTS — in stream order
+// that is the moment the dense forward before it has drained. pg_wait_phase parks a one-wave kernel on ANOTHER stream until
+// the word has reached a target (bounded: it is a scheduling hint, never a correctness condition). The training pipeline
+// uses the pair to start a later batch's early aggregation (HBM-bound, on the load stream) when the compute stream enters
+// its latency-bound tail (head, backward aggregation, weight gradient, optimiser) instead of beside the HBM-bound dense
+// forward (DESIGN section 6 "early aggregation": 23.5 vs 16.8 us for k_linear_fwd).
+struct PhaseSig {
+  unsigned long long* word = nullptr;
+};
+extern thread_local PhaseSig g_phase_sig;
+inline PhaseSig take_phase_sig() {
+  PhaseSig p = g_phase_sig;
+  g_phase_sig = PhaseSig{};
+  return p;
+}
+__device__ __forceinline__ void phase_signal(const PhaseSig& p) {
+  if (p.word && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    __hip_atomic_fetch_add(p.word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ void prof_succ_stamp(const ProfSucc& p) {
   if (p.ring && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
     p.ring[(size_t)((uint32_t)(p.step ? *p.step : 0) % (uint32_t)p.ring_len) * PG_PROF_WORDS + 1] = wall_clock64();
@@ -81,6 +104,78 @@ __device__ __forceinline__ void prof_end(unsigned long long* e) {
   __syncthreads();
   if (threadIdx.x == 0)
     atomicMax(e + PG_PROF_END0 + PG_PROF_SHARD_STRIDE * (blockIdx.x % PG_PROF_SHARDS), wall_clock64());
+}
+
+// ---- PG_BOUNDS: the debug build that bounds-checks ids ----------------------------------------------------------
+// `make bounds` compiles every unit with -DPG_BOUNDS into libpagraph_hip_bounds.so (PG_BOUNDS=1 makes pagraph_amd/_lib.py load
+// that one). Every index a kernel reads from a buffer SOMEBODY ELSE wrote and then follows — vertex ids into the graph / the
+// slot map / the bitmap, block edges into a layer, cache slots and staged-row numbers into the feature rows — goes through
+// PG_IDX(i, bnd, which, kernel, site): inside [0, bnd.n[which]) it is the index; outside, the FIRST offender of the process is
+// recorded (kernel, site, value, bound, block; a count of all of them) and the access is redirected to element 0, so the launch
+// completes and pg_bounds_report() can say which kernel followed which bad index — instead of a hipErrorIllegalAddress
+// somewhere behind it (the reference has one assert, storage.py:149, and no bounds checks on ids).
+// Bounds the C-ABI does not carry come from a registry of buffer extents (pg_bounds_region, filled by _lib.ptr() for every
+// tensor handed to the library): bounds_elems(p, elem_size) = elements from p to the end of the registered buffer holding p,
+// or "unknown" (then the check is skipped). The product build compiles all of this away: Bnd is empty, PG_IDX(i, ...) is i.
+enum {
+  PG_K_FWD_ROWS = 1, PG_K_COMPOSE, PG_K_SX_SAMPLE, PG_K_SX_RELABEL, PG_K_BM_RANK, PG_K_T_KEYS, PG_K_T_BLOCK, PG_K_SPLIT,
+  PG_K_GATHER, PG_K_LABELS, PG_K_LINEAR_ROWS, PG_K_BWD_W_ROWS, PG_K_HEAD, PG_K_BWD_GATHER, PG_K_SPMM_FWD, PG_K_SPMM_BWD,
+  PG_K_SCATTER, PG_K_COUNT_
+};
+#ifdef PG_BOUNDS
+constexpr long long kBndUnknown = 0x7fffffffffffffffll;
+struct Bnd {
+  long long n[4] = {kBndUnknown, kBndUnknown, kBndUnknown, kBndUnknown};
+};
+struct BoundsRec {
+  unsigned long long hit, kernel, site, value, bound, block, count, pad;
+};
+static __device__ BoundsRec g_bounds_rec;      // one per translation unit (no relocatable device code): see bounds_register
+__device__ __forceinline__ long long bounds_idx(long long i, long long n, int kernel, int site) {
+  if ((unsigned long long)i < (unsigned long long)n) return i;
+  atomicAdd(&g_bounds_rec.count, 1ull);
+  if (atomicCAS(&g_bounds_rec.hit, 0ull, 1ull) == 0ull) {
+    g_bounds_rec.kernel = (unsigned long long)kernel;
+    g_bounds_rec.site = (unsigned long long)site;
+    g_bounds_rec.value = (unsigned long long)i;
+    g_bounds_rec.bound = (unsigned long long)n;
+    g_bounds_rec.block = (unsigned long long)blockIdx.x;
+  }
+  return 0;
+}
+#define PG_IDX(i, bnd, which, kernel, site) \
+  ((std::decay_t<decltype(i)>)pg::bounds_idx((long long)(i), (bnd).n[which], kernel, site))
+typedef int (*bounds_collect_fn)(BoundsRec* out, int reset);
+void bounds_register(bounds_collect_fn fn, const char* unit);        // pg_api.hip
+long long bounds_elems(const void* p, size_t elem_size);              // pg_api.hip: kBndUnknown when p is in no registered buffer
+static int bounds_collect_unit(BoundsRec* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bounds_rec), sizeof(BoundsRec)) != hipSuccess) return -1;
+  if (reset) {
+    BoundsRec z{};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bounds_rec), &z, sizeof(BoundsRec)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+static const int g_bounds_registered = (bounds_register(&bounds_collect_unit, __BASE_FILE__), 0);
+inline Bnd bnd(long long a = kBndUnknown, long long b = kBndUnknown, long long c = kBndUnknown, long long d = kBndUnknown) {
+  Bnd r;
+  r.n[0] = a; r.n[1] = b; r.n[2] = c; r.n[3] = d;
+  return r;
+}
+#else
+struct Bnd {};
+#define PG_IDX(i, bnd, which, kernel, site) (i)
+inline long long bounds_elems(const void*, size_t) { return 0; }
+inline Bnd bnd(long long = 0, long long = 0, long long = 0, long long = 0) { return Bnd{}; }
+#endif
+
+// a slot of a pg_row_source_t through the debug build's checks: >= 0 a cache row (bound [1]), <= -3 a staged row (bound [2])
+__device__ __forceinline__ int32_t bnd_slot(int32_t sl, const Bnd& b, int kernel, int site) {
+#ifdef PG_BOUNDS
+  if (sl >= 0) return PG_IDX(sl, b, 1, kernel, site);
+  if (sl <= -3) return -(int32_t)PG_IDX((long long)(-sl - 3), b, 2, kernel, site + 1) - 3;
+#endif
+  return sl;
 }
 
 inline int hip_fail(hipError_t e) {

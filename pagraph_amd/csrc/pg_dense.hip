@@ -26,7 +26,6 @@
 #include <cstdlib>
 
 #include "pg_common.h"
-#include "pg_rows_w.h"
 
 namespace pg {
 
@@ -65,10 +64,11 @@ struct RowsArg {
   const int32_t* slots;
   const float* staged;
   int32_t staged_stride;
+  Bnd bnd;                  // PG_BOUNDS: [1] rows of the cache, [2] rows of the staged block
 };
 
 __device__ __forceinline__ const float* row_of(const float* cache, int32_t cstride, const RowsArg& ra, int64_t r) {
-  const int32_t sl = ra.slots[r];
+  const int32_t sl = bnd_slot(ra.slots[r], ra.bnd, PG_K_LINEAR_ROWS, 1);
   if (sl >= 0) return cache + (int64_t)sl * cstride;
   if (sl <= -3) return ra.staged + (int64_t)(-(sl + 3)) * ra.staged_stride;
   return nullptr;
@@ -299,337 +299,6 @@ __global__ __launch_bounds__(NW * 64) void k_linear_fwd(const float* __restrict_
   }
 }
 
-// ---- layer 0's aggregation AND its NodeUpdate in one kernel (round 4; gcn_nssc.py:64-74 + :14-24 over storage.py:176-204) ---
-// k_spmm_fwd_rows_w + k_linear_fwd without the round trip of the aggregated rows through memory between them and without
-// the second launch: a block of 8 waves owns a tile of 32 destinations.
-//   phase 1  each wave aggregates 4 of the tile's destinations exactly as k_spmm_fwd_rows_w does (rows_w_accumulate: whole
-//            source rows, coalesced, straight from the cache / the staged miss block, dropout mask, edge order, / degree) —
-//            the index loads of all four are issued before the first row load — and writes each finished row twice: to
-//            `agg` in memory (the weight gradient reads it in the backward pass) and to the tile's A operand in LDS
-//            (32 rows x (K + pad) floats: 77 KB at K = 600, two blocks per CU);
-//   phase 2  k_linear_fwd's K loop with the A operand read from LDS: wave w owns octets [o_beg, o_end) of K — the same split
-//            over 8 waves, the same MFMA sequence per octet — and reads its share of W straight from memory, 16 bytes per
-//            lane and octet (four consecutive octets of a weight row share a 128-byte line: the L1 serves three of them);
-//   phase 3  the waves' partial 32 x 32 tiles are added in wave order through LDS (aliased onto the A operand), + bias,
-//            activation / skip-concat, exactly k_linear_fwd's epilogue.
-// Same arithmetic in the same order as the pair, so `agg` AND Y are bit-identical to it (tests/test_gpu_parity.py).
-// (The first version of this round split K over the waves DURING the gather — 128-byte segments of 8 rows per load
-// instruction — and reached 2 TB/s: 45 us against 18 + 15 for the pair.)
-struct AggArgs {               // (the index / row pointers are kernel parameters of their own: __restrict__, so that the
-  int32_t cache_stride, staged_stride;   // wave-uniform index loads become scalar loads that are issued together)
-  int32_t reduce;              // PG_REDUCE_MEAN | PG_REDUCE_SUM
-  float* agg;
-  int32_t agg_stride, store_mode;
-  DropArgs d;                  // DROP == false: only d.step is read (the profiling ring's index)
-  unsigned long long* prof;
-  int32_t prof_ring;
-  unsigned long long* dbg;     // experiment: per block 4 stamps (start, after phase 1, after phase 2, end)
-};
-
-constexpr int kAggWaves = 8;                     // = k_linear_fwd's NW for K >= 256: the K split this kernel reproduces
-constexpr int kAggDpw = kTile / kAggWaves;       // destinations per wave
-static_assert(kAggDpw == 4, "k_agg_dense_fwd spells out four destinations per wave");
-
-// floats per row of the A operand in LDS: >= K rounded up to whole pieces, and an ODD number of 16-byte pieces, so that the
-// 16-byte reads of 8 consecutive rows at one column (a quarter of an MFMA operand fetch) fall into 8 different bank groups
-inline __host__ __device__ int agg_as_stride(int K) {
-  int p = (K + 3) / 4 + 1;
-  if (!(p & 1)) ++p;
-  return 4 * p;
-}
-
-template <int WV, bool DROP, bool TAIL, int M, int NT>
-__global__ __launch_bounds__(kAggWaves * 64, 4) void k_agg_dense_fwd(const int32_t* __restrict__ indptr,
-                                                                      const int32_t* __restrict__ src,
-                                                                      const int32_t* __restrict__ slots,
-                                                                      const int32_t* __restrict__ edge_slots,
-                                                                      const float* __restrict__ cache,
-                                                                      const float* __restrict__ staged, const AggArgs g,
-                                                                      const float* __restrict__ W /* [N][K] */,
-                                                                      const float* __restrict__ bias, float* __restrict__ Y,
-                                                                      int32_t y_stride, int64_t n, int32_t K, int32_t N,
-                                                                      int32_t act, int32_t as_stride) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // A operand [32][as_stride]; then the partial tiles
-  const uint32_t step = drop_step_of(g.d);
-  unsigned long long* pslot = prof_begin(g.prof, g.prof_ring, step, g.prof ? (unsigned long long)indptr[n] : 0ull);
-  const RowsW rows{src, slots, edge_slots, cache, staged, g.cache_stride, g.staged_stride};
-  const int lane = threadIdx.x & (kWave - 1);
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-  const int64_t r0 = (int64_t)blockIdx.x, G = (int64_t)gridDim.x;   // tile row j = destination r0 + G * j (see the launcher)
-  const int pieces = (K + 3) / 4;
-  const int tail = K & 3;
-  if (g.dbg && threadIdx.x == 0) g.dbg[blockIdx.x * 4 + 0] = wall_clock64();
-  // ---- phase 1: the wave's destinations r0 + w + 8 i ----
-  {
-    int32_t beg[kAggDpw], deg[kAggDpw];
-    bool fast = true;
-#pragma unroll
-    for (int i = 0; i < kAggDpw; ++i) {
-      const int64_t v = r0 + G * (w + kAggWaves * i);
-      const int64_t vc = v < n ? v : n - 1;          // unconditional scalar loads: the four pairs are in flight together
-      const int32_t b0 = indptr[vc], e0 = indptr[vc + 1];
-      beg[i] = b0;
-      deg[i] = v < n ? e0 - b0 : 0;
-      fast = fast && deg[i] <= 2;
-    }
-    // fast path (wave-uniform): every destination of the wave has at most two in-edges — the sampler's fan-out. All EIGHT
-    // source rows are in flight together, one 64-piece column group m at a time (the next group's loads are issued before
-    // this group is consumed): a destination's piece is final as soon as its two rows' pieces have arrived, so nothing
-    // accumulates across groups. Straight-line code: the index loads are two rounds (positions, then slots) of four loads
-    // each, the row loads are unconditional (a row that contributes nothing — padding, an unresolved miss, a missing second
-    // edge — reads the home's first row and is replaced by zeros, which adds +0: the same bits as skipping it).
-    if (fast) {
-      int32_t pp[kAggDpw], ps[kAggDpw];
-#pragma unroll
-      for (int i = 0; i < kAggDpw; ++i) {
-        pp[i] = 0;
-        ps[i] = -2;
-      }
-      if (deg[0] | deg[1] | deg[2] | deg[3]) {        // (kAggDpw == 4) an edge exists, so src[0] does: lanes without an
-        int32_t idx[kAggDpw];                         // edge read it, unconditionally — no branch between the loads
-#pragma unroll
-        for (int i = 0; i < kAggDpw; ++i) idx[i] = lane < deg[i] ? beg[i] + lane : 0;
-#pragma unroll
-        for (int i = 0; i < kAggDpw; ++i) pp[i] = src[idx[i]];
-        if (edge_slots) {
-#pragma unroll
-          for (int i = 0; i < kAggDpw; ++i) ps[i] = edge_slots[idx[i]];
-        } else {
-#pragma unroll
-          for (int i = 0; i < kAggDpw; ++i) ps[i] = slots[pp[i]];
-        }
-#pragma unroll
-        for (int i = 0; i < kAggDpw; ++i) ps[i] = lane < deg[i] ? ps[i] : -2;
-      }
-      const float4* const dummy = reinterpret_cast<const float4*>(rows.cache ? rows.cache : rows.staged);
-      const float4* rp[kAggDpw][2];
-      uint32_t pos[kAggDpw][2];
-      bool ok[kAggDpw][2];
-#pragma unroll
-      for (int i = 0; i < kAggDpw; ++i) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int32_t sl = __builtin_amdgcn_readlane(ps[i], e);
-          pos[i][e] = (uint32_t)__builtin_amdgcn_readlane(pp[i], e);
-          ok[i][e] = e < deg[i] && sl != -1 && sl != -2;            // padding / an unresolved miss contributes nothing
-          const float4* real = sl >= 0
-                                   ? reinterpret_cast<const float4*>(rows.cache + (int64_t)sl * rows.cache_stride)
-                                   : reinterpret_cast<const float4*>(rows.staged + (int64_t)(-sl - 3) * rows.staged_stride);
-          rp[i][e] = ok[i][e] ? real : dummy;
-        }
-      }
-      float4 xbuf[2][kAggDpw][2];
-      auto issue = [&](int m, float4 (&x)[kAggDpw][2]) {
-        const int c = m * kWave + lane;
-        if (m < M - 1 || c < pieces) {
-#pragma unroll
-          for (int i = 0; i < kAggDpw; ++i) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) x[i][e] = rp[i][e][c];
-          }
-        }
-      };
-      issue(0, xbuf[0]);
-      asm volatile("" ::: "memory");
-      uint32_t keep[kAggDpw][2];
-#pragma unroll
-      for (int m = 0; m < M; ++m) {
-        if (m + 1 < M) {
-          issue(m + 1, xbuf[(m + 1) & 1]);
-          asm volatile("" ::: "memory");            // the next group's loads are issued HERE, ahead of this group's draws
-        }
-        if constexpr (DROP) {
-          if ((m & 1) == 0) {                        // one draw serves groups m and m + 1 (its two halves)
-#pragma unroll
-            for (int i = 0; i < kAggDpw; ++i) {
-#pragma unroll
-              for (int e = 0; e < 2; ++e) {
-                keep[i][e] = 0;
-                if (ok[i][e] && m * kWave < pieces) {
-                  uint32_t o[4];
-                  Philox::gen(pos[i][e], (uint32_t)((m >> 1) * kWave + lane), g.d.tag, step, g.d.k0, g.d.k1, o);
-                  keep[i][e] = keep_bits(o, g.d.thr);
-                }
-              }
-            }
-          }
-        }
-        const int c = m * kWave + lane;
-        if (m < M - 1 || c < pieces) {
-#pragma unroll
-          for (int i = 0; i < kAggDpw; ++i) {
-            const int64_t v = r0 + G * (w + kAggWaves * i);
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              float4 xv = xbuf[m & 1][i][e];
-              if (!ok[i][e]) xv = make_float4(0.f, 0.f, 0.f, 0.f);
-              if constexpr (DROP) xv = keep_apply(xv, keep[i][e] >> (4 * (m & 1)), g.d.scale);
-              if constexpr (TAIL) {
-                if (c == pieces - 1) {
-                  if (tail < 2) xv.y = 0.f;
-                  if (tail < 3) xv.z = 0.f;
-                  xv.w = 0.f;
-                }
-              }
-              SV<4>::add(a, xv);
-            }
-            if (g.reduce == PG_REDUCE_MEAN && deg[i] > 0) SV<4>::div(a, (float)deg[i]);
-            if (v < n) store_row_piece(reinterpret_cast<float4*>(g.agg + v * g.agg_stride) + c, a, g.store_mode);
-            reinterpret_cast<float4*>(smem + (size_t)(w + kAggWaves * i) * as_stride)[c] = a;
-          }
-        }
-      }
-    } else {
-      // any degree: one destination at a time, k_spmm_fwd_rows_w's own loop (kept rolled: the fast path is the one that runs)
-#pragma unroll 1
-      for (int i = 0; i < kAggDpw; ++i) {
-        const int64_t v = r0 + G * (w + kAggWaves * i);
-        int32_t b0 = 0, e0 = 0;
-        if (v < n) {
-          b0 = indptr[v];
-          e0 = indptr[v + 1];
-        }
-        float4 acc[M];
-        bool any = false;
-#pragma unroll
-        for (int m = 0; m < M; ++m) acc[m] = make_float4(0.f, 0.f, 0.f, 0.f);
-        rows_w_accumulate<DROP, TAIL, M, false, false>(rows, b0, e0, lane, pieces, tail, step, g.d, 0, 0, acc, any);
-        const float dg = (float)(e0 - b0);
-        float4* orow = reinterpret_cast<float4*>(g.agg + v * g.agg_stride);
-        float4* arow = reinterpret_cast<float4*>(smem + (size_t)(w + kAggWaves * i) * as_stride);
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-          const int c = m * kWave + lane;
-          if (m < M - 1 || c < pieces) {
-            if (g.reduce == PG_REDUCE_MEAN && e0 > b0) SV<4>::div(acc[m], dg);
-            if (v < n) store_row_piece(orow + c, acc[m], g.store_mode);
-            arow[c] = acc[m];                         // (rows past n: zeros — their outputs are never written)
-          }
-        }
-      }
-    }
-  }
-  // ---- phase 2: k_linear_fwd's K loop, A from LDS ----
-  const int half = lane >> 5;
-  const int octets = (K + 7) / 8;
-  const int o_beg = (octets * w) / kAggWaves, o_end = (octets * (w + 1)) / kAggWaves;
-  f32x16 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const float* xa = smem + (size_t)(lane & 31) * as_stride + 4 * half;
-  auto load_w = [&](const float* wr, bool col_ok, int o, df4& b) {      // k_linear_fwd's load1, W side
-    const int left = K - (o * 8 + 4 * half);
-    b = df4{0.f, 0.f, 0.f, 0.f};
-    if (left <= 0 || !col_ok) return;
-    if (WV == 4) {
-      b = *reinterpret_cast<const df4*>(wr + o * 8);
-    } else if (WV == 2) {
-      const df2 lo = *reinterpret_cast<const df2*>(wr + o * 8);
-      b.x = lo.x; b.y = lo.y;
-      if (left > 2) {
-        const df2 hi = *reinterpret_cast<const df2*>(wr + o * 8 + 2);
-        b.z = hi.x; b.w = hi.y;
-      }
-    } else {
-      b.x = wr[o * 8];
-      if (left > 1) b.y = wr[o * 8 + 1];
-      if (left > 2) b.z = wr[o * 8 + 2];
-      if (left > 3) b.w = wr[o * 8 + 3];
-    }
-    if (left < 4) {
-      if (left < 2) b.y = 0.f;
-      if (left < 3) b.z = 0.f;
-      b.w = 0.f;
-    }
-  };
-  // octets whose W fragments are in flight together: all of the wave's share at K = 600 (9-10 octets) with one column tile.
-  // The first batch is requested BEFORE the barrier that closes phase 1 (it does not depend on the aggregation): its
-  // latency passes while the block's slower waves finish their rows.
-  constexpr int OB = NT == 1 ? 10 : 5;
-  df4 b[NT][OB];
-  auto load_batch = [&](int ob) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int col = t * kTile + (lane & 31);
-      const bool col_ok = col < N;
-      const float* wr = W + (int64_t)(col_ok ? col : 0) * K + 4 * half;
-#pragma unroll
-      for (int i = 0; i < OB; ++i) {
-        b[t][i] = df4{0.f, 0.f, 0.f, 0.f};
-        if (ob + i < o_end) load_w(wr, col_ok, ob + i, b[t][i]);
-      }
-    }
-  };
-  load_batch(o_beg);
-  asm volatile("" ::: "memory");
-  __syncthreads();
-  if (g.dbg && threadIdx.x == 0) g.dbg[blockIdx.x * 4 + 1] = wall_clock64();
-  for (int ob = o_beg; ob < o_end; ob += OB) {
-    if (ob != o_beg) load_batch(ob);
-#pragma unroll
-    for (int i = 0; i < OB; ++i) {
-      if (ob + i < o_end) {                           // wave-uniform
-        // columns in [K, 4 * pieces) of an LDS row are zeros (the TAIL mask of the aggregation); a quad wholly past K is
-        // not read (as_stride >= 4 * pieces only)
-        df4 a = df4{0.f, 0.f, 0.f, 0.f};
-        if (K - ((ob + i) * 8 + 4 * half) > 0) a = *reinterpret_cast<const df4*>(xa + (ob + i) * 8);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t][i].x, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t][i].y, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t][i].z, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t][i].w, acc[t], 0, 0, 0);
-        }
-      }
-    }
-  }
-  if (g.dbg && threadIdx.x == 0) g.dbg[blockIdx.x * 4 + 2] = wall_clock64();
-  // ---- phase 3: k_linear_fwd's epilogue per column tile (the partial tiles reuse the A operand's LDS) ----
-  float (*red)[kTile][kXsStride] = reinterpret_cast<float (*)[kTile][kXsStride]>(smem);
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    __syncthreads();                                  // every wave is done with the A operand / the previous tile's partials
-    // C layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[w][(r & 3) + 8 * (r >> 2) + 4 * half][lane & 31] = acc[t][r];
-    __syncthreads();
-    const int n0 = t * kTile;
-    const int orow = threadIdx.x >> 3, oc = (threadIdx.x & 7) * 4;
-    if (threadIdx.x < 256 && r0 + G * orow < n) {
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[j] = red[0][orow][oc + j] + red[1][orow][oc + j] + red[2][orow][oc + j] + red[3][orow][oc + j];
-#pragma unroll
-        for (int ww = 4; ww < kAggWaves; ++ww) v[j] += red[ww][orow][oc + j];
-        if (bias && n0 + oc + j < N) v[j] += bias[n0 + oc + j];
-      }
-      float* yr = Y + (r0 + G * orow) * y_stride + n0 + oc;
-      const bool vec_ok = (N & 3) == 0 && (y_stride & 3) == 0 && n0 + oc + 3 < N;
-      if (act == 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
-      }
-      if (vec_ok) {
-        *reinterpret_cast<df4*>(yr) = df4{v[0], v[1], v[2], v[3]};
-        if (act == 2)
-          *reinterpret_cast<df4*>(yr + N) = df4{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f,
-                                                v[2] > 0.f ? v[2] : 0.f, v[3] > 0.f ? v[3] : 0.f};
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (n0 + oc + j < N) {
-            yr[j] = v[j];
-            if (act == 2) yr[N + j] = v[j] > 0.f ? v[j] : 0.f;
-          }
-      }
-    }
-  }
-  if (g.dbg && threadIdx.x == 0) g.dbg[blockIdx.x * 4 + 3] = wall_clock64();
-  prof_end(pslot);
-}
-
 // gradient of the pre-activation z w.r.t. the loss, from the gradient G of the (activated) output and the
 // saved output Yout: act 0: G; act 1 (relu): G * (Yout > 0); act 2 (concat): G[:, :N] + G[:, N:] * (Yout[:, :N] > 0)
 __device__ __forceinline__ float dz_at(const float* __restrict__ G, int32_t g_stride, const float* __restrict__ Yout,
@@ -703,7 +372,7 @@ __device__ __forceinline__ void linear_bwd_w_block(const BwdWArgs& g, unsigned b
   int32_t my_slot = -2;
   if constexpr (ROWS) {
     const int64_t r = rb + lane;
-    if (lane < rpw && r < re) my_slot = ra.slots[r];
+    if (lane < rpw && r < re) my_slot = bnd_slot(ra.slots[r], ra.bnd, PG_K_BWD_W_ROWS, 1);
   }
   auto xload = [&](int rel /* wave-uniform: even row of the pair, relative to rb */, int64_t r) -> float {
     if constexpr (ROWS) {
@@ -830,14 +499,7 @@ static inline int bwd_rows_per_wave(int64_t n, int32_t K, int32_t N) {
 
 using namespace pg;
 
-static unsigned long long* g_agg_dbg = nullptr;
-
 extern "C" {
-
-int pg_debug_agg_stamps(uint64_t* p) {   // experiment hook (tools/exp_agg_dense.py): 4 stamps per block of k_agg_dense_fwd
-  g_agg_dbg = reinterpret_cast<unsigned long long*>(p);
-  return PG_OK;
-}
 
 // a row source's envelope for the dense kernels: 16-byte aligned rows in both homes
 static int rows_arg(const pg_row_source_t* X, int32_t K, const float** base, int32_t* stride, RowsArg* ra) {
@@ -854,6 +516,8 @@ static int rows_arg(const pg_row_source_t* X, int32_t K, const float** base, int
   ra->slots = X->slots;
   ra->staged = X->staged ? X->staged : X->cache;
   ra->staged_stride = X->staged ? X->staged_stride : X->cache_stride;
+  ra->bnd = bnd(0, X->cache ? bounds_elems(X->cache, 4) / X->cache_stride : 0,
+                X->staged ? bounds_elems(X->staged, 4) / X->staged_stride : (X->cache ? bounds_elems(X->cache, 4) / X->cache_stride : 0));
   return PG_OK;
 }
 
@@ -936,95 +600,6 @@ int pg_linear2_fwd(const float* X, int32_t x_stride, const float* W, const float
                    int64_t n, int32_t N, int32_t act, pg_stream_t stream) {
   if (K2 <= 0) return PG_ERR_INVALID;
   return linear_fwd(X, x_stride, W, bias, X2, x2_stride, W2, bias2, K2, Y, y_stride, n, K, N, act, stream);
-}
-
-int pg_agg_linear_fwd(const int32_t* indptr, const int32_t* src, const pg_row_source_t* rows, int64_t n_dst, int32_t K,
-                      int reduce, const pg_dropout_t* drop, const float* W, const float* bias, int32_t N, int32_t act,
-                      float* agg, int32_t agg_stride, float* Y, int32_t y_stride, uint64_t* prof, int32_t prof_ring,
-                      pg_stream_t stream) {
-  if (!rows || n_dst < 0 || K <= 0 || N <= 0 || act < 0 || act > 2 || y_stride < (act == 2 ? 2 * N : N)) return PG_ERR_INVALID;
-  if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return reduce == PG_REDUCE_MAX ? PG_ERR_UNSUPPORTED : PG_ERR_INVALID;
-  if (drop && drop->threshold > 65535u) return PG_ERR_INVALID;
-  if (prof && prof_ring <= 0) return PG_ERR_INVALID;
-  const int32_t k4 = (K + 3) & ~3;
-  // the envelope of pg_spmm_fwd_rows (wide rows of whole 16-byte pieces) and of pg_linear_fwd (N <= 64); K >= 256 is also
-  // what makes the dense kernel split K over 8 waves, the split this kernel reproduces
-  if (K < 256 || k4 > 1024 || N > 2 * kTile || agg_stride < k4 || (agg_stride & 3) || (reinterpret_cast<uintptr_t>(agg) & 15))
-    return PG_ERR_UNSUPPORTED;
-  if (rows->cache && (rows->cache_stride < k4 || (rows->cache_stride & 3) || (reinterpret_cast<uintptr_t>(rows->cache) & 15)))
-    return PG_ERR_UNSUPPORTED;
-  if (rows->staged && (rows->staged_stride < k4 || (rows->staged_stride & 3) || (reinterpret_cast<uintptr_t>(rows->staged) & 15)))
-    return PG_ERR_UNSUPPORTED;
-  if (n_dst == 0) return PG_OK;
-  if (!indptr || !src || !rows->slots || !W || !agg || !Y) return PG_ERR_INVALID;
-  AggArgs g{};
-  g.cache_stride = rows->cache_stride; g.staged_stride = rows->staged_stride;
-  g.reduce = reduce; g.agg = agg; g.agg_stride = agg_stride;
-  static const int store_mode = fwd_rows_store_mode();
-  g.store_mode = store_mode;
-  const bool has_drop = drop_args(drop, &g.d);
-  if (!has_drop) {
-    g.d = DropArgs{};
-    if (drop) g.d.step = drop->step;                  // the profiling ring is indexed by the caller's step counter
-  }
-  g.prof = reinterpret_cast<unsigned long long*>(prof);
-  g.prof_ring = prof_ring;
-  g.dbg = g_agg_dbg;
-  const uintptr_t wa = reinterpret_cast<uintptr_t>(W);
-  const int wv = (K % 4 == 0 && !(wa & 15)) ? 4 : ((K % 2 == 0 && !(wa & 7)) ? 2 : 1);
-  // Tiles are STRIDED: tile t owns destinations t, t + G, t + 2 G, ... (at most 32 of them). With G = 512 — two blocks per CU
-  // on 256 CUs, the residency the LDS tile allows — every CU carries the same number of rows however many the launch has
-  // (9 532 real rows are 298 contiguous tiles: 42 CUs with two of them finish 50 % after the others), and the empty
-  // padding rows at the end of a fixed-shape layer are dealt evenly to all tiles instead of forming blocks of their own.
-  const int64_t g32 = ceil_div<int64_t>(n_dst, kTile);
-  static const int tiles_cfg = getenv("PG_AGG_TILES") ? atoi(getenv("PG_AGG_TILES")) : 512;
-  const int64_t G = (tiles_cfg > 0 && n_dst >= 4096 && g32 < tiles_cfg) ? tiles_cfg : g32;
-  const dim3 grid((unsigned)G);
-  const int32_t as_stride = agg_as_stride(K);
-  size_t lds = (size_t)kTile * as_stride * sizeof(float);
-  const size_t lds_red = (size_t)kAggWaves * kTile * kXsStride * sizeof(float);
-  if (lds < lds_red) lds = lds_red;
-  const bool tail = (K & 3) != 0;
-  const int nt = N > kTile ? 2 : 1;
-  // one instantiation per (W access width, dropout, ragged K, pieces per lane, column tiles); each may use > 64 KB of LDS
-#define PG_AGG_K(WV, DROP, TAIL, M, NT)                                                                                \
-  do {                                                                                                                 \
-    auto kfn = k_agg_dense_fwd<WV, DROP, TAIL, M, NT>;                                                                 \
-    static bool attr_set = false;                                                                                      \
-    if (!attr_set) {                                                                                                   \
-      PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,       \
-                                 160 * 1024 - 256));                                                                   \
-      attr_set = true;                                                                                                 \
-    }                                                                                                                  \
-    hipLaunchKernelGGL(kfn, grid, dim3(kAggWaves * 64), lds, as_stream(stream), indptr, src, rows->slots,            \
-                       rows->edge_slots, rows->cache, rows->staged, g, W, bias, Y, y_stride, n_dst, K, N, act,       \
-                       as_stride);                                                                                \
-  } while (0)
-#define PG_AGG_NT(WV, DROP, TAIL, M) \
-  do { if (nt == 2) PG_AGG_K(WV, DROP, TAIL, M, 2); else PG_AGG_K(WV, DROP, TAIL, M, 1); } while (0)
-#define PG_AGG_M(WV, DROP, TAIL)                                  \
-  do {                                                            \
-    if (k4 <= 512) PG_AGG_NT(WV, DROP, TAIL, 2);                  \
-    else if (k4 <= 768) PG_AGG_NT(WV, DROP, TAIL, 3);             \
-    else PG_AGG_NT(WV, DROP, TAIL, 4);                            \
-  } while (0)
-#define PG_AGG_D(WV, TAIL) \
-  do { if (has_drop) PG_AGG_M(WV, true, TAIL); else PG_AGG_M(WV, false, TAIL); } while (0)
-  // (a ragged K is never 16-byte aligned per weight row: WV 4 implies !tail)
-  if (wv == 4) PG_AGG_D(4, false);
-  else if (wv == 2) { if (tail) PG_AGG_D(2, true); else PG_AGG_D(2, false); }
-  else { if (tail) PG_AGG_D(1, true); else PG_AGG_D(1, false); }
-#undef PG_AGG_D
-#undef PG_AGG_M
-#undef PG_AGG_NT
-#undef PG_AGG_K
-  PG_LAUNCH_CHECK();
-  if (g.prof) {                 // the next dense / head launch of this thread stamps this entry's word [1]
-    g_prof_succ.ring = g.prof;
-    g_prof_succ.ring_len = prof_ring;
-    g_prof_succ.step = g.d.step;
-  }
-  return PG_OK;
 }
 
 /* out[j] = sum over chunks of part[c][j] (chunk order), j < nk -> dW[j], nk <= j < nk + N -> db[j - nk] */

@@ -47,6 +47,7 @@ struct GatherArgs {
   int32_t n_fields;
   int32_t vec[PG_MAX_FIELDS];  // 4 / 2 / 1 floats per access; 0 = lane-per-row (narrow field)
   pg_field_t f[PG_MAX_FIELDS];
+  Bnd bnd;                     // PG_BOUNDS: [0] vertices of the partition (an id is followed into slot_map)
 };
 
 typedef float vf4 __attribute__((ext_vector_type(4)));
@@ -132,7 +133,8 @@ __global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ ids, 
                                                const int64_t* __restrict__ nid_map, int32_t* __restrict__ miss_pos,
                                                int64_t* __restrict__ miss_fullid, int32_t* __restrict__ miss_count,
                                                int32_t* __restrict__ slots_out,
-                                               unsigned long long* __restrict__ stats, const SplitDedup dd) {
+                                               unsigned long long* __restrict__ stats, const SplitDedup dd, const Bnd bnd) {
+  // PG_BOUNDS: [0] vertices of the partition (an id is followed into slot_map and nid_map)
   __shared__ int32_t s_wave[4], s_valid[4], s_dups[4];
   __shared__ int32_t s_base;
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ ids, 
   bool miss = false;
   if (row < n) {
     id = ids[row];
+    if (id >= 0) id = PG_IDX(id, bnd, 0, PG_K_SPLIT, 1);
     const int32_t s = id < 0 ? -2 : slot_map[id];   // id < 0: padding of a fixed-shape NodeFlow
     miss = s == -1;
     if (slots_out) slots_out[row] = s;  // coalesced; k_gather then skips the random slot_map lookup
@@ -217,6 +220,7 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(const GatherArgs a) {
         slot = a.slots[row0 + t];
       } else {
         id = a.ids[row0 + t];
+        if (id >= 0) id = PG_IDX(id, a.bnd, 0, PG_K_GATHER, 1);
         slot = id < 0 ? -2 : (FULL ? (int32_t)id : a.slot_map[id]);
       }
       s_slot[t] = slot;
@@ -407,6 +411,7 @@ static int launch_gather(GatherArgs& a, hipStream_t st, pg_timer* timer = nullpt
   // begin / end timestamps — what rocprofv3 reports — not the gaps to neighbouring event packets
   // tile height: 8 rows/block once the launch has >= 32K blocks anyway, 4 rows/block at the
   // minibatch shape (~34K rows -> ~8.5K blocks) to keep every CU fed through the tail.
+  if (!FULL && a.slot_map) a.bnd = bnd(bounds_elems(a.slot_map, 4));
   if (a.n >= (int64_t)1 << 18) {
     const int64_t blocks = ceil_div<int64_t>(a.n, 8);
     if (timer)
@@ -511,10 +516,10 @@ static int launch_split(const int64_t* ids, int64_t n, const int32_t* slot_map, 
   }
   if (dedup && dedup->n_ranges > 1 && (dedup->sorted_mask & ((1u << (dedup->n_ranges - 1)) - 1u)))
     hipLaunchKernelGGL(k_split<true>, dim3(grid), dim3(256), 0, st, ids, n, slot_map, nid_map, miss_pos, miss_fullid,
-                       miss_count, slots_out, sp, dd);
+                       miss_count, slots_out, sp, dd, bnd(bounds_elems(slot_map, 4)));
   else
     hipLaunchKernelGGL(k_split<false>, dim3(grid), dim3(256), 0, st, ids, n, slot_map, nid_map, miss_pos, miss_fullid,
-                       miss_count, slots_out, sp, dd);
+                       miss_count, slots_out, sp, dd, bnd(bounds_elems(slot_map, 4)));
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
@@ -610,12 +615,13 @@ int pg_split_rows_dedup(const int64_t* ids, int64_t n, const int32_t* slot_map, 
 // step once the table is cached). Padding ids (< 0) -> -2; stats[0] += rows looked up (storage.py:203's try counter).
 __global__ __launch_bounds__(256) void k_slots_full(const int64_t* __restrict__ ids, int64_t n,
                                                     const int32_t* __restrict__ slot_map, int32_t* __restrict__ slots_out,
-                                                    unsigned long long* __restrict__ stats) {
+                                                    unsigned long long* __restrict__ stats, const Bnd bnd) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int valid = 0;
   if (i < n) {
-    const int64_t v = ids[i];
+    int64_t v = ids[i];
     valid = v >= 0;
+    if (valid) v = PG_IDX(v, bnd, 0, PG_K_SPLIT, 2);
     slots_out[i] = valid ? slot_map[v] : -2;
   }
   if (stats) {
@@ -636,7 +642,7 @@ int pg_slots_full(const int64_t* ids, int64_t n, const int32_t* slot_map, int32_
   if (n == 0) return PG_OK;
   if (!ids || !slot_map || !slots_out) return PG_ERR_INVALID;
   hipLaunchKernelGGL(k_slots_full, dim3((unsigned)ceil_div<int64_t>(n, 256)), dim3(256), 0, as_stream(stream), ids, n, slot_map,
-                     slots_out, reinterpret_cast<unsigned long long*>(stats));
+                     slots_out, reinterpret_cast<unsigned long long*>(stats), bnd(bounds_elems(slot_map, 4)));
   PG_LAUNCH_CHECK();
   return PG_OK;
 }

@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
                                                   const float* __restrict__ grad_scale_dev, HeadDrop d, int reduce,
                                                   int64_t n_dst, float* __restrict__ logits,
                                                   float* __restrict__ dagg, float* __restrict__ part, int dagg_per_edge,
-                                                  int row_len, const ProfSucc succ, const HeadSelf self) {
+                                                  int row_len, const ProfSucc succ, const HeadSelf self, const Bnd bnd,
+                                                  const PhaseSig phase) {
+  // PG_BOUNDS: [0] rows of h (a block edge is followed into the source layer's activations)
+  phase_signal(phase);       // "the dense forward before this launch has drained" (pg_phase_arm / pg_wait_phase)
   prof_succ_stamp(succ);     // a profiled predecessor's "my successor started" stamp (pg_common.h)
   const int Ks = self.Ks, Kt = K + Ks;          // input columns: [0, K) aggregated, [K, Kt) the destination's own row
   __shared__ __attribute__((aligned(16))) float s_rows[4][kHeadRows][kHeadMax];   // the waves' aggregated rows
@@ -124,8 +127,8 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
   }
 #pragma unroll
   for (int it = 0; it < kHeadRows; ++it) {
-    s0[it] = beg[it] < end[it] ? src[beg[it]] : -1;
-    s1[it] = beg[it] + 1 < end[it] ? src[beg[it] + 1] : -1;
+    s0[it] = beg[it] < end[it] ? PG_IDX(src[beg[it]], bnd, 0, PG_K_HEAD, 1) : -1;
+    s1[it] = beg[it] + 1 < end[it] ? PG_IDX(src[beg[it] + 1], bnd, 0, PG_K_HEAD, 2) : -1;
   }
   float x0[kHeadRows], x1[kHeadRows];
 #pragma unroll
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
       if (s0[it] >= 0) a += d.thr ? (keep0[it] ? x0[it] * d.scale : 0.f) : x0[it];
       if (s1[it] >= 0) a += d.thr ? (keep1[it] ? x1[it] * d.scale : 0.f) : x1[it];
       for (int32_t e = beg[it] + 2; e < end[it]; ++e) {     // fan-out > 2: the rest of the row, one by one
-        const int32_t sr = src[e];
+        const int32_t sr = PG_IDX(src[e], bnd, 0, PG_K_HEAD, 3);
         a += dropped(sr, h[(int64_t)sr * h_stride + lane]);
       }
       if (reduce == PG_REDUCE_MEAN && end[it] > beg[it]) a /= (float)(end[it] - beg[it]);
@@ -373,8 +376,10 @@ static int head_impl(const int32_t* indptr, const int32_t* src, const float* h, 
 #define PG_HEAD(R)                                                                                                   \
   hipLaunchKernelGGL(k_gcn_head<R>, dim3((unsigned)blocks), dim3(256), 0, st, indptr, src, h, h_stride, K, W, bias, C, \
                      labels, ignore_index, n_valid_dev, grad_scale_dev, d, reduce, n_dst, logits, dagg, partials,          \
-                     (flags & PG_HEAD_DAGG_PER_EDGE) ? 1 : 0, (int)pg_gcn_head_row_len(Kt, C), succ, self)
+                     (flags & PG_HEAD_DAGG_PER_EDGE) ? 1 : 0, (int)pg_gcn_head_row_len(Kt, C), succ, self,                \
+                     bnd(bounds_elems(h, 4) / h_stride), phase)
   const ProfSucc succ = take_prof_succ();
+  const PhaseSig phase = take_phase_sig();
   if (rpw == 1) PG_HEAD(1);
   else if (rpw == 2) PG_HEAD(2);
   else if (rpw == 4) PG_HEAD(4);
@@ -407,6 +412,30 @@ int pg_sage_head(const int32_t* indptr, const int32_t* src, const float* h, int3
   HeadSelf self{h_self, W_self, bias_self, dself, hs_stride, Ks};
   return head_impl(indptr, src, h, h_stride, K, W, bias, C, labels, ignore_index, n_valid_dev, grad_scale_dev, drop, reduce,
                    n_dst, logits, dagg, partials, dW_both, db_loss, flags, self, stream);
+}
+
+
+int pg_phase_arm(uint64_t* word, int32_t* was_pending) {
+  if (was_pending) *was_pending = g_phase_sig.word != nullptr;
+  g_phase_sig.word = reinterpret_cast<unsigned long long*>(word);
+  return PG_OK;
+}
+
+__global__ void k_wait_phase(const unsigned long long* __restrict__ word, unsigned long long target, unsigned long long ticks) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long t0 = wall_clock64();
+  while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    if (wall_clock64() - t0 > ticks) break;        // a hint, not a condition: never hold the stream for long
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
+int pg_wait_phase(const uint64_t* word, uint64_t target, uint32_t timeout_us, pg_stream_t stream) {
+  if (!word) return PG_ERR_INVALID;
+  hipLaunchKernelGGL(k_wait_phase, dim3(1), dim3(64), 0, as_stream(stream), reinterpret_cast<const unsigned long long*>(word),
+                     (unsigned long long)target, (unsigned long long)timeout_us * 100ull);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
 }
 
 }  // extern "C"

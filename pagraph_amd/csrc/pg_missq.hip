@@ -912,6 +912,7 @@ int pg_missq_create(int device, int n_slots, int64_t max_rows, const pg_missq_fi
       const size_t bytes = (size_t)max_rows * q->sstride[f] * sizeof(float);
       ok = ok && hipHostMalloc((void**)&s.staging_h[f], bytes, hipHostMallocDefault) == hipSuccess;
       ok = ok && hipMalloc((void**)&s.staged_d[f], bytes) == hipSuccess;
+      if (ok) (void)pg_bounds_region(s.staged_d[f], (int64_t)bytes);   // (debug build: the block's extent bounds staged-row numbers)
     }
     ok = ok && hipEventCreateWithFlags(&s.filled, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&s.tail_go, hipEventDisableTiming) == hipSuccess;

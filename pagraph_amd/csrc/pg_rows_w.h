@@ -55,6 +55,7 @@ struct RowsW {                  // where the source rows live (pg_row_source_t, 
   const float* cache;
   const float* staged;
   int32_t cache_stride, staged_stride;
+  Bnd bnd;                      // PG_BOUNDS: [0] rows of the source layer (slots' length), [1] rows of the cache, [2] of the staged block
 };
 
 // acc[m] = piece (m * 64 + lane) of the reduction over edges [beg, end) — NOT yet divided by the degree.
@@ -71,8 +72,9 @@ __device__ __forceinline__ void rows_w_accumulate(const RowsW& r, int32_t beg, i
       my_p = pre_p;
       my_s = pre_s;
     } else if (lane < ne) {
-      my_p = r.src[eb + lane];
+      my_p = PG_IDX(r.src[eb + lane], r.bnd, 0, PG_K_FWD_ROWS, 1);
       my_s = r.edge_slots ? r.edge_slots[eb + lane] : r.slots[my_p];
+      my_s = bnd_slot(my_s, r.bnd, PG_K_FWD_ROWS, 2);
     }
     for (int e0 = 0; e0 < ne; e0 += kRowsPair) {
       float4 x[kRowsPair][M];

@@ -390,6 +390,7 @@ struct SampleGArgs {
   int32_t k, g_shift, iters;   // group of 1 << g_shift lanes per destination, `iters` destinations per group
   uint32_t layer, epoch, batch, seed_lo, seed_hi;
   unsigned long long* bitmap;
+  uint8_t* dirty;              // one byte per kWordsPerBlock bitmap words: set when a word of the unit turns non-zero (see k_bm_rank)
   int32_t* blk_indptr;
   int32_t* blk_src;            // picks in CSR position, as vertex ids until X relabels them
   int32_t* ecnt;               // edges of the block
@@ -401,6 +402,7 @@ struct SampleGArgs {
   int32_t* top_cnt;
   int64_t* nm_top;             // fixed-shape layout: node_mapping at the top layer's offset (ids, then -1 up to nm_cap)
   int32_t nm_cap;
+  Bnd bnd;                     // PG_BOUNDS: [0] vertices of the graph (a destination id is followed into indptr)
 };
 
 __device__ __forceinline__ void sample_body(const SampleGArgs& a, const int blk, int* lds) {
@@ -417,7 +419,7 @@ __device__ __forceinline__ void sample_body(const SampleGArgs& a, const int blk,
     const int64_t p = p_base + (int64_t)it * vpi;
     int64_t beg = 0, deg = 0, v = -1;
     if (p < n) {
-      v = a.dst_ids[p];
+      v = PG_IDX(a.dst_ids[p], a.bnd, 0, PG_K_SX_SAMPLE, 1);
       beg = a.indptr[v];
       deg = a.indptr[v + 1] - beg;
     }
@@ -437,7 +439,7 @@ __device__ __forceinline__ void sample_body(const SampleGArgs& a, const int blk,
     if (it > 0) {
       beg = deg = 0; v = -1;
       if (p < n) {
-        v = a.dst_ids[p];
+        v = PG_IDX(a.dst_ids[p], a.bnd, 0, PG_K_SX_SAMPLE, 2);
         beg = a.indptr[v];
         deg = a.indptr[v + 1] - beg;
       }
@@ -478,7 +480,8 @@ __device__ __forceinline__ void sample_body(const SampleGArgs& a, const int blk,
     if (gl == 0 && p == a.cap_rows) *a.ecnt = pos;
     if (u >= 0) {
       a.blk_src[pos + gl] = u;
-      atomicOr(&a.bitmap[u >> 6], 1ull << (u & 63));
+      // the first mark in a word also flags the word's 1024-word unit (a plain store of 1: every racer writes the same byte)
+      if (atomicOr(&a.bitmap[u >> 6], 1ull << (u & 63)) == 0ull) a.dirty[u >> 16] = 1;
     }
     if (a.top_ids && gl == 0) {
       if (p < n) a.top_ids[p] = v;
@@ -506,13 +509,14 @@ struct RelabelXArgs {
   int32_t* sizes_pinned;
   int32_t* sizes_dev;
   int32_t pad_off[PG_MAX_LAYERS + 1];
+  Bnd bnd;                     // PG_BOUNDS: [0] vertices of the graph (blk_src holds vertex ids until relabelled), [1] edge capacity
 };
 
 __device__ __forceinline__ void relabel_body(const RelabelXArgs& a, const int blk, const int nblk) {
   const int64_t tid = (int64_t)blk * blockDim.x + threadIdx.x, nth = (int64_t)nblk * blockDim.x;
-  const int nnz = *a.ecnt;
+  const int nnz = (int)PG_IDX((long long)*a.ecnt, a.bnd, 1, PG_K_SX_RELABEL, 2);
   for (int64_t e = tid; e < nnz; e += nth) {
-    const int32_t u = a.blk_src[e];
+    const int32_t u = PG_IDX(a.blk_src[e], a.bnd, 0, PG_K_SX_RELABEL, 1);
     const int64_t w = u >> 6;
     const unsigned long long below = a.bm[w] & ((1ull << (u & 63)) - 1ull);
     a.blk_src[e] = (int32_t)(a.word_rank[w] + __popcll(below));
@@ -556,6 +560,11 @@ struct RankArgs {
   const int32_t* clear_cnt;
   int64_t clear_cap;
   int64_t n_words;
+  // Round 5: S flags every 1024-word unit it marks a first bit in; a unit that is not flagged holds no bit of this layer, so
+  // the block neither loads its words nor writes their ranks (nobody reads the rank of an empty word) and counts 0 for it. At
+  // 10^8 vertices a layer of <= 24 K ids dirties a few hundred of the bitmap's 1 526 units — the launch used to read all
+  // 12.5 MB twice and write 6 MB of ranks per layer. The block that owns a unit clears its flag once it has read it.
+  uint8_t* dirty;                 // [ceil(n_words / 1024)] flags of `bm` (NULL: every unit is read)
   int32_t m;                      // the block covers 1024 * m words, 4 per thread and round
   unsigned long long* agg;
   uint32_t tag;
@@ -565,6 +574,7 @@ struct RankArgs {
   uint32_t* word_rank;
   int32_t* count_out;
   int64_t* nm_out;                // fixed-shape layout: node_mapping at this layer's offset (NULL otherwise)
+  Bnd bnd;                        // PG_BOUNDS: [0] vertices of the graph (an id of the clear list is followed into the bitmap)
 };
 
 __global__ __launch_bounds__(256) void k_bm_rank(const RankArgs a) {
@@ -578,19 +588,31 @@ __global__ __launch_bounds__(256) void k_bm_rank(const RankArgs a) {
     int64_t n = *a.clear_cnt;
     if (n > a.clear_cap) n = a.clear_cap;
     for (int64_t i = (int64_t)blk * blockDim.x + tid; i < n; i += (int64_t)gridDim.x * blockDim.x)
-      a.other_bm[a.clear_ids[i] >> 6] = 0ull;
+      a.other_bm[PG_IDX(a.clear_ids[i], a.bnd, 0, PG_K_BM_RANK, 1) >> 6] = 0ull;
+  }
+  unsigned long long live = ~0ull;        // bit r: round r's unit is flagged (block-uniform)
+  const bool flagged = a.dirty != nullptr && a.m <= 64;
+  if (flagged) {
+    live = 0ull;
+    const int64_t n_units = (a.n_words + kWordsPerBlock - 1) / kWordsPerBlock;
+    for (int r = 0; r < a.m; ++r) {
+      const int64_t unit = (int64_t)blk * a.m + r;
+      if (unit < n_units && a.dirty[unit]) live |= 1ull << r;
+    }
   }
   for (int r = 0; r < a.m; ++r) {
     const int64_t w0 = wblk + (int64_t)r * kWordsPerBlock + tid * 4;
+    const bool on = (live >> (r & 63)) & 1ull;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      w[i] = (w0 + i < a.n_words) ? a.bm[w0 + i] : 0ull;
+      w[i] = (on && w0 + i < a.n_words) ? a.bm[w0 + i] : 0ull;
       mine += __popcll(w[i]);
       if (clear_all && w0 + i < a.n_words) a.other_bm[w0 + i] = 0ull;
     }
   }
   int tot;
-  (void)block_excl_scan(mine, lds, &tot);
+  (void)block_excl_scan(mine, lds, &tot);       // (a block barrier: every thread has read the flags)
+  if (flagged && tid < a.m && ((live >> tid) & 1ull)) a.dirty[(int64_t)blk * a.m + tid] = 0;
   if (tid == 0)
     __hip_atomic_store(a.agg + blk, ((unsigned long long)a.tag << 32) | (uint32_t)tot, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
@@ -602,6 +624,7 @@ __global__ __launch_bounds__(256) void k_bm_rank(const RankArgs a) {
   int carry = lds[16];
   if (blk == (int)gridDim.x - 1 && tid == 0) *a.count_out = carry + tot;
   for (int r = 0; r < a.m; ++r) {
+    if (!((live >> (r & 63)) & 1ull)) continue;          // block-uniform: an empty unit emits nothing and moves no position
     const int64_t w0 = wblk + (int64_t)r * kWordsPerBlock + tid * 4;
     int c = 0;
 #pragma unroll
@@ -642,12 +665,14 @@ __global__ __launch_bounds__(256) void k_t_keys(const int32_t* __restrict__ indp
                                                 const int32_t* __restrict__ nnz_dev, int32_t cap_edges,
                                                 int32_t pad_key, int32_t* __restrict__ key,
                                                 int32_t* __restrict__ val, int32_t* __restrict__ tcnt,
-                                                int32_t* __restrict__ heavy) {
-  const int n = *n_dst_dev, nnz = *nnz_dev;
+                                                int32_t* __restrict__ heavy, Bnd bnd) {
+  // PG_BOUNDS: [0] destination rows + 1, [1] edge capacity + 1, [2] source rows (a block edge is followed into tcnt)
+  const int n = (int)PG_IDX((long long)*n_dst_dev, bnd, 0, PG_K_T_KEYS, 1);
+  const int nnz = (int)PG_IDX((long long)*nnz_dev, bnd, 1, PG_K_T_KEYS, 2);
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
   for (int v = tid; v < n; v += nth) {
     for (int e = indptr[v]; e < indptr[v + 1]; ++e) {
-      const int sr = src[e];
+      const int sr = PG_IDX(src[e], bnd, 2, PG_K_T_KEYS, 3);
       key[e] = sr;
       val[e] = v;
       atomicAdd(tcnt + sr, 1);
@@ -686,7 +711,8 @@ __global__ __launch_bounds__(1024) void k_t_block(const int32_t* __restrict__ in
                                                   int32_t cap_rows, int val_bits, int key_bits,
                                                   uint32_t* __restrict__ stage, int32_t* __restrict__ tptr,
                                                   int32_t* __restrict__ tdst, int32_t* __restrict__ heavy,
-                                                  int32_t heavy_cap) {
+                                                  int32_t heavy_cap, Bnd bnd) {
+  // PG_BOUNDS: [0] destination rows + 1, [1] edge capacity + 1, [2] source rows (a block edge becomes a sort key / an LDS index)
   using Sort = rocprim::block_radix_sort<uint32_t, 1024, ITEMS>;
   constexpr int kN = 1024 * ITEMS;
   __shared__ union {
@@ -697,7 +723,8 @@ __global__ __launch_bounds__(1024) void k_t_block(const int32_t* __restrict__ in
   __shared__ uint32_t edge_key[1024];
   __shared__ int32_t wave_min[16];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
-  const int n = *n_dst_dev, nnz = *nnz_dev;
+  const int n = (int)PG_IDX((long long)*n_dst_dev, bnd, 0, PG_K_T_BLOCK, 1);
+  const int nnz = (int)PG_IDX((long long)*nnz_dev, bnd, 1, PG_K_T_BLOCK, 2);
   if (tid == 0 && heavy) heavy[0] = 0;
   // keys in edge order, ITEMS consecutive edges per thread (blocked): indptr goes through LDS (one round of independent,
   // coalesced loads), a thread's source ids are ITEMS independent loads, its first edge's destination one binary search
@@ -707,7 +734,7 @@ __global__ __launch_bounds__(1024) void k_t_block(const int32_t* __restrict__ in
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
     const int e = tid * ITEMS + j;
-    k[j] = e < nnz ? (uint32_t)src[e] : 0u;
+    k[j] = e < nnz ? (uint32_t)PG_IDX(src[e], bnd, 2, PG_K_T_BLOCK, 3) : 0u;
   }
   __syncthreads();
   {
@@ -862,6 +889,7 @@ struct pg_sampler {
   // device buffers
   unsigned long long* bitmap = nullptr;
   unsigned long long* bitmap_b = nullptr;   // layers alternate between the two (the other one is being cleared)
+  uint8_t* dirty = nullptr;                 // [2][n_bm_blocks] unit flags of bitmap / bitmap_b (k_sx sets, k_bm_rank reads + clears)
   uint32_t* word_rank = nullptr;
   int32_t* partial = nullptr;
   int64_t* layer_ids[PG_MAX_LAYERS] = {nullptr};
@@ -880,6 +908,7 @@ static void sampler_free(pg_sampler* s) {
   if (!s) return;
   (void)hipFree(s->bitmap);
   (void)hipFree(s->bitmap_b);
+  (void)hipFree(s->dirty);
   (void)hipFree(s->word_rank);
   (void)hipFree(s->partial);
   for (auto p : s->layer_ids) (void)hipFree(p);
@@ -935,6 +964,8 @@ int pg_sampler_create(int64_t V, const int64_t* indptr, const int32_t* indices, 
   ok &= hipMalloc(&s->bitmap, s->n_words * 8) == hipSuccess;
   ok &= hipMalloc(&s->bitmap_b, s->n_words * 8) == hipSuccess;
   ok &= hipMalloc(&s->word_rank, s->n_words * 4) == hipSuccess;
+  ok &= hipMalloc(&s->dirty, (size_t)2 * s->n_bm_blocks + 8) == hipSuccess;
+  if (ok) ok &= hipMemset(s->dirty, 0, (size_t)2 * s->n_bm_blocks + 8) == hipSuccess;
   ok &= hipMalloc(&s->partial, (size_t)s->n_bm_blocks * 4 + 4) == hipSuccess;
   for (int l = 0; l <= L; ++l) ok &= hipMalloc(&s->layer_ids[l], s->cap[l] * 8) == hipSuccess;
   ok &= hipMalloc(&s->counters, 2 * PG_MAX_LAYERS * 4) == hipSuccess;
@@ -1029,6 +1060,7 @@ static int transpose_block(pg_sampler* s, const pg_nodeflow_desc_t* o, int b, co
   const int32_t cap_edges = (int32_t)(s->cap[b + 1] * s->k);
   const int32_t pad_key = (int32_t)s->cap[b];
   int32_t *key_in = s->tkey, *key_out = s->tkey + s->max_edges, *val_in = s->tkey + 2 * s->max_edges;
+  const Bnd tb = bnd(s->cap[b + 1] + 1, (long long)cap_edges + 1, s->cap[b]);
   // small blocks (the seeds' block of a 2-layer step: 12 000 edges): one workgroup does it all (PG_T_DEVICE_SORT=1: never)
   static const bool device_sort = getenv("PG_T_DEVICE_SORT") != nullptr;
   const int64_t larger = cap_edges > s->cap[b] + 1 ? cap_edges : s->cap[b] + 1;
@@ -1040,16 +1072,18 @@ static int transpose_block(pg_sampler* s, const pg_nodeflow_desc_t* o, int b, co
       const int32_t hcap = (int32_t)(cap_edges / PG_HEAVY_ROW);
       if (larger <= 1024 * 4)
         hipLaunchKernelGGL(k_t_block<4>, dim3(1), dim3(1024), 0, ax, indptr_b, src_b, n_dst, nnz, cap_edges,
-                           (int32_t)s->cap[b], vb, kb, reinterpret_cast<uint32_t*>(key_in), tptr_b, tdst_b, heavy_b, hcap);
+                           (int32_t)s->cap[b], vb, kb, reinterpret_cast<uint32_t*>(key_in), tptr_b, tdst_b, heavy_b, hcap,
+                           tb);
       else
         hipLaunchKernelGGL(k_t_block<12>, dim3(1), dim3(1024), 0, ax, indptr_b, src_b, n_dst, nnz, cap_edges,
-                           (int32_t)s->cap[b], vb, kb, reinterpret_cast<uint32_t*>(key_in), tptr_b, tdst_b, heavy_b, hcap);
+                           (int32_t)s->cap[b], vb, kb, reinterpret_cast<uint32_t*>(key_in), tptr_b, tdst_b, heavy_b, hcap,
+                           tb);
       PG_LAUNCH_CHECK();
       return PG_OK;
     }
   }
   hipLaunchKernelGGL(k_t_keys, dim3(grid_for(s->cap[b + 1], 256, 1024)), dim3(256), 0, ax, indptr_b, src_b, n_dst, nnz,
-                     cap_edges, pad_key, key_in, val_in, s->tcnt, heavy_b);
+                     cap_edges, pad_key, key_in, val_in, s->tcnt, heavy_b, tb);
   PG_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_scan_cnt<true>, dim3(1), dim3(kScanThreads), 0, ax, s->tcnt, n_src, tptr_b, scan_total_dummy,
                      (int32_t)s->cap[b]);
@@ -1166,10 +1200,12 @@ static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t
       s_blocks = (int)ceil_div<int64_t>(cap_dst + 1, (int64_t)vpi * a.iters);
       a.layer = (uint32_t)b; a.epoch = prm.epoch; a.batch = prm.batch; a.seed_lo = prm.seed_lo; a.seed_hi = prm.seed_hi;
       a.bitmap = bm;
+      a.dirty = s->dirty + (size_t)(s->rank_launches & 1) * s->n_bm_blocks;
       a.blk_indptr = o->blk_indptr + o->blk_indptr_off[b];
       a.blk_src = o->blk_src + o->blk_src_off[b];
       a.ecnt = ecnt + b;
       a.agg = s->agg; a.tag = ++s->tag ? s->tag : ++s->tag; a.err = s->err;
+      a.bnd = bnd(s->V);
       if (b == L - 1) {
         a.dst_ids = prm.seeds; a.n_dev = nullptr; a.n_imm = prm.n_seeds;
         a.top_ids = s->layer_ids[L]; a.top_cnt = lcnt + L;
@@ -1190,6 +1226,8 @@ static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t
     if (b < 0) break;
     RankArgs r{};
     r.bm = bm; r.other_bm = other; r.n_words = s->n_words;
+    static const bool no_flags = getenv("PG_SAMPLER_NO_UNIT_FLAGS") != nullptr;     // A/B: every unit is read (rounds 3-4)
+    r.dirty = no_flags ? nullptr : s->dirty + (size_t)(s->rank_launches & 1) * s->n_bm_blocks;
     if (s->clear_by_ids) {
       // `other` holds the marks of the previous rank launch's layer: layer b + 1 of this call, or — for the first rank
       // launch of a call — layer 0 of the previous call (its ids and count are still in place: this call has not emitted
@@ -1201,6 +1239,7 @@ static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t
     r.agg = s->agg; r.tag = ++s->tag ? s->tag : ++s->tag; r.err = s->err;
     r.out_ids = s->layer_ids[b]; r.cap = s->cap[b]; r.word_rank = s->word_rank; r.count_out = lcnt + b;
     r.nm_out = padded ? o->node_mapping + pad_off[b] : nullptr;
+    r.bnd = bnd(s->V);
     hipLaunchKernelGGL(k_bm_rank, dim3(s->rank_blocks), dim3(256), 0, st, r);
     PG_LAUNCH_CHECK();
     ++s->rank_launches;
@@ -1212,6 +1251,7 @@ static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t
     x.nm_tail = padded ? o->node_mapping + pad_off[b] : nullptr;
     x.lcnt_b = lcnt + b; x.cap_b = (int32_t)s->cap[b];
     x_blocks = grid_for(s->cap[b + 1] * s->k, 256, 256);
+    x.bnd = bnd(s->V, s->cap[b + 1] * s->k + 1);
     if (b == 0 && padded) {
       x.final_sizes = 1; x.num_layers = L + 1; x.lcnt = lcnt; x.ecnt_all = ecnt;
       x.layer_offsets = o->layer_offsets; x.sizes_pinned = o->sizes_pinned; x.sizes_dev = o->sizes_dev;

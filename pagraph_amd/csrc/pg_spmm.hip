@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void k_spmm_fwd(const int32_t* __restrict__ in
                                                   const int32_t* __restrict__ src,
                                                   const float* __restrict__ h, int32_t h_stride, int64_t n_dst,
                                                   int32_t dim, int reduce, float* __restrict__ out,
-                                                  int32_t out_stride, int lpr_log2) {
+                                                  int32_t out_stride, int lpr_log2, const Bnd bnd) {
+  // PG_BOUNDS: [0] rows of h (a block edge is followed into the source layer)
   using S = SV<VEC>;
   using V = typename S::type;
   const int lpr = 1 << lpr_log2;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void k_spmm_fwd(const int32_t* __restrict__ in
 #pragma unroll
     for (int m = 0; m < kMaxAcc; ++m) acc[m] = (MAXR && end > beg) ? S::fill(kNegInf) : S::zero();
     for (int32_t e = beg; e < end; ++e) {
-      const V* hrow = reinterpret_cast<const V*>(h + (int64_t)src[e] * h_stride);
+      const V* hrow = reinterpret_cast<const V*>(h + (int64_t)PG_IDX(src[e], bnd, 0, PG_K_SPMM_FWD, 1) * h_stride);
 #pragma unroll
       for (int m = 0; m < kMaxAcc; ++m) {
         const int c = c0 + m * lpr + gl;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_drop(const int32_t* __restrict
                                                        const int32_t* __restrict__ src,
                                                        const float* __restrict__ h, int32_t h_stride, int64_t n_dst,
                                                        int32_t dim, int reduce, float* __restrict__ out,
-                                                       int32_t out_stride, int lpr_log2, DropArgs d) {
+                                                       int32_t out_stride, int lpr_log2, DropArgs d, const Bnd bnd) {
   using S = SV<4>;
   const int lpr = 1 << lpr_log2;
   const int lane = threadIdx.x & (kWave - 1);
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_drop(const int32_t* __restrict
 #pragma unroll
     for (int m = 0; m < kMaxAcc; ++m) acc[m] = (MAXR && end > beg) ? S::fill(kNegInf) : S::zero();
     for (int32_t e = beg; e < end; ++e) {
-      const int32_t sr = src[e];
+      const int32_t sr = PG_IDX(src[e], bnd, 0, PG_K_SPMM_FWD, 2);
       const float4* hrow = reinterpret_cast<const float4*>(h + (int64_t)sr * h_stride);
       uint32_t o[4] = {0, 0, 0, 0};
       int have_q = -1;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict
                                                        const float* __restrict__ staged, int32_t staged_stride,
                                                        int64_t n_dst, int32_t dim, int reduce,
                                                        float* __restrict__ out, int32_t out_stride, DropArgs d,
-                                                       unsigned long long* __restrict__ prof, int prof_ring) {
+                                                       unsigned long long* __restrict__ prof, int prof_ring, Bnd bnd) {
   using S = SV<4>;
   const uint32_t step = drop_step_of(d);
   unsigned long long* pslot = prof_begin(prof, prof_ring, step, prof ? (unsigned long long)indptr[n_dst] : 0ull);
@@ -231,8 +232,9 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows(const int32_t* __restrict
         // flight together (edge_slots: slots[src[e]] composed per edge beforehand — one dependent load less)
         int32_t my_p = 0, my_s = -2;
         if (lane < ne) {
-          my_p = src[eb + lane];
+          my_p = PG_IDX(src[eb + lane], bnd, 0, PG_K_FWD_ROWS, 4);
           my_s = edge_slots ? edge_slots[eb + lane] : slots[my_p];
+          my_s = bnd_slot(my_s, bnd, PG_K_FWD_ROWS, 5);
         }
         for (int e0 = 0; e0 < ne; e0 += kRowsBatch) {
           // the loads of up to kRowsBatch source rows are issued before the first is consumed; the accumulation
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows_w(const int32_t* __restri
                                                          int64_t n_dst, int32_t dim, int reduce,
                                                          float* __restrict__ out, int32_t out_stride, DropArgs d,
                                                          unsigned long long* __restrict__ prof, int prof_ring,
-                                                         int store_mode) {
+                                                         int store_mode, Bnd bnd) {
   using S = SV<4>;
   const uint32_t step = drop_step_of(d);
   unsigned long long* pslot = prof_begin(prof, prof_ring, step, prof ? (unsigned long long)indptr[n_dst] : 0ull);
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(256) void k_spmm_fwd_rows_w(const int32_t* __restri
     bool any = false;            // MAXR: a row was taken
 #pragma unroll
     for (int m = 0; m < M; ++m) acc[m] = MAXR ? S::fill(kNegInf) : S::zero();
-    const RowsW rw{src, slots, edge_slots, cache, staged, cache_stride, staged_stride};
+    const RowsW rw{src, slots, edge_slots, cache, staged, cache_stride, staged_stride, bnd};
     rows_w_accumulate<DROP, TAIL, M, MAXR, false>(rw, beg, end, lane, pieces, tail, step, d, 0, 0, acc, any);
     const float dg = (float)(end - beg);
     float4* orow = reinterpret_cast<float4*>(out + v * out_stride);
@@ -452,7 +454,7 @@ __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, in
                                            const int32_t* __restrict__ indptr, const float* __restrict__ go,
                                            int32_t go_stride, int32_t dim, int reduce, float* __restrict__ gh,
                                            int32_t gh_stride, int lpr_log2, DropArgs d, int first, int stride, DzOut z,
-                                           MaxIn mi, int parts);
+                                           MaxIn mi, int parts, const Bnd& bnd);
 
 constexpr int kBwdBatch = 4;
 
@@ -466,13 +468,14 @@ __global__ __launch_bounds__(256) void k_spmm_bwd_gather(const int32_t* __restri
                                                          float* __restrict__ gh, int32_t gh_stride, int lpr_log2,
                                                          int skip_heavy, DropArgs d, const int32_t* __restrict__ heavy,
                                                          int32_t heavy_cap, int32_t n_row_blocks, DzOut z, MaxIn mi,
-                                                         int hub_parts) {
+                                                         int hub_parts, const Bnd bnd) {
+  // PG_BOUNDS: [0] destination rows of grad_out (an entry of the source-major copy is followed into them), [1] source rows
   using S = SV<VEC>;
   using V = typename S::type;
   if ((int)blockIdx.x >= n_row_blocks) {
     heavy_rows<VEC, DROP, 256, MAXR>(heavy, heavy_cap, tptr, tdst, indptr, go, go_stride, dim, reduce, gh, gh_stride,
                                      lpr_log2, d, (int)blockIdx.x - n_row_blocks, (int)gridDim.x - n_row_blocks, z, mi,
-                                     hub_parts);
+                                     hub_parts, bnd);
     return;
   }
   const int lpr = 1 << lpr_log2;
@@ -508,7 +511,7 @@ __global__ __launch_bounds__(256) void k_spmm_bwd_gather(const int32_t* __restri
     for (int32_t t = beg; t < end; t += kBwdBatch) {
       int32_t v[kBwdBatch];
 #pragma unroll
-      for (int u = 0; u < kBwdBatch; ++u) v[u] = t + u < end ? tdst[t + u] : -1;
+      for (int u = 0; u < kBwdBatch; ++u) v[u] = t + u < end ? PG_IDX(tdst[t + u], bnd, 0, PG_K_BWD_GATHER, 1) : -1;
       V g[kBwdBatch];
       V ov[MAXR ? kBwdBatch : 1];
       float dg[kBwdBatch];
@@ -564,7 +567,7 @@ __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, in
                                            const int32_t* __restrict__ indptr, const float* __restrict__ go,
                                            int32_t go_stride, int32_t dim, int reduce, float* __restrict__ gh,
                                            int32_t gh_stride, int lpr_log2, DropArgs d, int first, int stride, DzOut z,
-                                           MaxIn mi, int parts) {
+                                           MaxIn mi, int parts, const Bnd& bnd) {
   constexpr int kHeavyThreads = T;
 
   using S = SV<VEC>;
@@ -585,7 +588,7 @@ __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, in
   first /= parts;
   stride /= parts;
   int n_heavy = heavy[0];
-  int32_t sr_next = first < heavy_cap ? heavy[1 + first] : 0;        // fetched with the count, not after it
+  int32_t sr_next = first < heavy_cap ? PG_IDX(heavy[1 + first], bnd, 1, PG_K_BWD_GATHER, 3) : 0;   // fetched with the count, not after it
   if (n_heavy > heavy_cap) n_heavy = heavy_cap;
   int lp_log2 = lpr_log2;                         // log2 of the lanes across THIS block's pieces
   for (int p = parts; p > 1; p >>= 1) --lp_log2;
@@ -596,7 +599,7 @@ __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, in
   const uint32_t step = DROP ? drop_step_of(d) : 0u;
   for (int hi = first; hi < n_heavy; hi += stride) {
     const int sr = sr_next;
-    if (hi + stride < n_heavy) sr_next = heavy[1 + hi + stride];
+    if (hi + stride < n_heavy) sr_next = PG_IDX(heavy[1 + hi + stride], bnd, 1, PG_K_BWD_GATHER, 4);
     const int32_t beg = tptr[sr], end = tptr[sr + 1];
     for (int c0 = 0; c0 < (parts > 1 ? 1 : pieces); c0 += lpr) {
       // (parts > 1: one pass, this lane's piece comes from the part's two runs of qn pieces)
@@ -613,7 +616,7 @@ __device__ __forceinline__ void heavy_rows(const int32_t* __restrict__ heavy, in
         const int n = end - base < kStage ? end - base : kStage;
         __syncthreads();
         for (int t = threadIdx.x; t < n; t += kHeavyThreads) {     // independent per t: all in flight together
-          const int32_t v = tdst[base + t];
+          const int32_t v = PG_IDX(tdst[base + t], bnd, 0, PG_K_BWD_GATHER, 2);
           s_v[t] = v;
           s_w[t] = (!MAXR && reduce == PG_REDUCE_MEAN) ? (float)(indptr[v + 1] - indptr[v]) : 1.f;
         }
@@ -733,7 +736,7 @@ int pg_spmm_fwd(const int32_t* indptr, const int32_t* src, const float* h, int32
   const int rows_per_block = 4 * (64 >> l2);
   const unsigned grid = (unsigned)ceil_div<int64_t>(n_dst, rows_per_block);
 #define PG_FWD(VEC, MAXR) \
-  hipLaunchKernelGGL((k_spmm_fwd<VEC, MAXR>), dim3(grid), dim3(256), 0, st, indptr, src, h, h_stride, n_dst, dim, reduce, out, out_stride, l2)
+  hipLaunchKernelGGL((k_spmm_fwd<VEC, MAXR>), dim3(grid), dim3(256), 0, st, indptr, src, h, h_stride, n_dst, dim, reduce, out, out_stride, l2, bnd(bounds_elems(h, 4) / h_stride))
   const bool mx = reduce == PG_REDUCE_MAX;
   if (vec == 4) { if (mx) PG_FWD(4, true); else PG_FWD(4, false); }
   else if (vec == 2) { if (mx) PG_FWD(2, true); else PG_FWD(2, false); }
@@ -760,10 +763,10 @@ int pg_spmm_fwd_drop(const int32_t* indptr, const int32_t* src, const float* h, 
   const dim3 grid((unsigned)ceil_div<int64_t>(n_dst, rows_per_block));
   if (reduce == PG_REDUCE_MAX)
     hipLaunchKernelGGL(k_spmm_fwd_drop<true>, grid, dim3(256), 0, as_stream(stream), indptr, src, h, h_stride, n_dst, dim,
-                       reduce, out, out_stride, l2, d);
+                       reduce, out, out_stride, l2, d, bnd(bounds_elems(h, 4) / h_stride));
   else
     hipLaunchKernelGGL(k_spmm_fwd_drop<false>, grid, dim3(256), 0, as_stream(stream), indptr, src, h, h_stride, n_dst, dim,
-                       reduce, out, out_stride, l2, d);
+                       reduce, out, out_stride, l2, d, bnd(bounds_elems(h, 4) / h_stride));
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
@@ -811,14 +814,18 @@ int pg_spmm_fwd_rows(const int32_t* indptr, const int32_t* src, const pg_row_sou
   }
   const unsigned grid = (unsigned)ceil_div<int64_t>(n_dst, 4);
   unsigned long long* pr = reinterpret_cast<unsigned long long*>(prof);
+  // (debug build: rows of the source layer / of the cache / of the staged block, from the registered extents of the buffers)
+  const Bnd rb = bnd(bounds_elems(rows->slots, 4), rows->cache ? bounds_elems(rows->cache, 4) / rows->cache_stride : 0,
+                     rows->staged ? bounds_elems(rows->staged, 4) / rows->staged_stride : 0);
+  (void)rb;
 #define PG_FWD_ROWS(DROP, TAIL, MAXR)                                                                                   \
   hipLaunchKernelGGL((k_spmm_fwd_rows<DROP, TAIL, MAXR>), dim3(grid), dim3(256), 0, as_stream(stream), indptr, src,       \
                      rows->slots, rows->edge_slots, rows->cache, rows->cache_stride, rows->staged, rows->staged_stride,   \
-                     n_dst, dim, reduce, out, out_stride, d, pr, (int)prof_ring)
+                     n_dst, dim, reduce, out, out_stride, d, pr, (int)prof_ring, rb)
 #define PG_FWD_ROWS_W(DROP, TAIL, M, MAXR)                                                                              \
   hipLaunchKernelGGL((k_spmm_fwd_rows_w<DROP, TAIL, M, MAXR>), dim3(grid), dim3(256), 0, as_stream(stream), indptr, src, \
                      rows->slots, rows->edge_slots, rows->cache, rows->cache_stride, rows->staged, rows->staged_stride, \
-                     n_dst, dim, reduce, out, out_stride, d, pr, (int)prof_ring, store_mode)
+                     n_dst, dim, reduce, out, out_stride, d, pr, (int)prof_ring, store_mode, rb)
 #define PG_FWD_ROWS_R(DROP, TAIL, MAXR)                               \
   do {                                                                \
     if (generic || dim4 > 1024) PG_FWD_ROWS(DROP, TAIL, MAXR);        \
@@ -938,7 +945,7 @@ static int bwd_gather_impl(const int32_t* tptr, const int32_t* tdst, const int32
 #define PG_BWD_GATHER(VEC, DROP, MAXR)                                                                                 \
   hipLaunchKernelGGL((k_spmm_bwd_gather<VEC, DROP, MAXR>), grid, dim3(256), 0, st, tptr, tdst, indptr, grad_out, go_stride, \
                      n_src, dim, reduce, grad_h, gh_stride, l2, hubs ? 1 : 0, d, heavy, heavy_cap, (int32_t)row_blocks, z, mi, \
-                     hub_parts)
+                     hub_parts, bnd(bounds_elems(grad_out, 4) / go_stride, n_src))
   if (mx) {
     if (v4 && dr) PG_BWD_GATHER(4, true, true);
     else if (v4) PG_BWD_GATHER(4, false, true);

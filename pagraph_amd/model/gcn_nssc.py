@@ -23,26 +23,6 @@ class NodeUpdate(nn.Module):
         self.concat = concat
         self.test = test
 
-    def _act_code(self):
-        """the dense kernels' epilogue for this NodeUpdate's activation, or None when it has to run as tensor ops"""
-        relu = self.activation in (torch.relu, torch.nn.functional.relu)
-        if self.concat:
-            return ops.ACT_CONCAT if relu else None
-        if self.activation is None:
-            return ops.ACT_NONE
-        return ops.ACT_RELU if relu else None
-
-    def aggregate_and_update(self, indptr, src, rows, n_dst, reduce, dropout):
-        """block_compute's reduce + this node UDF in one kernel when the block's source rows were never gathered
-        (ops.RowSource): ({'activation': y}, agg) or None (NodeFlow.block_compute then runs the two steps)."""
-        act = self._act_code()
-        if self.test or act is None:
-            return None
-        res = ops.aggregate_linear(indptr, src, rows, n_dst, self.linear, act, reduce, dropout)
-        if res is None:
-            return None
-        return {'activation': res[0]}, res[1]
-
     def forward(self, node):
         h = node.data['h']
         if self.test:

@@ -70,6 +70,8 @@ class RowSource:
         return ok
 
     def struct(self):
+        if L.BOUNDS:
+            L.note(self.slots), L.note(self.cache)
         return L.PgRowSource(self.slots.data_ptr(), self.cache.data_ptr() if self.cache is not None else 0,
                              self.staged_ptr, self.cache.stride(0) if self.cache is not None else self.dim,
                              self.staged_stride)
@@ -379,65 +381,6 @@ def _skinny_backward(ctx, gy, x, weight, y, need_x, need_w, need_b):
             gz = gy * (y > 0) if act == ACT_RELU else gy[:, :N] + gy[:, N:] * (y[:, :N] > 0)
         gx = gz @ weight
     return gx, gw, gb
-
-
-FUSE_AGG_LINEAR = os.environ.get("PG_FUSE_AGG_LINEAR", "0") != "0"
-
-
-class _AggLinear(torch.autograd.Function):
-    """act(aggregate(rows) @ W.T + b) in ONE kernel (pg_agg_linear_fwd): layer 0's block_compute — the reduce straight from
-    the feature cache (ops.RowSource) AND the NodeUpdate's dense step (gcn_nssc.py:66-74 + :14-24). agg and y are
-    bit-identical to aggregate_rows + _SkinnyLinear; the backward is _SkinnyLinear's over the saved agg (raw features carry
-    no gradient)."""
-
-    @staticmethod
-    def forward(ctx, indptr, src, rows, n_dst, reduce, drop, weight, bias, act):
-        lib = L.load()
-        N, K = weight.shape
-        pad = (K + 7) & ~7
-        agg = torch.empty((int(n_dst), pad), dtype=torch.float32, device=weight.device)[:, :K]
-        y = torch.empty((int(n_dst), 2 * N if act == ACT_CONCAT else N), dtype=torch.float32, device=weight.device)
-        rs = rows.struct()
-        d = drop.struct() if drop is not None else None
-        prof, ring, marker = (tuple(rows.prof) + (None,))[:3] if rows.prof is not None else (None, 0, None)
-        with torch.cuda.device(weight.device):
-            L.check(lib.pg_agg_linear_fwd(L.ptr(indptr), L.ptr(src), ctypes.byref(rs), int(n_dst), K, _REDUCE[reduce],
-                                          ctypes.byref(d) if d is not None else None, L.ptr(weight), L.ptr(bias), N, act,
-                                          L.ptr(agg), agg.stride(0), L.ptr(y), y.stride(0), L.ptr(prof), ring,
-                                          L.stream_ptr()), "pg_agg_linear_fwd")
-            if marker:
-                L.check(lib.pg_prof_stamp(L.ptr(prof), ring, L.ptr(drop.step) if drop is not None else None,
-                                          L.stream_ptr()), "pg_prof_stamp")
-        ctx.save_for_backward(agg, weight, y if act != ACT_NONE else None)
-        ctx.has_bias = bias is not None
-        ctx.bias_ref = bias
-        ctx.act = act
-        ctx.mark_non_differentiable(agg)
-        return y, agg
-
-    @staticmethod
-    def backward(ctx, gy, _gagg):
-        agg, weight, y = ctx.saved_tensors
-        _, gw, gb = _skinny_backward(ctx, gy, agg, weight, y, False, ctx.needs_input_grad[6], ctx.needs_input_grad[7])
-        return None, None, None, None, None, None, gw, gb, None
-
-
-def aggregate_linear(indptr, src, rows, n_dst, module, act=ACT_NONE, reduce="mean", dropout=None):
-    """(y, agg) = (act(module(aggregate(rows))), aggregate(rows)) through pg_agg_linear_fwd, or None when the pair does not fit
-    the fused kernel's envelope (the caller then runs block_aggregate + linear)"""
-    w, b = module.weight, module.bias
-    if not (FUSE_AGG_LINEAR and isinstance(rows, RowSource) and rows.aligned() and reduce in ("mean", "sum")
-            and w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.size(0) <= 64 and w.size(1) == rows.dim
-            and rows.dim >= 256 and (b is None or b.is_contiguous())):
-        return None
-    if dropout is not None and dropout.threshold == 0:
-        dropout = None
-    if _DEFER is not None and b is None:
-        _DEFER.saw_plain(w)                    # the deferring backward needs a bias (as ops.linear)
-    y, agg = _AggLinear.apply(indptr, src, rows, int(n_dst), reduce, dropout, w, b, act)
-    if act == ACT_CONCAT:
-        y._pg_concat_n = w.size(0)             # lets the consumer's backward produce this layer's dZ (see _DZ_STASH)
-    return y, agg
 
 
 def _bwd_w(lib, g, x, K, N, y, act, want_bias, weight=None, bias=None):

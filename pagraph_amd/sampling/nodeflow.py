@@ -157,16 +157,6 @@ class NodeFlow:
         src_field = message_func.src
         assert reduce_func.msg == message_func.out, "reduce must consume the message field"
         h = self.layers[i].data[src_field]
-        fused = getattr(apply_node_func, "aggregate_and_update", None)
-        if fused is not None and isinstance(h, RowSource):
-            # rows that were never gathered (layer 0 read straight from the feature cache) feeding a NodeUpdate whose first
-            # step is a skinny nn.Linear: reduce and node UDF in ONE kernel (ops.aggregate_linear); None = outside its envelope
-            res = fused(self.blk_indptr[i], self.blk_src[i], h, self.layer_size(i + 1), reduce_func.op, dropout)
-            if res is not None:
-                dst = self.layers[i + 1].data
-                dst[reduce_func.out] = res[1]
-                dst.update(res[0])
-                return
         agg = block_aggregate(self.blk_indptr[i], self.blk_src[i], h, self.layer_size(i + 1), reduce_func.op,
                               dropout=dropout, transpose=(self.blk_tptr[i], self.blk_tdst[i], self.blk_theavy[i]))
         dst = self.layers[i + 1].data

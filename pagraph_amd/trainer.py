@@ -193,6 +193,7 @@ def cycle_batches(sampler, steps):
 
 
 import os as _os_mod
+_PARTIAL_EARLY = bool(_os_mod.environ.get("PG_EARLY_AGG_PARTIAL"))    # diagnosis only (see GraphedTrainer._early_for)
 _LABELS_MEMSET = bool(_os_mod.environ.get("PG_LABELS_MEMSET"))     # A/B: the label lookup behind a zero fill (rounds 1-3)
 
 
@@ -337,6 +338,18 @@ class GraphedTrainer:
         # runs the model in between the values drift apart, which is harmless: a mask only has to differ from step to step.
         self.early_ordinal = 0           # the dropout step value of the last early aggregation (0: none yet)
         self._early_next = None
+        # Phase gate (round 5): an early aggregation is HBM-bound and so is the dense forward the compute stream starts every
+        # step with; beside each other both slow down (k_linear_fwd 23.5 instead of 16.8 us, and the backward kernels pay when
+        # the aggregation lands on them). The step's head launch therefore bumps a device counter when it STARTS (the dense
+        # forward has drained: pg_phase_arm), and an early aggregation waits on the load stream (pg_wait_phase: one wave,
+        # bounded) until the most recently issued step has got there — it then runs beside head / backward / optimiser, which
+        # are latency-bound and leave the memory system idle. A hint only: on a time-out the aggregation simply starts.
+        # PG_PHASE_GATE=0 switches it off; `phase_gate_us` is the bound of one wait.
+        self.phase_gate = _os.environ.get("PG_PHASE_GATE", "1") != "0"
+        self.phase_gate_us = int(_os.environ.get("PG_PHASE_GATE_US", "400"))
+        self._phase = torch.zeros(1, dtype=torch.int64, device=device)
+        self._phase_issued = 0           # steps issued whose head launch carries the signal
+        self._phase_ok = True            # False once a step body did not launch a head (the unfused path): no more waits
         self.keep_gc = False             # True: leave the interpreter's cyclic garbage collector on inside run_steps
         # True: prepare / compute run inside the reference's profiler ranges 'gpu-load' / 'gpu-compute' (pa_gcn.py:87,92);
         # off by default — a record_function costs the launch thread a few microseconds per step
@@ -345,7 +358,7 @@ class GraphedTrainer:
         # other streams — the sampler's ring, the cacher's cache / slot map / staging, the labels, the model and the optimiser
         # state — is recorded on those streams once, here (L.record_streams): dropped with steps in flight, their memory is
         # not reused before those steps have finished, with or without a finalizer.
-        L.record_streams([sampler.slots, sampler.seeds, cacher, self.labels, model, optimizer, self.flat],
+        L.record_streams([sampler.slots, sampler.seeds, cacher, self.labels, model, optimizer, self.flat, self._phase],
                          [self.load_stream, self.compute_stream, self.comm_stream])
 
     class _Slot:
@@ -495,10 +508,11 @@ class GraphedTrainer:
         m = self._bare_model()
         if mode in ("0", "false", "off") or plan is False or not virtual or not hasattr(m, "early_aggregations"):
             return None
-        if not self.cacher.full_cached:
-            # (a forced mode for partial caches existed for a day: the launch then waits for the batch's miss rows on the load
-            # stream — 0.32 instead of 0.15 ms/step — and the whole-suite runs that included its test met a rare
-            # hipErrorIllegalAddress right behind it; removed)
+        if not self.cacher.full_cached and not (mode == "1" and _PARTIAL_EARLY):
+            # (a forced mode for partial caches existed for a day in round 4: the launch then waits for the batch's miss rows on
+            # the load stream — 0.32 instead of 0.15 ms/step — and the whole-suite runs that included its test met a rare
+            # hipErrorIllegalAddress right behind it. Removed as a mode; PG_EARLY_AGG_PARTIAL=1 brings it back for the
+            # diagnosis of that fault only: tools/hunt_lifetimes.sh with the debug library, DESIGN section 3 'Lifetimes')
             return None
         out = []
         for blk, field, _red, _drop in m.early_aggregations(plan.num_layers, 0):
@@ -516,6 +530,8 @@ class GraphedTrainer:
                                            device=self.device) for blk, _f, rows in s.early}
             L.record_streams(s.agg0, [self.compute_stream])
             s.early_call = None
+        if not self.cacher.full_cached:
+            self.cacher.wait_misses(s.slot_index, ls)     # (PG_EARLY_AGG_PARTIAL only: the staged miss rows are read in place)
         if self._early_next is None or not self._prepared:
             # nothing of this trainer is prepared ahead: one read of the device counter (the pipeline is empty anyway)
             self.compute_stream.synchronize()
@@ -542,6 +558,9 @@ class GraphedTrainer:
                 launches.append((args, d))
                 keep.append((rs, nf.blk_indptr[blk], nf.blk_src[blk], prof, rows))
             call = s.early_call = (s.early, m.training, launches, keep)
+        if self.phase_gate and self._phase_ok and self._phase_issued > 0:
+            L.check(self._lib.pg_wait_phase(L.ptr(self._phase), self._phase_issued, self.phase_gate_us,
+                                            ctypes.c_void_p(ls.cuda_stream)), "pg_wait_phase")
         for args, d in call[2]:
             if d is not None:
                 d.step_value = self.early_ordinal
@@ -568,12 +587,14 @@ class GraphedTrainer:
         if self._gseed is None:                 # persistent d loss / d loss: no ones_like fill (nor a divide) per step
             self._gseed = torch.full((), 1.0 / self.world, dtype=torch.float32, device=self.device)
         loss = None
+        self._arm_phase()
         if self.fuse_head and isinstance(self.loss_fcn, ops.CrossEntropyLoss) and hasattr(self.model, 'forward_loss'):
             # output layer + loss + their gradients in one kernel (GCN); None = not applicable
             loss = self.model.forward_loss(s.nf, s.label, s.n_valid, self._gseed, self.loss_fcn.ignore_index)
         if loss is None:
             pred = self.model(s.nf)
             loss = self.loss_fcn(pred, s.label)
+        self._disarm_phase()
         if self.world > 1:
             self.flat.zero_()
             loss.backward(self._gseed)          # loss / world: the SUM all-reduce then yields DDP's mean gradient
@@ -589,6 +610,20 @@ class GraphedTrainer:
             self.optimizer.step()
         s.nf._pre_agg = None                    # consumed: an eager forward on this NodeFlow later aggregates for itself
         return loss
+
+    def _arm_phase(self):
+        """the step's head launch (pg_gcn_head / pg_sage_head, issued or captured by the forward that follows) bumps the phase
+        counter when it starts"""
+        if self.phase_gate and self._phase_ok:
+            L.check(self._lib.pg_phase_arm(L.ptr(self._phase), None), "pg_phase_arm")
+
+    def _disarm_phase(self):
+        if self.phase_gate and self._phase_ok:
+            pending = L.c_i32(0)
+            L.check(self._lib.pg_phase_arm(None, ctypes.byref(pending)), "pg_phase_arm")
+            if pending.value:
+                # this forward launched no fused head (outside its envelope): nobody bumps the counter, so nobody waits for it
+                self._phase_ok = False
 
     def _can_defer_partials(self):
         from .optim import Adam
@@ -621,11 +656,13 @@ class GraphedTrainer:
             if self._gseed is None:
                 self._gseed = torch.full((), 1.0, dtype=torch.float32, device=self.device)
             loss = None
+            self._arm_phase()
             if self.fuse_head and isinstance(self.loss_fcn, ops.CrossEntropyLoss) and hasattr(self.model, 'forward_loss'):
                 loss = self.model.forward_loss(s.nf, s.label, s.n_valid, self._gseed, self.loss_fcn.ignore_index)
             if loss is None:
                 pred = self.model(s.nf)
                 loss = self.loss_fcn(pred, s.label)
+            self._disarm_phase()
             loss.backward(self._gseed)
         self.optimizer.step(deferred=reg, bump=bump)
         s.nf._pre_agg = None
@@ -783,6 +820,8 @@ class GraphedTrainer:
         # this step had finished (measured: the sampler started only when the current graph ended). Call
         # synchronize() (or compute_stream.synchronize()) before reading it.
         self.steps_done += 1
+        if self._phase_ok:
+            self._phase_issued += 1      # (every step body, eager or replayed, carries one head launch with the signal)
         # the token of this step's buffers: the optimiser's launch count with this step's launch in. A step that enqueued
         # no optimiser launch at all (every gradient None) has no "last launch" to stand for it: None = release by event.
         self._last_token = None

@@ -25,6 +25,7 @@ _FAULT_LOG = None
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "bounds_selftest: provokes the debug library's bounds record on purpose")
 
 
 def pytest_sessionstart(session):
@@ -84,6 +85,25 @@ def pytest_runtest_call(item):
                     _FAULT_LOG.flush()
                 except (OSError, ValueError):
                     pass
+
+
+@pytest.fixture(autouse=True)
+def _bounds_after_each_test(request):
+    """PG_BOUNDS=1 (the debug library that bounds-checks ids, include/pagraph_hip.h pg_bounds_*): after every GPU test the
+    library is asked whether a kernel met an out-of-range index; the test then FAILS with the kernel, the call site, the
+    value and the bound — instead of a hipErrorIllegalAddress somewhere behind it (tools/hunt_lifetimes.sh)."""
+    yield
+    if os.environ.get("PG_BOUNDS") in (None, "", "0") or request.node.get_closest_marker("gpu") is None:
+        return
+    from pagraph_amd import _lib
+    if _lib._lib is None or not _lib.BOUNDS or request.node.get_closest_marker("bounds_selftest") is not None:
+        return
+    rec = _lib.bounds_report(reset=True)
+    if rec is not None:
+        msg = f"\n[bounds] {request.node.nodeid}: {rec}\n"
+        sys.stderr.write(msg)
+        sys.stderr.flush()
+        pytest.fail(f"PG_BOUNDS: a kernel followed an out-of-range index: {rec}", pytrace=False)
 
 
 @pytest.fixture(scope="session")

@@ -765,10 +765,19 @@ def test_early_layer0_aggregation_matches_the_in_step_one(dev, hiplib, ratio, mi
         tr.run_steps(cycle_batches(smp, steps), steps)
         tr.synchronize()
         used = sum(1 for s_ in tr.slots.values() if s_.early is not None)
+        # the phase signal (round 5): every step's head launch — eager, captured or replayed — bumped the device counter once,
+        # which is what the early aggregations of later batches wait for on the load stream (pg_phase_arm / pg_wait_phase)
+        assert tr.phase_gate and tr._phase_ok and int(tr._phase.item()) == tr._phase_issued == steps
         return torch.stack(out).cpu().numpy(), tr.early_ordinal, used
 
     base, n0, used0 = run("0", 0.0)
     assert n0 == 0 and used0 == 0
+    if ratio < 1.0 and os.environ.get("PG_EARLY_AGG_PARTIAL"):
+        # diagnosis only (tools/hunt_lifetimes.sh): round 4's forced mode for partial caches, behind whose test the rare
+        # illegal address of whole-suite runs appeared
+        got, n1, used1 = run("1", 0.0)
+        assert n1 >= 24 and used1 > 0 and np.array_equal(got, base)
+        return
     if ratio < 1.0:
         for mode in ("auto", "1"):                                 # a partial cache keeps the aggregation in the step
             got, n1, used1 = run(mode, 0.0)
@@ -1835,6 +1844,7 @@ def _fused_gather_aggregate_case(dev, hiplib, oracle, ratio, p_drop, reduce, Fd)
     sl = slots.cpu().numpy()
     assert np.array_equal(np.sort(-sl[sl <= -3] - 3), np.arange(m)) and np.all(sl[-7:] == -2)
     staged = torch.from_numpy(table[mfull[:m].cpu().numpy()]).to(dev) if m else None       # the miss path's copy
+    [L.note(t_) for t_ in (slots, cache, staged if m else None)]       # (debug build: the buffers' extents bound the indices)
     rs = L.PgRowSource(slots.data_ptr(), cache.data_ptr() if cache is not None else 0, staged.data_ptr() if m else 0,
                        cache.stride(0) if cache is not None else Fd, Fd)
     out = torch.empty((n_dst, Fd), dtype=torch.float32, device=dev)
@@ -1863,25 +1873,17 @@ def _fused_gather_aggregate_case(dev, hiplib, oracle, ratio, p_drop, reduce, Fd)
         assert torch.allclose(y8, out[:64] @ w8.t(), rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("Fd,N,act,reduce,p_drop,max_deg,use_es", [
-    (600, 32, 2, "mean", 0.2, 2, False),       # the benchmark's layer 0: fan-out 2, skip-concat, dropout
-    (600, 32, 2, "mean", 0.2, 2, True),        # + pre-composed edge slots
-    (602, 32, 2, "mean", 0.3, 2, False),       # Reddit's ragged width
-    (600, 64, 1, "sum", 0.0, 2, False),        # two column tiles (the second recomputes the aggregation), no dropout, sum
-    (600, 16, 0, "mean", 0.5, 7, False),       # destinations with more in-edges than the kernel keeps addresses for
-    (256, 41, 2, "mean", 0.1, 3, False),       # the narrowest K the 8-wave split serves, ragged N
-    (1000, 60, 1, "mean", 0.2, 150, False)])   # a hub destination
-def test_fused_aggregate_and_dense_step_is_bit_identical_to_the_pair(dev, hiplib, Fd, N, act, reduce, p_drop, max_deg, use_es):
-    """pg_agg_linear_fwd (layer 0's reduce AND its NodeUpdate in one kernel) == pg_spmm_fwd_rows + pg_linear_fwd, bit for bit:
-    the aggregated rows it writes and the activation output — hits, staged misses, padding sources, empty destinations,
-    a row count that is not a multiple of the tile."""
+@pytest.mark.parametrize("Fd,reduce,p_drop,max_deg", [(600, "mean", 0.2, 2), (602, "mean", 0.3, 2), (600, "sum", 0.0, 7),
+                                                     (1000, "mean", 0.2, 150)])
+def test_fused_gather_aggregate_with_composed_edge_slots(dev, hiplib, Fd, reduce, p_drop, max_deg):
+    """pg_row_source_t.edge_slots (slots[src[e]] per edge, composed beforehand by pg_compose_edge_slots off the consumer's
+    stream: one dependent index load less in pg_spmm_fwd_rows) gives the same rows, bit for bit, as the look-up inside the
+    kernel — hits, staged misses, padding sources, empty destinations, a hub destination."""
     from pagraph_amd import _lib as L
-    rng = np.random.default_rng(Fd + N + max_deg)
+    rng = np.random.default_rng(Fd + max_deg)
     n_cache, n_src, n_dst = 3000, 2600, 1191
     cs = (Fd + 7) & ~7
     fused = torch.from_numpy(rng.random((n_cache, cs), dtype=np.float32)).to(dev)         # fused cache rows [F | norm | pad]
-    if cs > Fd:
-        fused[:, Fd:] = float("nan")                                                      # never summed
     n_miss = 500
     staged_stride = (Fd + 3) & ~3
     staged = torch.from_numpy(rng.random((n_miss, staged_stride), dtype=np.float32)).to(dev)
@@ -1897,41 +1899,25 @@ def test_fused_aggregate_and_dense_step_is_bit_identical_to_the_pair(dev, hiplib
     indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
     src = rng.integers(0, n_src, int(indptr[-1])).astype(np.int32)
     d_indptr, d_src, d_slots = (torch.from_numpy(a).to(dev) for a in (indptr, src, slots))
-    es = torch.from_numpy(slots[src]).to(dev) if use_es else None
-    rs = L.PgRowSource(d_slots.data_ptr(), fused.data_ptr(), staged.data_ptr(), cs, staged_stride, es.data_ptr() if use_es else 0)
-    W = torch.from_numpy((rng.random((N, Fd), dtype=np.float32) - 0.5)).to(dev)
-    bias = torch.from_numpy(rng.random(N, dtype=np.float32)).to(dev)
-    stepd = torch.tensor([11], dtype=torch.int64, device=dev)
-    thr = min(65535, int(round(p_drop * 65536)))
-    drop = L.PgDropout(thr, 4, 0xABCDEF12345, L.ptr(stepd))
-    dp = ctypes.byref(drop)
-    red = {"mean": 0, "sum": 1}[reduce]
     sp = L.stream_ptr()
+    es = torch.empty(len(src), dtype=torch.int32, device=dev)
+    L.check(hiplib.pg_compose_edge_slots(L.ptr(d_src), len(src), L.ptr(d_slots), n_src, L.ptr(es), sp))
+    assert np.array_equal(es.cpu().numpy(), slots[src])
+    [L.note(t_) for t_ in (d_slots, fused, staged)]
+    stepd = torch.tensor([11], dtype=torch.int64, device=dev)
+    drop = L.PgDropout(min(65535, int(round(p_drop * 65536))), 4, 0xABCDEF12345, L.ptr(stepd))
+    red = {"mean": 0, "sum": 1}[reduce]
     pad = (Fd + 7) & ~7
-    ycols = 2 * N if act == 2 else N
-    # the pair
-    agg_ref = torch.zeros((n_dst, pad), device=dev)
-    y_ref = torch.empty((n_dst, ycols), device=dev)
-    L.check(hiplib.pg_spmm_fwd_rows(L.ptr(d_indptr), L.ptr(d_src), ctypes.byref(rs), n_dst, Fd, red, L.ptr(agg_ref), pad, dp,
-                                    None, 0, sp))
-    L.check(hiplib.pg_linear_fwd(L.ptr(agg_ref), pad, L.ptr(W), L.ptr(bias), L.ptr(y_ref), ycols, n_dst, Fd, N, act, sp))
-    # the fused kernel, with its self-timing ring
-    agg = torch.zeros((n_dst, pad), device=dev)
-    y = torch.empty((n_dst, ycols), device=dev)
-    prof = torch.zeros(L.PG_PROF_WORDS * 4, dtype=torch.int64, device=dev)
-    L.check(hiplib.pg_agg_linear_fwd(L.ptr(d_indptr), L.ptr(d_src), ctypes.byref(rs), n_dst, Fd, red, dp, L.ptr(W), L.ptr(bias),
-                                     N, act, L.ptr(agg), pad, L.ptr(y), ycols, L.ptr(prof), 4, sp))
+    outs = []
+    for use_es in (False, True):
+        rs = L.PgRowSource(d_slots.data_ptr(), fused.data_ptr(), staged.data_ptr(), cs, staged_stride, es.data_ptr() if use_es else 0)
+        out = torch.zeros((n_dst, pad), device=dev)
+        L.check(hiplib.pg_spmm_fwd_rows(L.ptr(d_indptr), L.ptr(d_src), ctypes.byref(rs), n_dst, Fd, red, L.ptr(out), pad,
+                                        ctypes.byref(drop), None, 0, sp))
+        outs.append(out)
     torch.cuda.synchronize()
     k4 = (Fd + 3) & ~3
-    assert torch.equal(agg[:, :k4], agg_ref[:, :k4])
-    assert torch.equal(y, y_ref)
-    e = prof.view(4, L.PG_PROF_WORDS)[11 % 4].tolist()
-    assert e[0] > 0 and e[2] == int(indptr[-1]) and max(e[L.PG_PROF_END0::L.PG_PROF_SHARD_STRIDE]) > e[0]
-    # envelope: the max reducer and narrow rows are the caller's to run as a pair
-    assert hiplib.pg_agg_linear_fwd(L.ptr(d_indptr), L.ptr(d_src), ctypes.byref(rs), n_dst, Fd, 2, dp, L.ptr(W), L.ptr(bias),
-                                    N, act, L.ptr(agg), pad, L.ptr(y), ycols, None, 0, sp) == -4
-    assert hiplib.pg_agg_linear_fwd(L.ptr(d_indptr), L.ptr(d_src), ctypes.byref(rs), n_dst, 128, red, dp, L.ptr(W), L.ptr(bias),
-                                    N, act, L.ptr(agg), pad, L.ptr(y), ycols, None, 0, sp) == -4
+    assert torch.equal(outs[0][:, :k4], outs[1][:, :k4]) and float(outs[0].abs().sum()) > 0
 
 
 @pytest.mark.parametrize("arch", ["gcn", "sage"])
@@ -2032,6 +2018,7 @@ def test_dense_step_from_row_source_is_bit_identical(dev, hiplib, n, K, N, K2, a
         X2 = torch.from_numpy(rng.standard_normal((n, (K2 + 3) & ~3), dtype=np.float32)).to(dev)
         W2 = torch.from_numpy(rng.standard_normal((N, K2), dtype=np.float32) * 0.05).to(dev)
         b2 = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(dev)
+    [L.note(t_) for t_ in (sl, cache, staged)]
     rs = L.PgRowSource(sl.data_ptr(), cache.data_ptr(), staged.data_ptr(), cs, ss)
     yc = 2 * N if act == 2 else N
     Ya = torch.empty((n, yc), device=dev); Yb = torch.empty((n, yc), device=dev)
@@ -2501,6 +2488,7 @@ def test_fused_gather_aggregate_ragged_width_vs_oracle(dev, hiplib, oracle, Fd, 
     fused = torch.full((V, stride), float("nan"), device=dev)          # [features | other field / padding = NaN]
     fused[:, :Fd] = torch.from_numpy(table).to(dev)
     slots = torch.from_numpy(ids.astype(np.int32)).to(dev)              # full cache: slot = id
+    [L.note(t_) for t_ in (slots, fused)]
     rs = L.PgRowSource(slots.data_ptr(), fused.data_ptr(), 0, stride, Fd)
     out = torch.full((n_dst, stride), 7.0, device=dev)
     stepd = torch.tensor([step], dtype=torch.int64, device=dev)

@@ -303,7 +303,7 @@ def test_bench_short_window_reports_steady_state(dev, hiplib):
     import json
     import subprocess
     import sys
-    flags = ["--skip-microbench", "--skip-cpu-baseline", "--skip-opt-hit", "--skip-reference-equivalent"]
+    flags = ["--skip-microbench", "--skip-cpu-baseline", "--skip-opt-hit", "--skip-reference-equivalent", "--no-configs"]
     def run(steps):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(steps),
                             "--warmup", "5"] + flags, capture_output=True, text=True, timeout=280)
@@ -326,3 +326,22 @@ def test_bench_short_window_reports_steady_state(dev, hiplib):
     assert short["warmup"] == 5 and short["steps"] == 20 and not short["misses_timed_out"]
     assert short["ms_per_step"] <= 1.5 * ref, (short["ms_per_step"], ref)
     assert short["miss_queue"]["sdma_engine_mask"] != 0          # the direct-SDMA copy path is the one that ran
+
+
+@pytest.mark.bounds_selftest
+def test_bounds_checking_debug_build_names_the_kernel(dev, hiplib):
+    """SURVEY 8b 'debug build bounds-checks ids': with PG_BOUNDS=1 the library is libpagraph_hip_bounds.so; a clean pipeline
+    leaves no record, and an id beyond the partition / a slot beyond the cache / an edge beyond the source layer are named
+    (kernel, site, value, bound) instead of faulting somewhere behind the kernel that followed them (tools/bounds_selftest.py)"""
+    import json
+    import subprocess
+    import sys
+    from pagraph_amd import _lib
+    if not os.path.exists(_lib.BOUNDS_LIB_PATH):
+        pytest.skip("libpagraph_hip_bounds.so is not built (make -C pagraph_amd/csrc bounds)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bounds_selftest.py")], capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, PG_BOUNDS="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["clean_pipeline"] is None and d["id_beyond_partition"]["unit"] == "pg_gather.hip"
+    assert d["slot_beyond_cache"]["unit"] == "pg_spmm.hip" and d["edge_beyond_layer"]["site"] == 1

@@ -7,8 +7,6 @@ mkdir -p "$OUT"
 SKIP="--skip-cpu-baseline --skip-opt-hit --skip-reference-equivalent --skip-microbench"
 timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "fused_aggregate_and_dense or presample or fused_gather_aggregate" 2>&1 | tail -5 > "$OUT/pytest_subset.txt"
 cat "$OUT/pytest_subset.txt"
-timeout 300 python tools/exp_agg_dense.py 2>&1 | grep -v amdgpu.ids | tee "$OUT/agg_dense_alone.txt"
-timeout 300 python tools/exp_agg_dense.py 12000 2>&1 | grep -v amdgpu.ids | tee -a "$OUT/agg_dense_alone.txt"
 for fuse in 0 1; do
   PG_FUSE_AGG_LINEAR=$fuse timeout 400 python bench.py $SKIP --cache-ratio 1.0 > "$OUT/bench_full_cache_fuse$fuse.json" 2>/dev/null
   PG_FUSE_AGG_LINEAR=$fuse timeout 400 python bench.py $SKIP > "$OUT/bench_fuse$fuse.json" 2>/dev/null

@@ -6,7 +6,7 @@ with the trace's End - Start?   (VERDICT r03 "next round" #1)
 
 usage: join_stamps_trace.py <stamps.npy> <kernel_trace.csv> [out.csv]
 
-Alignment: the i-th dispatch of k_spmm_fwd_rows* / k_agg_linear_fwd in the trace is forward number i of the process (every forward bumps the
+Alignment: the i-th dispatch of k_spmm_fwd_rows* in the trace is forward number i of the process (every forward bumps the
 dropout step the stamp ring is indexed by); the stamped steps are the LAST rows of the dump, so the tool tries the offsets near
 "trace dispatches - dumped steps" and keeps the one where the stamp durations correlate best with the trace durations.
 The two clocks differ by an unknown constant; it is estimated from the marker kernel (one thread: its stamp is taken within a
@@ -21,7 +21,7 @@ has_marker = st.shape[1] >= 6 and bool((st[:, 5] > 0).mean() > 0.5)
 has_succ = st.shape[1] >= 5 and bool((st[:, 4] > 0).mean() > 0.5)
 rows = list(csv.DictReader(open(sys.argv[2])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-fused = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if "k_spmm_fwd_rows" in r["Kernel_Name"] or "k_agg_linear_fwd" in r["Kernel_Name"]]
+fused = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if "k_spmm_fwd_rows" in r["Kernel_Name"]]
 mark = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if "k_prof_stamp" in r["Kernel_Name"]]
 fused = np.asarray(fused, dtype=np.int64)
 mark = np.asarray(mark, dtype=np.int64) if mark else None

@@ -22,8 +22,8 @@ for k, v in table.items():
     print(f"{k[:70]:70s} n={v['launches']:5d}  fetch {v['fetch_bytes_corrected_per_launch']/1e6:9.3f} MB  write {v['write_bytes_per_launch']/1e6:9.3f} MB  "
           f"{v['avg_ns_under_pmc']/1e3:8.1f} us")
 for k, v in table.items():
-    if "k_spmm_fwd_rows" in k or "k_agg_linear_fwd" in k:
-        short = "agg_linear_fwd" if "k_agg_linear_fwd" in k else "spmm_fwd_rows"
+    if "k_spmm_fwd_rows" in k:
+        short = "spmm_fwd_rows"
         rec = {"kernel": k.split("(")[0] + " in-loop (eager loop, layer 0 aggregated straight from the cache + staged miss rows)",
                "launches": v["launches"], "fetch_bytes_corrected_per_launch": v["fetch_bytes_corrected_per_launch"],
                "write_bytes_per_launch": v["write_bytes_per_launch"], "hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
