@@ -704,6 +704,14 @@ def run():
     g_full = DeviceGraph.from_csc(indptr, indices, V)
     in_deg = (indptr[1:] - indptr[:-1]).float()
 
+    # what dg.py --num-hops 2 (README.md:117: the value for a 2-layer model) would have to walk on this graph: the two-hop
+    # in-neighbourhood of every train vertex = sum(deg^2) adjacency entries, consumed by ONE sequential committer (every
+    # assignment reads r_vnum as the previous one left it, dg.py:71-83). Measured rate of pg_dg_partition_mt: 4.7e10 entries in
+    # 68 s on the 10M / 100M graph (tools/exp_dg_hops2.py). Reported so that config 5's `dg_hops` is an informed choice.
+    deg_d = (indptr[1:] - indptr[:-1]).double()
+    sum_deg_sq = float((deg_d * deg_d).sum().item())
+    dg_hops2_est_s = sum_deg_sq * (68.0 / 4.7e10)
+    del deg_d
     # ---- partition ------------------------------------------------------------------------
     t0 = time.time()
     if world == 1:
@@ -1292,6 +1300,8 @@ def run():
                        "miss_mode": args.miss_mode, "miss_wait": "host" if cacher.host_wait else "device",
                        "miss_mode_probe": mode_probe, "overlap": not args.no_overlap,
                        "partition_vertices": Vs, "dg_hops": args.dg_hops if world > 1 else None,
+                       "dg_hops2_cost": {"sum_deg_squared": sum_deg_sq, "estimated_seconds_one_committer": dg_hops2_est_s,
+                                         "basis": "4.7e10 adjacency entries in 68 s (10M/100M graph, 16 host threads)"},
                        "hip_graph_step": use_graph,
                        # block 0's aggregation launched ahead of its step on the load stream (GraphedTrainer.early_aggregate:
                        # 'auto' = when the whole table is cached)

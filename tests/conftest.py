@@ -93,6 +93,12 @@ def _bounds_after_each_test(request):
     library is asked whether a kernel met an out-of-range index; the test then FAILS with the kernel, the call site, the
     value and the bound — instead of a hipErrorIllegalAddress somewhere behind it (tools/hunt_lifetimes.sh)."""
     yield
+    if os.environ.get("PG_HUNT_SYNC") and request.node.get_closest_marker("gpu") is not None:
+        # tools/hunt_lifetimes.sh: a device-wide wait behind every test, so that an asynchronous fault is reported in the
+        # test whose work (or whose teardown) caused it, not at the first synchronising call of a later one
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
     if os.environ.get("PG_BOUNDS") in (None, "", "0") or request.node.get_closest_marker("gpu") is None:
         return
     from pagraph_amd import _lib
