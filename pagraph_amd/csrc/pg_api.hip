@@ -19,7 +19,6 @@
 namespace pg {
 thread_local int g_last_hip_error = 0;
 thread_local ProfSucc g_prof_succ;
-thread_local PhaseSig g_phase_sig;
 
 #ifdef PG_BOUNDS
 namespace {

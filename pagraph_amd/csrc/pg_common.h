@@ -55,28 +55,6 @@ inline ProfSucc take_prof_succ() {
   g_prof_succ = ProfSucc{};
   return p;
 }
-// ---- phase signal (round 5): "the dense forward of this step has finished" --------------------------------------------------
-// A trainer arms this thread-local record before it issues a step's body (pg_phase_arm); the step's head launch
-// (pg_gcn_head / pg_sage_head) takes it, and the kernel's first thread adds 1 to the word when it STARTS — in stream order
-// that is the moment the dense forward before it has drained. pg_wait_phase parks a one-wave kernel on ANOTHER stream until
-// the word has reached a target (bounded: it is a scheduling hint, never a correctness condition). The training pipeline
-// uses the pair to start a later batch's early aggregation (HBM-bound, on the load stream) when the compute stream enters
-// its latency-bound tail (head, backward aggregation, weight gradient, optimiser) instead of beside the HBM-bound dense
-// forward (DESIGN section 6 "early aggregation": 23.5 vs 16.8 us for k_linear_fwd).
-struct PhaseSig {
-  unsigned long long* word = nullptr;
-};
-extern thread_local PhaseSig g_phase_sig;
-inline PhaseSig take_phase_sig() {
-  PhaseSig p = g_phase_sig;
-  g_phase_sig = PhaseSig{};
-  return p;
-}
-__device__ __forceinline__ void phase_signal(const PhaseSig& p) {
-  if (p.word && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
-    __hip_atomic_fetch_add(p.word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 __device__ __forceinline__ void prof_succ_stamp(const ProfSucc& p) {
   if (p.ring && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
     p.ring[(size_t)((uint32_t)(p.step ? *p.step : 0) % (uint32_t)p.ring_len) * PG_PROF_WORDS + 1] = wall_clock64();

@@ -63,10 +63,8 @@ __global__ __launch_bounds__(256) void k_gcn_head(const int32_t* __restrict__ in
                                                   const float* __restrict__ grad_scale_dev, HeadDrop d, int reduce,
                                                   int64_t n_dst, float* __restrict__ logits,
                                                   float* __restrict__ dagg, float* __restrict__ part, int dagg_per_edge,
-                                                  int row_len, const ProfSucc succ, const HeadSelf self, const Bnd bnd,
-                                                  const PhaseSig phase) {
+                                                  int row_len, const ProfSucc succ, const HeadSelf self, const Bnd bnd) {
   // PG_BOUNDS: [0] rows of h (a block edge is followed into the source layer's activations)
-  phase_signal(phase);       // "the dense forward before this launch has drained" (pg_phase_arm / pg_wait_phase)
   prof_succ_stamp(succ);     // a profiled predecessor's "my successor started" stamp (pg_common.h)
   const int Ks = self.Ks, Kt = K + Ks;          // input columns: [0, K) aggregated, [K, Kt) the destination's own row
   __shared__ __attribute__((aligned(16))) float s_rows[4][kHeadRows][kHeadMax];   // the waves' aggregated rows
@@ -377,9 +375,8 @@ static int head_impl(const int32_t* indptr, const int32_t* src, const float* h, 
   hipLaunchKernelGGL(k_gcn_head<R>, dim3((unsigned)blocks), dim3(256), 0, st, indptr, src, h, h_stride, K, W, bias, C, \
                      labels, ignore_index, n_valid_dev, grad_scale_dev, d, reduce, n_dst, logits, dagg, partials,          \
                      (flags & PG_HEAD_DAGG_PER_EDGE) ? 1 : 0, (int)pg_gcn_head_row_len(Kt, C), succ, self,                \
-                     bnd(bounds_elems(h, 4) / h_stride), phase)
+                     bnd(bounds_elems(h, 4) / h_stride))
   const ProfSucc succ = take_prof_succ();
-  const PhaseSig phase = take_phase_sig();
   if (rpw == 1) PG_HEAD(1);
   else if (rpw == 2) PG_HEAD(2);
   else if (rpw == 4) PG_HEAD(4);
@@ -414,28 +411,5 @@ int pg_sage_head(const int32_t* indptr, const int32_t* src, const float* h, int3
                    n_dst, logits, dagg, partials, dW_both, db_loss, flags, self, stream);
 }
 
-
-int pg_phase_arm(uint64_t* word, int32_t* was_pending) {
-  if (was_pending) *was_pending = g_phase_sig.word != nullptr;
-  g_phase_sig.word = reinterpret_cast<unsigned long long*>(word);
-  return PG_OK;
-}
-
-__global__ void k_wait_phase(const unsigned long long* __restrict__ word, unsigned long long target, unsigned long long ticks) {
-  if (threadIdx.x != 0) return;
-  const unsigned long long t0 = wall_clock64();
-  while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-    if (wall_clock64() - t0 > ticks) break;        // a hint, not a condition: never hold the stream for long
-    __builtin_amdgcn_s_sleep(8);
-  }
-}
-
-int pg_wait_phase(const uint64_t* word, uint64_t target, uint32_t timeout_us, pg_stream_t stream) {
-  if (!word) return PG_ERR_INVALID;
-  hipLaunchKernelGGL(k_wait_phase, dim3(1), dim3(64), 0, as_stream(stream), reinterpret_cast<const unsigned long long*>(word),
-                     (unsigned long long)target, (unsigned long long)timeout_us * 100ull);
-  PG_LAUNCH_CHECK();
-  return PG_OK;
-}
 
 }  // extern "C"

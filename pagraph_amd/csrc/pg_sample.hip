@@ -390,7 +390,6 @@ struct SampleGArgs {
   int32_t k, g_shift, iters;   // group of 1 << g_shift lanes per destination, `iters` destinations per group
   uint32_t layer, epoch, batch, seed_lo, seed_hi;
   unsigned long long* bitmap;
-  uint8_t* dirty;              // one byte per kWordsPerBlock bitmap words: set when a word of the unit turns non-zero (see k_bm_rank)
   int32_t* blk_indptr;
   int32_t* blk_src;            // picks in CSR position, as vertex ids until X relabels them
   int32_t* ecnt;               // edges of the block
@@ -480,8 +479,7 @@ __device__ __forceinline__ void sample_body(const SampleGArgs& a, const int blk,
     if (gl == 0 && p == a.cap_rows) *a.ecnt = pos;
     if (u >= 0) {
       a.blk_src[pos + gl] = u;
-      // the first mark in a word also flags the word's 1024-word unit (a plain store of 1: every racer writes the same byte)
-      if (atomicOr(&a.bitmap[u >> 6], 1ull << (u & 63)) == 0ull) a.dirty[u >> 16] = 1;
+      atomicOr(&a.bitmap[u >> 6], 1ull << (u & 63));
     }
     if (a.top_ids && gl == 0) {
       if (p < n) a.top_ids[p] = v;
@@ -560,11 +558,6 @@ struct RankArgs {
   const int32_t* clear_cnt;
   int64_t clear_cap;
   int64_t n_words;
-  // Round 5: S flags every 1024-word unit it marks a first bit in; a unit that is not flagged holds no bit of this layer, so
-  // the block neither loads its words nor writes their ranks (nobody reads the rank of an empty word) and counts 0 for it. At
-  // 10^8 vertices a layer of <= 24 K ids dirties a few hundred of the bitmap's 1 526 units — the launch used to read all
-  // 12.5 MB twice and write 6 MB of ranks per layer. The block that owns a unit clears its flag once it has read it.
-  uint8_t* dirty;                 // [ceil(n_words / 1024)] flags of `bm` (NULL: every unit is read)
   int32_t m;                      // the block covers 1024 * m words, 4 per thread and round
   unsigned long long* agg;
   uint32_t tag;
@@ -590,29 +583,17 @@ __global__ __launch_bounds__(256) void k_bm_rank(const RankArgs a) {
     for (int64_t i = (int64_t)blk * blockDim.x + tid; i < n; i += (int64_t)gridDim.x * blockDim.x)
       a.other_bm[PG_IDX(a.clear_ids[i], a.bnd, 0, PG_K_BM_RANK, 1) >> 6] = 0ull;
   }
-  unsigned long long live = ~0ull;        // bit r: round r's unit is flagged (block-uniform)
-  const bool flagged = a.dirty != nullptr && a.m <= 64;
-  if (flagged) {
-    live = 0ull;
-    const int64_t n_units = (a.n_words + kWordsPerBlock - 1) / kWordsPerBlock;
-    for (int r = 0; r < a.m; ++r) {
-      const int64_t unit = (int64_t)blk * a.m + r;
-      if (unit < n_units && a.dirty[unit]) live |= 1ull << r;
-    }
-  }
   for (int r = 0; r < a.m; ++r) {
     const int64_t w0 = wblk + (int64_t)r * kWordsPerBlock + tid * 4;
-    const bool on = (live >> (r & 63)) & 1ull;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      w[i] = (on && w0 + i < a.n_words) ? a.bm[w0 + i] : 0ull;
+      w[i] = (w0 + i < a.n_words) ? a.bm[w0 + i] : 0ull;
       mine += __popcll(w[i]);
       if (clear_all && w0 + i < a.n_words) a.other_bm[w0 + i] = 0ull;
     }
   }
   int tot;
-  (void)block_excl_scan(mine, lds, &tot);       // (a block barrier: every thread has read the flags)
-  if (flagged && tid < a.m && ((live >> tid) & 1ull)) a.dirty[(int64_t)blk * a.m + tid] = 0;
+  (void)block_excl_scan(mine, lds, &tot);
   if (tid == 0)
     __hip_atomic_store(a.agg + blk, ((unsigned long long)a.tag << 32) | (uint32_t)tot, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
@@ -624,7 +605,6 @@ __global__ __launch_bounds__(256) void k_bm_rank(const RankArgs a) {
   int carry = lds[16];
   if (blk == (int)gridDim.x - 1 && tid == 0) *a.count_out = carry + tot;
   for (int r = 0; r < a.m; ++r) {
-    if (!((live >> (r & 63)) & 1ull)) continue;          // block-uniform: an empty unit emits nothing and moves no position
     const int64_t w0 = wblk + (int64_t)r * kWordsPerBlock + tid * 4;
     int c = 0;
 #pragma unroll
@@ -889,7 +869,6 @@ struct pg_sampler {
   // device buffers
   unsigned long long* bitmap = nullptr;
   unsigned long long* bitmap_b = nullptr;   // layers alternate between the two (the other one is being cleared)
-  uint8_t* dirty = nullptr;                 // [2][n_bm_blocks] unit flags of bitmap / bitmap_b (k_sx sets, k_bm_rank reads + clears)
   uint32_t* word_rank = nullptr;
   int32_t* partial = nullptr;
   int64_t* layer_ids[PG_MAX_LAYERS] = {nullptr};
@@ -908,7 +887,6 @@ static void sampler_free(pg_sampler* s) {
   if (!s) return;
   (void)hipFree(s->bitmap);
   (void)hipFree(s->bitmap_b);
-  (void)hipFree(s->dirty);
   (void)hipFree(s->word_rank);
   (void)hipFree(s->partial);
   for (auto p : s->layer_ids) (void)hipFree(p);
@@ -964,8 +942,6 @@ int pg_sampler_create(int64_t V, const int64_t* indptr, const int32_t* indices, 
   ok &= hipMalloc(&s->bitmap, s->n_words * 8) == hipSuccess;
   ok &= hipMalloc(&s->bitmap_b, s->n_words * 8) == hipSuccess;
   ok &= hipMalloc(&s->word_rank, s->n_words * 4) == hipSuccess;
-  ok &= hipMalloc(&s->dirty, (size_t)2 * s->n_bm_blocks + 8) == hipSuccess;
-  if (ok) ok &= hipMemset(s->dirty, 0, (size_t)2 * s->n_bm_blocks + 8) == hipSuccess;
   ok &= hipMalloc(&s->partial, (size_t)s->n_bm_blocks * 4 + 4) == hipSuccess;
   for (int l = 0; l <= L; ++l) ok &= hipMalloc(&s->layer_ids[l], s->cap[l] * 8) == hipSuccess;
   ok &= hipMalloc(&s->counters, 2 * PG_MAX_LAYERS * 4) == hipSuccess;
@@ -1200,7 +1176,6 @@ static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t
       s_blocks = (int)ceil_div<int64_t>(cap_dst + 1, (int64_t)vpi * a.iters);
       a.layer = (uint32_t)b; a.epoch = prm.epoch; a.batch = prm.batch; a.seed_lo = prm.seed_lo; a.seed_hi = prm.seed_hi;
       a.bitmap = bm;
-      a.dirty = s->dirty + (size_t)(s->rank_launches & 1) * s->n_bm_blocks;
       a.blk_indptr = o->blk_indptr + o->blk_indptr_off[b];
       a.blk_src = o->blk_src + o->blk_src_off[b];
       a.ecnt = ecnt + b;
@@ -1226,8 +1201,6 @@ static int enqueue_chain(pg_sampler* s, const pg_nodeflow_desc_t* o, hipStream_t
     if (b < 0) break;
     RankArgs r{};
     r.bm = bm; r.other_bm = other; r.n_words = s->n_words;
-    static const bool no_flags = getenv("PG_SAMPLER_NO_UNIT_FLAGS") != nullptr;     // A/B: every unit is read (rounds 3-4)
-    r.dirty = no_flags ? nullptr : s->dirty + (size_t)(s->rank_launches & 1) * s->n_bm_blocks;
     if (s->clear_by_ids) {
       // `other` holds the marks of the previous rank launch's layer: layer b + 1 of this call, or — for the first rank
       // launch of a call — layer 0 of the previous call (its ids and count are still in place: this call has not emitted

@@ -338,18 +338,6 @@ class GraphedTrainer:
         # runs the model in between the values drift apart, which is harmless: a mask only has to differ from step to step.
         self.early_ordinal = 0           # the dropout step value of the last early aggregation (0: none yet)
         self._early_next = None
-        # Phase gate (round 5): an early aggregation is HBM-bound and so is the dense forward the compute stream starts every
-        # step with; beside each other both slow down (k_linear_fwd 23.5 instead of 16.8 us, and the backward kernels pay when
-        # the aggregation lands on them). The step's head launch therefore bumps a device counter when it STARTS (the dense
-        # forward has drained: pg_phase_arm), and an early aggregation waits on the load stream (pg_wait_phase: one wave,
-        # bounded) until the most recently issued step has got there — it then runs beside head / backward / optimiser, which
-        # are latency-bound and leave the memory system idle. A hint only: on a time-out the aggregation simply starts.
-        # PG_PHASE_GATE=0 switches it off; `phase_gate_us` is the bound of one wait.
-        self.phase_gate = _os.environ.get("PG_PHASE_GATE", "1") != "0"
-        self.phase_gate_us = int(_os.environ.get("PG_PHASE_GATE_US", "400"))
-        self._phase = torch.zeros(1, dtype=torch.int64, device=device)
-        self._phase_issued = 0           # steps issued whose head launch carries the signal
-        self._phase_ok = True            # False once a step body did not launch a head (the unfused path): no more waits
         self.keep_gc = False             # True: leave the interpreter's cyclic garbage collector on inside run_steps
         # True: prepare / compute run inside the reference's profiler ranges 'gpu-load' / 'gpu-compute' (pa_gcn.py:87,92);
         # off by default — a record_function costs the launch thread a few microseconds per step
@@ -358,7 +346,7 @@ class GraphedTrainer:
         # other streams — the sampler's ring, the cacher's cache / slot map / staging, the labels, the model and the optimiser
         # state — is recorded on those streams once, here (L.record_streams): dropped with steps in flight, their memory is
         # not reused before those steps have finished, with or without a finalizer.
-        L.record_streams([sampler.slots, sampler.seeds, cacher, self.labels, model, optimizer, self.flat, self._phase],
+        L.record_streams([sampler.slots, sampler.seeds, cacher, self.labels, model, optimizer, self.flat],
                          [self.load_stream, self.compute_stream, self.comm_stream])
 
     class _Slot:
@@ -421,10 +409,6 @@ class GraphedTrainer:
         s.agg0 = None          # ... and their outputs {block: [destination capacity, padded dim]}
         s.early_call = None    # ... and the cached arguments of its launch
         s.early_training = None  # ... and the model's mode (train / eval) they were aggregated in
-        s.batch_plan = None      # pg_batch_plan_t of the slot's load-stream work (prepare as ONE C call), or False
-        s.batch_key = None       # ... and what it was built over
-        with torch.cuda.stream(self.load_stream):
-            s.ready.record()     # (torch creates an event's handle at its first record: pg_batch_prepare needs it)
         # allocated on the load stream, read by the captured step on the compute stream (and by the sampler's chain when it
         # clears through the previous ids): see L.record_streams
         L.record_streams([s.out, s.label, s.n_valid3], [self.compute_stream, self.load_stream, self.sampler.stream])
@@ -456,11 +440,6 @@ class GraphedTrainer:
             ls.wait_event(s.done)                # the graph that read these buffers has finished
         if dbg is not None:
             ev[2].record(ls)
-        if s.batch_plan and dbg is None and not s.done_recorded and self._prepare_native(nf, s):
-            if s.nf is None:
-                s.nf = nf
-            s.nf_cur = nf
-            return s
         ls.wait_event(nf._slot.ready)            # the sampler wrote this NodeFlow on its own stream
         # no `with torch.cuda.stream(...)`, no tensor ops: everything below is a C-ABI call given the stream
         # explicitly (the launch thread is the bottleneck of a ~0.2 ms step)
@@ -469,7 +448,6 @@ class GraphedTrainer:
             # first use of the slot, or the cache was (re)built since (auto_cache after the first step)
             s.slot_index = self.sampler.slots.index(nf._slot)
             s.plan = self._plan_for(nf, s)
-            s.batch_plan = None
         if s.plan is not False:
             self.cacher.fetch_planned(s.plan, ids, ls, slot=s.slot_index)
         else:
@@ -493,8 +471,6 @@ class GraphedTrainer:
         if dbg is not None:
             ev[3].record(ls)
             dbg.append(ev)
-        if s.batch_plan is None:
-            s.batch_plan = self._build_batch_plan(nf, s)      # from the slot's next batch on: one C call (False: not this shape)
         # the static NodeFlow views of a slot are rebuilt per batch but alias the same memory:
         # keep the first one (the graph captured ITS tensors) and only refresh the frames
         if s.nf is None:
@@ -536,9 +512,6 @@ class GraphedTrainer:
 
     def _aggregate_early(self, nf, s, ls):
         call = self._early_args(nf, s, ls)
-        if self.phase_gate and self._phase_ok and self._phase_issued > 0:
-            L.check(self._lib.pg_wait_phase(L.ptr(self._phase), self._phase_issued, self.phase_gate_us,
-                                            ctypes.c_void_p(ls.cuda_stream)), "pg_wait_phase")
         for args, d in call[2]:
             if d is not None:
                 d.step_value = self.early_ordinal
@@ -584,84 +557,6 @@ class GraphedTrainer:
             call = s.early_call = (s.early, m.training, launches, keep)
         return call
 
-    # -- prepare() as one C call (round 5) --------------------------------------------------------------------------
-    def _build_batch_plan(self, nf, s):
-        """pg_batch_plan_t for this ring slot, or False when the slot's load-stream work is not the shape pg_batch_prepare
-        covers: a table resident in HBM whose fetched rows are all read in place (the slot look-up is the whole fetch),
-        deferred transposes, the self-cleaning label look-up. PG_NATIVE_PREPARE=0 keeps the call-by-call sequence."""
-        import os as _os
-        c, plan = self.cacher, s.plan
-        if (_os.environ.get("PG_NATIVE_PREPARE", "1") == "0" or plan is None or plan is False or not plan.virtual
-                or plan.dense_rows != 0 or not c.full_cached or _LABELS_MEMSET):
-            return False
-        o0, o1 = nf._layer_offsets[-2], nf._layer_offsets[-1]
-        if o1 <= o0 or getattr(nf._slot.ready, "cuda_event", None) in (None, 0) or getattr(s.ready, "cuda_event", None) in (None, 0):
-            return False
-        ids = nf._node_mapping.tousertensor()
-        bp = L.PgBatchPlan()
-        bp.load_stream = self.load_stream.cuda_stream
-        bp.ev_sampled = nf._slot.ready.cuda_event
-        bp.ev_ready = s.ready.cuda_event
-        bp.ids = ids.data_ptr() + 8 * plan.row_lo
-        bp.rows = plan.rows
-        bp.slot_map = L.ptr(c.slot_map).value
-        bp.slots_out = L.ptr(plan.slots).value
-        bp.stats = L.ptr(c._stats).value if c.log else None
-        bp.transpose = 1 if self.sampler.defer_transpose else 0
-        bp.sampler = self.sampler.handle.value if self.sampler.defer_transpose else None
-        bp.desc = nf._slot.desc
-        bp.phase_word = L.ptr(self._phase).value
-        bp.phase_timeout_us = self.phase_gate_us
-        bp.n_early = 0
-        bp.label_ids = ids.data_ptr() + 8 * o0
-        bp.n_label_rows = o1 - o0
-        bp.labels = L.ptr(self.labels).value
-        bp.labels_len = self.labels.numel()
-        bp.label_fill = -100
-        bp.label_out = L.ptr(s.label).value
-        bp.n_valid = L.ptr(s.n_valid).value
-        bp.label_scratch = s.n_valid3.data_ptr() + 4
-        s.batch_key = (plan, c.log, None)
-        return bp
-
-    def _prepare_native(self, nf, s):
-        """prepare() of a slot that has a batch plan; False = the plan no longer fits (the caller runs the generic sequence
-        and builds a new one)"""
-        c, bp = self.cacher, s.batch_plan
-        if s.plan is None or s.plan is False or s.plan.cache_epoch != c._cache_epoch or s.batch_key[0] is not s.plan \
-                or s.batch_key[1] != c.log:
-            s.batch_plan = None
-            return False
-        step_value = 0
-        if s.early is not None:
-            call = self._early_args(nf, s, self.load_stream)
-            if s.batch_key[2] is not call:
-                # the early launches' arguments, once per (slot, plan, model mode): the C struct's copies of what
-                # _aggregate_early passes call by call
-                if len(call[2]) > L.PG_MAX_LAYERS:
-                    s.batch_plan = False
-                    return False
-                for i, ((args, d), (blk, _f, rows)) in enumerate(zip(call[2], s.early)):
-                    e = bp.early[i]
-                    out = s.agg0[blk]
-                    e.indptr, e.src = L.ptr(nf.blk_indptr[blk]).value, L.ptr(nf.blk_src[blk]).value
-                    e.rows = rows.struct()
-                    e.n_dst, e.dim, e.reduce = int(out.size(0)), rows.dim, args[5]
-                    e.out, e.out_stride = L.ptr(out).value, out.stride(0)
-                    e.has_drop = 1 if d is not None else 0
-                    if d is not None:
-                        e.drop = d
-                    prof, ring = (rows.prof[0], rows.prof[1]) if rows.prof is not None else (None, 0)
-                    e.prof, e.prof_ring = (L.ptr(prof).value if prof is not None else None), ring
-                bp.n_early = len(call[2])
-                s.batch_key = (s.batch_key[0], s.batch_key[1], call)
-            step_value = self.early_ordinal
-        target = self._phase_issued if (self.phase_gate and self._phase_ok and s.early is not None) else 0
-        L.check(self._lib.pg_batch_prepare(ctypes.byref(bp), target, step_value), "pg_batch_prepare")
-        if s.early is not None:
-            s.early_training = self._bare_model().training
-        return True
-
     def _frames_for(self, s):
         rs = s.plan.row_sources if s.plan else {}
         for i in range(s.nf.num_layers):
@@ -682,14 +577,12 @@ class GraphedTrainer:
         if self._gseed is None:                 # persistent d loss / d loss: no ones_like fill (nor a divide) per step
             self._gseed = torch.full((), 1.0 / self.world, dtype=torch.float32, device=self.device)
         loss = None
-        self._arm_phase()
         if self.fuse_head and isinstance(self.loss_fcn, ops.CrossEntropyLoss) and hasattr(self.model, 'forward_loss'):
             # output layer + loss + their gradients in one kernel (GCN); None = not applicable
             loss = self.model.forward_loss(s.nf, s.label, s.n_valid, self._gseed, self.loss_fcn.ignore_index)
         if loss is None:
             pred = self.model(s.nf)
             loss = self.loss_fcn(pred, s.label)
-        self._disarm_phase()
         if self.world > 1:
             self.flat.zero_()
             loss.backward(self._gseed)          # loss / world: the SUM all-reduce then yields DDP's mean gradient
@@ -705,20 +598,6 @@ class GraphedTrainer:
             self.optimizer.step()
         s.nf._pre_agg = None                    # consumed: an eager forward on this NodeFlow later aggregates for itself
         return loss
-
-    def _arm_phase(self):
-        """the step's head launch (pg_gcn_head / pg_sage_head, issued or captured by the forward that follows) bumps the phase
-        counter when it starts"""
-        if self.phase_gate and self._phase_ok:
-            L.check(self._lib.pg_phase_arm(L.ptr(self._phase), None), "pg_phase_arm")
-
-    def _disarm_phase(self):
-        if self.phase_gate and self._phase_ok:
-            pending = L.c_i32(0)
-            L.check(self._lib.pg_phase_arm(None, ctypes.byref(pending)), "pg_phase_arm")
-            if pending.value:
-                # this forward launched no fused head (outside its envelope): nobody bumps the counter, so nobody waits for it
-                self._phase_ok = False
 
     def _can_defer_partials(self):
         from .optim import Adam
@@ -751,13 +630,11 @@ class GraphedTrainer:
             if self._gseed is None:
                 self._gseed = torch.full((), 1.0, dtype=torch.float32, device=self.device)
             loss = None
-            self._arm_phase()
             if self.fuse_head and isinstance(self.loss_fcn, ops.CrossEntropyLoss) and hasattr(self.model, 'forward_loss'):
                 loss = self.model.forward_loss(s.nf, s.label, s.n_valid, self._gseed, self.loss_fcn.ignore_index)
             if loss is None:
                 pred = self.model(s.nf)
                 loss = self.loss_fcn(pred, s.label)
-            self._disarm_phase()
             loss.backward(self._gseed)
         self.optimizer.step(deferred=reg, bump=bump)
         s.nf._pre_agg = None
@@ -915,8 +792,6 @@ class GraphedTrainer:
         # this step had finished (measured: the sampler started only when the current graph ended). Call
         # synchronize() (or compute_stream.synchronize()) before reading it.
         self.steps_done += 1
-        if self._phase_ok:
-            self._phase_issued += 1      # (every step body, eager or replayed, carries one head launch with the signal)
         # the token of this step's buffers: the optimiser's launch count with this step's launch in. A step that enqueued
         # no optimiser launch at all (every gradient None) has no "last launch" to stand for it: None = release by event.
         self._last_token = None
