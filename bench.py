@@ -161,6 +161,22 @@ def make_host_table(V, Fdim, rank, local_rank, world, dev, tag):
     from pagraph_amd.data import synthetic as syn
     if world == 1:
         t0 = time.time()
+        if os.environ.get("PG_HOST_TABLE_THP", "1") != "0":
+            # (round 5) the table in transparent huge pages, registered with the runtime: the CPU row gather of
+            # the miss path is 25-30 % faster out of them (storage.huge_page_tensor, profiles/r05/host_gather_sweep.txt).
+            # PG_HOST_TABLE_THP=0: a hipHostMalloc'ed table as in rounds 1-4
+            from pagraph_amd.storage import huge_page_tensor
+            tab, ok = huge_page_tensor((V, Fdim))
+            if ok:
+                syn.fill_random_features(tab, device=dev)
+                try:
+                    thp = [l for l in open("/proc/self/smaps_rollup") if "AnonHugePages" in l][0].split()[1]
+                except Exception:
+                    thp = "?"
+                log(f"[bench] host table {V}x{Fdim} in huge pages (AnonHugePages {thp} kB), registered, filled in {time.time()-t0:.1f}s")
+                return tab, True
+            del tab
+            log("[bench] hipHostRegister of the huge-page table failed -> pinned allocation")
         tab = torch.empty((V, Fdim), dtype=torch.float32, pin_memory=True)
         syn.fill_random_features(tab, device=dev)
         log(f"[bench] host table {V}x{Fdim} pinned + filled in {time.time()-t0:.1f}s")

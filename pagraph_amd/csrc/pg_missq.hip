@@ -42,6 +42,9 @@
 #include <hsa/hsa_ext_amd.h>
 #include <hsa/amd_hsa_signal.h>
 
+#include <pthread.h>
+#include <sched.h>
+
 #include "pg_common.h"
 
 namespace pg {
@@ -221,7 +224,28 @@ class Pool {
       stall_every_ = atoi(t);
       if (const char* c = strchr(t, ',')) stall_us_ = atoi(c + 1);
     }
-    for (int i = 1; i < n_; ++i) th_.emplace_back([this] { loop(); });
+    // PG_MISSQ_PIN=<stride>: gather thread i is pinned to the (i * stride)-th CPU of the process's affinity set (experiment,
+    // round 5: does a thread that cannot migrate deliver more evenly on a shared box? profiles/r05/host_gather_sweep.txt)
+    const char* pin = getenv("PG_MISSQ_PIN");
+    const int stride = pin ? atoi(pin) : 0;
+    for (int i = 1; i < n_; ++i) th_.emplace_back([this, i, stride] {
+      if (stride > 0) {
+        cpu_set_t all, one;
+        CPU_ZERO(&all);
+        if (sched_getaffinity(0, sizeof(all), &all) == 0) {
+          const int n = CPU_COUNT(&all);
+          int want = n > 0 ? (i * stride) % n : -1, seen = 0;
+          for (int c = 0; c < CPU_SETSIZE && want >= 0; ++c)
+            if (CPU_ISSET(c, &all) && seen++ == want) {
+              CPU_ZERO(&one);
+              CPU_SET(c, &one);
+              (void)pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+              break;
+            }
+        }
+      }
+      loop();
+    });
   }
   ~Pool() {
     stop_.store(true, std::memory_order_release);

@@ -1,1 +1,1 @@
-from .storage import GraphCacheServer, HostFeatureStore
+from .storage import GraphCacheServer, HostFeatureStore, huge_page_tensor

@@ -30,6 +30,51 @@ class _NodeFrame:
         self._frame = cols
 
 
+_THP_MIN_BYTES = 64 << 20
+
+
+def huge_page_tensor(shape, dtype=torch.float32, register=True):
+    """A host tensor in an anonymous mapping backed by transparent huge pages (`madvise(MADV_HUGEPAGE)`), page-locked with
+    hipHostRegister so that copy engines and zero-copy kernels may read it: (tensor, device_addressable).
+    Why (round 5, profiles/r05/host_gather_sweep.txt): the miss path's CPU row gather reads ~3 300 random 2.4 KB rows per step out
+    of a 24 GB table (storage.py:128 `table[nids]`); in 4 KB pages that is 6 M TLB entries and one page walk per row — the same
+    gather takes 248 / 127 / 82 us on 2 / 4 / 8 threads out of huge pages against 309 / 176 / 115 us out of hipHostMalloc'ed
+    memory, i.e. FOUR threads hold the step on its PCIe floor (0.1500 ms at 5.9 CPUs) where eight were needed.
+    Falls back to what the kernel gives (MADV_HUGEPAGE refused: ordinary pages, still registered)."""
+    import mmap
+    import weakref
+    import numpy as np
+    n = 1
+    for d in shape:
+        n *= int(d)
+    itemsize = torch.empty((), dtype=dtype).element_size()
+    nbytes = max(n * itemsize, itemsize)
+    mm = mmap.mmap(-1, nbytes, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
+    try:
+        mm.madvise(mmap.MADV_HUGEPAGE)
+    except (AttributeError, OSError, ValueError):
+        pass
+    arr = np.frombuffer(mm, dtype=np.uint8, count=n * itemsize)
+    t = torch.from_numpy(arr).view(dtype).reshape(tuple(int(d) for d in shape))     # storage -> ndarray -> mmap stay alive together
+    ok = False
+    if register and torch.cuda.is_available() and n:
+        try:
+            ptr = t.data_ptr()
+            ok = int(torch.cuda.cudart().cudaHostRegister(ptr, n * itemsize, 0)) == 0
+            if ok:
+                weakref.finalize(arr, _unregister, ptr)          # before the mapping goes
+        except Exception:
+            ok = False
+    return t, ok
+
+
+def _unregister(ptr):
+    try:
+        torch.cuda.cudart().cudaHostUnregister(ptr)
+    except Exception:
+        pass
+
+
 class HostFeatureStore:
     """In-process stand-in for the DGL shared-memory graph store the reference
     attaches to (server/pa_server.py:33-54, examples/profile/pa_gcn.py:33): a
@@ -52,12 +97,24 @@ class HostFeatureStore:
             if key not in done:
                 u = t.unsqueeze(1) if t.dim() == 1 else t
                 u = u.to(torch.float32).contiguous()
-                if pin and torch.cuda.is_available() and not u.is_pinned():
+                vis = None
+                if (pin and torch.cuda.is_available() and not u.is_pinned() and u.numel() * 4 >= _THP_MIN_BYTES
+                        and os.environ.get("PG_HOST_TABLE_THP", "1") != "0"):
+                    # a large table moves into huge pages (huge_page_tensor: the CPU row gather's TLB reach), registered
+                    try:
+                        h, ok = huge_page_tensor(u.shape)
+                        if ok:
+                            h.copy_(u)
+                            u, vis = h, True
+                    except (OSError, RuntimeError, ValueError):
+                        pass
+                if vis is None and pin and torch.cuda.is_available() and not u.is_pinned():
                     try:
                         u = u.pin_memory()
                     except RuntimeError:
                         pass  # too large to pin: the staged / async miss paths still work from pageable memory
-                vis = u.is_pinned() if torch.cuda.is_available() else False
+                if vis is None:
+                    vis = u.is_pinned() if torch.cuda.is_available() else False
                 done[key] = (u, vis)
             u, vis = done[key]
             if device_visible is not None and name in device_visible:

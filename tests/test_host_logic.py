@@ -310,3 +310,22 @@ def test_run_group_kills_the_whole_process_group_on_a_timeout(tmp_path):
         raise AssertionError("the grandchild survived the group kill")
     r = run_group([sys.executable, "-c", "print('fine')"], 30)
     assert r.returncode == 0 and r.stdout.strip() == "fine"
+
+
+def test_huge_page_tensor_is_an_ordinary_tensor():
+    """storage.huge_page_tensor: a host tensor in a MADV_HUGEPAGE mapping (the CPU row gather's TLB reach); without a GPU it
+    is simply not registered. Values, views and lifetime behave like any tensor's (the mapping lives as long as the storage)."""
+    import gc
+    import numpy as np
+    import torch
+    from pagraph_amd.storage import huge_page_tensor
+    t, ok = huge_page_tensor((1000, 37))
+    assert t.shape == (1000, 37) and t.dtype == torch.float32 and (ok is False or torch.cuda.is_available())
+    ref = torch.arange(37000, dtype=torch.float32).reshape(1000, 37)
+    t.copy_(ref)
+    v = t[100:200, 3:9]
+    del t
+    gc.collect()
+    assert torch.equal(v, ref[100:200, 3:9])
+    e, _ = huge_page_tensor((0, 5))
+    assert e.numel() == 0
