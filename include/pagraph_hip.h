@@ -62,6 +62,15 @@ int pg_last_hip_error(void);
 int pg_bounds_enabled(void);
 int pg_bounds_region(const void* base, int64_t bytes);
 int pg_bounds_report(uint64_t* rec, char* unit, int32_t unit_len, int32_t reset);
+/* A captured step as plain launches (round 5; csrc/pg_tape.hip): pg_tape_from_graph walks a hipGraph_t that is a linear chain of
+ * kernel / memset nodes (a single-stream capture of this library's launches) and keeps the nodes' launch parameters; the graph —
+ * owner of the parameter storage and of the memory its pointers refer to — must outlive the tape. pg_tape_launch issues the same
+ * kernels with the same arguments in the same order on `stream`, without hipGraphLaunch's ~12 us between two replays.
+ * PG_ERR_UNSUPPORTED for any other graph shape (the caller keeps replaying the graph). */
+typedef struct pg_tape pg_tape_t;
+int pg_tape_from_graph(void* hip_graph, pg_tape_t** out, int32_t* n_kernels, int32_t* n_other);
+int pg_tape_launch(const pg_tape_t* tape, pg_stream_t stream);
+int pg_tape_destroy(pg_tape_t* tape);
 /* number of CUs of the current device, or <0 when no HIP device is visible */
 int pg_device_cu_count(void);
 

@@ -77,6 +77,9 @@ _SIGS = {
     "pg_bounds_region": (ctypes.c_int, [vp, c_i64]),
     "pg_bounds_report": (ctypes.c_int, [ctypes.POINTER(c_u64), ctypes.c_char_p, c_i32, c_i32]),
     "pg_device_cu_count": (ctypes.c_int, []),
+    "pg_tape_from_graph": (ctypes.c_int, [vp, ctypes.POINTER(vp), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
+    "pg_tape_launch": (ctypes.c_int, [vp, vp]),
+    "pg_tape_destroy": (ctypes.c_int, [vp]),
     "pg_slot_map_reset": (ctypes.c_int, [vp, c_i64, vp]),
     "pg_slot_map_assign": (ctypes.c_int, [vp, vp, c_i64, vp]),
     "pg_slot_map_export": (ctypes.c_int, [vp, c_i64, vp, vp, vp]),

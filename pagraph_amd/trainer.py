@@ -359,7 +359,7 @@ class GraphedTrainer:
             L.safe_stream_wait(getattr(self, name, None))
         if L.del_waits_enabled():
             for s_ in list(getattr(self, "slots", {}).values()):
-                s_.graph = None
+                self._drop_graph(s_)
             self.graph_b = None
 
     def __enter__(self):
@@ -397,6 +397,7 @@ class GraphedTrainer:
         s.done = torch.cuda.Event()
         s.done_recorded = False
         s.graph = None
+        s.tape = None
         s.graph_synced = False
         s.graph_plan = None
         s.graph_epoch = -1
@@ -599,6 +600,40 @@ class GraphedTrainer:
         s.nf._pre_agg = None                    # consumed: an eager forward on this NodeFlow later aggregates for itself
         return loss
 
+    # -- the captured step as plain launches (round 5; csrc/pg_tape.hip) --------------------------------------------------
+    def _flat_wanted(self):
+        """replay a captured step as its kernels launched one by one instead of with hipGraphLaunch: between two graph replays
+        the stream idles ~12 us, between two dependent kernels of one stream ~3.4 us. One GPU only (a captured collective is
+        not a plain kernel node). PG_FLAT_REPLAY=0 keeps the graph launch."""
+        import os as _os
+        return self.world == 1 and _os.environ.get("PG_FLAT_REPLAY", "1") != "0"
+
+    def _make_tape(self, s):
+        s.tape = None
+        if not self._flat_wanted():
+            return
+        try:
+            s.graph.instantiate()                     # (keep_graph=True defers it; the graph launch stays available)
+            raw = s.graph.raw_cuda_graph()
+            tape, nk, no = L.vp(), L.c_i32(0), L.c_i32(0)
+            rc = self._lib.pg_tape_from_graph(ctypes.c_void_p(int(raw)), ctypes.byref(tape), ctypes.byref(nk), ctypes.byref(no))
+            if rc == 0 and nk.value > 0:
+                s.tape = tape
+        except Exception:
+            s.tape = None
+
+    def _replay(self, s, stream):
+        if getattr(s, "tape", None) is not None:
+            L.check(self._lib.pg_tape_launch(s.tape, ctypes.c_void_p(stream.cuda_stream)), "pg_tape_launch")
+        else:
+            s.graph.replay()
+
+    def _drop_graph(self, s):
+        if getattr(s, "tape", None) is not None:
+            self._lib.pg_tape_destroy(s.tape)          # (holds pointers into the graph's nodes: goes first)
+            s.tape = None
+        s.graph = None
+
     def _can_defer_partials(self):
         from .optim import Adam
         m = self._bare_model()
@@ -736,7 +771,7 @@ class GraphedTrainer:
         if s.graph is not None and s.graph_plan is not s.plan:
             # the captured step reads the cache / the slot array / the staged block of the fetch plan it was captured
             # over: a new plan (the cache changed, the miss queue was rebuilt) needs a new capture
-            s.graph = None
+            self._drop_graph(s)
         if s.ext_drop is not None and not s.ext_drop._drop_step_primed:
             # this slot's (captured) step expects the dropout counter to hold the NEXT value; somebody ran the model the
             # other way since (an eager forward bumps first, then uses): one eager increment puts it back
@@ -745,7 +780,7 @@ class GraphedTrainer:
         counted = self._step_cell is not None
         issued0 = self.optimizer.steps_issued() if counted else 0
         if s.graph is not None and (self.world == 1 or s.graph_synced) and self._on_main:
-            s.graph.replay()                                  # steady state: one launch
+            self._replay(s, main)                             # steady state: one launch
             if counted:
                 self.optimizer.note_replayed_steps(1)
             loss = s.loss.clone() if self.keep_losses else s.loss
@@ -754,7 +789,7 @@ class GraphedTrainer:
                 warm = self.steps_done < self.warmup_eager
                 synced = bool(self.allreduce_in_graph)       # did the body below already all-reduce and step?
                 if s.graph is not None:
-                    s.graph.replay()
+                    self._replay(s, main)
                     synced = s.graph_synced
                     if counted and (self.world == 1 or synced):
                         self.optimizer.note_replayed_steps(1)
@@ -766,7 +801,7 @@ class GraphedTrainer:
                 else:
                     if self.world > 1 and self.allreduce_in_graph is None:
                         self.allreduce_in_graph = self._probe_graph_allreduce()
-                    g = torch.cuda.CUDAGraph()
+                    g = torch.cuda.CUDAGraph(keep_graph=True) if self._flat_wanted() else torch.cuda.CUDAGraph()
                     if self.world == 1:
                         self.optimizer.zero_grad(set_to_none=True)
                     self._prime_drop_step()                      # an eager increment: must stay outside the capture
@@ -774,10 +809,11 @@ class GraphedTrainer:
                     with torch.cuda.graph(g, stream=main, capture_error_mode="thread_local"):
                         s.loss = (self._step_body_deferred(s) if self._can_defer_partials() else self._step_body(s)).detach()
                     s.graph = g
+                    self._make_tape(s)
                     s.graph_epoch = self.cacher._cache_epoch
                     s.graph_plan = s.plan
                     s.graph_synced = synced = bool(self.allreduce_in_graph)
-                    g.replay()                                   # capture does not execute
+                    self._replay(s, main)                        # capture does not execute
                     if counted and (self.world == 1 or synced):
                         self.optimizer.note_replayed_steps(1)
                 if self.world > 1 and not synced:
