@@ -481,9 +481,15 @@ class GraphCacheServer:
         self._adopt_cache(nids, fused, views, is_full)
 
     # -- buffers for the miss path --------------------------------------------
-    def _ensure_capacity(self, n):
+    def _ensure_capacity(self, n, stream=None):
+        """(re)allocate the miss-list scratch for n rows. `stream`: the stream whose kernels FILL these buffers — they are
+        allocated from ITS pool (a block of another stream's pool may still be written by that stream's running kernels;
+        see GraphedTrainer.prepare)"""
         if n <= self._cap:
             return
+        if stream is not None and stream != torch.cuda.current_stream(self.device):
+            with torch.cuda.stream(stream):
+                return self._ensure_capacity(n)
         cap = max(n, int(self._cap * 1.5), 1024)
         self._miss_pos = torch.empty(cap, dtype=torch.int32, device=self.device)
         self._slots = torch.empty(cap, dtype=torch.int32, device=self.device)
@@ -738,11 +744,11 @@ class GraphCacheServer:
         sp = ctypes.c_void_p(stream.cuda_stream)
         ids = ctypes.c_void_p(node_mapping.data_ptr() + 8 * plan.row_lo)
         if plan.virtual:
-            return self._fetch_virtual(plan, ids, sp, slot)
+            return self._fetch_virtual(plan, ids, sp, slot, stream)
         if self.full_cached and not self.log:
             L.check(self.lib.pg_gather_rows_full(ids, R, plan.fields, plan.n_fields, sp), "pg_gather_rows_full")
             return
-        self._ensure_capacity(R)
+        self._ensure_capacity(R, stream)
         if self.miss_mode == "async" and not self.full_cached:
             if slot is None:
                 raise L.PgError("miss_mode='async' needs fetch_planned(..., slot=k)")
@@ -777,7 +783,7 @@ class GraphCacheServer:
                     L.ptr(tab), tab.stride(0), L.ptr(self._miss_pos), L.ptr(self._miss_fullid), R,
                     L.ptr(self._miss_count), self.dims[name], L.ptr(o), o.stride(0), sp), "pg_scatter_rows_from_host")
 
-    def _fetch_virtual(self, plan, ids, sp, slot):
+    def _fetch_virtual(self, plan, ids, sp, slot, stream=None):
         """split every needed row (slots + miss list), gather only the rows of the layers that are read row by row,
         hand the miss list to the queue: rows of the leading layers stay in the cache / the staged block"""
         R = plan.rows
@@ -788,7 +794,7 @@ class GraphCacheServer:
             miss_pos, miss_fullid, miss_count = self._missq_buffers(slot, R)
             self._order_after_tail(slot, sp)
         else:
-            self._ensure_capacity(R)
+            self._ensure_capacity(R, stream)
             miss_pos, miss_fullid, miss_count = L.ptr(self._miss_pos), L.ptr(self._miss_fullid), L.ptr(self._miss_count)
         dd = self._plan_dedup(plan, slot) if use_q else None
         if self.full_cached and not use_q:

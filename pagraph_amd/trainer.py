@@ -448,9 +448,20 @@ class GraphedTrainer:
         if s.plan is None or (s.plan is not False and s.plan.cache_epoch != self.cacher._cache_epoch):
             # first use of the slot, or the cache was (re)built since (auto_cache after the first step)
             s.slot_index = self.sampler.slots.index(nf._slot)
-            s.plan = self._plan_for(nf, s)
+            # The plan's buffers (its slot array first of all) are FIRST WRITTEN by this stream's k_split: they must come out
+            # of THIS stream's allocator pool. Allocated on whatever stream is current — the compute stream inside run_steps —
+            # the allocator may hand out a block an eager warm-up step has just freed while its kernels are still running
+            # (legal for a tensor that is next used on that same stream), and those kernels then write their floats over the
+            # slot array the load stream has filled meanwhile: the rare hipErrorIllegalAddress of rounds 4-5, named by the
+            # debug build as k_spmm_fwd_rows following float bit patterns (DESIGN section 3 'Lifetimes').
+            # (PG_PLAN_ON_CURRENT_STREAM=1 restores the old allocation for the test that demonstrates the hazard)
+            if _os_mod.environ.get("PG_PLAN_ON_CURRENT_STREAM"):
+                s.plan = self._plan_for(nf, s)
+            else:
+                with torch.cuda.stream(ls):
+                    s.plan = self._plan_for(nf, s)
         if s.plan is not False:
-            self.cacher.fetch_planned(s.plan, ids, ls, slot=s.slot_index)
+            self.cacher.fetch_planned(s.plan, ids, ls, slot=s.slot_index)      # (allocates under `ls` itself where it must)
         else:
             with torch.cuda.stream(ls):
                 self.cacher.fetch_data(nf, out=s.out, need=self.need, slot=s.slot_index)

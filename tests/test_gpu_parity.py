@@ -811,6 +811,72 @@ def test_early_layer0_aggregation_matches_the_in_step_one(dev, hiplib, ratio, mi
     assert not np.array_equal(drop[:24], base)                     # ... and dropout was really on
 
 
+@pytest.mark.parametrize("on_current_stream", [False, True])
+def test_fetch_plan_buffers_come_from_the_stream_that_fills_them(dev, hiplib, monkeypatch, on_current_stream):
+    """The rare hipErrorIllegalAddress of rounds 4-5, made deterministic. A fetch plan's slot array is first written by k_split
+    on the LOAD stream. Allocated while the COMPUTE stream is current (as run_steps has it), torch's allocator may hand out a
+    block that an eager step has just freed while its kernels are still queued — legal for a tensor next used on that stream —
+    and those kernels then write their floats over the slots the load stream has filled meanwhile; pg_spmm_fwd_rows later
+    follows float bit patterns as cache slots (named by the PG_BOUNDS build under host load). GraphedTrainer.prepare
+    therefore builds the plan with the load stream current. PG_PLAN_ON_CURRENT_STREAM=1 (second case) restores the old
+    allocation and the very same sequence corrupts the slot array."""
+    import torch.nn.functional as Fn
+    from pagraph_amd.model import GCNSampling
+    from pagraph_amd.optim import Adam
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    from pagraph_amd.trainer import GraphedTrainer
+    if on_current_stream:
+        monkeypatch.setenv("PG_PLAN_ON_CURRENT_STREAM", "1")
+    rng = np.random.default_rng(3)
+    V, Fd, C, B = 6000, 600, 7, 600
+    g = DeviceGraph(_rand_csc(rng, V, 40000))
+    feats = torch.from_numpy(rng.standard_normal((V, Fd)).astype(np.float32))
+    labels = torch.from_numpy(rng.integers(0, C, V)).to(dev)
+    c = GraphCacheServer(HostFeatureStore({"features": feats}), V, torch.arange(V), 0, miss_mode="async")
+    c.init_field(["features"])
+    c.auto_cache(g, ["features"], cache_ratio=0.4)
+    model = GCNSampling(Fd, 32, C, 1, Fn.relu, 0.0).to(dev)
+    smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=True, num_hops=2, seed_nodes=np.arange(0, V, 2), prefetch=True,
+                          seed=1, static=True, defer_transpose=True)
+    tr = GraphedTrainer(model, torch.nn.CrossEntropyLoss(), Adam(model.parameters(), lr=1e-2), c, smp, labels, dev,
+                        need=model.required_inputs(3))
+    it = iter(smp)
+    nf = next(it)
+    rows = nf.layer_size(0)                       # the plan covers layer 0 (the only layer a sampled GCN fetches)
+    cs = tr.compute_stream
+    prev = torch.cuda.current_stream(dev)
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(cs)                     # what run_steps does for the whole loop
+    try:
+        # an "eager step": float outputs whose kernels are still queued (behind a spin) when Python has already freed them
+        torch.cuda._sleep(300_000_000)
+        junk = [torch.empty(rows, dtype=torch.float32, device=dev) for _ in range(48)]
+        for t in junk:
+            t.fill_(3.25)
+        del junk, t
+        s = tr.prepare(nf)                        # builds the slot's fetch plan and runs k_split on the load stream
+        tr.load_stream.synchronize()              # the split is done; the compute stream is still spinning
+        assert cs.query() is False
+        with torch.cuda.stream(tr.load_stream):
+            filled = s.plan.slots.clone()
+        tr.load_stream.synchronize()
+        cs.synchronize()                          # the stale fills run now
+        after = s.plan.slots.clone()
+        cs.synchronize()
+    finally:
+        torch.cuda.set_stream(prev)
+    sl = filled.cpu().numpy()
+    assert ((sl >= -2 - rows) & (sl < c.cached_num)).all()            # cache slots, staged-row numbers, padding
+    poisoned = int((after.cpu().numpy() == np.float32(3.25).view(np.int32)).sum())
+    if on_current_stream:
+        assert poisoned > 0, "the hazard did not show (allocator picked other blocks?)"
+    else:
+        assert poisoned == 0 and torch.equal(after, filled)
+    smp.release(nf)
+    tr.close(); smp.close(); c.close()
+
+
 def test_stress_objects_dropped_with_work_in_flight(dev, hiplib):
     """Samplers, cachers (async miss queue: worker thread, gather pool, SDMA copies), trainers with captured step graphs and
     optimisers with a mirrored step counter are created, driven WITHOUT a final synchronise, and dropped in every order
