@@ -296,7 +296,7 @@ def stream_ptr(stream=None):
 
 def del_waits_enabled():
     """PG_NO_DEL_WAIT=1 switches the finalizers' stream waits off (diagnosis: with them off, only the allocator-side
-    lifetime rule below protects a pipeline that is dropped with work in flight — DESIGN section 3 'Lifetimes')"""
+    lifetime rule below protects a pipeline that is dropped with work in flight — DESIGN section 3 'The rare illegal address')"""
     return not os.environ.get("PG_NO_DEL_WAIT")
 
 

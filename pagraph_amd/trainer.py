@@ -193,7 +193,6 @@ def cycle_batches(sampler, steps):
 
 
 import os as _os_mod
-_PARTIAL_EARLY = bool(_os_mod.environ.get("PG_EARLY_AGG_PARTIAL"))    # diagnosis only (see GraphedTrainer._early_for)
 _LABELS_MEMSET = bool(_os_mod.environ.get("PG_LABELS_MEMSET"))     # A/B: the label lookup behind a zero fill (rounds 1-3)
 
 
@@ -453,7 +452,7 @@ class GraphedTrainer:
             # the allocator may hand out a block an eager warm-up step has just freed while its kernels are still running
             # (legal for a tensor that is next used on that same stream), and those kernels then write their floats over the
             # slot array the load stream has filled meanwhile: the rare hipErrorIllegalAddress of rounds 4-5, named by the
-            # debug build as k_spmm_fwd_rows following float bit patterns (DESIGN section 3 'Lifetimes').
+            # debug build as k_spmm_fwd_rows following float bit patterns (DESIGN section 3 'The rare illegal address').
             # (PG_PLAN_ON_CURRENT_STREAM=1 restores the old allocation for the test that demonstrates the hazard)
             if _os_mod.environ.get("PG_PLAN_ON_CURRENT_STREAM"):
                 s.plan = self._plan_for(nf, s)
@@ -508,11 +507,9 @@ class GraphedTrainer:
         m = self._bare_model()
         if mode in ("0", "false", "off") or plan is False or not virtual or not hasattr(m, "early_aggregations"):
             return None
-        if not self.cacher.full_cached and not (mode == "1" and _PARTIAL_EARLY):
+        if not self.cacher.full_cached:
             # (a forced mode for partial caches existed for a day in round 4: the launch then waits for the batch's miss rows on
-            # the load stream — 0.32 instead of 0.15 ms/step — and the whole-suite runs that included its test met a rare
-            # hipErrorIllegalAddress right behind it. Removed as a mode; PG_EARLY_AGG_PARTIAL=1 brings it back for the
-            # diagnosis of that fault only: tools/hunt_lifetimes.sh with the debug library, DESIGN section 3 'Lifetimes')
+            # the load stream — 0.32 instead of 0.15 ms/step; removed)
             return None
         out = []
         for blk, field, _red, _drop in m.early_aggregations(plan.num_layers, 0):
@@ -539,8 +536,6 @@ class GraphedTrainer:
                                            device=self.device) for blk, _f, rows in s.early}
             L.record_streams(s.agg0, [self.compute_stream])
             s.early_call = None
-        if not self.cacher.full_cached:
-            self.cacher.wait_misses(s.slot_index, ls)     # (PG_EARLY_AGG_PARTIAL only: the staged miss rows are read in place)
         if self._early_next is None or not self._prepared:
             # nothing of this trainer is prepared ahead: one read of the device counter (the pipeline is empty anyway)
             self.compute_stream.synchronize()
