@@ -1319,6 +1319,11 @@ def run():
                        "dg_hops2_cost": {"sum_deg_squared": sum_deg_sq, "estimated_seconds_one_committer": dg_hops2_est_s,
                                          "basis": "4.7e10 adjacency entries in 68 s (10M/100M graph, 16 host threads)"},
                        "hip_graph_step": use_graph,
+                       # how a captured step is replayed: its kernels as plain launches (csrc/pg_tape.hip, the default on one GPU)
+                       # or hipGraphLaunch (PG_FLAT_REPLAY=0, world > 1, or a graph that is not a chain of kernel / memset nodes)
+                       "step_replay": ("plain launches (pg_tape)" if use_graph and any(getattr(s_, "tape", None) is not None
+                                                                                         for s_ in trainer.slots.values())
+                                       else ("hipGraphLaunch" if use_graph else "eager")),
                        # block 0's aggregation launched ahead of its step on the load stream (GraphedTrainer.early_aggregate:
                        # 'auto' = when the whole table is cached)
                        "early_layer0_aggregation": bool(early_agg),

@@ -593,6 +593,53 @@ int pg_sage_head(const int32_t* indptr, const int32_t* src, const float* h, int3
                  int64_t n_dst, float* logits, float* dagg, float* dself, float* partials, float* dW_both, float* db_loss,
                  int32_t flags, pg_stream_t stream);
 
+/* The load-stream half of one minibatch as ONE call (round 5; csrc/pg_pipeline.hip) for a table that is resident in HBM —
+ * pa_gcn.py:86-91's 'gpu-load' range: the slot look-up of fetch_from_cache (storage.py:207-216; the rows are then read in place),
+ * the sampled blocks' source-major copies, the aggregations of raw rows that run ahead of their step, labels[batch_nids]
+ * (pa_gcn.py:89-90). Every argument that does not change from batch to batch is resolved once per ring slot in the plan; the
+ * call issues, on plan->load_stream: wait(ev_sampled) · pg_slots_full · pg_sampler_transpose ·
+ * pg_spmm_fwd_rows per early block (drop.step_value := drop_step_value) · pg_gather_labels_sc · record(ev_ready).
+ * Parts whose pointers / counts are NULL / 0 are skipped. ev_* are hipEvent_t handles owned by the caller. */
+typedef struct pg_batch_early {
+  const int32_t* indptr;
+  const int32_t* src;
+  pg_row_source_t rows;
+  int64_t n_dst;
+  int32_t dim, reduce;
+  float* out;
+  int32_t out_stride, has_drop;
+  pg_dropout_t drop;
+  uint64_t* prof;
+  int32_t prof_ring, _pad;
+} pg_batch_early_t;
+typedef struct pg_batch_plan {
+  pg_stream_t load_stream;
+  void* ev_sampled;          /* recorded by the caller behind pg_sampler_sample on the sampler's stream */
+  void* ev_ready;            /* recorded here: the step's consumer waits for it */
+  /* slots of the rows that are read in place */
+  const int64_t* ids;
+  int64_t rows;
+  const int32_t* slot_map;
+  int32_t* slots_out;
+  uint64_t* stats;           /* may be NULL */
+  /* source-major block copies */
+  pg_sampler_t* sampler;     /* may be NULL */
+  pg_nodeflow_desc_t desc;
+  int32_t transpose, n_early;
+  /* aggregations that run ahead of the step */
+  pg_batch_early_t early[PG_MAX_LAYERS];
+  /* labels of the seeds */
+  const int64_t* label_ids;
+  int64_t n_label_rows;
+  const int64_t* labels;
+  int64_t labels_len, label_fill;
+  int64_t* label_out;
+  int32_t* n_valid;
+  int32_t* label_scratch;
+} pg_batch_plan_t;
+int pg_batch_prepare(const pg_batch_plan_t* plan, uint64_t drop_step_value);
+
+
 
 /* pg_gcn_head_ex's flags: PG_HEAD_SUM_PARTIALS as above; PG_HEAD_DAGG_PER_EDGE: under PG_REDUCE_MEAN dagg[v] leaves
  * already divided by v's in-degree in the block (what each in-edge carries back) — feed it to pg_spmm_bwd_gather /

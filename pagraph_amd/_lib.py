@@ -65,6 +65,20 @@ class PgDropout(ctypes.Structure):
     _fields_ = [("threshold", c_u32), ("tag", c_u32), ("seed", c_u64), ("step", vp), ("step_value", c_u64)]
 
 
+class PgBatchEarly(ctypes.Structure):
+    _fields_ = [("indptr", vp), ("src", vp), ("rows", PgRowSource), ("n_dst", c_i64), ("dim", c_i32), ("reduce", c_i32),
+                ("out", vp), ("out_stride", c_i32), ("has_drop", c_i32), ("drop", PgDropout), ("prof", vp),
+                ("prof_ring", c_i32), ("_pad", c_i32)]
+
+
+class PgBatchPlan(ctypes.Structure):
+    _fields_ = [("load_stream", vp), ("ev_sampled", vp), ("ev_ready", vp), ("ids", vp), ("rows", c_i64), ("slot_map", vp),
+                ("slots_out", vp), ("stats", vp), ("sampler", vp), ("desc", PgNodeflowDesc), ("transpose", c_i32),
+                ("n_early", c_i32), ("early", PgBatchEarly * PG_MAX_LAYERS), ("label_ids", vp), ("n_label_rows", c_i64),
+                ("labels", vp), ("labels_len", c_i64), ("label_fill", c_i64), ("label_out", vp), ("n_valid", vp),
+                ("label_scratch", vp)]
+
+
 class PgError(RuntimeError):
     pass
 
@@ -77,6 +91,7 @@ _SIGS = {
     "pg_bounds_region": (ctypes.c_int, [vp, c_i64]),
     "pg_bounds_report": (ctypes.c_int, [ctypes.POINTER(c_u64), ctypes.c_char_p, c_i32, c_i32]),
     "pg_device_cu_count": (ctypes.c_int, []),
+    "pg_batch_prepare": (ctypes.c_int, [ctypes.POINTER(PgBatchPlan), c_u64]),
     "pg_tape_from_graph": (ctypes.c_int, [vp, ctypes.POINTER(vp), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     "pg_tape_launch": (ctypes.c_int, [vp, vp]),
     "pg_tape_destroy": (ctypes.c_int, [vp]),

@@ -409,6 +409,10 @@ class GraphedTrainer:
         s.agg0 = None          # ... and their outputs {block: [destination capacity, padded dim]}
         s.early_call = None    # ... and the cached arguments of its launch
         s.early_training = None  # ... and the model's mode (train / eval) they were aggregated in
+        s.batch_plan = None      # pg_batch_plan_t of the slot's load-stream work (prepare as ONE C call), or False
+        s.batch_key = None       # ... and what it was built over
+        with torch.cuda.stream(self.load_stream):
+            s.ready.record()     # (torch creates an event's handle at its first record: pg_batch_prepare needs it)
         # allocated on the load stream, read by the captured step on the compute stream (and by the sampler's chain when it
         # clears through the previous ids): see L.record_streams
         L.record_streams([s.out, s.label, s.n_valid3], [self.compute_stream, self.load_stream, self.sampler.stream])
@@ -440,6 +444,11 @@ class GraphedTrainer:
             ls.wait_event(s.done)                # the graph that read these buffers has finished
         if dbg is not None:
             ev[2].record(ls)
+        if s.batch_plan and dbg is None and not s.done_recorded and self._prepare_native(nf, s):
+            if s.nf is None:
+                s.nf = nf
+            s.nf_cur = nf
+            return s
         ls.wait_event(nf._slot.ready)            # the sampler wrote this NodeFlow on its own stream
         # no `with torch.cuda.stream(...)`, no tensor ops: everything below is a C-ABI call given the stream
         # explicitly (the launch thread is the bottleneck of a ~0.2 ms step)
@@ -459,6 +468,7 @@ class GraphedTrainer:
             else:
                 with torch.cuda.stream(ls):
                     s.plan = self._plan_for(nf, s)
+            s.batch_plan = None
         if s.plan is not False:
             self.cacher.fetch_planned(s.plan, ids, ls, slot=s.slot_index)      # (allocates under `ls` itself where it must)
         else:
@@ -482,6 +492,8 @@ class GraphedTrainer:
         if dbg is not None:
             ev[3].record(ls)
             dbg.append(ev)
+        if s.batch_plan is None:
+            s.batch_plan = self._build_batch_plan(nf, s)      # from the slot's next batch on: one C call (False: not this shape)
         # the static NodeFlow views of a slot are rebuilt per batch but alias the same memory:
         # keep the first one (the graph captured ITS tensors) and only refresh the frames
         if s.nf is None:
@@ -563,6 +575,81 @@ class GraphedTrainer:
                 keep.append((rs, nf.blk_indptr[blk], nf.blk_src[blk], prof, rows))
             call = s.early_call = (s.early, m.training, launches, keep)
         return call
+
+    # -- prepare() as one C call (round 5) --------------------------------------------------------------------------
+    def _build_batch_plan(self, nf, s):
+        """pg_batch_plan_t for this ring slot, or False when the slot's load-stream work is not the shape pg_batch_prepare
+        covers: a table resident in HBM whose fetched rows are all read in place (the slot look-up is the whole fetch),
+        deferred transposes, the self-cleaning label look-up. PG_NATIVE_PREPARE=0 keeps the call-by-call sequence."""
+        import os as _os
+        c, plan = self.cacher, s.plan
+        if (_os.environ.get("PG_NATIVE_PREPARE", "1") == "0" or plan is None or plan is False or not plan.virtual
+                or plan.dense_rows != 0 or not c.full_cached or _LABELS_MEMSET):
+            return False
+        o0, o1 = nf._layer_offsets[-2], nf._layer_offsets[-1]
+        if o1 <= o0 or getattr(nf._slot.ready, "cuda_event", None) in (None, 0) or getattr(s.ready, "cuda_event", None) in (None, 0):
+            return False
+        ids = nf._node_mapping.tousertensor()
+        bp = L.PgBatchPlan()
+        bp.load_stream = self.load_stream.cuda_stream
+        bp.ev_sampled = nf._slot.ready.cuda_event
+        bp.ev_ready = s.ready.cuda_event
+        bp.ids = ids.data_ptr() + 8 * plan.row_lo
+        bp.rows = plan.rows
+        bp.slot_map = L.ptr(c.slot_map).value
+        bp.slots_out = L.ptr(plan.slots).value
+        bp.stats = L.ptr(c._stats).value if c.log else None
+        bp.transpose = 1 if self.sampler.defer_transpose else 0
+        bp.sampler = self.sampler.handle.value if self.sampler.defer_transpose else None
+        bp.desc = nf._slot.desc
+        bp.n_early = 0
+        bp.label_ids = ids.data_ptr() + 8 * o0
+        bp.n_label_rows = o1 - o0
+        bp.labels = L.ptr(self.labels).value
+        bp.labels_len = self.labels.numel()
+        bp.label_fill = -100
+        bp.label_out = L.ptr(s.label).value
+        bp.n_valid = L.ptr(s.n_valid).value
+        bp.label_scratch = s.n_valid3.data_ptr() + 4
+        s.batch_key = (plan, c.log, None)
+        return bp
+
+    def _prepare_native(self, nf, s):
+        """prepare() of a slot that has a batch plan; False = the plan no longer fits (the caller runs the generic sequence
+        and builds a new one)"""
+        c, bp = self.cacher, s.batch_plan
+        if s.plan is None or s.plan is False or s.plan.cache_epoch != c._cache_epoch or s.batch_key[0] is not s.plan \
+                or s.batch_key[1] != c.log:
+            s.batch_plan = None
+            return False
+        step_value = 0
+        if s.early is not None:
+            call = self._early_args(nf, s, self.load_stream)
+            if s.batch_key[2] is not call:
+                # the early launches' arguments, once per (slot, plan, model mode): the C struct's copies of what
+                # _aggregate_early passes call by call
+                if len(call[2]) > L.PG_MAX_LAYERS:
+                    s.batch_plan = False
+                    return False
+                for i, ((args, d), (blk, _f, rows)) in enumerate(zip(call[2], s.early)):
+                    e = bp.early[i]
+                    out = s.agg0[blk]
+                    e.indptr, e.src = L.ptr(nf.blk_indptr[blk]).value, L.ptr(nf.blk_src[blk]).value
+                    e.rows = rows.struct()
+                    e.n_dst, e.dim, e.reduce = int(out.size(0)), rows.dim, args[5]
+                    e.out, e.out_stride = L.ptr(out).value, out.stride(0)
+                    e.has_drop = 1 if d is not None else 0
+                    if d is not None:
+                        e.drop = d
+                    prof, ring = (rows.prof[0], rows.prof[1]) if rows.prof is not None else (None, 0)
+                    e.prof, e.prof_ring = (L.ptr(prof).value if prof is not None else None), ring
+                bp.n_early = len(call[2])
+                s.batch_key = (s.batch_key[0], s.batch_key[1], call)
+            step_value = self.early_ordinal
+        L.check(self._lib.pg_batch_prepare(ctypes.byref(bp), step_value), "pg_batch_prepare")
+        if s.early is not None:
+            s.early_training = self._bare_model().training
+        return True
 
     def _frames_for(self, s):
         rs = s.plan.row_sources if s.plan else {}
