@@ -329,3 +329,22 @@ def test_huge_page_tensor_is_an_ordinary_tensor():
     assert torch.equal(v, ref[100:200, 3:9])
     e, _ = huge_page_tensor((0, 5))
     assert e.numel() == 0
+
+
+def test_record_streams_walks_owners_without_a_gpu():
+    """_lib.record_streams (the allocator-side lifetime rule: tensor.record_stream for every foreign stream an owner's buffers
+    meet) walks tensors, containers, modules, optimisers and pagraph_amd objects; CPU tensors and `None` streams are skipped."""
+    import torch
+    from pagraph_amd import _lib
+    from pagraph_amd.model import GCNSampling
+    m = GCNSampling(8, 4, 3, 1, torch.relu, 0.0)
+    opt = torch.optim.Adam(m.parameters())
+    loss = sum((p * p).sum() for p in m.parameters())
+    loss.backward()
+    opt.step()
+    cyc = {"a": [torch.zeros(3), (torch.ones(2), None)], "m": m, "o": opt}
+    cyc["self"] = cyc                                   # cycles do not recurse for ever
+    _lib.record_streams(cyc, [None])                    # no stream: nothing to do
+    _lib.record_streams(cyc, [object()])                # CPU tensors: never touched
+    _lib.safe_stream_wait(None)
+    assert _lib.del_waits_enabled() is True
