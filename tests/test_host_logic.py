@@ -348,3 +348,38 @@ def test_record_streams_walks_owners_without_a_gpu():
     _lib.record_streams(cyc, [object()])                # CPU tensors: never touched
     _lib.safe_stream_wait(None)
     assert _lib.del_waits_enabled() is True
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """every struct that crosses the C-ABI by value or by pointer (include/pagraph_hip.h) has the same size and field offsets
+    in pagraph_amd/_lib.py's ctypes mirror: compiled with gcc from the header itself"""
+    import ctypes
+    import shutil
+    import subprocess
+    from pagraph_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    pairs = {"pg_field_t": _lib.PgField, "pg_nodeflow_desc_t": _lib.PgNodeflowDesc, "pg_missq_field_t": _lib.PgMissqField,
+             "pg_row_source_t": _lib.PgRowSource, "pg_dedup_t": _lib.PgDedup, "pg_dropout_t": _lib.PgDropout,
+             "pg_batch_early_t": _lib.PgBatchEarly, "pg_batch_plan_t": _lib.PgBatchPlan}
+    # C field names where the mirror uses another (padding) name are skipped; every other field is compared by name
+    lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{os.path.join(ROOT, "include", "pagraph_hip.h")}"', "int main(void) {"]
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            if fname.startswith("_pad"):
+                continue
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    r = subprocess.run(["gcc", "-o", str(exe), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True).stdout.split("\n")
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in out if l.strip()}
+    for cname, cls in pairs.items():
+        assert got[(cname, "size")] == ctypes.sizeof(cls), (cname, got[(cname, "size")], ctypes.sizeof(cls))
+        for fname, _ in cls._fields_:
+            if not fname.startswith("_pad"):
+                assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
