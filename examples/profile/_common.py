@@ -136,6 +136,7 @@ def trainer(rank, world_size, args, arch, backend='nccl'):
     if rank == 0 and args.profile:
         print(prof.key_averages().table(sort_by='cuda_time_total'))
     print('Total Time: {:.4f}s'.format(toc - tic))
+    loop.close(); sampler.close(); cacher.close()       # deterministic teardown (streams waited for, library handles released)
     dist.destroy_process_group()
 
 
