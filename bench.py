@@ -149,6 +149,15 @@ def parse():
                    "N-rank path (collectives, dg, closures, miss queues, captures, replica check) before the big set-up")
     p.add_argument("--no-configs", action="store_true", help="do not append the `configs` block (BASELINE configs 2 and 3, each "
                    "timed by a child run of this script) to the headline line")
+    p.add_argument("--as-rank-of", type=int, default=0, metavar="P",
+                   help="ONE GPU only (round 6): run ONE rank's share of a P-GPU job — dg over P partitions on the host, the rank "
+                        "with the largest closure (or --which-rank), its own closure / local-out-degree cache / seeds, the N > 1 "
+                        "step shape over a one-rank RCCL group (flat gradient buffer, all-reduce in the step), one epoch of the "
+                        "step count all P ranks would run after MAX-equalisation. Reports a PROJECTED epoch time (equalised "
+                        "steps x this rank's ms/step), labelled as such: RCCL across ranks is the one thing it cannot show")
+    p.add_argument("--which-rank", type=int, default=None, help="--as-rank-of: the partition to run (default: largest closure)")
+    p.add_argument("--dist-step", action="store_true", help="one GPU: the N > 1 step shape (one-rank RCCL group, trainer "
+                   "world_size 2) over the 1naive partition — the A/B partner of the default one-GPU step")
     p.add_argument("--no-adapt-cpu-share", action="store_true", help="keep --cpu-share as given; default: after the set-up "
                    "steps every rank sets it from its own CPU-gather rate vs PCIe (GraphCacheServer.adapt_cpu_share)")
     return p.parse_args()
@@ -602,10 +611,16 @@ CONFIG_LEGS = (
     # config 3: the headline graph with config 3's own model — GraphSAGE-mean, hidden 16, lr 1e-2 (pa_gs.py:134,141) — and the
     # 30 % hot-degree cache: one whole epoch (1 084 steps)
     ("config3_rmat_10M_graphsage_30pct_cache", ["--model", "graphsage", "--cache-ratio", "0.30"]),
+    # config 4 (round 6): the headline graph partitioned by dg x 4 with --num-hops 2 (README.md:117), ONE rank's share — the
+    # partition with the largest closure, its cache by LOCAL out-degree (storage.py:100) — through the N > 1 step shape over a
+    # one-rank RCCL group, for the step count the four ranks would agree on. A projection of the 4-GPU epoch, not a measurement
+    ("config4_rank_of_4", ["--as-rank-of", "4", "--dg-hops", "2", "--cache-ratio", "0.30"]),
+    # config 5: 10^8 vertices / 10^9 edges, dg x 8, one rank's share, features in host DRAM (240 GB) with the async miss path
+    ("config5_rank_of_8", ["--vertices", "100000000", "--edges", "1000000000", "--as-rank-of", "8", "--cache-ratio", "0.30"]),
 )
 
 
-def config_legs(args, budget_s=150.0):
+def config_legs(args, budget_s=420.0):
     import subprocess
     out = {}
     t_all = time.time()
@@ -638,6 +653,12 @@ def config_legs(args, budget_s=150.0):
                 "roofline": {k_: rf.get(k_) for k_ in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms",
                                                        "launches_timed", "algorithmic_bytes_per_launch", "kernel_body_ms")},
                 "leg_wall_s": time.time() - t0}
+            if d["config"].get("rank_of_P"):
+                out[name]["rank_of_P"] = d["config"]["rank_of_P"]
+                out[name]["step_shape"] = d["config"]["step_shape"]
+                out[name]["step_replay"] = d["config"]["step_replay"]
+                out[name]["allreduce_in_graph"] = d["config"]["allreduce_in_graph"]
+                out[name]["projected_epoch_s"] = d["config"]["rank_of_P"]["projected_epoch_s"]
         except Exception as e:                      # a leg that fails must not take the headline line with it
             out[name] = {"error": f"{type(e).__name__}: {str(e)[-800:]}", "leg_wall_s": time.time() - t0}
         log(f"[bench] configs block: {name} -> {json.dumps(out[name])[:300]}")
@@ -677,6 +698,16 @@ def run():
     gpu = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(gpu)
     dev = torch.device("cuda", gpu)
+    # ---- one rank's share of a P-GPU job on this one GPU (--as-rank-of P) / the N > 1 step shape alone (--dist-step) ----
+    emul_P = int(args.as_rank_of) if world == 1 else 0
+    dist_step = bool(world == 1 and (emul_P > 1 or args.dist_step))
+    step_world = world if world > 1 else (max(2, emul_P) if dist_step else 1)     # what the trainer is told
+    if dist_step:
+        import socket
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_), RANK="0", WORLD_SIZE="1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1)      # REAL RCCL, of one rank: all a one-GPU box can host
 
     from pagraph_amd import _lib as L
     from pagraph_amd import parallel
@@ -730,7 +761,34 @@ def run():
     del deg_d
     # ---- partition ------------------------------------------------------------------------
     t0 = time.time()
-    if world == 1:
+    share_rec_p = None
+    if world == 1 and emul_P > 1:
+        # dg over P partitions exactly as rank 0 of a P-GPU run does it (dg.py:59-103), then EVERY partition's closure — their
+        # sizes are what the question is about — and the step count the P ranks would agree on (parallel.equalize_steps = MAX)
+        t_dg = time.time()
+        b, _, p_vnum, r_vnum = dg_raw(emul_P, indptr.cpu().numpy(), indices.cpu().numpy(), V, train_full.numpy(), args.dg_hops)
+        dg_s = time.time() - t_dg
+        belongs_d = torch.from_numpy(b).to(dev)
+        log(f"[bench] dg P={emul_P} hops={args.dg_hops}: {dg_s:.1f}s p_vnum={p_vnum.tolist()} r_vnum={r_vnum.tolist()}")
+        parts = []
+        t_cl = time.time()
+        for r_ in range(emul_P):
+            tr_ = torch.nonzero(belongs_d == r_).squeeze(1)
+            _ip, _ix, s2f_, st_ = closure_device(g_full, tr_.cpu(), num_hops)
+            parts.append({"rank": r_, "train_vertices": int(tr_.numel()), "partition_vertices": int(s2f_.numel()),
+                          "partition_nnz": int(_ix.numel()), "steps": -(-int(st_.numel()) // B)})
+            del _ip, _ix, s2f_, st_
+        cl_s = time.time() - t_cl
+        which = args.which_rank if args.which_rank is not None else max(parts, key=lambda e: e["partition_vertices"])["rank"]
+        eq_steps = max(e["steps"] for e in parts)
+        share_rec_p = {"P": emul_P, "dg_hops": args.dg_hops, "dg_seconds": dg_s, "closures_seconds": cl_s, "p_vnum": p_vnum.tolist(),
+                       "r_vnum": r_vnum.tolist(), "partitions": parts, "rank_run": which,
+                       "rank_chosen_by": "--which-rank" if args.which_rank is not None else "largest closure",
+                       "equalised_steps_per_epoch": eq_steps, "equalisation": "MAX over the P partitions' own step counts "
+                       "(parallel.equalize_steps); a rank that runs out of seeds wraps around"}
+        my_train = torch.nonzero(belongs_d == which).squeeze(1).cpu()
+        del belongs_d
+    elif world == 1:
         my_train = train_full
     else:
         belongs = torch.empty(V, dtype=torch.int8)
@@ -786,7 +844,7 @@ def run():
     store = HostFeatureStore(fields, pin=False,               # both tables are already pinned / registered
                              device_visible={"features": table_device_visible, "norm": True})
     cacher = GraphCacheServer(store, Vs, sub2full, gpu, miss_mode=args.miss_mode,
-                              host_threads=args.host_threads or default_host_threads(world))
+                              host_threads=args.host_threads or default_host_threads(max(world, emul_P, 1)))
     cacher.init_field(embed_names)
     cacher.log = True
     if world > torch.cuda.device_count():
@@ -833,12 +891,15 @@ def run():
                               transpose=None if args.no_transpose else 'auto',
                               defer_transpose=use_graph and not args.inline_transpose)
     steps_per_epoch = parallel.equalize_steps(len(sampler), device=dev)
+    if share_rec_p is not None:
+        share_rec_p["own_steps_per_epoch"] = int(steps_per_epoch)
+        steps_per_epoch = int(share_rec_p["equalised_steps_per_epoch"])       # what all P ranks would run (cycle_batches wraps)
     # default: one whole epoch of this rank's seeds (1084 steps at N = 1: a quarter of a second), nothing extrapolated
     K = args.steps if args.steps is not None else min(steps_per_epoch, 5000)
     W = args.warmup
     S = 1                                                # set-up steps: the cache is filled after the first one
     if use_graph:
-        trainer = GraphedTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, need=need, world_size=world,
+        trainer = GraphedTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, need=need, world_size=step_world,
                                  keep_losses=False, lookahead=args.lookahead)
         S = 3 + 2 * len(sampler.slots)                   # eager warm-up + one capture and first replay per ring slot
         trainer.keep_primed = not args.cold_start
@@ -1221,7 +1282,7 @@ def run():
                                    "end): no dependent dense / head launch followed it"}
     traffic, traffic_src = pmc_traffic(fused_rec["kernel"] if fused_rec else "k_gather")
     default_workload = (V, E, Fdim, B, k, args.model, args.cache_ratio) == (10_000_000, 100_000_000, 600, 6000, 2, "gcn", 0.30)
-    if not default_workload or world > 1:
+    if not default_workload or world > 1 or dist_step:
         traffic, traffic_src = None, "no PMC pass committed for this workload"
 
     dom = fused_rec or gather_rec or {"kernel": "k_gather", "achieved": float("nan"), "frac": float("nan")}
@@ -1253,7 +1314,7 @@ def run():
         del probe, freq
 
     ref_eq = None
-    if world == 1 and use_graph and not args.skip_reference_equivalent and need is not None and not cacher.full_cached:
+    if world == 1 and not dist_step and use_graph and not args.skip_reference_equivalent and need is not None and not cacher.full_cached:
         # single-GPU lines only (like cpu_baseline): a second trainer would re-bind the flat gradient buffer
         ref_eq = reference_equivalent_leg(args, model, loss_fcn, optimizer, cacher, g, subtrain, labels, dev, world, rank)
         ref_eq["roofline_frac_optimised_path_for_comparison"] = roofline["frac"]
@@ -1261,7 +1322,7 @@ def run():
         ref_eq = "this run itself fetches every layer and field"
 
     cpu = None
-    if rank == 0 and world == 1 and not args.skip_cpu_baseline:
+    if rank == 0 and world == 1 and not dist_step and not args.skip_cpu_baseline:
         labels_h = labels.cpu()
         cpu_args = (args, g, sub2full.cpu().numpy(), sampler.seeds.cpu().numpy(), feat_tab,
                     norm_tab if norm_tab is not None else torch.zeros((V, 1)), labels_h, steps_per_epoch)
@@ -1286,7 +1347,7 @@ def run():
             "epoch_s_local": reg_epoch["elapsed"] * steps_per_epoch / reg_epoch["steps"],
             "cache_hit_pct_rows_fetched": 100.0 * (1.0 - miss_rate), "cpu_share": cacher.cpu_share, "cpu_share_adapt": share_rec,
             "miss_mode": cacher.miss_mode, "miss_wait": "host" if cacher.host_wait else "device",
-            "allreduce_in_graph": getattr(trainer, "allreduce_in_graph", None) if world > 1 else None,
+            "allreduce_in_graph": getattr(trainer, "allreduce_in_graph", None) if (world > 1 or dist_step) else None,
             "miss_mode_probe": mode_probe, "host": dict(host_info(cacher), timed_region_cgroup=cpu_quota),
             "miss_queue": mq_stats, "host_longest_iterations_ms": host_longest,
             "slowest_window_ms_per_step": max(windows) if windows else None}
@@ -1306,7 +1367,22 @@ def run():
                                    f"2-layer {'GCN' if args.model == 'gcn' else 'GraphSAGE-mean'} hidden {hidden}, "
                                    f"batch {B}, fan-out {k}, {int(args.cache_ratio*100)}% "
                                    f"{'hot-degree' if args.cache_policy == 'degree' else 'presampled-frequency (opt-in policy)'} cache, "
-                                   f"{('dg(hops=%d)' % args.dg_hops) if world > 1 else '1naive'} partition x{world}, closure hops {num_hops}",
+                                   f"{('dg(hops=%d)' % args.dg_hops) if (world > 1 or emul_P > 1) else '1naive'} partition "
+                                   f"x{emul_P if emul_P > 1 else world}, closure hops {num_hops}"
+                                   + (f" — ONE rank's share (partition {share_rec_p['rank_run']}: {share_rec_p['rank_chosen_by']}) on one "
+                                      f"GPU through the N > 1 step shape over a one-rank RCCL group; NOT a scaling number"
+                                      if share_rec_p else (" — N > 1 step shape over a one-rank RCCL group" if dist_step else "")),
+                       # --as-rank-of P: what dg did to the closures, the rank that was run, and the projection
+                       "rank_of_P": (dict(share_rec_p, ms_per_step=reg_epoch["ms_per_step"],
+                                          cache_hit_pct_rows_fetched=100.0 * (1.0 - miss_rate), cached_rows=int(cacher.cached_num),
+                                          partition_vertices_run=Vs, host_threads=cacher.host_threads,
+                                          projected_epoch_s=share_rec_p["equalised_steps_per_epoch"] * reg_epoch["ms_per_step"] / 1e3,
+                                          projected_epoch_s_is="a PROJECTION: equalised steps x the measured ms/step of the rank with "
+                                          "the largest closure, alone on its GPU and its host share; the all-reduce ran over a "
+                                          "one-rank RCCL group (no xGMI traffic, no waiting for slower ranks)")
+                                     if share_rec_p else None),
+                       "step_shape": ("N > 1 (flat gradient buffer, reduce-only sums + all-reduce + Adam) over a one-rank RCCL group, "
+                                      f"trainer world_size {step_world}" if dist_step else ("N > 1" if world > 1 else "one GPU")),
                        "steps_per_epoch": steps_per_epoch, "epoch_steps_timed": reg_epoch["steps"],
                        "epoch_ms_per_step": reg_epoch["ms_per_step"], "window_ms_per_step": reg_win["ms_per_step"],
                        "window_ms_per_step_windows": reg_win["windows"],
@@ -1315,7 +1391,7 @@ def run():
                        "setup_steps": S, "pipeline": "cold (drained before the timed region)" if args.cold_start else "primed",
                        "miss_mode": args.miss_mode, "miss_wait": "host" if cacher.host_wait else "device",
                        "miss_mode_probe": mode_probe, "overlap": not args.no_overlap,
-                       "partition_vertices": Vs, "dg_hops": args.dg_hops if world > 1 else None,
+                       "partition_vertices": Vs, "dg_hops": args.dg_hops if (world > 1 or emul_P > 1) else None,
                        "dg_hops2_cost": {"sum_deg_squared": sum_deg_sq, "estimated_seconds_one_committer": dg_hops2_est_s,
                                          "basis": "4.7e10 adjacency entries in 68 s (10M/100M graph, 16 host threads)"},
                        "hip_graph_step": use_graph,
@@ -1327,7 +1403,7 @@ def run():
                        # block 0's aggregation launched ahead of its step on the load stream (GraphedTrainer.early_aggregate:
                        # 'auto' = when the whole table is cached)
                        "early_layer0_aggregation": bool(early_agg),
-                       "allreduce_in_graph": getattr(trainer, "allreduce_in_graph", None) if world > 1 else None,
+                       "allreduce_in_graph": getattr(trainer, "allreduce_in_graph", None) if (world > 1 or dist_step) else None,
                        "fetch": "all layers+fields (reference)" if need is None else "only what the model reads"},
             # headline = the reference's counting (every row of every layer, storage.py:203-204,219-227): from the
             # reference-equivalent leg when the timed loop itself fetches only what the model reads
@@ -1356,9 +1432,10 @@ def run():
             "ranks": per_rank,
             # (main() replaces this by the `configs` block: BASELINE configs 2 and 3 as child runs, for the headline workload
             # on one GPU only — the small-graph runs of the tests and the N > 1 lines do not spawn full-size children)
-            "_wants_configs": bool(default_workload and world == 1 and not args.no_configs and use_graph and not args.fetch_all),
+            "_wants_configs": bool(default_workload and world == 1 and not dist_step and not args.no_configs and use_graph
+                                   and not args.fetch_all),
         }
-    if world > 1:
+    if world > 1 or dist_step:
         dist.barrier()
         dist.destroy_process_group()
     return out

@@ -576,11 +576,11 @@ int pg_xent_bwd(const float* dlogits, int32_t d_stride, int64_t n, int32_t C, co
  *   not counted. partials: pg_gcn_head_scratch(n_dst, K, C) floats. drop may be NULL. Deterministic.          */
 int64_t pg_gcn_head_scratch(int64_t n_dst, int32_t K, int32_t C);
 /* floats between two blocks' rows of that scratch: [C * K] dW | [C] db | [1] loss, padded to a multiple of 4 — the
- * `part_len` a caller hands pg_adam_step_partials when it lets the optimiser add the rows up (sum_partials = 0)   */
+ * `part_len` a caller puts into pg_adam_tensor_t when it lets the optimiser add the rows up (sum_partials = 0)   */
 int32_t pg_gcn_head_row_len(int32_t K, int32_t C);
 /* pg_gcn_head_ex / pg_linear_bwd_w_ex: the same with `sum_partials` = 0 leaving the per-block / per-chunk partial rows
  * un-summed in `partials` ([rows][C*K + C + 1] resp. [rows][N*K + N], rows = scratch size / row length) for
- * pg_adam_step_partials; dW / db(_loss) are then not written.                                            */
+ * pg_adam_step; dW / db(_loss) are then not written.                                                     */
 /* The same head for GraphSAGE's output NodeUpdate z = fc_neigh(agg) + fc_self(h_self) (graphsage_nssc.py:24, the last layer of
  * graphsage_nssc.py:55-72; round 4): h_self [n_dst, >= Ks] is the destinations' own input (not aggregated, not dropped), W_self
  * [C, Ks], bias_self [C] or NULL; K + Ks <= 64. dself [n_dst, Ks] = dZ W_self. Partial rows: pg_gcn_head_scratch(n_dst, K + Ks, C)
@@ -685,43 +685,53 @@ int pg_gcn_head(const int32_t* indptr, const int32_t* src, const float* h, int32
 /* Optimiser step — torch.optim.Adam(model.parameters(), lr, weight_decay) of examples/profile/pa_gcn.py:137-139
  * (amsgrad off, maximize off), same arithmetic as torch's: g += wd * p; m = b1 m + (1 - b1) g;
  * v = b2 v + (1 - b2) g^2; p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps), t = *step_dev + 1.
- * One launch for up to PG_ADAM_MAX_TENSORS fp32 tensors (host arrays of device pointers + element counts).
- * *step_dev (device int64, completed steps) is advanced by the kernel; ticket_dev is one device uint32 the
- * caller zeroes once.                                                                                 */
+ * ONE launch for up to PG_ADAM_MAX_TENSORS fp32 tensors, described by a pg_adam_desc_t (round 6: the three entry points
+ * with up to 24 positional arguments are gone). *step_dev (device int64, completed steps) is advanced by the kernel's last
+ * block; ticket_dev is one device uint32 the caller zeroes once; bump_dev (device int64, may be NULL) is advanced by one
+ * together with *step_dev — the model's dropout step counter, which saves the step's separate increment launch.
+ *
+ * Per tensor: partials == NULL -> the gradient is read from grad[] as is. Otherwise element o of the gradient is the sum
+ * over part_chunks rows of partials[c * part_len + part_off + o] — the un-summed per-chunk rows pg_linear_bwd_w_ex /
+ * pg_gcn_head_ex leave with sum_partials = 0 — added in exactly pg_sum_partials' order (bit-identical) and stored to grad[].
+ * partials2 (may be NULL): a SECOND set of rows for a parameter that is applied twice per step — GraphSAGE's NodeUpdate
+ * `lid` runs on every block >= lid (graphsage_nssc.py:92-131) — gradient = sum(partials) + sum(partials2), what autograd's
+ * accumulation of the two summed contributions yields. is_adam == 0: reduce only (param / exp_avg / exp_avg_sq may be
+ * NULL) — pg_gcn_head's loss scalar lives in the same rows.
+ *
+ * mode PG_ADAM_FULL: sums + update. PG_ADAM_REDUCE_ONLY: only the sums are written to grad[] (every tensor must have
+ * partials; step / ticket / bump are not touched) — the N > 1 step: grad[] are views of the flat buffer the gradient
+ * all-reduce (pa_gcn.py:65,96: DDP) works on, and a second, plain PG_ADAM_FULL launch applies the update behind it.  */
 #define PG_ADAM_MAX_TENSORS 16
-int pg_adam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
-                 float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
-                 float weight_decay, int64_t* step_dev, uint32_t* ticket_dev, pg_stream_t stream);
-/* Mirror a step counter to the host: from now on every pg_adam_step* launch given `step_dev` also writes the new step
+#define PG_ADAM_FULL 0
+#define PG_ADAM_REDUCE_ONLY 1
+typedef struct pg_adam_tensor {
+  float* param;
+  float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t numel;
+  const float* partials;
+  const float* partials2;
+  int32_t part_chunks, part_len, part_off;
+  int32_t part2_chunks, part2_len, part2_off;
+  int32_t is_adam, _pad;
+} pg_adam_tensor_t;
+typedef struct pg_adam_desc {
+  int32_t n_tensors, mode;
+  float lr, beta1, beta2, eps, weight_decay, _pad;
+  int64_t* step_dev;
+  uint32_t* ticket_dev;
+  int64_t* bump_dev;
+  pg_adam_tensor_t t[PG_ADAM_MAX_TENSORS];
+} pg_adam_desc_t;
+int pg_adam_step(const pg_adam_desc_t* desc, pg_stream_t stream);
+/* Mirror a step counter to the host: from now on every pg_adam_step launch given `step_dev` also writes the new step
  * count to *mirror_host (pinned host memory mapped into the device; NULL = stop), from its last block, after the device
  * counter. A launch thread that recycles per-step buffers can then POLL "step n has run" in its own memory instead of
  * recording an event on the compute stream (an event costs the stream that records it ~5 us, ~13 when another stream
  * waits for it). The kernels are the last launches of a training step, so "the optimiser of step n has started its last
  * block" implies every earlier kernel of that step has finished. Up to 16 registered counters per process.          */
 int pg_adam_step_mirror(int64_t* step_dev, int64_t* mirror_host);
-/* The same step with the ordered partial sums of pg_linear_bwd_w_ex / pg_gcn_head_ex (sum_partials = 0) folded in:
- * tensor i's gradient element o = grads[i][o] when partials[i] == NULL, else the sum over part_chunks[i] rows of
- * partials[i][c * part_len[i] + part_off[i] + o], added in exactly pg_sum_partials' order (bit-identical result) and
- * stored to grads[i]. is_adam[i] == 0: reduce only (params / exp_avg / exp_avg_sq [i] may be NULL) — pg_gcn_head's
- * loss scalar. Three launches of the replayed GCN step (two partial sums + Adam) become one. bump_dev (device
- * int64, may be NULL) is advanced by one together with *step_dev: the model's dropout step counter, which saves the
- * step's separate counter-increment launch.                                                             */
-int pg_adam_step_partials(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
-                          float* const* exp_avg_sq, const int64_t* numel, const float* const* partials,
-                          const int32_t* part_chunks, const int32_t* part_len, const int32_t* part_off,
-                          const int32_t* is_adam, float lr, float beta1, float beta2, float eps, float weight_decay,
-                          int64_t* step_dev, uint32_t* ticket_dev, int64_t* bump_dev, pg_stream_t stream);
-/* the same with a SECOND set of partial rows per tensor (partials2[i] may be NULL): a parameter that is applied twice
- * per step — GraphSAGE's NodeUpdate `lid` runs on every block >= lid (graphsage_nssc.py:92-131) — gets
- * sum(partials) + sum(partials2), each summed in pg_sum_partials' order, i.e. exactly what autograd's accumulation of
- * the two summed contributions yields (a two-term fp32 add commutes).                                       */
-int pg_adam_step_partials2(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
-                           float* const* exp_avg_sq, const int64_t* numel, const float* const* partials,
-                           const int32_t* part_chunks, const int32_t* part_len, const int32_t* part_off,
-                           const float* const* partials2, const int32_t* part2_chunks, const int32_t* part2_len,
-                           const int32_t* part2_off, const int32_t* is_adam, float lr, float beta1, float beta2,
-                           float eps, float weight_decay, int64_t* step_dev, uint32_t* ticket_dev, int64_t* bump_dev,
-                           pg_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 4. Offline partitioning (host)  —  PaGraph/partition/dg.py:59-103

@@ -23,6 +23,7 @@ PG_MAX_LAYERS = 8
 PG_HEAVY_ROW = 32
 PG_ADAM_MAX_TENSORS = 16
 PG_HEAD_SUM_PARTIALS, PG_HEAD_DAGG_PER_EDGE = 1, 2
+PG_ADAM_FULL, PG_ADAM_REDUCE_ONLY = 0, 1
 PG_REDUCE_MEAN = 0
 PG_REDUCE_SUM = 1
 PG_REDUCE_MAX = 2
@@ -77,6 +78,18 @@ class PgBatchPlan(ctypes.Structure):
                 ("n_early", c_i32), ("early", PgBatchEarly * PG_MAX_LAYERS), ("label_ids", vp), ("n_label_rows", c_i64),
                 ("labels", vp), ("labels_len", c_i64), ("label_fill", c_i64), ("label_out", vp), ("n_valid", vp),
                 ("label_scratch", vp)]
+
+
+class PgAdamTensor(ctypes.Structure):
+    _fields_ = [("param", vp), ("grad", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("numel", c_i64), ("partials", vp),
+                ("partials2", vp), ("part_chunks", c_i32), ("part_len", c_i32), ("part_off", c_i32), ("part2_chunks", c_i32),
+                ("part2_len", c_i32), ("part2_off", c_i32), ("is_adam", c_i32), ("_pad", c_i32)]
+
+
+class PgAdamDesc(ctypes.Structure):
+    _fields_ = [("n_tensors", c_i32), ("mode", c_i32), ("lr", ctypes.c_float), ("beta1", ctypes.c_float),
+                ("beta2", ctypes.c_float), ("eps", ctypes.c_float), ("weight_decay", ctypes.c_float), ("_pad", ctypes.c_float),
+                ("step_dev", vp), ("ticket_dev", vp), ("bump_dev", vp), ("t", PgAdamTensor * PG_ADAM_MAX_TENSORS)]
 
 
 class PgError(RuntimeError):
@@ -177,12 +190,7 @@ _SIGS = {
     "pg_gcn_head": (ctypes.c_int, [vp, vp, vp, c_i32, c_i32, vp, vp, c_i32, vp, c_i64, vp, vp, vp, ctypes.c_int,
                                    c_i64, vp, vp, vp, vp, vp, vp]),
     "pg_adam_step_mirror": (ctypes.c_int, [vp, vp]),
-    "pg_adam_step": (ctypes.c_int, [c_i32, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float,
-                                    ctypes.c_float, ctypes.c_float, vp, vp, vp]),
-    "pg_adam_step_partials": (ctypes.c_int, [c_i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float,
-                                             ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]),
-    "pg_adam_step_partials2": (ctypes.c_int, [c_i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float,
-                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]),
+    "pg_adam_step": (ctypes.c_int, [ctypes.POINTER(PgAdamDesc), vp]),
     "pg_gcn_head_ex": (ctypes.c_int, [vp, vp, vp, c_i32, c_i32, vp, vp, c_i32, vp, c_i64, vp, vp, vp, ctypes.c_int,
                                       c_i64, vp, vp, vp, vp, vp, c_i32, vp]),
     "pg_sage_head": (ctypes.c_int, [vp, vp, vp, c_i32, c_i32, vp, vp, vp, c_i32, c_i32, vp, vp, c_i32, vp, c_i64, vp, vp, vp,

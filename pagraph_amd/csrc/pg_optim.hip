@@ -21,6 +21,7 @@ struct AdamArgs {
   float lr, beta1, beta2, eps, weight_decay;
   int64_t* step;                      // device: completed steps
   uint32_t* ticket;                   // device, zero between launches
+  int64_t* bump;                      // optional: one more device counter advanced with the step (the model's dropout step)
   int64_t* mirror;                    // optional, pinned host memory: the new step count, written by the last block
 };
 
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(256) void k_adam(const AdamArgs a) {
       const int64_t ns = *a.step + 1;
       *a.step = ns;
       *a.ticket = 0;
+      if (a.bump) *a.bump += 1;
       if (a.mirror) __hip_atomic_store(a.mirror, ns, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void k_adam_partials(const AdamPartArgs a) {
   const int64_t total = a.end[a.n_tensors - 1];
   // the bias corrections (two double-precision pow) once per block, while the partial rows are on their way
   __shared__ float s_bc[2];
-  if (threadIdx.x == 255) {
+  if (threadIdx.x == 255 && a.step) {
     const double t = (double)(*a.step + 1);
     s_bc[0] = (float)(1.0 - pow((double)a.beta1, t));
     s_bc[1] = (float)sqrt(1.0 - pow((double)a.beta2, t));
@@ -193,6 +195,7 @@ __global__ __launch_bounds__(256) void k_adam_partials(const AdamPartArgs a) {
       pp[o] = p - step_size * (m / denom);
     }
   }
+  if (!a.step) return;                  // reduce only (uniform): the sums are in g[], nothing else moves
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t done = atomicAdd(a.ticket, 1u) + 1;
@@ -244,75 +247,65 @@ extern "C" int pg_adam_step_mirror(int64_t* step_dev, int64_t* mirror_host) {
   return PG_OK;
 }
 
-extern "C" int pg_adam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
-                            float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2,
-                            float eps, float weight_decay, int64_t* step_dev, uint32_t* ticket_dev,
-                            pg_stream_t stream) {
-  if (n_tensors <= 0 || n_tensors > PG_ADAM_MAX_TENSORS || !params || !grads || !exp_avg || !exp_avg_sq || !numel ||
-      !step_dev || !ticket_dev)
-    return PG_ERR_INVALID;
-  AdamArgs a{};
-  int64_t tot = 0;
-  for (int i = 0; i < n_tensors; ++i) {
-    if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] <= 0) return PG_ERR_INVALID;
-    a.p[i] = params[i]; a.g[i] = grads[i]; a.m[i] = exp_avg[i]; a.v[i] = exp_avg_sq[i];
-    tot += numel[i];
-    a.end[i] = tot;
+// ONE entry point (round 6; it used to be three with up to 24 positional arguments): the descriptor says per tensor
+// whether the gradient is read as is or summed from one / two sets of partial rows, and per launch whether the update runs
+// (PG_ADAM_FULL) or only the sums are written to grads[] (PG_ADAM_REDUCE_ONLY: the N > 1 step — the summed gradient goes
+// straight into the flat buffer the all-reduce works on; a second, plain launch applies the update behind the collective).
+extern "C" int pg_adam_step(const pg_adam_desc_t* d, pg_stream_t stream) {
+  if (!d || d->n_tensors <= 0 || d->n_tensors > PG_ADAM_MAX_TENSORS) return PG_ERR_INVALID;
+  if (d->mode != PG_ADAM_FULL && d->mode != PG_ADAM_REDUCE_ONLY) return PG_ERR_INVALID;
+  const bool reduce_only = d->mode == PG_ADAM_REDUCE_ONLY;
+  if (!reduce_only && (!d->step_dev || !d->ticket_dev)) return PG_ERR_INVALID;
+  bool any_part = false;
+  for (int i = 0; i < d->n_tensors; ++i) {
+    const pg_adam_tensor_t& t = d->t[i];
+    if (!t.grad || t.numel <= 0) return PG_ERR_INVALID;
+    const bool upd = t.is_adam && !reduce_only;
+    if (upd && (!t.param || !t.exp_avg || !t.exp_avg_sq)) return PG_ERR_INVALID;
+    if (t.partials && (t.part_chunks <= 0 || t.part_off < 0 || (int64_t)t.part_off + t.numel > t.part_len)) return PG_ERR_INVALID;
+    if (t.partials2 && (!t.partials || t.part2_chunks <= 0 || t.part2_off < 0 || (int64_t)t.part2_off + t.numel > t.part2_len))
+      return PG_ERR_INVALID;
+    if (reduce_only && !t.partials) return PG_ERR_INVALID;          // nothing to do for a tensor without partial rows
+    any_part = any_part || t.partials != nullptr;
   }
-  a.n_tensors = n_tensors;
-  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
-  a.step = step_dev; a.ticket = ticket_dev; a.mirror = mirror_of(step_dev);
-  int64_t g = ceil_div<int64_t>(tot, 256);
-  hipLaunchKernelGGL(k_adam, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, as_stream(stream), a);
-  PG_LAUNCH_CHECK();
-  return PG_OK;
-}
-
-extern "C" int pg_adam_step_partials(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
-                                     float* const* exp_avg_sq, const int64_t* numel, const float* const* partials,
-                                     const int32_t* part_chunks, const int32_t* part_len, const int32_t* part_off,
-                                     const int32_t* is_adam, float lr, float beta1, float beta2, float eps,
-                                     float weight_decay, int64_t* step_dev, uint32_t* ticket_dev, int64_t* bump_dev,
-                                     pg_stream_t stream) {
-  return pg_adam_step_partials2(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, partials, part_chunks, part_len,
-                                part_off, nullptr, nullptr, nullptr, nullptr, is_adam, lr, beta1, beta2, eps,
-                                weight_decay, step_dev, ticket_dev, bump_dev, stream);
-}
-
-extern "C" int pg_adam_step_partials2(int32_t n_tensors, float* const* params, float* const* grads,
-                                      float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
-                                      const float* const* partials, const int32_t* part_chunks, const int32_t* part_len,
-                                      const int32_t* part_off, const float* const* partials2,
-                                      const int32_t* part2_chunks, const int32_t* part2_len, const int32_t* part2_off,
-                                      const int32_t* is_adam, float lr, float beta1, float beta2, float eps,
-                                      float weight_decay, int64_t* step_dev, uint32_t* ticket_dev, int64_t* bump_dev,
-                                      pg_stream_t stream) {
-  if (partials2 && (!part2_chunks || !part2_len || !part2_off)) return PG_ERR_INVALID;
-  if (n_tensors <= 0 || n_tensors > PG_ADAM_MAX_TENSORS || !params || !grads || !exp_avg || !exp_avg_sq || !numel ||
-      !partials || !part_chunks || !part_len || !part_off || !is_adam || !step_dev || !ticket_dev)
-    return PG_ERR_INVALID;
+  hipStream_t st = as_stream(stream);
+  if (!any_part) {
+    AdamArgs a{};
+    int64_t tot = 0;
+    for (int i = 0; i < d->n_tensors; ++i) {
+      const pg_adam_tensor_t& t = d->t[i];
+      if (!t.is_adam) return PG_ERR_INVALID;
+      a.p[i] = t.param; a.g[i] = t.grad; a.m[i] = t.exp_avg; a.v[i] = t.exp_avg_sq;
+      tot += t.numel;
+      a.end[i] = tot;
+    }
+    a.n_tensors = d->n_tensors;
+    a.lr = d->lr; a.beta1 = d->beta1; a.beta2 = d->beta2; a.eps = d->eps; a.weight_decay = d->weight_decay;
+    a.step = d->step_dev; a.ticket = d->ticket_dev; a.bump = d->bump_dev; a.mirror = mirror_of(d->step_dev);
+    int64_t g = ceil_div<int64_t>(tot, 256);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, st, a);
+    PG_LAUNCH_CHECK();
+    return PG_OK;
+  }
   AdamPartArgs a{};
   int64_t tot = 0;
-  for (int i = 0; i < n_tensors; ++i) {
-    if (!grads[i] || numel[i] <= 0) return PG_ERR_INVALID;
-    if (is_adam[i] && (!params[i] || !exp_avg[i] || !exp_avg_sq[i])) return PG_ERR_INVALID;
-    if (partials[i] && (part_chunks[i] <= 0 || part_off[i] < 0 || (int64_t)part_off[i] + numel[i] > part_len[i]))
-      return PG_ERR_INVALID;
-    a.p[i] = params[i]; a.g[i] = grads[i]; a.m[i] = exp_avg[i]; a.v[i] = exp_avg_sq[i];
-    a.part[i] = partials[i]; a.chunks[i] = part_chunks[i]; a.len[i] = part_len[i]; a.off[i] = part_off[i];
-    a.adam[i] = is_adam[i];
-    if (partials2 && partials2[i]) {
-      if (!partials[i] || part2_chunks[i] <= 0 || part2_off[i] < 0 || (int64_t)part2_off[i] + numel[i] > part2_len[i])
-        return PG_ERR_INVALID;
-      a.part2[i] = partials2[i]; a.chunks2[i] = part2_chunks[i]; a.len2[i] = part2_len[i]; a.off2[i] = part2_off[i];
-    }
-    tot += numel[i];
+  for (int i = 0; i < d->n_tensors; ++i) {
+    const pg_adam_tensor_t& t = d->t[i];
+    a.p[i] = t.param; a.g[i] = t.grad; a.m[i] = t.exp_avg; a.v[i] = t.exp_avg_sq;
+    a.part[i] = t.partials; a.chunks[i] = t.part_chunks; a.len[i] = t.part_len; a.off[i] = t.part_off;
+    a.adam[i] = (t.is_adam && !reduce_only) ? 1 : 0;
+    a.part2[i] = t.partials2; a.chunks2[i] = t.part2_chunks; a.len2[i] = t.part2_len; a.off2[i] = t.part2_off;
+    tot += t.numel;
     a.end[i] = tot;
   }
-  a.n_tensors = n_tensors;
-  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
-  a.step = step_dev; a.ticket = ticket_dev; a.bump = bump_dev; a.mirror = mirror_of(step_dev);
-  hipLaunchKernelGGL(k_adam_partials, dim3((unsigned)ceil_div<int64_t>(tot, 64)), dim3(256), 0, as_stream(stream), a);
+  a.n_tensors = d->n_tensors;
+  a.lr = d->lr; a.beta1 = d->beta1; a.beta2 = d->beta2; a.eps = d->eps; a.weight_decay = d->weight_decay;
+  // reduce only: no step counter, no ticket, no bump, no mirror — the launch behind the collective advances them
+  a.step = reduce_only ? nullptr : d->step_dev;
+  a.ticket = reduce_only ? nullptr : d->ticket_dev;
+  a.bump = reduce_only ? nullptr : d->bump_dev;
+  a.mirror = reduce_only ? nullptr : mirror_of(d->step_dev);
+  hipLaunchKernelGGL(k_adam_partials, dim3((unsigned)ceil_div<int64_t>(tot, 64)), dim3(256), 0, st, a);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }

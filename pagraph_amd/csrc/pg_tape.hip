@@ -5,7 +5,11 @@
 // walks the captured graph once — it must be a linear chain of kernel and memset nodes, which a single-stream capture of this
 // library's launches is — and keeps each node's launch parameters (the graph, which owns the parameter storage and the memory pool
 // the pointers refer to, must outlive the tape); pg_tape_launch issues them in order on a stream: the same kernels with the same
-// arguments in the same order, without the graph launch.
+// arguments in the same order, without the graph launch. Anything that is not such a launch — a kernel launched through the
+// module API or with an `extra` buffer (RCCL's captured collectives), a cooperative launch, a copy, a host node, a child graph —
+// makes pg_tape_from_graph return PG_ERR_UNSUPPORTED and the caller keeps hipGraphLaunch. The caller must also rule out
+// captured torch RNG kernels, whose seed / offset torch refreshes in CUDAGraph.replay() only (trainer.GraphedTrainer._tape_of).
+#include <cstring>
 #include <vector>
 
 #include "pg_common.h"
@@ -63,7 +67,28 @@ int pg_tape_from_graph(void* hip_graph, pg_tape_t** out, int32_t* n_kernels, int
     if (ty == hipGraphNodeTypeKernel) {
       op.kind = 0;
       if (hipGraphKernelNodeGetParams(nd, &op.k) != hipSuccess) { delete t; return PG_ERR_HIP; }
-      if (op.k.extra) { delete t; return PG_ERR_UNSUPPORTED; }
+      if (op.k.extra || !op.k.func) { delete t; return PG_ERR_UNSUPPORTED; }
+      // pg_tape_launch issues hipLaunchKernel(func, ...): `func` must be a HOST function the runtime has a device kernel
+      // registered for. A node captured from hipModuleLaunchKernel (JIT-compiled kernels: jiterator, a user's Triton op)
+      // carries a hipFunction_t there instead — the launch would fail half-way through the step.
+      {
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, op.k.func) != hipSuccess) {
+          (void)hipGetLastError();
+          delete t;
+          return PG_ERR_UNSUPPORTED;
+        }
+      }
+      // attributes a plain launch would drop: a cooperative launch keeps hipGraphLaunch (the query failing = none set)
+      {
+        hipKernelNodeAttrValue av;
+        memset(&av, 0, sizeof(av));
+        if (hipGraphKernelNodeGetAttribute(nd, hipKernelNodeAttributeCooperative, &av) == hipSuccess) {
+          if (av.cooperative) { delete t; return PG_ERR_UNSUPPORTED; }
+        } else {
+          (void)hipGetLastError();
+        }
+      }
       ++nk;
     } else if (ty == hipGraphNodeTypeMemset) {
       op.kind = 1;

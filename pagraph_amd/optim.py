@@ -85,110 +85,135 @@ class Adam(torch.optim.Optimizer):
             self._dev_state[gi] = st
         return st
 
+    def _init_state(self, ps, step_dev):
+        for p in ps:
+            st = self.state[p]
+            if not st:
+                st['step'] = step_dev          # shared by the group's tensors (torch keeps one per tensor)
+                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                raise L.PgError("pagraph_amd.optim.Adam needs contiguous fp32 parameters and gradients")
+
+    def _desc(self, group, mode, step_dev, ticket, bump):
+        d = L.PgAdamDesc()
+        d.mode = mode
+        b1, b2 = group['betas']
+        d.lr, d.beta1, d.beta2, d.eps, d.weight_decay = (float(group['lr']), float(b1), float(b2), float(group['eps']),
+                                                         float(group['weight_decay']))
+        d.step_dev, d.ticket_dev = L.ptr(step_dev).value, L.ptr(ticket).value
+        d.bump_dev = L.ptr(bump).value if bump is not None else None
+        return d
+
     @torch.no_grad()
     def step(self, closure=None, deferred=None, bump=None):
         """deferred: an ops.DeferredPartials registry — gradients whose per-chunk partial rows were left un-summed by
-        the weight-gradient kernels are added up (pg_sum_partials' order) inside this step's single launch"""
+        the weight-gradient kernels are added up (pg_sum_partials' order) inside this step's single launch.
+        bump: optional device int64[1] advanced by the step's (last) launch — the model's dropout step counter"""
         if deferred is not None and deferred.mixed():
             raise L.PgError("deferred partial sums: a parameter was used by a deferring dense step AND by a library "
                             "nn.Linear in the same step; its gradient would be incomplete (run without fuse_partials)")
         if deferred is not None and not deferred.conflict and (deferred.by_param or deferred.extra):
             return self._step_deferred(deferred, bump)
-        if bump is not None:
-            bump.add_(1)           # nothing was deferred (library fall-backs ran): the counter still advances once per step
         if deferred is not None and deferred.conflict:
             raise L.PgError("deferred partial sums: a parameter received more than two gradient contributions in one step")
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for gi, group in enumerate(self.param_groups):
-            ps = [p for p in group['params'] if p.grad is not None]
-            if not ps:
-                continue
+        launched = False
+        live = [(gi, group, [p for p in group['params'] if p.grad is not None]) for gi, group in enumerate(self.param_groups)]
+        live = [e for e in live if e[2]]
+        for li, (gi, group, ps) in enumerate(live):
             dev = ps[0].device
             if not ps[0].is_cuda:
                 raise L.PgError("pagraph_amd.optim.Adam runs on the GPU only (no CPU fallback)")
             step_dev, ticket = self._group_state(gi, dev)
-            for p in ps:
-                st = self.state[p]
-                if not st:
-                    st['step'] = step_dev          # shared by the group's tensors (torch keeps one per tensor)
-                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
-                    raise L.PgError("pagraph_amd.optim.Adam needs contiguous fp32 parameters and gradients")
-            b1, b2 = group['betas']
+            self._init_state(ps, step_dev)
             for c0 in range(0, len(ps), L.PG_ADAM_MAX_TENSORS):
                 chunk = ps[c0:c0 + L.PG_ADAM_MAX_TENSORS]
-                n = len(chunk)
-                arr = lambda xs: (ctypes.c_void_p * n)(*[x.data_ptr() for x in xs])
-                numel = (ctypes.c_int64 * n)(*[p.numel() for p in chunk])
                 last = c0 + L.PG_ADAM_MAX_TENSORS >= len(ps)
-                # only the last chunk of a group advances the shared step counter
+                # only the last chunk of a group advances the shared step counter (and, in the very last launch, `bump`)
                 sd = step_dev if last else step_dev.clone()
+                d = self._desc(group, L.PG_ADAM_FULL, sd, ticket, bump if (last and li == len(live) - 1) else None)
+                d.n_tensors = len(chunk)
+                for k, p in enumerate(chunk):
+                    t = d.t[k]
+                    t.param, t.grad = p.data_ptr(), p.grad.data_ptr()
+                    t.exp_avg, t.exp_avg_sq = self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr()
+                    t.numel, t.is_adam = p.numel(), 1
                 with torch.cuda.device(dev):
-                    L.check(self._lib.pg_adam_step(n, arr(chunk), arr([p.grad for p in chunk]),
-                                                   arr([self.state[p]['exp_avg'] for p in chunk]),
-                                                   arr([self.state[p]['exp_avg_sq'] for p in chunk]), numel,
-                                                   float(group['lr']), float(b1), float(b2), float(group['eps']),
-                                                   float(group['weight_decay']), L.ptr(sd), L.ptr(ticket),
-                                                   L.stream_ptr()), "pg_adam_step")
+                    L.check(self._lib.pg_adam_step(ctypes.byref(d), L.stream_ptr()), "pg_adam_step")
+                launched = True
                 if last and gi == 0 and not torch.cuda.is_current_stream_capturing():
                     self._issued += 1
+        if bump is not None and not launched:
+            bump.add_(1)           # no gradient anywhere: the counter still advances once per step
         return loss
 
-    @torch.no_grad()
-    def _step_deferred(self, reg, bump=None):
-        """bump: optional device int64[1] advanced by the same launch (the model's dropout step counter)"""
-        groups = [g for g in self.param_groups if any(p.grad is not None for p in g['params'])]
+    def _deferred_desc(self, reg, mode, bump, grads=None):
+        """the descriptor of a launch that sums `reg`'s partial rows; grads: {parameter data_ptr: tensor the sum is written
+        to} (default: the parameter's .grad)"""
+        groups = [g for g in self.param_groups if any(p.data_ptr() in reg.by_param or p.grad is not None for p in g['params'])]
         if len(groups) != 1:
             raise L.PgError("deferred partial sums need exactly one parameter group")
         group = groups[0]
         gi = self.param_groups.index(group)
         ps = [p for p in group['params'] if p.grad is not None]
+        if mode == L.PG_ADAM_REDUCE_ONLY:
+            ps = [p for p in ps if p.data_ptr() in reg.by_param]
         dev = ps[0].device
         step_dev, ticket = self._group_state(gi, dev)
-        for p in ps:
-            st = self.state[p]
-            if not st:
-                st['step'] = step_dev
-                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-            if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
-                raise L.PgError("pagraph_amd.optim.Adam needs contiguous fp32 parameters and gradients")
+        self._init_state(ps, step_dev)
         n = len(ps) + len(reg.extra)
         if n > L.PG_ADAM_MAX_TENSORS:
-            raise L.PgError("too many tensors for one pg_adam_step_partials launch")
-        vp, i32 = ctypes.c_void_p, ctypes.c_int32
-        P, G, M, V, PT = (vp * n)(), (vp * n)(), (vp * n)(), (vp * n)(), (vp * n)()
-        numel = (ctypes.c_int64 * n)()
-        chunks, rowlen, off, adam = (i32 * n)(), (i32 * n)(), (i32 * n)(), (i32 * n)()
-        PT2, chunks2, rowlen2, off2 = (vp * n)(), (i32 * n)(), (i32 * n)(), (i32 * n)()
+            raise L.PgError("too many tensors for one pg_adam_step launch with deferred partial sums")
+        d = self._desc(group, mode, step_dev, ticket, bump)
+        d.n_tensors = n
         for k, p in enumerate(ps):
-            P[k], G[k] = p.data_ptr(), p.grad.data_ptr()
-            M[k], V[k] = self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr()
-            numel[k], adam[k] = p.numel(), 1
+            t = d.t[k]
+            g = p.grad if grads is None else grads[p.data_ptr()]
+            t.param, t.grad = p.data_ptr(), g.data_ptr()
+            t.exp_avg, t.exp_avg_sq = self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr()
+            t.numel, t.is_adam = p.numel(), 1
             e = reg.by_param.get(p.data_ptr())
             if e is not None:
                 if e[4] != p.numel():
                     raise L.PgError("deferred partial sums: registered size differs from the parameter's")
-                PT[k], chunks[k], rowlen[k], off[k] = e[0].data_ptr(), e[1], e[2], e[3]
+                t.partials, t.part_chunks, t.part_len, t.part_off = e[0].data_ptr(), e[1], e[2], e[3]
                 e2 = reg.second.get(p.data_ptr())
                 if e2 is not None:             # applied twice this step: sum(first) + sum(second)
                     if e2[4] != p.numel():
                         raise L.PgError("deferred partial sums: registered size differs from the parameter's")
-                    PT2[k], chunks2[k], rowlen2[k], off2[k] = e2[0].data_ptr(), e2[1], e2[2], e2[3]
+                    t.partials2, t.part2_chunks, t.part2_len, t.part2_off = e2[0].data_ptr(), e2[1], e2[2], e2[3]
         for j, (dst, part, ch, rl, of) in enumerate(reg.extra):
-            k = len(ps) + j
-            G[k], PT[k], numel[k] = dst.data_ptr(), part.data_ptr(), dst.numel()
-            chunks[k], rowlen[k], off[k], adam[k] = ch, rl, of, 0
-        b1, b2 = group['betas']
+            t = d.t[len(ps) + j]
+            t.grad, t.partials, t.numel = dst.data_ptr(), part.data_ptr(), dst.numel()
+            t.part_chunks, t.part_len, t.part_off, t.is_adam = ch, rl, of, 0
+        return d, dev, gi
+
+    @torch.no_grad()
+    def _step_deferred(self, reg, bump=None):
+        """bump: optional device int64[1] advanced by the same launch (the model's dropout step counter)"""
+        d, dev, gi = self._deferred_desc(reg, L.PG_ADAM_FULL, bump)
         with torch.cuda.device(dev):
-            L.check(self._lib.pg_adam_step_partials2(n, P, G, M, V, numel, PT, chunks, rowlen, off, PT2, chunks2, rowlen2,
-                                                     off2, adam, float(group['lr']), float(b1), float(b2),
-                                                     float(group['eps']), float(group['weight_decay']), L.ptr(step_dev),
-                                                     L.ptr(ticket), L.ptr(bump), L.stream_ptr()), "pg_adam_step_partials")
+            L.check(self._lib.pg_adam_step(ctypes.byref(d), L.stream_ptr()), "pg_adam_step (deferred partial sums)")
         if gi == 0 and not torch.cuda.is_current_stream_capturing():
             self._issued += 1
         return None
+
+    @torch.no_grad()
+    def reduce_deferred(self, reg, grads):
+        """The N > 1 step (GraphedTrainer): ONE launch adds `reg`'s partial rows up — pg_sum_partials' order, the same
+        kernel as the fused step — and writes every parameter's summed gradient to grads[parameter data_ptr] (views of the
+        flat buffer the all-reduce works on) and the reduce-only outputs (the fused head's loss) to their destinations.
+        No update, no counter moves: step() behind the collective does that. Every parameter with a gradient must have
+        deferred rows (the trainer checks the model's `deferrable_parameters`)."""
+        if reg.mixed() or reg.conflict:
+            raise L.PgError("deferred partial sums: a parameter took a non-deferring path or more than two contributions")
+        missing = [p for g in self.param_groups for p in g['params'] if p.grad is not None and p.data_ptr() not in reg.by_param]
+        if missing:
+            raise L.PgError(f"reduce_deferred: {len(missing)} parameter(s) with a gradient have no deferred partial rows")
+        d, dev, _ = self._deferred_desc(reg, L.PG_ADAM_REDUCE_ONLY, None, grads=grads)
+        with torch.cuda.device(dev):
+            L.check(self._lib.pg_adam_step(ctypes.byref(d), L.stream_ptr()), "pg_adam_step (reduce only)")

@@ -240,6 +240,9 @@ class GraphedTrainer:
         self.pg = process_group
         self.flat = None
         self.graph_b = None
+        self.tape_b = None
+        self._bump_b = None
+        self._bump = None                # the dropout step counter the N > 1 optimiser launch advances (deferred step body)
         # world > 1: is the gradient all-reduce captured INSIDE the step's graph (one launch per step) or issued
         # eagerly between two graphs (three launches)? None = not probed yet; see _probe_graph_allreduce.
         # PG_GRAPH_ALLREDUCE=0 forces the eager collective.
@@ -261,8 +264,10 @@ class GraphedTrainer:
                 dist.broadcast(p.data, src=0, group=self.pg)
             self.flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=device)
             o = 0
+            self._flat_params, self._flat_views = params, {}
             for p in params:
                 p.grad = self.flat[o:o + p.numel()].view_as(p)
+                self._flat_views[p.data_ptr()] = p.grad
                 o += p.numel()
         assert sampler.static, "GraphedTrainer needs NeighborSampler(static=True)"
         self.model, self.loss_fcn, self.optimizer = model, ops.fused_loss(loss_fcn), optimizer
@@ -359,7 +364,7 @@ class GraphedTrainer:
         if L.del_waits_enabled():
             for s_ in list(getattr(self, "slots", {}).values()):
                 self._drop_graph(s_)
-            self.graph_b = None
+            self._drop_graph_b()
 
     def __enter__(self):
         return self
@@ -696,24 +701,44 @@ class GraphedTrainer:
     # -- the captured step as plain launches (round 5; csrc/pg_tape.hip) --------------------------------------------------
     def _flat_wanted(self):
         """replay a captured step as its kernels launched one by one instead of with hipGraphLaunch: between two graph replays
-        the stream idles ~12 us, between two dependent kernels of one stream ~3.4 us. One GPU only (a captured collective is
-        not a plain kernel node). PG_FLAT_REPLAY=0 keeps the graph launch."""
+        the stream idles ~12 us, between two dependent kernels of one stream ~3.4 us. N > 1 (round 6): the same — when every node
+        of the captured step is a plain kernel / memset launch (pg_tape_from_graph refuses anything else: a captured RCCL
+        collective that is not one stays inside hipGraphLaunch). PG_FLAT_REPLAY=0 keeps the graph launch."""
         import os as _os
-        return self.world == 1 and _os.environ.get("PG_FLAT_REPLAY", "1") != "0"
+        return _os.environ.get("PG_FLAT_REPLAY", "1") != "0"
 
-    def _make_tape(self, s):
-        s.tape = None
+    def _tape_of(self, graph):
+        """(tape or None, executed) for a freshly captured torch.cuda.CUDAGraph(keep_graph=True) on the CURRENT stream.
+        The graph is replayed ONCE through torch (executed = True) with the default generator's Philox offset read on both
+        sides: CUDAGraph.replay() refills the seed / offset tensors of every RNG kernel the capture holds and advances the
+        offset (CUDAGeneratorState::replay_prologue) — a tape does neither, so a captured torch RNG kernel (nn.Dropout of a
+        model with fuse_dropout=False, a user's loss) would draw the SAME numbers on every replay. A capture
+        that consumed torch RNG therefore keeps hipGraphLaunch; so does one with a node that is not a plain launch."""
         if not self._flat_wanted():
-            return
+            return None, False
+        executed = False
         try:
-            s.graph.instantiate()                     # (keep_graph=True defers it; the graph launch stays available)
-            raw = s.graph.raw_cuda_graph()
+            graph.instantiate()                       # (keep_graph=True defers it; the graph launch stays available)
+            gen = torch.cuda.default_generators[self.device.index if self.device.index is not None
+                                                else torch.cuda.current_device()]
+            off0 = gen.get_offset()
+            graph.replay()
+            executed = True
+            if gen.get_offset() != off0:
+                return None, executed
+            raw = graph.raw_cuda_graph()
             tape, nk, no = L.vp(), L.c_i32(0), L.c_i32(0)
             rc = self._lib.pg_tape_from_graph(ctypes.c_void_p(int(raw)), ctypes.byref(tape), ctypes.byref(nk), ctypes.byref(no))
             if rc == 0 and nk.value > 0:
-                s.tape = tape
+                return tape, executed
         except Exception:
-            s.tape = None
+            pass
+        return None, executed
+
+    def _make_tape(self, s):
+        """-> True when the slot's graph has been executed once on the way (the caller then skips its first replay)"""
+        s.tape, executed = self._tape_of(s.graph)
+        return executed
 
     def _replay(self, s, stream):
         if getattr(s, "tape", None) is not None:
@@ -730,7 +755,7 @@ class GraphedTrainer:
     def _can_defer_partials(self):
         from .optim import Adam
         m = self._bare_model()
-        return (self.fuse_partials and self.world == 1 and isinstance(self.optimizer, Adam)
+        return (self.fuse_partials and isinstance(self.optimizer, Adam)
                 and getattr(m, "deferrable_parameters", False) and len(self.optimizer.param_groups) == 1)
 
     def _prime_drop_step(self):
@@ -743,8 +768,11 @@ class GraphedTrainer:
             m.externalise_drop_step()
 
     def _step_body_deferred(self, s):
-        """_step_body for one GPU with the partial sums (and the dropout step counter's increment) folded into the
-        optimiser's launch"""
+        """_step_body with the partial sums (and the dropout step counter's increment) folded into the optimiser's launch.
+        One GPU: [dense, head, backward aggregation, weight gradient, sums + Adam]. N > 1 (round 6): the same kernels, then
+        ONE reduce-only launch that writes every summed gradient straight into the flat buffer (no zero fill, no
+        AccumulateGrad add per parameter), the all-reduce of that buffer, and the plain Adam launch, which also advances the
+        dropout counter: two launches more than the one-GPU step, whatever the model."""
         m = self._bare_model()
         import contextlib
         import os as _os
@@ -753,10 +781,11 @@ class GraphedTrainer:
             # the counter was primed by compute() (outside any capture); only this forward skips the model's own bump
             bump, scope = m._drop_step, m.drop_step_external()
             s.ext_drop = m
+        self._bump = bump
         with scope, ops.defer_partials() as reg:
             self._frames_for(s)
-            if self._gseed is None:
-                self._gseed = torch.full((), 1.0, dtype=torch.float32, device=self.device)
+            if self._gseed is None:       # persistent d loss / d loss (1 / world: the SUM all-reduce then yields DDP's mean)
+                self._gseed = torch.full((), 1.0 / self.world, dtype=torch.float32, device=self.device)
             loss = None
             if self.fuse_head and isinstance(self.loss_fcn, ops.CrossEntropyLoss) and hasattr(self.model, 'forward_loss'):
                 loss = self.model.forward_loss(s.nf, s.label, s.n_valid, self._gseed, self.loss_fcn.ignore_index)
@@ -764,7 +793,20 @@ class GraphedTrainer:
                 pred = self.model(s.nf)
                 loss = self.loss_fcn(pred, s.label)
             loss.backward(self._gseed)
-        self.optimizer.step(deferred=reg, bump=bump)
+        if self.world == 1:
+            self.optimizer.step(deferred=reg, bump=bump)
+        else:
+            self.optimizer.reduce_deferred(reg, self._flat_views)
+            for p_ in self._flat_params:
+                p_.grad = self._flat_views[p_.data_ptr()]          # (no kernel: the attribute only)
+            if self.allreduce_in_graph:
+                if torch.cuda.is_current_stream_capturing():
+                    import torch.distributed as dist
+                    dist.all_reduce(self.flat, group=self.pg)
+                else:
+                    self._eager_all_reduce(self.flat)
+                self.optimizer.step(bump=bump)
+            # else: compute() issues the eager all-reduce and the optimiser's launch (_sync_and_step) behind this body
         s.nf._pre_agg = None
         return loss
 
@@ -804,7 +846,8 @@ class GraphedTrainer:
         self.compute_stream.synchronize()
         if int(flag.item()) == 0:
             return False
-        want = float(self.world * (self.world + 1) // 2)
+        n_ = dist.get_world_size(self.pg)         # (the group's size: a one-rank group may stand in for a larger job)
+        want = float(n_ * (n_ + 1) // 2)
         good = 1
         try:
             for _ in range(2):
@@ -841,21 +884,35 @@ class GraphedTrainer:
         self.compute_stream.wait_stream(cs)
 
     def _sync_and_step(self, capture_ok):
-        """world > 1: all-reduce the flat gradient (eager), then the optimizer step (graph B)"""
+        """world > 1: all-reduce the flat gradient (eager), then the optimizer step (graph B, replayed as a plain launch
+        when it is one)"""
         self._eager_all_reduce(self.flat)
-        if self.graph_b is not None:
-            self.graph_b.replay()
+        kw = {"bump": self._bump} if self._bump is not None else {}
+        if self.graph_b is not None and self._bump_b is self._bump:
+            if self.tape_b is not None:
+                L.check(self._lib.pg_tape_launch(self.tape_b, ctypes.c_void_p(self.compute_stream.cuda_stream)), "pg_tape_launch")
+            else:
+                self.graph_b.replay()
         elif not capture_ok:
-            self.optimizer.step()                 # (an eager step counts itself)
+            self.optimizer.step(**kw)             # (an eager step counts itself)
             return
         else:
-            g = torch.cuda.CUDAGraph()
+            self._drop_graph_b()
+            g = torch.cuda.CUDAGraph(keep_graph=True) if self._flat_wanted() else torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=self.compute_stream, capture_error_mode="thread_local"):
-                self.optimizer.step()
-            self.graph_b = g
-            g.replay()
+                self.optimizer.step(**kw)
+            self.graph_b, self._bump_b = g, self._bump
+            self.tape_b, executed = self._tape_of(g)
+            if not executed:
+                g.replay()
         if self._step_cell is not None:
             self.optimizer.note_replayed_steps(1)
+
+    def _drop_graph_b(self):
+        if getattr(self, "tape_b", None) is not None:
+            self._lib.pg_tape_destroy(self.tape_b)
+            self.tape_b = None
+        self.graph_b = None
 
     def compute(self, s):
         main = self.compute_stream
@@ -887,26 +944,27 @@ class GraphedTrainer:
                     if counted and (self.world == 1 or synced):
                         self.optimizer.note_replayed_steps(1)
                 elif warm:
-                    if self.world == 1:
-                        self.optimizer.zero_grad(set_to_none=True)
+                    if self.world == 1 or self._can_defer_partials():
+                        self.optimizer.zero_grad(set_to_none=True)   # (deferred: autograd takes the placeholders, no add)
                     self._prime_drop_step()
                     s.loss = (self._step_body_deferred(s) if self._can_defer_partials() else self._step_body(s)).detach()
                 else:
                     if self.world > 1 and self.allreduce_in_graph is None:
                         self.allreduce_in_graph = self._probe_graph_allreduce()
                     g = torch.cuda.CUDAGraph(keep_graph=True) if self._flat_wanted() else torch.cuda.CUDAGraph()
-                    if self.world == 1:
+                    if self.world == 1 or self._can_defer_partials():
                         self.optimizer.zero_grad(set_to_none=True)
                     self._prime_drop_step()                      # an eager increment: must stay outside the capture
                     # thread_local: RCCL's watchdog thread may touch the runtime while this thread captures
                     with torch.cuda.graph(g, stream=main, capture_error_mode="thread_local"):
                         s.loss = (self._step_body_deferred(s) if self._can_defer_partials() else self._step_body(s)).detach()
                     s.graph = g
-                    self._make_tape(s)
+                    executed = self._make_tape(s)                # (replays once through torch when it builds a tape)
                     s.graph_epoch = self.cacher._cache_epoch
                     s.graph_plan = s.plan
                     s.graph_synced = synced = bool(self.allreduce_in_graph)
-                    self._replay(s, main)                        # capture does not execute
+                    if not executed:
+                        self._replay(s, main)                    # capture does not execute
                     if counted and (self.world == 1 or synced):
                         self.optimizer.note_replayed_steps(1)
                 if self.world > 1 and not synced:

@@ -692,6 +692,58 @@ def test_graphed_trainer_matches_eager(dev, hiplib):
     assert losses["graph"][-1] < losses["graph"][0]
 
 
+def test_tape_refuses_a_capture_that_consumed_torch_rng(dev, hiplib):
+    """torch.cuda.CUDAGraph.replay() refreshes the Philox seed / offset of every torch RNG kernel in
+    the graph; the plain-launch tape (pg_tape_launch) cannot. A model that falls back to nn.Dropout (fuse_dropout=False)
+    must therefore keep hipGraphLaunch — same loss trajectory with PG_FLAT_REPLAY on and off, no tape built — while the
+    same model with the fused mask (no torch RNG in the capture) is taped."""
+    import torch.nn.functional as Fn
+    from pagraph_amd.model import GCNSampling
+    from pagraph_amd.optim import Adam
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    from pagraph_amd.trainer import GraphedTrainer, cycle_batches
+    rng = np.random.default_rng(11)
+    V, Fdim, C, B = 4000, 64, 5, 400
+    g = DeviceGraph(_rand_csc(rng, V, 24000))
+    feats = rng.standard_normal((V, Fdim)).astype(np.float32)
+    labels = torch.from_numpy(rng.integers(0, C, V)).to(dev)
+    train = np.arange(0, V, 2, dtype=np.int64)
+    res = {}
+    for mode in ("torch-rng-flat", "torch-rng-graph", "fused-flat"):
+        os.environ.pop("PG_FLAT_REPLAY", None)
+        if mode == "torch-rng-graph":
+            os.environ["PG_FLAT_REPLAY"] = "0"
+        try:
+            store = HostFeatureStore({"features": torch.from_numpy(feats)})
+            c = GraphCacheServer(store, V, torch.arange(V), 0, miss_mode="zerocopy")
+            c.init_field(["features"])
+            c.auto_cache(g, ["features"], cache_ratio=1.0)
+            torch.manual_seed(0)
+            torch.cuda.manual_seed(1234)
+            model = GCNSampling(Fdim, 16, C, 1, Fn.relu, 0.3).to(dev)
+            model.fuse_dropout = not mode.startswith("torch-rng")
+            opt = Adam(model.parameters(), lr=1e-2)
+            smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=True, num_hops=2, seed_nodes=train, prefetch=True, seed=9,
+                                  static=True)
+            tr = GraphedTrainer(model, torch.nn.CrossEntropyLoss(), opt, c, smp, labels, dev, need=model.required_inputs(3))
+            tr.fuse_gather = model.fuse_dropout       # nn.Dropout needs materialised rows
+            out = []
+            tr.on_step = lambda step, loss: out.append(loss.detach().clone())
+            tr.run_steps(cycle_batches(smp, 40), 40)
+            tr.synchronize()
+            torch.cuda.synchronize()
+            res[mode] = (torch.stack(out).cpu().numpy(), [s_.tape is not None for s_ in tr.slots.values() if s_.graph is not None])
+            tr.close()
+        finally:
+            os.environ.pop("PG_FLAT_REPLAY", None)
+    assert res["torch-rng-flat"][1] and not any(res["torch-rng-flat"][1])          # RNG in the capture: no tape
+    assert res["fused-flat"][1] and all(res["fused-flat"][1])                      # none: taped
+    assert np.isfinite(res["torch-rng-flat"][0]).all()
+    # the same masks, replay after replay, as hipGraphLaunch draws them (a tape would repeat one mask per ring slot)
+    assert np.array_equal(res["torch-rng-flat"][0], res["torch-rng-graph"][0])
+
+
 @pytest.mark.parametrize("arch,hidden,C,p_drop", [("sage", 32, 5, 0.0), ("sage", 16, 70, 0.0), ("sage", 32, 70, 0.25),
                                                   ("gcn", 64, 5, 0.0), ("gcn", 16, 70, 0.25), ("sage", 8, 5, 0.0)])
 def test_graphed_trainer_outside_the_fused_head_envelope(dev, hiplib, arch, hidden, C, p_drop):

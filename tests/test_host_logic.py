@@ -361,7 +361,8 @@ def test_ctypes_structs_match_the_header(tmp_path):
         pytest.skip("no gcc")
     pairs = {"pg_field_t": _lib.PgField, "pg_nodeflow_desc_t": _lib.PgNodeflowDesc, "pg_missq_field_t": _lib.PgMissqField,
              "pg_row_source_t": _lib.PgRowSource, "pg_dedup_t": _lib.PgDedup, "pg_dropout_t": _lib.PgDropout,
-             "pg_batch_early_t": _lib.PgBatchEarly, "pg_batch_plan_t": _lib.PgBatchPlan}
+             "pg_batch_early_t": _lib.PgBatchEarly, "pg_batch_plan_t": _lib.PgBatchPlan,
+             "pg_adam_tensor_t": _lib.PgAdamTensor, "pg_adam_desc_t": _lib.PgAdamDesc}
     # C field names where the mirror uses another (padding) name are skipped; every other field is compared by name
     lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{os.path.join(ROOT, "include", "pagraph_hip.h")}"', "int main(void) {"]
     for cname, cls in pairs.items():

@@ -36,26 +36,35 @@ def _rccl_one_rank_worker(rank, port, out_dir):
     labels = torch.from_numpy(rng.integers(0, C, V)).to(dev)
     train = np.arange(0, V, 2, dtype=np.int64)
     res = {}
-    for mode in ("eager", "ingraph"):
+    # eager: graph A -> all-reduce on the communication stream -> graph B; ingraph: the collective captured in the step;
+    # *-unfused: round 5's step shape (flat.zero_(), one ordered sum per weight gradient, AccumulateGrad's add per parameter,
+    # hipGraphLaunch) as the checker of round 6's (reduce-only sums straight into the flat buffer, plain launches)
+    for mode in ("eager", "ingraph", "eager-unfused", "ingraph-unfused"):
         store = HostFeatureStore({"features": torch.from_numpy(feats)})
         c = GraphCacheServer(store, V, torch.arange(V), 0, miss_mode="async")
         c.init_field(["features"])
         c.auto_cache(g, ["features"], cache_ratio=0.5)
         torch.manual_seed(1)
-        model = GCNSampling(Fdim, 8, C, 1, Fn.relu, 0.0).to(dev)
+        model = GCNSampling(Fdim, 8, C, 1, Fn.relu, 0.25).to(dev)
         need = model.required_inputs(3)
         opt = Adam(model.parameters(), lr=1e-2)
         smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=True, num_hops=2, seed_nodes=train, prefetch=True, seed=3,
                               static=True, defer_transpose=True)
         tr = GraphedTrainer(model, torch.nn.CrossEntropyLoss(), opt, c, smp, labels, dev, need=need, world_size=2)
-        # eager: graph A -> all-reduce on the communication stream -> graph B; ingraph: the collective captured in the step
-        tr.allreduce_in_graph = (mode == "ingraph")
+        tr.allreduce_in_graph = mode.startswith("ingraph")
+        if mode.endswith("unfused"):
+            tr.fuse_partials = False
+            os.environ["PG_FLAT_REPLAY"] = "0"
         out = []
         tr.on_step = lambda step, loss: out.append(loss.detach().clone())
         tr.run_steps(cycle_batches(smp, 30), 30)      # 3 eager steps, 8 captures (each microseconds behind an eager collective), replays
         tr.synchronize()
         torch.cuda.synchronize()
-        res[mode] = (torch.stack(out).cpu(), [p.detach().cpu().clone() for p in model.parameters()], bool(tr.allreduce_in_graph))
+        os.environ.pop("PG_FLAT_REPLAY", None)
+        taped = [s_.tape is not None for s_ in tr.slots.values() if s_.graph is not None]
+        res[mode] = (torch.stack(out).cpu(), [p.detach().cpu().clone() for p in model.parameters()], bool(tr.allreduce_in_graph),
+                     taped, int(model._drop_step.item()), int(opt.steps_issued()))
+        tr.close()
         c.shutdown_miss_queue()
     torch.save(res, os.path.join(out_dir, "r0.pt"))
     dist.destroy_process_group()
@@ -73,9 +82,16 @@ def test_graphed_trainer_over_an_rccl_group_survives_its_captures(dev, hiplib, t
     assert r["eager"][2] is False and r["ingraph"][2] is True
     assert torch.isfinite(r["eager"][0]).all() and len(r["eager"][0]) == 30
     assert float(r["eager"][0][-5:].mean()) < float(r["eager"][0][:5].mean())        # it trains
-    assert torch.allclose(r["eager"][0], r["ingraph"][0], rtol=1e-5, atol=1e-6)
-    for a, b in zip(r["eager"][1], r["ingraph"][1]):
-        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    # round 6: the N > 1 step keeps the one-GPU step's kernels (sums folded into ONE reduce-only launch that writes the flat
+    # gradient buffer) and is replayed as plain launches — the same bits as round 5's shape, which is the checker here
+    for a_, b_ in (("eager", "ingraph"), ("eager", "eager-unfused"), ("ingraph", "ingraph-unfused")):
+        assert torch.equal(r[a_][0], r[b_][0]), (a_, b_, r[a_][0], r[b_][0])
+        for a, b in zip(r[a_][1], r[b_][1]):
+            assert torch.equal(a, b), (a_, b_)
+        assert r[a_][5] == r[b_][5]                                                 # optimiser launches
+    assert r["eager"][4] == r["ingraph"][4]                                         # dropout counter
+    assert r["eager"][3] and all(r["eager"][3]) and all(r["ingraph"][3])              # taped (a one-rank all-reduce is no node)
+    assert not any(r["eager-unfused"][3])
 
 
 def _two_rank_graph_worker(rank, world, port, out_dir):
