@@ -22,6 +22,10 @@ import os
 import sys
 import time
 
+# (before the first HIP call: see pagraph_amd/__init__.py — more than ~6 hardware queues per process cost every side-stream
+# kernel ~45 us; the N > 1 step's extra streams push the pipeline over that)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -77,7 +81,7 @@ def host_info(cacher=None):
         quota = None if q == "max" else int(q) / int(per)
     except (OSError, ValueError):
         pass
-    return {"cpu_model": model, "cpus_online": os.cpu_count(),
+    return {"cpu_model": model, "cpus_online": os.cpu_count(), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
             "cpus_affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
             "cgroup_cpu_quota": quota, "miss_gather_threads": getattr(cacher, "host_threads", None)}
 
@@ -158,6 +162,9 @@ def parse():
     p.add_argument("--which-rank", type=int, default=None, help="--as-rank-of: the partition to run (default: largest closure)")
     p.add_argument("--dist-step", action="store_true", help="one GPU: the N > 1 step shape (one-rank RCCL group, trainer "
                    "world_size 2) over the 1naive partition — the A/B partner of the default one-GPU step")
+    p.add_argument("--extra-streams", type=int, default=0, help="diagnosis: create and use N more streams before the trainer")
+    p.add_argument("--no-fuse-partials", action="store_true", help="A/B: the weight gradients' ordered partial sums as launches "
+                   "of their own (+ AccumulateGrad's adds when N > 1) instead of inside the optimiser's launch")
     p.add_argument("--no-adapt-cpu-share", action="store_true", help="keep --cpu-share as given; default: after the set-up "
                    "steps every rank sets it from its own CPU-gather rate vs PCIe (GraphCacheServer.adapt_cpu_share)")
     return p.parse_args()
@@ -670,6 +677,11 @@ def main():
     # ('total dims', 'Cache Memory', ...) go to stderr
     real_stdout = sys.stdout
     sys.stdout = sys.stderr
+    # ... also what C libraries print: RCCL writes its version banner to the C stdout, which libc flushes at exit — BEHIND the
+    # JSON line when stdout is a pipe. File descriptor 1 points at stderr for the whole run and comes back for the line.
+    sys.stdout.flush()
+    saved_fd1 = os.dup(1)
+    os.dup2(2, 1)
     try:
         out = run()
         if out is not None and out.pop("_wants_configs", False):
@@ -679,6 +691,12 @@ def main():
             torch.cuda.empty_cache()
             out["configs"] = config_legs(parse())
     finally:
+        try:
+            ctypes.CDLL(None).fflush(None)           # whatever C code buffered for "stdout" goes to stderr now
+        except Exception:
+            pass
+        os.dup2(saved_fd1, 1)
+        os.close(saved_fd1)
         sys.stdout = real_stdout
     if out is not None:
         print(json.dumps(out), flush=True)
@@ -702,12 +720,17 @@ def run():
     emul_P = int(args.as_rank_of) if world == 1 else 0
     dist_step = bool(world == 1 and (emul_P > 1 or args.dist_step))
     step_world = world if world > 1 else (max(2, emul_P) if dist_step else 1)     # what the trainer is told
-    if dist_step:
+    init_pg_only = int(os.environ.get("PG_BENCH_INIT_PG", 0)) if world == 1 and not dist_step else 0
+    if dist_step or init_pg_only:
         import socket
         s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_), RANK="0", WORLD_SIZE="1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=0, world_size=1)      # REAL RCCL, of one rank: all a one-GPU box can host
+        if init_pg_only >= 2:      # diagnosis (tools/exp_rccl_presence.sh): the communicator exists, the trainer does not use it
+            t_ = torch.ones(8, device=dev)
+            dist.all_reduce(t_)
+            torch.cuda.synchronize()
 
     from pagraph_amd import _lib as L
     from pagraph_amd import parallel
@@ -844,7 +867,9 @@ def run():
     store = HostFeatureStore(fields, pin=False,               # both tables are already pinned / registered
                              device_visible={"features": table_device_visible, "norm": True})
     cacher = GraphCacheServer(store, Vs, sub2full, gpu, miss_mode=args.miss_mode,
-                              host_threads=args.host_threads or default_host_threads(max(world, emul_P, 1)))
+                              host_threads=args.host_threads or default_host_threads(world))
+    # (--as-rank-of P: the rank gets THIS box's one-GPU share of host threads — a one-GPU slice of a node; a P-GPU node has to
+    # bring P times that for the projection to hold. --host-threads 2 shows the rank on a starved host.)
     cacher.init_field(embed_names)
     cacher.log = True
     if world > torch.cuda.device_count():
@@ -898,12 +923,22 @@ def run():
     K = args.steps if args.steps is not None else min(steps_per_epoch, 5000)
     W = args.warmup
     S = 1                                                # set-up steps: the cache is filled after the first one
+    if args.extra_streams:
+        # diagnosis (tools/exp_hw_queues2.sh): a few more streams that have run one kernel each — what torch.distributed's NCCL
+        # stream and a communication stream add to the process — to show what the hardware-queue count does to the step
+        _xs = [torch.cuda.Stream(device=dev) for _ in range(args.extra_streams)]
+        for x_ in _xs:
+            with torch.cuda.stream(x_):
+                torch.zeros(8, device=dev).add_(1)
+        torch.cuda.synchronize()
     if use_graph:
         trainer = GraphedTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, need=need, world_size=step_world,
                                  keep_losses=False, lookahead=args.lookahead)
         S = 3 + 2 * len(sampler.slots)                   # eager warm-up + one capture and first replay per ring slot
         trainer.keep_primed = not args.cold_start
         trainer.fuse_gather = fuse_gather
+        if args.no_fuse_partials:
+            trainer.fuse_partials = False
     else:
         trainer = MinibatchTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, overlap=not args.no_overlap,
                                    need=need)
@@ -1435,7 +1470,7 @@ def run():
             "_wants_configs": bool(default_workload and world == 1 and not dist_step and not args.no_configs and use_graph
                                    and not args.fetch_all),
         }
-    if world > 1 or dist_step:
+    if world > 1 or dist_step or init_pg_only:
         dist.barrier()
         dist.destroy_process_group()
     return out

@@ -5,6 +5,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")      # before the first HIP call (pagraph_amd/__init__.py)
+
 import numpy as np
 import torch
 import torch.distributed as dist

@@ -256,7 +256,10 @@ class GraphedTrainer:
         # after the previous step's eager all-reduce: with the collective on that stream every rank of the first real N > 1 run
         # would have died at its first capture (tools/exp_rccl_capture.py: `nosleep` aborts, `other` / `flow` run). Collectives
         # captured INSIDE a graph are fine (the process group does not hand them to the watchdog).
-        self.comm_stream = torch.cuda.Stream(device=device) if self.world > 1 else None
+        # Created AFTER the pipeline's own streams (below): the runtime multiplexes a priority class's streams onto a handful of
+        # hardware queues in the order they are first used, and a communication stream taken first pushes the compute stream
+        # onto a queue it then shares (round 6: the N > 1 step on one GPU at 0.20 instead of 0.10 ms, tools/exp_rccl_presence.sh)
+        self.comm_stream = torch.cuda.Stream(device=device) if (self.world > 1 and _os.environ.get("PG_COMM_STREAM_FIRST")) else None
         if self.world > 1:
             import torch.distributed as dist
             params = [p for p in model.parameters() if p.requires_grad]
@@ -279,6 +282,8 @@ class GraphedTrainer:
         # eager warm-up, capture and replay all run on ONE non-default stream, so autograd's
         # AccumulateGrad nodes and the captured graphs agree on the stream
         self.compute_stream = L.pipeline_stream(device, "compute", int(_os.environ.get("PG_PRIO_COMPUTE", 0)))
+        if self.world > 1 and not _os.environ.get("PG_COMM_STREAM_FIRST"):
+            self.comm_stream = torch.cuda.Stream(device=device)
         sampler.consumer_stream = self.compute_stream   # ring slots are recycled after the graph that read them
         sampler.manual_release = True
         # the sampler's own "slot free" event (recorded on the compute stream by sampler.release right after the step)

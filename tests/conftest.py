@@ -14,6 +14,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # SIGABRT / SIGFPE (PG_NATIVE_BACKTRACE, installed when libpagraph_hip.so is loaded — before faulthandler, which chains to it)
 # and (ii) keeps Python's faulthandler output of every thread in a file that survives the run (gpurun_out/ travels back from
 # the GPU box), besides pytest's own copy on stderr.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")          # as pagraph_amd/__init__.py sets it (before the first HIP call)
 os.environ.setdefault("PG_NATIVE_BACKTRACE", "1")
 _out = os.path.join(ROOT, "gpurun_out")
 if os.path.isdir(_out) and os.access(_out, os.W_OK):

@@ -29,8 +29,9 @@ def _rccl_one_rank_worker(rank, port, out_dir):
     from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
     from pagraph_amd.trainer import GraphedTrainer, cycle_batches
     rng = np.random.default_rng(5)
-    V, Fdim, C, B = 4000, 32, 4, 250
-    adj = _rand_csc(rng, V, 24000)
+    # (B * fan-out >= 1024 rows at the first dense step: below that the NON-deferring path takes the library GEMM, other bits)
+    V, Fdim, C, B = 8000, 32, 4, 600
+    adj = _rand_csc(rng, V, 48000)
     g = DeviceGraph(adj)
     feats = rng.standard_normal((V, Fdim)).astype(np.float32)
     labels = torch.from_numpy(rng.integers(0, C, V)).to(dev)
