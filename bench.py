@@ -789,8 +789,21 @@ def run():
         # dg over P partitions exactly as rank 0 of a P-GPU run does it (dg.py:59-103), then EVERY partition's closure — their
         # sizes are what the question is about — and the step count the P ranks would agree on (parallel.equalize_steps = MAX)
         t_dg = time.time()
-        b, _, p_vnum, r_vnum = dg_raw(emul_P, indptr.cpu().numpy(), indices.cpu().numpy(), V, train_full.numpy(), args.dg_hops)
-        dg_s = time.time() - t_dg
+        # (the synthetic graph is a pure function of V and E: a second run on the same box — the profiling passes — reuses dg's
+        # result; the record says so)
+        import tempfile
+        dg_file = os.path.join(tempfile.gettempdir(), f"pagraph_bench_dg_{V}_{E}_P{emul_P}_h{args.dg_hops}.npz")
+        dg_cached = os.path.exists(dg_file) and not os.environ.get("PG_BENCH_NO_DG_CACHE")
+        if dg_cached:
+            z_ = np.load(dg_file)
+            b, p_vnum, r_vnum, dg_s = z_["belongs"], z_["p_vnum"], z_["r_vnum"], float(z_["seconds"])
+        else:
+            b, _, p_vnum, r_vnum = dg_raw(emul_P, indptr.cpu().numpy(), indices.cpu().numpy(), V, train_full.numpy(), args.dg_hops)
+            dg_s = time.time() - t_dg
+            try:
+                np.savez(dg_file, belongs=b, p_vnum=p_vnum, r_vnum=r_vnum, seconds=dg_s)
+            except OSError:
+                pass
         belongs_d = torch.from_numpy(b).to(dev)
         log(f"[bench] dg P={emul_P} hops={args.dg_hops}: {dg_s:.1f}s p_vnum={p_vnum.tolist()} r_vnum={r_vnum.tolist()}")
         parts = []
@@ -804,7 +817,8 @@ def run():
         cl_s = time.time() - t_cl
         which = args.which_rank if args.which_rank is not None else max(parts, key=lambda e: e["partition_vertices"])["rank"]
         eq_steps = max(e["steps"] for e in parts)
-        share_rec_p = {"P": emul_P, "dg_hops": args.dg_hops, "dg_seconds": dg_s, "closures_seconds": cl_s, "p_vnum": p_vnum.tolist(),
+        share_rec_p = {"P": emul_P, "dg_hops": args.dg_hops, "dg_seconds": dg_s, "dg_result_reused_from_an_earlier_run_on_this_box": bool(dg_cached),
+                       "closures_seconds": cl_s, "p_vnum": p_vnum.tolist(),
                        "r_vnum": r_vnum.tolist(), "partitions": parts, "rank_run": which,
                        "rank_chosen_by": "--which-rank" if args.which_rank is not None else "largest closure",
                        "equalised_steps_per_epoch": eq_steps, "equalisation": "MAX over the P partitions' own step counts "

@@ -92,6 +92,11 @@ class PgAdamDesc(ctypes.Structure):
                 ("step_dev", vp), ("ticket_dev", vp), ("bump_dev", vp), ("t", PgAdamTensor * PG_ADAM_MAX_TENSORS)]
 
 
+class PgDgGpuStats(ctypes.Structure):
+    _fields_ = [(n, c_i64) for n in ("batches", "batches_redone", "largest_batch", "fresh_entries", "corr_entries", "workgroups")] + \
+               [(n, ctypes.c_double) for n in ("seconds_total", "seconds_expand", "seconds_lists", "seconds_commit", "seconds_apply")]
+
+
 class PgError(RuntimeError):
     pass
 
@@ -203,6 +208,7 @@ _SIGS = {
                                          c_i32, c_i32, vp, vp, vp, c_i32, vp]),
     "pg_dg_partition": (ctypes.c_int, [c_i64, vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp]),
     "pg_dg_partition_mt": (ctypes.c_int, [c_i64, vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp, c_i32]),
+    "pg_dg_partition_gpu": (ctypes.c_int, [c_i64, vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp, ctypes.POINTER(PgDgGpuStats), vp]),
     "pg_np_argsort_f64": (ctypes.c_int, [vp, c_i32, vp]),
     "pg_rmat_edges": (ctypes.c_int, [c_u64, c_i32, c_u32, c_u32, c_u32, c_i64, c_i64, vp, vp, vp]),
     "pg_random_features": (ctypes.c_int, [c_u64, c_i64, c_i64, c_i32, vp, c_i64, vp]),

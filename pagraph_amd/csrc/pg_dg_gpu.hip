@@ -1,0 +1,397 @@
+// dg with the neighbour sets built on the GPU (round 6) — PaGraph/partition/dg.py:14-103, hops 1 and 2, bit-identical to
+// pg_dg_partition (tests: all G4 fixtures + a 10^6-vertex graph against the sequential code).
+//
+// What is sequential in dg is ONE decision per train vertex that reads p_vnum / r_vnum as the previous decision left them
+// (dg.py:47-55,71-83). What is expensive is building N(v) — the de-duplicated one- or two-hop in-neighbourhood: sum(deg^2) =
+// 4.7e10 adjacency entries on the 10M / 100M graph, 6.9e11 on config 5's — and that depends on the graph only. Round 3 put
+// host threads on it (68 s at 10M through one committer; ~1000 s extrapolated at 10^8). Here the device does it, in BATCHES of
+// consecutive train vertices, against a SNAPSHOT of the assignment state taken at the batch's start, and hands the host
+// exactly what the snapshot cannot know:
+//
+//   com0[v][p]   = |{u in N(v) : u assigned to p in the snapshot}|                       (dg.py:47-50, the settled part)
+//   corr(v)      = the members of N(v) that belong to THIS batch and precede v            (assigned between snapshot and v's turn)
+//   fresh(v)     = {(u, m) : u in N(v), m = the partitions whose redundancy set lacked u in the snapshot, m != 0}
+//
+// The host then walks the batch in train order with the reference's float64 score and numpy's argsort (pg_np_argsort_f64):
+// com[p] = 1 + com0[v][p] + |{u in corr(v) : belongs[u] == p}|; after the arg-max, r_vnum[ind] grows by the members of
+// fresh(v) whose mask has bit `ind` and that are still missing from the HOST's exact r_belongs[ind] bitmap (test-and-set) —
+// fresh(v) is a superset of N(v) \ r_belongs[ind] whatever the snapshot's age, so the count is exact. The decisions go back,
+// and one kernel applies them to the snapshot from the same lists (no second expansion). Early batches are tiny (the first
+// hubs' sets are the whole graph and every partition lacks all of it); the batch doubles while the lists stay small, and a
+// batch whose lists overflow their buffers is simply redone at half the size.
+//
+// De-duplication of a two-hop multiset: one V-bit bitmap per workgroup in HBM (atomicOr returns "was it new"), cleared by
+// walking the same lists again. 288 GB of HBM pays for a few hundred private bitmaps even at 10^8 vertices (12.5 MB each).
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <vector>
+
+#include "pg_common.h"
+
+using namespace pg;
+
+namespace {
+
+constexpr int kDgThreads = 256;
+constexpr int kMaxP = 16;              // the fresh-list key packs the partition mask into 16 bits
+constexpr int kLongQueue = 1024;       // such lists queued per vertex (more: the finding wave walks them itself)
+constexpr int kLongList = 1024;        // adjacency lists above this are walked by the whole workgroup, the others per wave
+
+struct DgExpandArgs {
+  const int64_t* indptr;
+  const int32_t* indices;
+  const int64_t* bv;          // batch vertices (train order)
+  int32_t n;                  // batch size
+  int32_t P;
+  int32_t hops;
+  const int8_t* bel;          // snapshot of belongs: >= 0 partition, -1 unassigned, -2 member of this batch
+  const uint16_t* rmask;      // snapshot: bit p = the vertex is in r_belongs[p]
+  uint32_t* pool;             // gridDim.x de-duplication bitmaps
+  int64_t words;              // uint32 words per bitmap
+  int32_t* com0;              // [n][P]
+  unsigned long long* fresh;  // keys: batch index << 44 | vertex << 16 | mask
+  unsigned long long* corr;   // keys: batch index << 32 | vertex
+  unsigned long long cap_fresh, cap_corr;
+  unsigned long long* counters;   // [0] fresh, [1] corr, [2] next batch index
+};
+
+__device__ __forceinline__ void emit(unsigned long long* buf, unsigned long long* counter, unsigned long long cap, bool pred,
+                                     unsigned long long key) {
+  const unsigned long long m = __ballot(pred);
+  if (!m) return;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)m) - 1;
+  unsigned long long base = 0;
+  if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(m));
+  base = __shfl(base, leader);
+  if (pred) {
+    const unsigned long long at = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+    if (at < cap) buf[at] = key;
+  }
+}
+
+// one member of the multiset: first visit -> what the snapshot says about it
+template <bool DEDUP>
+__device__ __forceinline__ void visit(const DgExpandArgs& a, uint32_t* bm, int32_t* s_com, int32_t i, int64_t v, bool live,
+                                      int32_t w, uint16_t full) {
+  bool first = live;
+  if (DEDUP && live) {
+    const uint32_t bit = 1u << (w & 31);
+    first = !(atomicOr(&bm[w >> 5], bit) & bit);
+  }
+  int8_t b = -1;
+  uint16_t miss = 0;
+  if (first) {
+    b = a.bel[w];
+    miss = (uint16_t)(~a.rmask[w]) & full;
+    if (b >= 0) atomicAdd(&s_com[b], 1);
+  }
+  emit(a.corr, a.counters + 1, a.cap_corr, first && b == -2 && (int64_t)w < v, ((unsigned long long)i << 32) | (uint32_t)w);
+  emit(a.fresh, a.counters + 0, a.cap_fresh, first && miss != 0,
+       ((unsigned long long)i << 44) | ((unsigned long long)(uint32_t)w << 16) | miss);
+}
+
+// walk the multiset of batch vertex v: in(v) (hops 1), plus in(u) for every u in in(v) (hops 2: dg.py:22-27). `f(live, w)` is
+// called wave-uniformly (every lane of a wave calls it the same number of times; `live` says whether the lane holds a member).
+template <typename F>
+__device__ __forceinline__ void walk(const DgExpandArgs& a, int64_t v, int32_t* s_long, int32_t* s_nlong, F f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = kDgThreads / 64;
+  const int64_t b0 = a.indptr[v], e0 = a.indptr[v + 1];
+  // the vertex's own list, by the whole workgroup
+  for (int64_t q = b0 + threadIdx.x; q - threadIdx.x < e0; q += kDgThreads) {
+    const bool live = q < e0;
+    f(live, live ? a.indices[q] : 0);
+  }
+  if (a.hops < 2) return;
+  if (threadIdx.x == 0) *s_nlong = 0;
+  __syncthreads();
+  // short lists: one wave per neighbour; long ones are queued for the whole workgroup
+  for (int64_t j = b0 + wave; j < e0; j += nwave) {
+    const int32_t u = a.indices[j];
+    const int64_t b1 = a.indptr[u], e1 = a.indptr[u + 1];
+    if (e1 - b1 > kLongList) {
+      int at = 0;
+      if (lane == 0) {
+        at = atomicAdd(s_nlong, 1);
+        if (at < kLongQueue) s_long[at] = u;
+      }
+      if (__shfl(at, 0) < kLongQueue) continue;      // queued for the whole workgroup (a full queue: this wave walks it)
+    }
+    for (int64_t q = b1 + lane; q - lane < e1; q += 64) {
+      const bool live = q < e1;
+      f(live, live ? a.indices[q] : 0);
+    }
+  }
+  __syncthreads();
+  const int nl = *s_nlong < kLongQueue ? *s_nlong : kLongQueue;
+  for (int k = 0; k < nl; ++k) {
+    const int32_t u = s_long[k];
+    const int64_t b1 = a.indptr[u], e1 = a.indptr[u + 1];
+    for (int64_t q = b1 + threadIdx.x; q - threadIdx.x < e1; q += kDgThreads) {
+      const bool live = q < e1;
+      f(live, live ? a.indices[q] : 0);
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kDgThreads) void k_dg_expand(const DgExpandArgs a) {
+  __shared__ int32_t s_com[kMaxP];
+  __shared__ int32_t s_long[kLongQueue];
+  __shared__ int32_t s_nlong;
+  __shared__ int32_t s_i;
+  uint32_t* bm = a.pool + (size_t)blockIdx.x * (size_t)a.words;
+  const uint16_t full = (uint16_t)((1u << a.P) - 1u);
+  for (;;) {
+    if (threadIdx.x == 0) s_i = (int32_t)atomicAdd(a.counters + 2, 1ull);
+    if (threadIdx.x < kMaxP) s_com[threadIdx.x] = 0;
+    __syncthreads();
+    const int32_t i = s_i;
+    if (i >= a.n) return;
+    const int64_t v = a.bv[i];
+    if (a.hops >= 2) {
+      walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { visit<true>(a, bm, s_com, i, v, live, w, full); });
+      __syncthreads();
+      // clear the bitmap the way it was filled (the words of a two-hop set are scattered: a memset of 12.5 MB per vertex at
+      // 10^8 vertices would cost more than the second walk)
+      walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { if (live) bm[w >> 5] = 0u; });
+    } else {
+      walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { visit<false>(a, bm, s_com, i, v, live, w, full); });
+    }
+    __syncthreads();
+    if (threadIdx.x < a.P) a.com0[(size_t)i * a.P + threadIdx.x] = s_com[threadIdx.x];
+    __syncthreads();
+  }
+}
+
+__global__ void k_dg_mark(const int64_t* bv, int32_t n, int8_t* bel, int8_t value) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) bel[bv[i]] = value;
+}
+
+// the batch's decisions applied to the snapshot: belongs, and r_belongs[ind] |= N(v) + {v} from the fresh lists themselves
+__global__ void k_dg_apply(const int64_t* bv, const int8_t* ind, int32_t n, const unsigned long long* fresh,
+                           unsigned long long n_fresh, int8_t* bel, uint16_t* rmask) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < (unsigned long long)n) {
+    const int64_t v = bv[t];
+    bel[v] = ind[t];
+    atomicOr((unsigned int*)(rmask + (v & ~1ll)), (unsigned int)(1u << ind[t]) << ((v & 1) * 16));
+  }
+  for (unsigned long long q = t; q < n_fresh; q += (unsigned long long)gridDim.x * blockDim.x) {
+    const unsigned long long k = fresh[q];
+    const int32_t i = (int32_t)(k >> 44);
+    const int64_t u = (int64_t)((k >> 16) & 0xFFFFFFFull);
+    const uint32_t bit = 1u << ind[i];
+    if ((uint32_t)(k & 0xFFFFu) & bit) atomicOr((unsigned int*)(rmask + (u & ~1ll)), bit << ((u & 1) * 16));
+  }
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess ? PG_OK : PG_ERR_NOMEM; }
+  template <typename T> T* as() { return reinterpret_cast<T*>(p); }
+};
+struct HostBuf {
+  void* p = nullptr;
+  ~HostBuf() { if (p) (void)hipHostFree(p); }
+  int alloc(size_t bytes) { return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? PG_OK : PG_ERR_NOMEM; }
+  template <typename T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const int32_t* indices_dev,
+                                   const int64_t* train_nids, int64_t n_train, int32_t P, int32_t hops,
+                                   int8_t* belongs_out, uint8_t* r_mask_out, int64_t* p_vnum_out, int64_t* r_vnum_out,
+                                   pg_dg_gpu_stats_t* stats, pg_stream_t stream) {
+  if (V <= 0 || !indptr_dev || !indices_dev || n_train < 0 || (n_train > 0 && !train_nids) || !belongs_out) return PG_ERR_INVALID;
+  if (P < 2 || P > 127 || hops < 1) return PG_ERR_INVALID;
+  // what this path covers; the caller falls back to pg_dg_partition_mt otherwise (same result, host only)
+  if (P > kMaxP || hops > 2 || V >= (1ll << 28)) return PG_ERR_UNSUPPORTED;
+  for (int64_t i = 0; i < n_train; ++i) {
+    if (train_nids[i] < 0 || train_nids[i] >= V) return PG_ERR_INVALID;
+    if (i && train_nids[i] <= train_nids[i - 1]) return PG_ERR_UNSUPPORTED;      // ascending, distinct (dg.py:122 np.nonzero)
+  }
+  hipStream_t st = as_stream(stream);
+  const double t_begin = now_s();
+  int dev = 0, cus = 0;
+  PG_HIP(hipGetDevice(&dev));
+  PG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int64_t words = (V + 31) / 32;
+  // bitmaps: up to 4 workgroups per CU, at most ~16 GB of them
+  int n_wg = hops >= 2 ? cus * 4 : cus * 8;
+  if (hops >= 2) n_wg = (int)std::max<int64_t>(cus, std::min<int64_t>(n_wg, (16ll << 30) / (words * 4)));
+  const int32_t b_max = 1 << 16;
+  const unsigned long long cap_fresh = (unsigned long long)std::max<int64_t>(V + 4096, 48ll << 20);
+  const unsigned long long cap_corr = 16ull << 20;
+
+  DevBuf d_bel, d_rmask, d_pool, d_bv, d_com0, d_fresh, d_fresh2, d_corr, d_corr2, d_cnt, d_ind, d_tmp;
+  HostBuf h_fresh, h_corr, h_com0, h_cnt, h_bv, h_ind;
+  const size_t rmask_elems = (size_t)((V + 1) & ~1ll);
+  if (d_bel.alloc((size_t)V) || d_rmask.alloc(rmask_elems * 2) || d_pool.alloc(hops >= 2 ? (size_t)n_wg * words * 4 : 4) ||
+      d_bv.alloc((size_t)b_max * 8) || d_com0.alloc((size_t)b_max * P * 4) || d_fresh.alloc(cap_fresh * 8) ||
+      d_fresh2.alloc(cap_fresh * 8) || d_corr.alloc(cap_corr * 8) || d_corr2.alloc(cap_corr * 8) || d_cnt.alloc(32) ||
+      d_ind.alloc((size_t)b_max))
+    return PG_ERR_NOMEM;
+  if (h_fresh.alloc(cap_fresh * 8) || h_corr.alloc(cap_corr * 8) || h_com0.alloc((size_t)b_max * P * 4) || h_cnt.alloc(32) ||
+      h_bv.alloc((size_t)b_max * 8) || h_ind.alloc((size_t)b_max))
+    return PG_ERR_NOMEM;
+  size_t tmp_bytes = 0, tb2 = 0;
+  {
+    unsigned long long* k = nullptr;
+    PG_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, k, k, (size_t)cap_fresh, 0, 64, st));
+    PG_HIP(rocprim::radix_sort_keys(nullptr, tb2, k, k, (size_t)cap_corr, 0, 64, st));
+    tmp_bytes = std::max(tmp_bytes, tb2);
+  }
+  if (d_tmp.alloc(tmp_bytes)) return PG_ERR_NOMEM;
+  PG_HIP(hipMemsetAsync(d_bel.p, 0xFF, (size_t)V, st));
+  PG_HIP(hipMemsetAsync(d_rmask.p, 0, rmask_elems * 2, st));
+  if (hops >= 2) PG_HIP(hipMemsetAsync(d_pool.p, 0, (size_t)n_wg * words * 4, st));
+
+  // host state (exact): dg.py:62-66
+  const size_t n_words64 = (size_t)(V + 63) / 64;
+  std::vector<std::vector<uint64_t>> rbits(P, std::vector<uint64_t>(n_words64, 0));
+  std::vector<int64_t> p_vnum(P, 0), r_vnum(P, 0), com(P);
+  std::vector<double> score(P);
+  std::vector<int32_t> order(P);
+  const double avg = (double)V * 0.65 / (double)P;
+  std::memset(belongs_out, 0xFF, (size_t)V);
+
+  pg_dg_gpu_stats_t s{};
+  int64_t i0 = 0;
+  int32_t bsz = 1;
+  while (i0 < n_train) {
+    const int32_t b = (int32_t)std::min<int64_t>(std::min<int64_t>(bsz, b_max), n_train - i0);
+    std::memcpy(h_bv.p, train_nids + i0, (size_t)b * 8);
+    const double t0 = now_s();
+    PG_HIP(hipMemcpyAsync(d_bv.p, h_bv.p, (size_t)b * 8, hipMemcpyHostToDevice, st));
+    PG_HIP(hipMemsetAsync(d_cnt.p, 0, 32, st));
+    hipLaunchKernelGGL(k_dg_mark, dim3((b + 255) / 256), dim3(256), 0, st, d_bv.as<int64_t>(), b, d_bel.as<int8_t>(), (int8_t)-2);
+    DgExpandArgs a{};
+    a.indptr = indptr_dev; a.indices = indices_dev; a.bv = d_bv.as<int64_t>(); a.n = b; a.P = P; a.hops = hops;
+    a.bel = d_bel.as<int8_t>(); a.rmask = d_rmask.as<uint16_t>(); a.pool = d_pool.as<uint32_t>(); a.words = words;
+    a.com0 = d_com0.as<int32_t>(); a.fresh = d_fresh.as<unsigned long long>(); a.corr = d_corr.as<unsigned long long>();
+    a.cap_fresh = cap_fresh; a.cap_corr = cap_corr; a.counters = d_cnt.as<unsigned long long>();
+    hipLaunchKernelGGL(k_dg_expand, dim3((unsigned)std::min<int>(n_wg, b)), dim3(kDgThreads), 0, st, a);
+    PG_LAUNCH_CHECK();
+    PG_HIP(hipMemcpyAsync(h_cnt.p, d_cnt.p, 32, hipMemcpyDeviceToHost, st));
+    PG_HIP(hipStreamSynchronize(st));
+    const unsigned long long n_fresh = h_cnt.as<unsigned long long>()[0], n_corr = h_cnt.as<unsigned long long>()[1];
+    s.seconds_expand += now_s() - t0;
+    ++s.batches;
+    if (n_fresh > cap_fresh || n_corr > cap_corr) {
+      // the lists did not fit: the same vertices again in a smaller batch (one vertex always fits: cap_fresh > V)
+      hipLaunchKernelGGL(k_dg_mark, dim3((b + 255) / 256), dim3(256), 0, st, d_bv.as<int64_t>(), b, d_bel.as<int8_t>(), (int8_t)-1);
+      ++s.batches_redone;
+      if (b == 1) return PG_ERR_UNSUPPORTED;        // (cannot happen: see cap_fresh / a single vertex has no corr entries)
+      bsz = std::max(1, b / 2);
+      continue;
+    }
+    const double t1 = now_s();
+    // group the lists by batch index (a whole-key sort: a few ms for the largest list; rocPRIM's bit-range variant left lists of
+    // ~1 K keys ungrouped on ROCm 7.0) and bring them over
+    unsigned long long* fr = d_fresh.as<unsigned long long>();
+    unsigned long long* co = d_corr.as<unsigned long long>();
+    if (b > 1) {
+      size_t tb = tmp_bytes;
+      if (n_fresh > 1) {
+        PG_HIP(rocprim::radix_sort_keys(d_tmp.p, tb, d_fresh.as<unsigned long long>(), d_fresh2.as<unsigned long long>(),
+                                        (size_t)n_fresh, 0, 64, st));
+        fr = d_fresh2.as<unsigned long long>();
+      }
+      tb = tmp_bytes;
+      if (n_corr > 1) {
+        PG_HIP(rocprim::radix_sort_keys(d_tmp.p, tb, d_corr.as<unsigned long long>(), d_corr2.as<unsigned long long>(),
+                                        (size_t)n_corr, 0, 64, st));
+        co = d_corr2.as<unsigned long long>();
+      }
+    }
+    if (n_fresh) PG_HIP(hipMemcpyAsync(h_fresh.p, fr, (size_t)n_fresh * 8, hipMemcpyDeviceToHost, st));
+    if (n_corr) PG_HIP(hipMemcpyAsync(h_corr.p, co, (size_t)n_corr * 8, hipMemcpyDeviceToHost, st));
+    PG_HIP(hipMemcpyAsync(h_com0.p, d_com0.p, (size_t)b * P * 4, hipMemcpyDeviceToHost, st));
+    PG_HIP(hipStreamSynchronize(st));
+    s.seconds_lists += now_s() - t1;
+    s.fresh_entries += (int64_t)n_fresh;
+    s.corr_entries += (int64_t)n_corr;
+    // ---- the committer: dg.py:71-83 in train order ------------------------------------------------------------------
+    const double t2 = now_s();
+    const unsigned long long* hf = h_fresh.as<unsigned long long>();
+    const unsigned long long* hc = h_corr.as<unsigned long long>();
+    const int32_t* hcom = h_com0.as<int32_t>();
+    int8_t* hind = h_ind.as<int8_t>();
+    unsigned long long qf = 0, qc = 0;
+    for (int32_t i = 0; i < b; ++i) {
+      const int64_t nid = train_nids[i0 + i];
+      for (int p = 0; p < P; ++p) com[p] = 1 + hcom[(size_t)i * P + p];
+      for (; qc < n_corr && (int32_t)(hc[qc] >> 32) == i; ++qc) {
+        const int8_t bb = belongs_out[(uint32_t)hc[qc]];
+        if (bb >= 0) ++com[bb];
+      }
+      for (int p = 0; p < P; ++p)
+        score[p] = (double)com[p] * (-(double)p_vnum[p] + avg) / (double)(r_vnum[p] + 1);
+      pg_np_argsort_f64(score.data(), P, order.data());
+      const int32_t o0 = order[P - 2], o1 = order[P - 1];
+      const int32_t ind = (score[o0] != score[o1]) ? o1 : ((p_vnum[o0] < p_vnum[o1]) ? o0 : o1);
+      hind[i] = (int8_t)ind;
+      belongs_out[nid] = (int8_t)ind;
+      ++p_vnum[ind];
+      uint64_t* rb = rbits[ind].data();
+      int64_t fresh = 0;
+      const unsigned long long bit = 1ull << ind;
+      for (; qf < n_fresh && (int32_t)(hf[qf] >> 44) == i; ++qf) {
+        const unsigned long long k = hf[qf];
+        if (!(k & bit)) continue;
+        const uint64_t u = (k >> 16) & 0xFFFFFFFull;
+        uint64_t& w = rb[u >> 6];
+        const uint64_t ub = 1ull << (u & 63);
+        if (!(w & ub)) { w |= ub; ++fresh; }
+      }
+      uint64_t& ws = rb[(size_t)nid >> 6];
+      const uint64_t nb = 1ull << (nid & 63);
+      if (!(ws & nb)) { ws |= nb; ++fresh; }
+      r_vnum[ind] += fresh;
+    }
+    if (qf != n_fresh || qc != n_corr) {                       // (a list that is not grouped by batch index: cannot happen)
+      fprintf(stderr, "[pg_dg_partition_gpu] internal: batch at %lld of %d: fresh %llu / %llu (next group %d), corr %llu / %llu (next group %d)\n",
+              (long long)i0, b, qf, n_fresh, qf < n_fresh ? (int)(hf[qf] >> 44) : -1, qc, n_corr,
+              qc < n_corr ? (int)(hc[qc] >> 32) : -1);
+      return PG_ERR_HIP;
+    }
+    s.seconds_commit += now_s() - t2;
+    // ---- decisions back to the snapshot --------------------------------------------------------------------------------
+    const double t3 = now_s();
+    PG_HIP(hipMemcpyAsync(d_ind.p, h_ind.p, (size_t)b, hipMemcpyHostToDevice, st));
+    {
+      const unsigned long long work = std::max<unsigned long long>(n_fresh, (unsigned long long)b);
+      const unsigned grid = (unsigned)std::min<unsigned long long>((work + 255) / 256, 1u << 16);
+      hipLaunchKernelGGL(k_dg_apply, dim3(grid), dim3(256), 0, st, d_bv.as<int64_t>(), d_ind.as<int8_t>(), b, fr, n_fresh,
+                         d_bel.as<int8_t>(), d_rmask.as<uint16_t>());
+      PG_LAUNCH_CHECK();
+    }
+    PG_HIP(hipStreamSynchronize(st));        // (h_ind / h_bv are reused by the next batch)
+    s.seconds_apply += now_s() - t3;
+    i0 += b;
+    s.largest_batch = std::max<int64_t>(s.largest_batch, b);
+    // grow while the lists are far from their buffers
+    if (n_fresh < cap_fresh / 8 && n_corr < cap_corr / 8) bsz = std::min<int32_t>(b_max, std::max(bsz, b) * 2);
+    else if (n_fresh > cap_fresh / 2 || n_corr > cap_corr / 2) bsz = std::max(1, b / 2);
+  }
+  if (r_mask_out)
+    for (int p = 0; p < P; ++p)
+      for (int64_t v = 0; v < V; ++v) r_mask_out[(size_t)p * V + v] = (rbits[p][(size_t)v >> 6] >> (v & 63)) & 1u;
+  if (p_vnum_out) std::copy(p_vnum.begin(), p_vnum.end(), p_vnum_out);
+  if (r_vnum_out) std::copy(r_vnum.begin(), r_vnum.end(), r_vnum_out);
+  s.seconds_total = now_s() - t_begin;
+  s.workgroups = n_wg;
+  if (stats) *stats = s;
+  return PG_OK;
+}

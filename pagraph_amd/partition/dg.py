@@ -32,20 +32,51 @@ def default_threads():
     return max(1, min(32, cpus))
 
 
-def dg_raw(partition_num, indptr, indices, vnum, train_nids, hops, threads=None):
-    """-> (belongs int8 [V], r_mask uint8 [P, V], p_vnum, r_vnum). threads: host threads sharing the work inside
-    each vertex when hops == 2 (default: every CPU the process may use; the result does not depend on it)"""
+LAST_GPU_STATS = None       # pg_dg_gpu_stats_t of the last device-assisted run (diagnosis / bench.py's record)
+
+
+def dg_raw(partition_num, indptr, indices, vnum, train_nids, hops, threads=None, device="auto", want_r_mask=True):
+    """-> (belongs int8 [V], r_mask uint8 [P, V] (or None), p_vnum, r_vnum).
+
+    device='auto' (default): the neighbour sets are built on the GPU (pg_dg_partition_gpu, round 6: hops 1 and 2, P <= 16)
+    when one is there — `indptr` / `indices` may be CUDA tensors (the graph already in HBM) or host arrays (uploaded) — else
+    on the host; 'cpu' forces the host code (pg_dg_partition_mt). Both give the same partition, bit for bit.
+    threads: host threads of the hops == 2 builder team of the host code (default: every CPU the process may use)."""
+    global LAST_GPU_STATS
+    import torch
     lib = L.load()
-    if threads is None:
-        threads = int(os.environ.get("PG_DG_THREADS", 0)) or default_threads()
     train = np.ascontiguousarray(train_nids, dtype=np.int64)
     belongs = np.empty(vnum, dtype=np.int8)
-    r_mask = np.empty((partition_num, vnum), dtype=np.uint8)
+    r_mask = np.empty((partition_num, vnum), dtype=np.uint8) if want_r_mask else None
     p_vnum = np.zeros(partition_num, dtype=np.int64)
     r_vnum = np.zeros(partition_num, dtype=np.int64)
     vp = ctypes.c_void_p
+    on_dev = torch.is_tensor(indptr) and indptr.is_cuda
+    if device != "cpu" and (on_dev or torch.cuda.is_available()) and partition_num <= 16 and hops <= 2 and vnum < (1 << 28) \
+            and (len(train) < 2 or bool(np.all(np.diff(train) > 0))):
+        ip = indptr if on_dev else torch.as_tensor(np.ascontiguousarray(indptr, dtype=np.int64)).cuda()
+        ix = indices if on_dev else torch.as_tensor(np.ascontiguousarray(indices, dtype=np.int32)).cuda()
+        ip, ix = ip.to(torch.int64).contiguous(), ix.to(torch.int32).contiguous()
+        st = L.PgDgGpuStats()
+        with torch.cuda.device(ip.device):
+            rc = lib.pg_dg_partition_gpu(vnum, L.ptr(ip), L.ptr(ix), vp(train.ctypes.data), len(train), partition_num, hops,
+                                         vp(belongs.ctypes.data), vp(r_mask.ctypes.data) if want_r_mask else None,
+                                         vp(p_vnum.ctypes.data), vp(r_vnum.ctypes.data), ctypes.byref(st), L.stream_ptr())
+        if rc == 0:
+            LAST_GPU_STATS = {n: getattr(st, n) for n, _ in st._fields_}
+            return belongs, r_mask, p_vnum, r_vnum
+        if rc != -4:                       # anything but PG_ERR_UNSUPPORTED is an error, not a reason to fall back
+            L.check(rc, "pg_dg_partition_gpu")
+    LAST_GPU_STATS = None
+    if threads is None:
+        threads = int(os.environ.get("PG_DG_THREADS", 0)) or default_threads()
+    if torch.is_tensor(indptr):
+        indptr, indices = indptr.cpu().numpy(), indices.cpu().numpy()
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
     L.check(lib.pg_dg_partition_mt(vnum, vp(indptr.ctypes.data), vp(indices.ctypes.data), vp(train.ctypes.data),
-                                   len(train), partition_num, hops, vp(belongs.ctypes.data), vp(r_mask.ctypes.data),
+                                   len(train), partition_num, hops, vp(belongs.ctypes.data),
+                                   vp(r_mask.ctypes.data) if want_r_mask else None,
                                    vp(p_vnum.ctypes.data), vp(r_vnum.ctypes.data), int(threads)), "pg_dg_partition_mt")
     return belongs, r_mask, p_vnum, r_vnum
 

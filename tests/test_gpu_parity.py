@@ -1878,8 +1878,32 @@ from tests import test_host_logic as _host   # noqa: E402
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "g4_*.npz"))), ids=os.path.basename)
-def test_dg_vs_reference_golden_on_gpu_box(hiplib, path):
-    _host.test_dg_product_vs_reference_golden(hiplib, path)
+@pytest.mark.parametrize("device", ["cpu", "cuda"])
+def test_dg_vs_reference_golden_on_gpu_box(hiplib, path, device):
+    """device='cuda': pg_dg_partition_gpu (round 6) against the reference's own outputs — every G4 fixture has P <= 16 and
+    hops <= 2, the envelope of the device-assisted path"""
+    _host.test_dg_product_vs_reference_golden(hiplib, path, device=device)
+
+
+@pytest.mark.parametrize("V,E,P,hops", [(1_000_000, 10_000_000, 4, 2), (1_000_000, 10_000_000, 8, 1), (300_000, 3_000_000, 16, 2),
+                                        (5000, 40000, 3, 2)])
+def test_dg_gpu_equals_the_sequential_host_code(dev, hiplib, V, E, P, hops):
+    """pg_dg_partition_gpu == pg_dg_partition_mt bit for bit on RMAT graphs with hubs (the first train vertices' two-hop sets
+    are most of the graph: batches of one, redone batches, the lists' buffers near their limits) — belongs, r_belongs,
+    p_vnum, r_vnum (dg.py:59-103)"""
+    from pagraph_amd.data import synthetic as syn
+    import importlib
+    dgmod = importlib.import_module("pagraph_amd.partition.dg")
+    indptr, indices = syn.rmat_graph(V, E, device=dev)
+    train_mask, _, _ = syn.split_dataset(V)
+    train = torch.nonzero(train_mask).squeeze(1).numpy()
+    a = dgmod.dg_raw(P, indptr, indices, V, train, hops, device="cuda")
+    st = dict(dgmod.LAST_GPU_STATS)
+    b = dgmod.dg_raw(P, indptr, indices, V, train, hops, device="cpu")
+    assert dgmod.LAST_GPU_STATS is None
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert a[2].sum() == len(train) and st["batches"] >= 1 and st["largest_batch"] >= min(len(train), 64)
 
 
 @pytest.mark.parametrize("V,E,P,hops", [(3000, 20000, 4, 1), (3000, 12000, 8, 2), (1500, 6000, 3, 3), (2000, 9000, 16, 2)])

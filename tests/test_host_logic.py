@@ -74,12 +74,16 @@ def test_host_gather_rows(hiplib):
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "g4_*.npz"))), ids=os.path.basename)
-def test_dg_product_vs_reference_golden(hiplib, path):
-    """pg_dg_partition (C++) reproduces the reference dg() outputs (dg.py:59-103)"""
-    from pagraph_amd.partition.dg import dg_raw
+def test_dg_product_vs_reference_golden(hiplib, path, device="cpu"):
+    """pg_dg_partition (C++; device='cuda': pg_dg_partition_gpu, the neighbour sets built on the device) reproduces the
+    reference dg() outputs (dg.py:59-103)"""
+    import importlib
+    dgmod = importlib.import_module("pagraph_amd.partition.dg")
     z = np.load(path)
     P, V, hops = int(z["P"]), int(z["V"]), int(z["hops"])
-    belongs, r_mask, p_vnum, r_vnum = dg_raw(P, z["csc_indptr"], z["csc_indices"].astype(np.int32), V, z["train_nids"], hops)
+    belongs, r_mask, p_vnum, r_vnum = dgmod.dg_raw(P, z["csc_indptr"], z["csc_indices"].astype(np.int32), V, z["train_nids"], hops,
+                                                   device=device)
+    assert (dgmod.LAST_GPU_STATS is not None) == (device != "cpu" and P <= 16 and hops <= 2)      # (else: the host code)
     for p in range(P):
         assert np.array_equal(np.where(belongs == p)[0], z[f"sub_trainv_{p}"])
         assert np.array_equal(np.where(r_mask[p] != 0)[0], z[f"sub_v_{p}"])
