@@ -121,9 +121,7 @@ def parse():
     p.add_argument("--skip-microbench", action="store_true")
     p.add_argument("--dg-hops", type=int, default=None,
                    help="hops used by dg's affinity score (dg.py --num-hops). Default: 2 (README.md:117, the value for a "
-                        "2-layer model without preprocessing = BASELINE configs[3]) up to 2e7 vertices — sum(deg^2) = "
-                        "4.7e10 adjacency entries on the 10M/100M graph, ~1 min with the builder/committer threads of "
-                        "pg_dg_partition_mt (500 s in one thread) — and 1 beyond that (config 5's graph would take >10 min)")
+                        "2-layer model without preprocessing = BASELINE configs 4 and 5)")
     p.add_argument("--fetch-all", action="store_true",
                    help="fetch every layer and field like the reference (default: only what the model reads, SURVEY 8f-2)")
     p.add_argument("--skip-reference-equivalent", action="store_true", help="skip the short run that fetches every layer "
@@ -527,7 +525,7 @@ def preflight(world, rank, gpu, dev, args):
         enter("dg (rank 0) + broadcast")
         belongs = torch.empty(V, dtype=torch.int8)
         if rank == 0:
-            belongs = torch.from_numpy(dg_raw(world, indptr.cpu().numpy(), indices.cpu().numpy(), V, train_full.numpy(), 1)[0])
+            belongs = torch.from_numpy(dg_raw(world, indptr, indices, V, train_full.numpy(), 2, want_r_mask=False)[0])
         belongs = belongs.to(dev)
         parallel.broadcast_tensor(belongs, src=0)
         my_train = torch.nonzero(belongs == rank).squeeze(1).cpu()
@@ -736,7 +734,9 @@ def run():
     from pagraph_amd import parallel
     from pagraph_amd.data import synthetic as syn
     from pagraph_amd.model import GCNSampling, GraphSageSampling
-    from pagraph_amd.partition.dg import dg_raw
+    import importlib
+    dgmod = importlib.import_module("pagraph_amd.partition.dg")
+    dg_raw = dgmod.dg_raw
     from pagraph_amd.partition.utils import closure_device
     from pagraph_amd.sampling import DeviceGraph, NeighborSampler
     from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
@@ -757,7 +757,7 @@ def run():
 
     V, E, Fdim, C, B, k = args.vertices, args.edges, args.feat_size, args.n_classes, args.batch_size, args.num_neighbors
     if args.dg_hops is None:
-        args.dg_hops = 2 if V <= 20_000_000 else 1
+        args.dg_hops = 2        # README.md:117: --num-hops of a 2-layer model without preprocessing (BASELINE configs 4 and 5)
     n_layers = 1
     num_hops = n_layers + 1                                   # pa_gcn.py:52
     hidden = 32 if args.model == "gcn" else 16                # pa_gcn.py:130 / pa_gs.py:134
@@ -774,13 +774,12 @@ def run():
     g_full = DeviceGraph.from_csc(indptr, indices, V)
     in_deg = (indptr[1:] - indptr[:-1]).float()
 
-    # what dg.py --num-hops 2 (README.md:117: the value for a 2-layer model) would have to walk on this graph: the two-hop
-    # in-neighbourhood of every train vertex = sum(deg^2) adjacency entries, consumed by ONE sequential committer (every
-    # assignment reads r_vnum as the previous one left it, dg.py:71-83). Measured rate of pg_dg_partition_mt: 4.7e10 entries in
-    # 68 s on the 10M / 100M graph (tools/exp_dg_hops2.py). Reported so that config 5's `dg_hops` is an informed choice.
+    # what dg.py --num-hops 2 (README.md:117: the value for a 2-layer model) has to walk on this graph: the two-hop in-neighbourhood
+    # of every train vertex = sum(deg^2) adjacency entries. Round 6: the device builds those sets (pg_dg_partition_gpu, ~1.4e10
+    # entries per second: 8.5 s on the 10M / 100M graph, 133 s on config 5's — profiles/r06/dg_gpu_*.json); round 3's host team
+    # took 68 s at 10M through one committer and was never run at 10^8 (~1000 s).
     deg_d = (indptr[1:] - indptr[:-1]).double()
     sum_deg_sq = float((deg_d * deg_d).sum().item())
-    dg_hops2_est_s = sum_deg_sq * (68.0 / 4.7e10)
     del deg_d
     # ---- partition ------------------------------------------------------------------------
     t0 = time.time()
@@ -794,12 +793,14 @@ def run():
         import tempfile
         dg_file = os.path.join(tempfile.gettempdir(), f"pagraph_bench_dg_{V}_{E}_P{emul_P}_h{args.dg_hops}.npz")
         dg_cached = os.path.exists(dg_file) and not os.environ.get("PG_BENCH_NO_DG_CACHE")
+        dg_stats = None
         if dg_cached:
             z_ = np.load(dg_file)
             b, p_vnum, r_vnum, dg_s = z_["belongs"], z_["p_vnum"], z_["r_vnum"], float(z_["seconds"])
         else:
-            b, _, p_vnum, r_vnum = dg_raw(emul_P, indptr.cpu().numpy(), indices.cpu().numpy(), V, train_full.numpy(), args.dg_hops)
+            b, _, p_vnum, r_vnum = dg_raw(emul_P, indptr, indices, V, train_full.numpy(), args.dg_hops, want_r_mask=False)
             dg_s = time.time() - t_dg
+            dg_stats = dgmod.LAST_GPU_STATS
             try:
                 np.savez(dg_file, belongs=b, p_vnum=p_vnum, r_vnum=r_vnum, seconds=dg_s)
             except OSError:
@@ -817,7 +818,9 @@ def run():
         cl_s = time.time() - t_cl
         which = args.which_rank if args.which_rank is not None else max(parts, key=lambda e: e["partition_vertices"])["rank"]
         eq_steps = max(e["steps"] for e in parts)
-        share_rec_p = {"P": emul_P, "dg_hops": args.dg_hops, "dg_seconds": dg_s, "dg_result_reused_from_an_earlier_run_on_this_box": bool(dg_cached),
+        share_rec_p = {"P": emul_P, "dg_hops": args.dg_hops, "dg_seconds": dg_s,
+                       "dg_on": "device-assisted (pg_dg_partition_gpu)" if dg_stats else ("reused" if dg_cached else "host (pg_dg_partition_mt)"),
+                       "dg_device_stats": dg_stats, "dg_result_reused_from_an_earlier_run_on_this_box": bool(dg_cached),
                        "closures_seconds": cl_s, "p_vnum": p_vnum.tolist(),
                        "r_vnum": r_vnum.tolist(), "partitions": parts, "rank_run": which,
                        "rank_chosen_by": "--which-rank" if args.which_rank is not None else "largest closure",
@@ -829,17 +832,10 @@ def run():
         my_train = train_full
     else:
         belongs = torch.empty(V, dtype=torch.int8)
-        # what the other ranks are about to wait for in the broadcast below (so that a driver time-out is attributable): the
-        # hops-2 score walks sum(deg^2) adjacency entries — 4.7e10 on the 10M/100M graph = 68 s with 16 host threads
-        # (tools/exp_dg_hops2.py, committer-bound, so fewer threads cost little); hops 1 is ~1 s per 10^7 train vertices
-        deg_f = (indptr[1:] - indptr[:-1]).double()
-        work = float((deg_f * deg_f).sum().item()) if args.dg_hops >= 2 else float(deg_f.sum().item())
-        dg_est = work * (68.0 / 4.7e10) if args.dg_hops >= 2 else 2.0 + train_full.numel() * 1e-7
-        log(f"[bench] rank {rank}: dg P={world} hops={args.dg_hops} on rank 0 — time budget ~{dg_est:.0f} s "
-            f"({work:.2e} adjacency entries to walk); the other ranks wait in a broadcast meanwhile")
+        log(f"[bench] rank {rank}: dg P={world} hops={args.dg_hops} on rank 0 (neighbour sets built on its GPU: ~9 s at 10M / 100M, "
+            f"~2 min at 10^8 / 10^9 with hops 2); the other ranks wait in a broadcast meanwhile")
         if rank == 0:
-            b, _, p_vnum, r_vnum = dg_raw(world, indptr.cpu().numpy(), indices.cpu().numpy(), V, train_full.numpy(),
-                                          args.dg_hops)
+            b, _, p_vnum, r_vnum = dg_raw(world, indptr, indices, V, train_full.numpy(), args.dg_hops, want_r_mask=False)
             belongs = torch.from_numpy(b)
             log(f"[bench] dg P={world} hops={args.dg_hops}: {time.time()-t0:.1f}s p_vnum={p_vnum.tolist()} r_vnum={r_vnum.tolist()}")
         belongs = belongs.to(dev)
@@ -1441,8 +1437,8 @@ def run():
                        "miss_mode": args.miss_mode, "miss_wait": "host" if cacher.host_wait else "device",
                        "miss_mode_probe": mode_probe, "overlap": not args.no_overlap,
                        "partition_vertices": Vs, "dg_hops": args.dg_hops if (world > 1 or emul_P > 1) else None,
-                       "dg_hops2_cost": {"sum_deg_squared": sum_deg_sq, "estimated_seconds_one_committer": dg_hops2_est_s,
-                                         "basis": "4.7e10 adjacency entries in 68 s (10M/100M graph, 16 host threads)"},
+                       "dg_hops2_work": {"sum_deg_squared": sum_deg_sq,
+                                         "note": "adjacency entries dg --num-hops 2 walks; pg_dg_partition_gpu: ~1.4e10 per second"},
                        "hip_graph_step": use_graph,
                        # how a captured step is replayed: its kernels as plain launches (csrc/pg_tape.hip, the default on one GPU)
                        # or hipGraphLaunch (PG_FLAT_REPLAY=0, world > 1, or a graph that is not a chain of kernel / memset nodes)

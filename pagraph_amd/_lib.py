@@ -93,7 +93,7 @@ class PgAdamDesc(ctypes.Structure):
 
 
 class PgDgGpuStats(ctypes.Structure):
-    _fields_ = [(n, c_i64) for n in ("batches", "batches_redone", "largest_batch", "fresh_entries", "corr_entries", "workgroups")] + \
+    _fields_ = [(n, c_i64) for n in ("batches", "batches_redone", "largest_batch", "fresh_entries", "corr_entries", "workgroups", "candidate_misses")] + \
                [(n, ctypes.c_double) for n in ("seconds_total", "seconds_expand", "seconds_lists", "seconds_commit", "seconds_apply")]
 
 

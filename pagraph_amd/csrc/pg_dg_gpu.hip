@@ -52,6 +52,10 @@ struct DgExpandArgs {
   uint32_t* pool;             // gridDim.x de-duplication bitmaps
   int64_t words;              // uint32 words per bitmap
   int32_t* com0;              // [n][P]
+  uint16_t* cand;             // [n] the partitions whose fresh members are listed for the vertex (see candidates())
+  float a[kMaxP];             // (avg - p_vnum[p]) / (r_vnum[p] + 1) at the batch's start (dg.py:54-55 without com)
+  float theta;                // a partition is a candidate when its best possible score >= theta x the best certain one
+  int32_t all_candidates;     // 1: every partition for every vertex (near the end of the run, when a[] moves fast)
   unsigned long long* fresh;  // keys: batch index << 44 | vertex << 16 | mask
   unsigned long long* corr;   // keys: batch index << 32 | vertex
   unsigned long long cap_fresh, cap_corr;
@@ -73,25 +77,56 @@ __device__ __forceinline__ void emit(unsigned long long* buf, unsigned long long
   }
 }
 
-// one member of the multiset: first visit -> what the snapshot says about it
+// pass 1, one member of the multiset: first visit -> which partition the snapshot has it in, or is it a batch member
 template <bool DEDUP>
-__device__ __forceinline__ void visit(const DgExpandArgs& a, uint32_t* bm, int32_t* s_com, int32_t i, int64_t v, bool live,
-                                      int32_t w, uint16_t full) {
+__device__ __forceinline__ void visit1(const DgExpandArgs& a, uint32_t* bm, int32_t* s_com, int32_t i, int64_t v, bool live,
+                                       int32_t w) {
   bool first = live;
   if (DEDUP && live) {
     const uint32_t bit = 1u << (w & 31);
     first = !(atomicOr(&bm[w >> 5], bit) & bit);
   }
   int8_t b = -1;
-  uint16_t miss = 0;
   if (first) {
     b = a.bel[w];
-    miss = (uint16_t)(~a.rmask[w]) & full;
     if (b >= 0) atomicAdd(&s_com[b], 1);
   }
-  emit(a.corr, a.counters + 1, a.cap_corr, first && b == -2 && (int64_t)w < v, ((unsigned long long)i << 32) | (uint32_t)w);
-  emit(a.fresh, a.counters + 0, a.cap_fresh, first && miss != 0,
+  const bool pending = first && b == -2 && (int64_t)w < v;
+  if (pending) atomicAdd(&s_com[kMaxP], 1);
+  emit(a.corr, a.counters + 1, a.cap_corr, pending, ((unsigned long long)i << 32) | (uint32_t)w);
+}
+
+// pass 2: the member leaves the bitmap (whoever finds its bit still set clears it; two lanes may both find it — a duplicate
+// entry, which the host's test-and-set and k_dg_apply's atomicOr absorb) and is listed if a CANDIDATE partition lacks it
+template <bool DEDUP>
+__device__ __forceinline__ void visit2(const DgExpandArgs& a, uint32_t* bm, int32_t i, bool live, int32_t w, uint16_t cand) {
+  bool first = live;
+  if (DEDUP && live) {
+    const uint32_t bit = 1u << (w & 31);
+    // (a load that cannot be served from the CU's own cache: the line may still show the bit as the previous vertex left it)
+    first = (__hip_atomic_load(&bm[w >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) != 0u;
+    if (first) atomicAnd(&bm[w >> 5], ~bit);
+  }
+  uint16_t miss = 0;
+  if (first) miss = (uint16_t)(~a.rmask[w]) & cand;
+  emit(a.fresh, a.counters + 0, a.cap_fresh, miss != 0,
        ((unsigned long long)i << 44) | ((unsigned long long)(uint32_t)w << 16) | miss);
+}
+
+// Which partitions can still win vertex i (dg.py:51-55,30-35)? score[p] = com[p] * a[p] with com[p] between 1 + com0[p] and
+// 1 + com0[p] + (batch members among the neighbours), and a[p] a little below its value at the batch's start. A partition whose
+// best case stays under theta x the best certain score is left out of the fresh list — the list then names, per member, only the
+// CANDIDATES that lack it, instead of every partition that will never get the vertex anyway (a vertex 600 000 vertices of
+// partition 3's set lack costs every neighbour of theirs an entry otherwise: 8.7e9 entries on the 10M / 100M graph, 70 GB over
+// PCIe). It is a guess, and the host checks it: a decision outside the candidates ends the batch in front of that vertex.
+__device__ __forceinline__ uint16_t candidates(const DgExpandArgs& a, const int32_t* s_com, int32_t i, uint16_t full) {
+  if (a.all_candidates || i == 0) return full;       // (a batch's first vertex always has them all: the run cannot stall)
+  float best = 0.f;
+  for (int q = 0; q < a.P; ++q) best = fmaxf(best, (float)(1 + s_com[q]) * a.a[q]);
+  uint16_t c = 0;
+  for (int p = 0; p < a.P; ++p)
+    if ((float)(1 + s_com[p] + s_com[kMaxP]) * a.a[p] >= a.theta * best) c |= (uint16_t)(1u << p);
+  return c;
 }
 
 // walk the multiset of batch vertex v: in(v) (hops 1), plus in(u) for every u in in(v) (hops 2: dg.py:22-27). `f(live, w)` is
@@ -139,30 +174,34 @@ __device__ __forceinline__ void walk(const DgExpandArgs& a, int64_t v, int32_t* 
 }
 
 __global__ __launch_bounds__(kDgThreads) void k_dg_expand(const DgExpandArgs a) {
-  __shared__ int32_t s_com[kMaxP];
+  __shared__ int32_t s_com[kMaxP + 1];          // per partition: settled members; [kMaxP]: batch members in front of v
   __shared__ int32_t s_long[kLongQueue];
   __shared__ int32_t s_nlong;
   __shared__ int32_t s_i;
+  __shared__ uint16_t s_cand;
   uint32_t* bm = a.pool + (size_t)blockIdx.x * (size_t)a.words;
   const uint16_t full = (uint16_t)((1u << a.P) - 1u);
   for (;;) {
     if (threadIdx.x == 0) s_i = (int32_t)atomicAdd(a.counters + 2, 1ull);
-    if (threadIdx.x < kMaxP) s_com[threadIdx.x] = 0;
+    if (threadIdx.x <= kMaxP) s_com[threadIdx.x] = 0;
     __syncthreads();
     const int32_t i = s_i;
     if (i >= a.n) return;
     const int64_t v = a.bv[i];
-    if (a.hops >= 2) {
-      walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { visit<true>(a, bm, s_com, i, v, live, w, full); });
-      __syncthreads();
-      // clear the bitmap the way it was filled (the words of a two-hop set are scattered: a memset of 12.5 MB per vertex at
-      // 10^8 vertices would cost more than the second walk)
-      walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { if (live) bm[w >> 5] = 0u; });
-    } else {
-      walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { visit<false>(a, bm, s_com, i, v, live, w, full); });
-    }
+    if (a.hops >= 2) walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { visit1<true>(a, bm, s_com, i, v, live, w); });
+    else walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { visit1<false>(a, bm, s_com, i, v, live, w); });
     __syncthreads();
+    if (threadIdx.x == 0) {
+      s_cand = candidates(a, s_com, i, full);
+      a.cand[i] = s_cand;
+    }
     if (threadIdx.x < a.P) a.com0[(size_t)i * a.P + threadIdx.x] = s_com[threadIdx.x];
+    __syncthreads();
+    const uint16_t cand = s_cand;
+    // the second walk empties the bitmap the way it was filled (the words of a two-hop set are scattered: a memset of 12.5 MB per
+    // vertex at 10^8 vertices would cost more) and lists the members the candidates lack
+    if (a.hops >= 2) walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { visit2<true>(a, bm, i, live, w, cand); });
+    else walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { visit2<false>(a, bm, i, live, w, cand); });
     __syncthreads();
   }
 }
@@ -184,6 +223,7 @@ __global__ void k_dg_apply(const int64_t* bv, const int8_t* ind, int32_t n, cons
   for (unsigned long long q = t; q < n_fresh; q += (unsigned long long)gridDim.x * blockDim.x) {
     const unsigned long long k = fresh[q];
     const int32_t i = (int32_t)(k >> 44);
+    if (i >= n) continue;                      // (the batch ended in front of this vertex: its lists are dropped)
     const int64_t u = (int64_t)((k >> 16) & 0xFFFFFFFull);
     const uint32_t bit = 1u << ind[i];
     if ((uint32_t)(k & 0xFFFFu) & bit) atomicOr((unsigned int*)(rmask + (u & ~1ll)), bit << ((u & 1) * 16));
@@ -228,21 +268,22 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
   PG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const int64_t words = (V + 31) / 32;
   // bitmaps: up to 4 workgroups per CU, at most ~16 GB of them
+  // (2, 4 or 8 workgroups per CU expand at the same rate: profiles/r06/dg_gpu_sweep.txt)
   int n_wg = hops >= 2 ? cus * 4 : cus * 8;
   if (hops >= 2) n_wg = (int)std::max<int64_t>(cus, std::min<int64_t>(n_wg, (16ll << 30) / (words * 4)));
   const int32_t b_max = 1 << 16;
   const unsigned long long cap_fresh = (unsigned long long)std::max<int64_t>(V + 4096, 48ll << 20);
   const unsigned long long cap_corr = 16ull << 20;
 
-  DevBuf d_bel, d_rmask, d_pool, d_bv, d_com0, d_fresh, d_fresh2, d_corr, d_corr2, d_cnt, d_ind, d_tmp;
-  HostBuf h_fresh, h_corr, h_com0, h_cnt, h_bv, h_ind;
+  DevBuf d_bel, d_rmask, d_pool, d_bv, d_com0, d_cand, d_fresh, d_fresh2, d_corr, d_corr2, d_cnt, d_ind, d_tmp;
+  HostBuf h_fresh, h_corr, h_com0, h_cand, h_cnt, h_bv, h_ind;
   const size_t rmask_elems = (size_t)((V + 1) & ~1ll);
   if (d_bel.alloc((size_t)V) || d_rmask.alloc(rmask_elems * 2) || d_pool.alloc(hops >= 2 ? (size_t)n_wg * words * 4 : 4) ||
-      d_bv.alloc((size_t)b_max * 8) || d_com0.alloc((size_t)b_max * P * 4) || d_fresh.alloc(cap_fresh * 8) ||
+      d_bv.alloc((size_t)b_max * 8) || d_com0.alloc((size_t)b_max * P * 4) || d_cand.alloc((size_t)b_max * 2) || d_fresh.alloc(cap_fresh * 8) ||
       d_fresh2.alloc(cap_fresh * 8) || d_corr.alloc(cap_corr * 8) || d_corr2.alloc(cap_corr * 8) || d_cnt.alloc(32) ||
       d_ind.alloc((size_t)b_max))
     return PG_ERR_NOMEM;
-  if (h_fresh.alloc(cap_fresh * 8) || h_corr.alloc(cap_corr * 8) || h_com0.alloc((size_t)b_max * P * 4) || h_cnt.alloc(32) ||
+  if (h_fresh.alloc(cap_fresh * 8) || h_corr.alloc(cap_corr * 8) || h_com0.alloc((size_t)b_max * P * 4) || h_cand.alloc((size_t)b_max * 2) || h_cnt.alloc(32) ||
       h_bv.alloc((size_t)b_max * 8) || h_ind.alloc((size_t)b_max))
     return PG_ERR_NOMEM;
   size_t tmp_bytes = 0, tb2 = 0;
@@ -279,6 +320,19 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
     DgExpandArgs a{};
     a.indptr = indptr_dev; a.indices = indices_dev; a.bv = d_bv.as<int64_t>(); a.n = b; a.P = P; a.hops = hops;
     a.bel = d_bel.as<int8_t>(); a.rmask = d_rmask.as<uint16_t>(); a.pool = d_pool.as<uint32_t>(); a.words = words;
+    a.cand = d_cand.as<uint16_t>();
+    {
+      // dg.py:54-55 without com, as of now; near the end of the run (avg - p_vnum within a few batches of zero, or past it)
+      // it moves too fast inside a batch for a guess: every partition is a candidate then
+      bool fast = false;
+      for (int p = 0; p < P; ++p) {
+        const double room = avg - (double)p_vnum[p];
+        a.a[p] = (float)(room / (double)(r_vnum[p] + 1));
+        if (room < 8.0 * (double)b) fast = true;
+      }
+      a.theta = 0.95f;         // (0.8: 1 wrong guess and 1.11e9 list entries on the 10M / 100M graph; 0.95: 14 and 0.94e9, 9 % faster)
+      a.all_candidates = (fast || b == 1) ? 1 : 0;
+    }
     a.com0 = d_com0.as<int32_t>(); a.fresh = d_fresh.as<unsigned long long>(); a.corr = d_corr.as<unsigned long long>();
     a.cap_fresh = cap_fresh; a.cap_corr = cap_corr; a.counters = d_cnt.as<unsigned long long>();
     hipLaunchKernelGGL(k_dg_expand, dim3((unsigned)std::min<int>(n_wg, b)), dim3(kDgThreads), 0, st, a);
@@ -288,6 +342,7 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
     const unsigned long long n_fresh = h_cnt.as<unsigned long long>()[0], n_corr = h_cnt.as<unsigned long long>()[1];
     s.seconds_expand += now_s() - t0;
     ++s.batches;
+
     if (n_fresh > cap_fresh || n_corr > cap_corr) {
       // the lists did not fit: the same vertices again in a smaller batch (one vertex always fits: cap_fresh > V)
       hipLaunchKernelGGL(k_dg_mark, dim3((b + 255) / 256), dim3(256), 0, st, d_bv.as<int64_t>(), b, d_bel.as<int8_t>(), (int8_t)-1);
@@ -318,6 +373,7 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
     if (n_fresh) PG_HIP(hipMemcpyAsync(h_fresh.p, fr, (size_t)n_fresh * 8, hipMemcpyDeviceToHost, st));
     if (n_corr) PG_HIP(hipMemcpyAsync(h_corr.p, co, (size_t)n_corr * 8, hipMemcpyDeviceToHost, st));
     PG_HIP(hipMemcpyAsync(h_com0.p, d_com0.p, (size_t)b * P * 4, hipMemcpyDeviceToHost, st));
+    PG_HIP(hipMemcpyAsync(h_cand.p, d_cand.p, (size_t)b * 2, hipMemcpyDeviceToHost, st));
     PG_HIP(hipStreamSynchronize(st));
     s.seconds_lists += now_s() - t1;
     s.fresh_entries += (int64_t)n_fresh;
@@ -328,7 +384,9 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
     const unsigned long long* hc = h_corr.as<unsigned long long>();
     const int32_t* hcom = h_com0.as<int32_t>();
     int8_t* hind = h_ind.as<int8_t>();
+    const uint16_t* hcand = h_cand.as<uint16_t>();
     unsigned long long qf = 0, qc = 0;
+    int32_t done = 0;                      // vertices of this batch that were decided
     for (int32_t i = 0; i < b; ++i) {
       const int64_t nid = train_nids[i0 + i];
       for (int p = 0; p < P; ++p) com[p] = 1 + hcom[(size_t)i * P + p];
@@ -341,6 +399,12 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
       pg_np_argsort_f64(score.data(), P, order.data());
       const int32_t o0 = order[P - 2], o1 = order[P - 1];
       const int32_t ind = (score[o0] != score[o1]) ? o1 : ((p_vnum[o0] < p_vnum[o1]) ? o0 : o1);
+      if (!((hcand[i] >> ind) & 1)) {
+        // the device did not list the members partition `ind` lacks (it guessed that `ind` could not win): the batch ends
+        // here, this vertex opens the next one — where it has every partition as a candidate
+        ++s.candidate_misses;
+        break;
+      }
       hind[i] = (int8_t)ind;
       belongs_out[nid] = (int8_t)ind;
       ++p_vnum[ind];
@@ -359,30 +423,35 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
       const uint64_t nb = 1ull << (nid & 63);
       if (!(ws & nb)) { ws |= nb; ++fresh; }
       r_vnum[ind] += fresh;
+      done = i + 1;
     }
-    if (qf != n_fresh || qc != n_corr) {                       // (a list that is not grouped by batch index: cannot happen)
-      fprintf(stderr, "[pg_dg_partition_gpu] internal: batch at %lld of %d: fresh %llu / %llu (next group %d), corr %llu / %llu (next group %d)\n",
-              (long long)i0, b, qf, n_fresh, qf < n_fresh ? (int)(hf[qf] >> 44) : -1, qc, n_corr,
-              qc < n_corr ? (int)(hc[qc] >> 32) : -1);
+    if (done == b && (qf != n_fresh || qc != n_corr)) {        // (a list that is not grouped by batch index: cannot happen)
+      fprintf(stderr, "[pg_dg_partition_gpu] internal: batch at %lld of %d: fresh %llu / %llu, corr %llu / %llu\n", (long long)i0, b,
+              qf, n_fresh, qc, n_corr);
       return PG_ERR_HIP;
     }
+    if (done == 0) return PG_ERR_HIP;                           // (a batch's first vertex has every candidate)
     s.seconds_commit += now_s() - t2;
     // ---- decisions back to the snapshot --------------------------------------------------------------------------------
     const double t3 = now_s();
-    PG_HIP(hipMemcpyAsync(d_ind.p, h_ind.p, (size_t)b, hipMemcpyHostToDevice, st));
+    PG_HIP(hipMemcpyAsync(d_ind.p, h_ind.p, (size_t)done, hipMemcpyHostToDevice, st));
+    if (done < b)
+      hipLaunchKernelGGL(k_dg_mark, dim3((b - done + 255) / 256), dim3(256), 0, st, d_bv.as<int64_t>() + done, b - done,
+                         d_bel.as<int8_t>(), (int8_t)-1);
     {
-      const unsigned long long work = std::max<unsigned long long>(n_fresh, (unsigned long long)b);
+      const unsigned long long work = std::max<unsigned long long>(n_fresh, (unsigned long long)done);
       const unsigned grid = (unsigned)std::min<unsigned long long>((work + 255) / 256, 1u << 16);
-      hipLaunchKernelGGL(k_dg_apply, dim3(grid), dim3(256), 0, st, d_bv.as<int64_t>(), d_ind.as<int8_t>(), b, fr, n_fresh,
+      hipLaunchKernelGGL(k_dg_apply, dim3(grid), dim3(256), 0, st, d_bv.as<int64_t>(), d_ind.as<int8_t>(), done, fr, n_fresh,
                          d_bel.as<int8_t>(), d_rmask.as<uint16_t>());
       PG_LAUNCH_CHECK();
     }
     PG_HIP(hipStreamSynchronize(st));        // (h_ind / h_bv are reused by the next batch)
     s.seconds_apply += now_s() - t3;
-    i0 += b;
-    s.largest_batch = std::max<int64_t>(s.largest_batch, b);
-    // grow while the lists are far from their buffers
-    if (n_fresh < cap_fresh / 8 && n_corr < cap_corr / 8) bsz = std::min<int32_t>(b_max, std::max(bsz, b) * 2);
+    i0 += done;
+    s.largest_batch = std::max<int64_t>(s.largest_batch, done);
+    // grow while the lists are far from their buffers and the guesses hold; a batch that ended early sets the size for the next
+    if (done < b) bsz = std::max(1, std::max(done, b / 4));
+    else if (n_fresh < cap_fresh / 8 && n_corr < cap_corr / 8) bsz = std::min<int32_t>(b_max, std::max(bsz, b) * 2);
     else if (n_fresh > cap_fresh / 2 || n_corr > cap_corr / 2) bsz = std::max(1, b / 2);
   }
   if (r_mask_out)
