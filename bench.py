@@ -118,6 +118,8 @@ def parse():
     p.add_argument("--no-overlap", action="store_true")
     p.add_argument("--skip-cpu-baseline", action="store_true")
     p.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    p.add_argument("--cpu-baseline-min-steps", type=int, default=0, help="run at least this many CPU minibatches whatever the time")
+    p.add_argument("--cpu-baseline-one-leg", action="store_true", help="the 16-thread leg only (no second leg on every core)")
     p.add_argument("--skip-microbench", action="store_true")
     p.add_argument("--dg-hops", type=int, default=None,
                    help="hops used by dg's affinity score (dg.py --num-hops). Default: 2 (README.md:117, the value for a "
@@ -250,7 +252,7 @@ def make_host_table(V, Fdim, rank, local_rank, world, dev, tag):
 
 
 # ----------------------------------------------------------------------------- CPU baseline
-def cpu_baseline(args, g, sub2full_h, seeds_h, feat_tab, norm_tab, labels_dense_h, steps_per_epoch, budget_s, threads=16):
+def cpu_baseline(args, g, sub2full_h, seeds_h, feat_tab, norm_tab, labels_dense_h, steps_per_epoch, budget_s, threads=16, min_steps=0):
     """The reference's CPU path restated, timed on this box's host cores on a
     bounded sample of the same workload: C/OpenMP sampler (oracle) + torch CPU `table[nid_map[ids]]`
     for every NodeFlow row and field (dgl_gcn.py:83 / storage.py:117-131) + H2D + torch-CPU model
@@ -285,7 +287,7 @@ def cpu_baseline(args, g, sub2full_h, seeds_h, feat_tab, norm_tab, labels_dense_
     t_s = t_l = t_m = 0.0
     done = 0
     t_begin = time.time()
-    while done < 64 and (time.time() - t_begin) < budget_s:
+    while done < 64 and ((time.time() - t_begin) < budget_s or done < min_steps) and done * B < len(seeds_h):
         t0 = time.time()
         nf = oracle.sample_nodeflow(indptr_h, indices_h, seeds_h[done * B:(done + 1) * B], k, hops, 0, 0, done)
         t1 = time.time()
@@ -611,8 +613,11 @@ CONFIG_LEGS = (
     # config 2: Reddit's shape (232 965 vertices, mean degree 492, feat 602, 41 classes), table resident in HBM, 2-layer GCN —
     # 26 steps per epoch, ten epochs (examples/profile/pa_gcn.py:144-150 defaults; SURVEY 8d "Config 2")
     ("config2_reddit_shape_full_cache_gcn",
+     # ... with BASELINE config 1 beside it (round 6): the reference's CPU plumbing restated on the SAME graph on the host cores —
+     # the oracle's sampler + torch CPU table[nid_map[ids]] for every layer and field (dgl_gcn.py:83, storage.py:126-131) + the
+     # model on the CPU, 16 threads, at least one epoch's 26 minibatches
      ["--vertices", "232965", "--edges", "57300000", "--feat-size", "602", "--n-classes", "41", "--cache-ratio", "1.0",
-      "--model", "gcn", "--steps", "260"]),
+      "--model", "gcn", "--steps", "260", "--cpu-baseline-seconds", "4", "--cpu-baseline-min-steps", "26", "--cpu-baseline-one-leg"]),
     # config 3: the headline graph with config 3's own model — GraphSAGE-mean, hidden 16, lr 1e-2 (pa_gs.py:134,141) — and the
     # 30 % hot-degree cache: one whole epoch (1 084 steps)
     ("config3_rmat_10M_graphsage_30pct_cache", ["--model", "graphsage", "--cache-ratio", "0.30"]),
@@ -631,7 +636,9 @@ def config_legs(args, budget_s=420.0):
     t_all = time.time()
     for name, flags in CONFIG_LEGS:
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--warmup", "10", "--no-configs", "--skip-microbench",
-               "--skip-cpu-baseline", "--skip-opt-hit", "--skip-reference-equivalent"] + flags
+               "--skip-opt-hit", "--skip-reference-equivalent"] + flags
+        if "--cpu-baseline-min-steps" not in flags:
+            cmd.append("--skip-cpu-baseline")
         if args.host_threads:
             cmd += ["--host-threads", str(args.host_threads)]
         t0 = time.time()
@@ -658,6 +665,8 @@ def config_legs(args, budget_s=420.0):
                 "roofline": {k_: rf.get(k_) for k_ in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms",
                                                        "launches_timed", "algorithmic_bytes_per_launch", "kernel_body_ms")},
                 "leg_wall_s": time.time() - t0}
+            if d.get("cpu_baseline"):
+                out[name]["cpu_baseline"] = d["cpu_baseline"]        # (config 1: the CPU plumbing on this leg's graph)
             if d["config"].get("rank_of_P"):
                 out[name]["rank_of_P"] = d["config"]["rank_of_P"]
                 out[name]["step_shape"] = d["config"]["step_shape"]
@@ -1374,11 +1383,13 @@ def run():
         # leg 1: 16 threads = the reference's sampler num_workers (pa_gcn.py:148); leg 2: every core the process may
         # use — the affinity mask, capped by the cgroup CPU quota, which is what "all cores" means
         # inside this container
-        cpu = cpu_baseline(*cpu_args, args.cpu_baseline_seconds, threads=16)
+        cpu = cpu_baseline(*cpu_args, args.cpu_baseline_seconds, threads=16, min_steps=args.cpu_baseline_min_steps)
         hi = host_info()
         all_cores = int(min(hi["cpus_affinity"] or hi["cpus_online"] or 16, hi["cgroup_cpu_quota"] or 1 << 30))
         cpu["cores_usable"] = all_cores
-        if all_cores != 16:
+        if args.cpu_baseline_one_leg:
+            cpu["all_cores"] = None
+        elif all_cores != 16:
             leg = cpu_baseline(*cpu_args, args.cpu_baseline_seconds / 2, threads=all_cores)
             cpu["all_cores"] = {k_: leg[k_] for k_ in ("value", "unit", "cores", "sample", "ms_per_step")}
         else:

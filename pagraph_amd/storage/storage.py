@@ -234,6 +234,9 @@ class _FetchPlan:
                  "layer_lo", "first_layer", "num_layers", "same_fields", "dedup")
 
 
+_DEFERRED_MISSQ = []      # miss queues whose owner was finalised where it could not wait for the device (close())
+
+
 class GraphCacheServer:
     """Manage graph features: static top-out-degree HBM cache + hit/miss gather."""
 
@@ -1018,6 +1021,13 @@ class GraphCacheServer:
                 "waits_by_spin_kernel": int(v[3]), "us_submit_to_published": v[4], "us_cpu_gather": v[5],
                 "us_enqueue": v[6], "us_submit_to_done": v[7],
                 "sdma_engine_mask": int(eng.value),      # 0 = hipMemcpyAsync (the runtime picks the engine)
+                # which way the worker's copies go (csrc/pg_missq.hip): straight to one calibrated SDMA engine with the consumer
+                # watching the completion signal (the default); the same engine but ordered through the copy stream
+                # (PG_MISSQ_NO_DIRECT=1); or hipMemcpyAsync on the copy stream when ROCr's engine interface is not usable
+                # (the probe failed, or PG_MISSQ_HSA_COPY=0) — the tested fallback
+                "copy_path": ("hipMemcpyAsync on the copy stream (fallback)" if not eng.value else
+                              ("ROCr SDMA engine, ordered through the copy stream" if os.environ.get("PG_MISSQ_NO_DIRECT") == "1"
+                               else "ROCr SDMA engine, direct (consumer watches the completion signal)")),
                 "sdma_engine_h2d_GBps": {b: round(rate[b], 1) for b in range(16) if rate[b] > 0}}
 
     def miss_queue_longest(self, reset=False):
@@ -1060,16 +1070,30 @@ class GraphCacheServer:
     def close(self):
         """deterministic teardown: wait for the device (kernels of the pipeline may still read the cache, the slot map and the
         miss queue's staged blocks), then stop the miss queue's threads and free its buffers. Idempotent."""
+        waited = False
         try:
             if (L.del_waits_enabled() and torch.cuda.is_available() and getattr(self, "device", None) is not None
                     and not torch.cuda.is_current_stream_capturing()):
                 torch.cuda.synchronize(self.device)
+                waited = True
         except Exception:
             pass
         try:
             if getattr(self, "_missq", None):
-                self.lib.pg_missq_destroy(self._missq)
+                if waited or not torch.cuda.is_available():
+                    self.lib.pg_missq_destroy(self._missq)
+                else:
+                    # The wait had to be skipped (a finalizer running inside a capture of this thread, or PG_NO_DEL_WAIT): a
+                    # hipFree inside a capture invalidates it, and the staged blocks may still be read by kernels in flight
+                    # (ADVICE r05). The queue is parked and destroyed by the next close() of ANY cacher that could wait.
+                    _DEFERRED_MISSQ.append((self.lib, self._missq, getattr(self, "device", None)))
                 self._missq = None
+            if waited:
+                while _DEFERRED_MISSQ:
+                    lib_, q_, dev_ = _DEFERRED_MISSQ.pop()
+                    if dev_ is not None and dev_ != self.device:
+                        torch.cuda.synchronize(dev_)
+                    lib_.pg_missq_destroy(q_)
         except Exception:
             pass
 

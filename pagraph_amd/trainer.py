@@ -46,7 +46,10 @@ class MinibatchTrainer:
         return False
 
     def __del__(self):
-        self.close()                     # best-effort backstop; the buffers' lifetimes are the allocator's (L.record_streams)
+        try:
+            self.close()                 # best-effort backstop; the buffers' lifetimes are the allocator's (L.record_streams)
+        except Exception:                # (interpreter shutdown: module globals may be gone already)
+            pass
 
     def __init__(self, model, loss_fcn, optimizer, cacher, sampler, labels, device, overlap=True, need=None):
         self.need = need             # fetch_data(need=...): None = every layer and field, like the reference
@@ -382,7 +385,10 @@ class GraphedTrainer:
         # best-effort backstop (never inside a capture: L.safe_stream_wait). What keeps a dropped trainer's buffers from being
         # recycled under kernels still in flight is the allocator itself: every buffer another stream touches is recorded on
         # that stream where it is created (L.record_streams in __init__ / _make_slot / _aggregate_early)
-        self.close()
+        try:
+            self.close()
+        except Exception:                # (interpreter shutdown: module globals may be gone already)
+            pass
 
     def _make_slot(self, nf):
         s = GraphedTrainer._Slot()
@@ -634,13 +640,15 @@ class GraphedTrainer:
             return False
         step_value = 0
         if s.early is not None:
+            if len(s.early) > L.PG_MAX_LAYERS:
+                # (checked BEFORE _early_args, which hands out this batch's dropout step value: the generic sequence the caller
+                # falls back to asks for it again — ADVICE r05)
+                s.batch_plan = False
+                return False
             call = self._early_args(nf, s, self.load_stream)
             if s.batch_key[2] is not call:
                 # the early launches' arguments, once per (slot, plan, model mode): the C struct's copies of what
                 # _aggregate_early passes call by call
-                if len(call[2]) > L.PG_MAX_LAYERS:
-                    s.batch_plan = False
-                    return False
                 for i, ((args, d), (blk, _f, rows)) in enumerate(zip(call[2], s.early)):
                     e = bp.early[i]
                     out = s.agg0[blk]

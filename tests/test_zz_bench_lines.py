@@ -244,6 +244,44 @@ def test_cli_pipeline_end_to_end(dev, hiplib, tmp_path):
     assert len(vals) == 2 and 0.2 < vals[1] <= vals[0] <= 1.0      # degree policy <= oracle
 
 
+@pytest.mark.parametrize("env", [{"PG_MISSQ_NO_DIRECT": "1"}, {"PG_MISSQ_HSA_COPY": "0"}], ids=["copy-stream", "hipMemcpyAsync"])
+def test_miss_queue_fallback_copy_paths(dev, hiplib, env, tmp_path):
+    """The worker's copies normally go straight to one calibrated SDMA engine (hsa_amd_memory_async_copy_on_engine), the consumer
+    watching the completion signal. Both fallbacks — the same engine ordered through the copy stream (PG_MISSQ_NO_DIRECT=1), and
+    hipMemcpyAsync when ROCr's engine interface is unusable (PG_MISSQ_HSA_COPY=0 = the probe of csrc/pg_missq.hip failing) — are
+    one ROCm update away from being the only path: G1 bit-exact in every async mode, the fused / virtual paths
+    equal to the materialised ones, check_misses() clean, and a bench line that names the path and its copy rate. The switches are
+    read once per process, hence the child processes. storage.py:117-131."""
+    import json
+    import subprocess
+    import sys
+    child = dict(os.environ, **env)
+    sel = ("(test_fetch_data_vs_reference_golden and async) or (test_fetch_only_what_the_model_reads and async) or "
+           "(test_virtual_layer0_matches_materialised and async) or test_async_miss_path_survives_hardware_queue_sharing or "
+           "(test_early_layer0_aggregation_matches_the_in_step_one and async)")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu",
+                        "-k", sel, "-p", "no:cacheprovider"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=child)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
+    assert " passed" in r.stdout and "failed" not in r.stdout
+    # ... and the training loop over that path: the line says which one it was and what the copies reached
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--vertices", "1000000", "--edges", "10000000", "--steps", "200",
+                        "--no-configs", "--skip-microbench", "--skip-cpu-baseline", "--skip-opt-hit", "--skip-reference-equivalent"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(child, PG_MISSQ_COPYLOG="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    mq = d["miss_queue"]
+    want = "copy stream" if "PG_MISSQ_NO_DIRECT" in env else "hipMemcpyAsync"
+    assert want in mq["copy_path"], mq["copy_path"]
+    assert (mq["sdma_engine_mask"] == 0) == ("PG_MISSQ_HSA_COPY" in env)
+    assert d["trained"]["finite"] and not d["misses_timed_out"] and d["config"]["miss_mode"] == "async"
+    assert mq["timed_region"]["jobs"] >= 200 and d["cache_hit_pct_rows_fetched_by_timed_loop"] < 100.0
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out) and os.access(out, os.W_OK):
+        with open(os.path.join(out, f"missq_fallback_{'_'.join(env)}.json"), "w") as f:
+            json.dump({"env": env, "copy_path": mq["copy_path"], "ms_per_step": d["config"]["epoch_ms_per_step"],
+                       "miss_copy_GBps_windows": d.get("miss_copy_GBps_windows"), "miss_queue": mq}, f)
+
+
 def test_bench_default_path_end_to_end_small(dev, hiplib):
     """`python bench.py` with every default phase on (timed loop, gather micro-benchmark, cache-policy analysis,
     CPU baseline) at a small size: exactly one JSON line on stdout carrying the contract's keys"""
