@@ -27,7 +27,6 @@
 #include <cstdlib>
 #include <cstring>
 
-#include <rocprim/block/block_radix_sort.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "pg_common.h"
@@ -681,9 +680,17 @@ __global__ __launch_bounds__(256) void k_t_heavy(const int32_t* __restrict__ tpt
 // The same transpose in ONE workgroup, for blocks of at most 1024 * ITEMS edges and source rows (the 12 000-edge seeds'
 // block of the benchmark's step): no global atomics (the hub's counter was one contended address), no multi-pass device sort
 // (seven small launches running beside the compute stream's HBM-bound kernel), one CU. Edges are packed
-// (source << val_bits | destination) in edge = destination order and sorted STABLY on the source bits only (LSD block radix
-// sort) — every source's destinations stay ascending, exactly the device sort's result. tptr comes from the
-// run starts: rs[s] = first sorted position of source s (or nnz), then tptr[s] = min over s' >= s of rs[s'] (suffix-min scan).
+// (source << val_bits | destination) in edge = destination order and sorted STABLY on the source bits only — every source's
+// destinations stay ascending, exactly the device sort's result. tptr comes from the run starts: rs[s] = first sorted position
+// of source s (or nnz), then tptr[s] = min over s' >= s of rs[s'] (suffix-min scan).
+// Round 6: the sort is written here (rounds 2-5: rocprim::block_radix_sort, four 4-bit passes, 37.8 us — the longest kernel of
+// every step). Source ids of such a block have at most 14 bits: TWO least-significant-digit passes of 7 bits. The keys live in
+// LDS in edge order; wave w owns the contiguous range [w * 64 * ITEMS, (w + 1) * 64 * ITEMS) and walks it in ITEMS rounds of 64
+// consecutive keys (lane = position inside the round), so "earlier in the input" = (earlier wave, earlier round, lower lane):
+//   rank of a key among the keys of its wave with the same digit = the wave's running count of that digit (LDS, one counter
+//   per wave and digit) + the lanes below it in this round that hold the same digit (seven ballots build the match mask);
+//   an exclusive scan over the 128 x 16 counters in (digit, wave) order turns ranks into positions; the keys are written back
+//   to LDS at their positions (every key was read into registers before the first one is written: in place).
 template <int ITEMS>
 __global__ __launch_bounds__(1024) void k_t_block(const int32_t* __restrict__ indptr, const int32_t* __restrict__ src,
                                                   const int32_t* __restrict__ n_dst_dev,
@@ -693,15 +700,17 @@ __global__ __launch_bounds__(1024) void k_t_block(const int32_t* __restrict__ in
                                                   int32_t* __restrict__ tdst, int32_t* __restrict__ heavy,
                                                   int32_t heavy_cap, Bnd bnd) {
   // PG_BOUNDS: [0] destination rows + 1, [1] edge capacity + 1, [2] source rows (a block edge becomes a sort key / an LDS index)
-  using Sort = rocprim::block_radix_sort<uint32_t, 1024, ITEMS>;
   constexpr int kN = 1024 * ITEMS;
+  constexpr int kDigitBits = 7, kDigits = 1 << kDigitBits, kWaves = 1024 / kWave;
   __shared__ union {
-    typename Sort::storage_type sort;
+    uint32_t keys[kN];
     int32_t rs[kN + 1];
     int32_t ip[kN + 1];                           // the block's indptr while the keys are built (n_dst <= cap_edges <= kN)
   } lds;
+  __shared__ int32_t hist[kDigits * kWaves];      // [digit][wave]: counts, then exclusive positions
   __shared__ uint32_t edge_key[1024];
   __shared__ int32_t wave_min[16];
+  __shared__ int32_t wave_sum[16];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
   const int n = (int)PG_IDX((long long)*n_dst_dev, bnd, 0, PG_K_T_BLOCK, 1);
   const int nnz = (int)PG_IDX((long long)*nnz_dev, bnd, 1, PG_K_T_BLOCK, 2);
@@ -739,9 +748,61 @@ __global__ __launch_bounds__(1024) void k_t_block(const int32_t* __restrict__ in
       }
     }
   }
-  __syncthreads();                                // lds.ip is dead: the sort's storage may overwrite it
-  Sort().sort(k, lds.sort, (unsigned)val_bits, (unsigned)(val_bits + key_bits));
-  __syncthreads();                                // lds.sort is dead from here on: rs may overwrite it
+  __syncthreads();                                // lds.ip is dead: the keys take its place, in edge order
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) lds.keys[tid * ITEMS + j] = k[j];
+  // ---- stable LSD passes over the source bits ------------------------------------------------------------------------
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int shift = val_bits; shift < val_bits + key_bits; shift += kDigitBits) {
+    for (int i = tid; i < kDigits * kWaves; i += 1024) hist[i] = 0;
+    __syncthreads();
+    uint32_t kr[ITEMS];
+    int32_t rank[ITEMS];
+    volatile int32_t* hw = hist + w;              // this wave's column: hist[digit * kWaves + w]
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+      const uint32_t key = lds.keys[(w * ITEMS + r) * kWave + lane];
+      const uint32_t d = (key >> shift) & (uint32_t)(kDigits - 1);
+      unsigned long long m = ~0ull;               // lanes of this round that hold the same digit
+#pragma unroll
+      for (int bit = 0; bit < kDigitBits; ++bit) {
+        const unsigned long long bm = __ballot((d >> bit) & 1u);
+        m &= ((d >> bit) & 1u) ? bm : ~bm;
+      }
+      const int32_t before = hw[d * kWaves];      // the wave's count of this digit in its earlier rounds
+      kr[r] = key;
+      rank[r] = before + __popcll(m & below);
+      if ((m & below) == 0ull) hw[d * kWaves] = before + __popcll(m);     // the digit's lowest lane keeps the count
+    }
+    __syncthreads();
+    // exclusive scan of hist in (digit, wave) order = memory order: two entries per thread
+    {
+      const int32_t a0 = hist[2 * tid], a1 = hist[2 * tid + 1];
+      int32_t incl = a0 + a1;
+#pragma unroll
+      for (int dlt = 1; dlt < kWave; dlt <<= 1) {
+        const int32_t t = __shfl_up(incl, dlt);
+        if (lane >= dlt) incl += t;
+      }
+      if (lane == kWave - 1) wave_sum[w] = incl;
+      __syncthreads();
+      int32_t base = 0;
+      for (int ww = 0; ww < w; ++ww) base += wave_sum[ww];
+      const int32_t excl = base + incl - (a0 + a1);
+      hist[2 * tid] = excl;
+      hist[2 * tid + 1] = excl + a0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+      const uint32_t d = (kr[r] >> shift) & (uint32_t)(kDigits - 1);
+      lds.keys[hist[d * kWaves + w] + rank[r]] = kr[r];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) k[j] = lds.keys[tid * ITEMS + j];
+  __syncthreads();                                // lds.keys is dead from here on: rs may overwrite it
   for (int i = tid; i <= kN; i += 1024) lds.rs[i] = nnz;
   edge_key[tid] = k[ITEMS - 1];
   __syncthreads();

@@ -2386,6 +2386,11 @@ def _rank_share_checks(dev, oracle, g_full, V, table, belongs, P, B, k, hops, ra
                               sub2full, 0, miss_mode="async")
     cacher.init_field(["features"])
     cacher.log = True
+    # the reference's cache-size rule subtracts the PEAK allocation (storage.py:70-84): building the synthetic graph and the
+    # partition on this GPU is not part of the trainer process that rule was written for
+    del g_full
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(dev)
     cacher.auto_cache(g, ["features"], cache_ratio=ratio)
     n_cached = int(Vs * ratio)
     assert cacher.cached_num == n_cached and not cacher.full_cached
