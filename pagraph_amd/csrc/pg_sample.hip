@@ -679,187 +679,151 @@ __global__ __launch_bounds__(256) void k_t_heavy(const int32_t* __restrict__ tpt
 
 // The same transpose in ONE workgroup, for blocks of at most 1024 * ITEMS edges and source rows (the 12 000-edge seeds'
 // block of the benchmark's step): no global atomics (the hub's counter was one contended address), no multi-pass device sort
-// (seven small launches running beside the compute stream's HBM-bound kernel), one CU. Edges are packed
-// (source << val_bits | destination) in edge = destination order and sorted STABLY on the source bits only — every source's
-// destinations stay ascending, exactly the device sort's result. tptr comes from the run starts: rs[s] = first sorted position
-// of source s (or nnz), then tptr[s] = min over s' >= s of rs[s'] (suffix-min scan).
-// Round 6: the sort is written here (rounds 2-5: rocprim::block_radix_sort, four 4-bit passes, 37.8 us — the longest kernel of
-// every step). Source ids of such a block have at most 14 bits: TWO least-significant-digit passes of 7 bits. The keys live in
-// LDS in edge order; wave w owns the contiguous range [w * 64 * ITEMS, (w + 1) * 64 * ITEMS) and walks it in ITEMS rounds of 64
-// consecutive keys (lane = position inside the round), so "earlier in the input" = (earlier wave, earlier round, lower lane):
-//   rank of a key among the keys of its wave with the same digit = the wave's running count of that digit (LDS, one counter
-//   per wave and digit) + the lanes below it in this round that hold the same digit (seven ballots build the match mask);
-//   an exclusive scan over the 128 x 16 counters in (digit, wave) order turns ranks into positions; the keys are written back
-//   to LDS at their positions (every key was read into registers before the first one is written: in place).
+// (seven small launches running beside the compute stream's HBM-bound kernel), one CU.
+// Round 6: a counting sort by source, entirely in LDS (145 KB of the CU's 160). Rounds 2-5 packed (source, destination) keys and
+// sorted them stably with rocprim::block_radix_sort (37.8 us, the longest kernel of every step); a hand-written stable LSD sort
+// (two 7-bit passes, ranks from seven-ballot match masks) measured 34 us — phase stamps showed the passes VALU-bound: one CU
+// issues 64 lanes per clock, and 14 ballots + mask updates per key are ~55 vector instructions x 12 288 keys. A (source,
+// destination) pair is unique, so stability is not needed if every source's destinations are simply put in ascending order:
+//   1. destination of every edge: the thread of destination v writes v over its edges [indptr[v], indptr[v + 1])   (LDS array B)
+//   2. histogram of the sources (LDS adds), exclusive scan = tptr (written out coalesced); sources with more than PG_HEAVY_ROW
+//      edges are the backward pass's hub list
+//   3. placement in ANY order: position = returning LDS add on the source's running end                        (B -> B)
+//   4. every edge counts the destinations of its source that are smaller than its own = its rank               (B -> C)
+//      (sum over sources of count^2 reads: sources of a fan-out-2 block have one or two edges)
+//   5. hubs: their destinations set bits in a bitmap; the set bits in order are the sorted list                 (B -> C)
+//   6. tdst = C, coalesced.
 template <int ITEMS>
 __global__ __launch_bounds__(1024) void k_t_block(const int32_t* __restrict__ indptr, const int32_t* __restrict__ src,
                                                   const int32_t* __restrict__ n_dst_dev,
                                                   const int32_t* __restrict__ nnz_dev, int32_t cap_edges,
-                                                  int32_t cap_rows, int val_bits, int key_bits,
-                                                  uint32_t* __restrict__ stage, int32_t* __restrict__ tptr,
+                                                  int32_t cap_rows, int32_t* __restrict__ tptr,
                                                   int32_t* __restrict__ tdst, int32_t* __restrict__ heavy,
                                                   int32_t heavy_cap, Bnd bnd) {
-  // PG_BOUNDS: [0] destination rows + 1, [1] edge capacity + 1, [2] source rows (a block edge becomes a sort key / an LDS index)
+  // PG_BOUNDS: [0] destination rows + 1, [1] edge capacity + 1, [2] source rows (a block edge becomes an LDS index)
   constexpr int kN = 1024 * ITEMS;
-  constexpr int kDigitBits = 7, kDigits = 1 << kDigitBits, kWaves = 1024 / kWave;
-  __shared__ union {
-    uint32_t keys[kN];
-    int32_t rs[kN + 1];
-    int32_t ip[kN + 1];                           // the block's indptr while the keys are built (n_dst <= cap_edges <= kN)
-  } lds;
-  __shared__ int32_t hist[kDigits * kWaves];      // [digit][wave]: counts, then exclusive positions
-  __shared__ uint32_t edge_key[1024];
-  __shared__ int32_t wave_min[16];
+  constexpr int kWords = kN / 32;
+  constexpr int kHubs = kN / (PG_HEAVY_ROW + 1) + 1;       // more sources than this cannot have > PG_HEAVY_ROW edges each
+  // A is indexed by source id both at random (adds) and ITEMS-in-a-row per thread (scan): one word of padding per 32 keeps the
+  // row-wise accesses of a wave off the same banks
+#define T_PAD(i) ((i) + ((i) >> 5))
+  __shared__ int32_t A[T_PAD(kN) + 2];            // per source: edge count -> exclusive start -> (after placement) end
+  __shared__ int32_t B[kN];                       // per edge: its destination; then the destinations grouped by source
+  __shared__ int32_t C[kN];                       // the destinations grouped by source, ascending inside a source = tdst
+  __shared__ uint32_t bits[kWords];
   __shared__ int32_t wave_sum[16];
+  __shared__ int32_t hub_start[kHubs], hub_count[kHubs];
+  __shared__ int32_t n_hubs;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
   const int n = (int)PG_IDX((long long)*n_dst_dev, bnd, 0, PG_K_T_BLOCK, 1);
   const int nnz = (int)PG_IDX((long long)*nnz_dev, bnd, 1, PG_K_T_BLOCK, 2);
-  if (tid == 0 && heavy) heavy[0] = 0;
-  // keys in edge order, ITEMS consecutive edges per thread (blocked): indptr goes through LDS (one round of independent,
-  // coalesced loads), a thread's source ids are ITEMS independent loads, its first edge's destination one binary search
-  // in LDS, the following ones a walk — no dependent global-memory chain per destination
-  for (int i = tid; i <= n; i += 1024) lds.ip[i] = indptr[i];
-  uint32_t k[ITEMS];
+  if (tid == 0) {
+    if (heavy) heavy[0] = 0;
+    n_hubs = 0;
+  }
+  // one value per thread -> its exclusive prefix over the workgroup (contains barriers: called by every thread)
+  auto block_exclusive = [&](int32_t x) -> int32_t {
+    int32_t incl = x;
+#pragma unroll
+    for (int dlt = 1; dlt < kWave; dlt <<= 1) {
+      const int32_t t = __shfl_up(incl, dlt);
+      if (lane >= dlt) incl += t;
+    }
+    __syncthreads();                              // (wave_sum may still be read by the previous call)
+    if (lane == kWave - 1) wave_sum[w] = incl;
+    __syncthreads();
+    int32_t base = 0;
+    for (int ww = 0; ww < w; ++ww) base += wave_sum[ww];
+    return base + incl - x;
+  };
+  // ---- loads: edge e = tid + 1024 j (coalesced), destination v = tid + 1024 j; all in flight together ------------------
+  int32_t sr[ITEMS], ip0[ITEMS], ip1[ITEMS];
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
-    const int e = tid * ITEMS + j;
-    k[j] = e < nnz ? (uint32_t)PG_IDX(src[e], bnd, 2, PG_K_T_BLOCK, 3) : 0u;
+    const int e = tid + j * 1024;
+    sr[j] = e < nnz ? (int32_t)PG_IDX(src[e], bnd, 2, PG_K_T_BLOCK, 3) : -1;
+    ip0[j] = e < n ? indptr[e] : 0;
+    ip1[j] = e < n ? indptr[e + 1] : 0;
   }
+  for (int i = tid; i < T_PAD(kN) + 2; i += 1024) A[i] = 0;
   __syncthreads();
-  {
-    const int e0 = tid * ITEMS;
-    int v = 0;
-    if (e0 < nnz) {
-      int lo = 0, hi = n;                         // smallest index with ip[index] > e0 (ip[n] = nnz > e0)
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (lds.ip[mid] > e0) hi = mid; else lo = mid + 1;
-      }
-      v = lo - 1;
-    }
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-      const int e = e0 + j;
-      if (e < nnz) {
-        while (lds.ip[v + 1] <= e) ++v;           // skips empty destinations
-        k[j] = (k[j] << val_bits) | (uint32_t)v;
-      } else {
-        k[j] = 0xFFFFFFFFu;                       // padding sorts behind every source
-      }
-    }
-  }
-  __syncthreads();                                // lds.ip is dead: the keys take its place, in edge order
-#pragma unroll
-  for (int j = 0; j < ITEMS; ++j) lds.keys[tid * ITEMS + j] = k[j];
-  // ---- stable LSD passes over the source bits ------------------------------------------------------------------------
-  const unsigned long long below = (1ull << lane) - 1ull;
-  for (int shift = val_bits; shift < val_bits + key_bits; shift += kDigitBits) {
-    for (int i = tid; i < kDigits * kWaves; i += 1024) hist[i] = 0;
-    __syncthreads();
-    uint32_t kr[ITEMS];
-    int32_t rank[ITEMS];
-    volatile int32_t* hw = hist + w;              // this wave's column: hist[digit * kWaves + w]
-#pragma unroll
-    for (int r = 0; r < ITEMS; ++r) {
-      const uint32_t key = lds.keys[(w * ITEMS + r) * kWave + lane];
-      const uint32_t d = (key >> shift) & (uint32_t)(kDigits - 1);
-      unsigned long long m = ~0ull;               // lanes of this round that hold the same digit
-#pragma unroll
-      for (int bit = 0; bit < kDigitBits; ++bit) {
-        const unsigned long long bm = __ballot((d >> bit) & 1u);
-        m &= ((d >> bit) & 1u) ? bm : ~bm;
-      }
-      const int32_t before = hw[d * kWaves];      // the wave's count of this digit in its earlier rounds
-      kr[r] = key;
-      rank[r] = before + __popcll(m & below);
-      if ((m & below) == 0ull) hw[d * kWaves] = before + __popcll(m);     // the digit's lowest lane keeps the count
-    }
-    __syncthreads();
-    // exclusive scan of hist in (digit, wave) order = memory order: two entries per thread
-    {
-      const int32_t a0 = hist[2 * tid], a1 = hist[2 * tid + 1];
-      int32_t incl = a0 + a1;
-#pragma unroll
-      for (int dlt = 1; dlt < kWave; dlt <<= 1) {
-        const int32_t t = __shfl_up(incl, dlt);
-        if (lane >= dlt) incl += t;
-      }
-      if (lane == kWave - 1) wave_sum[w] = incl;
-      __syncthreads();
-      int32_t base = 0;
-      for (int ww = 0; ww < w; ++ww) base += wave_sum[ww];
-      const int32_t excl = base + incl - (a0 + a1);
-      hist[2 * tid] = excl;
-      hist[2 * tid + 1] = excl + a0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < ITEMS; ++r) {
-      const uint32_t d = (kr[r] >> shift) & (uint32_t)(kDigits - 1);
-      lds.keys[hist[d * kWaves + w] + rank[r]] = kr[r];
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int j = 0; j < ITEMS; ++j) k[j] = lds.keys[tid * ITEMS + j];
-  __syncthreads();                                // lds.keys is dead from here on: rs may overwrite it
-  for (int i = tid; i <= kN; i += 1024) lds.rs[i] = nnz;
-  edge_key[tid] = k[ITEMS - 1];
-  __syncthreads();
-  const uint32_t vmask = (1u << val_bits) - 1u;
-  uint32_t prev = tid ? edge_key[tid - 1] : 0xFFFFFFFFu;
+  // ---- 1 + 2: destinations per edge, histogram of the sources -------------------------------------------------------------
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
-    const int i = tid * ITEMS + j;
-    if (i < cap_edges) tdst[i] = k[j] != 0xFFFFFFFFu ? (int32_t)(k[j] & vmask) : 0;
-    const bool first = (i == 0) || (prev >> val_bits) != (k[j] >> val_bits);
-    if (k[j] != 0xFFFFFFFFu && first) lds.rs[k[j] >> val_bits] = i;
-    prev = k[j];
+    const int v = tid + j * 1024;
+    for (int e = ip0[j]; e < ip1[j]; ++e) B[e] = v;
+    if (sr[j] >= 0) atomicAdd(&A[T_PAD(sr[j])], 1);
   }
   __syncthreads();
-  // suffix-min over rs[0 .. kN]: inside the thread's ITEMS entries, then across threads (wave shuffles + 16 wave minima)
-  int32_t loc[ITEMS];
-  int32_t m = 0x7fffffff;
-#pragma unroll
-  for (int j = ITEMS - 1; j >= 0; --j) {
-    const int32_t r = lds.rs[tid * ITEMS + j];
-    m = r < m ? r : m;
-    loc[j] = m;
-  }
-  int32_t incl = m;
-#pragma unroll
-  for (int dlt = 1; dlt < kWave; dlt <<= 1) {
-    const int32_t t = __shfl_down(incl, dlt);
-    if (lane + dlt < kWave) incl = t < incl ? t : incl;
-  }
-  if (lane == 0) wave_min[w] = incl;
-  int32_t after = __shfl_down(incl, 1);           // min over the later lanes of this wave
-  if (lane == kWave - 1) after = 0x7fffffff;
-  __syncthreads();
-  for (int ww = w + 1; ww < 16; ++ww) after = wave_min[ww] < after ? wave_min[ww] : after;
-  after = after < nnz ? after : nnz;              // rs[kN] = nnz closes the scan
+  int32_t d[ITEMS];
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
-    loc[j] = loc[j] < after ? loc[j] : after;     // = tptr[tid * ITEMS + j]
-    const int sr = tid * ITEMS + j;
-    if (sr <= cap_rows) tptr[sr] = loc[j];
+    const int e = tid + j * 1024;
+    d[j] = e < nnz ? B[e] : 0;
   }
-  if (heavy) {
-    // hub list from the registers: a source's edge count is the next tptr minus its own (the next thread's first one
-    // crosses through LDS)
-    edge_key[tid] = (uint32_t)loc[0];
-    __syncthreads();
-    const int32_t next_first = tid + 1 < 1024 ? (int32_t)edge_key[tid + 1] : nnz;
+  // exclusive scan of the counts: thread t owns sources [t * ITEMS, (t + 1) * ITEMS)
+  int32_t cnt[ITEMS], start[ITEMS];
+  int32_t sum = 0;
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-      const int sr = tid * ITEMS + j;
-      const int32_t nxt = j + 1 < ITEMS ? loc[j + 1] : next_first;
-      if (sr < cap_rows && nxt - loc[j] > PG_HEAVY_ROW) {
+  for (int j = 0; j < ITEMS; ++j) {
+    cnt[j] = A[T_PAD(tid * ITEMS + j)];
+    start[j] = sum;
+    sum += cnt[j];
+  }
+  const int32_t base = block_exclusive(sum);      // (its barriers also separate the reads of B above from the writes below)
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    start[j] += base;
+    A[T_PAD(tid * ITEMS + j)] = start[j];
+    if (cnt[j] > PG_HEAVY_ROW) {
+      const int h = atomicAdd(&n_hubs, 1);
+      hub_start[h] = start[j];
+      hub_count[h] = cnt[j];
+      if (heavy) {
         const int i = atomicAdd(heavy, 1);
-        if (i < heavy_cap) heavy[1 + i] = sr;
+        if (i < heavy_cap) heavy[1 + i] = tid * ITEMS + j;
       }
     }
   }
+  if (tid == 1023) A[T_PAD(kN)] = base + sum;      // = nnz
+  __syncthreads();
+  for (int i = tid; i <= cap_rows; i += 1024) tptr[i] = A[T_PAD(i)];        // coalesced; sources past the last real one: nnz
+  __syncthreads();
+  // ---- 3: placement (any order inside a source) ----------------------------------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j)
+    if (sr[j] >= 0) B[atomicAdd(&A[T_PAD(sr[j])], 1)] = d[j];
+  __syncthreads();
+  // ---- 4: rank inside the source (A[s] is now the source's end, A[s - 1] the previous source's end = its start) -----------
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    if (sr[j] < 0) continue;
+    const int32_t end = A[T_PAD(sr[j])];
+    const int32_t beg = sr[j] ? A[T_PAD(sr[j] - 1)] : 0;
+    if (end - beg > PG_HEAVY_ROW) continue;       // hubs: below
+    int32_t rank = 0;
+    for (int32_t q = beg; q < end; ++q) rank += B[q] < d[j] ? 1 : 0;
+    C[beg + rank] = d[j];
+  }
+  // ---- 5: hubs — set bits, then the set bits in order ---------------------------------------------------------------------
+  const int nh = n_hubs;                          // (written before the barriers above)
+  for (int h = 0; h < nh; ++h) {
+    const int32_t beg = hub_start[h], c = hub_count[h];
+    for (int i = tid; i < kWords; i += 1024) bits[i] = 0u;
+    __syncthreads();
+    for (int i = tid; i < c; i += 1024) {
+      const int32_t v = B[beg + i];
+      atomicOr(&bits[v >> 5], 1u << (v & 31));
+    }
+    __syncthreads();
+    uint32_t word = tid < kWords ? bits[tid] : 0u;
+    int32_t at = beg + block_exclusive(__popc(word));
+    for (; word; word &= word - 1u) C[at++] = tid * 32 + (__ffs((int)word) - 1);
+  }
+  __syncthreads();
+  // ---- 6: out -------------------------------------------------------------------------------------------------------------
+  for (int i = tid; i < cap_edges; i += 1024) tdst[i] = i < nnz ? C[i] : 0;
+#undef T_PAD
 }
 
 // copy seeds into the top layer buffer + set its count; publishes the call's parameters on the device
@@ -1109,12 +1073,10 @@ static int transpose_block(pg_sampler* s, const pg_nodeflow_desc_t* o, int b, co
       const int32_t hcap = (int32_t)(cap_edges / PG_HEAVY_ROW);
       if (larger <= 1024 * 4)
         hipLaunchKernelGGL(k_t_block<4>, dim3(1), dim3(1024), 0, ax, indptr_b, src_b, n_dst, nnz, cap_edges,
-                           (int32_t)s->cap[b], vb, kb, reinterpret_cast<uint32_t*>(key_in), tptr_b, tdst_b, heavy_b, hcap,
-                           tb);
+                           (int32_t)s->cap[b], tptr_b, tdst_b, heavy_b, hcap, tb);
       else
         hipLaunchKernelGGL(k_t_block<12>, dim3(1), dim3(1024), 0, ax, indptr_b, src_b, n_dst, nnz, cap_edges,
-                           (int32_t)s->cap[b], vb, kb, reinterpret_cast<uint32_t*>(key_in), tptr_b, tdst_b, heavy_b, hcap,
-                           tb);
+                           (int32_t)s->cap[b], tptr_b, tdst_b, heavy_b, hcap, tb);
       PG_LAUNCH_CHECK();
       return PG_OK;
     }
@@ -1422,3 +1384,4 @@ int pg_bitmap_to_ids(const uint64_t* bitmap, int64_t n_words, int64_t* out_ids, 
 }
 
 }  // extern "C"
+
