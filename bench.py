@@ -362,9 +362,10 @@ def gather_microbench(cacher, g, dev, rows_list=(42000, 1 << 18, 1 << 20, 1 << 2
         slots = torch.empty(R, dtype=torch.int32, device=dev)
         fsets = [L.make_fields((cacher.gpu_fix_cache[n], o[n], cacher.dims[n], cacher.gpu_fix_cache[n].stride(0),
                                 o[n].stride(0)) for n in names) for o in outs]
+        ml = L.miss_list(mpos, mfull, mcnt)
         call = lambda i, tmr=None: L.check(lib.pg_gather_rows(L.ptr(idsets[i % NS]), R, L.ptr(cacher.slot_map), L.ptr(cacher.nid_map),
-                                                              fsets[i % NS][0], fsets[i % NS][1], L.ptr(mpos), L.ptr(mfull),
-                                                              L.ptr(mcnt), L.ptr(slots), None, tmr, sp))
+                                                              fsets[i % NS][0], fsets[i % NS][1], ctypes.byref(ml), L.ptr(slots),
+                                                              None, tmr, None, sp))
         for i in range(max(3, NS)):
             call(i)
         reps = max(20, 2 * NS)

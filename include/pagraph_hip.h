@@ -105,12 +105,10 @@ int pg_slot_map_export(const int32_t* slot_map, int64_t node_num, uint8_t* gpu_f
  * For every r in [0,n): id = ids[r] (id < 0 = padding, row skipped); s = slot_map[id];
  *   s >= 0 : out_f[r,:] = cache_f[s,:]  for every field f            (storage.py:191-193)
  *   s <  0 : row r is appended to the miss list:
- *            miss_pos[j] = r, miss_fullid[j] = nid_map[id]           (storage.py:117,182)
- * `miss_count` (device or pinned int32, zeroed by this call) receives the
+ *            miss->pos[j] = r, miss->fullid[j] = nid_map[id]         (storage.py:117,182)
+ * `miss->count` (device or pinned int32, zeroed by this call) receives the
  * number of misses; miss list order is unspecified (a permutation of the
  * reference's mask order) — results do not depend on it.
- * miss_pos / miss_fullid need capacity n.  They may be pinned-host pointers
- * so the host can read them after the stream reaches this point.
  * slot_scratch: optional device int32[n]; when given, the split pass stores every row's slot
  * there (coalesced) and the copy pass reads it back instead of repeating the random lookup.
  * stats: optional device uint64[2], ACCUMULATED (not reset): [0] += rows looked up (ids >= 0),
@@ -119,23 +117,15 @@ int pg_slot_map_export(const int32_t* slot_map, int64_t node_num, uint8_t* gpu_f
  * (hipExtLaunchKernelGGL start / stop events; not the split pass), so pg_timer_elapsed_ms reads that kernel's
  * own begin-to-end time on `stream`, like rocprofv3's k_gather row.                                    */
 typedef struct pg_timer pg_timer_t;
-int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
-                   const pg_field_t* fields, int n_fields, int32_t* miss_pos, int64_t* miss_fullid,
-                   int32_t* miss_count, int32_t* slot_scratch, uint64_t* stats, pg_timer_t* timer,
-                   pg_stream_t stream);
-
-/* The two halves of pg_gather_rows on their own, for callers that do not materialise every row:
- * pg_split_rows = the hit/miss split only (storage.py:176-182): slots_out[r] (device int32[n], required) receives
- *   slot_map[id] for a hit, -(j + 3) for the row that became entry j of the miss list, -2 for padding (id < 0);
- *   miss list / miss_count / stats exactly as pg_gather_rows.
- * pg_gather_rows_presplit = the copy only, for n rows whose slots are given (slots[r] >= 0: out_f[r,:] =
- *   cache_f[slots[r],:]; anything else leaves the row untouched). `slots` / `fields[].out` may point into the middle
- *   of a NodeFlow's arrays: rows of layers whose features are consumed in place (pg_spmm_fwd_rows) are skipped. */
-int pg_split_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map, int32_t* miss_pos,
-                  int64_t* miss_fullid, int32_t* miss_count, int32_t* slots_out, uint64_t* stats,
-                  pg_stream_t stream);
-/* Miss-list index dedup (north star: "index dedup" in the gather). The reference looks every layer's ids up on
- * their own (storage.py:173-200), so a vertex that sits in two layers of a NodeFlow is fetched from the host twice
+/* the miss list of one launch: miss->pos / fullid need capacity n and may be pinned-host pointers; miss->count (device or
+ * pinned int32) is zeroed by the call */
+typedef struct pg_miss_list {
+  int32_t* pos;
+  int64_t* fullid;
+  int32_t* count;
+} pg_miss_list_t;
+/* Miss-list index dedup (north star: "index dedup" in the gather; `dedup` may be NULL). The reference looks every layer's ids
+ * up on their own (storage.py:173-200), so a vertex that sits in two layers of a NodeFlow is fetched from the host twice
  * when it misses. With a pg_dedup_t the split pass keeps the FIRST occurrence of a missed id in the miss list and
  * diverts a later one to the dup list: rows [lo[r], lo[r+1]) are layer r of the launch (lo[0] = 0, lo[n_ranges] = n);
  * bit r of sorted_mask says layer r's ids ascend (sampler spec rule 5: every non-seed layer; the padding ids < 0 of a
@@ -153,13 +143,20 @@ typedef struct pg_dedup {
   int32_t* dup_src;
   int32_t* dup_count;
 } pg_dedup_t;
-int pg_gather_rows_dedup(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
-                         const pg_field_t* fields, int n_fields, int32_t* miss_pos, int64_t* miss_fullid,
-                         int32_t* miss_count, int32_t* slot_scratch, uint64_t* stats, pg_timer_t* timer,
-                         const pg_dedup_t* dedup, pg_stream_t stream);
-int pg_split_rows_dedup(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
-                        int32_t* miss_pos, int64_t* miss_fullid, int32_t* miss_count, int32_t* slots_out,
-                        uint64_t* stats, const pg_dedup_t* dedup, pg_stream_t stream);
+int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
+                   const pg_field_t* fields, int n_fields, const pg_miss_list_t* miss, int32_t* slot_scratch,
+                   uint64_t* stats, pg_timer_t* timer, const pg_dedup_t* dedup, pg_stream_t stream);
+
+/* The two halves of pg_gather_rows on their own, for callers that do not materialise every row:
+ * pg_split_rows = the hit/miss split only (storage.py:176-182): slots_out[r] (device int32[n], required) receives
+ *   slot_map[id] for a hit, -(j + 3) for the row that became entry j of the miss list, -2 for padding (id < 0);
+ *   miss list / stats / dedup exactly as pg_gather_rows.
+ * pg_gather_rows_presplit = the copy only, for n rows whose slots are given (slots[r] >= 0: out_f[r,:] =
+ *   cache_f[slots[r],:]; anything else leaves the row untouched). `slots` / `fields[].out` may point into the middle
+ *   of a NodeFlow's arrays: rows of layers whose features are consumed in place (pg_spmm_fwd_rows) are skipped. */
+int pg_split_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
+                  const pg_miss_list_t* miss, int32_t* slots_out, uint64_t* stats, const pg_dedup_t* dedup,
+                  pg_stream_t stream);
 /* slots_out[i] = slot_map[ids[i]] (ids[i] < 0, the padding of a fixed-shape layer: -2) for a launch over a FULLY cached table
  * (storage.py:207-216): what pg_split_rows writes when nothing can miss, without the miss list and its counter's zero fill.
  * stats (may be NULL): stats[0] += rows looked up.                                                                    */
@@ -187,7 +184,7 @@ int pg_gather_rows_full(const int64_t* ids, int64_t n, const pg_field_t* fields,
 /* batch_labels = labels[batch_nids] (examples/profile/pa_gcn.py:99-100): out[i] = labels[ids[i]], or
  * `fill` where ids[i] is outside [0, n_labels) (padding ids of a fixed-shape NodeFlow are -1).
  * n_valid_out (device int32, may be NULL): number of i with out[i] != fill and >= 0 — the rows a loss with
- * ignore_index = fill will count (pg_gcn_head reads it).                                             */
+ * ignore_index = fill will count (pg_head reads it).                                             */
 int pg_gather_labels(const int64_t* ids, int64_t n, const int64_t* labels, int64_t n_labels, int64_t fill,
                      int64_t* out, int32_t* n_valid_out, pg_stream_t stream);
 /* The same with a self-cleaning count: scratch2 = two device int32 words, zero before the FIRST call and owned by this call
@@ -237,7 +234,7 @@ typedef struct pg_missq_field {
 int pg_missq_create(int device, int n_slots, int64_t max_rows, const pg_missq_field_t* fields, int n_fields,
                     int n_threads, pg_missq_t** out);
 int pg_missq_destroy(pg_missq_t* q);
-/* the slot's miss-list buffers, to be passed to pg_gather_rows as miss_pos / miss_fullid / miss_count */
+/* the slot's miss-list buffers, to be passed to pg_gather_rows as its pg_miss_list_t */
 int pg_missq_slot_buffers(pg_missq_t* q, int slot, int32_t** miss_pos_dev, int64_t** miss_fullid_pinned,
                           int32_t** miss_count_dev);
 /* call right after pg_gather_rows(...slot buffers...) on the same stream: publishes the miss list to the
@@ -255,7 +252,7 @@ int pg_missq_submit_range(pg_missq_t* q, int slot, float* const* out_ptrs, const
  * `stream`). The publish step turns every dup entry's "earlier row" into that row's staged index; after the primary
  * rows' scatter the worker fills the repeats on the device (pg_scatter_rows_dups) — they never cross PCIe. The publish
  * step also rewrites the repeats' OWN entries of `slots_dev` to their primary's value, -(staged row + 3), so that a
- * consumer reading rows in place through that array (pg_spmm_fwd_rows, pg_linear2_fwd_rows) finds them.        */
+ * consumer reading rows in place through that array (pg_spmm_fwd_rows, pg_linear_fwd with X1rows) finds them.        */
 int pg_missq_submit_dedup(pg_missq_t* q, int slot, float* const* out_ptrs, const int32_t* out_strides,
                           const int32_t* pos_lo, const int32_t* slots_dev, pg_stream_t stream);
 int pg_missq_slot_dup_buffers(pg_missq_t* q, int slot, int32_t** dup_pos_dev, int32_t** dup_src_dev,
@@ -417,9 +414,6 @@ int pg_spmm_fwd(const int32_t* indptr, const int32_t* src, const float* h, int32
                 int64_t n_dst, int32_t dim, int reduce, float* out, int32_t out_stride,
                 pg_stream_t stream);
 /* grad_h[src[e],:] += grad_out[v,:] * (mean ? 1/deg(v) : 1). grad_h must be zeroed by the caller. */
-int pg_spmm_bwd(const int32_t* indptr, const int32_t* src, const float* grad_out, int32_t go_stride,
-                int64_t n_dst, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,
-                pg_stream_t stream);
 
 /* The same aggregation with the model's nn.Dropout (gcn_nssc.py:66-69, graphsage_nssc.py:86-89: dropout
  * on a layer's input right before it is aggregated) folded in: out = reduce(dropout(h)[src]) without
@@ -455,8 +449,8 @@ int pg_spmm_fwd_drop(const int32_t* indptr, const int32_t* src, const float* h, 
  * prof (device uint64[PG_PROF_WORDS * prof_ring], zero-initialised, may be NULL): the kernel usually runs inside a
  * replayed hipGraph, where HIP events cannot be attached to it, so it times itself with the device wall clock (100 MHz
  * ticks). Entry i = (*drop->step, or 0) % prof_ring, words: [0] start of the first wave; [1] start of the first wave of
- * the next dependent dense / head launch issued by the same host thread (pg_linear_fwd, pg_linear2_fwd[_rows],
- * pg_gcn_head[_ex]) — [1] - [0] is the time this kernel occupies its stream: body, drain, end-of-kernel release and the
+ * the next dependent dense / head launch issued by the same host thread (pg_linear_fwd,
+ * pg_head) — [1] - [0] is the time this kernel occupies its stream: body, drain, end-of-kernel release and the
  * successor's launch latency, the figure rocprofv3's End - Start of the dispatch agrees with; [2] edges aggregated;
  * [PG_PROF_END0 + PG_PROF_SHARD_STRIDE * s], s < PG_PROF_SHARDS: latest end-of-block stamp of the blocks b with
  * b % PG_PROF_SHARDS == s (the kernel body ends at their maximum; one 128-byte line per shard — sixteen shards on ONE
@@ -481,78 +475,98 @@ int pg_compose_edge_slots(const int32_t* src, int64_t n_edges, const int32_t* sl
 int pg_spmm_fwd_rows(const int32_t* indptr, const int32_t* src, const pg_row_source_t* rows, int64_t n_dst,
                      int32_t dim, int reduce, float* out, int32_t out_stride, const pg_dropout_t* drop,
                      uint64_t* prof, int32_t prof_ring, pg_stream_t stream);
-/* A stream restricted to the CUs of `mask` (hipExtStreamCreateWithCUMask; bit i of word i / 32 = CU i). No reference
- * counterpart: the reference's only streams are torch's (pa_gcn.py:86-92 uses the default stream). */
-int pg_stream_create_masked(const uint32_t* mask, int32_t words, pg_stream_t* out);
-int pg_stream_destroy(pg_stream_t stream);
 /* Profiling aid: one-thread marker kernel, ring[(*step or 0) % ring_len] = device wall clock (100 MHz ticks). Launched
  * right behind a kernel inside a captured step it gives that kernel's TRUE end as the stream sees it (the write-back of
  * what the kernel left dirty in L2 included): a dispatch cannot start before its predecessor has completed.          */
 int pg_prof_stamp(uint64_t* ring, int32_t ring_len, const uint64_t* step, pg_stream_t stream);
-/* grad_h[src[e],:] += grad_out[v,:] * (mean ? 1/deg(v) : 1) * mask(src[e],:) * scale; grad_h zeroed by caller */
-int pg_spmm_bwd_drop(const int32_t* indptr, const int32_t* src, const float* grad_out, int32_t go_stride,
-                     int64_t n_dst, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,
-                     const pg_dropout_t* drop, pg_stream_t stream);
+/* Backward of a block aggregation (the autograd side of nf.block_compute, gcn_nssc.py:71-74). ONE entry point with a
+ * descriptor (round 6: pg_spmm_bwd, _drop, _max, _gather, _gather_dz, _gather_max took 10 - 17 positional arguments):
+ *  - scatter form (tptr == NULL): grad_h[src[e],:] += grad_out[v,:] * (mean ? 1/deg(v) : 1) * mask(src[e],:) * scale over the
+ *    destination-major block (fp32 atomics; grad_h zeroed by the caller; src / grad_h may be NULL only for an edgeless block).
+ *  - gather form (tptr != NULL) over the block's source-major copy (pg_nodeflow_desc_t.blk_tptr / blk_tdst):
+ *    grad_h[s,:] = mask(s,:) * scale * sum over s's edges of grad_out[dst,:] * (mean ? 1/deg(dst) : 1), destinations
+ *    ascending. Every one of the n_src rows is written (no zero fill, no atomics, deterministic). indptr = the
+ *    destination-major indptr (degrees; PG_REDUCE_SUM: unused). heavy (device, may be NULL): the block's hub list
+ *    (blk_theavy: [0] = count, then sources with more than PG_HEAVY_ROW edges; heavy_cap = room behind the count) — those
+ *    rows get a block each in a second launch instead of one lane group.
+ *    dz (may be NULL): dZ of the NodeUpdate that produced the aggregated rows, when that was a skip-concat y = [z | relu(z)]
+ *    (gcn_nssc.py:20-21; dim = 2 N): dz[s, j] = grad_h[s, j] + (act_out[s, j] > 0 ? grad_h[s, N + j] : 0), j < N — what
+ *    pg_linear_bwd_w(act = 2) derives with a launch of its own. act_out = the forward input of the aggregation (row stride
+ *    act_stride), dz [n_src, N] dense. Needs 16-byte pieces and dim / 4 <= 64 (else PG_ERR_UNSUPPORTED).
+ *  - PG_REDUCE_MAX (both forms). DGL 0.4.1's rule (its ReduceMax functor's backward is `val == accum` [recollection; DGL is
+ *    not in the reference checkout — parity unpinned]): a destination's gradient goes, whole, to EVERY in-edge whose message
+ *    equals the maximum (ties are not split): grad_h[s, c] (+)= sum over s's edges (s -> v) of
+ *    (x[s, c] == out[v, c] ? grad_out[v, c] : 0) * dmask(s, c) with x = dropout(h) as the forward saw it. h = the forward's
+ *    input [n_src, dim], out = its output [n_dst, dim]; dz as above with act_out = h.
+ * has_drop: the model's dropout in front of the aggregation (the same counter-based mask as the forward).        */
+typedef struct pg_spmm_bwd_desc {
+  const int32_t* indptr;
+  const int32_t* src;
+  const int32_t* tptr;
+  const int32_t* tdst;
+  const int32_t* heavy;
+  const float* grad_out;
+  float* grad_h;
+  const float* h;
+  const float* out;
+  const float* act_out;
+  float* dz;
+  int64_t n_dst, n_src;
+  int32_t go_stride, gh_stride, h_stride, out_stride, act_stride, dim, reduce, heavy_cap, has_drop, _pad;
+  pg_dropout_t drop;
+} pg_spmm_bwd_desc_t;
+int pg_spmm_bwd(const pg_spmm_bwd_desc_t* desc, pg_stream_t stream);
 
-/* The same gradient in gather form over the block's source-major copy (pg_nodeflow_desc_t.blk_tptr /
- * blk_tdst): grad_h[s,:] = mask(s,:) * scale * sum over s's edges of grad_out[dst,:] * (mean ? 1/deg(dst) : 1),
- * destinations ascending. Every one of the n_src rows is written (no zero fill, no atomics, deterministic).
- * indptr is the destination-major indptr (degrees). heavy (device, may be NULL): the block's hub list
- * (blk_theavy: [0] = count, then sources with more than PG_HEAVY_ROW edges; heavy_cap = room behind the
- * count) — those rows get a block each in a second launch instead of one lane group. drop may be NULL. */
-int pg_spmm_bwd_gather(const int32_t* tptr, const int32_t* tdst, const int32_t* indptr, const float* grad_out,
-                       int32_t go_stride, int64_t n_src, int32_t dim, int reduce, float* grad_h,
-                       int32_t gh_stride, const int32_t* heavy, int32_t heavy_cap, const pg_dropout_t* drop,
-                       pg_stream_t stream);
-/* the same + dZ of the NodeUpdate that produced the aggregated rows, when that was a skip-concat y = [z | relu(z)]
- * (gcn_nssc.py:20-21; dim = 2 N): dz[s, j] = grad_h[s, j] + (act_out[s, j] > 0 ? grad_h[s, N + j] : 0), j < N — what
- * pg_linear_bwd_w(act = 2) derives with a launch of its own. act_out = the forward input of the aggregation (row stride
- * act_stride), dz [n_src, N] dense. Needs 16-byte pieces and dim / 4 <= 64 (else PG_ERR_UNSUPPORTED).     */
-int pg_spmm_bwd_gather_dz(const int32_t* tptr, const int32_t* tdst, const int32_t* indptr, const float* grad_out,
-                          int32_t go_stride, int64_t n_src, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,
-                          const int32_t* heavy, int32_t heavy_cap, const pg_dropout_t* drop, const float* act_out,
-                          int32_t act_stride, float* dz, pg_stream_t stream);
-
-/* Backward of the PG_REDUCE_MAX aggregation. DGL 0.4.1's rule (its ReduceMax functor's backward is `val == accum`
- * [recollection; DGL is not in the reference checkout — parity unpinned]): a destination's gradient goes, whole, to EVERY
- * in-edge whose message equals the maximum (ties are not split):
- *   grad_h[s, c] (+)= sum over s's edges (s -> v) of  (x[s, c] == out[v, c] ? grad_out[v, c] : 0) * dmask(s, c)
- * with x = dropout(h) as the forward saw it (x = h, dmask = 1 without dropout; else x = keep ? h * scale : 0 and
- * dmask = keep ? scale : 0). h = the forward's input [n_src, dim], out = its output [n_dst, dim].
- * pg_spmm_bwd_max: scatter form (fp32 atomics; grad_h zeroed by the caller).
- * pg_spmm_bwd_gather_max: gather form over the block's source-major copy, destinations ascending, every row written,
- * deterministic; heavy / heavy_cap as pg_spmm_bwd_gather; dz (may be NULL) as pg_spmm_bwd_gather_dz with act_out = h. */
-int pg_spmm_bwd_max(const int32_t* indptr, const int32_t* src, const float* grad_out, int32_t go_stride,
-                    int64_t n_dst, int32_t dim, const float* h, int32_t h_stride, const float* out,
-                    int32_t out_stride, float* grad_h, int32_t gh_stride, const pg_dropout_t* drop,
-                    pg_stream_t stream);
-int pg_spmm_bwd_gather_max(const int32_t* tptr, const int32_t* tdst, const float* grad_out, int32_t go_stride,
-                           int64_t n_src, int32_t dim, const float* h, int32_t h_stride, const float* out,
-                           int32_t out_stride, float* grad_h, int32_t gh_stride, const int32_t* heavy,
-                           int32_t heavy_cap, const pg_dropout_t* drop, float* dz, pg_stream_t stream);
-
-/* Skinny dense step of the first layer — NodeUpdate.forward at PaGraph/model/gcn_nssc.py:18-23 and
- * graphsage_nssc.py:24-29 — on fp32 MFMA: Z = X[n,K] * W^T + bias with W = nn.Linear's weight [N,K],
- * N <= 64, any K (Reddit's 602: the last octet is zero-filled past K; W rows are read with the widest aligned
- * access K allows), X 16-byte aligned with x_stride % 4 == 0. The epilogue applies NodeUpdate's
- * activation: act 0: Y = Z; 1: Y = relu(Z); 2: Y = [Z | relu(Z)] (2N columns, the skip connection).
- * Returns PG_ERR_UNSUPPORTED outside that envelope (callers then use the library GEMM).            */
-int pg_linear_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, float* Y,
-                  int32_t y_stride, int64_t n, int32_t K, int32_t N, int32_t act, pg_stream_t stream);
-/* GraphSAGE's NodeUpdate, `fc_self(h) + fc_neigh(neigh)` then the activation (graphsage_nssc.py:24-29), in one
- * pass: Z = X W^T + bias + X2 W2^T + bias2 (W [N,K], W2 [N,K2]; same envelope for both operand pairs).      */
-int pg_linear2_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, int32_t K,
-                   const float* X2, int32_t x2_stride, const float* W2, const float* bias2, int32_t K2,
-                   float* Y, int32_t y_stride, int64_t n, int32_t N, int32_t act, pg_stream_t stream);
-/* dW[N,K] = dZ^T X and (db != NULL) db[N] = column sums of dZ, any N and K, where dZ is derived from
- * G = dL/dY and the saved output Yout according to `act` (act 0: dZ = G, Yout may be NULL). dW (contiguous)
- * and db are overwritten. dz_scratch: device fp32 [n, N], required when act != 0; it holds dZ afterwards
- * (callers reuse it for dX = dZ W). partials: device fp32 scratch of pg_linear_bwd_w_scratch(n, K, N)
- * floats (per-row-chunk partial tiles, summed in chunk order: the result is deterministic).          */
+/* Skinny dense step of the layers — NodeUpdate.forward at PaGraph/model/gcn_nssc.py:18-23 and graphsage_nssc.py:21-30 — on
+ * fp32 MFMA: Z = X1[n,K1] W1^T + bias1 (+ X2[n,K2] W2^T + bias2: GraphSAGE's `fc_self(h) + fc_neigh(neigh)`, K2 == 0: none)
+ * with W = nn.Linear's weight [N,K], N <= 64, any K (Reddit's 602: the last octet is zero-filled past K; W rows are read with
+ * the widest aligned access K allows), X 16-byte aligned with stride % 4 == 0. The epilogue applies NodeUpdate's activation:
+ * act 0: Y = Z; 1: Y = relu(Z); 2: Y = [Z | relu(Z)] (2N columns, the skip connection). The FIRST operand is dense (X1) or
+ * read in place from a row source (X1rows, round 3: fc_self(h) of a layer whose 'features' were never gathered into a frame —
+ * h = the cache / the miss queue's staged block through pg_row_source_t, exactly as pg_spmm_fwd_rows reads them; the same
+ * bytes as pg_gather_rows + the dense form: bit-identical; rows with slot -1 / -2 count as zero rows) — exactly one of the two.
+ * Returns PG_ERR_UNSUPPORTED outside that envelope (callers then use the library GEMM).
+ * Round 6: ONE entry point with a descriptor (pg_linear_fwd / pg_linear2_fwd / pg_linear2_fwd_rows took 11 - 16 arguments). */
+typedef struct pg_linear_fwd_desc {
+  const float* X1;
+  const pg_row_source_t* X1rows;
+  const float* W1;
+  const float* bias1;            /* [N] or NULL */
+  const float* X2;               /* second operand, or NULL with K2 == 0 */
+  const float* W2;
+  const float* bias2;
+  float* Y;
+  int64_t n;
+  int32_t x1_stride, K1, x2_stride, K2, y_stride, N, act, _pad;
+} pg_linear_fwd_desc_t;
+int pg_linear_fwd(const pg_linear_fwd_desc_t* desc, pg_stream_t stream);
+/* dW1[N,K1] = dZ^T X1 and (db1 != NULL) db1[N] = column sums of dZ, any N and K, where dZ is derived from dY = dL/dY and the
+ * saved output Yout according to `act` (act 0: dZ = dY, Yout may be NULL). K2 > 0: BOTH weight gradients of GraphSAGE's
+ * NodeUpdate over the same dZ in ONE launch (round 4: dW2 = dZ^T X2; the same blocks and arithmetic as one launch per operand:
+ * bit-identical partial rows and sums). The first operand is dense (X1) or read in place (X1rows), the second dense.
+ * dz_scratch: device fp32 [n, N], required when act != 0; it holds dZ afterwards (callers reuse it for dX = dZ W).
+ * partials1 / partials2: device fp32 scratch of pg_linear_bwd_w_scratch(n, K1 | K2, N) floats (per-row-chunk partial tiles).
+ * sum_partials = 1: the chunks are summed in chunk order into dW / db by an ordered second launch (deterministic);
+ * 0: they stay un-summed ([rows][N*K + N]) for pg_adam_step, dW / db are not written.
+ * Round 6: ONE entry point (pg_linear_bwd_w / _ex / _rows / pg_linear2_bwd_w took 15 - 23 positional arguments). */
 int64_t pg_linear_bwd_w_scratch(int64_t n, int32_t K, int32_t N);
-int pg_linear_bwd_w(const float* G, int32_t g_stride, const float* X, int32_t x_stride, int64_t n,
-                    int32_t K, int32_t N, float* dW, float* db, const float* Yout, int32_t yo_stride,
-                    int32_t act, float* dz_scratch, float* partials, pg_stream_t stream);
+typedef struct pg_linear_bwd_desc {
+  const float* dY;
+  const float* X1;
+  const pg_row_source_t* X1rows;
+  const float* X2;               /* NULL with K2 == 0 */
+  const float* Yout;
+  float* dW1;
+  float* db1;
+  float* dW2;
+  float* db2;
+  float* dz_scratch;
+  float* partials1;
+  float* partials2;
+  int64_t n;
+  int32_t dy_stride, x1_stride, K1, x2_stride, K2, N, yo_stride, act, sum_partials, _pad;
+} pg_linear_bwd_desc_t;
+int pg_linear_bwd_w(const pg_linear_bwd_desc_t* desc, pg_stream_t stream);
 
 /* Loss head — torch.nn.CrossEntropyLoss() of examples/profile/pa_gcn.py:80,101-104 (pa_gs.py likewise):
  * log-softmax + NLL over logits[n, C], mean over the rows whose label is neither ignore_index nor
@@ -578,20 +592,48 @@ int64_t pg_gcn_head_scratch(int64_t n_dst, int32_t K, int32_t C);
 /* floats between two blocks' rows of that scratch: [C * K] dW | [C] db | [1] loss, padded to a multiple of 4 — the
  * `part_len` a caller puts into pg_adam_tensor_t when it lets the optimiser add the rows up (sum_partials = 0)   */
 int32_t pg_gcn_head_row_len(int32_t K, int32_t C);
-/* pg_gcn_head_ex / pg_linear_bwd_w_ex: the same with `sum_partials` = 0 leaving the per-block / per-chunk partial rows
+/* pg_head / pg_linear_bwd_w with `sum_partials` = 0 / without PG_HEAD_SUM_PARTIALS leave the per-block / per-chunk partial rows
  * un-summed in `partials` ([rows][C*K + C + 1] resp. [rows][N*K + N], rows = scratch size / row length) for
  * pg_adam_step; dW / db(_loss) are then not written.                                                     */
-/* The same head for GraphSAGE's output NodeUpdate z = fc_neigh(agg) + fc_self(h_self) (graphsage_nssc.py:24, the last layer of
- * graphsage_nssc.py:55-72; round 4): h_self [n_dst, >= Ks] is the destinations' own input (not aggregated, not dropped), W_self
- * [C, Ks], bias_self [C] or NULL; K + Ks <= 64. dself [n_dst, Ks] = dZ W_self. Partial rows: pg_gcn_head_scratch(n_dst, K + Ks, C)
- * floats laid out [C x K] dW | [C x Ks] dW_self | [C] db | loss per block (pg_gcn_head_row_len(K + Ks, C) apart); with
- * PG_HEAD_SUM_PARTIALS dW_both receives [C x K | C x Ks] contiguous and db_loss [C + 1]; both biases have the gradient db. */
-int pg_sage_head(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
-                 const float* W, const float* bias, const float* h_self, int32_t hs_stride, int32_t Ks,
-                 const float* W_self, const float* bias_self, int32_t C, const int64_t* labels, int64_t ignore_index,
-                 const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
-                 int64_t n_dst, float* logits, float* dagg, float* dself, float* partials, float* dW_both, float* db_loss,
-                 int32_t flags, pg_stream_t stream);
+/* GraphSAGE's output NodeUpdate z = fc_neigh(agg) + fc_self(h_self) (graphsage_nssc.py:24, the last layer of
+ * graphsage_nssc.py:55-72; round 4) is the same head with the descriptor's self_* fields set: h_self [n_dst, >= Ks] is the
+ * destinations' own input (not aggregated, not dropped), W_self [C, Ks], bias_self [C] or NULL; K + Ks <= 64.
+ * dself [n_dst, Ks] = dZ W_self. Partial rows: pg_gcn_head_scratch(n_dst, K + Ks, C) floats laid out
+ * [C x K] dW | [C x Ks] dW_self | [C] db | loss per block (pg_gcn_head_row_len(K + Ks, C) apart); with PG_HEAD_SUM_PARTIALS dW
+ * receives [C x K | C x Ks] contiguous and db_loss [C + 1]; both biases have the gradient db.
+ *
+ * flags: PG_HEAD_SUM_PARTIALS — the per-block partial rows are summed into dW / db_loss by an ordered second launch (without
+ * it they stay un-summed in `partials` for pg_adam_step, dW / db_loss are not written); PG_HEAD_DAGG_PER_EDGE — under
+ * PG_REDUCE_MEAN dagg[v] leaves already divided by v's in-degree in the block (what each in-edge carries back): feed it to
+ * pg_spmm_bwd with PG_REDUCE_SUM, same operations in the same order without the backward's degree loads.
+ * Round 6: ONE entry point with a descriptor (pg_gcn_head / pg_gcn_head_ex / pg_sage_head took 21 - 28 positional arguments). */
+#define PG_HEAD_SUM_PARTIALS 1
+#define PG_HEAD_DAGG_PER_EDGE 2
+typedef struct pg_head_desc {
+  const int32_t* indptr;         /* the last block, destination-major */
+  const int32_t* src;
+  const float* h;                /* [n_src, K] the layer below's output */
+  const float* W;                /* [C, K] */
+  const float* bias;             /* [C] or NULL */
+  const int64_t* labels;         /* [n_dst] */
+  const int32_t* n_valid_dev;    /* labels the loss counts (pg_gather_labels) */
+  const float* grad_scale_dev;   /* device scalar d(objective)/d(loss), NULL = 1 */
+  int64_t ignore_index, n_dst;
+  int32_t h_stride, K, C, reduce, flags, has_drop;
+  pg_dropout_t drop;             /* the model's dropout in front of the aggregation (has_drop) */
+  float* logits;                 /* [n_dst, C] or NULL */
+  float* dagg;                   /* [n_dst, K] */
+  float* partials;               /* pg_gcn_head_scratch(n_dst, K + Ks, C) floats */
+  float* dW;                     /* [C, K (+ Ks)] */
+  float* db_loss;                /* [C + 1]: db, then the mean loss */
+  /* GraphSAGE's self operand (Ks == 0: none) */
+  const float* h_self;
+  const float* W_self;
+  const float* bias_self;
+  float* dself;
+  int32_t hs_stride, Ks;
+} pg_head_desc_t;
+int pg_head(const pg_head_desc_t* desc, pg_stream_t stream);
 
 /* The load-stream half of one minibatch as ONE call (round 5; csrc/pg_pipeline.hip) for a table that is resident in HBM —
  * pa_gcn.py:86-91's 'gpu-load' range: the slot look-up of fetch_from_cache (storage.py:207-216; the rows are then read in place),
@@ -641,47 +683,6 @@ int pg_batch_prepare(const pg_batch_plan_t* plan, uint64_t drop_step_value);
 
 
 
-/* pg_gcn_head_ex's flags: PG_HEAD_SUM_PARTIALS as above; PG_HEAD_DAGG_PER_EDGE: under PG_REDUCE_MEAN dagg[v] leaves
- * already divided by v's in-degree in the block (what each in-edge carries back) — feed it to pg_spmm_bwd_gather /
- * pg_spmm_bwd_drop with PG_REDUCE_SUM: same operations in the same order, without the backward's degree loads.  */
-#define PG_HEAD_SUM_PARTIALS 1
-#define PG_HEAD_DAGG_PER_EDGE 2
-int pg_gcn_head_ex(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
-                   const float* W, const float* bias, int32_t C, const int64_t* labels, int64_t ignore_index,
-                   const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
-                   int64_t n_dst, float* logits, float* dagg, float* partials, float* dW, float* db_loss,
-                   int32_t flags, pg_stream_t stream);
-int pg_linear_bwd_w_ex(const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n, int32_t K,
-                       int32_t N, float* dW, float* db, const float* Yout, int32_t yo_stride, int32_t act,
-                       float* dz_scratch, float* partials, int32_t sum_partials, pg_stream_t stream);
-
-/* NodeUpdate's dense step with its FIRST operand read in place from a row source (round 3; graphsage_nssc.py:21-30 —
- * fc_self(h) of a layer whose 'features' were never gathered into a frame: h = the cache / the miss queue's staged block
- * through pg_row_source_t, exactly as pg_spmm_fwd_rows reads them). Same arithmetic on the same bytes as
- * pg_gather_rows + pg_linear2_fwd / pg_linear_bwd_w_ex: bit-identical results. Rows with slot -1 / -2 (padding of a
- * fixed-shape layer) count as zero rows. K2 = 0 (X2, W2, bias2 NULL): the one-operand step. Needs 16-byte aligned
- * rows in both homes (strides % 4 == 0, >= K rounded up to 4), N <= 64 for the forward.                         */
-int pg_linear2_fwd_rows(const pg_row_source_t* X, int32_t K, const float* W, const float* bias, const float* X2,
-                        int32_t x2_stride, const float* W2, const float* bias2, int32_t K2, float* Y, int32_t y_stride,
-                        int64_t n, int32_t N, int32_t act, pg_stream_t stream);
-int pg_linear_bwd_w_rows(const float* dY, int32_t dy_stride, const pg_row_source_t* X, int64_t n, int32_t K, int32_t N,
-                         float* dW, float* db, const float* Yout, int32_t yo_stride, int32_t act, float* dz_scratch,
-                         float* partials, int32_t sum_partials, pg_stream_t stream);
-/* Both weight gradients of GraphSAGE's NodeUpdate z = fc_self(h) + fc_neigh(neigh) (graphsage_nssc.py:24) in ONE launch
- * (round 4): dW1 = dZ^T X1, dW2 = dZ^T X2 over the same dZ (derived once from dY / Yout when act != 0, as
- * pg_linear_bwd_w does). The first operand is dense (X1) or read in place (X1rows) — exactly one of the two is given; the
- * second is dense. Same blocks, same arithmetic as pg_linear_bwd_w_ex / pg_linear_bwd_w_rows called once per operand:
- * bit-identical partial rows (partials1 / partials2: pg_linear_bwd_w_scratch(n, K1 | K2, N) floats each) and sums.   */
-int pg_linear2_bwd_w(const float* dY, int32_t dy_stride, const float* X1, int32_t x1_stride, const pg_row_source_t* X1rows,
-                     int32_t K1, const float* X2, int32_t x2_stride, int32_t K2, int64_t n, int32_t N, float* dW1, float* db1,
-                     float* dW2, float* db2, const float* Yout, int32_t yo_stride, int32_t act, float* dz_scratch,
-                     float* partials1, float* partials2, int32_t sum_partials, pg_stream_t stream);
-int pg_gcn_head(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
-                const float* W, const float* bias, int32_t C, const int64_t* labels, int64_t ignore_index,
-                const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
-                int64_t n_dst, float* logits, float* dagg, float* partials, float* dW, float* db_loss,
-                pg_stream_t stream);
-
 /* Optimiser step — torch.optim.Adam(model.parameters(), lr, weight_decay) of examples/profile/pa_gcn.py:137-139
  * (amsgrad off, maximize off), same arithmetic as torch's: g += wd * p; m = b1 m + (1 - b1) g;
  * v = b2 v + (1 - b2) g^2; p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps), t = *step_dev + 1.
@@ -692,11 +693,11 @@ int pg_gcn_head(const int32_t* indptr, const int32_t* src, const float* h, int32
  *
  * Per tensor: partials == NULL -> the gradient is read from grad[] as is. Otherwise element o of the gradient is the sum
  * over part_chunks rows of partials[c * part_len + part_off + o] — the un-summed per-chunk rows pg_linear_bwd_w_ex /
- * pg_gcn_head_ex leave with sum_partials = 0 — added in exactly pg_sum_partials' order (bit-identical) and stored to grad[].
+ * pg_head leave with sum_partials = 0 — added in exactly pg_sum_partials' order (bit-identical) and stored to grad[].
  * partials2 (may be NULL): a SECOND set of rows for a parameter that is applied twice per step — GraphSAGE's NodeUpdate
  * `lid` runs on every block >= lid (graphsage_nssc.py:92-131) — gradient = sum(partials) + sum(partials2), what autograd's
  * accumulation of the two summed contributions yields. is_adam == 0: reduce only (param / exp_avg / exp_avg_sq may be
- * NULL) — pg_gcn_head's loss scalar lives in the same rows.
+ * NULL) — pg_head's loss scalar lives in the same rows.
  *
  * mode PG_ADAM_FULL: sums + update. PG_ADAM_REDUCE_ONLY: only the sums are written to grad[] (every tensor must have
  * partials; step / ticket / bump are not touched) — the N > 1 step: grad[] are views of the flat buffer the gradient
@@ -765,7 +766,8 @@ typedef struct pg_dg_gpu_stats {
 } pg_dg_gpu_stats_t;
 int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const int32_t* indices_dev, const int64_t* train_nids,
                         int64_t n_train, int32_t P, int32_t hops, int8_t* belongs_out, uint8_t* r_mask_out,
-                        int64_t* p_vnum_out, int64_t* r_vnum_out, pg_dg_gpu_stats_t* stats, pg_stream_t stream);
+                        int64_t* vnum_out /* [2][P]: p_vnum then r_vnum, may be NULL */, pg_dg_gpu_stats_t* stats,
+                        pg_stream_t stream);
 /* order[0..n) = np.argsort(v) (default kind) of n <= 127 float64 on numpy 2.2's scalar path (npysort/quicksort.cpp,
  * heapsort.cpp restated): what dg's arg-max sorts its scores with. Exported so the tests can pin it against numpy.  */
 int pg_np_argsort_f64(const double* v, int32_t n, int32_t* order);

@@ -57,6 +57,10 @@ class PgRowSource(ctypes.Structure):
                 ("edge_slots", vp)]
 
 
+class PgMissList(ctypes.Structure):
+    _fields_ = [("pos", vp), ("fullid", vp), ("count", vp)]
+
+
 class PgDedup(ctypes.Structure):
     _fields_ = [("n_ranges", c_i32), ("lo", c_i32 * (PG_MAX_LAYERS + 1)), ("sorted_mask", c_u32), ("dup_pos", vp),
                 ("dup_src", vp), ("dup_count", vp)]
@@ -64,6 +68,34 @@ class PgDedup(ctypes.Structure):
 
 class PgDropout(ctypes.Structure):
     _fields_ = [("threshold", c_u32), ("tag", c_u32), ("seed", c_u64), ("step", vp), ("step_value", c_u64)]
+
+
+class PgSpmmBwdDesc(ctypes.Structure):
+    _fields_ = [("indptr", vp), ("src", vp), ("tptr", vp), ("tdst", vp), ("heavy", vp), ("grad_out", vp), ("grad_h", vp), ("h", vp),
+                ("out", vp), ("act_out", vp), ("dz", vp), ("n_dst", c_i64), ("n_src", c_i64), ("go_stride", c_i32),
+                ("gh_stride", c_i32), ("h_stride", c_i32), ("out_stride", c_i32), ("act_stride", c_i32), ("dim", c_i32),
+                ("reduce", c_i32), ("heavy_cap", c_i32), ("has_drop", c_i32), ("_pad", c_i32), ("drop", PgDropout)]
+
+
+class PgLinearFwdDesc(ctypes.Structure):
+    _fields_ = [("X1", vp), ("X1rows", vp), ("W1", vp), ("bias1", vp), ("X2", vp), ("W2", vp), ("bias2", vp), ("Y", vp),
+                ("n", c_i64), ("x1_stride", c_i32), ("K1", c_i32), ("x2_stride", c_i32), ("K2", c_i32), ("y_stride", c_i32),
+                ("N", c_i32), ("act", c_i32), ("_pad", c_i32)]
+
+
+class PgLinearBwdDesc(ctypes.Structure):
+    _fields_ = [("dY", vp), ("X1", vp), ("X1rows", vp), ("X2", vp), ("Yout", vp), ("dW1", vp), ("db1", vp), ("dW2", vp),
+                ("db2", vp), ("dz_scratch", vp), ("partials1", vp), ("partials2", vp), ("n", c_i64), ("dy_stride", c_i32),
+                ("x1_stride", c_i32), ("K1", c_i32), ("x2_stride", c_i32), ("K2", c_i32), ("N", c_i32), ("yo_stride", c_i32),
+                ("act", c_i32), ("sum_partials", c_i32), ("_pad", c_i32)]
+
+
+class PgHeadDesc(ctypes.Structure):
+    _fields_ = [("indptr", vp), ("src", vp), ("h", vp), ("W", vp), ("bias", vp), ("labels", vp), ("n_valid_dev", vp),
+                ("grad_scale_dev", vp), ("ignore_index", c_i64), ("n_dst", c_i64), ("h_stride", c_i32), ("K", c_i32), ("C", c_i32),
+                ("reduce", c_i32), ("flags", c_i32), ("has_drop", c_i32), ("drop", PgDropout), ("logits", vp), ("dagg", vp),
+                ("partials", vp), ("dW", vp), ("db_loss", vp), ("h_self", vp), ("W_self", vp), ("bias_self", vp), ("dself", vp),
+                ("hs_stride", c_i32), ("Ks", c_i32)]
 
 
 class PgBatchEarly(ctypes.Structure):
@@ -116,11 +148,9 @@ _SIGS = {
     "pg_slot_map_reset": (ctypes.c_int, [vp, c_i64, vp]),
     "pg_slot_map_assign": (ctypes.c_int, [vp, vp, c_i64, vp]),
     "pg_slot_map_export": (ctypes.c_int, [vp, c_i64, vp, vp, vp]),
-    "pg_gather_rows": (ctypes.c_int, [vp, c_i64, vp, vp, ctypes.POINTER(PgField), ctypes.c_int, vp, vp, vp, vp, vp, vp, vp]),
-    "pg_split_rows": (ctypes.c_int, [vp, c_i64, vp, vp, vp, vp, vp, vp, vp, vp]),
-    "pg_gather_rows_dedup": (ctypes.c_int, [vp, c_i64, vp, vp, ctypes.POINTER(PgField), ctypes.c_int, vp, vp, vp, vp, vp, vp,
-                                            ctypes.POINTER(PgDedup), vp]),
-    "pg_split_rows_dedup": (ctypes.c_int, [vp, c_i64, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(PgDedup), vp]),
+    "pg_gather_rows": (ctypes.c_int, [vp, c_i64, vp, vp, ctypes.POINTER(PgField), ctypes.c_int, ctypes.POINTER(PgMissList), vp, vp,
+                                      vp, ctypes.POINTER(PgDedup), vp]),
+    "pg_split_rows": (ctypes.c_int, [vp, c_i64, vp, vp, ctypes.POINTER(PgMissList), vp, vp, ctypes.POINTER(PgDedup), vp]),
     "pg_scatter_rows_dups": (ctypes.c_int, [vp, vp, vp, c_i64, vp, c_i32, vp, c_i32, c_i32, vp]),
     "pg_gather_rows_presplit": (ctypes.c_int, [vp, c_i64, ctypes.POINTER(PgField), ctypes.c_int, vp, vp]),
     "pg_gather_rows_full": (ctypes.c_int, [vp, c_i64, ctypes.POINTER(PgField), ctypes.c_int, vp]),
@@ -168,47 +198,26 @@ _SIGS = {
     "pg_frontier_mark_neighbors": (ctypes.c_int, [vp, vp, vp, c_i64, vp, ctypes.c_int, vp]),
     "pg_bitmap_to_ids": (ctypes.c_int, [vp, c_i64, vp, c_i64, vp, vp, vp, vp]),
     "pg_spmm_fwd": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp]),
-    "pg_spmm_bwd": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp]),
+    "pg_spmm_bwd": (ctypes.c_int, [ctypes.POINTER(PgSpmmBwdDesc), vp]),
     "pg_spmm_fwd_drop": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, vp]),
     "pg_spmm_fwd_rows": (ctypes.c_int, [vp, vp, ctypes.POINTER(PgRowSource), c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, vp,
                                         c_i32, vp]),
     "pg_prof_stamp": (ctypes.c_int, [vp, c_i32, vp, vp]),
     "pg_slots_full": (ctypes.c_int, [vp, c_i64, vp, vp, vp, vp]),
-    "pg_stream_create_masked": (ctypes.c_int, [vp, c_i32, ctypes.POINTER(ctypes.c_void_p)]),
-    "pg_stream_destroy": (ctypes.c_int, [vp]),
     "pg_compose_edge_slots": (ctypes.c_int, [vp, c_i64, vp, c_i64, vp, vp]),
-    "pg_spmm_bwd_drop": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, vp]),
-    "pg_spmm_bwd_gather": (ctypes.c_int, [vp, vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, c_i32, vp, vp]),
-    "pg_spmm_bwd_gather_dz": (ctypes.c_int, [vp, vp, vp, vp, c_i32, c_i64, c_i32, ctypes.c_int, vp, c_i32, vp, c_i32, vp, vp,
-                                             c_i32, vp, vp]),
-    "pg_spmm_bwd_max": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, vp, c_i32, vp, c_i32, vp, c_i32, vp, vp]),
-    "pg_spmm_bwd_gather_max": (ctypes.c_int, [vp, vp, vp, c_i32, c_i64, c_i32, vp, c_i32, vp, c_i32, vp, c_i32, vp, c_i32, vp,
-                                              vp, vp]),
-    "pg_linear_fwd": (ctypes.c_int, [vp, c_i32, vp, vp, vp, c_i32, c_i64, c_i32, c_i32, c_i32, vp]),
-    "pg_linear2_fwd": (ctypes.c_int, [vp, c_i32, vp, vp, c_i32, vp, c_i32, vp, vp, c_i32, vp, c_i32, c_i64, c_i32, c_i32, vp]),
+    "pg_linear_fwd": (ctypes.c_int, [ctypes.POINTER(PgLinearFwdDesc), vp]),
     "pg_linear_bwd_w_scratch": (c_i64, [c_i64, c_i32, c_i32]),
-    "pg_linear_bwd_w": (ctypes.c_int, [vp, c_i32, vp, c_i32, c_i64, c_i32, c_i32, vp, vp, vp, c_i32, c_i32, vp, vp, vp]),
+    "pg_linear_bwd_w": (ctypes.c_int, [ctypes.POINTER(PgLinearBwdDesc), vp]),
     "pg_xent_fwd": (ctypes.c_int, [vp, c_i32, vp, c_i64, c_i32, c_i64, vp, c_i32, vp, vp, vp]),
     "pg_xent_bwd": (ctypes.c_int, [vp, c_i32, c_i64, c_i32, vp, vp, vp, c_i32, vp]),
     "pg_gcn_head_scratch": (c_i64, [c_i64, c_i32, c_i32]),
     "pg_gcn_head_row_len": (c_i32, [c_i32, c_i32]),
-    "pg_gcn_head": (ctypes.c_int, [vp, vp, vp, c_i32, c_i32, vp, vp, c_i32, vp, c_i64, vp, vp, vp, ctypes.c_int,
-                                   c_i64, vp, vp, vp, vp, vp, vp]),
+    "pg_head": (ctypes.c_int, [ctypes.POINTER(PgHeadDesc), vp]),
     "pg_adam_step_mirror": (ctypes.c_int, [vp, vp]),
     "pg_adam_step": (ctypes.c_int, [ctypes.POINTER(PgAdamDesc), vp]),
-    "pg_gcn_head_ex": (ctypes.c_int, [vp, vp, vp, c_i32, c_i32, vp, vp, c_i32, vp, c_i64, vp, vp, vp, ctypes.c_int,
-                                      c_i64, vp, vp, vp, vp, vp, c_i32, vp]),
-    "pg_sage_head": (ctypes.c_int, [vp, vp, vp, c_i32, c_i32, vp, vp, vp, c_i32, c_i32, vp, vp, c_i32, vp, c_i64, vp, vp, vp,
-                                    ctypes.c_int, c_i64, vp, vp, vp, vp, vp, vp, c_i32, vp]),
-    "pg_linear_bwd_w_ex": (ctypes.c_int, [vp, c_i32, vp, c_i32, c_i64, c_i32, c_i32, vp, vp, vp, c_i32, c_i32, vp, vp, c_i32,
-                                          vp]),
-    "pg_linear2_fwd_rows": (ctypes.c_int, [vp, c_i32, vp, vp, vp, c_i32, vp, vp, c_i32, vp, c_i32, c_i64, c_i32, c_i32, vp]),
-    "pg_linear_bwd_w_rows": (ctypes.c_int, [vp, c_i32, vp, c_i64, c_i32, c_i32, vp, vp, vp, c_i32, c_i32, vp, vp, c_i32, vp]),
-    "pg_linear2_bwd_w": (ctypes.c_int, [vp, c_i32, vp, c_i32, vp, c_i32, vp, c_i32, c_i32, c_i64, c_i32, vp, vp, vp, vp, vp,
-                                         c_i32, c_i32, vp, vp, vp, c_i32, vp]),
     "pg_dg_partition": (ctypes.c_int, [c_i64, vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp]),
     "pg_dg_partition_mt": (ctypes.c_int, [c_i64, vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp, c_i32]),
-    "pg_dg_partition_gpu": (ctypes.c_int, [c_i64, vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp, ctypes.POINTER(PgDgGpuStats), vp]),
+    "pg_dg_partition_gpu": (ctypes.c_int, [c_i64, vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, ctypes.POINTER(PgDgGpuStats), vp]),
     "pg_np_argsort_f64": (ctypes.c_int, [vp, c_i32, vp]),
     "pg_rmat_edges": (ctypes.c_int, [c_u64, c_i32, c_u32, c_u32, c_u32, c_i64, c_i64, vp, vp, vp]),
     "pg_random_features": (ctypes.c_int, [c_u64, c_i64, c_i64, c_i32, vp, c_i64, vp]),
@@ -398,36 +407,11 @@ def record_streams(root, streams, _seen=None, _depth=0):
             record_streams(getattr(root, k, None), streams, _seen, _depth + 1)
 
 
-_MASKED = {}     # (device index, role, user name) -> torch ExternalStream over a CU-masked HIP stream (one per process and role)
-
-
 def pipeline_stream(device, role, priority=0, name=None):
     """A stream for one role of the training pipeline: 'side' (sampler chain, load stream: a handful of small latency-bound
-    launches per step) or 'compute' (the replayed step, HBM-bound). Default: a plain torch stream of the given priority.
-    PG_CU_SIDE=<n> (experiment): the side streams may only use n CUs (the low n bits of the CU mask, which
-    ROCr deals round-robin over the XCDs) and the compute stream only the others, so the side launches never take wave
-    slots next to the HBM-bound kernels. CU-masked streams have the default priority."""
-    import os
-    n = int(os.environ.get("PG_CU_SIDE", "0") or 0)
-    dev = torch.device(device)
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    cus = torch.cuda.get_device_properties(idx).multi_processor_count
-    if n <= 0 or n >= cus or role not in ("side", "compute"):
-        return torch.cuda.Stream(device=device, priority=priority)
-    if role == "compute" and os.environ.get("PG_CU_COMPUTE_ALL"):
-        return torch.cuda.Stream(device=device, priority=priority)
-    if (idx, role, name) in _MASKED:
-        # ONE masked stream per (device, role, user name) and process: pg_stream_create_masked's stream is never destroyed by its users
-        # (ADVICE r04: every sampler / trainer leaked one); the requested priority does not apply to CU-masked streams
-        return _MASKED[(idx, role, name)]
-    words = (cus + 31) // 32
-    bits = ((1 << n) - 1) if role == "side" else (((1 << cus) - 1) ^ ((1 << n) - 1))
-    arr = (ctypes.c_uint32 * words)(*[(bits >> (32 * i)) & 0xFFFFFFFF for i in range(words)])
-    out = ctypes.c_void_p()
-    with torch.cuda.device(idx):
-        check(load().pg_stream_create_masked(arr, words, ctypes.byref(out)), "pg_stream_create_masked")
-    _MASKED[(idx, role, name)] = torch.cuda.ExternalStream(out.value, device=dev)
-    return _MASKED[(idx, role, name)]
+    launches per step) or 'compute' (the replayed step). A plain torch stream of the given priority (rounds 4-5 also had an
+    experimental CU-masked variant, PG_CU_SIDE: measured, no gain, removed in round 6 — HISTORY.md)."""
+    return torch.cuda.Stream(device=device, priority=priority)
 
 
 def ptr(t):
@@ -437,6 +421,12 @@ def ptr(t):
     if BOUNDS:
         note(t)
     return ctypes.c_void_p(t.data_ptr())
+
+
+def miss_list(pos, fullid, count):
+    """pg_miss_list_t from three tensors / raw pointers (kept alive by the caller)"""
+    as_ptr = lambda x: x if isinstance(x, (int, type(None))) else (x.value if isinstance(x, ctypes.c_void_p) else ptr(x).value)
+    return PgMissList(as_ptr(pos), as_ptr(fullid), as_ptr(count))
 
 
 def make_fields(items):

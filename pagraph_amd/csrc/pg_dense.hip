@@ -578,28 +578,23 @@ static int linear_fwd(const float* X, int32_t x_stride, const float* W, const fl
   return PG_OK;
 }
 
-int pg_linear_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, float* Y, int32_t y_stride,
-                  int64_t n, int32_t K, int32_t N, int32_t act, pg_stream_t stream) {
-  return linear_fwd(X, x_stride, W, bias, nullptr, 0, nullptr, nullptr, 0, Y, y_stride, n, K, N, act, stream);
-}
-
-int pg_linear2_fwd_rows(const pg_row_source_t* X, int32_t K, const float* W, const float* bias, const float* X2,
-                        int32_t x2_stride, const float* W2, const float* bias2, int32_t K2, float* Y, int32_t y_stride,
-                        int64_t n, int32_t N, int32_t act, pg_stream_t stream) {
-  const float* base = nullptr;
-  int32_t stride = 0;
-  RowsArg ra{};
-  const int rc = rows_arg(X, K, &base, &stride, &ra);
-  if (rc != PG_OK) return rc;
-  return linear_fwd(base, stride, W, bias, X2, x2_stride, W2, bias2, K2 > 0 ? K2 : 0, Y, y_stride, n, K, N, act, stream,
-                    &ra);
-}
-
-int pg_linear2_fwd(const float* X, int32_t x_stride, const float* W, const float* bias, int32_t K, const float* X2,
-                   int32_t x2_stride, const float* W2, const float* bias2, int32_t K2, float* Y, int32_t y_stride,
-                   int64_t n, int32_t N, int32_t act, pg_stream_t stream) {
-  if (K2 <= 0) return PG_ERR_INVALID;
-  return linear_fwd(X, x_stride, W, bias, X2, x2_stride, W2, bias2, K2, Y, y_stride, n, K, N, act, stream);
+// ONE forward entry point (round 6: pg_linear_fwd, pg_linear2_fwd and pg_linear2_fwd_rows — 11 to 16 positional arguments — are
+// gone): the descriptor's first operand is dense (X1) or read in place (X1rows), the second one optional (K2 == 0: none).
+int pg_linear_fwd(const pg_linear_fwd_desc_t* d, pg_stream_t stream) {
+  if (!d) return PG_ERR_INVALID;
+  if ((d->X1 != nullptr) == (d->X1rows != nullptr)) return PG_ERR_INVALID;       // exactly one form of the first operand
+  if (d->K2 < 0) return PG_ERR_INVALID;
+  if (d->X1rows) {
+    const float* base = nullptr;
+    int32_t stride = 0;
+    RowsArg ra{};
+    const int rc = rows_arg(d->X1rows, d->K1, &base, &stride, &ra);
+    if (rc != PG_OK) return rc;
+    return linear_fwd(base, stride, d->W1, d->bias1, d->X2, d->x2_stride, d->W2, d->bias2, d->K2, d->Y, d->y_stride, d->n, d->K1,
+                      d->N, d->act, stream, &ra);
+  }
+  return linear_fwd(d->X1, d->x1_stride, d->W1, d->bias1, d->X2, d->x2_stride, d->W2, d->bias2, d->K2, d->Y, d->y_stride, d->n,
+                    d->K1, d->N, d->act, stream);
 }
 
 /* out[j] = sum over chunks of part[c][j] (chunk order), j < nk -> dW[j], nk <= j < nk + N -> db[j - nk] */
@@ -622,35 +617,9 @@ int64_t pg_linear_bwd_w_scratch(int64_t n, int32_t K, int32_t N) {
   return ceil_div<int64_t>(n, 4 * bwd_rows_per_wave(n, K, N)) * ((int64_t)N * K + N);
 }
 
-int pg_linear_bwd_w(const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n, int32_t K,
-                    int32_t N, float* dW, float* db, const float* Yout, int32_t yo_stride, int32_t act,
-                    float* dz_scratch, float* partials, pg_stream_t stream) {
-  return pg_linear_bwd_w_ex(dY, dy_stride, X, x_stride, n, K, N, dW, db, Yout, yo_stride, act, dz_scratch, partials, 1,
-                            stream);
-}
-
 static int linear_bwd_w(const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n, int32_t K,
                         int32_t N, float* dW, float* db, const float* Yout, int32_t yo_stride, int32_t act,
                         float* dz_scratch, float* partials, int32_t sum_partials, const RowsArg* rows, pg_stream_t stream);
-
-int pg_linear_bwd_w_ex(const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n, int32_t K,
-                       int32_t N, float* dW, float* db, const float* Yout, int32_t yo_stride, int32_t act,
-                       float* dz_scratch, float* partials, int32_t sum_partials, pg_stream_t stream) {
-  return linear_bwd_w(dY, dy_stride, X, x_stride, n, K, N, dW, db, Yout, yo_stride, act, dz_scratch, partials, sum_partials,
-                      nullptr, stream);
-}
-
-int pg_linear_bwd_w_rows(const float* dY, int32_t dy_stride, const pg_row_source_t* X, int64_t n, int32_t K, int32_t N,
-                         float* dW, float* db, const float* Yout, int32_t yo_stride, int32_t act, float* dz_scratch,
-                         float* partials, int32_t sum_partials, pg_stream_t stream) {
-  const float* base = nullptr;
-  int32_t stride = 0;
-  RowsArg ra{};
-  const int rc = rows_arg(X, K, &base, &stride, &ra);
-  if (rc != PG_OK) return rc;
-  return linear_bwd_w(dY, dy_stride, base, stride, n, K, N, dW, db, Yout, yo_stride, act, dz_scratch, partials,
-                      sum_partials, &ra, stream);
-}
 
 // fills the launch record of one weight gradient; returns its grid (0: nothing to do) or a negative error
 static int64_t bwd_w_args(BwdWArgs* a, const float* dY, int32_t dy_stride, const float* X, int32_t x_stride, int64_t n,
@@ -699,10 +668,10 @@ static int linear_bwd_w(const float* dY, int32_t dy_stride, const float* X, int3
   return PG_OK;
 }
 
-int pg_linear2_bwd_w(const float* dY, int32_t dy_stride, const float* X1, int32_t x1_stride, const pg_row_source_t* X1rows,
-                     int32_t K1, const float* X2, int32_t x2_stride, int32_t K2, int64_t n, int32_t N, float* dW1, float* db1,
-                     float* dW2, float* db2, const float* Yout, int32_t yo_stride, int32_t act, float* dz_scratch,
-                     float* partials1, float* partials2, int32_t sum_partials, pg_stream_t stream) {
+static int linear2_bwd_w(const float* dY, int32_t dy_stride, const float* X1, int32_t x1_stride, const pg_row_source_t* X1rows,
+                         int32_t K1, const float* X2, int32_t x2_stride, int32_t K2, int64_t n, int32_t N, float* dW1, float* db1,
+                         float* dW2, float* db2, const float* Yout, int32_t yo_stride, int32_t act, float* dz_scratch,
+                         float* partials1, float* partials2, int32_t sum_partials, pg_stream_t stream) {
   if (n < 0 || K1 <= 0 || K2 <= 0 || N <= 0 || x2_stride < K2 || act < 0 || act > 2 || dy_stride < (act == 2 ? 2 * N : N))
     return PG_ERR_INVALID;
   if (act != 0 && (!Yout || yo_stride < N || !dz_scratch)) return PG_ERR_INVALID;
@@ -744,6 +713,29 @@ int pg_linear2_bwd_w(const float* dY, int32_t dy_stride, const float* X1, int32_
                      partials2, (int32_t)ch2, nk2, N, dW2, db2, nk2 + N);
   PG_LAUNCH_CHECK();
   return PG_OK;
+}
+
+// ONE weight-gradient entry point (round 6: pg_linear_bwd_w, _ex, _rows and pg_linear2_bwd_w — 15 to 23 positional arguments —
+// are gone): one operand (K2 == 0) or GraphSAGE's two over the same dZ in one launch; the first dense or read in place.
+int pg_linear_bwd_w(const pg_linear_bwd_desc_t* d, pg_stream_t stream) {
+  if (!d) return PG_ERR_INVALID;
+  if ((d->X1 != nullptr) == (d->X1rows != nullptr)) return PG_ERR_INVALID;
+  if (d->K2 > 0)
+    return linear2_bwd_w(d->dY, d->dy_stride, d->X1, d->x1_stride, d->X1rows, d->K1, d->X2, d->x2_stride, d->K2, d->n, d->N, d->dW1,
+                         d->db1, d->dW2, d->db2, d->Yout, d->yo_stride, d->act, d->dz_scratch, d->partials1, d->partials2,
+                         d->sum_partials, stream);
+  if (d->K2 < 0 || d->X2 || d->dW2 || d->db2 || d->partials2) return PG_ERR_INVALID;
+  if (d->X1rows) {
+    const float* base = nullptr;
+    int32_t stride = 0;
+    RowsArg ra{};
+    const int rc = rows_arg(d->X1rows, d->K1, &base, &stride, &ra);
+    if (rc != PG_OK) return rc;
+    return linear_bwd_w(d->dY, d->dy_stride, base, stride, d->n, d->K1, d->N, d->dW1, d->db1, d->Yout, d->yo_stride, d->act,
+                        d->dz_scratch, d->partials1, d->sum_partials, &ra, stream);
+  }
+  return linear_bwd_w(d->dY, d->dy_stride, d->X1, d->x1_stride, d->n, d->K1, d->N, d->dW1, d->db1, d->Yout, d->yo_stride, d->act,
+                      d->dz_scratch, d->partials1, d->sum_partials, nullptr, stream);
 }
 
 }  // extern "C"

@@ -251,8 +251,10 @@ double now_s() {
 
 extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const int32_t* indices_dev,
                                    const int64_t* train_nids, int64_t n_train, int32_t P, int32_t hops,
-                                   int8_t* belongs_out, uint8_t* r_mask_out, int64_t* p_vnum_out, int64_t* r_vnum_out,
+                                   int8_t* belongs_out, uint8_t* r_mask_out, int64_t* vnum_out,
                                    pg_dg_gpu_stats_t* stats, pg_stream_t stream) {
+  int64_t* p_vnum_out = vnum_out;                          // [2][P]: p_vnum, then r_vnum (dg.py:65-66)
+  int64_t* r_vnum_out = vnum_out ? vnum_out + P : nullptr;
   if (V <= 0 || !indptr_dev || !indices_dev || n_train < 0 || (n_train > 0 && !train_nids) || !belongs_out) return PG_ERR_INVALID;
   if (P < 2 || P > 127 || hops < 1) return PG_ERR_INVALID;
   // what this path covers; the caller falls back to pg_dg_partition_mt otherwise (same result, host only)

@@ -558,10 +558,13 @@ int pg_slot_map_export(const int32_t* slot_map, int64_t node_num, uint8_t* gpu_f
   return PG_OK;
 }
 
-int pg_gather_rows_dedup(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
-                         const pg_field_t* fields, int n_fields, int32_t* miss_pos, int64_t* miss_fullid,
-                         int32_t* miss_count, int32_t* slot_scratch, uint64_t* stats, pg_timer_t* timer,
-                         const pg_dedup_t* dedup, pg_stream_t stream) {
+int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
+                   const pg_field_t* fields, int n_fields, const pg_miss_list_t* miss, int32_t* slot_scratch,
+                   uint64_t* stats, pg_timer_t* timer, const pg_dedup_t* dedup, pg_stream_t stream) {
+  if (!miss) return PG_ERR_INVALID;
+  int32_t* miss_pos = miss->pos;
+  int64_t* miss_fullid = miss->fullid;
+  int32_t* miss_count = miss->count;
   if (n < 0 || n > INT32_MAX || !miss_count) return PG_ERR_INVALID;
   hipStream_t st = as_stream(stream);
   PG_HIP(hipMemsetAsync(miss_count, 0, sizeof(int32_t), st));
@@ -583,24 +586,13 @@ int pg_gather_rows_dedup(const int64_t* ids, int64_t n, const int32_t* slot_map,
   return launch_gather<false>(a, st, timer);
 }
 
-int pg_gather_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
-                   const pg_field_t* fields, int n_fields, int32_t* miss_pos, int64_t* miss_fullid,
-                   int32_t* miss_count, int32_t* slot_scratch, uint64_t* stats, pg_timer_t* timer,
-                   pg_stream_t stream) {
-  return pg_gather_rows_dedup(ids, n, slot_map, nid_map, fields, n_fields, miss_pos, miss_fullid, miss_count,
-                              slot_scratch, stats, timer, nullptr, stream);
-}
-
-int pg_split_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map, int32_t* miss_pos,
-                  int64_t* miss_fullid, int32_t* miss_count, int32_t* slots_out, uint64_t* stats,
+int pg_split_rows(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
+                  const pg_miss_list_t* miss, int32_t* slots_out, uint64_t* stats, const pg_dedup_t* dedup,
                   pg_stream_t stream) {
-  return pg_split_rows_dedup(ids, n, slot_map, nid_map, miss_pos, miss_fullid, miss_count, slots_out, stats, nullptr,
-                             stream);
-}
-
-int pg_split_rows_dedup(const int64_t* ids, int64_t n, const int32_t* slot_map, const int64_t* nid_map,
-                        int32_t* miss_pos, int64_t* miss_fullid, int32_t* miss_count, int32_t* slots_out,
-                        uint64_t* stats, const pg_dedup_t* dedup, pg_stream_t stream) {
+  if (!miss) return PG_ERR_INVALID;
+  int32_t* miss_pos = miss->pos;
+  int64_t* miss_fullid = miss->fullid;
+  int32_t* miss_count = miss->count;
   if (n < 0 || n > INT32_MAX || !miss_count) return PG_ERR_INVALID;
   hipStream_t st = as_stream(stream);
   PG_HIP(hipMemsetAsync(miss_count, 0, sizeof(int32_t), st));

@@ -338,15 +338,6 @@ int64_t pg_gcn_head_scratch(int64_t n_dst, int32_t K, int32_t C) {
   return ceil_div<int64_t>(n_dst, 4 * head_rows(n_dst)) * (int64_t)pg_gcn_head_row_len(K, C);
 }
 
-int pg_gcn_head(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
-                const float* W, const float* bias, int32_t C, const int64_t* labels, int64_t ignore_index,
-                const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
-                int64_t n_dst,
-                float* logits, float* dagg, float* partials, float* dW, float* db_loss, pg_stream_t stream) {
-  return pg_gcn_head_ex(indptr, src, h, h_stride, K, W, bias, C, labels, ignore_index, n_valid_dev, grad_scale_dev, drop,
-                        reduce, n_dst, logits, dagg, partials, dW, db_loss, 1, stream);
-}
-
 static int head_impl(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
                      const float* W, const float* bias, int32_t C, const int64_t* labels, int64_t ignore_index,
                      const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
@@ -390,26 +381,16 @@ static int head_impl(const int32_t* indptr, const int32_t* src, const float* h, 
                                  stream);
 }
 
-int pg_gcn_head_ex(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
-                   const float* W, const float* bias, int32_t C, const int64_t* labels, int64_t ignore_index,
-                   const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
-                   int64_t n_dst, float* logits, float* dagg, float* partials, float* dW, float* db_loss,
-                   int32_t flags, pg_stream_t stream) {
-  return head_impl(indptr, src, h, h_stride, K, W, bias, C, labels, ignore_index, n_valid_dev, grad_scale_dev, drop, reduce,
-                   n_dst, logits, dagg, partials, dW, db_loss, flags, HeadSelf{}, stream);
+// ONE entry point for the output head (round 6: pg_gcn_head, pg_gcn_head_ex and pg_sage_head — 21 to 28 positional arguments —
+// are gone): the descriptor's self_* fields select GraphSAGE's two-operand output layer (Ks > 0) or the GCN head (Ks == 0).
+int pg_head(const pg_head_desc_t* d, pg_stream_t stream) {
+  if (!d) return PG_ERR_INVALID;
+  if (d->Ks < 0 || (d->Ks == 0 && (d->h_self || d->W_self || d->dself))) return PG_ERR_INVALID;
+  HeadSelf self{};
+  if (d->Ks > 0) self = HeadSelf{d->h_self, d->W_self, d->bias_self, d->dself, d->hs_stride, d->Ks};
+  return head_impl(d->indptr, d->src, d->h, d->h_stride, d->K, d->W, d->bias, d->C, d->labels, d->ignore_index, d->n_valid_dev,
+                   d->grad_scale_dev, d->has_drop ? &d->drop : nullptr, d->reduce, d->n_dst, d->logits, d->dagg, d->partials,
+                   d->dW, d->db_loss, d->flags, self, stream);
 }
-
-int pg_sage_head(const int32_t* indptr, const int32_t* src, const float* h, int32_t h_stride, int32_t K,
-                 const float* W, const float* bias, const float* h_self, int32_t hs_stride, int32_t Ks,
-                 const float* W_self, const float* bias_self, int32_t C, const int64_t* labels, int64_t ignore_index,
-                 const int32_t* n_valid_dev, const float* grad_scale_dev, const pg_dropout_t* drop, int reduce,
-                 int64_t n_dst, float* logits, float* dagg, float* dself, float* partials, float* dW_both, float* db_loss,
-                 int32_t flags, pg_stream_t stream) {
-  if (Ks <= 0) return PG_ERR_INVALID;
-  HeadSelf self{h_self, W_self, bias_self, dself, hs_stride, Ks};
-  return head_impl(indptr, src, h, h_stride, K, W, bias, C, labels, ignore_index, n_valid_dev, grad_scale_dev, drop, reduce,
-                   n_dst, logits, dagg, partials, dW_both, db_loss, flags, self, stream);
-}
-
 
 }  // extern "C"

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_adam(const AdamArgs a) {
 // the sum over `chunks[i]` partial rows of part[i][c * len[i] + off[i] + o], added in EXACTLY k_sum_partials' order
 // (4 chunk groups x 8 rotating accumulators, pairwise combine) so that the trajectory is bit-identical to the
 // three-launch version; the sum is also written to g[i] (p.grad stays meaningful). adam[i] == 0: reduce only (the
-// loss scalar of pg_gcn_head lives in the same partial rows). Block = 64 elements x 4 chunk groups.
+// loss scalar of pg_head lives in the same partial rows). Block = 64 elements x 4 chunk groups.
 struct AdamPartArgs {
   float* p[PG_ADAM_MAX_TENSORS];
   float* g[PG_ADAM_MAX_TENSORS];
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void k_adam_partials(const AdamPartArgs a) {
       const int cb = grp * per, ce = (cb + per < nch) ? cb + per : nch;
       const float* col = pt + of + o;
       int c = cb;
-      // 32 loads in flight per round (the head's partials are one row per block of pg_gcn_head: ~94 rows per chunk
+      // 32 loads in flight per round (the head's partials are one row per block of pg_head: ~94 rows per chunk
       // group, twelve dependent rounds of 8 — the critical path of this launch); the additions keep k_sum_partials'
       // order: accumulator u & 7 takes rows c + u in ascending order
       for (; c + 31 < ce; c += 32) {

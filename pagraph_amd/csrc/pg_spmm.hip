@@ -873,13 +873,15 @@ int pg_compose_edge_slots(const int32_t* src, int64_t n_edges, const int32_t* sl
   return PG_OK;
 }
 
-int pg_spmm_bwd_drop(const int32_t* indptr, const int32_t* src, const float* grad_out, int32_t go_stride,
+static int spmm_bwd_plain_(const int32_t* indptr, const int32_t* src, const float* grad_out, int32_t go_stride, int64_t n_dst,
+                           int32_t dim, int reduce, float* grad_h, int32_t gh_stride, pg_stream_t stream);
+static int spmm_bwd_drop_(const int32_t* indptr, const int32_t* src, const float* grad_out, int32_t go_stride,
                      int64_t n_dst, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,
                      const pg_dropout_t* drop, pg_stream_t stream) {
   DropArgs d;
   if (drop && drop->threshold > 65535u) return PG_ERR_INVALID;
   if (!drop_args(drop, &d))
-    return pg_spmm_bwd(indptr, src, grad_out, go_stride, n_dst, dim, reduce, grad_h, gh_stride, stream);
+    return spmm_bwd_plain_(indptr, src, grad_out, go_stride, n_dst, dim, reduce, grad_h, gh_stride, stream);
   if (n_dst < 0 || dim <= 0 || go_stride < dim || gh_stride < dim || dim % 4) return PG_ERR_INVALID;
   if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return PG_ERR_INVALID;
   if (n_dst == 0) return PG_OK;
@@ -890,13 +892,6 @@ int pg_spmm_bwd_drop(const int32_t* indptr, const int32_t* src, const float* gra
                      as_stream(stream), indptr, src, grad_out, go_stride, n_dst, dim, reduce, grad_h, gh_stride, l2, d);
   PG_LAUNCH_CHECK();
   return PG_OK;
-}
-
-int pg_spmm_bwd_gather(const int32_t* tptr, const int32_t* tdst, const int32_t* indptr, const float* grad_out,
-                       int32_t go_stride, int64_t n_src, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,
-                       const int32_t* heavy, int32_t heavy_cap, const pg_dropout_t* drop, pg_stream_t stream) {
-  return pg_spmm_bwd_gather_dz(tptr, tdst, indptr, grad_out, go_stride, n_src, dim, reduce, grad_h, gh_stride, heavy,
-                               heavy_cap, drop, nullptr, 0, nullptr, stream);
 }
 
 static int bwd_gather_impl(const int32_t* tptr, const int32_t* tdst, const int32_t* indptr, const float* grad_out,
@@ -961,7 +956,7 @@ static int bwd_gather_impl(const int32_t* tptr, const int32_t* tdst, const int32
   return PG_OK;
 }
 
-int pg_spmm_bwd_gather_dz(const int32_t* tptr, const int32_t* tdst, const int32_t* indptr, const float* grad_out,
+static int spmm_bwd_gather_dz_(const int32_t* tptr, const int32_t* tdst, const int32_t* indptr, const float* grad_out,
                           int32_t go_stride, int64_t n_src, int32_t dim, int reduce, float* grad_h, int32_t gh_stride,
                           const int32_t* heavy, int32_t heavy_cap, const pg_dropout_t* drop, const float* act_out,
                           int32_t act_stride, float* dz, pg_stream_t stream) {
@@ -969,7 +964,7 @@ int pg_spmm_bwd_gather_dz(const int32_t* tptr, const int32_t* tdst, const int32_
                          drop, act_out, act_stride, dz, nullptr, stream);
 }
 
-int pg_spmm_bwd_gather_max(const int32_t* tptr, const int32_t* tdst, const float* grad_out, int32_t go_stride,
+static int spmm_bwd_gather_max_(const int32_t* tptr, const int32_t* tdst, const float* grad_out, int32_t go_stride,
                            int64_t n_src, int32_t dim, const float* h, int32_t h_stride, const float* out,
                            int32_t out_stride, float* grad_h, int32_t gh_stride, const int32_t* heavy,
                            int32_t heavy_cap, const pg_dropout_t* drop, float* dz, pg_stream_t stream) {
@@ -978,7 +973,7 @@ int pg_spmm_bwd_gather_max(const int32_t* tptr, const int32_t* tdst, const float
                          heavy_cap, drop, h, h_stride, dz, &mi, stream);
 }
 
-int pg_spmm_bwd_max(const int32_t* indptr, const int32_t* src, const float* grad_out, int32_t go_stride, int64_t n_dst,
+static int spmm_bwd_max_(const int32_t* indptr, const int32_t* src, const float* grad_out, int32_t go_stride, int64_t n_dst,
                     int32_t dim, const float* h, int32_t h_stride, const float* out, int32_t out_stride, float* grad_h,
                     int32_t gh_stride, const pg_dropout_t* drop, pg_stream_t stream) {
   if (n_dst < 0 || dim <= 0 || go_stride < dim || gh_stride < dim || h_stride < dim || out_stride < dim) return PG_ERR_INVALID;
@@ -1002,7 +997,7 @@ int pg_spmm_bwd_max(const int32_t* indptr, const int32_t* src, const float* grad
   return PG_OK;
 }
 
-int pg_spmm_bwd(const int32_t* indptr, const int32_t* src, const float* grad_out, int32_t go_stride, int64_t n_dst,
+static int spmm_bwd_plain_(const int32_t* indptr, const int32_t* src, const float* grad_out, int32_t go_stride, int64_t n_dst,
                 int32_t dim, int reduce, float* grad_h, int32_t gh_stride, pg_stream_t stream) {
   if (n_dst < 0 || dim <= 0 || go_stride < dim || gh_stride < dim) return PG_ERR_INVALID;
   if (reduce != PG_REDUCE_MEAN && reduce != PG_REDUCE_SUM) return PG_ERR_INVALID;
@@ -1015,6 +1010,27 @@ int pg_spmm_bwd(const int32_t* indptr, const int32_t* src, const float* grad_out
                      n_dst, dim, reduce, grad_h, gh_stride, l2);
   PG_LAUNCH_CHECK();
   return PG_OK;
+}
+
+// ONE entry point for the backward of a block aggregation (round 6: pg_spmm_bwd, _drop, _max, _gather, _gather_dz and
+// _gather_max — 10 to 17 positional arguments — are gone): gather form over the block's source-major copy when the descriptor
+// has one (tptr), else the scatter form; PG_REDUCE_MAX takes the forward's input and output.
+int pg_spmm_bwd(const pg_spmm_bwd_desc_t* d, pg_stream_t stream) {
+  if (!d) return PG_ERR_INVALID;
+  const pg_dropout_t* drop = d->has_drop ? &d->drop : nullptr;
+  if (d->tptr) {
+    if (d->reduce == PG_REDUCE_MAX)
+      return spmm_bwd_gather_max_(d->tptr, d->tdst, d->grad_out, d->go_stride, d->n_src, d->dim, d->h, d->h_stride, d->out,
+                                  d->out_stride, d->grad_h, d->gh_stride, d->heavy, d->heavy_cap, drop, d->dz, stream);
+    return spmm_bwd_gather_dz_(d->tptr, d->tdst, d->indptr, d->grad_out, d->go_stride, d->n_src, d->dim, d->reduce, d->grad_h,
+                               d->gh_stride, d->heavy, d->heavy_cap, drop, d->act_out, d->act_stride, d->dz, stream);
+  }
+  if (d->dz || d->act_out || d->heavy) return PG_ERR_INVALID;          // those belong to the gather form
+  if (d->reduce == PG_REDUCE_MAX)
+    return spmm_bwd_max_(d->indptr, d->src, d->grad_out, d->go_stride, d->n_dst, d->dim, d->h, d->h_stride, d->out, d->out_stride,
+                         d->grad_h, d->gh_stride, drop, stream);
+  return spmm_bwd_drop_(d->indptr, d->src, d->grad_out, d->go_stride, d->n_dst, d->dim, d->reduce, d->grad_h, d->gh_stride, drop,
+                        stream);
 }
 
 }  // extern "C"

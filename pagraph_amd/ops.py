@@ -97,6 +97,32 @@ def aggregate_rows(indptr, src, rows, n_dst, reduce="mean", dropout=None):
     return out
 
 
+def spmm_bwd_call(lib, grad_out, grad_h, n_src, reduce, indptr=None, src=None, transposed=None, drop_struct=None, h=None, out=None,
+                  act_out=None, dz=None, stream=None):
+    """pg_spmm_bwd through its descriptor (pg_spmm_bwd_desc_t): gather form when `transposed` = (tptr, tdst, heavy) is given,
+    else the scatter form over (indptr, src); reduce 'max' needs the forward's input h and output out. Returns the C code."""
+    d = L.PgSpmmBwdDesc()
+    d.indptr, d.src = L.ptr(indptr).value, L.ptr(src).value
+    if transposed is not None:
+        tptr, tdst, heavy = transposed
+        d.tptr, d.tdst, d.heavy = L.ptr(tptr).value, L.ptr(tdst).value, L.ptr(heavy).value
+        d.heavy_cap = heavy.numel() - 1 if heavy is not None else 0
+    d.grad_out, d.go_stride = L.ptr(grad_out).value, grad_out.stride(0)
+    d.grad_h, d.gh_stride = L.ptr(grad_h).value, (grad_h.stride(0) if grad_h is not None else grad_out.size(1))
+    d.n_dst, d.n_src, d.dim = grad_out.size(0), int(n_src), grad_out.size(1)
+    d.reduce = reduce if isinstance(reduce, int) else _REDUCE[reduce]
+    if h is not None:
+        d.h, d.h_stride = L.ptr(h).value, h.stride(0)
+    if out is not None:
+        d.out, d.out_stride = L.ptr(out).value, out.stride(0)
+    if act_out is not None:
+        d.act_out, d.act_stride = L.ptr(act_out).value, act_out.stride(0)
+    d.dz = L.ptr(dz).value
+    if drop_struct is not None:
+        d.has_drop, d.drop = 1, drop_struct
+    return lib.pg_spmm_bwd(ctypes.byref(d), stream if stream is not None else L.stream_ptr())
+
+
 class _BlockAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, indptr, src, h, n_dst, reduce, drop, tptr, tdst, heavy, dz_n=0):
@@ -145,26 +171,16 @@ class _BlockAggregate(torch.autograd.Function):
             y = ctx.saved_tensors[5] if ctx.dz_n else None
             dz = torch.empty((ctx.n_src, ctx.dz_n), dtype=torch.float32, device=go.device) if ctx.dz_n else None
             with torch.cuda.device(go.device):
-                L.check(lib.pg_spmm_bwd_gather_dz(L.ptr(tptr), L.ptr(tdst), L.ptr(indptr), L.ptr(go), go.stride(0), ctx.n_src,
-                                                  go.size(1), _REDUCE[ctx.reduce], L.ptr(gh), gh.stride(0), L.ptr(heavy),
-                                                  heavy.numel() - 1 if heavy is not None else 0,
-                                                  ctypes.byref(d) if d is not None else None, L.ptr(y),
-                                                  y.stride(0) if y is not None else 0, L.ptr(dz), L.stream_ptr()),
-                        "pg_spmm_bwd_gather_dz")
+                L.check(spmm_bwd_call(lib, go, gh, ctx.n_src, ctx.reduce, indptr=indptr, transposed=(tptr, tdst, heavy), drop_struct=d,
+                                      act_out=y, dz=dz), "pg_spmm_bwd (gather form)")
             if dz is not None:
                 _stash_dz(gh, dz)
             return (None, None, gh) + (None,) * 7
         indptr, src = ctx.saved_tensors
         gh = torch.zeros((ctx.n_src, go.size(1)), dtype=torch.float32, device=go.device)
         with torch.cuda.device(go.device):
-            if ctx.drop is None:
-                L.check(lib.pg_spmm_bwd(L.ptr(indptr), L.ptr(src), L.ptr(go), go.stride(0), go.size(0), go.size(1),
-                                        _REDUCE[ctx.reduce], L.ptr(gh), gh.stride(0), L.stream_ptr()), "pg_spmm_bwd")
-            else:
-                d = ctx.drop.struct()
-                L.check(lib.pg_spmm_bwd_drop(L.ptr(indptr), L.ptr(src), L.ptr(go), go.stride(0), go.size(0),
-                                             go.size(1), _REDUCE[ctx.reduce], L.ptr(gh), gh.stride(0),
-                                             ctypes.byref(d), L.stream_ptr()), "pg_spmm_bwd_drop")
+            L.check(spmm_bwd_call(lib, go, gh, ctx.n_src, ctx.reduce, indptr=indptr, src=src,
+                                  drop_struct=ctx.drop.struct() if ctx.drop is not None else None), "pg_spmm_bwd (scatter form)")
         return (None, None, gh) + (None,) * 7
 
 
@@ -173,23 +189,19 @@ class _BlockAggregate(torch.autograd.Function):
         """pg_spmm_bwd_gather_max over the source-major copy when the sampler built one, else the scatter form"""
         indptr, src, h, out = ctx.saved_tensors[:4]
         d = ctx.drop.struct() if ctx.drop is not None else None
-        dp = ctypes.byref(d) if d is not None else None
         with torch.cuda.device(go.device):
             if ctx.use_t:
                 tptr, tdst, heavy = ctx.saved_tensors[4:7]
                 gh = torch.empty((ctx.n_src, go.size(1)), dtype=torch.float32, device=go.device)
                 dz = torch.empty((ctx.n_src, ctx.dz_n), dtype=torch.float32, device=go.device) if ctx.dz_n else None
-                L.check(lib.pg_spmm_bwd_gather_max(L.ptr(tptr), L.ptr(tdst), L.ptr(go), go.stride(0), ctx.n_src, go.size(1),
-                                                   L.ptr(h), h.stride(0), L.ptr(out), out.stride(0), L.ptr(gh), gh.stride(0),
-                                                   L.ptr(heavy), heavy.numel() - 1 if heavy is not None else 0, dp,
-                                                   L.ptr(dz), L.stream_ptr()), "pg_spmm_bwd_gather_max")
+                L.check(spmm_bwd_call(lib, go, gh, ctx.n_src, "max", transposed=(tptr, tdst, heavy), drop_struct=d, h=h, out=out,
+                                      dz=dz), "pg_spmm_bwd (max, gather form)")
                 if dz is not None:
                     _stash_dz(gh, dz)
                 return gh
             gh = torch.zeros((ctx.n_src, go.size(1)), dtype=torch.float32, device=go.device)
-            L.check(lib.pg_spmm_bwd_max(L.ptr(indptr), L.ptr(src), L.ptr(go), go.stride(0), go.size(0), go.size(1),
-                                        L.ptr(h), h.stride(0), L.ptr(out), out.stride(0), L.ptr(gh), gh.stride(0), dp,
-                                        L.stream_ptr()), "pg_spmm_bwd_max")
+            L.check(spmm_bwd_call(lib, go, gh, ctx.n_src, "max", indptr=indptr, src=src, drop_struct=d, h=h, out=out),
+                    "pg_spmm_bwd (max, scatter form)")
         return gh
 
 
@@ -309,6 +321,46 @@ def _apply_act(z, act):
     return z
 
 
+def linear_fwd_call(lib, x1, w1, b1, y, n, N, act, x2=None, w2=None, b2=None, stream=None):
+    """pg_linear_fwd through its descriptor (include/pagraph_hip.h pg_linear_fwd_desc_t): x1 a [n, K1] tensor or an
+    ops.RowSource (rows read in place); optional second operand pair. Returns the C return code."""
+    d = L.PgLinearFwdDesc()
+    keep = None
+    if isinstance(x1, RowSource):
+        keep = x1.struct()
+        d.X1rows = ctypes.addressof(keep)
+        d.K1 = w1.size(1)
+    else:
+        d.X1, d.x1_stride, d.K1 = L.ptr(x1).value, x1.stride(0), w1.size(1)
+    d.W1, d.bias1 = L.ptr(w1).value, L.ptr(b1).value
+    if x2 is not None:
+        d.X2, d.x2_stride, d.K2 = L.ptr(x2).value, x2.stride(0), w2.size(1)
+        d.W2, d.bias2 = L.ptr(w2).value, L.ptr(b2).value
+    d.Y, d.y_stride, d.n, d.N, d.act = L.ptr(y).value, y.stride(0), int(n), int(N), int(act)
+    return lib.pg_linear_fwd(ctypes.byref(d), stream if stream is not None else L.stream_ptr())
+
+
+def linear_bwd_call(lib, g, x1, K1, N, dW1, db1, part1, sum_partials, y=None, act=0, dz=None, x2=None, K2=0, dW2=None, db2=None,
+                    part2=None, stream=None):
+    """pg_linear_bwd_w through its descriptor (pg_linear_bwd_desc_t): one weight gradient, or with x2 GraphSAGE's two over the
+    same dZ in one launch; x1 a tensor or an ops.RowSource. Returns the C return code."""
+    d = L.PgLinearBwdDesc()
+    keep = None
+    if isinstance(x1, RowSource):
+        keep = x1.struct()
+        d.X1rows = ctypes.addressof(keep)
+    else:
+        d.X1, d.x1_stride = L.ptr(x1).value, x1.stride(0)
+    d.dY, d.dy_stride, d.K1, d.N, d.n = L.ptr(g).value, g.stride(0), int(K1), int(N), x1.size(0)
+    if x2 is not None:
+        d.X2, d.x2_stride, d.K2 = L.ptr(x2).value, x2.stride(0), int(K2)
+        d.dW2, d.db2, d.partials2 = L.ptr(dW2).value, L.ptr(db2).value, L.ptr(part2).value
+    d.Yout, d.yo_stride, d.act = L.ptr(y).value, (y.stride(0) if y is not None else 0), int(act)
+    d.dW1, d.db1, d.dz_scratch, d.partials1 = L.ptr(dW1).value, L.ptr(db1).value, L.ptr(dz).value, L.ptr(part1).value
+    d.sum_partials = int(sum_partials)
+    return lib.pg_linear_bwd_w(ctypes.byref(d), stream if stream is not None else L.stream_ptr())
+
+
 class _SkinnyLinear(torch.autograd.Function):
     """NodeUpdate's dense step y = act(x @ W.T + b) with the tall-skinny pieces on the fp32-MFMA kernels
     of pg_dense.hip: forward (bias + activation / skip-concat fused in the epilogue) when out_features <= 64
@@ -323,8 +375,7 @@ class _SkinnyLinear(torch.autograd.Function):
         if N <= 64 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and weight.is_contiguous():
             y = torch.empty((n, 2 * N if act == ACT_CONCAT else N), dtype=torch.float32, device=x.device)
             with torch.cuda.device(x.device):
-                L.check(lib.pg_linear_fwd(L.ptr(x), x.stride(0), L.ptr(weight), L.ptr(bias), L.ptr(y), y.stride(0), n, K,
-                                          N, act, L.stream_ptr()), "pg_linear_fwd")
+                L.check(linear_fwd_call(lib, x, weight, bias, y, n, N, act), "pg_linear_fwd")
         else:
             y = _apply_act(torch.nn.functional.linear(x, weight, bias), act)
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
@@ -359,14 +410,10 @@ def _skinny_backward(ctx, gy, x, weight, y, need_x, need_w, need_b):
         with torch.cuda.device(x.device):
             if ready is not None:        # dZ came with the gradient (pg_spmm_bwd_gather_dz): plain dY = dZ, no act
                 dz = ready
-                L.check(lib.pg_linear_bwd_w_ex(L.ptr(dz), dz.stride(0), L.ptr(x), x.stride(0), x.size(0), K, N,
-                                               L.ptr(gw), L.ptr(gb), None, 0, ACT_NONE, None, L.ptr(part),
-                                               0 if defer else 1, L.stream_ptr()), "pg_linear_bwd_w")
+                L.check(linear_bwd_call(lib, dz, x, K, N, gw, gb, part, 0 if defer else 1), "pg_linear_bwd_w")
             else:
                 dz = torch.empty((x.size(0), N), dtype=torch.float32, device=x.device) if act != ACT_NONE else None
-                L.check(lib.pg_linear_bwd_w_ex(L.ptr(gy), gy.stride(0), L.ptr(x), x.stride(0), x.size(0), K, N,
-                                               L.ptr(gw), L.ptr(gb), L.ptr(y), y.stride(0) if y is not None else 0, act,
-                                               L.ptr(dz), L.ptr(part), 0 if defer else 1, L.stream_ptr()),
+                L.check(linear_bwd_call(lib, gy, x, K, N, gw, gb, part, 0 if defer else 1, y=y, act=act, dz=dz),
                         "pg_linear_bwd_w")
         if defer:
             rowlen = N * K + N
@@ -394,15 +441,8 @@ def _bwd_w(lib, g, x, K, N, y, act, want_bias, weight=None, bias=None):
     dz = torch.empty((x.size(0), N), dtype=torch.float32, device=x.device) if act != ACT_NONE else None
     defer = _DEFER is not None and weight is not None and want_bias and bias is not None
     with torch.cuda.device(x.device):
-        if isinstance(x, RowSource):     # the rows were never gathered: read them where they live
-            rs = x.struct()
-            L.check(lib.pg_linear_bwd_w_rows(L.ptr(g), g.stride(0), ctypes.byref(rs), x.size(0), K, N, L.ptr(gw), L.ptr(gb),
-                                             L.ptr(y), y.stride(0) if y is not None else 0, act, L.ptr(dz), L.ptr(part),
-                                             0 if defer else 1, L.stream_ptr()), "pg_linear_bwd_w_rows")
-        else:
-            L.check(lib.pg_linear_bwd_w_ex(L.ptr(g), g.stride(0), L.ptr(x), x.stride(0), x.size(0), K, N, L.ptr(gw),
-                                           L.ptr(gb), L.ptr(y), y.stride(0) if y is not None else 0, act, L.ptr(dz),
-                                           L.ptr(part), 0 if defer else 1, L.stream_ptr()), "pg_linear_bwd_w")
+        # (a RowSource: the rows were never gathered — read where they live)
+        L.check(linear_bwd_call(lib, g, x, K, N, gw, gb, part, 0 if defer else 1, y=y, act=act, dz=dz), "pg_linear_bwd_w")
     if defer:
         rowlen = N * K + N
         if not _DEFER.add(weight, part, part.numel() // rowlen, rowlen, 0):
@@ -412,11 +452,8 @@ def _bwd_w(lib, g, x, K, N, y, act, want_bias, weight=None, bias=None):
     return gw, gb, (dz if dz is not None else g)
 
 
-PAIR_BWD_W = os.environ.get("PG_PAIR_BWD_W", "1") != "0"      # both weight gradients of a two-operand NodeUpdate in one launch
-
-
 def _bwd_w_pair(lib, g, x1, x2, w1, w2, y, act, has_bias, bias_refs):
-    """_bwd_w for both operands of _DualLinear in ONE launch (pg_linear2_bwd_w): (dW1, db1, dW2, db2, dZ) — the same
+    """_bwd_w for both operands of _DualLinear in ONE launch (pg_linear_bwd_w with K2 > 0): (dW1, db1, dW2, db2, dZ) — the same
     partial rows, sums and deferral as two _bwd_w calls"""
     n, N = x1.size(0), w1.size(0)
     K1, K2 = w1.size(1), w2.size(1)
@@ -431,14 +468,9 @@ def _bwd_w_pair(lib, g, x1, x2, w1, w2, y, act, has_bias, bias_refs):
     d1 = _DEFER is not None and has_bias[0] and bias_refs[0] is not None
     d2 = _DEFER is not None and has_bias[1] and bias_refs[1] is not None
     defer = d1 and d2
-    rows = x1 if isinstance(x1, RowSource) else None
-    rs = rows.struct() if rows is not None else None
     with torch.cuda.device(dev):
-        L.check(lib.pg_linear2_bwd_w(L.ptr(g), g.stride(0), None if rows is not None else L.ptr(x1),
-                                     0 if rows is not None else x1.stride(0), ctypes.byref(rs) if rs is not None else None, K1,
-                                     L.ptr(x2), x2.stride(0), K2, n, N, L.ptr(gw1), L.ptr(gb1), L.ptr(gw2), L.ptr(gb2),
-                                     L.ptr(y), y.stride(0) if y is not None else 0, act, L.ptr(dz), L.ptr(part1), L.ptr(part2),
-                                     0 if defer else 1, L.stream_ptr()), "pg_linear2_bwd_w")
+        L.check(linear_bwd_call(lib, g, x1, K1, N, gw1, gb1, part1, 0 if defer else 1, y=y, act=act, dz=dz, x2=x2, K2=K2, dW2=gw2,
+                                db2=gb2, part2=part2), "pg_linear_bwd_w (two operands)")
     if defer:
         for (w, b, part, K) in ((w1, bias_refs[0], part1, K1), (w2, bias_refs[1], part2, K2)):
             rowlen = N * K + N
@@ -453,7 +485,7 @@ def _bwd_w_pair(lib, g, x1, x2, w1, w2, y, act, has_bias, bias_refs):
 
 class _DualLinear(torch.autograd.Function):
     """GraphSAGE's NodeUpdate dense step y = act(x1 @ W1.T + b1 + x2 @ W2.T + b2) (graphsage_nssc.py:24-29) in
-    one MFMA pass (pg_linear2_fwd) instead of two GEMMs, an add, and the activation / concat kernels; the
+    one MFMA pass (pg_linear_fwd with two operands) instead of two GEMMs, an add, and the activation / concat kernels; the
     backward derives dZ once and runs the weight-gradient kernel per operand."""
 
     @staticmethod
@@ -465,17 +497,9 @@ class _DualLinear(torch.autograd.Function):
         y = torch.empty((n, 2 * N if act == ACT_CONCAT else N), dtype=torch.float32, device=x1.device)
         rows = x1 if isinstance(x1, RowSource) else None
         with torch.cuda.device(x1.device):
-            if rows is not None:
-                # fc_self(h) of a layer whose features stayed in the cache / the staged miss block (graphsage_nssc.py:24):
-                # the gather is the dense kernel's own LDS fill
-                rs = rows.struct()
-                L.check(lib.pg_linear2_fwd_rows(ctypes.byref(rs), K1, L.ptr(w1), L.ptr(b1), L.ptr(x2), x2.stride(0),
-                                                L.ptr(w2), L.ptr(b2), K2, L.ptr(y), y.stride(0), n, N, act,
-                                                L.stream_ptr()), "pg_linear2_fwd_rows")
-            else:
-                L.check(lib.pg_linear2_fwd(L.ptr(x1), x1.stride(0), L.ptr(w1), L.ptr(b1), K1, L.ptr(x2), x2.stride(0),
-                                           L.ptr(w2), L.ptr(b2), K2, L.ptr(y), y.stride(0), n, N, act, L.stream_ptr()),
-                        "pg_linear2_fwd")
+            # (a RowSource: fc_self(h) of a layer whose features stayed in the cache / the staged miss block, graphsage_nssc.py:24
+            # — the gather is the dense kernel's own LDS fill)
+            L.check(linear_fwd_call(lib, x1, w1, b1, y, n, N, act, x2=x2, w2=w2, b2=b2), "pg_linear_fwd (two operands)")
         ctx.rows = rows
         ctx.save_for_backward(x1 if rows is None else None, w1, x2, w2, y if act != ACT_NONE else None)
         ctx.bias = (b1 is not None, b2 is not None)
@@ -494,7 +518,7 @@ class _DualLinear(torch.autograd.Function):
         need = ctx.needs_input_grad
         both_or_none = _DEFER is None or all(ctx.bias[i] and ctx.bias_refs[i] is not None for i in (0, 1)) \
             or not any(ctx.bias[i] and ctx.bias_refs[i] is not None for i in (0, 1))
-        if (PAIR_BWD_W and both_or_none and x2.stride(1) == 1 and gy.stride(1) == 1
+        if (both_or_none and x2.stride(1) == 1 and gy.stride(1) == 1
                 and (isinstance(x1, RowSource) or x1.stride(1) == 1)):
             gw1, gb1, gw2, gb2, dz = _bwd_w_pair(lib, gy, x1, x2, w1, w2, y, ctx.act, ctx.bias, ctx.bias_refs)
         else:
@@ -612,9 +636,28 @@ def fused_loss(loss_fcn):
     return loss_fcn
 
 
+def head_desc(indptr, src, h, weight, bias, labels, n_valid, grad_seed, ignore_index, reduce, drop_struct, logits, dagg, part, dW,
+              db_loss, flags, h_self=None, w_self=None, b_self=None, dself=None):
+    """pg_head_desc_t of one output-head launch (include/pagraph_hip.h); the tensors must stay alive until it is enqueued"""
+    d = L.PgHeadDesc()
+    d.indptr, d.src, d.h, d.W, d.bias = L.ptr(indptr).value, L.ptr(src).value, L.ptr(h).value, L.ptr(weight).value, L.ptr(bias).value
+    d.labels, d.n_valid_dev, d.grad_scale_dev = L.ptr(labels).value, L.ptr(n_valid).value, L.ptr(grad_seed).value
+    d.ignore_index, d.n_dst = int(ignore_index), labels.numel()
+    d.h_stride, d.K, d.C, d.reduce, d.flags = h.stride(0), weight.size(1), weight.size(0), _REDUCE[reduce], int(flags)
+    d.has_drop = 1 if drop_struct is not None else 0
+    if drop_struct is not None:
+        d.drop = drop_struct
+    d.logits, d.dagg, d.partials = L.ptr(logits).value, L.ptr(dagg).value, L.ptr(part).value
+    d.dW, d.db_loss = L.ptr(dW).value, L.ptr(db_loss).value
+    if h_self is not None:
+        d.h_self, d.W_self, d.bias_self, d.dself = L.ptr(h_self).value, L.ptr(w_self).value, L.ptr(b_self).value, L.ptr(dself).value
+        d.hs_stride, d.Ks = h_self.stride(0), w_self.size(1)
+    return d
+
+
 class _GCNHead(torch.autograd.Function):
     """last aggregation (+ dropout) -> output linear layer -> CrossEntropyLoss and all their gradients in one
-    pass (pg_gcn_head). The gradients are computed in the forward, already multiplied by `grad_seed` (a device
+    pass (pg_head). The gradients are computed in the forward, already multiplied by `grad_seed` (a device
     scalar: d objective / d loss); backward hands them out when it is called with that very tensor and
     rescales otherwise."""
 
@@ -633,13 +676,10 @@ class _GCNHead(torch.autograd.Function):
         d = drop.struct() if drop is not None and drop.threshold else None
         # deferral needs the registered gradient seed (the gradients leave the kernel already scaled) and a bias
         defer = _DEFER is not None and bias is not None and grad_seed is not None
+        hd = head_desc(indptr, src, h, weight, bias, labels, n_valid, grad_seed, ignore_index, reduce, d, logits, dagg, part, gw,
+                       gbl, (0 if defer else L.PG_HEAD_SUM_PARTIALS) | L.PG_HEAD_DAGG_PER_EDGE)
         with torch.cuda.device(h.device):
-            L.check(lib.pg_gcn_head_ex(L.ptr(indptr), L.ptr(src), L.ptr(h), h.stride(0), K, L.ptr(weight), L.ptr(bias), C,
-                                       L.ptr(labels), int(ignore_index), L.ptr(n_valid), L.ptr(grad_seed),
-                                       ctypes.byref(d) if d is not None else None, _REDUCE[reduce], n_dst, L.ptr(logits),
-                                       L.ptr(dagg), L.ptr(part), L.ptr(gw), L.ptr(gbl),
-                                       (0 if defer else L.PG_HEAD_SUM_PARTIALS) | L.PG_HEAD_DAGG_PER_EDGE, L.stream_ptr()),
-                    "pg_gcn_head")
+            L.check(lib.pg_head(ctypes.byref(hd), L.stream_ptr()), "pg_head")
         if defer:
             rowlen = lib.pg_gcn_head_row_len(K, C)      # C * K + C + 1 padded to whole 16-byte pieces
             chunks = part.numel() // rowlen
@@ -670,7 +710,6 @@ class _GCNHead(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             K = dagg.size(1)
             d = ctx.drop.struct() if ctx.drop is not None else None
-            dp = ctypes.byref(d) if d is not None else None
             with torch.cuda.device(dagg.device):
                 if ctx.use_t:
                     tptr, tdst, heavy = saved[6:9]
@@ -678,24 +717,21 @@ class _GCNHead(torch.autograd.Function):
                     y = saved[9] if ctx.dz_n else None
                     dz = torch.empty((ctx.n_src, ctx.dz_n), dtype=torch.float32, device=dagg.device) if ctx.dz_n else None
                     # dagg left the head per edge (PG_HEAD_DAGG_PER_EDGE): the mean's backward is a plain sum of it
-                    L.check(lib.pg_spmm_bwd_gather_dz(L.ptr(tptr), L.ptr(tdst), L.ptr(indptr), L.ptr(dagg), K, ctx.n_src, K,
-                                                      L.PG_REDUCE_SUM, L.ptr(gh), K, L.ptr(heavy),
-                                                      heavy.numel() - 1 if heavy is not None else 0, dp, L.ptr(y),
-                                                      y.stride(0) if y is not None else 0, L.ptr(dz), L.stream_ptr()),
-                            "pg_spmm_bwd_gather_dz")
+                    L.check(spmm_bwd_call(lib, dagg, gh, ctx.n_src, L.PG_REDUCE_SUM, indptr=indptr, transposed=(tptr, tdst, heavy),
+                                          drop_struct=d, act_out=y, dz=dz), "pg_spmm_bwd (gather form)")
                     if dz is not None:
                         _stash_dz(gh, dz)
                 else:
                     gh = torch.zeros((ctx.n_src, K), dtype=torch.float32, device=dagg.device)
-                    L.check(lib.pg_spmm_bwd_drop(L.ptr(indptr), L.ptr(src), L.ptr(dagg), K, dagg.size(0), K,
-                                                 L.PG_REDUCE_SUM, L.ptr(gh), K, dp, L.stream_ptr()), "pg_spmm_bwd_drop")
+                    L.check(spmm_bwd_call(lib, dagg, gh, ctx.n_src, L.PG_REDUCE_SUM, indptr=indptr, src=src, drop_struct=d),
+                            "pg_spmm_bwd (scatter form)")
         C = gw.size(0)
         return (None, None, gh, gw, gbl[:C] if ctx.has_bias else None) + (None,) * 11
 
 
 class _SageHead(torch.autograd.Function):
     """_GCNHead for GraphSAGE's output NodeUpdate z = fc_neigh(aggregate(dropout(h))) + fc_self(h_self)
-    (graphsage_nssc.py:24, pg_sage_head): loss and every gradient — dAgg (scattered back over the block in backward),
+    (graphsage_nssc.py:24, pg_head): loss and every gradient — dAgg (scattered back over the block in backward),
     dSelf, both weight matrices, both biases — in one pass, already multiplied by `grad_seed`."""
 
     @staticmethod
@@ -714,14 +750,11 @@ class _SageHead(torch.autograd.Function):
         part = torch.empty(lib.pg_gcn_head_scratch(n_dst, Kt, C), dtype=torch.float32, device=h.device)
         d = drop.struct() if drop is not None and drop.threshold else None
         defer = _DEFER is not None and b_n is not None and b_s is not None and grad_seed is not None
+        hd = head_desc(indptr, src, h, w_n, b_n, labels, n_valid, grad_seed, ignore_index, reduce, d, None, dagg, part, buf, gbl,
+                       (0 if defer else L.PG_HEAD_SUM_PARTIALS) | L.PG_HEAD_DAGG_PER_EDGE, h_self=h_self, w_self=w_s, b_self=b_s,
+                       dself=dself)
         with torch.cuda.device(h.device):
-            L.check(lib.pg_sage_head(L.ptr(indptr), L.ptr(src), L.ptr(h), h.stride(0), K, L.ptr(w_n), L.ptr(b_n),
-                                     L.ptr(h_self), h_self.stride(0), Ks, L.ptr(w_s), L.ptr(b_s), C, L.ptr(labels),
-                                     int(ignore_index), L.ptr(n_valid), L.ptr(grad_seed),
-                                     ctypes.byref(d) if d is not None else None, _REDUCE[reduce], n_dst, None, L.ptr(dagg),
-                                     L.ptr(dself), L.ptr(part), L.ptr(buf), L.ptr(gbl),
-                                     (0 if defer else L.PG_HEAD_SUM_PARTIALS) | L.PG_HEAD_DAGG_PER_EDGE, L.stream_ptr()),
-                    "pg_sage_head")
+            L.check(lib.pg_head(ctypes.byref(hd), L.stream_ptr()), "pg_head (GraphSAGE)")
         ok = [True] * 4
         if defer:
             rowlen = lib.pg_gcn_head_row_len(Kt, C)
@@ -755,19 +788,16 @@ class _SageHead(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             K = dagg.size(1)
             d = ctx.drop.struct() if ctx.drop is not None else None
-            dp = ctypes.byref(d) if d is not None else None
             with torch.cuda.device(dagg.device):
                 if ctx.use_t:
                     tptr, tdst, heavy = saved[8:11]
                     gh = torch.empty((ctx.n_src, K), dtype=torch.float32, device=dagg.device)
-                    L.check(lib.pg_spmm_bwd_gather(L.ptr(tptr), L.ptr(tdst), L.ptr(indptr), L.ptr(dagg), K, ctx.n_src, K,
-                                                   L.PG_REDUCE_SUM, L.ptr(gh), K, L.ptr(heavy),
-                                                   heavy.numel() - 1 if heavy is not None else 0, dp, L.stream_ptr()),
-                            "pg_spmm_bwd_gather")
+                    L.check(spmm_bwd_call(lib, dagg, gh, ctx.n_src, L.PG_REDUCE_SUM, indptr=indptr, transposed=(tptr, tdst, heavy),
+                                          drop_struct=d), "pg_spmm_bwd (gather form)")
                 else:
                     gh = torch.zeros((ctx.n_src, K), dtype=torch.float32, device=dagg.device)
-                    L.check(lib.pg_spmm_bwd_drop(L.ptr(indptr), L.ptr(src), L.ptr(dagg), K, dagg.size(0), K,
-                                                 L.PG_REDUCE_SUM, L.ptr(gh), K, dp, L.stream_ptr()), "pg_spmm_bwd_drop")
+                    L.check(spmm_bwd_call(lib, dagg, gh, ctx.n_src, L.PG_REDUCE_SUM, indptr=indptr, src=src, drop_struct=d),
+                            "pg_spmm_bwd (scatter form)")
         C = gwn.size(0)
         ok = ctx.deferred_ok
         gb = gbl[:C]
@@ -778,7 +808,7 @@ class _SageHead(torch.autograd.Function):
 
 
 def head_fits(n_agg_cols, n_self_cols, n_classes, weights, dropout_active):
-    """the STATIC part of pg_gcn_head / pg_sage_head's envelope, from the module alone: a model asks BEFORE it runs (and
+    """the STATIC part of pg_head / pg_head's envelope, from the module alone: a model asks BEFORE it runs (and
     consumes) the layers below the head — a head that declines afterwards leaves a NodeFlow whose frames were popped
     (`pa_gs.py --n-hidden 32` raised KeyError('features') in the fall-back forward)."""
     if n_agg_cols + n_self_cols > 64 or n_classes > 64:
@@ -791,7 +821,7 @@ def head_fits(n_agg_cols, n_self_cols, n_classes, weights, dropout_active):
 def sage_head(indptr, src, h, fc_neigh, h_self, fc_self, labels, n_valid, grad_seed=None, ignore_index=-100, reduce="mean",
               dropout=None, transpose=None):
     """loss of GraphSAGE's output layer over the last NodeFlow block: CrossEntropyLoss(fc_neigh(aggregate(dropout(h))) +
-    fc_self(h_self)) with every gradient produced in the same pass (pg_sage_head). None when the shapes are outside the
+    fc_self(h_self)) with every gradient produced in the same pass (pg_head). None when the shapes are outside the
     kernel's envelope (the caller then runs the unfused path)."""
     wn, bn, ws, bs = fc_neigh.weight, fc_neigh.bias, fc_self.weight, fc_self.bias
     ok = lambda t: torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1

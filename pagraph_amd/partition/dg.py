@@ -58,11 +58,13 @@ def dg_raw(partition_num, indptr, indices, vnum, train_nids, hops, threads=None,
         ix = indices if on_dev else torch.as_tensor(np.ascontiguousarray(indices, dtype=np.int32)).cuda()
         ip, ix = ip.to(torch.int64).contiguous(), ix.to(torch.int32).contiguous()
         st = L.PgDgGpuStats()
+        vnum2 = np.zeros((2, partition_num), dtype=np.int64)
         with torch.cuda.device(ip.device):
             rc = lib.pg_dg_partition_gpu(vnum, L.ptr(ip), L.ptr(ix), vp(train.ctypes.data), len(train), partition_num, hops,
                                          vp(belongs.ctypes.data), vp(r_mask.ctypes.data) if want_r_mask else None,
-                                         vp(p_vnum.ctypes.data), vp(r_vnum.ctypes.data), ctypes.byref(st), L.stream_ptr())
+                                         vp(vnum2.ctypes.data), ctypes.byref(st), L.stream_ptr())
         if rc == 0:
+            p_vnum, r_vnum = vnum2[0].copy(), vnum2[1].copy()
             LAST_GPU_STATS = {n: getattr(st, n) for n, _ in st._fields_}
             return belongs, r_mask, p_vnum, r_vnum
         if rc != -4:                       # anything but PG_ERR_UNSUPPORTED is an error, not a reason to fall back

@@ -566,10 +566,10 @@ class GraphCacheServer:
                 same = need is None or all(set(need[l]) == set(need[lay[0]]) for l in lay)
                 dd = self._dedup_for(slot, [offsets[l] - row_lo for l in lay] + [offsets[lay[-1] + 1] - row_lo], lay[0],
                                      nodeflow.num_layers, same)
-            L.check(self.lib.pg_gather_rows_dedup(L.ptr(nf_nids), R, L.ptr(self.slot_map), L.ptr(self.nid_map), fields, nf,
-                                                  miss_pos, miss_fullid, miss_count,
-                                                  L.ptr(self._slots), L.ptr(self._stats) if self.log else None, timer,
-                                                  ctypes.byref(dd) if dd is not None else None, sp),
+            ml = L.miss_list(miss_pos, miss_fullid, miss_count)
+            L.check(self.lib.pg_gather_rows(L.ptr(nf_nids), R, L.ptr(self.slot_map), L.ptr(self.nid_map), fields, nf,
+                                            ctypes.byref(ml), L.ptr(self._slots), L.ptr(self._stats) if self.log else None, timer,
+                                            ctypes.byref(dd) if dd is not None else None, sp),
                     "pg_gather_rows")
             if timer is not None:
                 self.profile.append([timer, R, None])
@@ -764,10 +764,10 @@ class GraphCacheServer:
             timer = L.vp()
             L.check(self.lib.pg_timer_create(ctypes.byref(timer)), "pg_timer_create")
         dd = self._plan_dedup(plan, slot) if self.miss_mode == "async" and not self.full_cached else None
-        L.check(self.lib.pg_gather_rows_dedup(ids, R, L.ptr(self.slot_map), L.ptr(self.nid_map), plan.fields, plan.n_fields,
-                                              miss_pos, miss_fullid, miss_count, L.ptr(self._slots),
-                                              L.ptr(self._stats) if self.log else None, timer,
-                                              ctypes.byref(dd) if dd is not None else None, sp), "pg_gather_rows")
+        ml = L.miss_list(miss_pos, miss_fullid, miss_count)
+        L.check(self.lib.pg_gather_rows(ids, R, L.ptr(self.slot_map), L.ptr(self.nid_map), plan.fields, plan.n_fields,
+                                        ctypes.byref(ml), L.ptr(self._slots), L.ptr(self._stats) if self.log else None, timer,
+                                        ctypes.byref(dd) if dd is not None else None, sp), "pg_gather_rows")
         if timer is not None:
             self.profile.append([timer, R, None])
         if self.full_cached:
@@ -805,9 +805,10 @@ class GraphCacheServer:
             L.check(self.lib.pg_slots_full(ids, R, L.ptr(self.slot_map), L.ptr(plan.slots),
                                            L.ptr(self._stats) if self.log else None, sp), "pg_slots_full")
         else:
-            L.check(self.lib.pg_split_rows_dedup(ids, R, L.ptr(self.slot_map), L.ptr(self.nid_map), miss_pos, miss_fullid,
-                                                 miss_count, L.ptr(plan.slots), L.ptr(self._stats) if self.log else None,
-                                                 ctypes.byref(dd) if dd is not None else None, sp),
+            ml = L.miss_list(miss_pos, miss_fullid, miss_count)
+            L.check(self.lib.pg_split_rows(ids, R, L.ptr(self.slot_map), L.ptr(self.nid_map), ctypes.byref(ml), L.ptr(plan.slots),
+                                           L.ptr(self._stats) if self.log else None,
+                                           ctypes.byref(dd) if dd is not None else None, sp),
                     "pg_split_rows")
         if plan.dense_rows > 0:
             timer = None

@@ -204,8 +204,9 @@ def test_gather_vs_oracle_random(dev, hiplib, oracle, n, F, ratio):
     scratch = torch.empty(n, dtype=torch.int32, device=dev) if n % 2 else None   # both code paths
     stats = torch.tensor([5, 7], dtype=torch.int64, device=dev)                    # accumulated, not reset
     fields, nf = L.make_fields([(cache, out, F, F, F)])
+    ml = L.miss_list(mpos, mfull, mcnt)
     L.check(hiplib.pg_gather_rows(L.ptr(d_ids), n, L.ptr(slot), L.ptr(torch.from_numpy(nid_map).to(dev)), fields, nf,
-                                  L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt), L.ptr(scratch), L.ptr(stats), None, sp))
+                                  ctypes.byref(ml), L.ptr(scratch), L.ptr(stats), None, None, sp))
     m = int(mcnt.item())
     assert m == st.miss_num
     assert stats.tolist() == [5 + n, 7 + m]
@@ -561,8 +562,9 @@ def test_full_size_gather_properties(dev, hiplib):
     mcnt = torch.zeros(1, dtype=torch.int32, device=dev)
     fields, nf = L.make_fields([(cache, out, F, F, F)])
     for _ in range(2):                                                   # idempotent
-        L.check(hiplib.pg_gather_rows(L.ptr(ids), R, L.ptr(slot), L.ptr(nid_map), fields, nf, L.ptr(mpos), L.ptr(mfull),
-                                      L.ptr(mcnt), None, None, None, sp))
+        ml = L.miss_list(mpos, mfull, mcnt)
+        L.check(hiplib.pg_gather_rows(L.ptr(ids), R, L.ptr(slot), L.ptr(nid_map), fields, nf, ctypes.byref(ml), None, None, None,
+                                      None, sp))
     m = int(mcnt.item())
     hit = slot[ids] >= 0
     assert m == int((~hit).sum())
@@ -1473,12 +1475,10 @@ def test_spmm_max_reducer_vs_oracle(dev, hiplib, oracle, n_dst, n_src, deg, dim,
     assert np.array_equal(grads[0], grads[1])                                    # gather form: fixed summation order
     for g in grads:
         assert np.allclose(g, want_g, rtol=0, atol=TOL * max(1.0, float(scale)))
-    # raw C-ABI: the sum / mean backward entry points refuse the max reducer (its backward needs h and out)
-    from pagraph_amd import _lib as L
+    # raw C-ABI: the max reducer's backward needs the forward's input and output
     gh = torch.zeros((n_src, dim), device=dev)
     tgo = torch.from_numpy(go).to(dev)
-    assert hiplib.pg_spmm_bwd(L.ptr(tip), L.ptr(tsr), L.ptr(tgo), dim, n_dst, dim, L.PG_REDUCE_MAX, L.ptr(gh), dim,
-                              L.stream_ptr()) == -1
+    assert ops.spmm_bwd_call(hiplib, tgo, gh, n_src, "max", indptr=tip, src=tsr) == -1
 
 
 @pytest.mark.gpu
@@ -1569,7 +1569,7 @@ def test_adam_step_matches_torch(dev, hiplib, wd):
                                                                   (1000, 700, 3, 32, 41, 0.25, 10, False), (33, 20, 1, 64, 7, 0.0, 0, False),
                                                                   (500, 2000, 4, 16, 64, 0.9, 0, False)])
 def test_gcn_output_head_vs_oracle(dev, hiplib, oracle, n_dst, n_src, deg, K, C, p, ignored, hubs):
-    """pg_gcn_head (aggregation + dropout + output linear layer + CrossEntropyLoss + all gradients in one pass)
+    """pg_head (aggregation + dropout + output linear layer + CrossEntropyLoss + all gradients in one pass)
     vs the float64 restatement and vs the unfused ops of this library; gather-form and scatter-form backward;
     bit-identical between two runs."""
     from pagraph_amd import ops
@@ -1636,16 +1636,17 @@ def test_gcn_output_head_vs_oracle(dev, hiplib, oracle, n_dst, n_src, deg, K, C,
         dagg = torch.empty((n_dst, K), device=dev)
         part = torch.empty(lib.pg_gcn_head_scratch(n_dst, K, C), device=dev)
         dstruct = spec.struct() if spec is not None else None
-        L.check(lib.pg_gcn_head_ex(L.ptr(tip), L.ptr(tsr), L.ptr(th), K, K, L.ptr(lin.weight), L.ptr(lin.bias), C, L.ptr(tl),
-                                   -100, L.ptr(n_valid), L.ptr(seed_t), ctypes.byref(dstruct) if dstruct is not None else None,
-                                   L.PG_REDUCE_MEAN, n_dst, None, L.ptr(dagg), L.ptr(part), L.ptr(buf), L.ptr(buf[C * K:]),
-                                   flags, L.stream_ptr()), "pg_gcn_head_ex")
+        hd = ops.head_desc(tip, tsr, th, lin.weight, lin.bias, tl, n_valid, seed_t, -100, "mean", dstruct, None, dagg, part, buf,
+                           buf[C * K:], flags)
+        L.check(lib.pg_head(ctypes.byref(hd), L.stream_ptr()), "pg_head")
         outs.append((dagg, buf))
     deg = torch.from_numpy(np.maximum(cnt, 1).astype(np.float32)).to(dev)[:, None]
     assert torch.equal(outs[1][0], outs[0][0] / deg) and torch.equal(outs[1][1], outs[0][1])
-    assert lib.pg_gcn_head_ex(L.ptr(tip), L.ptr(tsr), L.ptr(th), K, K, L.ptr(lin.weight), L.ptr(lin.bias), C, L.ptr(tl), -100,
-                              L.ptr(n_valid), L.ptr(seed_t), None, L.PG_REDUCE_MEAN, n_dst, None, L.ptr(dagg), L.ptr(part),
-                              L.ptr(buf), L.ptr(buf[C * K:]), 4, L.stream_ptr()) == -1      # PG_ERR_INVALID: unknown flag
+    hd = ops.head_desc(tip, tsr, th, lin.weight, lin.bias, tl, n_valid, seed_t, -100, "mean", None, None, dagg, part, buf, buf[C * K:], 4)
+    assert lib.pg_head(ctypes.byref(hd), L.stream_ptr()) == -1                                   # PG_ERR_INVALID: unknown flag
+    hd = ops.head_desc(tip, tsr, th, lin.weight, lin.bias, tl, n_valid, seed_t, -100, "mean", None, None, dagg, part, buf, buf[C * K:], 1)
+    hd.dself = L.ptr(dagg).value                                                                    # self operand fields without Ks
+    assert lib.pg_head(ctypes.byref(hd), L.stream_ptr()) == -1
     # and the unfused ops of the library agree
     lin.zero_grad()
     th2 = torch.from_numpy(h).to(dev).requires_grad_(True)
@@ -1771,7 +1772,7 @@ def test_gcn_forward_loss_matches_forward_plus_loss(dev, hiplib):
 @pytest.mark.parametrize("agg", ["mean", "gcn"])
 def test_sage_forward_loss_matches_forward_plus_loss(dev, hiplib, agg):
     """GraphSageSampling.forward_loss (the output NodeUpdate fc_neigh(neigh) + fc_self(h), its aggregation, the loss and all
-    their gradients in one kernel: pg_sage_head) == CrossEntropyLoss(model(nf)) in value and in every parameter gradient,
+    their gradients in one kernel: pg_head) == CrossEntropyLoss(model(nf)) in value and in every parameter gradient,
     with dropout (same step counter) and without; 'pool' and CPU labels decline (None)."""
     from pagraph_amd import ops
     from pagraph_amd.data import synthetic as syn
@@ -2000,8 +2001,9 @@ def _fused_gather_aggregate_case(dev, hiplib, oracle, ratio, p_drop, reduce, Fd)
     mfull = torch.empty(n_src, dtype=torch.int64, device=dev)
     mcnt = torch.zeros(1, dtype=torch.int32, device=dev)
     stats = torch.zeros(2, dtype=torch.int64, device=dev)
-    L.check(hiplib.pg_split_rows(L.ptr(d_ids), n_src, L.ptr(slot_map), L.ptr(d_nid_map), L.ptr(mpos),
-                                 L.ptr(mfull), L.ptr(mcnt), L.ptr(slots), L.ptr(stats), sp))
+    ml = L.miss_list(mpos, mfull, mcnt)
+    L.check(hiplib.pg_split_rows(L.ptr(d_ids), n_src, L.ptr(slot_map), L.ptr(d_nid_map), ctypes.byref(ml), L.ptr(slots),
+                                 L.ptr(stats), None, sp))
     m = int(mcnt.item())
     assert stats.tolist() == [n_src - 7, m] and m == int((~st.gpu_flag[ids[:-7]].astype(bool)).sum())
     sl = slots.cpu().numpy()
@@ -2029,7 +2031,8 @@ def _fused_gather_aggregate_case(dev, hiplib, oracle, ratio, p_drop, reduce, Fd)
     # ... and armed the successor stamp: the next dense launch of this thread writes word [1] of the same entry
     if Fd % 4 == 0:
         w8, y8 = torch.rand((8, Fd), device=dev), torch.empty((64, 8), device=dev)
-        L.check(hiplib.pg_linear_fwd(L.ptr(out), out.stride(0), L.ptr(w8), None, L.ptr(y8), 8, 64, Fd, 8, 0, sp))
+        from pagraph_amd import ops as _ops
+        L.check(_ops.linear_fwd_call(hiplib, out, w8, None, y8, 64, 8, 0, stream=sp))
         torch.cuda.synchronize()
         t_succ = prof.view(16, L.PG_PROF_WORDS)[step % 16, 1].item()
         assert t_succ >= t1 and t_succ - t0 < 100_000_000
@@ -2185,12 +2188,15 @@ def test_dense_step_from_row_source_is_bit_identical(dev, hiplib, n, K, N, K2, a
     rs = L.PgRowSource(sl.data_ptr(), cache.data_ptr(), staged.data_ptr(), cs, ss)
     yc = 2 * N if act == 2 else N
     Ya = torch.empty((n, yc), device=dev); Yb = torch.empty((n, yc), device=dev)
-    x2p, x2s = (L.ptr(X2), X2.stride(0)) if K2 else (None, 0)
-    L.check(hiplib.pg_linear2_fwd(L.ptr(Xd), cs, L.ptr(W), L.ptr(b), K, x2p, x2s, L.ptr(W2), L.ptr(b2), K2, L.ptr(Ya), yc,
-                                  n, N, act, None) if K2 else
-            hiplib.pg_linear_fwd(L.ptr(Xd), cs, L.ptr(W), L.ptr(b), L.ptr(Ya), yc, n, K, N, act, None), "dense fwd")
-    L.check(hiplib.pg_linear2_fwd_rows(ctypes.byref(rs), K, L.ptr(W), L.ptr(b), x2p, x2s, L.ptr(W2), L.ptr(b2), K2,
-                                       L.ptr(Yb), yc, n, N, act, None), "pg_linear2_fwd_rows")
+    # (through the descriptor of the C-ABI entry point: ops.linear_fwd_call / linear_bwd_call only fill pg_linear_*_desc_t)
+    from pagraph_amd import ops
+    from pagraph_amd.ops import RowSource
+    rows_src = RowSource(sl, cache, staged.data_ptr(), ss, K, keep=(staged,))
+    Xv = Xd[:, :K] if Xd.size(1) != K else Xd            # [n, K] view of the gathered copy (row stride cs)
+    X2v = X2[:, :K2] if K2 else None
+    L.check(ops.linear_fwd_call(hiplib, Xv, W, b, Ya, n, N, act, x2=X2v, w2=W2, b2=b2, stream=ctypes.c_void_p(0)), "dense fwd")
+    L.check(ops.linear_fwd_call(hiplib, rows_src, W, b, Yb, n, N, act, x2=X2v, w2=W2, b2=b2, stream=ctypes.c_void_p(0)),
+            "pg_linear_fwd (rows in place)")
     torch.cuda.synchronize()
     assert torch.equal(Ya, Yb)
     # weight gradient of the first operand
@@ -2201,12 +2207,8 @@ def test_dense_step_from_row_source_is_bit_identical(dev, hiplib, n, K, N, K2, a
         part = torch.zeros(scratch, device=dev)
         dW = torch.empty((N, K), device=dev); db = torch.empty(N, device=dev)
         dz = torch.empty((n, N), device=dev)
-        if rows:
-            L.check(hiplib.pg_linear_bwd_w_rows(L.ptr(G), yc, ctypes.byref(rs), n, K, N, L.ptr(dW), L.ptr(db), L.ptr(Ya), yc,
-                                                act, L.ptr(dz), L.ptr(part), 1, None), "pg_linear_bwd_w_rows")
-        else:
-            L.check(hiplib.pg_linear_bwd_w_ex(L.ptr(G), yc, L.ptr(Xd), cs, n, K, N, L.ptr(dW), L.ptr(db), L.ptr(Ya), yc,
-                                              act, L.ptr(dz), L.ptr(part), 1, None), "pg_linear_bwd_w_ex")
+        L.check(ops.linear_bwd_call(hiplib, G, rows_src if rows else Xv, K, N, dW, db, part, 1, y=Ya, act=act, dz=dz,
+                                    stream=ctypes.c_void_p(0)), "pg_linear_bwd_w")
         torch.cuda.synchronize()
         res.append((dW.clone(), db.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
@@ -2221,21 +2223,18 @@ def test_dense_step_from_row_source_is_bit_identical(dev, hiplib, n, K, N, K2, a
         p2 = torch.zeros(sc2, device=dev); dW2 = torch.empty((N, K2), device=dev); db2 = torch.empty(N, device=dev)
         dzr = torch.empty((n, N), device=dev)
         p1 = torch.zeros(scratch, device=dev); dW1 = torch.empty((N, K), device=dev); db1 = torch.empty(N, device=dev)
-        L.check(hiplib.pg_linear_bwd_w_ex(L.ptr(G), yc, L.ptr(Xd), cs, n, K, N, L.ptr(dW1), L.ptr(db1), L.ptr(Ya), yc, act,
-                                          L.ptr(dzr), L.ptr(p1), 1, None))
-        dzin, dzs = (dzr, N) if act else (G, yc)
-        L.check(hiplib.pg_linear_bwd_w_ex(L.ptr(dzin), dzs, L.ptr(X2), X2.stride(0), n, K2, N, L.ptr(dW2), L.ptr(db2), None, 0, 0,
-                                          None, L.ptr(p2), 1, None))
+        L.check(ops.linear_bwd_call(hiplib, G, Xv, K, N, dW1, db1, p1, 1, y=Ya, act=act, dz=dzr, stream=ctypes.c_void_p(0)))
+        dzin = dzr if act else G
+        L.check(ops.linear_bwd_call(hiplib, dzin, X2v, K2, N, dW2, db2, p2, 1, stream=ctypes.c_void_p(0)))
         for rows in (False, True):
             for summed in (1, 0):
                 q1 = torch.zeros(scratch, device=dev); q2 = torch.zeros(sc2, device=dev)
                 eW1 = torch.full((N, K), 7.0, device=dev); eb1 = torch.full((N,), 7.0, device=dev)
                 eW2 = torch.full((N, K2), 7.0, device=dev); eb2 = torch.full((N,), 7.0, device=dev)
                 dz2 = torch.empty((n, N), device=dev)
-                L.check(hiplib.pg_linear2_bwd_w(L.ptr(G), yc, None if rows else L.ptr(Xd), 0 if rows else cs,
-                                                ctypes.byref(rs) if rows else None, K, L.ptr(X2), X2.stride(0), K2, n, N, L.ptr(eW1),
-                                                L.ptr(eb1), L.ptr(eW2), L.ptr(eb2), L.ptr(Ya), yc, act, L.ptr(dz2), L.ptr(q1),
-                                                L.ptr(q2), summed, None), "pg_linear2_bwd_w")
+                L.check(ops.linear_bwd_call(hiplib, G, rows_src if rows else Xv, K, N, eW1, eb1, q1, summed, y=Ya, act=act, dz=dz2,
+                                            x2=X2v, K2=K2, dW2=eW2, db2=eb2, part2=q2, stream=ctypes.c_void_p(0)),
+                        "pg_linear_bwd_w (two operands)")
                 torch.cuda.synchronize()
                 assert torch.equal(q1, p1) and torch.equal(q2, p2), (rows, summed)
                 if summed:
@@ -2244,9 +2243,10 @@ def test_dense_step_from_row_source_is_bit_identical(dev, hiplib, n, K, N, K2, a
                     assert float(eW1.min()) == 7.0 and float(eb2.min()) == 7.0          # left to the optimiser's launch
                 if act:
                     assert torch.equal(dz2, dzr)
-        assert hiplib.pg_linear2_bwd_w(L.ptr(G), yc, L.ptr(Xd), cs, ctypes.byref(rs), K, L.ptr(X2), X2.stride(0), K2, n, N,
-                                       L.ptr(dW1), L.ptr(db1), L.ptr(dW2), L.ptr(db2), L.ptr(Ya), yc, act, L.ptr(dzr), L.ptr(p1),
-                                       L.ptr(p2), 1, None) == -1                          # both forms of the first operand
+        bad = L.PgLinearBwdDesc()
+        bad.dY, bad.X1, bad.X1rows = L.ptr(G).value, L.ptr(Xd).value, ctypes.addressof(rs)       # both forms of the first operand
+        bad.n, bad.K1, bad.N, bad.dy_stride, bad.x1_stride = n, K, N, yc, cs
+        assert hiplib.pg_linear_bwd_w(ctypes.byref(bad), None) == -1
 
 
 def ops_aggregate_identity(rows, dev):

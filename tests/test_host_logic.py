@@ -28,7 +28,7 @@ def test_version_and_errors(hiplib):
     assert hiplib.pg_strerror(0) == b"ok"
     assert hiplib.pg_strerror(-1) == b"invalid argument"
     # argument validation happens before any HIP call
-    assert hiplib.pg_gather_rows(None, -1, None, None, None, 0, None, None, None, None, None, None, None) == -1
+    assert hiplib.pg_gather_rows(None, -1, None, None, None, 0, None, None, None, None, None, None) == -1
     assert hiplib.pg_spmm_fwd(None, None, None, 4, 5, 8, 0, None, 8, None) == -1      # h_stride < dim
     assert hiplib.pg_sampler_create(0, None, None, 1, 1, 1, None) == -1
     assert hiplib.pg_rmat_edges(1, 0, 1, 1, 1, 0, 10, None, None, None) == -1
@@ -366,7 +366,9 @@ def test_ctypes_structs_match_the_header(tmp_path):
     pairs = {"pg_field_t": _lib.PgField, "pg_nodeflow_desc_t": _lib.PgNodeflowDesc, "pg_missq_field_t": _lib.PgMissqField,
              "pg_row_source_t": _lib.PgRowSource, "pg_dedup_t": _lib.PgDedup, "pg_dropout_t": _lib.PgDropout,
              "pg_batch_early_t": _lib.PgBatchEarly, "pg_batch_plan_t": _lib.PgBatchPlan,
-             "pg_adam_tensor_t": _lib.PgAdamTensor, "pg_adam_desc_t": _lib.PgAdamDesc}
+             "pg_adam_tensor_t": _lib.PgAdamTensor, "pg_adam_desc_t": _lib.PgAdamDesc, "pg_head_desc_t": _lib.PgHeadDesc, "pg_spmm_bwd_desc_t": _lib.PgSpmmBwdDesc,
+             "pg_linear_fwd_desc_t": _lib.PgLinearFwdDesc, "pg_linear_bwd_desc_t": _lib.PgLinearBwdDesc,
+             "pg_dg_gpu_stats_t": _lib.PgDgGpuStats}
     # C field names where the mirror uses another (padding) name are skipped; every other field is compared by name
     lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{os.path.join(ROOT, "include", "pagraph_hip.h")}"', "int main(void) {"]
     for cname, cls in pairs.items():

@@ -60,8 +60,8 @@ def main():
     mcnt = torch.zeros(1, dtype=torch.int32, device=dev)
     slots = torch.empty(n, dtype=torch.int32, device=dev)
     sp = L.stream_ptr()
-    L.check(lib.pg_split_rows(L.ptr(ids), n, L.ptr(slot_map), L.ptr(nid_map), L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt),
-                              L.ptr(slots), None, sp))
+    ml = L.miss_list(mpos, mfull, mcnt)
+    L.check(lib.pg_split_rows(L.ptr(ids), n, L.ptr(slot_map), L.ptr(nid_map), ctypes.byref(ml), L.ptr(slots), None, None, sp))
     r = L.bounds_report()
     out["id_beyond_partition"] = r
     assert r and r["kernel"].startswith("k_split") and r["value"] == V + 5 and r["bound"] == V and r["offenders"] == 1, r

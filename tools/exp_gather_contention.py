@@ -22,7 +22,7 @@ def gather_timed(n=30):
     ts = []
     for _ in range(n):
         t = L.vp(); L.check(lib.pg_timer_create(ctypes.byref(t)))
-        L.check(lib.pg_gather_rows(L.ptr(ids), R, L.ptr(slot), L.ptr(nid_map), fields, nf, L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt), L.ptr(slots), None, t, L.stream_ptr(sL)))
+        L.check(lib.pg_gather_rows(L.ptr(ids), R, L.ptr(slot), L.ptr(nid_map), fields, nf, ctypes.byref(L.miss_list(mpos, mfull, mcnt)), L.ptr(slots), None, t, None, L.stream_ptr(sL)))
         ts.append(t); time.sleep(0.0005)
     torch.cuda.synchronize()
     out_ms = []
@@ -51,7 +51,7 @@ def loop(n, with_scatter, with_busy, gap):
     if with_busy: busy("mix", 400)
     for _ in range(n):
         t = L.vp(); L.check(lib.pg_timer_create(ctypes.byref(t)))
-        L.check(lib.pg_gather_rows(L.ptr(ids), R, L.ptr(slot), L.ptr(nid_map), fields, nf, L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt), L.ptr(slots), None, t, L.stream_ptr(sL)))
+        L.check(lib.pg_gather_rows(L.ptr(ids), R, L.ptr(slot), L.ptr(nid_map), fields, nf, ctypes.byref(L.miss_list(mpos, mfull, mcnt)), L.ptr(slots), None, t, None, L.stream_ptr(sL)))
         if with_scatter:
             L.check(lib.pg_scatter_rows_from_host(L.ptr(tab), F, L.ptr(pos), L.ptr(fullh), M, L.ptr(cnt), F, L.ptr(out), F, L.stream_ptr(sL)))
         ts.append(t)

@@ -36,6 +36,6 @@ def timeit(fn, reps=50):
 for frac in (0.0, 0.25, 1.0):
     ids = ids_with_miss(frac)
     for name, mf in (("dev", mfull_d), ("pinned", mfull_p)):
-        t = timeit(lambda: L.check(lib.pg_gather_rows(L.ptr(ids), R, L.ptr(slot), L.ptr(nid_map), fields, nf, L.ptr(mpos), L.ptr(mf), L.ptr(mcnt), L.ptr(slots), None, None, sp)))
+        t = timeit(lambda: L.check(lib.pg_gather_rows(L.ptr(ids), R, L.ptr(slot), L.ptr(nid_map), fields, nf, ctypes.byref(L.miss_list(mpos, mf, mcnt)), L.ptr(slots), None, None, None, sp)))
         hits = R - int(mcnt.item())
         print(f"miss_frac={frac:.2f} missbuf={name:6s}: {t:6.1f} us/call (memset+kernel, back-to-back)  hits={hits}  alg GB/s={(hits*8*601+R*17)/t/1e3:.0f}")

@@ -28,7 +28,7 @@ lib = ops.L.load()
 go = torch.rand((n_dst, 64), device=dev)
 gh = torch.zeros((n_src, 64), device=dev)
 def run(src):
-    ops.L.check(lib.pg_spmm_bwd(ops.L.ptr(ipb), ops.L.ptr(src), ops.L.ptr(go), 64, n_dst, 64, 0, ops.L.ptr(gh), 64, ops.L.stream_ptr()), "bwd")
+    ops.L.check(ops.spmm_bwd_call(lib, go, gh, n_src, "mean", indptr=ipb, src=src), "bwd")
 print("real block      : %.1f us" % bench(lambda: run(srb)))
 uni = torch.randint(0, n_src, (srb.numel(),), device=dev, dtype=torch.int32)
 print("uniform sources : %.1f us" % bench(lambda: run(uni)))

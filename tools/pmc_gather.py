@@ -1,3 +1,4 @@
+import ctypes
 """PMC traffic measurement of k_gather (run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes).
 Launch order: 3x calibration copy (known bytes), 3x gather uniform ids, 3x gather degree-skewed ids, at R rows."""
 import sys, os
@@ -30,6 +31,6 @@ for _ in range(3):
 torch.cuda.synchronize()
 for ids in (ids_u, ids_s):
     for _ in range(3):
-        L.check(lib.pg_gather_rows(L.ptr(ids), R, L.ptr(slot), L.ptr(nid_map), fields, nf, L.ptr(mpos), L.ptr(mfull), L.ptr(mcnt), L.ptr(slots), None, None, sp))
+        L.check(lib.pg_gather_rows(L.ptr(ids), R, L.ptr(slot), L.ptr(nid_map), fields, nf, ctypes.byref(L.miss_list(mpos, mfull, mcnt)), L.ptr(slots), None, None, None, sp))
     torch.cuda.synchronize()
 print("rows", R, "copy bytes each way", R * F * 4, "gather algorithmic bytes", R * (8 * 601 + 17))
