@@ -133,7 +133,7 @@ typedef struct pg_miss_list {
  * itself). A repeat: slots_out / slot_scratch[row] stays -1, it is NOT in the miss list, (row, earlier row) is
  * appended to dup_pos / dup_src (device int32[n]) and *dup_count (device; reset by the call). stats count it as a
  * miss, like the reference. The consumer resolves dup_src to staged rows once the split has run
- * (pg_missq_submit_dedup does: dup_src[k] = -slots[dup_src[k]] - 3) and fills the rows with pg_scatter_rows_dups
+ * (pg_missq_submit does: dup_src[k] = -slots[dup_src[k]] - 3) and fills the rows with pg_scatter_rows_dups
  * after the primary rows have landed. Same frames, bit for bit; fewer rows over PCIe.                        */
 typedef struct pg_dedup {
   int32_t n_ranges;
@@ -237,24 +237,21 @@ int pg_missq_destroy(pg_missq_t* q);
 /* the slot's miss-list buffers, to be passed to pg_gather_rows as its pg_miss_list_t */
 int pg_missq_slot_buffers(pg_missq_t* q, int slot, int32_t** miss_pos_dev, int64_t** miss_fullid_pinned,
                           int32_t** miss_count_dev);
-/* call right after pg_gather_rows(...slot buffers...) on the same stream: publishes the miss list to the
- * worker. out_ptrs[f] / out_strides[f]: destination of field f's rows (NULL = field not wanted).   */
-int pg_missq_submit(pg_missq_t* q, int slot, float* const* out_ptrs, const int32_t* out_strides,
-                    pg_stream_t stream);
-/* the same with a per-field first scattered position: miss rows at positions >= pos_lo[f] go to
+/* call right after pg_gather_rows / pg_split_rows (...slot buffers...) on the same stream: publishes the miss list to the
+ * worker. out_ptrs[f] / out_strides[f]: destination of field f's rows (NULL with stride 0: field not wanted).
+ * pos_lo (may be NULL = 0): a per-field first scattered position — miss rows at positions >= pos_lo[f] go to
  * out_ptrs[f][(pos - pos_lo[f]) * stride]; rows below it are only copied to the slot's device staging block
- * (pg_missq_slot_staged), where pg_spmm_fwd_rows reads them. out_ptrs[f] == NULL with out_strides[f] == -1:
- * nothing of field f is scattered (copy only); NULL with stride 0: field not wanted.                  */
-int pg_missq_submit_range(pg_missq_t* q, int slot, float* const* out_ptrs, const int32_t* out_strides,
-                          const int32_t* pos_lo, pg_stream_t stream);
-/* pg_missq_submit_range for a launch that was split with a pg_dedup_t over the slot's dup buffers
- * (pg_missq_slot_dup_buffers): `slots_dev` = the slot array that split wrote (still intact at this point of
- * `stream`). The publish step turns every dup entry's "earlier row" into that row's staged index; after the primary
- * rows' scatter the worker fills the repeats on the device (pg_scatter_rows_dups) — they never cross PCIe. The publish
- * step also rewrites the repeats' OWN entries of `slots_dev` to their primary's value, -(staged row + 3), so that a
- * consumer reading rows in place through that array (pg_spmm_fwd_rows, pg_linear_fwd with X1rows) finds them.        */
-int pg_missq_submit_dedup(pg_missq_t* q, int slot, float* const* out_ptrs, const int32_t* out_strides,
-                          const int32_t* pos_lo, const int32_t* slots_dev, pg_stream_t stream);
+ * (pg_missq_slot_staged), where pg_spmm_fwd_rows reads them. out_ptrs[f] == NULL with out_strides[f] == -1: nothing of
+ * field f is scattered (copy only).
+ * slots_dev (may be NULL): for a launch that was split with a pg_dedup_t over the slot's dup buffers
+ * (pg_missq_slot_dup_buffers) = the slot array that split wrote (still intact at this point of `stream`). The publish step
+ * turns every dup entry's "earlier row" into that row's staged index; after the primary rows' scatter the worker fills the
+ * repeats on the device (pg_scatter_rows_dups) — they never cross PCIe. The publish step also rewrites the repeats' OWN
+ * entries of `slots_dev` to their primary's value, -(staged row + 3), so that a consumer reading rows in place through that
+ * array (pg_spmm_fwd_rows, pg_linear_fwd with X1rows) finds them.
+ * (Round 6: one entry point; pg_missq_submit_range / _submit_dedup were the same call with fewer arguments.) */
+int pg_missq_submit(pg_missq_t* q, int slot, float* const* out_ptrs, const int32_t* out_strides,
+                    const int32_t* pos_lo, const int32_t* slots_dev, pg_stream_t stream);
 int pg_missq_slot_dup_buffers(pg_missq_t* q, int slot, int32_t** dup_pos_dev, int32_t** dup_src_dev,
                               int32_t** dup_count_dev);
 /* device staging block of (slot, field): [max_rows, pg_missq_staged_stride] floats, row j = entry j of the slot's miss list once
@@ -285,15 +282,25 @@ int pg_missq_timed_out(pg_missq_t* q, int* out);
  * cost 15 ms). Round 3: it also waits (ROCr signals, no HIP call) until the copies handed straight to an SDMA
  * engine have landed — they sit in no HIP stream, so the synchronise that follows would not wait for them.   */
 int pg_missq_drain(pg_missq_t* q);
-/* counters since creation: out[0] jobs, out[1] rows moved, out[2] consumer waits ordered by event (copy already
- * enqueued), out[3] consumer waits by the spin kernel, out[4..7] mean per-job microseconds: submit->miss list
- * published, CPU row gather, copy enqueue, submit->job done                                             */
-int pg_missq_stats(pg_missq_t* q, double out[8]);
-/* which SDMA engine the worker's host->device copies go to (hsa_amd_sdma_engine_id_t bit; 0 = the HIP runtime's
- * own choice through hipMemcpyAsync) and the host->device GB/s every engine reached in the calibration at creation
- * (0 = engine not offered). The worker submits its copies to the fastest one directly (see pg_missq.hip).   */
+/* Everything the queue counts, in one call (round 6: five getters merged). Counters since creation; the us_* fields are
+ * mean per-job microseconds of the worker's phases (submit -> miss list published, CPU row gather, copy enqueue, submit ->
+ * job done); max_us_*: the LONGEST single occurrence of each since the last call with reset_max != 0 — a stall of the miss
+ * path shows in exactly one of them. rescued_chunks: 32-row chunks of the CPU gather the worker re-executed because the pool
+ * thread that had claimed them was overdue (lost its CPU with the chunk in hand); spared_jobs: jobs that gathered into a
+ * spare staging buffer because such a thread still held their slot's buffer — each a multi-millisecond stall that did not
+ * happen. sdma_engine_mask: the SDMA engine the worker's host->device copies go to (hsa_amd_sdma_engine_id_t bit; 0 = the HIP
+ * runtime's own choice through hipMemcpyAsync — the fallback path); engine_GBps: what every engine reached in the
+ * calibration at creation (0 = engine not offered).                                                          */
+typedef struct pg_missq_stats {
+  int64_t jobs, rows, waits_by_event, waits_by_spin_kernel, spared_jobs, rescued_chunks;
+  double us_submit_to_published, us_cpu_gather, us_enqueue, us_submit_to_done;
+  double max_us_wait_published, max_us_cpu_gather, max_us_enqueue, max_us_submit_to_done;
+  uint32_t sdma_engine_mask, _pad;
+  double engine_GBps[16];
+} pg_missq_stats_t;
+int pg_missq_stats(pg_missq_t* q, pg_missq_stats_t* out, int reset_max);
 /* cpu_share < 1 (pg_missq_set_cpu_share): the tail of the slot's latest miss list, [count * share / 256, count), read
- * from the pinned host table by the device on `stream` — call on the fetching stream right after pg_missq_submit*.
+ * from the pinned host table by the device on `stream` — call on the fetching stream right after pg_missq_submit.
  * The rows land in the slot's staged block in miss-list order (where an in-place consumer, or the consumer-side
  * scatter of a direct job, finds them); a field whose rows the WORKER scatters (no direct SDMA path) is scattered to
  * its frame here instead. No-op at share 1. The host table must be page-locked / registered.                       */
@@ -301,18 +308,6 @@ int pg_missq_device_tail(pg_missq_t* q, int slot, pg_stream_t stream);
 /* call on the fetching stream BEFORE the split of the slot's next submission when cpu_share < 1: the previous
  * submission's device tail (which runs on the queue's own stream) still reads the slot's miss list              */
 int pg_missq_order_after_tail(pg_missq_t* q, int slot, pg_stream_t stream);
-int pg_missq_copy_engine(pg_missq_t* q, uint32_t* engine_mask, double GBps[16]);
-/* the LONGEST single occurrence, in microseconds, of the worker's phases since the last call with reset != 0: [0] wait
- * for the published miss list (the device side: split + publish on the caller's stream), [1] CPU row gather, [2] enqueue
- * (copy submission + scatter launches), [3] submit -> done. A stall of the miss path shows in exactly one of them.     */
-int pg_missq_stats_max(pg_missq_t* q, double out[4], int reset);
-/* chunks (32 rows) of the CPU row gather that the worker re-executed because the pool thread that had claimed them was
- * overdue (lost its CPU with the chunk in hand): each one is a multi-millisecond stall of the step that did not happen */
-int pg_missq_rescued_chunks(pg_missq_t* q, int64_t* out);
-/* jobs that gathered into a spare staging buffer because the pool thread whose chunk was re-executed had not come back
- * yet and still held their slot's buffer (it may write into it when it does): each one is a stall of that length — 8-9 ms
- * on the shared boxes — that did not happen                                                                */
-int pg_missq_spared_jobs(pg_missq_t* q, int64_t* out);
 /* diagnosis (env PG_MISSQ_COPYLOG=1 at creation): the last `cap` host->device copies of the worker's wide field as
  * (bytes, milliseconds on the copy stream), oldest first; *n_out = entries written                        */
 int pg_missq_copy_log(pg_missq_t* q, int64_t* bytes, float* ms, int64_t cap, int64_t* n_out);

@@ -57,6 +57,14 @@ class PgRowSource(ctypes.Structure):
                 ("edge_slots", vp)]
 
 
+class PgMissqStats(ctypes.Structure):
+    _fields_ = [(n, c_i64) for n in ("jobs", "rows", "waits_by_event", "waits_by_spin_kernel", "spared_jobs", "rescued_chunks")] + \
+               [(n, ctypes.c_double) for n in ("us_submit_to_published", "us_cpu_gather", "us_enqueue", "us_submit_to_done",
+                                               "max_us_wait_published", "max_us_cpu_gather", "max_us_enqueue",
+                                               "max_us_submit_to_done")] + \
+               [("sdma_engine_mask", c_u32), ("_pad", c_u32), ("engine_GBps", ctypes.c_double * 16)]
+
+
 class PgMissList(ctypes.Structure):
     _fields_ = [("pos", vp), ("fullid", vp), ("count", vp)]
 
@@ -166,11 +174,8 @@ _SIGS = {
                                        ctypes.c_int, ctypes.POINTER(vp)]),
     "pg_missq_destroy": (ctypes.c_int, [vp]),
     "pg_missq_slot_buffers": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]),
-    "pg_missq_submit": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(c_i32), vp]),
-    "pg_missq_submit_range": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(c_i32),
-                                             ctypes.POINTER(c_i32), vp]),
-    "pg_missq_submit_dedup": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(c_i32),
-                                             ctypes.POINTER(c_i32), vp, vp]),
+    "pg_missq_submit": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), vp, vp]),
+    "pg_missq_stats": (ctypes.c_int, [vp, ctypes.POINTER(PgMissqStats), ctypes.c_int]),
     "pg_missq_slot_dup_buffers": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp),
                                                  ctypes.POINTER(vp)]),
     "pg_missq_staged_stride": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(c_i32)]),
@@ -181,13 +186,8 @@ _SIGS = {
     "pg_missq_wait_idle": (ctypes.c_int, [vp, ctypes.c_int]),
     "pg_missq_timed_out": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int)]),
     "pg_missq_drain": (ctypes.c_int, [vp]),
-    "pg_missq_stats": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double)]),
-    "pg_missq_copy_engine": (ctypes.c_int, [vp, ctypes.POINTER(c_u32), ctypes.POINTER(ctypes.c_double)]),
     "pg_missq_device_tail": (ctypes.c_int, [vp, ctypes.c_int, vp]),
     "pg_missq_order_after_tail": (ctypes.c_int, [vp, ctypes.c_int, vp]),
-    "pg_missq_spared_jobs": (ctypes.c_int, [vp, ctypes.POINTER(c_i64)]),
-    "pg_missq_stats_max": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
-    "pg_missq_rescued_chunks": (ctypes.c_int, [vp, ctypes.POINTER(c_i64)]),
     "pg_missq_copy_log": (ctypes.c_int, [vp, vp, vp, c_i64, ctypes.POINTER(c_i64)]),
     "pg_sampler_create": (ctypes.c_int, [c_i64, vp, vp, c_i32, c_i32, c_i32, ctypes.POINTER(vp)]),
     "pg_sampler_destroy": (ctypes.c_int, [vp]),

@@ -993,10 +993,6 @@ int pg_missq_slot_buffers(pg_missq_t* q, int slot, int32_t** miss_pos_dev, int64
   return PG_OK;
 }
 
-int pg_missq_submit(pg_missq_t* q, int slot, float* const* out_ptrs, const int32_t* out_strides, pg_stream_t stream) {
-  return pg_missq_submit_range(q, slot, out_ptrs, out_strides, nullptr, stream);
-}
-
 int pg_missq_slot_staged(pg_missq_t* q, int slot, int field, float** staged_dev) {
   if (!q || slot < 0 || slot >= q->n_slots || field < 0 || field >= q->n_fields || !staged_dev) return PG_ERR_INVALID;
   *staged_dev = q->slots[slot].staged_d[field];
@@ -1009,11 +1005,6 @@ int pg_missq_staged_stride(pg_missq_t* q, int field, int32_t* stride_out) {
   return PG_OK;
 }
 
-int pg_missq_submit_range(pg_missq_t* q, int slot, float* const* out_ptrs, const int32_t* out_strides,
-                          const int32_t* pos_lo, pg_stream_t stream) {
-  return pg_missq_submit_dedup(q, slot, out_ptrs, out_strides, pos_lo, nullptr, stream);
-}
-
 int pg_missq_slot_dup_buffers(pg_missq_t* q, int slot, int32_t** dup_pos_dev, int32_t** dup_src_dev,
                               int32_t** dup_count_dev) {
   if (!q || slot < 0 || slot >= q->n_slots) return PG_ERR_INVALID;
@@ -1024,8 +1015,8 @@ int pg_missq_slot_dup_buffers(pg_missq_t* q, int slot, int32_t** dup_pos_dev, in
   return PG_OK;
 }
 
-int pg_missq_submit_dedup(pg_missq_t* q, int slot, float* const* out_ptrs, const int32_t* out_strides,
-                          const int32_t* pos_lo, const int32_t* slots_dev, pg_stream_t stream) {
+int pg_missq_submit(pg_missq_t* q, int slot, float* const* out_ptrs, const int32_t* out_strides,
+                    const int32_t* pos_lo, const int32_t* slots_dev, pg_stream_t stream) {
   if (!q || slot < 0 || slot >= q->n_slots || !out_ptrs || !out_strides) return PG_ERR_INVALID;
   // the repeats are filled from the worker's staged rows: every primary row must go through the worker
   if (slots_dev && q->cpu_share.load(std::memory_order_relaxed) != 256) return PG_ERR_UNSUPPORTED;
@@ -1275,42 +1266,23 @@ int pg_missq_copy_log(pg_missq_t* q, int64_t* bytes, float* ms, int64_t cap, int
   return PG_OK;
 }
 
-int pg_missq_stats(pg_missq_t* q, double out[8]) {
+// ONE statistics call (round 6: pg_missq_stats, _stats_max, _spared_jobs, _rescued_chunks and _copy_engine merged)
+int pg_missq_stats(pg_missq_t* q, pg_missq_stats_t* out, int reset_max) {
   if (!q || !out) return PG_ERR_INVALID;
   std::lock_guard<std::mutex> l(q->m);
   const double n = q->n_jobs ? (double)q->n_jobs : 1.0;
-  out[0] = (double)q->n_jobs; out[1] = (double)q->n_rows;
-  out[2] = (double)q->n_wait_event; out[3] = (double)q->n_wait_spin;
-  out[4] = q->t_sub2flag / n; out[5] = q->t_gather / n; out[6] = q->t_enqueue / n; out[7] = q->t_total / n;
-  return PG_OK;
-}
-
-int pg_missq_stats_max(pg_missq_t* q, double out[4], int reset) {
-  if (!q || !out) return PG_ERR_INVALID;
-  std::lock_guard<std::mutex> l(q->m);
-  out[0] = q->mx_flag; out[1] = q->mx_gather; out[2] = q->mx_enqueue; out[3] = q->mx_total;
-  if (reset) q->mx_flag = q->mx_gather = q->mx_enqueue = q->mx_total = 0;
-  return PG_OK;
-}
-
-int pg_missq_spared_jobs(pg_missq_t* q, int64_t* out) {
-  if (!q || !out) return PG_ERR_INVALID;
-  std::lock_guard<std::mutex> l(q->m);
-  *out = q->n_spared;
-  return PG_OK;
-}
-
-int pg_missq_rescued_chunks(pg_missq_t* q, int64_t* out) {
-  if (!q || !out) return PG_ERR_INVALID;
-  *out = q->pool ? q->pool->rescued() : 0;
-  return PG_OK;
-}
-
-int pg_missq_copy_engine(pg_missq_t* q, uint32_t* engine_mask, double GBps[16]) {
-  if (!q || !engine_mask) return PG_ERR_INVALID;
-  *engine_mask = q->hsa_ok ? q->engine : 0u;
-  if (GBps)
-    for (int b = 0; b < 16; ++b) GBps[b] = q->engine_GBps[b];
+  out->jobs = (int64_t)q->n_jobs; out->rows = (int64_t)q->n_rows;
+  out->waits_by_event = (int64_t)q->n_wait_event; out->waits_by_spin_kernel = (int64_t)q->n_wait_spin;
+  out->spared_jobs = q->n_spared;
+  out->rescued_chunks = q->pool ? q->pool->rescued() : 0;
+  out->us_submit_to_published = q->t_sub2flag / n; out->us_cpu_gather = q->t_gather / n;
+  out->us_enqueue = q->t_enqueue / n; out->us_submit_to_done = q->t_total / n;
+  out->max_us_wait_published = q->mx_flag; out->max_us_cpu_gather = q->mx_gather;
+  out->max_us_enqueue = q->mx_enqueue; out->max_us_submit_to_done = q->mx_total;
+  if (reset_max) q->mx_flag = q->mx_gather = q->mx_enqueue = q->mx_total = 0;
+  out->sdma_engine_mask = q->hsa_ok ? q->engine : 0u;
+  out->_pad = 0;
+  for (int b = 0; b < 16; ++b) out->engine_GBps[b] = q->engine_GBps[b];
   return PG_OK;
 }
 

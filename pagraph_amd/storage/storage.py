@@ -581,7 +581,7 @@ class GraphCacheServer:
                     if name in out and name in names:
                         optrs[f] = out[name].data_ptr()
                         ostr[f] = out[name].stride(0)
-                L.check(self.lib.pg_missq_submit_dedup(self._missq, slot, optrs, ostr, None,
+                L.check(self.lib.pg_missq_submit(self._missq, slot, optrs, ostr, None,
                                                        L.ptr(self._slots) if dd is not None else None, sp), "pg_missq_submit")
                 self._missq_pending.add(slot)
                 if self._missq_share < 256:
@@ -773,7 +773,7 @@ class GraphCacheServer:
         if self.full_cached:
             return                       # every row was a hit (the general kernel ran only for the hit counters)
         if self.miss_mode == "async":
-            L.check(self.lib.pg_missq_submit_dedup(self._missq, slot, plan.optrs, plan.ostr, None,
+            L.check(self.lib.pg_missq_submit(self._missq, slot, plan.optrs, plan.ostr, None,
                                                    L.ptr(self._slots) if dd is not None else None, sp), "pg_missq_submit")
             self._missq_pending.add(slot)
             if self._missq_share < 256:
@@ -821,7 +821,7 @@ class GraphCacheServer:
             if timer is not None:   # 4th item: share of the split rows this copy launch covers
                 self.profile.append([timer, plan.dense_rows, None, plan.dense_rows / max(1, plan.rows)])
         if use_q:
-            L.check(self.lib.pg_missq_submit_dedup(self._missq, slot, plan.optrs, plan.ostr, plan.poslo,
+            L.check(self.lib.pg_missq_submit(self._missq, slot, plan.optrs, plan.ostr, plan.poslo,
                                                    L.ptr(plan.slots) if dd is not None else None, sp),
                     "pg_missq_submit_range")
             self._missq_pending.add(slot)
@@ -1007,29 +1007,22 @@ class GraphCacheServer:
         after the rows (event vs spin kernel), mean per-job microseconds of the worker's phases"""
         if self._missq is None:
             return None
-        v = (ctypes.c_double * 8)()
-        L.check(self.lib.pg_missq_stats(self._missq, v), "pg_missq_stats")
-        eng = L.c_u32(0)
-        rate = (ctypes.c_double * 16)()
-        L.check(self.lib.pg_missq_copy_engine(self._missq, ctypes.byref(eng), rate), "pg_missq_copy_engine")
-        resc = L.c_i64(0)
-        L.check(self.lib.pg_missq_rescued_chunks(self._missq, ctypes.byref(resc)), "pg_missq_rescued_chunks")
-        spared = L.c_i64(0)
-        L.check(self.lib.pg_missq_spared_jobs(self._missq, ctypes.byref(spared)), "pg_missq_spared_jobs")
-        return {"jobs": int(v[0]), "rows_per_job": v[1] / max(1.0, v[0]), "waits_by_event": int(v[2]),
-                "rescued_chunks": int(resc.value),       # overdue 32-row chunks of the CPU gather re-executed by the worker
-                "spared_jobs": int(spared.value),        # jobs that took a spare staging buffer instead of waiting for a straggler
-                "waits_by_spin_kernel": int(v[3]), "us_submit_to_published": v[4], "us_cpu_gather": v[5],
-                "us_enqueue": v[6], "us_submit_to_done": v[7],
-                "sdma_engine_mask": int(eng.value),      # 0 = hipMemcpyAsync (the runtime picks the engine)
+        st = L.PgMissqStats()
+        L.check(self.lib.pg_missq_stats(self._missq, ctypes.byref(st), 0), "pg_missq_stats")
+        return {"jobs": int(st.jobs), "rows_per_job": st.rows / max(1.0, st.jobs), "waits_by_event": int(st.waits_by_event),
+                "rescued_chunks": int(st.rescued_chunks),  # overdue 32-row chunks of the CPU gather re-executed by the worker
+                "spared_jobs": int(st.spared_jobs),        # jobs that took a spare staging buffer instead of waiting for a straggler
+                "waits_by_spin_kernel": int(st.waits_by_spin_kernel), "us_submit_to_published": st.us_submit_to_published,
+                "us_cpu_gather": st.us_cpu_gather, "us_enqueue": st.us_enqueue, "us_submit_to_done": st.us_submit_to_done,
+                "sdma_engine_mask": int(st.sdma_engine_mask),      # 0 = hipMemcpyAsync (the runtime picks the engine)
                 # which way the worker's copies go (csrc/pg_missq.hip): straight to one calibrated SDMA engine with the consumer
                 # watching the completion signal (the default); the same engine but ordered through the copy stream
                 # (PG_MISSQ_NO_DIRECT=1); or hipMemcpyAsync on the copy stream when ROCr's engine interface is not usable
                 # (the probe failed, or PG_MISSQ_HSA_COPY=0) — the tested fallback
-                "copy_path": ("hipMemcpyAsync on the copy stream (fallback)" if not eng.value else
+                "copy_path": ("hipMemcpyAsync on the copy stream (fallback)" if not st.sdma_engine_mask else
                               ("ROCr SDMA engine, ordered through the copy stream" if os.environ.get("PG_MISSQ_NO_DIRECT") == "1"
                                else "ROCr SDMA engine, direct (consumer watches the completion signal)")),
-                "sdma_engine_h2d_GBps": {b: round(rate[b], 1) for b in range(16) if rate[b] > 0}}
+                "sdma_engine_h2d_GBps": {b: round(st.engine_GBps[b], 1) for b in range(16) if st.engine_GBps[b] > 0}}
 
     def miss_queue_longest(self, reset=False):
         """the longest single occurrence (us) of each of the worker's phases since the last reset — a stall of the miss
@@ -1037,10 +1030,10 @@ class GraphCacheServer:
         submission, or the whole submit -> done span"""
         if self._missq is None:
             return None
-        v = (ctypes.c_double * 4)()
-        L.check(self.lib.pg_missq_stats_max(self._missq, v, 1 if reset else 0), "pg_missq_stats_max")
-        return {"wait_published": round(v[0], 1), "cpu_gather": round(v[1], 1), "enqueue": round(v[2], 1),
-                "submit_to_done": round(v[3], 1)}
+        st = L.PgMissqStats()
+        L.check(self.lib.pg_missq_stats(self._missq, ctypes.byref(st), 1 if reset else 0), "pg_missq_stats")
+        return {"wait_published": round(st.max_us_wait_published, 1), "cpu_gather": round(st.max_us_cpu_gather, 1),
+                "enqueue": round(st.max_us_enqueue, 1), "submit_to_done": round(st.max_us_submit_to_done, 1)}
 
     def miss_copy_log(self, cap=1 << 16):
         """(bytes, ms) of the worker's last host->device copies (needs PG_MISSQ_COPYLOG=1 in the environment)"""

@@ -366,7 +366,8 @@ def test_ctypes_structs_match_the_header(tmp_path):
     pairs = {"pg_field_t": _lib.PgField, "pg_nodeflow_desc_t": _lib.PgNodeflowDesc, "pg_missq_field_t": _lib.PgMissqField,
              "pg_row_source_t": _lib.PgRowSource, "pg_dedup_t": _lib.PgDedup, "pg_dropout_t": _lib.PgDropout,
              "pg_batch_early_t": _lib.PgBatchEarly, "pg_batch_plan_t": _lib.PgBatchPlan,
-             "pg_adam_tensor_t": _lib.PgAdamTensor, "pg_adam_desc_t": _lib.PgAdamDesc, "pg_head_desc_t": _lib.PgHeadDesc, "pg_spmm_bwd_desc_t": _lib.PgSpmmBwdDesc,
+             "pg_adam_tensor_t": _lib.PgAdamTensor, "pg_adam_desc_t": _lib.PgAdamDesc, "pg_head_desc_t": _lib.PgHeadDesc, "pg_missq_stats_t": _lib.PgMissqStats, "pg_miss_list_t": _lib.PgMissList,
+             "pg_spmm_bwd_desc_t": _lib.PgSpmmBwdDesc,
              "pg_linear_fwd_desc_t": _lib.PgLinearFwdDesc, "pg_linear_bwd_desc_t": _lib.PgLinearBwdDesc,
              "pg_dg_gpu_stats_t": _lib.PgDgGpuStats}
     # C field names where the mirror uses another (padding) name are skipped; every other field is compared by name
