@@ -229,10 +229,10 @@ def make_host_table(V, Fdim, rank, local_rank, world, dev, tag):
         tab = torch.from_file(path, shared=True, size=V * Fdim, dtype=torch.float32).view(V, Fdim)
     if not shared:
         private_gb = V * Fdim * 4 * world / 2 ** 30
-        budget_gb = float(os.environ.get("PG_BENCH_PRIVATE_TABLE_GB", 64))
+        budget_gb = 64.0
         if private_gb > budget_gb:
             raise SystemExit(f"bench.py: no shared mapping for the host feature table and {world} private copies would take "
-                             f"{private_gb:.0f} GB (> PG_BENCH_PRIVATE_TABLE_GB = {budget_gb:.0f}): refusing")
+                             f"{private_gb:.0f} GB (> {budget_gb:.0f}): refusing")
         log(f"[bench] rank {rank}: every rank keeps a private copy of the table ({private_gb:.1f} GB in total)")
         tab = torch.empty((V, Fdim), dtype=torch.float32)
         syn.fill_random_features(tab, device=dev)
@@ -728,17 +728,12 @@ def run():
     emul_P = int(args.as_rank_of) if world == 1 else 0
     dist_step = bool(world == 1 and (emul_P > 1 or args.dist_step))
     step_world = world if world > 1 else (max(2, emul_P) if dist_step else 1)     # what the trainer is told
-    init_pg_only = int(os.environ.get("PG_BENCH_INIT_PG", 0)) if world == 1 and not dist_step else 0
-    if dist_step or init_pg_only:
+    if dist_step:
         import socket
         s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_), RANK="0", WORLD_SIZE="1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=0, world_size=1)      # REAL RCCL, of one rank: all a one-GPU box can host
-        if init_pg_only >= 2:      # diagnosis (tools/exp_rccl_presence.sh): the communicator exists, the trainer does not use it
-            t_ = torch.ones(8, device=dev)
-            dist.all_reduce(t_)
-            torch.cuda.synchronize()
 
     from pagraph_amd import _lib as L
     from pagraph_amd import parallel
@@ -802,7 +797,7 @@ def run():
         # result; the record says so)
         import tempfile
         dg_file = os.path.join(tempfile.gettempdir(), f"pagraph_bench_dg_{V}_{E}_P{emul_P}_h{args.dg_hops}.npz")
-        dg_cached = os.path.exists(dg_file) and not os.environ.get("PG_BENCH_NO_DG_CACHE")
+        dg_cached = os.path.exists(dg_file)
         dg_stats = None
         if dg_cached:
             z_ = np.load(dg_file)
@@ -918,8 +913,6 @@ def run():
     else:
         model = GraphSageSampling(Fdim, hidden, C, n_layers, F.relu, 0.2, 'mean', False)
     model = model.to(dev)
-    if os.environ.get("PG_BENCH_DROP_OFFSET"):               # diagnosis: another stream of dropout masks (same seed, later steps)
-        model._drop_step += int(os.environ["PG_BENCH_DROP_OFFSET"])
     loss_fcn = torch.nn.CrossEntropyLoss()
     use_graph = not args.no_graph
     if use_graph:
@@ -994,7 +987,7 @@ def run():
     # safety net: a device-side wait for miss rows that timed out during set-up means the runtime put the consuming
     # stream and the copy stream on one hardware queue (seen when every stream has the same priority). Switch to
     # host-side waits (no spin kernel), rebuild the queue and repeat the set-up instead of aborting the run.
-    stuck = 1.0 if (use_graph and (cacher.misses_timed_out() or os.environ.get("PG_BENCH_TEST_HOST_WAIT_SWITCH"))) else 0.0
+    stuck = 1.0 if (use_graph and cacher.misses_timed_out()) else 0.0
     if world > 1:
         stuck = parallel.max_over_ranks(stuck, device=dev)
     if stuck:
@@ -1136,11 +1129,10 @@ def run():
         wev = [torch.cuda.Event(enable_timing=True)]
         host_t = []
         loss_ev = {}
-        loss_trace = os.environ.get("PG_BENCH_LOSS_TRACE")       # diagnosis: every step's loss (one clone launch per step)
         p_before = torch.cat([p_.detach().reshape(-1) for p_ in model.parameters()]).clone()
         def on_step(done_, loss_):
             host_t.append(time.perf_counter())
-            if done_ == 1 or done_ == K_ or loss_trace:   # evidence that the timed steps trained: a private copy of two loss values
+            if done_ == 1 or done_ == K_:   # evidence that the timed steps trained: a private copy of two loss values
                 loss_ev[done_] = loss_.detach().clone()          # (the slot's static loss tensor is overwritten 8 steps later)
             if done_ % win == 0 or done_ == K_:
                 e_ = torch.cuda.Event(enable_timing=True)
@@ -1159,8 +1151,7 @@ def run():
         t0 = time.time()
         done = trainer.run_steps(it, K_)
         t_issued = time.time() - t0          # launch thread done; ~= elapsed when the host is the bottleneck
-        if not os.environ.get("PG_BENCH_NO_DRAIN"):
-            cacher.drain_misses()            # worker's outstanding copies enqueued (host-side wait, no HIP call) ...
+        cacher.drain_misses()                # worker's outstanding copies enqueued (host-side wait, no HIP call) ...
         torch.cuda.synchronize()             # ... then the device
         if world > 1:
             dist.barrier()
@@ -1238,12 +1229,6 @@ def run():
         drop_step1 = int(model._drop_step.item()) if hasattr(model, "_drop_step") else 0
         early1 = getattr(trainer, "early_ordinal", 0)
         p_after = torch.cat([p_.detach().reshape(-1) for p_ in model.parameters()])
-        if loss_trace:
-            ls_ = np.array([float(loss_ev[i_].item()) for i_ in sorted(loss_ev)])
-            log(f"[bench] loss trace ({tag}, {len(ls_)} steps): means of 10 equal parts " +
-                " ".join(f"{c_.mean():.3f}" for c_ in np.array_split(ls_, 10)) + f"; max {ls_.max():.3f} nan {int(np.isnan(ls_).sum())}"
-                f"; first > 6: {np.flatnonzero(ls_ > 6)[:8].tolist()} early_ordinal {getattr(trainer, 'early_ordinal', None)}"
-                f" around: {[round(float(x_), 2) for x_ in ls_[max(0, int(np.flatnonzero(ls_ > 6)[0]) - 6):int(np.flatnonzero(ls_ > 6)[0]) + 6]] if (ls_ > 6).any() else None}")
         trained = {"loss_first": float(loss_ev[1].item()) if 1 in loss_ev else None,
                    "loss_last": float(loss_ev[K_].item()) if K_ in loss_ev else None,
                    "params_finite": bool(torch.isfinite(p_after).all().item()),
@@ -1492,7 +1477,7 @@ def run():
             "_wants_configs": bool(default_workload and world == 1 and not dist_step and not args.no_configs and use_graph
                                    and not args.fetch_all),
         }
-    if world > 1 or dist_step or init_pg_only:
+    if world > 1 or dist_step:
         dist.barrier()
         dist.destroy_process_group()
     return out

@@ -359,8 +359,8 @@ def record_streams(root, streams, _seen=None, _depth=0):
     events have completed — whatever drops the owner (refcount, cyclic GC, interpreter exit) and whether or not a
     finalizer ran. Called ONCE per buffer, where the buffer is created (the cost is paid at free time only).
     Walks tensors, lists / tuples / dicts / sets, nn.Modules (parameters + buffers), optimizers (state) and plain
-    pagraph_amd objects; PG_NO_RECORD_STREAM=1 switches it off (diagnosis)."""
-    if os.environ.get("PG_NO_RECORD_STREAM") or root is None:
+    pagraph_amd objects."""
+    if root is None:
         return
     streams = [s for s in streams if s is not None]
     if not streams:

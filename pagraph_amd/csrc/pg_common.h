@@ -259,16 +259,9 @@ __device__ __forceinline__ void store_row_piece(float4* p, const float4& v, int 
 }
 
 
-// PG_FWD_ROWS_STORE = plain | nt | wt: how k_spmm_fwd_rows_w writes `out` (see store_row_piece). Default wt (round 4):
-// dispatch End - Start in the training loop 20.5 (plain) / 19.2 (wt) / 21.5 (nt) us, alone on cold rows 16.1 / 15.2 / 15.0,
-// profiles/r04/fused_store_modes.txt.
-inline int fwd_rows_store_mode() {
-  const char* e = getenv("PG_FWD_ROWS_STORE");
-  if (!e) return PG_STORE_WT;
-  if (!strcmp(e, "wt")) return PG_STORE_WT;
-  if (!strcmp(e, "nt")) return PG_STORE_NT;
-  return PG_STORE_PLAIN;
-}
+// how k_spmm_fwd_rows_w writes `out` (see store_row_piece): write-through (round 4: dispatch End - Start in the training loop
+// 20.5 (plain) / 19.2 (wt) / 21.5 (nt) us, alone on cold rows 16.1 / 15.2 / 15.0, profiles/r04/fused_store_modes.txt)
+inline int fwd_rows_store_mode() { return PG_STORE_WT; }
 
 
 // uniform integer in [0, n) from a 64-bit draw: floor(r * n / 2^64)

@@ -545,13 +545,11 @@ static int linear_fwd(const float* X, int32_t x_stride, const float* W, const fl
   if (K2 == 0) X2 = W2 = bias2 = nullptr;
   const dim3 grid((unsigned)ceil_div<int64_t>(n, kTile), (unsigned)ceil_div<int>(N, kTile));
   // waves per tile: enough that a wave's share of K is a round or two of loads (each round = 4 octets in flight)
-  static const int nw_force = getenv("PG_LINEAR_WAVES") ? atoi(getenv("PG_LINEAR_WAVES")) : 0;
   const int octets = (K + 7) / 8 + (K2 + 7) / 8;
   // measured with both slabs in LDS: 8 waves win from K = 600 (13.7 us vs 14.2 / 15.3) to the two-operand K = 1200
   // (21.1 vs 23.5 / 24.7 at 12 000 rows; 13.2 vs 12.6 with 16 waves at 6 000)
   int nw = octets >= 32 ? 8 : 4;
-  if (nw_force == 4 || nw_force == 8 || nw_force == 16) nw = nw_force;
-  static const bool no_lds = getenv("PG_LINEAR_NO_LDS") != nullptr;
+  constexpr bool no_lds = false;              // (the straight-from-global variant of round 2: 18.1 us against 13.7)
   const ProfSucc succ = take_prof_succ();      // a profiled predecessor's "my successor started" stamp (pg_common.h)
 #define PG_LIN_FWD(WV, NW)                                                                                          \
   do {                                                                                                              \

@@ -243,7 +243,7 @@ extern "C" int pg_dg_partition_mt(int64_t V, const int64_t* indptr, const int32_
     std::vector<int32_t> order(P);
     const double avg = (double)V * 0.65 / (double)P;
     const int64_t W = (int64_t)sh.slots.size();
-    const bool dbg = getenv("PG_DG_DEBUG") != nullptr;
+    constexpr bool dbg = false;       // (committer / builder cycle counts: flip for a diagnosis build)
     uint64_t c_wait = 0, c_work = 0, n_bits = 0, n_wordsum = 0;
     for (int64_t i = 0; i < n_train; ++i) {
       Dg2Slot& sl = sh.slots[(size_t)(i % W)];

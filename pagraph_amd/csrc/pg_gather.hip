@@ -758,15 +758,9 @@ int pg::scatter_host_tail(const float* table, int64_t table_stride, const int32_
   // (round 3, measured inside the training loop with every miss row through this kernel — profiles/r03/zero_copy_grid.txt:
   // two-rows-per-wave kernel 8 / 16 / 24 / 48 / 96 / 192 blocks -> 0.372 / 0.231 / 0.217 / 0.250 / 0.279 / 0.288 ms/step;
   // wide kernel 4 / 8 / 12 / 16 / 24 / 48 -> 0.484 / 0.289 / 0.221 / 0.208 / 0.222 / 0.252)
-  static const int kEnvBlocks = [] {
-    const char* e = getenv("PG_SCATTER_HOST_BLOCKS");
-    return e ? atoi(e) : 0;
-  }();
-  const int kHostBlocks = kEnvBlocks > 0 ? kEnvBlocks : 24;
-  const int kWideBlocks = kEnvBlocks > 0 ? kEnvBlocks : 16;
+  constexpr int kHostBlocks = 24, kWideBlocks = 16;
   const int grid = grid_1d(n_max, 8, kHostBlocks);
-  static const bool narrow = getenv("PG_SCATTER_HOST_NARROW") != nullptr;     // A/B: the two-rows-per-wave kernel
-  if (!narrow && dim % 4 == 0 && dim >= 256 && dim <= 1024 && out_stride % 4 == 0 && table_stride % 4 == 0 &&
+  if (dim % 4 == 0 && dim >= 256 && dim <= 1024 && out_stride % 4 == 0 && table_stride % 4 == 0 &&
       aligned(table, 16) && aligned(out, 16)) {
     const int gw = grid_1d(n_max, 4 * kRowsWide, kWideBlocks);
 #define PG_WIDE(P)                                                                                                   \

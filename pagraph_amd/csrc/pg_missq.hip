@@ -214,21 +214,16 @@ class Pool {
     int64_t state_cap = 0;
   };
   explicit Pool(int n) : n_(n < 1 ? 1 : n) {
-    const char* e = getenv("PG_MISSQ_SPIN_US");
-    spin_us_ = e ? atoi(e) : 100;
-    const char* o = getenv("PG_MISSQ_OVERDUE_US");
-    overdue_us_ = o ? atoi(o) : 40;
+    spin_us_ = 100;
+    overdue_us_ = 40;
     // test hook: PG_MISSQ_TEST_STALL=<every>,<us> — a pool thread (never the caller) that claims every <every>-th
     // chunk sleeps <us> microseconds before it executes it, like a thread that lost its CPU with a chunk in hand
     if (const char* t = getenv("PG_MISSQ_TEST_STALL")) {
       stall_every_ = atoi(t);
       if (const char* c = strchr(t, ',')) stall_us_ = atoi(c + 1);
     }
-    // PG_MISSQ_PIN=<stride>: gather thread i is pinned to the (i * stride)-th CPU of the process's affinity set (experiment,
-    // round 5: does a thread that cannot migrate deliver more evenly on a shared box? profiles/r05/host_gather_sweep.txt)
-    const char* pin = getenv("PG_MISSQ_PIN");
-    const int stride = pin ? atoi(pin) : 0;
-    for (int i = 1; i < n_; ++i) th_.emplace_back([this, i, stride] {
+    const int stride = 0;      // (round 5 tried pinning gather thread i to a CPU: no steadier on a shared box — profiles/r05/host_gather_sweep.txt)
+    for (int i = 1; i < n_; ++i) th_.emplace_back([this, i] {
       if (stride > 0) {
         cpu_set_t all, one;
         CPU_ZERO(&all);
@@ -440,7 +435,7 @@ struct pg_missq {
   bool stop = false;
   int error = PG_OK;
   int64_t n_wait_event = 0, n_wait_spin = 0;   // how pg_missq_wait_device ordered the consumer (under m)
-  bool wait_value = getenv("PG_MISSQ_WAITVALUE") != nullptr;
+  bool wait_value = false;       // (round 3's hipStreamWaitValue variant of the wait: kept in the code, never selected)
   std::atomic<int> cpu_share{256};   // of 256: the leading share of every miss list that the CPU path moves
   // PG_MISSQ_DEBUG=1: accumulated worker phase times (us) printed at destroy
   double t_sync = 0, t_flag = 0, t_gather = 0, t_enqueue = 0, t_copy = 0, t_sub2flag = 0, t_sub2pop = 0;
@@ -506,9 +501,8 @@ struct CalibLock {
     }
     (void)fchmod(fd, 0600);
     // bounded: a stopped or hung rank that holds the lock must not block every other rank's queue creation for ever. A
-    // calibration takes ~10 ms per engine; after PG_MISSQ_CALIB_LOCK_MS (default 5000) this rank goes ahead without it.
-    const char* ms_e = getenv("PG_MISSQ_CALIB_LOCK_MS");
-    const long budget_ms = ms_e ? atol(ms_e) : 5000;
+    // calibration takes ~10 ms per engine; after 5 s this rank goes ahead without it.
+    const long budget_ms = 5000;
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
       if (flock(fd, LOCK_EX | LOCK_NB) == 0) return;
@@ -565,11 +559,9 @@ static void hsa_copy_init(pg_missq* q) {
   for (int f = 1; f < q->n_fields; ++f)
     if (q->fields[f].dim > q->fields[fw].dim) fw = f;
   const size_t bytes = std::min<size_t>((size_t)q->max_rows * q->sstride[fw] * sizeof(float), (size_t)16 << 20);
-  const char* force = getenv("PG_MISSQ_ENGINE");
   double best = 0;
   for (int b = 0; b < 16; ++b) {
     if (!((mask >> b) & 1u)) continue;
-    if (force && atoi(force) != b) continue;
     double sec = 0;
     if (!hsa_copy_sync(q, s0.staged_d[fw], s0.staging_h[fw], bytes, 1u << b, s0.sig[0], nullptr)) continue;
     if (!hsa_copy_sync(q, s0.staged_d[fw], s0.staging_h[fw], bytes, 1u << b, s0.sig[0], &sec) || sec <= 0) continue;
@@ -590,7 +582,7 @@ static void hsa_copy_init(pg_missq* q) {
   for (auto& s : q->slots)
     for (int f = 0; f < q->n_fields; ++f) hsa_signal_store_relaxed(s.sig[f], 0);
   q->hsa_ok = true;
-  if (getenv("PG_MISSQ_DEBUG") || getenv("PG_MISSQ_LOG_ENGINE")) {
+  if (getenv("PG_MISSQ_DEBUG")) {
     const char* rk = getenv("LOCAL_RANK");
     fprintf(stderr, "[missq] local rank %s device %d: direct SDMA copies on engine mask 0x%x; host->device GB/s per engine:",
             rk ? rk : "-", q->device, q->engine);
@@ -673,13 +665,12 @@ static void missq_worker(pg_missq* q) {
         const size_t copy_bytes = (size_t)m * srow * sizeof(float);    // what crosses PCIe (padding included: < 1 %)
         float* stg = s.staging_h[f];
         const int64_t* ids = s.fullid_h;
-        // PG_MISSQ_PREFETCH=<rows ahead>,<bytes of that row>: default 6 rows ahead, the whole row (up to 4 KB). Round 4: a
+        // prefetch: 6 rows ahead, the whole row (up to 4 KB). Round 4: a
         // thread that only had the head (256 bytes) of the row after next on its way spent its time waiting for DRAM — with
         // six whole rows in flight per thread the same gather takes 80 us instead of 100-114 on 12 threads, 119-135 on 6
         // (the step stays on its PCIe floor with half the threads), 280 instead of 508 on 2 (profiles/r04/host_gather_sweep.txt).
-        static const int pf_dist = getenv("PG_MISSQ_PREFETCH") ? std::max(1, atoi(getenv("PG_MISSQ_PREFETCH"))) : 6;
-        static const size_t pf_cfg = (getenv("PG_MISSQ_PREFETCH") && strchr(getenv("PG_MISSQ_PREFETCH"), ','))
-                                         ? (size_t)atol(strchr(getenv("PG_MISSQ_PREFETCH"), ',') + 1) : 4096;
+        constexpr int pf_dist = 6;
+        constexpr size_t pf_cfg = 4096;
         const size_t pf_bytes = std::min(pf_cfg, row_bytes);
         const auto ta = now();
         // a straggler of this slot's PREVIOUS job (a re-executed chunk's original owner) may still be copying into
@@ -739,7 +730,7 @@ static void missq_worker(pg_missq* q) {
             }
           } else if (direct) {
             const volatile int64_t* val = &reinterpret_cast<amd_signal_t*>(s.sig[f].handle)->value;
-            static const int poll_sleeps = getenv("PG_MISSQ_POLL_SLEEPS") ? atoi(getenv("PG_MISSQ_POLL_SLEEPS")) : 3;
+            constexpr int poll_sleeps = 3;
             hipLaunchKernelGGL(k_wait_hsa_signal, dim3(1), dim3(1), 0, q->copy_stream, val, q->timeout_d, poll_sleeps);
             if (hipGetLastError() != hipSuccess) rc = PG_ERR_HIP;
             if (logc) {
@@ -959,9 +950,9 @@ int pg_missq_create(int device, int n_slots, int64_t max_rows, const pg_missq_fi
     return PG_ERR_NOMEM;
   }
   // two spare staging buffers per field (see the worker: a job whose slot's buffer is still held by a straggler of the
-  // gather pool takes one instead of waiting for it); PG_MISSQ_SPARES=<n> (0: wait, as rounds 1-2 did)
+  // gather pool takes one instead of waiting for it)
   {
-    const int spares = getenv("PG_MISSQ_SPARES") ? atoi(getenv("PG_MISSQ_SPARES")) : 2;
+    const int spares = 2;
     for (int f = 0; f < n_fields; ++f)
       for (int i = 0; i < spares; ++i) {
         float* b = nullptr;
@@ -1139,7 +1130,7 @@ int pg_missq_wait_device(pg_missq_t* q, int slot, pg_stream_t stream) {
         if (enqueued && hsa_signal_load_scacquire(s.sig[f]) > 0) pending = true;
       }
     if (pending) {                     // (issued and already landed: nothing to wait for)
-      static const int poll_sleeps = getenv("PG_MISSQ_POLL_SLEEPS") ? atoi(getenv("PG_MISSQ_POLL_SLEEPS")) : 3;
+      constexpr int poll_sleeps = 3;
       hipLaunchKernelGGL(k_wait_direct, dim3(1), dim3(1), 0, as_stream(stream), s.issued_h, seq, sg, q->timeout_d,
                          poll_sleeps);
       PG_LAUNCH_CHECK();
@@ -1176,9 +1167,8 @@ int pg_missq_device_tail(pg_missq_t* q, int slot, pg_stream_t stream) {
   // The reads run on the queue's own copy stream (idle otherwise: direct jobs never touch it), ordered after the
   // caller's split by an event, and the consumer waits for `tail_done`: on the fetching stream they serialised with
   // the block transposes and the label lookup of the same minibatch (2 gather threads, share 0.31: 0.212 ms/step with
-  // the tail on the load stream). PG_MISSQ_TAIL_STREAM=caller keeps them on the caller's stream.
-  static const bool on_caller = getenv("PG_MISSQ_TAIL_STREAM") && !strcmp(getenv("PG_MISSQ_TAIL_STREAM"), "caller");
-  if (!on_caller) {
+  // the tail on the load stream).
+  {
     PG_HIP(hipEventRecord(s.tail_go, as_stream(stream)));
     PG_HIP(hipStreamWaitEvent(q->copy_stream, s.tail_go, 0));
     stream = (pg_stream_t)q->copy_stream;
@@ -1195,7 +1185,7 @@ int pg_missq_device_tail(pg_missq_t* q, int slot, pg_stream_t stream) {
                                  fd.dim, s.out[f], s.out_stride[f], stream);
     if (rc != PG_OK) return rc;
   }
-  if (!on_caller) {
+  {
     PG_HIP(hipEventRecord(s.tail_done, q->copy_stream));
     s.tail_pending = true;               // the slot's consumer orders itself after tail_done (pg_missq_wait*)
   }

@@ -1039,10 +1039,9 @@ int pg_sampler_capacity(const pg_sampler_t* s, int64_t* cap_nodes, int64_t* cap_
 
 // does block b take the one-workgroup transpose (k_t_block)?
 static bool transpose_one_workgroup(const pg_sampler* s, int b) {
-  static const bool device_sort = getenv("PG_T_DEVICE_SORT") != nullptr;
   const int64_t cap_edges = s->cap[b + 1] * s->k;
   const int64_t larger = cap_edges > s->cap[b] + 1 ? cap_edges : s->cap[b] + 1;
-  if (device_sort || larger > 1024 * 12) return false;
+  if (larger > 1024 * 12) return false;
   int vb = 1, kb = 1;
   while ((1ll << vb) < s->cap[b + 1]) ++vb;
   while ((1ll << kb) <= s->cap[b]) ++kb;
@@ -1062,10 +1061,9 @@ static int transpose_block(pg_sampler* s, const pg_nodeflow_desc_t* o, int b, co
   const int32_t pad_key = (int32_t)s->cap[b];
   int32_t *key_in = s->tkey, *key_out = s->tkey + s->max_edges, *val_in = s->tkey + 2 * s->max_edges;
   const Bnd tb = bnd(s->cap[b + 1] + 1, (long long)cap_edges + 1, s->cap[b]);
-  // small blocks (the seeds' block of a 2-layer step: 12 000 edges): one workgroup does it all (PG_T_DEVICE_SORT=1: never)
-  static const bool device_sort = getenv("PG_T_DEVICE_SORT") != nullptr;
+  // small blocks (the seeds' block of a 2-layer step: 12 000 edges): one workgroup does it all
   const int64_t larger = cap_edges > s->cap[b] + 1 ? cap_edges : s->cap[b] + 1;
-  if (!device_sort && larger <= 1024 * 12) {
+  if (larger <= 1024 * 12) {
     int vb = 1, kb = 1;
     while ((1ll << vb) < s->cap[b + 1]) ++vb;
     while ((1ll << kb) <= s->cap[b]) ++kb;
@@ -1312,7 +1310,7 @@ int pg_sampler_transpose(pg_sampler_t* s, const pg_nodeflow_desc_t* o, pg_stream
   // the multi-launch device sort of a large block: the launch sequence into a given slot from a given stream is fixed (all
   // sizes are read from the slot's device counters), so from the second call it is one hipGraph launch instead of ~8
   // kernel launches on the trainer's launch thread.
-  static const bool no_graph = getenv("PG_SAMPLER_NO_GRAPH") != nullptr;
+  constexpr bool no_graph = false;
   pg_sampler::SlotState* ss = nullptr;
   for (auto* c : s->tslot_states)
     if (c->key == o->node_mapping && c->stream == st && memcmp(&c->desc, o, sizeof(*o)) == 0) ss = c;

@@ -928,8 +928,8 @@ static int bwd_gather_impl(const int32_t* tptr, const int32_t* tdst, const int32
   const bool hubs = heavy && heavy_cap > 0;
   // hub rows: up to 16 extra blocks of the same launch (hub i goes to extra block i % 16)
   // ... each hub's columns dealt to `hub_parts` blocks when the row is one pass of an even number of 16-byte pieces
-  // (dim 64: 16 pieces, 4 parts of 2 + 2) — see heavy_rows; PG_HUB_PARTS=1 keeps one block per hub
-  static const int parts_cfg = getenv("PG_HUB_PARTS") ? atoi(getenv("PG_HUB_PARTS")) : 4;
+  // (dim 64: 16 pieces, 4 parts of 2 + 2) — see heavy_rows
+  constexpr int parts_cfg = 4;
   int hub_parts = 1;
   if (hubs && v4 && pieces <= (1 << l2) && pieces == (1 << l2))
     for (int p = parts_cfg; p > 1; p >>= 1)

@@ -47,8 +47,7 @@ class GraphSageSampling(FusedDropoutMixin, nn.Module):
         """model layer `lid` is applied to every block >= lid: with n_layers == 1 (pa_gs.py:134) a parameter receives at
         most TWO gradient contributions per step — what ops.defer_partials / pg_adam_step_partials2 fold into the
         optimiser's launch. Deeper stacks (three and more uses) and the preprocess variant keep the separate sums."""
-        import os
-        return self.n_layers == 1 and not self.preprocess and not os.environ.get("PG_NO_DEFER_SAGE")
+        return self.n_layers == 1 and not self.preprocess
 
     def __init__(self, in_feats, n_hidden, n_classes, n_layers, activation=None, dropout=0.,
                  aggregator_type='pool', preprocess=False):
@@ -90,11 +89,10 @@ class GraphSageSampling(FusedDropoutMixin, nn.Module):
         fc_self(h) of the block's destinations (:24: pg_linear2_fwd_rows / pg_linear_bwd_w_rows, which need at most 64
         hidden units); from model layer 1 on a layer's 'h' is the previous activation. With a wider hidden layer only
         layer 0 (a source of block 0 and nothing else) stays virtual. Not under preprocess (every layer goes through
-        fc_self / fc_neigh first, :76-87). PG_SAGE_VIRTUAL_L0=1: layer 0 only (rounds 1-2), for A/B runs."""
-        import os
+        fc_self / fc_neigh first, :76-87)."""
         if self.preprocess:
             return {}
-        if self.layers[0].fc_self.out_features > 64 or os.environ.get("PG_SAGE_VIRTUAL_L0"):
+        if self.layers[0].fc_self.out_features > 64:
             return {0: ['features']}
         return {l: ['features'] for l in range(num_layers)}
 

@@ -247,7 +247,7 @@ def _take_dz(gy, rows, N):
     return None
 
 
-FUSE_DZ = os.environ.get("PG_FUSE_DZ", "1") != "0"
+FUSE_DZ = True          # (a module attribute: the tests that compare the fused dZ with k_dz flip it)
 
 
 def _dz_fusable(h, dz_n):

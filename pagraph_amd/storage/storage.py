@@ -306,8 +306,8 @@ class GraphCacheServer:
         # engine), the rest is read by the device over PCIe on the fetching stream; 1.0 = all through the worker
         self.cpu_share = 1.0
         # index dedup of the miss list (pg_dedup_t): a vertex that misses in several layers of one NodeFlow crosses PCIe
-        # once and is copied on the device for the other layers. Async queue only. PG_DEDUP_MISSES=0 turns it off.
-        self.dedup_misses = os.environ.get("PG_DEDUP_MISSES", "1") != "0"
+        # once and is copied on the device for the other layers. Async queue only (an attribute: a caller may turn it off).
+        self.dedup_misses = True
         self._missq_dup = {}
         # state tensors were filled on the current stream; the fetching stream of a trainer does not synchronise with it
         torch.cuda.current_stream(self.device).synchronize()

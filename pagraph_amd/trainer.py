@@ -196,7 +196,6 @@ def cycle_batches(sampler, steps):
 
 
 import os as _os_mod
-_LABELS_MEMSET = bool(_os_mod.environ.get("PG_LABELS_MEMSET"))     # A/B: the label lookup behind a zero fill (rounds 1-3)
 
 
 class GraphedTrainer:
@@ -262,7 +261,7 @@ class GraphedTrainer:
         # Created AFTER the pipeline's own streams (below): the runtime multiplexes a priority class's streams onto a handful of
         # hardware queues in the order they are first used, and a communication stream taken first pushes the compute stream
         # onto a queue it then shares (round 6: the N > 1 step on one GPU at 0.20 instead of 0.10 ms, tools/exp_rccl_presence.sh)
-        self.comm_stream = torch.cuda.Stream(device=device) if (self.world > 1 and _os.environ.get("PG_COMM_STREAM_FIRST")) else None
+        self.comm_stream = None
         if self.world > 1:
             import torch.distributed as dist
             params = [p for p in model.parameters() if p.requires_grad]
@@ -285,27 +284,27 @@ class GraphedTrainer:
         # eager warm-up, capture and replay all run on ONE non-default stream, so autograd's
         # AccumulateGrad nodes and the captured graphs agree on the stream
         self.compute_stream = L.pipeline_stream(device, "compute", int(_os.environ.get("PG_PRIO_COMPUTE", 0)))
-        if self.world > 1 and not _os.environ.get("PG_COMM_STREAM_FIRST"):
+        if self.world > 1:
             self.comm_stream = torch.cuda.Stream(device=device)
         sampler.consumer_stream = self.compute_stream   # ring slots are recycled after the graph that read them
         sampler.manual_release = True
         # the sampler's own "slot free" event (recorded on the compute stream by sampler.release right after the step)
         # already orders every later use of the slot's buffers after that step: see prepare()
-        self._free_orders_slot = not _os.environ.get("PG_KEEP_DONE_EVENT")
+        self._free_orders_slot = True
         # ... and that event is polled by the launch thread before it samples into the slot again, not waited for by the
         # sampler's stream (sampler.host_gated): the compute stream records an event no stream waits for. With the default
         # ring of 8 slots the launch thread may be 8 - (lookahead + 2) = 4 steps ahead of the GPU before it has to wait.
-        sampler.host_gated = not _os.environ.get("PG_STREAM_GATED")
+        sampler.host_gated = True
         # ... and when the optimiser can mirror its step counter into pinned memory (pagraph_amd.optim.Adam: written by the
         # last block of the step's last launch) there is no event at all: a slot is free once the counter has reached the
         # step that read it. tools/exp_graph_gap.py: an event record nobody waits for in-stream still costs the compute
-        # stream 4.7 us per step. PG_NO_STEP_MIRROR=1 keeps the event.
+        # stream 4.7 us per step.
         # The token of a step is the OPTIMISER's count of step launches enqueued once that step's launch is in
         # (optim.Adam.steps_issued: eager steps count themselves, replays are reported below) — one sequence per optimiser,
         # so a second trainer on the same optimiser, or steps somebody runs between two run_steps calls, cannot make this
         # trainer's tokens lag the counter they are compared with (every released slot then read as free at once).
         self._step_cell = None
-        if sampler.host_gated and hasattr(optimizer, "enable_step_mirror") and not _os.environ.get("PG_NO_STEP_MIRROR"):
+        if sampler.host_gated and hasattr(optimizer, "enable_step_mirror"):
             self._step_cell = optimizer.enable_step_mirror(device)
             if self._step_cell is not None:
                 cell = self._step_cell
@@ -313,7 +312,7 @@ class GraphedTrainer:
         cacher.missq_slots = len(sampler.slots)
         # ring slot i of the sampler carries the batch whose miss job sits in queue slot i: before the sampler waits for
         # "slot free" (recorded after that batch's consumer) the job's copy must be in its queue — see prepare()
-        sampler.before_slot_reuse = None if _os.environ.get("PG_NO_SLOT_REUSE_WAIT") else cacher.wait_worker
+        sampler.before_slot_reuse = cacher.wait_worker
         # batches prepared ahead of the one being computed. The async miss path needs 2: its worker thread
         # must have finished batch k+1 (GPU publishes the miss list -> CPU gather -> copy enqueued) by the time
         # the host wants to enqueue compute(k+1), i.e. one whole step after it was submitted.
@@ -496,7 +495,7 @@ class GraphedTrainer:
             self._aggregate_early(nf, s, ls)
         o0, o1 = nf._layer_offsets[-2], nf._layer_offsets[-1]
         sp = ctypes.c_void_p(ls.cuda_stream)
-        if o1 > o0 and not _LABELS_MEMSET:
+        if o1 > o0:
             L.check(self._lib.pg_gather_labels_sc(ctypes.c_void_p(ids.data_ptr() + 8 * o0), o1 - o0, L.ptr(self.labels),
                                                   self.labels.numel(), -100, L.ptr(s.label), L.ptr(s.n_valid),
                                                   ctypes.c_void_p(s.n_valid3.data_ptr() + 4), sp), "pg_gather_labels_sc")
@@ -600,7 +599,7 @@ class GraphedTrainer:
         import os as _os
         c, plan = self.cacher, s.plan
         if (_os.environ.get("PG_NATIVE_PREPARE", "1") == "0" or plan is None or plan is False or not plan.virtual
-                or plan.dense_rows != 0 or not c.full_cached or _LABELS_MEMSET):
+                or plan.dense_rows != 0 or not c.full_cached):
             return False
         o0, o1 = nf._layer_offsets[-2], nf._layer_offsets[-1]
         if o1 <= o0 or getattr(nf._slot.ready, "cuda_event", None) in (None, 0) or getattr(s.ready, "cuda_event", None) in (None, 0):
@@ -776,8 +775,7 @@ class GraphedTrainer:
         counter AFTER the step, so the counter must hold the value this step uses"""
         import os as _os
         m = self._bare_model()
-        if (self._can_defer_partials() and m.training and hasattr(m, "externalise_drop_step")
-                and not _os.environ.get("PG_KEEP_BUMP_KERNEL")):
+        if self._can_defer_partials() and m.training and hasattr(m, "externalise_drop_step"):
             m.externalise_drop_step()
 
     def _step_body_deferred(self, s):
@@ -790,7 +788,7 @@ class GraphedTrainer:
         import contextlib
         import os as _os
         bump, scope = None, contextlib.nullcontext()
-        if m.training and hasattr(m, "externalise_drop_step") and not _os.environ.get("PG_KEEP_BUMP_KERNEL"):
+        if m.training and hasattr(m, "externalise_drop_step"):
             # the counter was primed by compute() (outside any capture); only this forward skips the model's own bump
             bump, scope = m._drop_step, m.drop_step_external()
             s.ext_drop = m
@@ -883,10 +881,6 @@ class GraphedTrainer:
         (see __init__: an eager collective must never sit on a stream that is captured later)"""
         import torch.distributed as dist
         import os as _os
-        if _os.environ.get("PG_COLLECTIVES_ON_COMPUTE_STREAM"):      # rounds 1-2 (reproduces the abort under RCCL)
-            with torch.cuda.stream(self.compute_stream):
-                dist.all_reduce(tensor, group=self.pg) if op is None else dist.all_reduce(tensor, op=op, group=self.pg)
-            return
         cs = self.comm_stream
         cs.wait_stream(self.compute_stream)
         with torch.cuda.stream(cs):

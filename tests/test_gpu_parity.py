@@ -2813,8 +2813,7 @@ def test_skinny_linear_ragged_K_on_the_mfma_kernel(dev, hiplib, n, K, N):
     x.copy_(torch.rand((n, K), device=dev) - 0.3)
     lin = torch.nn.Linear(K, N).to(dev)
     y = torch.empty((n, 2 * N), device=dev)
-    L.check(hiplib.pg_linear_fwd(L.ptr(x), x.stride(0), L.ptr(lin.weight), L.ptr(lin.bias), L.ptr(y), y.stride(0), n, K, N,
-                                 ops.ACT_CONCAT, L.stream_ptr()), "pg_linear_fwd")
+    L.check(ops.linear_fwd_call(hiplib, x, lin.weight, lin.bias, y, n, N, ops.ACT_CONCAT), "pg_linear_fwd")
     z = torch.nn.functional.linear(x.double(), lin.weight.double(), lin.bias.double())
     ref = torch.cat((z, torch.relu(z)), 1)
     assert float((y.double() - ref).abs().max()) < TOL * max(1.0, float(ref.abs().max()))
