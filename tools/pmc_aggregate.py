@@ -30,5 +30,5 @@ for k, v in table.items():
                "avg_ns_under_pmc": v["avg_ns_under_pmc"],
                "collected": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace, separate passes (FETCH_SIZE x2 on gfx950, "
                             "WRITE_SIZE x1, KiB; calibrated in the same run on the 2.5 GB cache-fill copies: x1.000 / x1.000), over "
-                            "PG_SAMPLER_NO_GRAPH=1 PG_MISSQ_HOST_WAIT=1 python bench.py --steps 60 --no-graph ... (tools/run_profiles.sh)"}
+                            "PG_MISSQ_HOST_WAIT=1 python bench.py --steps 60 --no-graph ... (tools/run_profiles.sh)"}
         json.dump(rec, open(os.path.join(out_dir, f"pmc_{short}_inloop.json"), "w"), indent=1)
