@@ -245,21 +245,4 @@ int pg_timer_elapsed_ms(pg_timer_t* t, float* ms) {
   return PG_OK;
 }
 
-/* A stream whose kernels may only run on the CUs named by `mask` (bit i of word i / 32: CU i as ROCr numbers them; 256 CUs
- * = 8 words on MI355X). The training pipeline gives its sampler / load streams a few CUs of their own and the compute stream the
- * rest (PG_CU_SIDE, pagraph_amd/_lib.py): a handful of small latency-bound launches beside an HBM-bound kernel cost that kernel
- * more than their own time when they take wave slots on every CU. */
-int pg_stream_create_masked(const uint32_t* mask, int32_t words, pg_stream_t* out) {
-  if (!mask || words <= 0 || !out) return PG_ERR_INVALID;
-  hipStream_t s = nullptr;
-  PG_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask));
-  *out = reinterpret_cast<pg_stream_t>(s);
-  return PG_OK;
-}
-int pg_stream_destroy(pg_stream_t s) {
-  if (!s) return PG_OK;
-  PG_HIP(hipStreamDestroy(pg::as_stream(s)));
-  return PG_OK;
-}
-
 }  // extern "C"

@@ -658,7 +658,7 @@ static int linear_bwd_w(const float* dY, int32_t dy_stride, const float* X, int3
   if (rows) hipLaunchKernelGGL(k_linear_bwd_w<true>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
   else hipLaunchKernelGGL(k_linear_bwd_w<false>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
   PG_LAUNCH_CHECK();
-  if (!sum_partials) return PG_OK;   // the consumer (pg_adam_step_partials) adds the chunks up itself
+  if (!sum_partials) return PG_OK;   // the consumer (pg_adam_step) adds the chunks up itself
   const int64_t nk = (int64_t)N * K;
   hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)ceil_div<int64_t>(nk + N, 64)), dim3(256), 0, as_stream(stream),
                      partials, (int32_t)chunks, nk, N, dW, db, nk + N);

@@ -374,7 +374,7 @@ static int head_impl(const int32_t* indptr, const int32_t* src, const float* h, 
   else PG_HEAD(8);
 #undef PG_HEAD
   PG_LAUNCH_CHECK();
-  if (!sum_partials) return PG_OK;   // pg_adam_step_partials adds the blocks' partials up
+  if (!sum_partials) return PG_OK;   // pg_adam_step adds the blocks' partials up
   // dW [C*K] (then dW_self [C*Ks]: the caller's dW buffer holds both, contiguous), then db [C] and the loss (db_loss[C])
   // contiguous behind them in the partial layout
   return pg_sum_partials_strided(partials, (int32_t)blocks, (int64_t)C * Kt, C + 1, pg_gcn_head_row_len(Kt, C), dW, db_loss,

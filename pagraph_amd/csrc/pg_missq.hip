@@ -59,7 +59,7 @@ __global__ void k_publish(const int32_t* __restrict__ count_dev, int32_t* count_
 // k_publish for a launch whose split ran with index dedup: every dup entry's "earlier row" becomes that row's
 // staged index (the split wrote -(j + 3) into the primary's slot), then the count is published as above
 // (round 3) ... and the repeat's OWN slot entry takes the primary's value: a consumer that reads rows in place through
-// the slot array (pg_spmm_fwd_rows, pg_linear2_fwd_rows: no frame the repeat could be copied into) then finds the
+// the slot array (pg_spmm_fwd_rows, pg_linear_fwd (rows in place): no frame the repeat could be copied into) then finds the
 // primary's staged row. A repeat is never a primary, so the entries read and the entries written are disjoint.
 __global__ __launch_bounds__(256) void k_publish_dedup(const int32_t* __restrict__ count_dev, int32_t* count_host,
                                                        uint32_t* flag_host, uint32_t seq, int32_t* slots,
@@ -439,7 +439,7 @@ struct pg_missq {
   std::atomic<int> cpu_share{256};   // of 256: the leading share of every miss list that the CPU path moves
   // PG_MISSQ_DEBUG=1: accumulated worker phase times (us) printed at destroy
   double t_sync = 0, t_flag = 0, t_gather = 0, t_enqueue = 0, t_copy = 0, t_sub2flag = 0, t_sub2pop = 0;
-  // the longest single occurrence of each phase since the last pg_missq_stats_max(reset): where a stall of the miss path sat
+  // the longest single occurrence of each phase since the last pg_missq_stats(reset_max): where a stall of the miss path sat
   double mx_flag = 0, mx_gather = 0, mx_enqueue = 0, mx_total = 0;
   double t_total = 0;
   bool copy_log = getenv("PG_MISSQ_COPYLOG") != nullptr;

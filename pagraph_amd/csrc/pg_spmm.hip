@@ -422,7 +422,7 @@ __device__ __forceinline__ float4 dz_piece(float4 lo, float4 hi, float4 y) {
   return lo;
 }
 
-// PG_REDUCE_MAX backward (pg_spmm_bwd_gather_max): the forward's input and output
+// PG_REDUCE_MAX backward (pg_spmm_bwd (max, gather form)): the forward's input and output
 struct MaxIn {
   const float* h;     // [n_src, dim] the aggregation's input (before dropout)
   const float* out;   // [n_dst, dim] its output

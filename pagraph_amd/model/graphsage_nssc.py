@@ -45,7 +45,7 @@ class GraphSageSampling(FusedDropoutMixin, nn.Module):
     @property
     def deferrable_parameters(self):
         """model layer `lid` is applied to every block >= lid: with n_layers == 1 (pa_gs.py:134) a parameter receives at
-        most TWO gradient contributions per step — what ops.defer_partials / pg_adam_step_partials2 fold into the
+        most TWO gradient contributions per step — what ops.defer_partials / pg_adam_step fold into the
         optimiser's launch. Deeper stacks (three and more uses) and the preprocess variant keep the separate sums."""
         return self.n_layers == 1 and not self.preprocess
 
@@ -86,7 +86,7 @@ class GraphSageSampling(FusedDropoutMixin, nn.Module):
     def virtual_inputs(self, num_layers):
         """Every layer's raw 'features' may stay un-materialised (ops.RowSource): they are read by model layer 0 only —
         as the source rows of a block's aggregation (graphsage_nssc.py:92-111: pg_spmm_fwd_rows) and as the self term
-        fc_self(h) of the block's destinations (:24: pg_linear2_fwd_rows / pg_linear_bwd_w_rows, which need at most 64
+        fc_self(h) of the block's destinations (:24: pg_linear_fwd (rows in place) / pg_linear_bwd_w (rows in place), which need at most 64
         hidden units); from model layer 1 on a layer's 'h' is the previous activation. With a wider hidden layer only
         layer 0 (a source of block 0 and nothing else) stays virtual. Not under preprocess (every layer goes through
         fc_self / fc_neigh first, :76-87)."""

@@ -186,7 +186,7 @@ class _BlockAggregate(torch.autograd.Function):
 
     @staticmethod
     def _backward_max(ctx, lib, go):
-        """pg_spmm_bwd_gather_max over the source-major copy when the sampler built one, else the scatter form"""
+        """pg_spmm_bwd (max, gather form) over the source-major copy when the sampler built one, else the scatter form"""
         indptr, src, h, out = ctx.saved_tensors[:4]
         d = ctx.drop.struct() if ctx.drop is not None else None
         with torch.cuda.device(go.device):
@@ -227,7 +227,7 @@ def block_aggregate(indptr, src, h, n_dst, reduce="mean", dropout=None, transpos
 ACT_NONE, ACT_RELU, ACT_CONCAT = 0, 1, 2
 
 # dZ side channel: when the rows an aggregation consumed were a skip-concat NodeUpdate's output y = [z | relu(z)]
-# (ops.linear tags such a y with `_pg_concat_n`), the aggregation's backward (pg_spmm_bwd_gather_dz) writes
+# (ops.linear tags such a y with `_pg_concat_n`), the aggregation's backward (pg_spmm_bwd (gather form + dZ)) writes
 # dZ = g[:, :N] + g[:, N:] * (z > 0) next to its grad_h and parks it here; the NodeUpdate's backward, called by autograd with
 # that very grad_h, picks it up and skips pg_linear_bwd_w's own dZ launch. The entry holds grad_h itself, so no other live
 # tensor can have its address; a summed gradient (y consumed twice) is a different tensor and simply misses.
@@ -251,7 +251,7 @@ FUSE_DZ = True          # (a module attribute: the tests that compare the fused 
 
 
 def _dz_fusable(h, dz_n):
-    """pg_spmm_bwd_gather_dz's envelope: [rows, 2 N] fp32 rows of 16-byte pieces, a whole row inside one lane group"""
+    """pg_spmm_bwd (gather form + dZ)'s envelope: [rows, 2 N] fp32 rows of 16-byte pieces, a whole row inside one lane group"""
     return FUSE_DZ and bool(dz_n) and h.size(1) == 2 * dz_n and h.size(1) % 8 == 0 and h.size(1) <= 256 and h.stride(0) % 4 == 0 \
         and h.data_ptr() % 16 == 0
 
@@ -260,7 +260,7 @@ class DeferredPartials:
     """While one of these is active (`with ops.defer_partials() as reg:`), the weight-gradient kernels leave their
     per-chunk partial rows un-summed and register them here, keyed by the parameter's storage; the optimiser
     (pagraph_amd.optim.Adam.step(deferred=reg)) adds them up — in pg_sum_partials' exact order — inside its own single
-    launch (pg_adam_step_partials). Two k_sum_partials launches of the replayed GCN step disappear. Only valid when
+    launch (pg_adam_step). Two k_sum_partials launches of the replayed GCN step disappear. Only valid when
     every parameter receives exactly ONE gradient contribution per step and nothing reads the gradients (or the fused
     head's loss value) before the optimiser has run."""
 
@@ -285,7 +285,7 @@ class DeferredPartials:
     def add(self, param, part, chunks, rowlen, off):
         """register one contribution; returns True for a parameter's first contribution of the step — the caller hands
         autograd its (still unsummed) gradient buffer only then and None for a later one, so that AccumulateGrad has
-        nothing to add: the optimiser's launch forms sum(first) + sum(second) (pg_adam_step_partials2)"""
+        nothing to add: the optimiser's launch forms sum(first) + sum(second) (pg_adam_step)"""
         e = (part, int(chunks), int(rowlen), int(off), param.numel())
         k = param.data_ptr()
         if k not in self.by_param:
@@ -408,7 +408,7 @@ def _skinny_backward(ctx, gy, x, weight, y, need_x, need_w, need_b):
         defer = _DEFER is not None and ctx.has_bias
         ready = _take_dz(gy, x.size(0), N) if act == ACT_CONCAT else None
         with torch.cuda.device(x.device):
-            if ready is not None:        # dZ came with the gradient (pg_spmm_bwd_gather_dz): plain dY = dZ, no act
+            if ready is not None:        # dZ came with the gradient (pg_spmm_bwd (gather form + dZ)): plain dY = dZ, no act
                 dz = ready
                 L.check(linear_bwd_call(lib, dz, x, K, N, gw, gb, part, 0 if defer else 1), "pg_linear_bwd_w")
             else:

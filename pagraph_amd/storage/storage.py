@@ -823,7 +823,7 @@ class GraphCacheServer:
         if use_q:
             L.check(self.lib.pg_missq_submit(self._missq, slot, plan.optrs, plan.ostr, plan.poslo,
                                                    L.ptr(plan.slots) if dd is not None else None, sp),
-                    "pg_missq_submit_range")
+                    "pg_missq_submit")
             self._missq_pending.add(slot)
             if self._missq_share < 256:      # the device reads the tail of the list into the staged block itself
                 self._device_tail(slot, sp)

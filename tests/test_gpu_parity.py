@@ -1208,7 +1208,7 @@ def test_loss_head_vs_oracle(dev, hiplib, oracle, n, C, ignored):
                                                            (300, 400, 4, 1100, "sum", 0.1), (64, 64, 3, 8, "mean", 0.9),
                                                            (200, 300, 2, 2048, "mean", 0.25)])
 def test_spmm_with_fused_dropout_vs_oracle(dev, hiplib, oracle, n_dst, n_src, deg, dim, reduce, p):
-    """pg_spmm_fwd_drop / pg_spmm_bwd_drop = aggregate(dropout(h)): the keep-mask is BIT exact against the
+    """pg_spmm_fwd_drop / pg_spmm_bwd = aggregate(dropout(h)): the keep-mask is BIT exact against the
     oracle's restatement of the counter-based spec (pg_dropout_t), values within 1e-4; a new step draws a new
     mask; threshold 0 is the plain aggregation."""
     from pagraph_amd import ops
@@ -1377,7 +1377,7 @@ def test_sampler_emits_source_major_blocks(dev, hiplib, static):
                                                            (6000, 9000, -2, 64, "mean", 0.5), (3000, 500, -3, 600, "sum", 0.0),
                                                            (2000, 300, -2, 33, "mean", 0.0)])
 def test_spmm_backward_gather_form_vs_oracle(dev, hiplib, oracle, n_dst, n_src, deg, dim, reduce, p):
-    """pg_spmm_bwd_gather (no atomics, no zero fill) == the scatter-form gradient of the oracle, with and
+    """pg_spmm_bwd (gather form) (no atomics, no zero fill) == the scatter-form gradient of the oracle, with and
     without the folded dropout mask; two runs are bit-identical (fixed summation order)"""
     from pagraph_amd import ops
     rng = np.random.default_rng(n_dst + 3 * dim)
@@ -1427,8 +1427,8 @@ def test_spmm_backward_gather_form_vs_oracle(dev, hiplib, oracle, n_dst, n_src, 
 def test_spmm_max_reducer_vs_oracle(dev, hiplib, oracle, n_dst, n_src, deg, dim, p):
     """a-10's third reducer (graphsage_nssc.py:106-110, fn.max = the 'pool' aggregator): PG_REDUCE_MAX forward is BIT
     exact against the oracle (zeros for a destination without in-edges); the backward — every in-edge whose message
-    equals the maximum receives the destination's gradient, DGL's `val == accum` — in scatter form (pg_spmm_bwd_max)
-    and in gather form over the source-major copy (pg_spmm_bwd_gather_max, hubs included, bit-identical between runs),
+    equals the maximum receives the destination's gradient, DGL's `val == accum` — in scatter form (pg_spmm_bwd (max))
+    and in gather form over the source-major copy (pg_spmm_bwd (max, gather form), hubs included, bit-identical between runs),
     with and without the folded dropout. Values come from a small integer set, so ties are everywhere."""
     from pagraph_amd import ops
     rng = np.random.default_rng(n_dst + 5 * dim + int(p * 10))
@@ -1485,7 +1485,7 @@ def test_spmm_max_reducer_vs_oracle(dev, hiplib, oracle, n_dst, n_src, deg, dim,
 @pytest.mark.parametrize("n,K1,K2,N,act", [(17000, 600, 600, 16, 2), (6000, 32, 32, 60, 0), (5000, 600, 64, 32, 1),
                                            (2049, 8, 600, 41, 0), (4096, 64, 64, 64, 2)])
 def test_dual_linear_vs_torch(dev, hiplib, n, K1, K2, N, act):
-    """pg_linear2_fwd (GraphSAGE NodeUpdate: fc_self(h) + fc_neigh(neigh), activation / skip-concat fused) and
+    """pg_linear_fwd (two operands) (GraphSAGE NodeUpdate: fc_self(h) + fc_neigh(neigh), activation / skip-concat fused) and
     its backward vs float64 torch: output, both weight / bias gradients and both input gradients within 1e-4"""
     from pagraph_amd import ops
     torch.manual_seed(n + K1 + N)
@@ -1662,7 +1662,7 @@ def test_gcn_output_head_vs_oracle(dev, hiplib, oracle, n_dst, n_src, deg, K, C,
                                                        (3000, 4000, 16, 0.25, "agg"), (2500, 3100, 8, 0.0, "head"),
                                                        (1500, 2000, 24, 0.5, "head")])
 def test_dz_from_backward_gather_bit_identical(dev, hiplib, monkeypatch, n_dst, n_src, N, p, consumer):
-    """pg_spmm_bwd_gather_dz: the skip-concat NodeUpdate's dZ written by the aggregation's backward (regular rows through
+    """pg_spmm_bwd (gather form + dZ): the skip-concat NodeUpdate's dZ written by the aggregation's backward (regular rows through
     the lane-group shuffle, hub rows through LDS) == the unfused k_dz path bit for bit, in dZ's consumers: the layer's
     weight / bias gradient and the gradient of its input. A gradient that is not the stashed tensor misses the stash."""
     from pagraph_amd import ops
@@ -2116,7 +2116,7 @@ def test_virtual_layer0_matches_materialised(dev, hiplib, arch, mode):
     model = model.to(dev).train()
     need = model.required_inputs(3)
     virt = model.virtual_inputs(3)
-    # GCN reads layer 0 only; GraphSAGE's self terms read layers 1 and 2 in place as well (pg_linear2_fwd_rows, round 3)
+    # GCN reads layer 0 only; GraphSAGE's self terms read layers 1 and 2 in place as well (pg_linear_fwd (rows in place), round 3)
     assert virt == ({0: ['features']} if arch == "gcn" else {0: ['features'], 1: ['features'], 2: ['features']})
     smp = NeighborSampler(g, B, k, neighbor_type='in', shuffle=False, num_hops=2, seed_nodes=np.arange(V), seed=1)
     it = iter(smp)
@@ -2159,8 +2159,8 @@ def test_virtual_layer0_matches_materialised(dev, hiplib, arch, mode):
 @pytest.mark.parametrize("n,K,N,K2,act", [(12000, 600, 16, 600, 2), (6000, 600, 16, 600, 1), (4133, 600, 32, 64, 2),
                                           (1000, 602, 16, 602, 0), (777, 256, 64, 0, 1), (50, 600, 16, 600, 2)])
 def test_dense_step_from_row_source_is_bit_identical(dev, hiplib, n, K, N, K2, act):
-    """pg_linear2_fwd_rows / pg_linear_bwd_w_rows read the first operand's rows where they live (cache slot, staged miss
-    row, zero for padding) and give exactly what pg_linear2_fwd / pg_linear_bwd_w_ex give on the gathered copy"""
+    """pg_linear_fwd (rows in place) / pg_linear_bwd_w (rows in place) read the first operand's rows where they live (cache slot, staged miss
+    row, zero for padding) and give exactly what pg_linear_fwd (two operands) / pg_linear_bwd_w give on the gathered copy"""
     from pagraph_amd import _lib as L
     rng = np.random.default_rng(n + K)
     cs = (K + 7) & ~7                      # fused cache rows are padded
@@ -2217,7 +2217,7 @@ def test_dense_step_from_row_source_is_bit_identical(dev, hiplib, n, K, N, K2, a
         want = ref.double().t() @ Xd[:, :K].double()
         assert (res[1][0].double() - want).abs().max() < 1e-3 * max(1.0, float(want.abs().max()))
     if K2:
-        # pg_linear2_bwd_w: BOTH operands' weight gradients in one launch == one pg_linear_bwd_w_ex / _rows call per operand,
+        # pg_linear_bwd_w (two operands): BOTH operands' weight gradients in one launch == one pg_linear_bwd_w / _rows call per operand,
         # partial rows and sums bit for bit (summed and left for the optimiser), first operand dense and read in place
         sc2 = hiplib.pg_linear_bwd_w_scratch(n, K2, N)
         p2 = torch.zeros(sc2, device=dev); dW2 = torch.empty((N, K2), device=dev); db2 = torch.empty(N, device=dev)
@@ -2523,7 +2523,7 @@ def test_cache_analysis_vs_reference_golden(dev, hiplib, golden_dir):
 
 
 def test_adam_with_deferred_partial_sums_is_bit_identical(dev, hiplib):
-    """ops.defer_partials + Adam.step(deferred=...) (pg_adam_step_partials: the two ordered partial sums of the replayed
+    """ops.defer_partials + Adam.step(deferred=...) (pg_adam_step: the two ordered partial sums of the replayed
     GCN step folded into the optimiser's launch) == the three-launch path, bit for bit, over several steps: parameters,
     Adam state, gradients left in p.grad, and the fused head's loss value"""
     import torch.nn.functional as Fn
@@ -2883,7 +2883,7 @@ def test_reddit_width_runs_on_the_fused_path(dev, hiplib, arch, ratio):
 def test_graphsage_deferred_partial_sums_two_uses_bit_identical(dev, hiplib):
     """GraphSAGE's first NodeUpdate runs on both blocks (graphsage_nssc.py:92-131): its parameters get TWO gradient
     contributions per step. ops.defer_partials hands autograd one placeholder and the optimiser's launch forms
-    sum(first) + sum(second) (pg_adam_step_partials2) — parameters, Adam state and p.grad equal the unfused path
+    sum(first) + sum(second) (pg_adam_step) — parameters, Adam state and p.grad equal the unfused path
     (k_sum_partials per contribution + AccumulateGrad's add + pg_adam_step) bit for bit over several steps"""
     import torch.nn.functional as Fn
     from pagraph_amd import ops
