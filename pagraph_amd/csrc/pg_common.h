@@ -15,11 +15,11 @@ struct pg_timer {
   hipEvent_t start, stop;
 };
 
-// internal (pg_dense.hip): ordered sum of per-chunk partial tiles
-extern "C" int pg_sum_partials(const float* partials, int32_t chunks, int64_t nk, int32_t N, float* dW, float* db,
+// internal (pg_dense.hip; not exported): ordered sum of per-chunk partial tiles
+extern "C" __attribute__((visibility("hidden"))) int pg_sum_partials(const float* partials, int32_t chunks, int64_t nk, int32_t N, float* dW, float* db,
                                pg_stream_t stream);
 // ... with `row_len` floats between two partial rows (pg_head pads its rows to whole 16-byte pieces)
-extern "C" int pg_sum_partials_strided(const float* partials, int32_t chunks, int64_t nk, int32_t N, int64_t row_len,
+extern "C" __attribute__((visibility("hidden"))) int pg_sum_partials_strided(const float* partials, int32_t chunks, int64_t nk, int32_t N, int64_t row_len,
                                        float* dW, float* db, pg_stream_t stream);
 
 namespace pg {
