@@ -484,6 +484,9 @@ class GraphedTrainer:
                 with torch.cuda.stream(ls):
                     s.plan = self._plan_for(nf, s)
             s.batch_plan = None
+            # ... and the compute stream READS them (the fused layer-0 aggregation follows plan.slots): recorded there, or a
+            # trainer dropped with a step in flight hands the block to the next allocation on a recycled load stream
+            L.record_streams(s.plan, [self.compute_stream])
         if s.plan is not False:
             self.cacher.fetch_planned(s.plan, ids, ls, slot=s.slot_index)      # (allocates under `ls` itself where it must)
         else:

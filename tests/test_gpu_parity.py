@@ -936,6 +936,102 @@ def test_fetch_plan_buffers_come_from_the_stream_that_fills_them(dev, hiplib, mo
     tr.close(); smp.close(); c.close()
 
 
+def _reachable_cuda_tensors(roots):
+    """(path, tensor) for every CUDA tensor reachable from `roots` through attributes, slots and containers: any class, any
+    depth — deliberately NOT _lib.record_streams' walk (pagraph_amd classes only, depth 6, a skip list of attribute names)"""
+    import types
+    seen, out, stack = set(), [], [(r, n) for n, r in roots.items()]
+    skip = (str, bytes, int, float, bool, type(None), type, types.ModuleType, types.FunctionType, types.BuiltinFunctionType,
+            types.CodeType, torch.cuda.Stream, torch.cuda.Event, torch.dtype, torch.device, np.ndarray)
+    while stack:
+        o, path = stack.pop()
+        if isinstance(o, skip) or id(o) in seen:
+            continue
+        seen.add(id(o))
+        if torch.is_tensor(o):
+            if o.is_cuda:
+                out.append((path, o))
+            if o.grad is not None:
+                stack.append((o.grad, path + ".grad"))
+        elif isinstance(o, dict):
+            stack.extend((v, path + "[%s]" % (k if isinstance(k, (str, int, tuple)) else type(k).__name__,))
+                         for k, v in list(o.items()))
+        elif isinstance(o, (list, tuple, set, frozenset)):
+            stack.extend((v, "%s[%d]" % (path, i)) for i, v in enumerate(list(o)))
+        elif isinstance(o, types.MethodType):
+            stack.append((o.__self__, path + ".__self__"))
+        else:
+            d = getattr(o, "__dict__", None)
+            if isinstance(d, dict):
+                stack.extend((v, path + "." + k) for k, v in list(d.items()))
+            for klass in type(o).__mro__:
+                for k in getattr(klass, "__slots__", ()) or ():
+                    if hasattr(o, k):
+                        stack.append((getattr(o, k), path + "." + k))
+    return out
+
+
+@pytest.mark.parametrize("kind", ["gcn", "sage"])
+def test_every_buffer_a_pipeline_reaches_is_recorded_or_known_single_stream(dev, hiplib, monkeypatch, kind):
+    """The lifetime rule of the pipeline (_lib.record_streams: a buffer used on a stream other than the one it was allocated on is
+    recorded there, so the allocator does not recycle it under kernels in flight) is enforced by a walk over the owners'
+    attributes that a new attribute on a new class could escape silently. Here Tensor.record_stream is spied on while a
+    pipeline is built and run, the owners are walked WITHOUT the walk's limits, and every device buffer found must either have
+    been recorded on a foreign stream or be one of the few kinds that live on a single stream by construction (listed below
+    with the reason). Round 6 found the fetch plan's slot array this way: allocated on the load stream, read by the compute
+    stream's fused aggregation, recorded nowhere."""
+    import re
+    import torch.nn.functional as Fn
+    from pagraph_amd.model import GCNSampling, GraphSageSampling
+    from pagraph_amd.optim import Adam
+    from pagraph_amd.sampling import DeviceGraph, NeighborSampler
+    from pagraph_amd.storage import GraphCacheServer, HostFeatureStore
+    from pagraph_amd.trainer import GraphedTrainer, cycle_batches
+    recorded = {}
+    orig = torch.Tensor.record_stream
+
+    def spy(t, s):
+        recorded.setdefault(t.untyped_storage().data_ptr(), set()).add(int(s.cuda_stream))
+        return orig(t, s)
+    monkeypatch.setattr(torch.Tensor, "record_stream", spy)
+    rng = np.random.default_rng(7)
+    V, Fdim, C, B = 6000, 256, 5, 400
+    g = DeviceGraph(_rand_csc(rng, V, 40000))
+    feats = torch.from_numpy(rng.standard_normal((V, Fdim)).astype(np.float32))
+    labels = torch.from_numpy(rng.integers(0, C, V)).to(dev)
+    c = GraphCacheServer(HostFeatureStore({"features": feats}), V, torch.arange(V), 0, miss_mode="async", host_threads=3)
+    c.init_field(["features"])
+    c.auto_cache(g, ["features"], cache_ratio=0.3)
+    torch.manual_seed(0)
+    model = (GCNSampling(Fdim, 16, C, 1, Fn.relu, 0.2) if kind == "gcn"
+             else GraphSageSampling(Fdim, 16, C, 1, Fn.relu, 0.2, 'mean')).to(dev)
+    opt = Adam(model.parameters(), lr=1e-2)
+    smp = NeighborSampler(g, B, 2, neighbor_type='in', shuffle=True, num_hops=2, seed_nodes=np.arange(0, V, 2, dtype=np.int64),
+                          prefetch=True, seed=1, static=True, defer_transpose=True)
+    tr = GraphedTrainer(model, torch.nn.CrossEntropyLoss(), opt, c, smp, labels, dev, need=model.required_inputs(3),
+                        keep_losses=False)
+    tr.run_steps(cycle_batches(smp, 48), 40)           # eager warm-up, both captures, replays: every lazy buffer exists
+    tr.synchronize()
+    single_stream = [
+        (r"\.grad$", "parameter gradients: created and consumed by the step, on the compute stream"),
+        (r"^opt\.state\[", "Adam moments: created by the first step on the compute stream, touched by nothing else"),
+        (r"^tr\._gseed$|\.loss$|^tr\.last_loss$", "the step's own scalars (compute stream; the host reads them after a synchronise)"),
+        (r"_out_deg$", "auto_cache's degree vector: default stream only, before training"),
+    ]
+    by_storage = {}
+    for path, t in _reachable_cuda_tensors({"tr": tr, "smp": smp, "c": c, "opt": opt, "model": model}):
+        by_storage.setdefault(t.untyped_storage().data_ptr(), []).append(path)
+    assert len(by_storage) > 60                        # the walk did reach the pipeline's buffers
+    loose = []
+    for ptr_, paths in by_storage.items():
+        if recorded.get(ptr_):
+            continue
+        if not any(re.search(rx, p) for p in paths for rx, _why in single_stream):
+            loose.append(min(paths, key=len))
+    tr.close(); smp.close(); c.close()
+    assert not loose, "device buffers no stream was recorded for: %s" % sorted(loose)
+
+
 def test_stress_objects_dropped_with_work_in_flight(dev, hiplib):
     """Samplers, cachers (async miss queue: worker thread, gather pool, SDMA copies), trainers with captured step graphs and
     optimisers with a mirrored step counter are created, driven WITHOUT a final synchronise, and dropped in every order
