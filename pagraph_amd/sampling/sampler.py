@@ -207,7 +207,10 @@ class NeighborSampler:
     def __del__(self):
         # best-effort backstop only (close() is the deterministic path; the buffers' lifetimes are the allocator's business,
         # see __init__): a chain still in flight when the sampler is dropped must not outlive the handle's scratch
-        self.close()
+        try:
+            self.close()
+        except Exception:                # (interpreter shutdown: module globals may be gone already)
+            pass
 
     def __len__(self):
         return self.num_batches

@@ -1102,7 +1102,10 @@ class GraphCacheServer:
         # best-effort backstop (close() is the deterministic path). The torch buffers of this object that other streams touch
         # are recorded on those streams by the trainers (L.record_streams): their memory outlives kernels in flight whatever
         # drops the object; the miss queue's own blocks are freed by the library behind hipFree's device-wide wait
-        self.close()
+        try:
+            self.close()
+        except Exception:                # (interpreter shutdown: module globals may be gone already)
+            pass
 
     # -- storage.py:207-216 ---------------------------------------------------
     def fetch_from_cache(self, nodeflow, out=None):
