@@ -162,6 +162,8 @@ def parse():
     p.add_argument("--which-rank", type=int, default=None, help="--as-rank-of: the partition to run (default: largest closure)")
     p.add_argument("--dist-step", action="store_true", help="one GPU: the N > 1 step shape (one-rank RCCL group, trainer "
                    "world_size 2) over the 1naive partition — the A/B partner of the default one-GPU step")
+    p.add_argument("--tape-collectives", action="store_true", help="A/B (N > 1 step): replay the captured step that holds the "
+                   "all-reduce as plain launches too (GraphedTrainer.tape_collectives; default: that graph keeps hipGraphLaunch)")
     p.add_argument("--extra-streams", type=int, default=0, help="diagnosis: create and use N more streams before the trainer")
     p.add_argument("--no-fuse-partials", action="store_true", help="A/B: the weight gradients' ordered partial sums as launches "
                    "of their own (+ AccumulateGrad's adds when N > 1) instead of inside the optimiser's launch")
@@ -952,6 +954,7 @@ def run():
         trainer.fuse_gather = fuse_gather
         if args.no_fuse_partials:
             trainer.fuse_partials = False
+        trainer.tape_collectives = bool(args.tape_collectives)
     else:
         trainer = MinibatchTrainer(model, loss_fcn, optimizer, cacher, sampler, labels, dev, overlap=not args.no_overlap,
                                    need=need)
@@ -1438,7 +1441,8 @@ def run():
                                          "note": "adjacency entries dg --num-hops 2 walks; pg_dg_partition_gpu: ~1.4e10 per second"},
                        "hip_graph_step": use_graph,
                        # how a captured step is replayed: its kernels as plain launches (csrc/pg_tape.hip, the default on one GPU)
-                       # or hipGraphLaunch (PG_FLAT_REPLAY=0, world > 1, or a graph that is not a chain of kernel / memset nodes)
+                       # or hipGraphLaunch (PG_FLAT_REPLAY=0, the N > 1 step with its all-reduce captured inside, or a graph that
+                       # is not a chain of kernel / memset nodes)
                        "step_replay": ("plain launches (pg_tape)" if use_graph and any(getattr(s_, "tape", None) is not None
                                                                                          for s_ in trainer.slots.values())
                                        else ("hipGraphLaunch" if use_graph else "eager")),

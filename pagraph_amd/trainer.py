@@ -250,6 +250,7 @@ class GraphedTrainer:
         # PG_GRAPH_ALLREDUCE=0 forces the eager collective.
         import os as _os
         self.allreduce_in_graph = False if _os.environ.get("PG_GRAPH_ALLREDUCE") == "0" else None
+        self.tape_collectives = False   # replay a captured step that holds an all-reduce as plain launches too? (_tape_of)
         # world > 1: EVERY eager collective of this trainer runs on a communication stream of its own, ordered with the compute
         # stream by wait_stream, never on the compute stream itself. ProcessGroupNCCL's watchdog thread polls the end event of
         # each eager collective until it has completed; on ROCm an event query fails with hipErrorCapturedEvent as soon as the
@@ -717,12 +718,13 @@ class GraphedTrainer:
     def _flat_wanted(self):
         """replay a captured step as its kernels launched one by one instead of with hipGraphLaunch: between two graph replays
         the stream idles ~12 us, between two dependent kernels of one stream ~3.4 us. N > 1 (round 6): the same — when every node
-        of the captured step is a plain kernel / memset launch (pg_tape_from_graph refuses anything else: a captured RCCL
-        collective that is not one stays inside hipGraphLaunch). PG_FLAT_REPLAY=0 keeps the graph launch."""
+        of the captured step is a plain kernel / memset launch (pg_tape_from_graph refuses anything else) and the graph holds no
+        collective (_tape_of): with the all-reduce in the graph the step is one hipGraphLaunch, with the eager all-reduce it is
+        tape A, the collective, tape B. PG_FLAT_REPLAY=0 keeps the graph launch everywhere."""
         import os as _os
         return _os.environ.get("PG_FLAT_REPLAY", "1") != "0"
 
-    def _tape_of(self, graph):
+    def _tape_of(self, graph, holds_collective=False):
         """(tape or None, executed) for a freshly captured torch.cuda.CUDAGraph(keep_graph=True) on the CURRENT stream.
         The graph is replayed ONCE through torch (executed = True) with the default generator's Philox offset read on both
         sides: CUDAGraph.replay() refills the seed / offset tensors of every RNG kernel the capture holds and advances the
@@ -730,6 +732,12 @@ class GraphedTrainer:
         model with fuse_dropout=False, a user's loss) would draw the SAME numbers on every replay. A capture
         that consumed torch RNG therefore keeps hipGraphLaunch; so does one with a node that is not a plain launch."""
         if not self._flat_wanted():
+            return None, False
+        if holds_collective and not self.tape_collectives:
+            # A captured RCCL all-reduce is a kernel node like any other to pg_tape_from_graph, and launching it again with the
+            # node's arguments is what the graph launch does too — but only the graph launch is what RCCL documents and what
+            # _probe_graph_allreduce has verified on THIS group, and no box of rounds 1-6 had a second GPU to try the other on:
+            # the one graph of the step that holds a collective keeps hipGraphLaunch (tape_collectives = True to try).
             return None, False
         executed = False
         try:
@@ -752,7 +760,7 @@ class GraphedTrainer:
 
     def _make_tape(self, s):
         """-> True when the slot's graph has been executed once on the way (the caller then skips its first replay)"""
-        s.tape, executed = self._tape_of(s.graph)
+        s.tape, executed = self._tape_of(s.graph, holds_collective=bool(self.world > 1 and self.allreduce_in_graph))
         return executed
 
     def _replay(self, s, stream):

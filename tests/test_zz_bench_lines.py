@@ -40,7 +40,8 @@ def _rccl_one_rank_worker(rank, port, out_dir):
     # eager: graph A -> all-reduce on the communication stream -> graph B; ingraph: the collective captured in the step;
     # *-unfused: round 5's step shape (flat.zero_(), one ordered sum per weight gradient, AccumulateGrad's add per parameter,
     # hipGraphLaunch) as the checker of round 6's (reduce-only sums straight into the flat buffer, plain launches)
-    for mode in ("eager", "ingraph", "eager-unfused", "ingraph-unfused"):
+    # ingraph-taped: the step that holds the (here empty) collective replayed as plain launches (tape_collectives, opt-in)
+    for mode in ("eager", "ingraph", "ingraph-taped", "eager-unfused", "ingraph-unfused"):
         store = HostFeatureStore({"features": torch.from_numpy(feats)})
         c = GraphCacheServer(store, V, torch.arange(V), 0, miss_mode="async")
         c.init_field(["features"])
@@ -53,6 +54,7 @@ def _rccl_one_rank_worker(rank, port, out_dir):
                               static=True, defer_transpose=True)
         tr = GraphedTrainer(model, torch.nn.CrossEntropyLoss(), opt, c, smp, labels, dev, need=need, world_size=2)
         tr.allreduce_in_graph = mode.startswith("ingraph")
+        tr.tape_collectives = mode == "ingraph-taped"
         if mode.endswith("unfused"):
             tr.fuse_partials = False
             os.environ["PG_FLAT_REPLAY"] = "0"
@@ -84,14 +86,16 @@ def test_graphed_trainer_over_an_rccl_group_survives_its_captures(dev, hiplib, t
     assert torch.isfinite(r["eager"][0]).all() and len(r["eager"][0]) == 30
     assert float(r["eager"][0][-5:].mean()) < float(r["eager"][0][:5].mean())        # it trains
     # round 6: the N > 1 step keeps the one-GPU step's kernels (sums folded into ONE reduce-only launch that writes the flat
-    # gradient buffer) and is replayed as plain launches — the same bits as round 5's shape, which is the checker here
-    for a_, b_ in (("eager", "ingraph"), ("eager", "eager-unfused"), ("ingraph", "ingraph-unfused")):
+    # gradient buffer) — the same bits as round 5's shape, which is the checker here
+    for a_, b_ in (("eager", "ingraph"), ("eager", "eager-unfused"), ("ingraph", "ingraph-unfused"), ("ingraph", "ingraph-taped")):
         assert torch.equal(r[a_][0], r[b_][0]), (a_, b_, r[a_][0], r[b_][0])
         for a, b in zip(r[a_][1], r[b_][1]):
             assert torch.equal(a, b), (a_, b_)
         assert r[a_][5] == r[b_][5]                                                 # optimiser launches
     assert r["eager"][4] == r["ingraph"][4]                                         # dropout counter
-    assert r["eager"][3] and all(r["eager"][3]) and all(r["ingraph"][3])              # taped (a one-rank all-reduce is no node)
+    # graph A of the eager shape is a tape; the step that holds the all-reduce keeps hipGraphLaunch — the replay RCCL documents
+    # and the trainer's probe verifies on the group — unless asked (a one-rank all-reduce is no node at all: it can be taped here)
+    assert r["eager"][3] and all(r["eager"][3]) and not any(r["ingraph"][3]) and all(r["ingraph-taped"][3])
     assert not any(r["eager-unfused"][3])
 
 
