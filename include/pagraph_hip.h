@@ -756,7 +756,7 @@ int pg_dg_partition_mt(int64_t V, const int64_t* indptr, const int32_t* indices,
  * list buffers of max(V, 48M) entries) and frees it before returning. PG_ERR_UNSUPPORTED (fall back to pg_dg_partition_mt):
  * P > 16, hops > 2, V >= 2^28, train ids not strictly ascending. Synchronises `stream`.                         */
 typedef struct pg_dg_gpu_stats {
-  int64_t batches, batches_redone, largest_batch, fresh_entries, corr_entries, workgroups, candidate_misses;
+  int64_t batches, batches_redone, largest_batch, fresh_entries, corr_entries, workgroups, candidate_misses, second_walks;
   double seconds_total, seconds_expand, seconds_lists, seconds_commit, seconds_apply;
 } pg_dg_gpu_stats_t;
 int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const int32_t* indices_dev, const int64_t* train_nids,

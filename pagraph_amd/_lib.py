@@ -133,7 +133,7 @@ class PgAdamDesc(ctypes.Structure):
 
 
 class PgDgGpuStats(ctypes.Structure):
-    _fields_ = [(n, c_i64) for n in ("batches", "batches_redone", "largest_batch", "fresh_entries", "corr_entries", "workgroups", "candidate_misses")] + \
+    _fields_ = [(n, c_i64) for n in ("batches", "batches_redone", "largest_batch", "fresh_entries", "corr_entries", "workgroups", "candidate_misses", "second_walks")] + \
                [(n, ctypes.c_double) for n in ("seconds_total", "seconds_expand", "seconds_lists", "seconds_commit", "seconds_apply")]
 
 

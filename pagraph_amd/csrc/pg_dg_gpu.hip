@@ -20,8 +20,15 @@
 // hubs' sets are the whole graph and every partition lacks all of it); the batch doubles while the lists stay small, and a
 // batch whose lists overflow their buffers is simply redone at half the size.
 //
-// De-duplication of a two-hop multiset: one V-bit bitmap per workgroup in HBM (atomicOr returns "was it new"), cleared by
-// walking the same lists again. 288 GB of HBM pays for a few hundred private bitmaps even at 10^8 vertices (12.5 MB each).
+// De-duplication of a two-hop multiset: one bitmap per workgroup in HBM — 288 GB pays for a few hundred private ones even at
+// 10^8 vertices (25 MB each). The expansion is bound by exactly that traffic: a multiset is sparse in the id space (mean 7 000
+// entries, 10^8 ids), so every entry costs one 128-byte line (PMC: 117 B fetched + 27 B written per entry visit,
+// profiles/r06/dg_gpu_expand_pmc.txt). The first version walked every multiset twice — once to set bits and count, once more to
+// clear them and list the fresh members — and paid that line twice. Now a word holds 16 members under a 16-bit GENERATION tag
+// (the workgroup's count of multisets so far): a word whose tag is stale counts as empty, nothing is ever cleared (a wrap of
+// the tag, every 65 000 multisets of a workgroup, zeroes its bitmap), and the members that lack some partition are put aside
+// during the one walk (a per-workgroup scratch list) and filtered by the candidates afterwards. A vertex whose list does not
+// fit the scratch takes the second walk under the next generation.
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
@@ -47,10 +54,14 @@ struct DgExpandArgs {
   int32_t n;                  // batch size
   int32_t P;
   int32_t hops;
-  const int8_t* bel;          // snapshot of belongs: >= 0 partition, -1 unassigned, -2 member of this batch
-  const uint16_t* rmask;      // snapshot: bit p = the vertex is in r_belongs[p]
-  uint32_t* pool;             // gridDim.x de-duplication bitmaps
+  const uint32_t* state;      // the snapshot, one word per vertex (ONE random read per member instead of two): bits 0-15: bit p =
+                              // the vertex is in r_belongs[p]; bits 16-23: belongs as int8 (>= 0 partition, -1 unassigned,
+                              // -2 member of this batch)
+  uint32_t* pool;             // gridDim.x de-duplication bitmaps: 16 members per word under a 16-bit generation tag
   int64_t words;              // uint32 words per bitmap
+  uint32_t* gens;             // [gridDim.x] the generation each workgroup's bitmap is at (kept across launches)
+  unsigned long long* scratch;    // [gridDim.x][scr_cap] members of the current multiset that lack a partition: vertex << 16 | mask
+  uint32_t scr_cap;
   int32_t* com0;              // [n][P]
   uint16_t* cand;             // [n] the partitions whose fresh members are listed for the vertex (see candidates())
   float a[kMaxP];             // (avg - p_vnum[p]) / (r_vnum[p] + 1) at the batch's start (dg.py:54-55 without com)
@@ -59,8 +70,26 @@ struct DgExpandArgs {
   unsigned long long* fresh;  // keys: batch index << 44 | vertex << 16 | mask
   unsigned long long* corr;   // keys: batch index << 32 | vertex
   unsigned long long cap_fresh, cap_corr;
-  unsigned long long* counters;   // [0] fresh, [1] corr, [2] next batch index
+  unsigned long long* counters;   // [0] fresh, [1] corr, [2] next batch index, [3] multisets walked twice
 };
+
+constexpr uint32_t kGenWrap = 0xFFF0u;     // a bitmap is zeroed when its generation gets here (two are used per vertex at most)
+constexpr uint32_t kGenStart = 0xFF00u;    // where a run starts: every workgroup wraps early — the tests walk that path too
+
+// first visit of member w in generation `gen`? (sets its bit; a word with another tag is an empty word)
+__device__ __forceinline__ bool first_visit(uint32_t* bm, uint32_t gen, int32_t w) {
+  uint32_t* p = bm + ((uint32_t)w >> 4);
+  const uint32_t bit = 1u << (w & 15), tag = gen << 16;
+  // (not from the CU's own cache: the line may still be there as an earlier multiset left it)
+  uint32_t cur = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (;;) {
+    const uint32_t base = (cur & 0xFFFF0000u) == tag ? cur : tag;
+    if (base & bit) return false;
+    const uint32_t seen = atomicCAS(p, cur, base | bit);
+    if (seen == cur) return true;
+    cur = seen;
+  }
+}
 
 __device__ __forceinline__ void emit(unsigned long long* buf, unsigned long long* counter, unsigned long long cap, bool pred,
                                      unsigned long long key) {
@@ -77,38 +106,46 @@ __device__ __forceinline__ void emit(unsigned long long* buf, unsigned long long
   }
 }
 
-// pass 1, one member of the multiset: first visit -> which partition the snapshot has it in, or is it a batch member
+// the walk, one member of the multiset: first visit -> which partition the snapshot has it in, or is it a batch member; a
+// member some partition's redundancy set lacks is put aside with the mask of those partitions
 template <bool DEDUP>
-__device__ __forceinline__ void visit1(const DgExpandArgs& a, uint32_t* bm, int32_t* s_com, int32_t i, int64_t v, bool live,
-                                       int32_t w) {
+__device__ __forceinline__ void visit1(const DgExpandArgs& a, uint32_t* bm, uint32_t gen, int32_t* s_com, uint32_t* s_nscr,
+                                       unsigned long long* scr, uint16_t full, int32_t i, int64_t v, bool live, int32_t w) {
   bool first = live;
-  if (DEDUP && live) {
-    const uint32_t bit = 1u << (w & 31);
-    first = !(atomicOr(&bm[w >> 5], bit) & bit);
-  }
+  if (DEDUP && live) first = first_visit(bm, gen, w);
   int8_t b = -1;
+  uint16_t lacks = 0;
   if (first) {
-    b = a.bel[w];
+    const uint32_t st = a.state[w];
+    b = (int8_t)(st >> 16);
     if (b >= 0) atomicAdd(&s_com[b], 1);
+    lacks = (uint16_t)(~st) & full;
   }
   const bool pending = first && b == -2 && (int64_t)w < v;
   if (pending) atomicAdd(&s_com[kMaxP], 1);
   emit(a.corr, a.counters + 1, a.cap_corr, pending, ((unsigned long long)i << 32) | (uint32_t)w);
+  const unsigned long long m = __ballot(lacks != 0);
+  if (m) {
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(s_nscr, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    if (lacks) {
+      const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (at < a.scr_cap) scr[at] = ((unsigned long long)(uint32_t)w << 16) | lacks;
+    }
+  }
 }
 
-// pass 2: the member leaves the bitmap (whoever finds its bit still set clears it; two lanes may both find it — a duplicate
-// entry, which the host's test-and-set and k_dg_apply's atomicOr absorb) and is listed if a CANDIDATE partition lacks it
+// the second walk of a multiset whose list did not fit the scratch, under a generation of its own: every member is met for
+// the first time again, and is listed if a CANDIDATE partition lacks it
 template <bool DEDUP>
-__device__ __forceinline__ void visit2(const DgExpandArgs& a, uint32_t* bm, int32_t i, bool live, int32_t w, uint16_t cand) {
+__device__ __forceinline__ void visit2(const DgExpandArgs& a, uint32_t* bm, uint32_t gen, int32_t i, bool live, int32_t w,
+                                       uint16_t cand) {
   bool first = live;
-  if (DEDUP && live) {
-    const uint32_t bit = 1u << (w & 31);
-    // (a load that cannot be served from the CU's own cache: the line may still show the bit as the previous vertex left it)
-    first = (__hip_atomic_load(&bm[w >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) != 0u;
-    if (first) atomicAnd(&bm[w >> 5], ~bit);
-  }
+  if (DEDUP && live) first = first_visit(bm, gen, w);
   uint16_t miss = 0;
-  if (first) miss = (uint16_t)(~a.rmask[w]) & cand;
+  if (first) miss = (uint16_t)(~a.state[w]) & cand;
   emit(a.fresh, a.counters + 0, a.cap_fresh, miss != 0,
        ((unsigned long long)i << 44) | ((unsigned long long)(uint32_t)w << 16) | miss);
 }
@@ -178,18 +215,37 @@ __global__ __launch_bounds__(kDgThreads) void k_dg_expand(const DgExpandArgs a) 
   __shared__ int32_t s_long[kLongQueue];
   __shared__ int32_t s_nlong;
   __shared__ int32_t s_i;
+  __shared__ uint32_t s_nscr;
   __shared__ uint16_t s_cand;
   uint32_t* bm = a.pool + (size_t)blockIdx.x * (size_t)a.words;
+  unsigned long long* scr = a.scratch + (size_t)blockIdx.x * (size_t)a.scr_cap;
   const uint16_t full = (uint16_t)((1u << a.P) - 1u);
+  uint32_t gen = a.gens[blockIdx.x];            // (every thread keeps the same count)
   for (;;) {
-    if (threadIdx.x == 0) s_i = (int32_t)atomicAdd(a.counters + 2, 1ull);
+    if (threadIdx.x == 0) {
+      s_i = (int32_t)atomicAdd(a.counters + 2, 1ull);
+      s_nscr = 0;
+    }
     if (threadIdx.x <= kMaxP) s_com[threadIdx.x] = 0;
     __syncthreads();
     const int32_t i = s_i;
-    if (i >= a.n) return;
+    if (i >= a.n) break;
+    if (a.hops >= 2) {
+      if (gen >= kGenWrap) {
+        // the tag wraps: an empty bitmap, tag 0 (no generation has it)
+        for (int64_t q = threadIdx.x; q < a.words; q += kDgThreads)
+          __hip_atomic_store(&bm[q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        __syncthreads();
+        gen = 0;
+      }
+      ++gen;
+    }
     const int64_t v = a.bv[i];
-    if (a.hops >= 2) walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { visit1<true>(a, bm, s_com, i, v, live, w); });
-    else walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { visit1<false>(a, bm, s_com, i, v, live, w); });
+    if (a.hops >= 2)
+      walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { visit1<true>(a, bm, gen, s_com, &s_nscr, scr, full, i, v, live, w); });
+    else
+      walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { visit1<false>(a, bm, gen, s_com, &s_nscr, scr, full, i, v, live, w); });
     __syncthreads();
     if (threadIdx.x == 0) {
       s_cand = candidates(a, s_com, i, full);
@@ -198,27 +254,43 @@ __global__ __launch_bounds__(kDgThreads) void k_dg_expand(const DgExpandArgs a) 
     if (threadIdx.x < a.P) a.com0[(size_t)i * a.P + threadIdx.x] = s_com[threadIdx.x];
     __syncthreads();
     const uint16_t cand = s_cand;
-    // the second walk empties the bitmap the way it was filled (the words of a two-hop set are scattered: a memset of 12.5 MB per
-    // vertex at 10^8 vertices would cost more) and lists the members the candidates lack
-    if (a.hops >= 2) walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { visit2<true>(a, bm, i, live, w, cand); });
-    else walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { visit2<false>(a, bm, i, live, w, cand); });
+    const uint32_t ns = s_nscr;
+    if (ns <= a.scr_cap) {
+      // the members put aside, filtered by the candidates
+      for (uint32_t q = threadIdx.x; q - threadIdx.x < ns; q += kDgThreads) {
+        const bool live = q < ns;
+        const unsigned long long e = live ? scr[q] : 0ull;
+        const uint16_t miss = (uint16_t)(e & 0xFFFFull) & cand;
+        emit(a.fresh, a.counters + 0, a.cap_fresh, miss != 0, ((unsigned long long)i << 44) | (e & ~0xFFFFull) | miss);
+      }
+    } else {
+      if (threadIdx.x == 0) atomicAdd(a.counters + 3, 1ull);
+      if (a.hops >= 2) {
+        ++gen;                                   // (kGenWrap leaves room for it)
+        walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { visit2<true>(a, bm, gen, i, live, w, cand); });
+      } else {
+        walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { visit2<false>(a, bm, gen, i, live, w, cand); });
+      }
+    }
     __syncthreads();
   }
+  if (threadIdx.x == 0) a.gens[blockIdx.x] = gen;
 }
 
-__global__ void k_dg_mark(const int64_t* bv, int32_t n, int8_t* bel, int8_t value) {
+__global__ void k_dg_mark(const int64_t* bv, int32_t n, uint32_t* state, int8_t value) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) bel[bv[i]] = value;
+  if (i < n) state[bv[i]] = (state[bv[i]] & 0xFF00FFFFu) | ((uint32_t)(uint8_t)value << 16);
 }
 
 // the batch's decisions applied to the snapshot: belongs, and r_belongs[ind] |= N(v) + {v} from the fresh lists themselves
 __global__ void k_dg_apply(const int64_t* bv, const int8_t* ind, int32_t n, const unsigned long long* fresh,
-                           unsigned long long n_fresh, int8_t* bel, uint16_t* rmask) {
+                           unsigned long long n_fresh, uint32_t* state) {
   const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < (unsigned long long)n) {
+    // (other threads set low bits of the same word meanwhile: two atomics, neither touches what the other writes)
     const int64_t v = bv[t];
-    bel[v] = ind[t];
-    atomicOr((unsigned int*)(rmask + (v & ~1ll)), (unsigned int)(1u << ind[t]) << ((v & 1) * 16));
+    atomicAnd(&state[v], 0xFF00FFFFu);
+    atomicOr(&state[v], ((uint32_t)(uint8_t)ind[t] << 16) | (1u << ind[t]));
   }
   for (unsigned long long q = t; q < n_fresh; q += (unsigned long long)gridDim.x * blockDim.x) {
     const unsigned long long k = fresh[q];
@@ -226,7 +298,7 @@ __global__ void k_dg_apply(const int64_t* bv, const int8_t* ind, int32_t n, cons
     if (i >= n) continue;                      // (the batch ended in front of this vertex: its lists are dropped)
     const int64_t u = (int64_t)((k >> 16) & 0xFFFFFFFull);
     const uint32_t bit = 1u << ind[i];
-    if ((uint32_t)(k & 0xFFFFu) & bit) atomicOr((unsigned int*)(rmask + (u & ~1ll)), bit << ((u & 1) * 16));
+    if ((uint32_t)(k & 0xFFFFu) & bit) atomicOr(&state[u], bit);
   }
 }
 
@@ -268,19 +340,27 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
   int dev = 0, cus = 0;
   PG_HIP(hipGetDevice(&dev));
   PG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  const int64_t words = (V + 31) / 32;
+  const int64_t words = (V + 15) / 16;
   // bitmaps: up to 4 workgroups per CU, at most ~16 GB of them
   // (2, 4 or 8 workgroups per CU expand at the same rate: profiles/r06/dg_gpu_sweep.txt)
   int n_wg = hops >= 2 ? cus * 4 : cus * 8;
   if (hops >= 2) n_wg = (int)std::max<int64_t>(cus, std::min<int64_t>(n_wg, (16ll << 30) / (words * 4)));
-  const int32_t b_max = 1 << 16;
+  // the scratch list of a multiset's members that lack a partition: V / 256 entries (a larger list: second walk), so that
+  // small graphs — the tests' — take both paths
+  const uint32_t scr_cap = (uint32_t)std::min<int64_t>(512 << 10, std::max<int64_t>(16, V / 256));
+  const int32_t b_max = 1 << 15;       // (8 192 / 16 384 / 32 768 / 65 536: 108 / 95 / 93 / 97-100 s at 10^8 vertices; 6.0 / 5.5 / - / 6.2-6.4 s at 10^7)
   const unsigned long long cap_fresh = (unsigned long long)std::max<int64_t>(V + 4096, 48ll << 20);
   const unsigned long long cap_corr = 16ull << 20;
 
-  DevBuf d_bel, d_rmask, d_pool, d_bv, d_com0, d_cand, d_fresh, d_fresh2, d_corr, d_corr2, d_cnt, d_ind, d_tmp;
+  DevBuf d_gens, d_scratch;
+  if (d_gens.alloc((size_t)n_wg * 4) || d_scratch.alloc((size_t)n_wg * scr_cap * 8)) return PG_ERR_NOMEM;
+  {
+    std::vector<uint32_t> g0((size_t)n_wg, kGenStart);
+    PG_HIP(hipMemcpy(d_gens.p, g0.data(), (size_t)n_wg * 4, hipMemcpyHostToDevice));
+  }
+  DevBuf d_state, d_pool, d_bv, d_com0, d_cand, d_fresh, d_fresh2, d_corr, d_corr2, d_cnt, d_ind, d_tmp;
   HostBuf h_fresh, h_corr, h_com0, h_cand, h_cnt, h_bv, h_ind;
-  const size_t rmask_elems = (size_t)((V + 1) & ~1ll);
-  if (d_bel.alloc((size_t)V) || d_rmask.alloc(rmask_elems * 2) || d_pool.alloc(hops >= 2 ? (size_t)n_wg * words * 4 : 4) ||
+  if (d_state.alloc((size_t)V * 4) || d_pool.alloc(hops >= 2 ? (size_t)n_wg * words * 4 : 4) ||
       d_bv.alloc((size_t)b_max * 8) || d_com0.alloc((size_t)b_max * P * 4) || d_cand.alloc((size_t)b_max * 2) || d_fresh.alloc(cap_fresh * 8) ||
       d_fresh2.alloc(cap_fresh * 8) || d_corr.alloc(cap_corr * 8) || d_corr2.alloc(cap_corr * 8) || d_cnt.alloc(32) ||
       d_ind.alloc((size_t)b_max))
@@ -296,8 +376,7 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
     tmp_bytes = std::max(tmp_bytes, tb2);
   }
   if (d_tmp.alloc(tmp_bytes)) return PG_ERR_NOMEM;
-  PG_HIP(hipMemsetAsync(d_bel.p, 0xFF, (size_t)V, st));
-  PG_HIP(hipMemsetAsync(d_rmask.p, 0, rmask_elems * 2, st));
+  PG_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_state.p), 0x00FF0000, (size_t)V, st));      // unassigned, in no set
   if (hops >= 2) PG_HIP(hipMemsetAsync(d_pool.p, 0, (size_t)n_wg * words * 4, st));
 
   // host state (exact): dg.py:62-66
@@ -318,10 +397,11 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
     const double t0 = now_s();
     PG_HIP(hipMemcpyAsync(d_bv.p, h_bv.p, (size_t)b * 8, hipMemcpyHostToDevice, st));
     PG_HIP(hipMemsetAsync(d_cnt.p, 0, 32, st));
-    hipLaunchKernelGGL(k_dg_mark, dim3((b + 255) / 256), dim3(256), 0, st, d_bv.as<int64_t>(), b, d_bel.as<int8_t>(), (int8_t)-2);
+    hipLaunchKernelGGL(k_dg_mark, dim3((b + 255) / 256), dim3(256), 0, st, d_bv.as<int64_t>(), b, d_state.as<uint32_t>(), (int8_t)-2);
     DgExpandArgs a{};
     a.indptr = indptr_dev; a.indices = indices_dev; a.bv = d_bv.as<int64_t>(); a.n = b; a.P = P; a.hops = hops;
-    a.bel = d_bel.as<int8_t>(); a.rmask = d_rmask.as<uint16_t>(); a.pool = d_pool.as<uint32_t>(); a.words = words;
+    a.state = d_state.as<uint32_t>(); a.pool = d_pool.as<uint32_t>(); a.words = words;
+    a.gens = d_gens.as<uint32_t>(); a.scratch = d_scratch.as<unsigned long long>(); a.scr_cap = scr_cap;
     a.cand = d_cand.as<uint16_t>();
     {
       // dg.py:54-55 without com, as of now; near the end of the run (avg - p_vnum within a few batches of zero, or past it)
@@ -342,12 +422,13 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
     PG_HIP(hipMemcpyAsync(h_cnt.p, d_cnt.p, 32, hipMemcpyDeviceToHost, st));
     PG_HIP(hipStreamSynchronize(st));
     const unsigned long long n_fresh = h_cnt.as<unsigned long long>()[0], n_corr = h_cnt.as<unsigned long long>()[1];
+    s.second_walks += (int64_t)h_cnt.as<unsigned long long>()[3];
     s.seconds_expand += now_s() - t0;
     ++s.batches;
 
     if (n_fresh > cap_fresh || n_corr > cap_corr) {
       // the lists did not fit: the same vertices again in a smaller batch (one vertex always fits: cap_fresh > V)
-      hipLaunchKernelGGL(k_dg_mark, dim3((b + 255) / 256), dim3(256), 0, st, d_bv.as<int64_t>(), b, d_bel.as<int8_t>(), (int8_t)-1);
+      hipLaunchKernelGGL(k_dg_mark, dim3((b + 255) / 256), dim3(256), 0, st, d_bv.as<int64_t>(), b, d_state.as<uint32_t>(), (int8_t)-1);
       ++s.batches_redone;
       if (b == 1) return PG_ERR_UNSUPPORTED;        // (cannot happen: see cap_fresh / a single vertex has no corr entries)
       bsz = std::max(1, b / 2);
@@ -414,6 +495,11 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
       int64_t fresh = 0;
       const unsigned long long bit = 1ull << ind;
       for (; qf < n_fresh && (int32_t)(hf[qf] >> 44) == i; ++qf) {
+        // (the list streams; the bitmap word it names does not: 12.5 MB per partition at 10^8 vertices, touched at random)
+        if (qf + 32 < n_fresh) {
+          const unsigned long long ka = hf[qf + 32];
+          if (ka & bit) __builtin_prefetch(&rb[((ka >> 16) & 0xFFFFFFFull) >> 6], 1, 1);
+        }
         const unsigned long long k = hf[qf];
         if (!(k & bit)) continue;
         const uint64_t u = (k >> 16) & 0xFFFFFFFull;
@@ -439,12 +525,12 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
     PG_HIP(hipMemcpyAsync(d_ind.p, h_ind.p, (size_t)done, hipMemcpyHostToDevice, st));
     if (done < b)
       hipLaunchKernelGGL(k_dg_mark, dim3((b - done + 255) / 256), dim3(256), 0, st, d_bv.as<int64_t>() + done, b - done,
-                         d_bel.as<int8_t>(), (int8_t)-1);
+                         d_state.as<uint32_t>(), (int8_t)-1);
     {
       const unsigned long long work = std::max<unsigned long long>(n_fresh, (unsigned long long)done);
       const unsigned grid = (unsigned)std::min<unsigned long long>((work + 255) / 256, 1u << 16);
       hipLaunchKernelGGL(k_dg_apply, dim3(grid), dim3(256), 0, st, d_bv.as<int64_t>(), d_ind.as<int8_t>(), done, fr, n_fresh,
-                         d_bel.as<int8_t>(), d_rmask.as<uint16_t>());
+                         d_state.as<uint32_t>());
       PG_LAUNCH_CHECK();
     }
     PG_HIP(hipStreamSynchronize(st));        // (h_ind / h_bv are reused by the next batch)

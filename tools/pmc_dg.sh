@@ -15,5 +15,7 @@ def tot(path, name):
 f, n, d = tot("/tmp/pmcdg_FETCH_SIZE/p_counter_collection.csv", "FETCH_SIZE")
 w, n2, d2 = tot("/tmp/pmcdg_WRITE_SIZE/p_counter_collection.csv", "WRITE_SIZE")
 print("k_dg_expand launches", n, "fetch GB (x2 corrected)", 2 * f * 1024 / 1e9, "write GB", w * 1024 / 1e9, "kernel seconds", d / 1e9, d2 / 1e9)
-print("per multiset entry (4.7259e10 x 2 walks): fetch B", 2 * f * 1024 / 9.45e10, "write B", w * 1024 / 9.45e10)
+# entries of the TRAIN vertices' two-hop multisets on the 10M / 100M graph: 3.085e10 (tools/exp_dg_multiset_shape.py); one walk
+# each since the generation-tagged bitmaps (the few multisets whose put-aside list overflows are walked twice)
+print("per multiset entry (3.085e10, one walk): fetch B", 2 * f * 1024 / 3.085e10, "write B", w * 1024 / 3.085e10)
 EOF
