@@ -10,13 +10,17 @@
 //
 //   com0[v][p]   = |{u in N(v) : u assigned to p in the snapshot}|                       (dg.py:47-50, the settled part)
 //   corr(v)      = the members of N(v) that belong to THIS batch and precede v            (assigned between snapshot and v's turn)
-//   fresh(v)     = {(u, m) : u in N(v), m = the partitions whose redundancy set lacked u in the snapshot, m != 0}
+//   fresh(v, p)  = {u in N(v) : the redundancy set of partition p lacked u in the snapshot}, for the CANDIDATE partitions p of v
 //
 // The host then walks the batch in train order with the reference's float64 score and numpy's argsort (pg_np_argsort_f64):
 // com[p] = 1 + com0[v][p] + |{u in corr(v) : belongs[u] == p}|; after the arg-max, r_vnum[ind] grows by the members of
-// fresh(v) whose mask has bit `ind` and that are still missing from the HOST's exact r_belongs[ind] bitmap (test-and-set) —
-// fresh(v) is a superset of N(v) \ r_belongs[ind] whatever the snapshot's age, so the count is exact. The decisions go back,
-// and one kernel applies them to the snapshot from the same lists (no second expansion). Early batches are tiny (the first
+// fresh(v, ind) that are still missing from the HOST's exact r_belongs[ind] bitmap (test-and-set) — fresh(v, ind) is a
+// superset of N(v) \ r_belongs[ind] whatever the snapshot's age, so the count is exact. Every (vertex, candidate partition)
+// pair has a list of its own — a range the vertex's workgroup reserves in that partition's buffer, after counting, with ONE
+// atomic per partition — and the host reads the one list it needs per vertex (RMAT has no communities: four vertices of five
+// have more than one candidate, and the partitions that lose lack far more members than the one that wins — 95 % of the
+// entries are never looked at; nothing is sorted). The decisions go back, and one kernel applies them to the snapshot
+// from the same lists (no second expansion). Early batches are tiny (the first
 // hubs' sets are the whole graph and every partition lacks all of it); the batch doubles while the lists stay small, and a
 // batch whose lists overflow their buffers is simply redone at half the size.
 //
@@ -43,7 +47,7 @@ using namespace pg;
 namespace {
 
 constexpr int kDgThreads = 256;
-constexpr int kMaxP = 16;              // the fresh-list key packs the partition mask into 16 bits
+constexpr int kMaxP = 16;              // a member's partition mask is 16 bits wide (scratch entries, the state word)
 constexpr int kLongQueue = 1024;       // such lists queued per vertex (more: the finding wave walks them itself)
 constexpr int kLongList = 1024;        // adjacency lists above this are walked by the whole workgroup, the others per wave
 
@@ -67,11 +71,14 @@ struct DgExpandArgs {
   float a[kMaxP];             // (avg - p_vnum[p]) / (r_vnum[p] + 1) at the batch's start (dg.py:54-55 without com)
   float theta;                // a partition is a candidate when its best possible score >= theta x the best certain one
   int32_t all_candidates;     // 1: every partition for every vertex (near the end of the run, when a[] moves fast)
-  unsigned long long* fresh;  // keys: batch index << 44 | vertex << 16 | mask
+  uint32_t* fresh;            // [P][cap_fresh] members; fresh(v, p) = fresh[p][fbase[v][p] .. + fcnt[v][p])
+  uint32_t* fcnt;             // [n][P]
+  uint32_t* fbase;            // [n][P]
   unsigned long long* corr;   // keys: batch index << 32 | vertex
   unsigned long long cap_fresh, cap_corr;
-  unsigned long long* counters;   // [0] fresh, [1] corr, [2] next batch index, [3] multisets walked twice
+  unsigned long long* counters;   // [1] corr, [2] next batch index, [3] multisets walked again, [4 + p] entries on partition p's lists
 };
+constexpr int kCounters = 4 + 16;
 
 constexpr uint32_t kGenWrap = 0xFFF0u;     // a bitmap is zeroed when its generation gets here (two are used per vertex at most)
 constexpr uint32_t kGenStart = 0xFF00u;    // where a run starts: every workgroup wraps early — the tests walk that path too
@@ -111,16 +118,23 @@ __device__ __forceinline__ void emit(unsigned long long* buf, unsigned long long
 template <bool DEDUP>
 __device__ __forceinline__ void visit1(const DgExpandArgs& a, uint32_t* bm, uint32_t gen, int32_t* s_com, uint32_t* s_nscr,
                                        unsigned long long* scr, uint16_t full, int32_t i, int64_t v, bool live, int32_t w) {
-  bool first = live;
-  if (DEDUP && live) first = first_visit(bm, gen, w);
+  // the snapshot first: a member that is neither assigned nor of this batch and that every partition's set already holds
+  // contributes nothing — it needs no de-duplication either, and its bitmap line is never touched (late in a run that is
+  // every vertex outside the train set and most of the rest)
   int8_t b = -1;
   uint16_t lacks = 0;
-  if (first) {
+  if (live) {
     const uint32_t st = a.state[w];
     b = (int8_t)(st >> 16);
-    if (b >= 0) atomicAdd(&s_com[b], 1);
     lacks = (uint16_t)(~st) & full;
   }
+  bool first = live && (b != -1 || lacks != 0);
+  if (DEDUP && first) first = first_visit(bm, gen, w);
+  if (!first) {
+    b = -1;
+    lacks = 0;
+  }
+  if (b >= 0) atomicAdd(&s_com[b], 1);
   const bool pending = first && b == -2 && (int64_t)w < v;
   if (pending) atomicAdd(&s_com[kMaxP], 1);
   emit(a.corr, a.counters + 1, a.cap_corr, pending, ((unsigned long long)i << 32) | (uint32_t)w);
@@ -137,17 +151,43 @@ __device__ __forceinline__ void visit1(const DgExpandArgs& a, uint32_t* bm, uint
   }
 }
 
-// the second walk of a multiset whose list did not fit the scratch, under a generation of its own: every member is met for
-// the first time again, and is listed if a CANDIDATE partition lacks it
+// fresh(v, p), in two rounds over the members (both wave-uniform). tally: how many members does candidate p lack?
+__device__ __forceinline__ void tally(int P, uint16_t cand, uint16_t miss, uint32_t* s_fcnt) {
+  if (!__ballot(miss != 0)) return;
+  for (int p = 0; p < P; ++p) {
+    if (!((cand >> p) & 1)) continue;
+    const unsigned long long m = __ballot((miss >> p) & 1);
+    if (m && (threadIdx.x & 63) == 0) atomicAdd(&s_fcnt[p], (uint32_t)__popcll(m));
+  }
+}
+// place: the member goes into the range the vertex has reserved on each of those partitions' buffers
+__device__ __forceinline__ void place(const DgExpandArgs& a, uint16_t cand, uint16_t miss, int32_t w, uint32_t* s_pos,
+                                      const unsigned long long* s_base) {
+  if (!__ballot(miss != 0)) return;
+  const int lane = threadIdx.x & 63;
+  for (int p = 0; p < a.P; ++p) {
+    if (!((cand >> p) & 1)) continue;
+    const bool pred = (miss >> p) & 1;
+    const unsigned long long m = __ballot(pred);
+    if (!m) continue;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t off = 0;
+    if (lane == leader) off = atomicAdd(&s_pos[p], (uint32_t)__popcll(m));
+    off = __shfl(off, leader);
+    if (pred) {
+      const unsigned long long at = s_base[p] + off + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+      if (at < a.cap_fresh) a.fresh[(size_t)p * a.cap_fresh + at] = (uint32_t)w;
+    }
+  }
+}
+
+// the walks of a multiset whose put-aside list did not fit the scratch, each under a generation of its own (every member is
+// met for the first time again): which candidates lack the member?
 template <bool DEDUP>
-__device__ __forceinline__ void visit2(const DgExpandArgs& a, uint32_t* bm, uint32_t gen, int32_t i, bool live, int32_t w,
-                                       uint16_t cand) {
-  bool first = live;
-  if (DEDUP && live) first = first_visit(bm, gen, w);
-  uint16_t miss = 0;
-  if (first) miss = (uint16_t)(~a.state[w]) & cand;
-  emit(a.fresh, a.counters + 0, a.cap_fresh, miss != 0,
-       ((unsigned long long)i << 44) | ((unsigned long long)(uint32_t)w << 16) | miss);
+__device__ __forceinline__ uint16_t revisit(const DgExpandArgs& a, uint32_t* bm, uint32_t gen, bool live, int32_t w, uint16_t cand) {
+  const uint16_t miss = live ? (uint16_t)((uint16_t)(~a.state[w]) & cand) : (uint16_t)0;
+  if (DEDUP && miss != 0 && !first_visit(bm, gen, w)) return 0;
+  return miss;
 }
 
 // Which partitions can still win vertex i (dg.py:51-55,30-35)? score[p] = com[p] * a[p] with com[p] between 1 + com0[p] and
@@ -216,6 +256,8 @@ __global__ __launch_bounds__(kDgThreads) void k_dg_expand(const DgExpandArgs a) 
   __shared__ int32_t s_nlong;
   __shared__ int32_t s_i;
   __shared__ uint32_t s_nscr;
+  __shared__ uint32_t s_fcnt[kMaxP], s_pos[kMaxP];
+  __shared__ unsigned long long s_base[kMaxP];
   __shared__ uint16_t s_cand;
   uint32_t* bm = a.pool + (size_t)blockIdx.x * (size_t)a.words;
   unsigned long long* scr = a.scratch + (size_t)blockIdx.x * (size_t)a.scr_cap;
@@ -227,6 +269,7 @@ __global__ __launch_bounds__(kDgThreads) void k_dg_expand(const DgExpandArgs a) 
       s_nscr = 0;
     }
     if (threadIdx.x <= kMaxP) s_com[threadIdx.x] = 0;
+    if (threadIdx.x < kMaxP) s_fcnt[threadIdx.x] = 0;
     __syncthreads();
     const int32_t i = s_i;
     if (i >= a.n) break;
@@ -255,22 +298,42 @@ __global__ __launch_bounds__(kDgThreads) void k_dg_expand(const DgExpandArgs a) 
     __syncthreads();
     const uint16_t cand = s_cand;
     const uint32_t ns = s_nscr;
-    if (ns <= a.scr_cap) {
-      // the members put aside, filtered by the candidates
-      for (uint32_t q = threadIdx.x; q - threadIdx.x < ns; q += kDgThreads) {
-        const bool live = q < ns;
-        const unsigned long long e = live ? scr[q] : 0ull;
-        const uint16_t miss = (uint16_t)(e & 0xFFFFull) & cand;
-        emit(a.fresh, a.counters + 0, a.cap_fresh, miss != 0, ((unsigned long long)i << 44) | (e & ~0xFFFFull) | miss);
-      }
+    const bool aside = ns <= a.scr_cap;
+    // round 1: the members each candidate lacks, counted
+    if (aside) {
+      for (uint32_t q = threadIdx.x; q - threadIdx.x < ns; q += kDgThreads)
+        tally(a.P, cand, q < ns ? (uint16_t)(scr[q] & 0xFFFFull) & cand : (uint16_t)0, s_fcnt);
     } else {
       if (threadIdx.x == 0) atomicAdd(a.counters + 3, 1ull);
       if (a.hops >= 2) {
-        ++gen;                                   // (kGenWrap leaves room for it)
-        walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { visit2<true>(a, bm, gen, i, live, w, cand); });
+        ++gen;                                   // (kGenWrap leaves room for two more)
+        walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { tally(a.P, cand, revisit<true>(a, bm, gen, live, w, cand), s_fcnt); });
       } else {
-        walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { visit2<false>(a, bm, gen, i, live, w, cand); });
+        walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { tally(a.P, cand, revisit<false>(a, bm, gen, live, w, cand), s_fcnt); });
       }
+    }
+    __syncthreads();
+    // one reservation per partition and vertex
+    if (threadIdx.x < a.P) {
+      const uint32_t c = s_fcnt[threadIdx.x];
+      const unsigned long long base = c ? atomicAdd(a.counters + 4 + threadIdx.x, (unsigned long long)c) : 0ull;
+      s_base[threadIdx.x] = base;
+      s_pos[threadIdx.x] = 0;
+      a.fcnt[(size_t)i * a.P + threadIdx.x] = c;
+      a.fbase[(size_t)i * a.P + threadIdx.x] = (uint32_t)(base < 0xFFFFFFFFull ? base : 0xFFFFFFFFull);
+    }
+    __syncthreads();
+    // round 2: into the reserved ranges
+    if (aside) {
+      for (uint32_t q = threadIdx.x; q - threadIdx.x < ns; q += kDgThreads) {
+        const unsigned long long e = q < ns ? scr[q] : 0ull;
+        place(a, cand, (uint16_t)(e & 0xFFFFull) & cand, (int32_t)(e >> 16), s_pos, s_base);
+      }
+    } else if (a.hops >= 2) {
+      ++gen;
+      walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { place(a, cand, revisit<true>(a, bm, gen, live, w, cand), w, s_pos, s_base); });
+    } else {
+      walk(a, v, s_long, &s_nlong, [&](bool live, int32_t w) { place(a, cand, revisit<false>(a, bm, gen, live, w, cand), w, s_pos, s_base); });
     }
     __syncthreads();
   }
@@ -282,24 +345,21 @@ __global__ void k_dg_mark(const int64_t* bv, int32_t n, uint32_t* state, int8_t 
   if (i < n) state[bv[i]] = (state[bv[i]] & 0xFF00FFFFu) | ((uint32_t)(uint8_t)value << 16);
 }
 
-// the batch's decisions applied to the snapshot: belongs, and r_belongs[ind] |= N(v) + {v} from the fresh lists themselves
-__global__ void k_dg_apply(const int64_t* bv, const int8_t* ind, int32_t n, const unsigned long long* fresh,
-                           unsigned long long n_fresh, uint32_t* state) {
-  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < (unsigned long long)n) {
-    // (other threads set low bits of the same word meanwhile: two atomics, neither touches what the other writes)
-    const int64_t v = bv[t];
+// the batch's decisions applied to the snapshot: belongs, and r_belongs[ind] |= N(v) + {v} from the list of (v, ind) itself.
+// One 64-thread block per decided vertex.
+__global__ __launch_bounds__(64) void k_dg_apply(const int64_t* bv, const int8_t* ind, int32_t P, const uint32_t* fresh,
+                                                 unsigned long long cap_fresh, const uint32_t* fbase, const uint32_t* fcnt,
+                                                 uint32_t* state) {
+  const int32_t i = blockIdx.x, p = ind[i];
+  if (threadIdx.x == 0) {
+    // (other blocks set low bits of the same word meanwhile: two atomics, neither touches what the other writes)
+    const int64_t v = bv[i];
     atomicAnd(&state[v], 0xFF00FFFFu);
-    atomicOr(&state[v], ((uint32_t)(uint8_t)ind[t] << 16) | (1u << ind[t]));
+    atomicOr(&state[v], ((uint32_t)(uint8_t)p << 16) | (1u << p));
   }
-  for (unsigned long long q = t; q < n_fresh; q += (unsigned long long)gridDim.x * blockDim.x) {
-    const unsigned long long k = fresh[q];
-    const int32_t i = (int32_t)(k >> 44);
-    if (i >= n) continue;                      // (the batch ended in front of this vertex: its lists are dropped)
-    const int64_t u = (int64_t)((k >> 16) & 0xFFFFFFFull);
-    const uint32_t bit = 1u << ind[i];
-    if ((uint32_t)(k & 0xFFFFu) & bit) atomicOr(&state[u], bit);
-  }
+  const uint32_t* lst = fresh + (size_t)p * cap_fresh + fbase[(size_t)i * P + p];
+  const uint32_t c = fcnt[(size_t)i * P + p];
+  for (uint32_t q = threadIdx.x; q < c; q += 64) atomicOr(&state[lst[q]], 1u << p);
 }
 
 struct DevBuf {
@@ -349,7 +409,8 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
   // small graphs — the tests' — take both paths
   const uint32_t scr_cap = (uint32_t)std::min<int64_t>(512 << 10, std::max<int64_t>(16, V / 256));
   const int32_t b_max = 1 << 15;       // (8 192 / 16 384 / 32 768 / 65 536: 108 / 95 / 93 / 97-100 s at 10^8 vertices; 6.0 / 5.5 / - / 6.2-6.4 s at 10^7)
-  const unsigned long long cap_fresh = (unsigned long long)std::max<int64_t>(V + 4096, 48ll << 20);
+  // entries per partition's list buffer: a single vertex's lists always fit (|N(v)| <= V each)
+  const unsigned long long cap_fresh = (unsigned long long)std::max<int64_t>(V + 4096, std::min<int64_t>(32ll << 20, 64 * V));
   const unsigned long long cap_corr = 16ull << 20;
 
   DevBuf d_gens, d_scratch;
@@ -358,22 +419,21 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
     std::vector<uint32_t> g0((size_t)n_wg, kGenStart);
     PG_HIP(hipMemcpy(d_gens.p, g0.data(), (size_t)n_wg * 4, hipMemcpyHostToDevice));
   }
-  DevBuf d_state, d_pool, d_bv, d_com0, d_cand, d_fresh, d_fresh2, d_corr, d_corr2, d_cnt, d_ind, d_tmp;
-  HostBuf h_fresh, h_corr, h_com0, h_cand, h_cnt, h_bv, h_ind;
+  DevBuf d_state, d_pool, d_bv, d_com0, d_cand, d_fresh, d_corr, d_corr2, d_cnt, d_ind, d_tmp, d_fcnt, d_fbase;
+  HostBuf h_fresh, h_corr, h_com0, h_cand, h_cnt, h_bv, h_ind, h_fcnt, h_fbase;
   if (d_state.alloc((size_t)V * 4) || d_pool.alloc(hops >= 2 ? (size_t)n_wg * words * 4 : 4) ||
-      d_bv.alloc((size_t)b_max * 8) || d_com0.alloc((size_t)b_max * P * 4) || d_cand.alloc((size_t)b_max * 2) || d_fresh.alloc(cap_fresh * 8) ||
-      d_fresh2.alloc(cap_fresh * 8) || d_corr.alloc(cap_corr * 8) || d_corr2.alloc(cap_corr * 8) || d_cnt.alloc(32) ||
-      d_ind.alloc((size_t)b_max))
+      d_bv.alloc((size_t)b_max * 8) || d_com0.alloc((size_t)b_max * P * 4) || d_cand.alloc((size_t)b_max * 2) ||
+      d_fresh.alloc((size_t)P * cap_fresh * 4) || d_fcnt.alloc((size_t)b_max * P * 4) || d_fbase.alloc((size_t)b_max * P * 4) ||
+      d_corr.alloc(cap_corr * 8) || d_corr2.alloc(cap_corr * 8) || d_cnt.alloc(kCounters * 8) || d_ind.alloc((size_t)b_max))
     return PG_ERR_NOMEM;
-  if (h_fresh.alloc(cap_fresh * 8) || h_corr.alloc(cap_corr * 8) || h_com0.alloc((size_t)b_max * P * 4) || h_cand.alloc((size_t)b_max * 2) || h_cnt.alloc(32) ||
-      h_bv.alloc((size_t)b_max * 8) || h_ind.alloc((size_t)b_max))
+  if (h_fresh.alloc((size_t)P * cap_fresh * 4) || h_fcnt.alloc((size_t)b_max * P * 4) || h_fbase.alloc((size_t)b_max * P * 4) ||
+      h_corr.alloc(cap_corr * 8) || h_com0.alloc((size_t)b_max * P * 4) || h_cand.alloc((size_t)b_max * 2) ||
+      h_cnt.alloc(kCounters * 8) || h_bv.alloc((size_t)b_max * 8) || h_ind.alloc((size_t)b_max))
     return PG_ERR_NOMEM;
-  size_t tmp_bytes = 0, tb2 = 0;
+  size_t tmp_bytes = 0;
   {
     unsigned long long* k = nullptr;
-    PG_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, k, k, (size_t)cap_fresh, 0, 64, st));
-    PG_HIP(rocprim::radix_sort_keys(nullptr, tb2, k, k, (size_t)cap_corr, 0, 64, st));
-    tmp_bytes = std::max(tmp_bytes, tb2);
+    PG_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, k, k, (size_t)cap_corr, 0, 64, st));
   }
   if (d_tmp.alloc(tmp_bytes)) return PG_ERR_NOMEM;
   PG_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_state.p), 0x00FF0000, (size_t)V, st));      // unassigned, in no set
@@ -396,7 +456,7 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
     std::memcpy(h_bv.p, train_nids + i0, (size_t)b * 8);
     const double t0 = now_s();
     PG_HIP(hipMemcpyAsync(d_bv.p, h_bv.p, (size_t)b * 8, hipMemcpyHostToDevice, st));
-    PG_HIP(hipMemsetAsync(d_cnt.p, 0, 32, st));
+    PG_HIP(hipMemsetAsync(d_cnt.p, 0, kCounters * 8, st));
     hipLaunchKernelGGL(k_dg_mark, dim3((b + 255) / 256), dim3(256), 0, st, d_bv.as<int64_t>(), b, d_state.as<uint32_t>(), (int8_t)-2);
     DgExpandArgs a{};
     a.indptr = indptr_dev; a.indices = indices_dev; a.bv = d_bv.as<int64_t>(); a.n = b; a.P = P; a.hops = hops;
@@ -415,18 +475,25 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
       a.theta = 0.95f;         // (0.8: 1 wrong guess and 1.11e9 list entries on the 10M / 100M graph; 0.95: 14 and 0.94e9, 9 % faster)
       a.all_candidates = (fast || b == 1) ? 1 : 0;
     }
-    a.com0 = d_com0.as<int32_t>(); a.fresh = d_fresh.as<unsigned long long>(); a.corr = d_corr.as<unsigned long long>();
+    a.com0 = d_com0.as<int32_t>(); a.fresh = d_fresh.as<uint32_t>(); a.corr = d_corr.as<unsigned long long>();
+    a.fcnt = d_fcnt.as<uint32_t>(); a.fbase = d_fbase.as<uint32_t>();
     a.cap_fresh = cap_fresh; a.cap_corr = cap_corr; a.counters = d_cnt.as<unsigned long long>();
     hipLaunchKernelGGL(k_dg_expand, dim3((unsigned)std::min<int>(n_wg, b)), dim3(kDgThreads), 0, st, a);
     PG_LAUNCH_CHECK();
-    PG_HIP(hipMemcpyAsync(h_cnt.p, d_cnt.p, 32, hipMemcpyDeviceToHost, st));
+    PG_HIP(hipMemcpyAsync(h_cnt.p, d_cnt.p, kCounters * 8, hipMemcpyDeviceToHost, st));
     PG_HIP(hipStreamSynchronize(st));
-    const unsigned long long n_fresh = h_cnt.as<unsigned long long>()[0], n_corr = h_cnt.as<unsigned long long>()[1];
+    const unsigned long long* n_list = h_cnt.as<unsigned long long>() + 4;      // entries on each partition's lists
+    const unsigned long long n_corr = h_cnt.as<unsigned long long>()[1];
+    unsigned long long n_fresh = 0, n_longest = 0;
+    for (int p = 0; p < P; ++p) {
+      n_fresh += n_list[p];
+      n_longest = std::max(n_longest, n_list[p]);
+    }
     s.second_walks += (int64_t)h_cnt.as<unsigned long long>()[3];
     s.seconds_expand += now_s() - t0;
     ++s.batches;
 
-    if (n_fresh > cap_fresh || n_corr > cap_corr) {
+    if (n_longest > cap_fresh || n_corr > cap_corr) {
       // the lists did not fit: the same vertices again in a smaller batch (one vertex always fits: cap_fresh > V)
       hipLaunchKernelGGL(k_dg_mark, dim3((b + 255) / 256), dim3(256), 0, st, d_bv.as<int64_t>(), b, d_state.as<uint32_t>(), (int8_t)-1);
       ++s.batches_redone;
@@ -435,25 +502,21 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
       continue;
     }
     const double t1 = now_s();
-    // group the lists by batch index (a whole-key sort: a few ms for the largest list; rocPRIM's bit-range variant left lists of
-    // ~1 K keys ungrouped on ROCm 7.0) and bring them over
-    unsigned long long* fr = d_fresh.as<unsigned long long>();
+    // group the corrections by batch index (a whole-key sort: rocPRIM's bit-range variant left lists of ~1 K keys ungrouped
+    // on ROCm 7.0) and bring everything over
     unsigned long long* co = d_corr.as<unsigned long long>();
-    if (b > 1) {
+    if (b > 1 && n_corr > 1) {
       size_t tb = tmp_bytes;
-      if (n_fresh > 1) {
-        PG_HIP(rocprim::radix_sort_keys(d_tmp.p, tb, d_fresh.as<unsigned long long>(), d_fresh2.as<unsigned long long>(),
-                                        (size_t)n_fresh, 0, 64, st));
-        fr = d_fresh2.as<unsigned long long>();
-      }
-      tb = tmp_bytes;
-      if (n_corr > 1) {
-        PG_HIP(rocprim::radix_sort_keys(d_tmp.p, tb, d_corr.as<unsigned long long>(), d_corr2.as<unsigned long long>(),
-                                        (size_t)n_corr, 0, 64, st));
-        co = d_corr2.as<unsigned long long>();
-      }
+      PG_HIP(rocprim::radix_sort_keys(d_tmp.p, tb, d_corr.as<unsigned long long>(), d_corr2.as<unsigned long long>(),
+                                      (size_t)n_corr, 0, 64, st));
+      co = d_corr2.as<unsigned long long>();
     }
-    if (n_fresh) PG_HIP(hipMemcpyAsync(h_fresh.p, fr, (size_t)n_fresh * 8, hipMemcpyDeviceToHost, st));
+    for (int p = 0; p < P; ++p)
+      if (n_list[p])
+        PG_HIP(hipMemcpyAsync(h_fresh.as<uint32_t>() + (size_t)p * cap_fresh, d_fresh.as<uint32_t>() + (size_t)p * cap_fresh,
+                              (size_t)n_list[p] * 4, hipMemcpyDeviceToHost, st));
+    PG_HIP(hipMemcpyAsync(h_fcnt.p, d_fcnt.p, (size_t)b * P * 4, hipMemcpyDeviceToHost, st));
+    PG_HIP(hipMemcpyAsync(h_fbase.p, d_fbase.p, (size_t)b * P * 4, hipMemcpyDeviceToHost, st));
     if (n_corr) PG_HIP(hipMemcpyAsync(h_corr.p, co, (size_t)n_corr * 8, hipMemcpyDeviceToHost, st));
     PG_HIP(hipMemcpyAsync(h_com0.p, d_com0.p, (size_t)b * P * 4, hipMemcpyDeviceToHost, st));
     PG_HIP(hipMemcpyAsync(h_cand.p, d_cand.p, (size_t)b * 2, hipMemcpyDeviceToHost, st));
@@ -463,12 +526,14 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
     s.corr_entries += (int64_t)n_corr;
     // ---- the committer: dg.py:71-83 in train order ------------------------------------------------------------------
     const double t2 = now_s();
-    const unsigned long long* hf = h_fresh.as<unsigned long long>();
+    const uint32_t* hf = h_fresh.as<uint32_t>();
+    const uint32_t* hfc = h_fcnt.as<uint32_t>();
+    const uint32_t* hfb = h_fbase.as<uint32_t>();
     const unsigned long long* hc = h_corr.as<unsigned long long>();
     const int32_t* hcom = h_com0.as<int32_t>();
     int8_t* hind = h_ind.as<int8_t>();
     const uint16_t* hcand = h_cand.as<uint16_t>();
-    unsigned long long qf = 0, qc = 0;
+    unsigned long long qc = 0;
     int32_t done = 0;                      // vertices of this batch that were decided
     for (int32_t i = 0; i < b; ++i) {
       const int64_t nid = train_nids[i0 + i];
@@ -493,16 +558,12 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
       ++p_vnum[ind];
       uint64_t* rb = rbits[ind].data();
       int64_t fresh = 0;
-      const unsigned long long bit = 1ull << ind;
-      for (; qf < n_fresh && (int32_t)(hf[qf] >> 44) == i; ++qf) {
+      const uint32_t* lst = hf + (size_t)ind * cap_fresh + hfb[(size_t)i * P + ind];
+      const uint32_t nl = hfc[(size_t)i * P + ind];
+      for (uint32_t q = 0; q < nl; ++q) {
         // (the list streams; the bitmap word it names does not: 12.5 MB per partition at 10^8 vertices, touched at random)
-        if (qf + 32 < n_fresh) {
-          const unsigned long long ka = hf[qf + 32];
-          if (ka & bit) __builtin_prefetch(&rb[((ka >> 16) & 0xFFFFFFFull) >> 6], 1, 1);
-        }
-        const unsigned long long k = hf[qf];
-        if (!(k & bit)) continue;
-        const uint64_t u = (k >> 16) & 0xFFFFFFFull;
+        if (q + 16 < nl) __builtin_prefetch(&rb[lst[q + 16] >> 6], 1, 1);
+        const uint64_t u = lst[q];
         uint64_t& w = rb[u >> 6];
         const uint64_t ub = 1ull << (u & 63);
         if (!(w & ub)) { w |= ub; ++fresh; }
@@ -513,9 +574,8 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
       r_vnum[ind] += fresh;
       done = i + 1;
     }
-    if (done == b && (qf != n_fresh || qc != n_corr)) {        // (a list that is not grouped by batch index: cannot happen)
-      fprintf(stderr, "[pg_dg_partition_gpu] internal: batch at %lld of %d: fresh %llu / %llu, corr %llu / %llu\n", (long long)i0, b,
-              qf, n_fresh, qc, n_corr);
+    if (done == b && qc != n_corr) {        // (a list that is not grouped by batch index: cannot happen)
+      fprintf(stderr, "[pg_dg_partition_gpu] internal: batch at %lld of %d: corr %llu / %llu\n", (long long)i0, b, qc, n_corr);
       return PG_ERR_HIP;
     }
     if (done == 0) return PG_ERR_HIP;                           // (a batch's first vertex has every candidate)
@@ -526,21 +586,17 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
     if (done < b)
       hipLaunchKernelGGL(k_dg_mark, dim3((b - done + 255) / 256), dim3(256), 0, st, d_bv.as<int64_t>() + done, b - done,
                          d_state.as<uint32_t>(), (int8_t)-1);
-    {
-      const unsigned long long work = std::max<unsigned long long>(n_fresh, (unsigned long long)done);
-      const unsigned grid = (unsigned)std::min<unsigned long long>((work + 255) / 256, 1u << 16);
-      hipLaunchKernelGGL(k_dg_apply, dim3(grid), dim3(256), 0, st, d_bv.as<int64_t>(), d_ind.as<int8_t>(), done, fr, n_fresh,
-                         d_state.as<uint32_t>());
-      PG_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL(k_dg_apply, dim3((unsigned)done), dim3(64), 0, st, d_bv.as<int64_t>(), d_ind.as<int8_t>(), P,
+                       d_fresh.as<uint32_t>(), cap_fresh, d_fbase.as<uint32_t>(), d_fcnt.as<uint32_t>(), d_state.as<uint32_t>());
+    PG_LAUNCH_CHECK();
     PG_HIP(hipStreamSynchronize(st));        // (h_ind / h_bv are reused by the next batch)
     s.seconds_apply += now_s() - t3;
     i0 += done;
     s.largest_batch = std::max<int64_t>(s.largest_batch, done);
     // grow while the lists are far from their buffers and the guesses hold; a batch that ended early sets the size for the next
     if (done < b) bsz = std::max(1, std::max(done, b / 4));
-    else if (n_fresh < cap_fresh / 8 && n_corr < cap_corr / 8) bsz = std::min<int32_t>(b_max, std::max(bsz, b) * 2);
-    else if (n_fresh > cap_fresh / 2 || n_corr > cap_corr / 2) bsz = std::max(1, b / 2);
+    else if (n_longest < cap_fresh / 8 && n_corr < cap_corr / 8) bsz = std::min<int32_t>(b_max, std::max(bsz, b) * 2);
+    else if (n_longest > cap_fresh / 2 || n_corr > cap_corr / 2) bsz = std::max(1, b / 2);
   }
   if (r_mask_out)
     for (int p = 0; p < P; ++p)
