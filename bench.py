@@ -1438,7 +1438,8 @@ def run():
                        "miss_mode_probe": mode_probe, "overlap": not args.no_overlap,
                        "partition_vertices": Vs, "dg_hops": args.dg_hops if (world > 1 or emul_P > 1) else None,
                        "dg_hops2_work": {"sum_deg_squared": sum_deg_sq,
-                                         "note": "adjacency entries dg --num-hops 2 walks; pg_dg_partition_gpu: ~1.4e10 per second"},
+                                         "note": "adjacency entries of all two-hop multisets (65 % of them belong to train vertices, which dg --num-hops 2 "
+                                                 "walks); pg_dg_partition_gpu expands ~1.2e10 per second"},
                        "hip_graph_step": use_graph,
                        # how a captured step is replayed: its kernels as plain launches (csrc/pg_tape.hip, the default on one GPU)
                        # or hipGraphLaunch (PG_FLAT_REPLAY=0, the N > 1 step with its all-reduce captured inside, or a graph that
