@@ -752,9 +752,12 @@ int pg_dg_partition_mt(int64_t V, const int64_t* indptr, const int32_t* indices,
  * a snapshot of the assignment state; per vertex the device hands back the per-partition count of settled members (dg.py:47-50),
  * the members assigned inside the batch, and the members some partition's r_belongs still lacked; the host applies dg.py:51-83
  * strictly in train order with exact bitmaps — bit-identical to pg_dg_partition (hops 1 and 2). 10M / 100M graph, hops 2:
- * seconds instead of 68 s; 10^8 / 10^9: minutes instead of ~1000 s. Allocates its own scratch (a few hundred V-bit bitmaps,
- * list buffers of max(V, 48M) entries) and frees it before returning. PG_ERR_UNSUPPORTED (fall back to pg_dg_partition_mt):
- * P > 16, hops > 2, V >= 2^28, train ids not strictly ascending. Synchronises `stream`.                         */
+ * 4 s instead of 68 s; 10^8 / 10^9: 1 min instead of ~1000 s. Allocates its own scratch (a few hundred de-duplication
+ * bitmaps of V / 4 bytes, at most 16 GB of them; one list buffer of max(V, min(32M, 64 V)) 4-byte entries per partition, on the
+ * device and pinned on the host) and frees it before returning. PG_ERR_UNSUPPORTED (fall back to pg_dg_partition_mt):
+ * P > 16, hops > 2, V >= 2^28, train ids not strictly ascending. Synchronises `stream`.
+ * stats: fresh_entries = entries on the (vertex, candidate partition) lists, second_walks = multisets whose put-aside list
+ * overflowed the scratch (walked three times instead of once), candidate_misses = batches cut short by a wrong guess.  */
 typedef struct pg_dg_gpu_stats {
   int64_t batches, batches_redone, largest_batch, fresh_entries, corr_entries, workgroups, candidate_misses, second_walks;
   double seconds_total, seconds_expand, seconds_lists, seconds_commit, seconds_apply;
