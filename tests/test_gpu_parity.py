@@ -2001,6 +2001,10 @@ def test_dg_gpu_equals_the_sequential_host_code(dev, hiplib, V, E, P, hops):
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
     assert a[2].sum() == len(train) and st["batches"] >= 1 and st["largest_batch"] >= min(len(train), 64)
+    # both list paths ran: most multisets' put-aside members fit the workgroup's scratch (V / 256 entries) and are walked once,
+    # the early ones (every partition lacks everything) do not and are walked again under generations of their own; at 10^6
+    # vertices every workgroup's generation tag wraps as well (a run starts 240 multisets short of the wrap)
+    assert st["second_walks"] < len(train) and (st["second_walks"] > 0 or hops == 1)      # (one hop: a list is a vertex's degree)
 
 
 @pytest.mark.parametrize("V,E,P,hops", [(3000, 20000, 4, 1), (3000, 12000, 8, 2), (1500, 6000, 3, 3), (2000, 9000, 16, 2)])
