@@ -686,13 +686,19 @@ __global__ __launch_bounds__(256) void k_t_heavy(const int32_t* __restrict__ tpt
 // issues 64 lanes per clock, and 14 ballots + mask updates per key are ~55 vector instructions x 12 288 keys. A (source,
 // destination) pair is unique, so stability is not needed if every source's destinations are simply put in ascending order:
 //   1. destination of every edge: the thread of destination v writes v over its edges [indptr[v], indptr[v + 1])   (LDS array B)
-//   2. histogram of the sources (LDS adds), exclusive scan = tptr (written out coalesced); sources with more than PG_HEAVY_ROW
-//      edges are the backward pass's hub list
-//   3. placement in ANY order: position = returning LDS add on the source's running end                        (B -> B)
-//   4. every edge counts the destinations of its source that are smaller than its own = its rank               (B -> C)
+//   2. histogram of the sources (returning LDS adds: the edge's ARRIVAL NUMBER inside its source), exclusive scan = tptr
+//      (written out coalesced, no barrier behind it); sources with more than PG_HEAVY_ROW edges are the backward pass's hub list
+//   3. placement in ANY order: start of the source + arrival number; a source's ONLY edge goes straight to C     (B -> B | C)
+//   4. every other edge counts the destinations of its source that are smaller than its own = its rank         (B -> C)
 //      (sum over sources of count^2 reads: sources of a fan-out-2 block have one or two edges)
 //   5. hubs: their destinations set bits in a bitmap; the set bits in order are the sorted list                 (B -> C)
 //   6. tdst = C, coalesced.
+#ifdef PG_T_STAMPS      // tools/exp_t_stamps.sh: where one launch of k_t_block spends its time (100 MHz wall clock, thread 0)
+__device__ long long g_t_stamps[16];
+#define T_STAMP(k) do { if (threadIdx.x == 0) g_t_stamps[k] = (long long)wall_clock64(); } while (0)
+#else
+#define T_STAMP(k) do { } while (0)
+#endif
 template <int ITEMS>
 __global__ __launch_bounds__(1024) void k_t_block(const int32_t* __restrict__ indptr, const int32_t* __restrict__ src,
                                                   const int32_t* __restrict__ n_dst_dev,
@@ -717,6 +723,7 @@ __global__ __launch_bounds__(1024) void k_t_block(const int32_t* __restrict__ in
   const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
   const int n = (int)PG_IDX((long long)*n_dst_dev, bnd, 0, PG_K_T_BLOCK, 1);
   const int nnz = (int)PG_IDX((long long)*nnz_dev, bnd, 1, PG_K_T_BLOCK, 2);
+  T_STAMP(0);
   if (tid == 0) {
     if (heavy) heavy[0] = 0;
     n_hubs = 0;
@@ -747,14 +754,17 @@ __global__ __launch_bounds__(1024) void k_t_block(const int32_t* __restrict__ in
   }
   for (int i = tid; i < T_PAD(kN) + 2; i += 1024) A[i] = 0;
   __syncthreads();
+  T_STAMP(1);
   // ---- 1 + 2: destinations per edge, histogram of the sources -------------------------------------------------------------
+  int32_t arr[ITEMS];                             // the edge's arrival number among the edges of its source
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
     const int v = tid + j * 1024;
     for (int e = ip0[j]; e < ip1[j]; ++e) B[e] = v;
-    if (sr[j] >= 0) atomicAdd(&A[T_PAD(sr[j])], 1);
+    arr[j] = sr[j] >= 0 ? atomicAdd(&A[T_PAD(sr[j])], 1) : 0;
   }
   __syncthreads();
+  T_STAMP(2);
   int32_t d[ITEMS];
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
@@ -787,24 +797,33 @@ __global__ __launch_bounds__(1024) void k_t_block(const int32_t* __restrict__ in
   }
   if (tid == 1023) A[T_PAD(kN)] = base + sum;      // = nnz
   __syncthreads();
-  for (int i = tid; i <= cap_rows; i += 1024) tptr[i] = A[T_PAD(i)];        // coalesced; sources past the last real one: nnz
-  __syncthreads();
-  // ---- 3: placement (any order inside a source) ----------------------------------------------------------------------------
-#pragma unroll
-  for (int j = 0; j < ITEMS; ++j)
-    if (sr[j] >= 0) B[atomicAdd(&A[T_PAD(sr[j])], 1)] = d[j];
-  __syncthreads();
-  // ---- 4: rank inside the source (A[s] is now the source's end, A[s - 1] the previous source's end = its start) -----------
+  T_STAMP(3);
+  // tptr out, coalesced (sources past the last real one: nnz). A keeps the starts from here on: no barrier behind this pass,
+  // the stores drain under the LDS work below. (Written from the scan's registers instead — 12 words per thread — the stores
+  // are 48 bytes apart inside an instruction: 5.9 us for the scan phase instead of 1.9.)
+  for (int i = tid; i <= cap_rows; i += 1024) tptr[i] = A[T_PAD(i)];
+  T_STAMP(4);
+  // ---- 3: placement: start of the source + arrival number (any order inside a source). A source's only edge is final. ------
+  int32_t beg[ITEMS], num[ITEMS];
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
     if (sr[j] < 0) continue;
-    const int32_t end = A[T_PAD(sr[j])];
-    const int32_t beg = sr[j] ? A[T_PAD(sr[j] - 1)] : 0;
-    if (end - beg > PG_HEAVY_ROW) continue;       // hubs: below
-    int32_t rank = 0;
-    for (int32_t q = beg; q < end; ++q) rank += B[q] < d[j] ? 1 : 0;
-    C[beg + rank] = d[j];
+    beg[j] = A[T_PAD(sr[j])];
+    num[j] = A[T_PAD(sr[j] + 1)] - beg[j];
+    if (num[j] == 1) C[beg[j]] = d[j];
+    else B[beg[j] + arr[j]] = d[j];
   }
+  __syncthreads();
+  T_STAMP(5);
+  // ---- 4: rank inside the source -------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    if (sr[j] < 0 || num[j] == 1 || num[j] > PG_HEAVY_ROW) continue;       // (hubs: below)
+    int32_t rank = 0;
+    for (int32_t q = beg[j]; q < beg[j] + num[j]; ++q) rank += B[q] < d[j] ? 1 : 0;
+    C[beg[j] + rank] = d[j];
+  }
+  T_STAMP(6);
   // ---- 5: hubs — set bits, then the set bits in order ---------------------------------------------------------------------
   const int nh = n_hubs;                          // (written before the barriers above)
   for (int h = 0; h < nh; ++h) {
@@ -821,8 +840,10 @@ __global__ __launch_bounds__(1024) void k_t_block(const int32_t* __restrict__ in
     for (; word; word &= word - 1u) C[at++] = tid * 32 + (__ffs((int)word) - 1);
   }
   __syncthreads();
+  T_STAMP(7);
   // ---- 6: out -------------------------------------------------------------------------------------------------------------
   for (int i = tid; i < cap_edges; i += 1024) tdst[i] = i < nnz ? C[i] : 0;
+  T_STAMP(8);
 #undef T_PAD
 }
 
@@ -1383,3 +1404,10 @@ int pg_bitmap_to_ids(const uint64_t* bitmap, int64_t n_words, int64_t* out_ids, 
 
 }  // extern "C"
 
+#ifdef PG_T_STAMPS
+extern "C" int pg_debug_t_stamps(long long* out16) {
+  PG_HIP(hipDeviceSynchronize());
+  PG_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(pg::g_t_stamps), 16 * sizeof(long long)));
+  return PG_OK;
+}
+#endif
