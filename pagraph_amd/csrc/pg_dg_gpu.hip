@@ -539,6 +539,8 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
       const int64_t nid = train_nids[i0 + i];
       for (int p = 0; p < P; ++p) com[p] = 1 + hcom[(size_t)i * P + p];
       for (; qc < n_corr && (int32_t)(hc[qc] >> 32) == i; ++qc) {
+        // (belongs is V bytes touched at random: the line of a correction a few vertices ahead is asked for now)
+        if (qc + 24 < n_corr) __builtin_prefetch(&belongs_out[(uint32_t)hc[qc + 24]], 0, 1);
         const int8_t bb = belongs_out[(uint32_t)hc[qc]];
         if (bb >= 0) ++com[bb];
       }
