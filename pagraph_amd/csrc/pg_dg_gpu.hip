@@ -402,7 +402,8 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
   PG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const int64_t words = (V + 15) / 16;
   // bitmaps: up to 4 workgroups per CU, at most ~16 GB of them
-  // (2, 4 or 8 workgroups per CU expand at the same rate: profiles/r06/dg_gpu_sweep.txt)
+  // (2, 4 or 8 workgroups per CU expand at the same rate: profiles/r06/dg_gpu_sweep.txt; again with the tagged bitmaps at 10^8
+  // vertices: 512 / 687 / 1 024 / 1 536 workgroups 38.4 / 38.7 / 40.8 / 42.0 s — the lines' traffic is the bound, not the waves in flight)
   int n_wg = hops >= 2 ? cus * 4 : cus * 8;
   if (hops >= 2) n_wg = (int)std::max<int64_t>(cus, std::min<int64_t>(n_wg, (16ll << 30) / (words * 4)));
   // the scratch list of a multiset's members that lack a partition: V / 256 entries (a larger list: second walk), so that
