@@ -26,13 +26,13 @@
 //
 // De-duplication of a two-hop multiset: one bitmap per workgroup in HBM — 288 GB pays for a few hundred private ones even at
 // 10^8 vertices (25 MB each). The expansion is bound by exactly that traffic: a multiset is sparse in the id space (mean 7 000
-// entries, 10^8 ids), so every entry costs one 128-byte line (PMC: 117 B fetched + 27 B written per entry visit,
-// profiles/r06/dg_gpu_expand_pmc.txt). The first version walked every multiset twice — once to set bits and count, once more to
+// entries, 10^8 ids), so every access is a 128-byte line of its own (PMC, profiles/r06/dg_gpu_expand_pmc.txt: 180 B fetched + 41 B
+// written per entry visit in the first version, 222 + 47 per entry now). The first version walked every multiset twice — once to set bits and count, once more to
 // clear them and list the fresh members — and paid that line twice. Now a word holds 16 members under a 16-bit GENERATION tag
 // (the workgroup's count of multisets so far): a word whose tag is stale counts as empty, nothing is ever cleared (a wrap of
 // the tag, every 65 000 multisets of a workgroup, zeroes its bitmap), and the members that lack some partition are put aside
 // during the one walk (a per-workgroup scratch list) and filtered by the candidates afterwards. A vertex whose list does not
-// fit the scratch takes the second walk under the next generation.
+// fit the scratch is walked twice more (count, then place), each time under a generation of its own.
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
@@ -406,7 +406,7 @@ extern "C" int pg_dg_partition_gpu(int64_t V, const int64_t* indptr_dev, const i
   // vertices: 512 / 687 / 1 024 / 1 536 workgroups 38.4 / 38.7 / 40.8 / 42.0 s — the lines' traffic is the bound, not the waves in flight)
   int n_wg = hops >= 2 ? cus * 4 : cus * 8;
   if (hops >= 2) n_wg = (int)std::max<int64_t>(cus, std::min<int64_t>(n_wg, (16ll << 30) / (words * 4)));
-  // the scratch list of a multiset's members that lack a partition: V / 256 entries (a larger list: second walk), so that
+  // the scratch list of a multiset's members that lack a partition: V / 256 entries (a larger list: two more walks), so that
   // small graphs — the tests' — take both paths
   const uint32_t scr_cap = (uint32_t)std::min<int64_t>(512 << 10, std::max<int64_t>(16, V / 256));
   const int32_t b_max = 1 << 15;       // (8 192 / 16 384 / 32 768 / 65 536: 108 / 95 / 93 / 97-100 s at 10^8 vertices; 6.0 / 5.5 / - / 6.2-6.4 s at 10^7)
