@@ -839,8 +839,8 @@ def run():
         my_train = train_full
     else:
         belongs = torch.empty(V, dtype=torch.int8)
-        log(f"[bench] rank {rank}: dg P={world} hops={args.dg_hops} on rank 0 (neighbour sets built on its GPU: ~9 s at 10M / 100M, "
-            f"~2 min at 10^8 / 10^9 with hops 2); the other ranks wait in a broadcast meanwhile")
+        log(f"[bench] rank {rank}: dg P={world} hops={args.dg_hops} on rank 0 (neighbour sets built on its GPU: ~4 s at 10M / 100M, "
+            f"~1 min at 10^8 / 10^9 with hops 2); the other ranks wait in a broadcast meanwhile")
         if rank == 0:
             b, _, p_vnum, r_vnum = dg_raw(world, indptr, indices, V, train_full.numpy(), args.dg_hops, want_r_mask=False)
             belongs = torch.from_numpy(b)
