@@ -1,12 +1,13 @@
 // dg with the neighbour sets built on the GPU (round 6) — PaGraph/partition/dg.py:14-103, hops 1 and 2, bit-identical to
-// pg_dg_partition (tests: all G4 fixtures + a 10^6-vertex graph against the sequential code).
+// pg_dg_partition (tests: all G4 fixtures + 10^6-vertex graphs against the sequential code; checked once at 10^8 vertices /
+// 10^9 edges, P = 8, hops 2: 56 s here, 1 915 s there, the same partition).
 //
 // What is sequential in dg is ONE decision per train vertex that reads p_vnum / r_vnum as the previous decision left them
 // (dg.py:47-55,71-83). What is expensive is building N(v) — the de-duplicated one- or two-hop in-neighbourhood: sum(deg^2) =
 // 4.7e10 adjacency entries on the 10M / 100M graph, 6.9e11 on config 5's — and that depends on the graph only. Round 3 put
-// host threads on it (68 s at 10M through one committer; ~1000 s extrapolated at 10^8). Here the device does it, in BATCHES of
-// consecutive train vertices, against a SNAPSHOT of the assignment state taken at the batch's start, and hands the host
-// exactly what the snapshot cannot know:
+// host threads on it (68 s at 10M through one committer). Here the device does it, in BATCHES of consecutive train vertices,
+// against a SNAPSHOT of the assignment state taken at the batch's start, and hands the host exactly what the snapshot
+// cannot know:
 //
 //   com0[v][p]   = |{u in N(v) : u assigned to p in the snapshot}|                       (dg.py:47-50, the settled part)
 //   corr(v)      = the members of N(v) that belong to THIS batch and precede v            (assigned between snapshot and v's turn)
@@ -19,20 +20,21 @@
 // pair has a list of its own — a range the vertex's workgroup reserves in that partition's buffer, after counting, with ONE
 // atomic per partition — and the host reads the one list it needs per vertex (RMAT has no communities: four vertices of five
 // have more than one candidate, and the partitions that lose lack far more members than the one that wins — 95 % of the
-// entries are never looked at; nothing is sorted). The decisions go back, and one kernel applies them to the snapshot
-// from the same lists (no second expansion). Early batches are tiny (the first
-// hubs' sets are the whole graph and every partition lacks all of it); the batch doubles while the lists stay small, and a
-// batch whose lists overflow their buffers is simply redone at half the size.
+// entries are never looked at; nothing is sorted). The decisions go back, and one kernel applies them to the snapshot from
+// the same lists (no second expansion). Early batches are tiny (the first hubs' sets are the whole graph and every partition
+// lacks all of it); the batch doubles while the lists stay small, and a batch whose lists overflow their buffers is simply
+// redone at half the size.
 //
 // De-duplication of a two-hop multiset: one bitmap per workgroup in HBM — 288 GB pays for a few hundred private ones even at
 // 10^8 vertices (25 MB each). The expansion is bound by exactly that traffic: a multiset is sparse in the id space (mean 7 000
-// entries, 10^8 ids), so every access is a 128-byte line of its own (PMC, profiles/r06/dg_gpu_expand_pmc.txt: 180 B fetched + 41 B
-// written per entry visit in the first version, 222 + 47 per entry now). The first version walked every multiset twice — once to set bits and count, once more to
-// clear them and list the fresh members — and paid that line twice. Now a word holds 16 members under a 16-bit GENERATION tag
-// (the workgroup's count of multisets so far): a word whose tag is stale counts as empty, nothing is ever cleared (a wrap of
-// the tag, every 65 000 multisets of a workgroup, zeroes its bitmap), and the members that lack some partition are put aside
-// during the one walk (a per-workgroup scratch list) and filtered by the candidates afterwards. A vertex whose list does not
-// fit the scratch is walked twice more (count, then place), each time under a generation of its own.
+// entries, 10^8 ids), so every access is a 128-byte line of its own (PMC, profiles/r06/dg_gpu_expand_pmc.txt: 180 B fetched +
+// 41 B written per entry visit in the first version, 222 + 47 per entry now). The first version walked every multiset twice —
+// once to set bits and count, once more to clear them and list the fresh members — and paid that line twice. Now a word holds
+// 16 members under a 16-bit GENERATION tag (the workgroup's count of multisets so far): a word whose tag is stale counts as
+// empty, nothing is ever cleared (a wrap of the tag, every 65 000 multisets of a workgroup, zeroes its bitmap), and the members
+// that lack some partition are put aside during the one walk (a per-workgroup scratch list) and filtered by the candidates
+// afterwards. A vertex whose list does not fit the scratch is walked twice more (count, then place), each time under a
+// generation of its own.
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
